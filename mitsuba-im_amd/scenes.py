@@ -1,0 +1,225 @@
+"""Synthetic scene generators + the flattened-scene container ("mi_scene" boundary content).
+
+The reference ships no cbox.xml / Veach-MIS / Sponza assets, so every BASELINE
+scene is generated here, deterministically, as the flattened arrays the C-ABI consumes
+(include/mi355pt.h) -- the same content an adapter would pull out of a live mitsuba::Scene
+(TriMesh::getTriangles/getVertexPositions/..., reference include/mitsuba/render/trimesh.h:122-160).
+
+`save_scene` writes the arrays in a small binary container ("MISCENE1") that the oracle-side
+harness (oracle/ref_build/harness.cpp) reads to build the very same scene inside the reference.
+"""
+import math
+import struct
+import numpy as np
+
+BSDF_DIFFUSE = 0
+BSDF_ROUGHCONDUCTOR = 1
+EMITTER_AREA = 0
+EMITTER_ENVMAP = 1
+FILTER_BOX = 0
+FILTER_GAUSSIAN = 1
+SAMPLER_INDEPENDENT = 0
+SAMPLER_SOBOL = 1
+DISTR_BECKMANN = 0
+DISTR_GGX = 1
+
+f32 = np.float32
+
+
+class Scene(dict):
+    """Plain dict of numpy arrays / scalars; attribute access for convenience."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def _quad(verts, tris, shape_ranges, quad_pts):
+    base = len(verts)
+    verts.extend(quad_pts)
+    tris.append((base, base + 1, base + 2))
+    tris.append((base, base + 2, base + 3))
+
+
+def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
+              distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
+              specular=(1.0, 1.0, 1.0), sample_visible=True):
+    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible),
+                reflectance=tuple(map(float, reflectance)), alpha=float(alpha),
+                eta=tuple(map(float, eta)), k=tuple(map(float, k)),
+                specular=tuple(map(float, specular)))
+
+
+# ---------------------------------------------------------------------------------------------
+# camera: reference src/sensors/perspective.cpp:126-178 (configure), src/libcore/transform.cpp:99-122
+# (perspective), :191-201 (lookAt), src/librender/sensor.cpp:237-280 (fov handling, fovAxis "x")
+# ---------------------------------------------------------------------------------------------
+def look_at(origin, target, up):
+    o = np.asarray(origin, f32); t = np.asarray(target, f32); u = np.asarray(up, f32)
+    d = (t - o).astype(f32); d = (d / f32(np.sqrt(np.dot(d, d)))).astype(f32)
+    left = np.cross(u, d).astype(f32); left = (left / f32(np.sqrt(np.dot(left, left)))).astype(f32)
+    new_up = np.cross(d, left).astype(f32)
+    m = np.eye(4, dtype=f32)
+    m[:3, 0] = left; m[:3, 1] = new_up; m[:3, 2] = d; m[:3, 3] = o
+    return m
+
+
+def sample_to_camera(xfov_deg, near, far, aspect):
+    """cameraToSample = scale(-0.5,-0.5*aspect,1) * translate(-1,-1/aspect,0) * perspective(xfov,near,far);
+    returns its inverse (crop window = full film)."""
+    recip = 1.0 / (far - near)
+    cot = 1.0 / math.tan(math.radians(xfov_deg / 2.0))
+    persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0],
+                      [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], dtype=np.float64)
+    tr = np.eye(4); tr[0, 3] = -1.0; tr[1, 3] = -1.0 / aspect
+    sc = np.diag([-0.5, -0.5 * aspect, 1.0, 1.0])
+    cam_to_sample = sc @ tr @ persp
+    return np.linalg.inv(cam_to_sample).astype(f32)
+
+
+def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near, far, width, height,
+                 spp, sampler, max_depth, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
+                 normals=None, uvs=None, strict_normals=False, hide_emitters=False, envmap=None,
+                 name="scene"):
+    sc = Scene()
+    sc.name = name
+    sc.pos = np.ascontiguousarray(np.asarray(verts, dtype=f32).reshape(-1, 3))
+    sc.idx = np.ascontiguousarray(np.asarray(tris, dtype=np.uint32).reshape(-1, 3))
+    sc.nrm = None if normals is None else np.ascontiguousarray(np.asarray(normals, dtype=f32).reshape(-1, 3))
+    sc.uv = None if uvs is None else np.ascontiguousarray(np.asarray(uvs, dtype=f32).reshape(-1, 2))
+    sc.shapes = shapes          # list of dict(first_tri, tri_count, first_vert, vert_count, bsdf, emitter, face_normals)
+    sc.bsdfs = bsdfs
+    sc.emitters = emitters      # list of dict(type, shape, radiance, weight)
+    sc.cam_to_world = np.ascontiguousarray(cam_to_world, dtype=f32)
+    sc.xfov = float(xfov); sc.near = float(near); sc.far = float(far)
+    sc.width = int(width); sc.height = int(height)
+    sc.sample_to_camera = sample_to_camera(xfov, near, far, width / height)
+    sc.filter = filter_kind
+    sc.filter_radius = 0.5 if filter_kind == FILTER_BOX else 2.0
+    sc.filter_stddev = 0.5
+    sc.max_depth = int(max_depth); sc.rr_depth = int(rr_depth)
+    sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
+    sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)
+    sc.envmap = envmap          # None or dict(rgb[h,w,3] f32, to_world[4,4], scale)
+    tri_shape = np.zeros(len(sc.idx), dtype=np.uint32)
+    for si, s in enumerate(shapes):
+        tri_shape[s["first_tri"]:s["first_tri"] + s["tri_count"]] = si
+    sc.tri_shape = tri_shape
+    return sc
+
+
+class _Builder:
+    def __init__(self):
+        self.verts, self.tris, self.shapes, self.bsdfs, self.emitters = [], [], [], [], []
+        self.normals = None
+
+    def bsdf(self, **kw):
+        self.bsdfs.append(make_bsdf(**kw))
+        return len(self.bsdfs) - 1
+
+    def begin(self):
+        self._ft, self._fv = len(self.tris), len(self.verts)
+
+    def quad(self, pts):
+        _quad(self.verts, self.tris, None, [tuple(map(float, p)) for p in pts])
+
+    def end(self, bsdf, radiance=None, face_normals=True):
+        em = -1
+        si = len(self.shapes)
+        if radiance is not None:
+            self.emitters.append(dict(type=EMITTER_AREA, shape=si, radiance=tuple(map(float, radiance)), weight=1.0))
+            em = len(self.emitters) - 1
+        self.shapes.append(dict(first_tri=self._ft, tri_count=len(self.tris) - self._ft,
+                                first_vert=self._fv, vert_count=len(self.verts) - self._fv,
+                                bsdf=bsdf, emitter=em, face_normals=int(face_normals)))
+
+
+def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5,
+                filter_kind=FILTER_BOX, seed=0):
+    """S1: the classic Cornell box data (units 0..560), one-sided `diffuse` everywhere with
+    consistent winding (face normals point into the room / out of the blocks), ceiling quad light lowered to
+    y=548.3 so that no two surfaces coincide; block bottoms (coplanar with the floor) are left out => 32 triangles."""
+    b = _Builder()
+    white = b.bsdf(reflectance=(0.725, 0.71, 0.68))
+    red = b.bsdf(reflectance=(0.63, 0.065, 0.05))
+    green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
+    lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78))
+    b.begin(); b.quad([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]); b.end(white)          # floor
+    b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)  # ceiling
+    b.begin(); b.quad([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]); b.end(white)  # back
+    b.begin(); b.quad([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]); b.end(green)          # right (x=0)
+    b.begin(); b.quad([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]); b.end(red)  # left
+    b.begin(); b.quad([(343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227)])
+    b.end(lightm, radiance=(17.0, 12.0, 4.0))
+    b.begin()                                                                                             # short block
+    b.quad([(130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)])
+    b.quad([(290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)])
+    b.quad([(130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)])
+    b.quad([(82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)])
+    b.quad([(240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225)])
+    b.end(white)
+    b.begin()                                                                                             # tall block
+    b.quad([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)])
+    b.quad([(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)])
+    b.quad([(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)])
+    b.quad([(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)])
+    b.quad([(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)])
+    b.end(white)
+    cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0,
+                        width, height, spp, sampler, max_depth, rr_depth, filter_kind, seed, name="cornell")
+
+
+def closed_box(width=128, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=8):
+    """The survey probe scene: closed 24-triangle diffuse cube room + small ceiling light,
+    camera inside. Every path stays inside, so avg path length is the reference's 6.10 figure."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.5, 0.5, 0.5))
+    lightm = b.bsdf(reflectance=(0.5, 0.5, 0.5))
+    L = 2.0
+    b.begin()
+    b.quad([(L, -L, -L), (-L, -L, -L), (-L, -L, L), (L, -L, L)])      # floor  (+y)
+    b.quad([(L, L, -L), (L, L, L), (-L, L, L), (-L, L, -L)])          # ceiling (-y)
+    b.quad([(L, -L, L), (-L, -L, L), (-L, L, L), (L, L, L)])          # back z=+L (-z)
+    b.quad([(-L, -L, -L), (L, -L, -L), (L, L, -L), (-L, L, -L)])      # front z=-L (+z)
+    b.quad([(-L, -L, L), (-L, -L, -L), (-L, L, -L), (-L, L, L)])      # x=-L (+x)
+    b.quad([(L, -L, -L), (L, -L, L), (L, L, L), (L, L, -L)])          # x=+L (-x)
+    b.end(grey)
+    b.begin(); b.quad([(0.5, 1.9, -0.5), (0.5, 1.9, 0.5), (-0.5, 1.9, 0.5), (-0.5, 1.9, -0.5)])
+    b.end(lightm, radiance=(20.0, 20.0, 20.0))
+    cam = look_at((0, 0, -1.9), (0, 0, 0), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 70.0, 0.01, 100.0,
+                        width, height, spp, sampler, max_depth, name="closed_box")
+
+
+# ---------------------------------------------------------------------------------------------
+# binary container for the oracle-side harness
+# ---------------------------------------------------------------------------------------------
+def save_scene(sc, path):
+    with open(path, "wb") as f:
+        f.write(b"MISCENE1")
+        has_n = int(sc.nrm is not None); has_uv = int(sc.uv is not None)
+        has_env = int(sc.envmap is not None)
+        f.write(struct.pack("<8I", len(sc.pos), len(sc.idx), len(sc.shapes), len(sc.bsdfs),
+                            len(sc.emitters), has_n, has_uv, has_env))
+        f.write(sc.pos.tobytes())
+        if has_n: f.write(sc.nrm.tobytes())
+        if has_uv: f.write(sc.uv.tobytes())
+        f.write(sc.idx.tobytes())
+        for s in sc.shapes:
+            f.write(struct.pack("<4I2i2I", s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"],
+                                s["bsdf"], s["emitter"], s["face_normals"], 0))
+        for b in sc.bsdfs:
+            f.write(struct.pack("<4I", b["type"], b["twosided"], b["distr"], b["sample_visible"]))
+            f.write(struct.pack("<13f", *b["reflectance"], b["alpha"], *b["eta"], *b["k"], *b["specular"]))
+        for e in sc.emitters:
+            f.write(struct.pack("<Ii4f", e["type"], e["shape"], *e["radiance"], e["weight"]))
+        f.write(sc.cam_to_world.tobytes())
+        f.write(struct.pack("<3f2I", sc.xfov, sc.near, sc.far, sc.width, sc.height))
+        f.write(struct.pack("<I2f", sc.filter, sc.filter_radius, sc.filter_stddev))
+        f.write(struct.pack("<2i2I", sc.max_depth, sc.rr_depth, sc.strict_normals, sc.hide_emitters))
+        f.write(struct.pack("<2IQ", sc.sampler, sc.spp, sc.seed))
+        if has_env:
+            rgb = np.ascontiguousarray(sc.envmap["rgb"], dtype=f32)
+            f.write(struct.pack("<2I", rgb.shape[1], rgb.shape[0]))
+            f.write(np.ascontiguousarray(sc.envmap["to_world"], dtype=f32).tobytes())
+            f.write(struct.pack("<f", sc.envmap["scale"]))
+            f.write(rgb.tobytes())

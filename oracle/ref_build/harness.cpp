@@ -1,0 +1,522 @@
+// oracle/ref_build/harness.cpp -- TEST INFRASTRUCTURE (checker), never shipped, never on the product path.
+//
+// Our own driver around the REFERENCE's compiled hot path (libmitsuba-core/-render + plugins built by the
+// Makefile next to this file from /root/reference).  It reads a flattened scene ("MISCENE1", written by
+// mitsuba-im_amd/scenes.py), rebuilds the same scene inside the reference programmatically (the XML loader
+// needs pugixml/Xerces, absent here: SURVEY.md §8c) and dumps golden vectors as .npy files:
+//   tables  : Sobol direction matrices / vdc matrices, SFMT known answers, TEA values
+//   samples : per-(pixel, sampleIndex) Li through MIPathTracer::Li + the sampler values consumed first
+//   image   : full SamplingIntegrator::renderBlock render (raw 5-channel ImageBlock) + wall time + ray counters
+//   hits    : Scene::rayIntersect records for camera rays
+//   units   : warp / BSDF / emitter / camera / filter unit vectors
+// It runs only in the build container (the reference cannot travel); the fixtures it writes are data.
+#include <mitsuba/mitsuba.h>
+#include <mitsuba/core/plugin.h>
+#include <mitsuba/core/statistics.h>
+#include <mitsuba/core/fstream.h>
+#include <mitsuba/core/bitmap.h>
+#include <mitsuba/core/sched.h>
+#include <mitsuba/core/random.h>
+#include <mitsuba/core/qmc.h>
+#include <mitsuba/core/warp.h>
+#include <mitsuba/core/timer.h>
+#include <mitsuba/render/scene.h>
+#include <mitsuba/render/trimesh.h>
+#include <mitsuba/render/integrator.h>
+#include <mitsuba/render/sampler.h>
+#include <mitsuba/render/sensor.h>
+#include <mitsuba/render/film.h>
+#include <mitsuba/render/emitter.h>
+#include <mitsuba/render/bsdf.h>
+#include <mitsuba/render/imageblock.h>
+#include <mitsuba/render/triaccel.h>
+#include <mitsuba/render/skdtree.h>
+#include <sobolseq.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <string>
+#include <thread>
+#include <atomic>
+#include <mutex>
+#include <unistd.h>
+
+using namespace mitsuba;
+
+// ------------------------------------------------------------------------------------------ npy writer
+static void save_npy(const std::string &path, const char *descr, const std::vector<size_t> &shape,
+                     const void *data, size_t bytes) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", path.c_str()); _exit(2); }
+    std::string sh = "(";
+    for (size_t i = 0; i < shape.size(); ++i) { sh += std::to_string(shape[i]); sh += (shape.size() == 1 || i + 1 < shape.size()) ? "," : ""; }
+    sh += ")";
+    std::string hdr = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': " + sh + ", }";
+    size_t total = 10 + hdr.size() + 1;
+    size_t pad = (64 - total % 64) % 64;
+    hdr += std::string(pad, ' ') + "\n";
+    unsigned char pre[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, (unsigned char)(hdr.size() & 0xff), (unsigned char)(hdr.size() >> 8)};
+    fwrite(pre, 1, 10, f); fwrite(hdr.data(), 1, hdr.size(), f); fwrite(data, 1, bytes, f); fclose(f);
+}
+template <typename T> static void save(const std::string &p, const char *d, std::vector<size_t> shape, const std::vector<T> &v) {
+    save_npy(p, d, shape, v.data(), v.size() * sizeof(T));
+}
+
+// ------------------------------------------------------------------------------------------ scene file
+struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
+struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
+struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight; };
+struct FScene {
+    uint32_t nVerts, nTris, nShapes, nBsdfs, nEmitters, hasN, hasUV, hasEnv;
+    std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx;
+    std::vector<FShape> shapes; std::vector<FBsdf> bsdfs; std::vector<FEmitter> emitters;
+    float camToWorld[16], fov, nearClip, farClip; uint32_t W, H;
+    uint32_t filter; float filterRadius, filterStddev;
+    int32_t maxDepth, rrDepth; uint32_t strictNormals, hideEmitters;
+    uint32_t sampler, spp; uint64_t seed;
+    uint32_t envW, envH; float envToWorld[16], envScale; std::vector<float> envRGB;
+};
+static void rd(FILE *f, void *p, size_t n) { if (fread(p, 1, n, f) != n) { fprintf(stderr, "short read\n"); _exit(2); } }
+static FScene loadScene(const char *path) {
+    FScene s; FILE *f = fopen(path, "rb"); if (!f) { fprintf(stderr, "cannot open %s\n", path); _exit(2); }
+    char magic[8]; rd(f, magic, 8); if (memcmp(magic, "MISCENE1", 8)) { fprintf(stderr, "bad magic\n"); _exit(2); }
+    rd(f, &s.nVerts, 32);
+    s.pos.resize(s.nVerts * 3); rd(f, s.pos.data(), s.pos.size() * 4);
+    if (s.hasN) { s.nrm.resize(s.nVerts * 3); rd(f, s.nrm.data(), s.nrm.size() * 4); }
+    if (s.hasUV) { s.uv.resize(s.nVerts * 2); rd(f, s.uv.data(), s.uv.size() * 4); }
+    s.idx.resize(s.nTris * 3); rd(f, s.idx.data(), s.idx.size() * 4);
+    s.shapes.resize(s.nShapes); rd(f, s.shapes.data(), s.nShapes * sizeof(FShape));
+    s.bsdfs.resize(s.nBsdfs); rd(f, s.bsdfs.data(), s.nBsdfs * sizeof(FBsdf));
+    s.emitters.resize(s.nEmitters); rd(f, s.emitters.data(), s.nEmitters * sizeof(FEmitter));
+    rd(f, s.camToWorld, 64); rd(f, &s.fov, 12); rd(f, &s.W, 8);
+    rd(f, &s.filter, 4); rd(f, &s.filterRadius, 8);
+    rd(f, &s.maxDepth, 8); rd(f, &s.strictNormals, 8);
+    rd(f, &s.sampler, 8); rd(f, &s.seed, 8);
+    if (s.hasEnv) {
+        rd(f, &s.envW, 8); rd(f, s.envToWorld, 64); rd(f, &s.envScale, 4);
+        s.envRGB.resize((size_t) s.envW * s.envH * 3); rd(f, s.envRGB.data(), s.envRGB.size() * 4);
+    }
+    fclose(f); return s;
+}
+
+// ------------------------------------------------------------------------------------------ build-defined "independent" stream
+// The reference's `independent` sampler seeds SFMT from time() (src/samplers/independent.cpp:58, src/libcore/random.cpp:477),
+// so "identical seeds" has to be defined by the build (SURVEY.md §7 "Determinism contract"): a counter-based stream over
+// the reference's own sampleTEA (include/mitsuba/core/qmc.h:146).  This subclass mirrors mitsuba-im_amd's definition
+// (DESIGN.md "independent stream") inside the reference so MIPathTracer::Li consumes exactly the same numbers.
+class SeededIndependent : public Sampler {
+public:
+    SeededIndependent(size_t spp, uint32_t seed, int width) : Sampler(Properties()), m_seed(seed), m_width(width) { m_sampleCount = spp; }
+    ref<Sampler> clone() { ref<SeededIndependent> s = new SeededIndependent(m_sampleCount, m_seed, m_width); return s.get(); }
+    void generate(const Point2i &pos, size_t nextSampleIdx) override {
+        m_pixel = (uint32_t) (pos.y * m_width + pos.x);
+        setSampleIndex(nextSampleIdx != (size_t) ~0 ? nextSampleIdx : m_sampleIndex);
+    }
+    void advance() { setSampleIndex(m_sampleIndex + 1); }
+    void setSampleIndex(size_t idx) { m_sampleIndex = idx; m_call = 0; }
+    inline uint64_t draw() {
+        uint32_t v0 = m_pixel ^ (m_seed * 0x9E3779B9u);
+        uint32_t v1 = ((uint32_t) m_sampleIndex << 8) | (m_call++ & 0xFFu);
+        return sampleTEA(v0, v1, 4);
+    }
+    static inline float toFloat(uint32_t bits) { union { uint32_t u; float f; } x; x.u = (bits >> 9) | 0x3f800000u; return x.f - 1.0f; }
+    Float next1D() { return toFloat((uint32_t) draw()); }
+    Point2 next2D() { uint64_t r = draw(); return Point2(toFloat((uint32_t) r), toFloat((uint32_t) (r >> 32))); }
+    std::string toString() const { return "SeededIndependent[]"; }
+    MTS_DECLARE_CLASS()
+private:
+    uint32_t m_seed, m_pixel = 0, m_call = 0; int m_width;
+};
+MTS_IMPLEMENT_CLASS(SeededIndependent, false, Sampler)
+
+// A recording proxy: forwards to the wrapped sampler and logs every value handed to the integrator.
+class RecordingSampler : public Sampler {
+public:
+    RecordingSampler(Sampler *inner) : Sampler(Properties()), m_inner(inner) { m_sampleCount = inner->getSampleCount(); }
+    ref<Sampler> clone() { return new RecordingSampler(m_inner->clone()); }
+    void setFilmResolution(const Vector2i &res, bool blocked) { m_inner->setFilmResolution(res, blocked); }
+    void generate(const Point2i &pos, size_t idx) override { m_inner->generate(pos, idx); m_sampleIndex = m_inner->getSampleIndex(); log.clear(); }
+    void advance() { m_inner->advance(); m_sampleIndex = m_inner->getSampleIndex(); log.clear(); }
+    void setSampleIndex(size_t i) { m_inner->setSampleIndex(i); m_sampleIndex = i; log.clear(); }
+    Float next1D() { Float v = m_inner->next1D(); log.push_back(v); return v; }
+    Point2 next2D() { Point2 v = m_inner->next2D(); log.push_back(v.x); log.push_back(v.y); return v; }
+    std::string toString() const { return "RecordingSampler[]"; }
+    std::vector<float> log;
+    MTS_DECLARE_CLASS()
+private:
+    ref<Sampler> m_inner;
+};
+MTS_IMPLEMENT_CLASS(RecordingSampler, false, Sampler)
+
+// ------------------------------------------------------------------------------------------ scene construction
+static ConfigurableObject *create(const Class *cls, const Properties &p) {
+    return PluginManager::getInstance()->createObject(cls, p);
+}
+static Spectrum rgb(const float *c) { Spectrum s; s.fromLinearRGB(c[0], c[1], c[2]); return s; }
+
+struct Built {
+    ref<Scene> scene; ref<Sensor> sensor; ref<Sampler> sampler; ref<SamplingIntegrator> integrator; ref<Film> film;
+    ref<ReconstructionFilter> filter;
+};
+
+static Built buildScene(const FScene &fs) {
+    Built b;
+    b.scene = new Scene();
+    // BSDFs
+    std::vector<ref<BSDF> > bsdfs;
+    for (const FBsdf &fb : fs.bsdfs) {
+        ref<BSDF> bsdf;
+        if (fb.type == 0) {
+            Properties p("diffuse"); p.setSpectrum("reflectance", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else {
+            Properties p("roughconductor");
+            p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx");
+            p.setFloat("alpha", fb.alpha);
+            p.setSpectrum("eta", rgb(fb.eta)); p.setSpectrum("k", rgb(fb.k));
+            p.setSpectrum("specularReflectance", rgb(fb.spec));
+            p.setBoolean("sampleVisible", fb.sampleVisible != 0);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        }
+        bsdf->configure();
+        if (fb.twosided) {
+            ref<BSDF> ts = static_cast<BSDF *>(create(MTS_CLASS(BSDF), Properties("twosided")));
+            ts->addChild(bsdf); bsdf->setParent(ts); ts->configure();
+            bsdf = ts;
+        }
+        bsdfs.push_back(bsdf);
+    }
+    // scene-level emitters (envmap) first, as the XML loader would add them before shapes are expanded
+    for (const FEmitter &fe : fs.emitters) {
+        if (fe.type != 1) continue;
+        ref<Bitmap> bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(fs.envW, fs.envH));
+        memcpy(bmp->getFloat32Data(), fs.envRGB.data(), fs.envRGB.size() * 4);
+        Properties p("envmap");
+        p.setData("bitmap", Properties::Data{(uint8_t *) bmp.get(), sizeof(Bitmap)});
+        Matrix4x4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = fs.envToWorld[i * 4 + j];
+        p.setTransform("toWorld", Transform(m)); p.setFloat("scale", fs.envScale);
+        p.setFloat("samplingWeight", fe.weight);
+        ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), p));
+        b.scene->addChild(em); em->setParent(b.scene);
+        // configured after the scene knows its bounds (Scene::initialize -> emitter->createShape)
+        em->configure();
+    }
+    // shapes
+    for (uint32_t si = 0; si < fs.nShapes; ++si) {
+        const FShape &sh = fs.shapes[si];
+        bool useN = fs.hasN && !sh.faceNormals;
+        ref<TriMesh> mesh = new TriMesh("shape" + std::to_string(si), sh.triCount, sh.vertCount, useN, fs.hasUV != 0, false, false,
+                                        sh.faceNormals != 0);
+        for (uint32_t v = 0; v < sh.vertCount; ++v) {
+            const float *p = &fs.pos[(sh.firstVert + v) * 3];
+            mesh->getVertexPositions()[v] = Point(p[0], p[1], p[2]);
+            if (useN) { const float *n = &fs.nrm[(sh.firstVert + v) * 3]; mesh->getVertexNormals()[v] = Normal(n[0], n[1], n[2]); }
+            if (fs.hasUV) { const float *t = &fs.uv[(sh.firstVert + v) * 2]; mesh->getVertexTexcoords()[v] = Point2(t[0], t[1]); }
+        }
+        for (uint32_t t = 0; t < sh.triCount; ++t)
+            for (int k = 0; k < 3; ++k)
+                mesh->getTriangles()[t].idx[k] = fs.idx[(sh.firstTri + t) * 3 + k] - sh.firstVert;
+        mesh->addChild(bsdfs[sh.bsdf]); bsdfs[sh.bsdf]->setParent(mesh);
+        if (sh.emitter >= 0) {
+            const FEmitter &fe = fs.emitters[sh.emitter];
+            Properties p("area"); p.setSpectrum("radiance", rgb(fe.radiance)); p.setFloat("samplingWeight", fe.weight);
+            ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), p));
+            mesh->addChild(em); em->setParent(mesh); em->configure();
+        }
+        mesh->configure();
+        b.scene->addChild(mesh); mesh->setParent(b.scene);
+    }
+    // film + filter
+    {
+        Properties fp(fs.filter == 0 ? "box" : "gaussian");
+        if (fs.filter == 1) fp.setFloat("stddev", fs.filterStddev);
+        b.filter = static_cast<ReconstructionFilter *>(create(MTS_CLASS(ReconstructionFilter), fp));
+        b.filter->configure();
+        Properties p("hdrfilm"); p.setInteger("width", fs.W); p.setInteger("height", fs.H); p.setBoolean("banner", false);
+        b.film = static_cast<Film *>(create(MTS_CLASS(Film), p));
+        b.film->addChild(b.filter); b.filter->setParent(b.film);
+        b.film->configure();
+    }
+    // sampler
+    if (fs.sampler == 1) {
+        Properties p("sobol"); p.setSize("sampleCount", fs.spp); p.setSize("scramble", (size_t) fs.seed);
+        b.sampler = static_cast<Sampler *>(create(MTS_CLASS(Sampler), p));
+        b.sampler->configure();
+    } else {
+        b.sampler = new SeededIndependent(fs.spp, (uint32_t) fs.seed, fs.W);
+    }
+    // sensor
+    {
+        Properties p("perspective");
+        Matrix4x4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = fs.camToWorld[i * 4 + j];
+        p.setTransform("toWorld", Transform(m));
+        p.setFloat("fov", fs.fov); p.setString("fovAxis", "x");
+        p.setFloat("nearClip", fs.nearClip); p.setFloat("farClip", fs.farClip);
+        b.sensor = static_cast<Sensor *>(create(MTS_CLASS(Sensor), p));
+        b.sensor->addChild(b.film); b.film->setParent(b.sensor);
+        b.sensor->addChild(b.sampler); b.sampler->setParent(b.sensor);
+        b.sensor->configure();
+        b.scene->addChild(b.sensor); b.sensor->setParent(b.scene);
+    }
+    // integrator
+    {
+        Properties p("path"); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
+        p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
+        b.integrator = static_cast<SamplingIntegrator *>(create(MTS_CLASS(Integrator), p));
+        b.integrator->configure();
+        b.scene->addChild(b.integrator); b.integrator->setParent(b.scene);
+    }
+    b.scene->configure();      // picks sensor/sampler, integrator->configureSampler (Sobol: setFilmResolution)
+    b.scene->initialize();     // kd-tree build + emitter PDF
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------ modes
+static void modeTables(const std::string &out) {
+    const uint32_t dims = 128;
+    std::vector<uint32_t> m32(sobol::Matrices::matrices32, sobol::Matrices::matrices32 + dims * 52);
+    save(out + "/sobol_matrices32.npy", "<u4", {dims, 52}, m32);
+    std::vector<uint64_t> vdc, vdci;
+    for (int m = 1; m <= 16; ++m) for (int c = 0; c < 52; ++c) {
+        vdc.push_back(sobol::Matrices::vdc_sobol_matrices[m - 1][c]);
+        vdci.push_back(sobol::Matrices::vdc_sobol_matrices_inv[m - 1][c]);
+    }
+    save(out + "/sobol_vdc.npy", "<u8", {16, 52}, vdc);
+    save(out + "/sobol_vdc_inv.npy", "<u8", {16, 52}, vdci);
+    // SFMT known answers (reference src/tests/test_random.cpp:433-508 uses Random(4321))
+    ref<Random> rng = new Random((uint64_t) 4321);
+    std::vector<uint64_t> kat; for (int i = 0; i < 1000; ++i) kat.push_back(rng->nextULong());
+    save(out + "/sfmt_kat_4321.npy", "<u8", {1000}, kat);
+    ref<Random> rng2 = new Random((uint64_t) 1234);
+    std::vector<float> fl; for (int i = 0; i < 256; ++i) fl.push_back(rng2->nextFloat());
+    save(out + "/sfmt_float_1234.npy", "<f4", {256}, fl);
+    std::vector<uint64_t> tea;
+    for (uint32_t a = 0; a < 16; ++a) for (uint32_t c = 0; c < 16; ++c) tea.push_back(sampleTEA(a * 2654435761u, c * 40503u + a, 4));
+    save(out + "/tea_4rounds.npy", "<u8", {16, 16}, tea);
+    // Sobol look_up + sampleSingle known answers
+    std::vector<uint64_t> lu; std::vector<float> sv;
+    for (uint32_t m = 2; m <= 12; m += 5) for (uint32_t fr = 0; fr < 20; fr += 3) for (uint32_t k = 0; k < 8; ++k) {
+        uint32_t px = (k * 2654435761u) & ((1u << m) - 1), py = (k * 40503u + fr * 977u) & ((1u << m) - 1);
+        uint64_t idx = sobol::look_up(m, fr, px, py, 0);
+        lu.push_back(m); lu.push_back(fr); lu.push_back(px); lu.push_back(py); lu.push_back(idx);
+        for (uint32_t d = 0; d < 8; ++d) sv.push_back(sobol::sampleSingle(idx, d * 7, 0));
+    }
+    save(out + "/sobol_lookup.npy", "<u8", {lu.size() / 5, 5}, lu);
+    save(out + "/sobol_values.npy", "<f4", {sv.size() / 8, 8}, sv);
+}
+
+static uint64_t g_rays = 0, g_shadow = 0;
+
+// per-(pixel, sampleIndex) Li; `pairs` = [px, py, sampleIdx]*n
+static void modeSamples(Built &b, const FScene &fs, const std::string &pairsPath, const std::string &out) {
+    FILE *f = fopen(pairsPath.c_str(), "rb"); if (!f) { fprintf(stderr, "no pairs\n"); _exit(2); }
+    fseek(f, 0, SEEK_END); size_t n = ftell(f) / 12; fseek(f, 0, SEEK_SET);
+    std::vector<uint32_t> pairs(n * 3); rd(f, pairs.data(), n * 12); fclose(f);
+    ref<RecordingSampler> rec = new RecordingSampler(b.sampler->clone());
+    b.integrator->configureSampler(b.scene, rec);
+    std::vector<float> li(n * 3), pos(n * 2), ray(n * 8), logv(n * 64, -1.0f); std::vector<int32_t> depth(n), nlog(n);
+    RadianceQueryRecord rRec(b.scene, rec);
+    for (size_t i = 0; i < n; ++i) {
+        Point2i px(pairs[i * 3], pairs[i * 3 + 1]);
+        rec->generate(px, pairs[i * 3 + 2]);
+        rRec.newQuery(RadianceQueryRecord::ESensorRay & ~RadianceQueryRecord::EOpacity, b.sensor->getMedium());
+        Point2 samplePos(Point2(px) + Vector2(rRec.nextSample2D()));
+        RayDifferential r;
+        Spectrum spec = b.sensor->sampleRayDifferential(r, samplePos, Point2(0.5f), 0.5f);
+        r.scaleDifferential(1.0f / std::sqrt((Float) fs.spp));
+        spec *= b.integrator->Li(r, rRec);
+        Float R, G, B; spec.toLinearRGB(R, G, B);
+        li[i * 3] = R; li[i * 3 + 1] = G; li[i * 3 + 2] = B;
+        pos[i * 2] = samplePos.x; pos[i * 2 + 1] = samplePos.y;
+        ray[i * 8 + 0] = r.o.x; ray[i * 8 + 1] = r.o.y; ray[i * 8 + 2] = r.o.z; ray[i * 8 + 3] = r.mint;
+        ray[i * 8 + 4] = r.d.x; ray[i * 8 + 5] = r.d.y; ray[i * 8 + 6] = r.d.z; ray[i * 8 + 7] = r.maxt;
+        depth[i] = rRec.depth;
+        nlog[i] = (int32_t) rec->log.size();
+        for (size_t k = 0; k < rec->log.size() && k < 64; ++k) logv[i * 64 + k] = rec->log[k];
+    }
+    save(out + "_li.npy", "<f4", {n, 3}, li);
+    save(out + "_pos.npy", "<f4", {n, 2}, pos);
+    save(out + "_ray.npy", "<f4", {n, 8}, ray);
+    save(out + "_depth.npy", "<i4", {n}, depth);
+    save(out + "_nsamples.npy", "<i4", {n}, nlog);
+    save(out + "_svalues.npy", "<f4", {n, 64}, logv);
+}
+
+// camera-ray hit records
+static void modeHits(Built &b, const FScene &fs, uint32_t step, const std::string &out) {
+    std::vector<float> rec; size_t n = 0;
+    for (uint32_t y = step / 2; y < fs.H; y += step) for (uint32_t x = step / 2; x < fs.W; x += step) {
+        RayDifferential r; b.sensor->sampleRayDifferential(r, Point2(x + 0.25f, y + 0.75f), Point2(0.5f), 0.5f);
+        Intersection its; bool hit = b.scene->rayIntersect(r, its);
+        float v[24] = {0}; v[0] = (float) x; v[1] = (float) y; v[2] = hit ? 1.f : 0.f;
+        if (hit) {
+            v[3] = its.t; v[4] = its.p.x; v[5] = its.p.y; v[6] = its.p.z;
+            v[7] = its.geoFrame.n.x; v[8] = its.geoFrame.n.y; v[9] = its.geoFrame.n.z;
+            v[10] = its.shFrame.n.x; v[11] = its.shFrame.n.y; v[12] = its.shFrame.n.z;
+            v[13] = its.shFrame.s.x; v[14] = its.shFrame.s.y; v[15] = its.shFrame.s.z;
+            v[16] = its.uv.x; v[17] = its.uv.y; v[18] = its.wi.x; v[19] = its.wi.y; v[20] = its.wi.z;
+            v[21] = (float) its.primIndex;
+            // global shape index = position in scene->getShapes()
+            const ref_vector<Shape> &shapes = b.scene->getShapes();
+            for (size_t s = 0; s < shapes.size(); ++s) if (shapes[s].get() == its.shape) v[22] = (float) s;
+        }
+        rec.insert(rec.end(), v, v + 24); ++n;
+    }
+    save(out, "<f4", {n, 24}, rec);
+}
+
+static void modeImage(Built &b, const FScene &fs, int threads, const std::string &out) {
+    // SamplingIntegrator::renderBlock over 32x32 blocks, `threads` workers each with its own sampler clone and ImageBlock;
+    // results summed into one film-sized 5-channel block (what BlockedRenderProcess::processResult -> Film::put does).
+    const int bs = 32; int bx = (fs.W + bs - 1) / bs, by = (fs.H + bs - 1) / bs;
+    int border = b.filter->getBorderSize();
+    size_t FW = fs.W + 2 * border, FH = fs.H + 2 * border;
+    std::vector<float> film(FW * FH * 5, 0.0f);
+    std::atomic<int> next(0); std::mutex mtx;
+    ref<Timer> timer = new Timer();
+    auto worker = [&](int tid) {
+        ref<Sampler> sampler = b.sampler->clone();
+        b.integrator->configureSampler(b.scene, sampler);
+        ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, Vector2i(bs, bs), b.filter);
+        bool stop = false;
+        while (true) {
+            int id = next++; if (id >= bx * by) break;
+            int ox = (id % bx) * bs, oy = (id / bx) * bs;
+            int w = std::min(bs, (int) fs.W - ox), h = std::min(bs, (int) fs.H - oy);
+            if (w != bs || h != bs) block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, Vector2i(w, h), b.filter);
+            block->setOffset(Point2i(ox, oy));
+            std::vector<TPoint2<uint8_t> > pts;
+            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) pts.push_back(TPoint2<uint8_t>(x, y));
+            b.integrator->renderBlock(b.scene, b.sensor, sampler, block, stop, pts);
+            const float *src = block->getBitmap()->getFloat32Data();
+            int sw = w + 2 * border, shh = h + 2 * border;
+            std::lock_guard<std::mutex> g(mtx);
+            for (int y = 0; y < shh; ++y) for (int x = 0; x < sw; ++x)
+                for (int c = 0; c < 5; ++c)
+                    film[((size_t) (oy + y) * FW + (ox + x)) * 5 + c] += src[((size_t) y * sw + x) * 5 + c];
+            if (w != bs || h != bs) block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, Vector2i(bs, bs), b.filter);
+        }
+    };
+    std::vector<std::thread> pool;
+    // mitsuba::Thread registration is needed for TLS-based statistics; run worker 0 inline, others as mitsuba threads is overkill:
+    // StatsCounter uses Thread::getID() modulo slots, which works for foreign threads after Thread::registerUnmanagedThread.
+    for (int t = 1; t < threads; ++t) pool.emplace_back([&, t] { Thread::registerUnmanagedThread("wrk" + std::to_string(t)); worker(t); });
+    worker(0);
+    for (auto &t : pool) t.join();
+    double sec = timer->getMicroseconds() * 1e-6;
+    save(out + "_film.npy", "<f4", {FH, FW, 5}, film);
+    double nsamples = (double) fs.W * fs.H * fs.spp;
+    std::string stats = Statistics::getInstance()->getStats();
+    FILE *f = fopen((out + "_stats.txt").c_str(), "w");
+    fprintf(f, "seconds %.6f\nsamples %.0f\nmsamples_per_s %.6f\nthreads %d\n%s\n", sec, nsamples, nsamples / sec * 1e-6, threads, stats.c_str());
+    fclose(f);
+    printf("render: %.3f s, %.4f Msamples/s (%d threads)\n", sec, nsamples / sec * 1e-6, threads);
+}
+
+static void modeCamera(Built &b, const FScene &fs, const std::string &out) {
+    std::vector<float> v;
+    // sampleToCamera is protected: recover it by probing m_sampleToCamera through sampleRayDifferential is lossy, so dump
+    // rays on a grid instead and the filter table; the host-side camera matrix is checked through these rays.
+    for (int j = 0; j <= 8; ++j) for (int i = 0; i <= 8; ++i) {
+        Point2 s(fs.W * (i / 8.0f), fs.H * (j / 8.0f));
+        RayDifferential r; b.sensor->sampleRayDifferential(r, s, Point2(0.5f), 0.5f);
+        float a[10] = {s.x, s.y, r.o.x, r.o.y, r.o.z, r.mint, r.d.x, r.d.y, r.d.z, r.maxt};
+        v.insert(v.end(), a, a + 10);
+    }
+    save(out + "_camrays.npy", "<f4", {81, 10}, v);
+    std::vector<float> ft;
+    for (int i = 0; i <= 320; ++i) ft.push_back(b.filter->evalDiscretized(-b.filter->getRadius() * 1.05f + i * (2.1f * b.filter->getRadius() / 320)));
+    ft.push_back(b.filter->getRadius()); ft.push_back((float) b.filter->getBorderSize());
+    save(out + "_filter.npy", "<f4", {ft.size()}, ft);
+}
+
+// unit vectors: warp functions, TriAccel::load, diffuse BSDF, emitter sampling
+static void modeUnits(Built &b, const FScene &fs, const std::string &out) {
+    std::vector<float> w;
+    for (int j = 0; j < 33; ++j) for (int i = 0; i < 33; ++i) {
+        Point2 s(std::min(i / 32.0f, 0.99999994f), std::min(j / 32.0f, 0.99999994f));
+        Vector h = warp::squareToCosineHemisphere(s); Point2 t = warp::squareToUniformTriangle(s); Point2 d = warp::squareToUniformDiskConcentric(s);
+        float a[9] = {s.x, s.y, h.x, h.y, h.z, t.x, t.y, d.x, d.y}; w.insert(w.end(), a, a + 9);
+    }
+    save(out + "_warp.npy", "<f4", {33 * 33, 9}, w);
+    std::vector<float> ta;
+    for (uint32_t t = 0; t < fs.nTris; ++t) {
+        const float *p0 = &fs.pos[fs.idx[t * 3] * 3], *p1 = &fs.pos[fs.idx[t * 3 + 1] * 3], *p2 = &fs.pos[fs.idx[t * 3 + 2] * 3];
+        TriAccel acc; acc.load(Point(p0[0], p0[1], p0[2]), Point(p1[0], p1[1], p1[2]), Point(p2[0], p2[1], p2[2]));
+        float a[10] = {(float) acc.k, acc.n_u, acc.n_v, acc.n_d, acc.a_u, acc.a_v, acc.b_nu, acc.b_nv, acc.c_nu, acc.c_nv};
+        ta.insert(ta.end(), a, a + 10);
+    }
+    save(out + "_triaccel.npy", "<f4", {fs.nTris, 10}, ta);
+    // emitter sampling from reference points = camera-ray hits
+    std::vector<float> em;
+    for (uint32_t y = 40; y < fs.H; y += fs.H / 6) for (uint32_t x = 40; x < fs.W; x += fs.W / 6) {
+        RayDifferential r; b.sensor->sampleRayDifferential(r, Point2(x + 0.5f, y + 0.5f), Point2(0.5f), 0.5f);
+        Intersection its; if (!b.scene->rayIntersect(r, its)) continue;
+        for (int k = 0; k < 4; ++k) {
+            Point2 s(0.13f + 0.23f * k, 0.91f - 0.27f * k);
+            DirectSamplingRecord dRec(its);
+            Spectrum val = b.scene->sampleEmitterDirect(dRec, s, true);
+            Float R, G, B; val.toLinearRGB(R, G, B);
+            float a[20] = {its.p.x, its.p.y, its.p.z, its.shFrame.n.x, its.shFrame.n.y, its.shFrame.n.z, s.x, s.y, R, G, B,
+                           dRec.p.x, dRec.p.y, dRec.p.z, dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist, dRec.pdf, 0};
+            if (!val.isZero()) a[19] = b.scene->pdfEmitterDirect(dRec);
+            em.insert(em.end(), a, a + 20);
+        }
+    }
+    save(out + "_emitter.npy", "<f4", {em.size() / 20, 20}, em);
+    // BSDF eval/pdf/sample for every BSDF at a hit (local frame), wi/u grids
+    std::vector<float> bs;
+    const ref_vector<Shape> &shapes = b.scene->getShapes();
+    for (size_t si = 0; si < shapes.size(); ++si) {
+        const BSDF *bsdf = const_cast<Shape *>(shapes[si].get())->getBSDF();
+        Intersection its; its.shape = const_cast<Shape *>(shapes[si].get()); its.p = Point(0.0f); its.uv = Point2(0.5f); its.hasUVPartials = false; its.time = 0;
+        its.shFrame = Frame(Normal(0, 0, 1)); its.geoFrame = its.shFrame;
+        for (int a = 0; a < 5; ++a) for (int k = 0; k < 9; ++k) {
+            float th = 0.1f + 0.33f * a, ph = 0.7f * a;
+            Vector wi(std::sin(th) * std::cos(ph), std::sin(th) * std::sin(ph), std::cos(th));
+            if (a == 4) wi.z = -wi.z;   // back side
+            Point2 u(0.07f + 0.11f * k, 0.93f - 0.1f * k);
+            its.wi = wi;
+            BSDFSamplingRecord bRec(its, NULL, ERadiance);
+            Float pdf = 0; Spectrum wgt = bsdf->sample(bRec, pdf, u);
+            Float R, G, B; wgt.toLinearRGB(R, G, B);
+            float rowv[24] = {(float) si, wi.x, wi.y, wi.z, u.x, u.y, R, G, B, pdf, bRec.wo.x, bRec.wo.y, bRec.wo.z, bRec.eta, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // eval/pdf for a fixed outgoing direction
+            Vector wo(std::sin(0.5f + 0.1f * k) * std::cos(2.1f), std::sin(0.5f + 0.1f * k) * std::sin(2.1f), std::cos(0.5f + 0.1f * k));
+            BSDFSamplingRecord eRec(its, wi, wo, ERadiance);
+            Spectrum ev = bsdf->eval(eRec); ev.toLinearRGB(R, G, B);
+            rowv[14] = wo.x; rowv[15] = wo.y; rowv[16] = wo.z; rowv[17] = R; rowv[18] = G; rowv[19] = B; rowv[20] = bsdf->pdf(eRec);
+            rowv[21] = (float) bsdf->getType();
+            bs.insert(bs.end(), rowv, rowv + 24);
+        }
+    }
+    save(out + "_bsdf.npy", "<f4", {bs.size() / 24, 24}, bs);
+}
+
+int main(int argc, char **argv) {
+    Class::staticInitialization();
+    Object::staticInitialization();
+    PluginManager::staticInitialization();
+    Statistics::staticInitialization();
+    Thread::staticInitialization();
+    Logger::staticInitialization();
+    FileStream::staticInitialization();
+    Spectrum::staticInitialization();
+    // Bitmap::staticInitialization() only initialises FormatConverter (fmtconv.cpp needs boost::mpl, absent) -> skipped; nothing here converts bitmaps.
+    Scheduler::staticInitialization();
+    Thread::getThread()->getLogger()->setLogLevel(EWarn);
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out>\n"); _exit(1); }
+    std::string a1 = argv[1];
+    if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
+    FScene fs = loadScene(argv[1]);
+    Built b = buildScene(fs);
+    std::string mode = argv[2];
+    if (mode == "samples") modeSamples(b, fs, argv[3], argv[4]);
+    else if (mode == "image") modeImage(b, fs, atoi(argv[3]), argv[4]);
+    else if (mode == "hits") modeHits(b, fs, atoi(argv[3]), argv[4]);
+    else if (mode == "camera") modeCamera(b, fs, argv[3]);
+    else if (mode == "units") modeUnits(b, fs, argv[3]);
+    else { fprintf(stderr, "unknown mode\n"); _exit(1); }
+    fflush(stdout);
+    _exit(0);   // skip the static shutdown sequence (the process hangs in thread cleanup otherwise)
+}
