@@ -1,0 +1,802 @@
+/* oracle/pt_oracle.c -- TEST INFRASTRUCTURE (see pt_oracle.h).  Plain-C CPU restatement of the reference's
+ * unidirectional path tracer: MIPathTracer::Li over Scene::rayIntersect + BSDF / emitter / sampler plugins.
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ *
+ * Arithmetic contract (shared with the HIP product only as a written specification, DESIGN.md §"arithmetic"):
+ *   - IEEE binary32, round-to-nearest, no contraction (compiled with -ffp-contract=off, no fast-math);
+ *     expressions are evaluated left to right exactly as written; x/len of vectors is "recip then multiply"
+ *     like the reference's TVector3::operator/= (include/mitsuba/core/vector.h:546-553).
+ *   - sin/cos of the concentric-disk map use the polynomial pair sinp/cosp below instead of libm, so that
+ *     CPU and GPU agree bit for bit (libm's sincosf differs between glibc and the GPU math library).
+ *   - closest hit = minimum t over all triangles passing the TriAccel test in [mint, maxt]; ties are broken
+ *     towards the lower global triangle index, which makes the result independent of traversal order
+ *     (the kd-tree of the reference keeps the last-tested of equal-t hits: SURVEY.md §7; scenes avoid coincident geometry).
+ */
+#include "pt_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <pthread.h>
+
+#define EPSILON 1e-4f            /* include/mitsuba/core/constants.h:28 */
+#define SHADOW_EPSILON 1e-3f     /* constants.h:29 */
+#define INV_PI 0.31830988618379067154f  /* constants.h:64 */
+#define ONE_MINUS_EPS 0.999999940395355225f /* constants.h:51 */
+#define M_PI_F 3.14159265358979323846f
+#define KD_AABB_EPSILON 1e-3f    /* include/mitsuba/render/gkdtree.h:50 */
+#define FILTER_RES 31            /* include/mitsuba/core/rfilter.h:28 */
+
+typedef struct { float x, y, z; } v3;
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline v3 normalize(v3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return scale(a, inv); }
+static inline int is_zero(v3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+static inline float maxf(float a, float b) { return a > b ? a : b; }
+static inline float minf(float a, float b) { return a < b ? a : b; }
+static inline float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+typedef struct { uint32_t k; float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_nv; } triaccel;
+typedef struct { v3 lo, hi; int32_t left, right, first, count; } bvh_node;   /* leaf: count > 0 */
+
+typedef struct {
+    int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter;
+} hit_t;
+
+struct orc_scene {
+    orc_scene_desc d;
+    float *pos, *nrm; uint32_t *idx; orc_shape *shapes; orc_material *materials; orc_emitter *emitters;
+    uint32_t *tri_shape;
+    triaccel *accel;
+    v3 aabb_lo, aabb_hi;            /* kd-tree root box incl. the reference's enlargement */
+    bvh_node *nodes; uint32_t *bvh_tris; int n_nodes;
+    /* emitters */
+    float *emitter_cdf; float emitter_norm;
+    float **area_cdf; float *inv_area;   /* per emitter */
+    /* film */
+    float filter_values[FILTER_RES + 1]; float filter_radius, filter_scale; int border;
+    uint32_t log_res; float resolution;
+    float inv_res_x, inv_res_y;
+};
+
+/* ------------------------------------------------------------------------------------------------ samplers */
+/* include/mitsuba/core/qmc.h:146-156 sampleTEA */
+uint64_t orc_tea(uint32_t v0, uint32_t v1, int rounds) {
+    uint32_t sum = 0;
+    for (int i = 0; i < rounds; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xC8013EA4u);
+        v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7E95761Eu);
+    }
+    return ((uint64_t) v1 << 32) + v0;
+}
+/* src/libcore/random.cpp:626-634 nextFloat bit trick */
+static inline float bits_to_float(uint32_t b) { union { uint32_t u; float f; } x; x.u = (b >> 9) | 0x3f800000u; return x.f - 1.0f; }
+
+/* src/samplers/sobolseq.h:43-58 sampleSingle (scramble 0) */
+float orc_sobol_sample(const orc_scene *s, uint64_t index, uint32_t dim) {
+    uint32_t result = 0;
+    for (uint32_t i = dim * 52; index; index >>= 1, ++i)
+        if (index & 1) result ^= s->d.sobol_matrices32[i];
+    return minf((float) result * (1.0f / 4294967296.0f), ONE_MINUS_EPS);
+}
+/* src/samplers/sobolseq.h:99-131 look_up (scramble 0) */
+uint64_t orc_sobol_look_up(const orc_scene *s, uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
+    const uint32_t m2 = m << 1;
+    uint64_t index = (uint64_t) frame << m2;
+    uint64_t delta = 0;
+    for (uint32_t c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= s->d.sobol_vdc[(m - 1) * 52 + c];
+    uint64_t b = (((uint64_t) px << m) | py) ^ delta;
+    for (uint32_t c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= s->d.sobol_vdc_inv[(m - 1) * 52 + c];
+    return index;
+}
+
+/* Sampler state: src/samplers/sobol.cpp:171-251 (generate/setSampleIndex/next1D/next2D, m_arrayStartDim = m_arrayEndDim = 5)
+ * and the build-defined independent stream (mirrored in oracle/ref_build/harness.cpp SeededIndependent). */
+typedef struct {
+    const orc_scene *sc; int kind;
+    uint32_t px, py; uint64_t sample_index, sobol_index; uint32_t dim;   /* sobol */
+    uint32_t v0, call;                                                  /* independent */
+    float *log; int nlog;
+} sampler_t;
+
+static void sampler_begin(sampler_t *sp, const orc_scene *sc, uint32_t px, uint32_t py, uint64_t sample_index, float *log) {
+    sp->sc = sc; sp->kind = (int) sc->d.sampler; sp->px = px; sp->py = py; sp->sample_index = sample_index;
+    sp->dim = 0; sp->log = log; sp->nlog = 0;
+    if (sp->kind == 1) {
+        /* sobol.cpp:204-216 setSampleIndex */
+        if (sc->log_res > 1) sp->sobol_index = orc_sobol_look_up(sc, sc->log_res, (uint32_t) sample_index, px, py);
+        else sp->sobol_index = sample_index;
+    } else {
+        sp->v0 = (py * sc->d.width + px) ^ ((uint32_t) sc->d.seed * 0x9E3779B9u);
+        sp->call = 0;
+    }
+}
+static inline void slog(sampler_t *sp, float v) { if (sp->log && sp->nlog < 64) sp->log[sp->nlog] = v; sp->nlog++; }
+static float next1D(sampler_t *sp) {
+    float v;
+    if (sp->kind == 1) {
+        if (sp->dim >= 5 && sp->dim < 5) sp->dim = 5;          /* sobol.cpp:220-221 with start == end == 5: never taken */
+        v = orc_sobol_sample(sp->sc, sp->sobol_index, sp->dim++);
+    } else {
+        uint32_t v1 = ((uint32_t) sp->sample_index << 8) | (sp->call++ & 0xFFu);
+        v = bits_to_float((uint32_t) orc_tea(sp->v0, v1, 4));
+    }
+    slog(sp, v); return v;
+}
+static void next2D(sampler_t *sp, float *x, float *y) {
+    if (sp->kind == 1) {
+        if (sp->dim + 1 >= 5 && sp->dim < 5) sp->dim = 5;      /* sobol.cpp:233-235: a 2D request at dim 4 skips to 5 */
+        if (sp->dim == 0 && sp->sobol_index != sp->sample_index) {  /* sobol.cpp:241-243 */
+            *x = orc_sobol_sample(sp->sc, sp->sobol_index, sp->dim++) * sp->sc->resolution - (float) (int32_t) sp->px;
+            *y = orc_sobol_sample(sp->sc, sp->sobol_index, sp->dim++) * sp->sc->resolution - (float) (int32_t) sp->py;
+        } else {
+            *x = orc_sobol_sample(sp->sc, sp->sobol_index, sp->dim++);
+            *y = orc_sobol_sample(sp->sc, sp->sobol_index, sp->dim++);
+        }
+    } else {
+        uint32_t v1 = ((uint32_t) sp->sample_index << 8) | (sp->call++ & 0xFFu);
+        uint64_t r = orc_tea(sp->v0, v1, 4);
+        *x = bits_to_float((uint32_t) r); *y = bits_to_float((uint32_t) (r >> 32));
+    }
+    slog(sp, *x); slog(sp, *y);
+}
+
+/* ------------------------------------------------------------------------------------------------ SFMT19937 (KAT only) */
+/* src/libcore/random.cpp:72-96 parameters, :397-406 init_gen_rand (64-bit seed), :322-346 period_certification,
+ * :353-390 gen_rand_all (SFMT recursion of Saito & Matsumoto), :288-296 gen_rand64, :626-634 nextFloat */
+#define SFMT_N 156
+#define SFMT_N32 624
+#define SFMT_N64 312
+typedef struct { uint32_t s[SFMT_N32]; int idx; } sfmt_t;
+static void sfmt_init(sfmt_t *st, uint64_t seed) {
+    uint64_t p[SFMT_N64]; p[0] = seed;
+    for (int i = 1; i < SFMT_N64; ++i) p[i] = 6364136223846793005ULL * (p[i - 1] ^ (p[i - 1] >> 62)) + (uint64_t) i;
+    memcpy(st->s, p, sizeof(p));  /* little-endian: psfmt64 aliases psfmt32 */
+    st->idx = SFMT_N32;
+    static const uint32_t parity[4] = {0x00000001u, 0, 0, 0x13c9e684u};
+    uint32_t inner = 0;
+    for (int i = 0; i < 4; ++i) inner ^= st->s[i] & parity[i];
+    for (int i = 16; i > 0; i >>= 1) inner ^= inner >> i;
+    if ((inner & 1) == 1) return;
+    for (int i = 0; i < 4; ++i) { uint32_t work = 1; for (int j = 0; j < 32; ++j) { if (work & parity[i]) { st->s[i] ^= work; return; } work <<= 1; } }
+}
+static void sfmt_recursion(uint32_t *r, const uint32_t *a, const uint32_t *b, const uint32_t *c, const uint32_t *d) {
+    /* 128-bit shifts by SL2 = SR2 = 1 byte; 32-bit shifts SL1 = 18, SR1 = 11; masks MSK1..4 */
+    static const uint32_t msk[4] = {0xdfffffefu, 0xddfecb7fu, 0xbffaffffu, 0xbffffff6u};
+    uint64_t al = ((uint64_t) a[1] << 32) | a[0], ah = ((uint64_t) a[3] << 32) | a[2];
+    uint64_t cl = ((uint64_t) c[1] << 32) | c[0], ch = ((uint64_t) c[3] << 32) | c[2];
+    uint64_t xh = (ah << 8) | (al >> 56), xl = al << 8;         /* lshift128(a, 1 byte) */
+    uint64_t yl = (cl >> 8) | (ch << 56), yh = ch >> 8;         /* rshift128(c, 1 byte) */
+    uint32_t x[4] = {(uint32_t) xl, (uint32_t) (xl >> 32), (uint32_t) xh, (uint32_t) (xh >> 32)};
+    uint32_t y[4] = {(uint32_t) yl, (uint32_t) (yl >> 32), (uint32_t) yh, (uint32_t) (yh >> 32)};
+    for (int i = 0; i < 4; ++i) r[i] = a[i] ^ x[i] ^ ((b[i] >> 11) & msk[i]) ^ y[i] ^ (d[i] << 18);
+}
+static void sfmt_gen_all(sfmt_t *st) {
+    uint32_t *s = st->s; const int POS1 = 122;
+    uint32_t *r1 = &s[(SFMT_N - 2) * 4], *r2 = &s[(SFMT_N - 1) * 4];
+    int i = 0;
+    for (; i < SFMT_N - POS1; ++i) { sfmt_recursion(&s[i * 4], &s[i * 4], &s[(i + POS1) * 4], r1, r2); r1 = r2; r2 = &s[i * 4]; }
+    for (; i < SFMT_N; ++i) { sfmt_recursion(&s[i * 4], &s[i * 4], &s[(i + POS1 - SFMT_N) * 4], r1, r2); r1 = r2; r2 = &s[i * 4]; }
+}
+static uint64_t sfmt_next64(sfmt_t *st) {
+    if (st->idx >= SFMT_N32) { sfmt_gen_all(st); st->idx = 0; }
+    uint64_t r = ((uint64_t) st->s[st->idx + 1] << 32) | st->s[st->idx]; st->idx += 2; return r;
+}
+void orc_sfmt_sequence(uint64_t seed, uint64_t n, uint64_t *out) { sfmt_t st; sfmt_init(&st, seed); for (uint64_t i = 0; i < n; ++i) out[i] = sfmt_next64(&st); }
+void orc_sfmt_floats(uint64_t seed, uint64_t n, float *out) { sfmt_t st; sfmt_init(&st, seed); for (uint64_t i = 0; i < n; ++i) out[i] = bits_to_float((uint32_t) (sfmt_next64(&st) & 0xFFFFFFFFu)); }
+
+/* ------------------------------------------------------------------------------------------------ warps */
+/* polynomial sin/cos on [-pi/4, pi/4] (Cephes single-precision minimax coefficients); see the arithmetic contract above */
+static inline float sinp(float x) { float z = x * x; float y = -1.9515295891e-4f * z; y = y + 8.3321608736e-3f; y = y * z; y = y - 1.6666654611e-1f; y = y * z; y = y * x; return y + x; }
+static inline float cosp(float x) { float z = x * x; float y = 2.443315711809948e-5f * z; y = y - 1.388731625493765e-3f; y = y * z; y = y + 4.166664568298827e-2f; y = y * z; y = y * z; float h = 0.5f * z; y = y - h; return y + 1.0f; }
+
+/* src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric.  phi = (pi/4)(r2/r1) in the first branch; in the second branch
+ * phi = pi/2 - (r1/r2)(pi/4), evaluated through sin(pi/2 - x) = cos x, cos(pi/2 - x) = sin x with x = (r1/r2)(pi/4). */
+static void disk_concentric(float sx, float sy, float *ox, float *oy) {
+    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, sn, cs;
+    if (r1 == 0 && r2 == 0) { *ox = 0; *oy = 0; return; }
+    if (r1 * r1 > r2 * r2) { r = r1; float x = (M_PI_F / 4.0f) * (r2 / r1); sn = sinp(x); cs = cosp(x); }
+    else { r = r2; float x = (r1 / r2) * (M_PI_F / 4.0f); sn = cosp(x); cs = sinp(x); }
+    *ox = r * cs; *oy = r * sn;
+}
+/* warp.cpp:43-52 squareToCosineHemisphere; math::safe_sqrt = sqrt(max(x,0)) (include/mitsuba/core/math.h:260-267) */
+static v3 cos_hemisphere(float sx, float sy) {
+    float px, py; disk_concentric(sx, sy, &px, &py);
+    float z = sqrtf(maxf(1.0f - px * px - py * py, 0.0f));
+    if (z == 0) z = 1e-10f;
+    return V(px, py, z);
+}
+/* warp.cpp:76-79 squareToUniformTriangle */
+static void uniform_triangle(float sx, float sy, float *bx, float *by) { float a = sqrtf(maxf(1.0f - sx, 0.0f)); *bx = 1 - a; *by = a * sy; }
+void orc_warp(float u, float v, float *o) { v3 h = cos_hemisphere(u, v); o[0] = h.x; o[1] = h.y; o[2] = h.z; uniform_triangle(u, v, &o[3], &o[4]); disk_concentric(u, v, &o[5], &o[6]); }
+
+/* ------------------------------------------------------------------------------------------------ geometry */
+static inline v3 vert(const orc_scene *s, uint32_t i) { return V(s->pos[i * 3], s->pos[i * 3 + 1], s->pos[i * 3 + 2]); }
+static inline v3 vnrm(const orc_scene *s, uint32_t i) { return V(s->nrm[i * 3], s->nrm[i * 3 + 1], s->nrm[i * 3 + 2]); }
+
+/* include/mitsuba/render/triaccel.h:61-94 TriAccel::load */
+static void triaccel_load(triaccel *ta, v3 A, v3 B, v3 C) {
+    static const int wald[4] = {1, 2, 0, 1};
+    v3 b = sub(C, A), c = sub(B, A), N = cross(c, b);
+    int k = 0;
+    for (int j = 0; j < 3; ++j) if (fabsf(comp(N, j)) > fabsf(comp(N, k))) k = j;
+    int u = wald[k], v = wald[k + 1];
+    float n_k = comp(N, k), denom = comp(b, u) * comp(c, v) - comp(b, v) * comp(c, u);
+    memset(ta, 0, sizeof(*ta));
+    if (denom == 0) { ta->k = 3; return; }
+    ta->k = (uint32_t) k;
+    ta->n_u = comp(N, u) / n_k; ta->n_v = comp(N, v) / n_k; ta->n_d = dot(A, N) / n_k;
+    ta->b_nu = comp(b, u) / denom; ta->b_nv = -comp(b, v) / denom;
+    ta->a_u = comp(A, u); ta->a_v = comp(A, v);
+    ta->c_nu = comp(c, v) / denom; ta->c_nv = -comp(c, u) / denom;
+}
+/* triaccel.h:96-158 TriAccel::rayIntersect */
+static inline int triaccel_intersect(const triaccel *ta, v3 o, v3 d, float mint, float maxt, float *u, float *v, float *t) {
+    float o_u, o_v, o_k, d_u, d_v, d_k;
+    switch (ta->k) {
+        case 0: o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; break;
+        case 1: o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; break;
+        case 2: o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; break;
+        default: return 0;
+    }
+    float tt = (ta->n_d - o_u * ta->n_u - o_v * ta->n_v - o_k) / (d_u * ta->n_u + d_v * ta->n_v + d_k);
+    if (tt < mint || tt > maxt) return 0;   /* NaN falls through both comparisons, exactly like the reference */
+    float hu = o_u + tt * d_u - ta->a_u, hv = o_v + tt * d_v - ta->a_v;
+    float uu = hv * ta->b_nu + hu * ta->b_nv, vv = hu * ta->c_nu + hv * ta->c_nv;
+    *u = uu; *v = vv; *t = tt;
+    return uu >= 0 && vv >= 0 && uu + vv <= 1.0f;
+}
+void orc_triaccel(const orc_scene *s, uint32_t tri, float *o) {
+    const triaccel *a = &s->accel[tri];
+    o[0] = (float) a->k; o[1] = a->n_u; o[2] = a->n_v; o[3] = a->n_d; o[4] = a->a_u; o[5] = a->a_v; o[6] = a->b_nu; o[7] = a->b_nv; o[8] = a->c_nu; o[9] = a->c_nv;
+}
+
+/* include/mitsuba/core/aabb.h:308-339 TAABB::rayIntersect(ray, nearT, farT) (dRcp = 1/d, include/mitsuba/core/ray.h:72-83) */
+static int aabb_ray(v3 lo, v3 hi, v3 o, v3 d, float *nearT, float *farT) {
+    float nt = -INFINITY, ft = INFINITY;
+    for (int i = 0; i < 3; ++i) {
+        float origin = comp(o, i), minv = comp(lo, i), maxv = comp(hi, i), di = comp(d, i);
+        if (di == 0) { if (origin < minv || origin > maxv) return 0; }
+        else {
+            float rcp = 1.0f / di;
+            float t1 = (minv - origin) * rcp, t2 = (maxv - origin) * rcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nt = maxf(t1, nt); ft = minf(t2, ft);
+            if (!(nt <= ft)) return 0;
+        }
+    }
+    *nearT = nt; *farT = ft; return 1;
+}
+/* src/librender/skdtree.cpp:112-142 (closest, shadow=0) and :207-226 (any hit, shadow=1): AABB clip + adaptive epsilon */
+static int clip_interval(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt, int shadow, float *mint, float *maxt) {
+    float nt, ft;
+    if (!aabb_ray(s->aabb_lo, s->aabb_hi, o, d, &nt, &ft)) return 0;
+    float rayMinT = rmint;
+    if (rayMinT == EPSILON) {
+        float m = maxf(maxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+        if (!shadow) m = maxf(m, EPSILON);
+        rayMinT *= m;
+    }
+    if (rayMinT > nt) nt = rayMinT;
+    if (rmaxt < ft) ft = rmaxt;
+    *mint = nt; *maxt = ft;
+    return ft > nt;
+}
+
+/* conservative slab test for the oracle's own BVH (not part of the reference; only prunes) */
+static inline int box_overlap(const bvh_node *n, v3 o, v3 inv, float mint, float maxt) {
+    float t0 = mint, t1 = maxt;
+    for (int i = 0; i < 3; ++i) {
+        float a = (comp(n->lo, i) - comp(o, i)) * comp(inv, i), b = (comp(n->hi, i) - comp(o, i)) * comp(inv, i);
+        if (a != a || b != b) continue;          /* 0 * inf: the ray lies in the slab plane -> do not prune on this axis */
+        float lo = minf(a, b), hi = maxf(a, b);
+        t0 = maxf(t0, lo); t1 = minf(t1, hi);
+    }
+    return t0 <= t1 * 1.0000005f + 1e-30f;
+}
+static inline int better(float t, uint32_t prim, float bt, uint32_t bprim) { return t < bt || (t == bt && prim < bprim); }
+
+static int traverse(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int shadow, float *bt, uint32_t *bprim, float *bu, float *bv) {
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int stack[128], sp = 0; stack[sp++] = 0;
+    int found = 0; float best = maxt; uint32_t bestPrim = 0xFFFFFFFFu;
+    while (sp) {
+        const bvh_node *n = &s->nodes[stack[--sp]];
+        if (!box_overlap(n, o, inv, mint, best)) continue;
+        if (n->count > 0) {
+            for (int i = 0; i < n->count; ++i) {
+                uint32_t prim = s->bvh_tris[n->first + i]; float u, v, t;
+                if (triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t)) {
+                    if (shadow) return 1;
+                    if (!found || better(t, prim, best, bestPrim)) { best = t; bestPrim = prim; *bu = u; *bv = v; found = 1; }
+                }
+            }
+        } else { stack[sp++] = n->left; stack[sp++] = n->right; }
+    }
+    if (found) { *bt = best; *bprim = bestPrim; }
+    return found;
+}
+static int traverse_brute(const orc_scene *s, v3 o, v3 d, float mint, float maxt, float *bt, uint32_t *bprim, float *bu, float *bv) {
+    int found = 0; float best = maxt; uint32_t bestPrim = 0xFFFFFFFFu;
+    for (uint32_t prim = 0; prim < s->d.n_tris; ++prim) {
+        float u, v, t;
+        if (triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t))
+            if (!found || better(t, prim, best, bestPrim)) { best = t; bestPrim = prim; *bu = u; *bv = v; found = 1; }
+    }
+    if (found) { *bt = best; *bprim = bestPrim; }
+    return found;
+}
+
+/* include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610 computeShadingFrame */
+static void fill_hit(const orc_scene *s, v3 d, float t, uint32_t prim, float u, float v, hit_t *h) {
+    uint32_t shape = s->tri_shape[prim]; const orc_shape *sh = &s->shapes[shape];
+    uint32_t i0 = s->idx[prim * 3], i1 = s->idx[prim * 3 + 1], i2 = s->idx[prim * 3 + 2];
+    v3 p0 = vert(s, i0), p1 = vert(s, i1), p2 = vert(s, i2);
+    float bx = 1 - u - v, by = u, bz = v;
+    h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = prim - sh->first_tri; h->shape = shape;
+    h->p = add(add(scale(p0, bx), scale(p1, by)), scale(p2, bz));
+    v3 side1 = sub(p1, p0), side2 = sub(p2, p0);
+    v3 fn = cross(side1, side2);
+    float len = sqrtf(dot(fn, fn));
+    if (!is_zero(fn)) { float r = 1.0f / len; fn = scale(fn, r); }
+    int smooth = s->nrm != NULL && !(sh->flags & 1u);
+    if (smooth) {
+        v3 n = add(add(scale(vnrm(s, i0), bx), scale(vnrm(s, i1), by)), scale(vnrm(s, i2), bz));
+        h->ns = normalize(n);
+        if (dot(fn, h->ns) < 0) fn = neg(fn);
+    } else h->ns = fn;
+    h->ng = fn;
+    v3 dpdu = side1;   /* no UV tangents: meshes on this path carry no texcoords (skdtree.h:373-380) */
+    h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
+    h->tt = cross(h->ns, h->s);
+    v3 md = neg(d);
+    h->wi = V(dot(md, h->s), dot(md, h->tt), dot(md, h->ns));   /* Frame::toLocal */
+    h->material = sh->bsdf; h->emitter = sh->emitter;
+}
+static int g_brute = 0;
+void orc_set_brute(int b) { g_brute = b; }
+static int ray_intersect(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt, hit_t *h, int brute) {
+    brute |= g_brute;
+    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0;
+    h->valid = 0;
+    if (!clip_interval(s, o, d, rmint, rmaxt, 0, &mint, &maxt)) return 0;
+    int found = brute ? traverse_brute(s, o, d, mint, maxt, &t, &prim, &u, &v) : traverse(s, o, d, mint, maxt, 0, &t, &prim, &u, &v);
+    if (!found) return 0;
+    fill_hit(s, d, t, prim, u, v, h);
+    return 1;
+}
+static int ray_occluded(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt) {
+    float mint, maxt, t, u, v; uint32_t prim;
+    if (!clip_interval(s, o, d, rmint, rmaxt, 1, &mint, &maxt)) return 0;
+    if (g_brute) return traverse_brute(s, o, d, mint, maxt, &t, &prim, &u, &v);
+    return traverse(s, o, d, mint, maxt, 1, &t, &prim, &u, &v);
+}
+static v3 to_world(const hit_t *h, v3 w) { return add(add(scale(h->s, w.x), scale(h->tt, w.y)), scale(h->ns, w.z)); }
+static v3 to_local(const hit_t *h, v3 w) { return V(dot(w, h->s), dot(w, h->tt), dot(w, h->ns)); }
+
+static void hit_out(const hit_t *h, float *o) {
+    o[0] = h->t; o[1] = h->p.x; o[2] = h->p.y; o[3] = h->p.z; o[4] = h->ng.x; o[5] = h->ng.y; o[6] = h->ng.z;
+    o[7] = h->ns.x; o[8] = h->ns.y; o[9] = h->ns.z; o[10] = h->s.x; o[11] = h->s.y; o[12] = h->s.z;
+    o[13] = h->u; o[14] = h->v; o[15] = h->wi.x; o[16] = h->wi.y; o[17] = h->wi.z; o[18] = (float) h->prim; o[19] = (float) h->shape;
+}
+int orc_ray_intersect(const orc_scene *s, const float *r, float *out) { hit_t h; int ok = ray_intersect(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7], &h, 0); if (ok) hit_out(&h, out); return ok; }
+int orc_ray_intersect_brute(const orc_scene *s, const float *r, float *out) { hit_t h; int ok = ray_intersect(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7], &h, 1); if (ok) hit_out(&h, out); return ok; }
+int orc_ray_occluded(const orc_scene *s, const float *r) { return ray_occluded(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7]); }
+
+/* ------------------------------------------------------------------------------------------------ camera */
+/* src/sensors/perspective.cpp:271-287 sampleRayDifferential (ray part), include/mitsuba/core/transform.h:108-125 */
+static void camera_ray(const orc_scene *s, float sx, float sy, v3 *o, v3 *d, float *mint, float *maxt) {
+    const float *m = s->d.sample_to_camera;
+    float px = sx * s->inv_res_x, py = sy * s->inv_res_y, pz = 0.0f;
+    float x = m[0] * px + m[1] * py + m[2] * pz + m[3];
+    float y = m[4] * px + m[5] * py + m[6] * pz + m[7];
+    float z = m[8] * px + m[9] * py + m[10] * pz + m[11];
+    float w = m[12] * px + m[13] * py + m[14] * pz + m[15];
+    v3 nearP = V(x, y, z);
+    if (w != 1.0f) { float r = 1.0f / w; nearP = scale(nearP, r); }   /* TPoint3::operator/ : recip then multiply */
+    v3 dl = normalize(nearP);
+    float invZ = 1.0f / dl.z;
+    *mint = s->d.near_clip * invZ; *maxt = s->d.far_clip * invZ;
+    const float *c = s->d.cam_to_world;
+    *o = V(c[3], c[7], c[11]);
+    *d = V(c[0] * dl.x + c[1] * dl.y + c[2] * dl.z, c[4] * dl.x + c[5] * dl.y + c[6] * dl.z, c[8] * dl.x + c[9] * dl.y + c[10] * dl.z);
+}
+void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d; camera_ray(s, sx, sy, &o, &d, &o8[3], &o8[7]); o8[0] = o.x; o8[1] = o.y; o8[2] = o.z; o8[4] = d.x; o8[5] = d.y; o8[6] = d.z; }
+
+/* ------------------------------------------------------------------------------------------------ BSDFs */
+#define BSDF_FLAG_TWOSIDED 1u
+/* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
+static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0; }
+
+/* src/bsdfs/diffuse.cpp:112-153 */
+static v3 diffuse_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    float f = INV_PI * wo.z;
+    return V(m->reflectance[0] * f, m->reflectance[1] * f, m->reflectance[2] * f);
+}
+static float diffuse_pdf(v3 wi, v3 wo) { if (wi.z <= 0 || wo.z <= 0) return 0.0f; return INV_PI * wo.z; }
+static v3 diffuse_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    *wo = cos_hemisphere(u, v); *eta = 1.0f; *pdf = INV_PI * wo->z;
+    return V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
+}
+/* dispatch incl. src/bsdfs/twosided.cpp:110-190 (flip wi/wo to the front side when wi.z < 0) */
+static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
+    if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    return diffuse_eval(m, wi, wo);
+}
+static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
+    if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    return diffuse_pdf(wi, wo);
+}
+static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {
+    int flipped = 0;
+    if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; flipped = 1; }
+    v3 w = diffuse_sample(m, wi, u, v, wo, pdf, eta);
+    if (flipped && !is_zero(w)) wo->z = -wo->z;
+    return w;
+}
+void orc_bsdf_sample(const orc_scene *s, uint32_t mi, const float *wi, float u, float v, float *o) {
+    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; v3 w = bsdf_sample(&s->materials[mi], V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta);
+    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = pdf; o[4] = wo.x; o[5] = wo.y; o[6] = wo.z; o[7] = eta;
+}
+void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float *wo, float *o) {
+    v3 e = bsdf_eval(&s->materials[mi], V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
+    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(&s->materials[mi], V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
+}
+
+/* ------------------------------------------------------------------------------------------------ emitters */
+/* include/mitsuba/core/pmf.h:124-137 DiscreteDistribution::sample (lower_bound over cdf[0..n]) */
+static uint32_t cdf_sample(const float *cdf, uint32_t n, float x) {
+    uint32_t lo = 0, hi = n + 1;                       /* first element of cdf[0..n] that is >= x */
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (cdf[mid] < x) lo = mid + 1; else hi = mid; }
+    int64_t e = (int64_t) lo - 1; if (e < 0) e = 0;
+    uint32_t index = (uint32_t) e; if (index > n - 1) index = n - 1;
+    while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
+    return index;
+}
+typedef struct { v3 p, n, d; float dist, pdf; int32_t emitter; } direct_t;
+
+/* src/emitters/area.cpp:106-111 AreaLight::eval */
+static v3 emitter_eval(const orc_scene *s, int32_t e, v3 ns, v3 d) {
+    if (dot(ns, d) <= 0) return V(0, 0, 0);
+    const float *r = s->emitters[e].radiance; return V(r[0], r[1], r[2]);
+}
+/* Scene::sampleEmitterDirect (src/librender/scene.cpp:860-884) -> AreaLight::sampleDirect (src/emitters/area.cpp:160-176)
+ * -> Shape::sampleDirect (src/librender/shape.cpp:102-115) -> TriMesh::samplePosition (src/librender/trimesh.cpp:413-425)
+ * -> Triangle::sample (src/libcore/triangle.cpp:24-59) */
+static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, float sy, direct_t *dr, int test_visibility, uint64_t *shadow_rays) {
+    uint32_t ne = s->d.n_emitters;
+    uint32_t ei = cdf_sample(s->emitter_cdf, ne, sx);
+    float emPdf = s->emitter_cdf[ei + 1] - s->emitter_cdf[ei];
+    sx = (sx - s->emitter_cdf[ei]) / (s->emitter_cdf[ei + 1] - s->emitter_cdf[ei]);
+    const orc_emitter *em = &s->emitters[ei];
+    const orc_shape *sh = &s->shapes[em->shape];
+    uint32_t ti = cdf_sample(s->area_cdf[ei], sh->tri_count, sy);
+    sy = (sy - s->area_cdf[ei][ti]) / (s->area_cdf[ei][ti + 1] - s->area_cdf[ei][ti]);
+    uint32_t prim = sh->first_tri + ti;
+    uint32_t i0 = s->idx[prim * 3], i1 = s->idx[prim * 3 + 1], i2 = s->idx[prim * 3 + 2];
+    v3 p0 = vert(s, i0), p1 = vert(s, i1), p2 = vert(s, i2);
+    float bx, by; uniform_triangle(sx, sy, &bx, &by);
+    v3 sideA = sub(p1, p0), sideB = sub(p2, p0);
+    dr->p = add(add(p0, scale(sideA, bx)), scale(sideB, by));
+    if (s->nrm != NULL && !(sh->flags & 1u))
+        dr->n = normalize(add(add(scale(vnrm(s, i0), 1.0f - bx - by), scale(vnrm(s, i1), bx)), scale(vnrm(s, i2), by)));
+    else dr->n = normalize(cross(sideA, sideB));
+    dr->pdf = s->inv_area[ei];
+    dr->d = sub(dr->p, ref);
+    float distSquared = dot(dr->d, dr->d);
+    dr->dist = sqrtf(distSquared);
+    { float r = 1.0f / dr->dist; dr->d = scale(dr->d, r); }
+    float dp = fabsf(dot(dr->d, dr->n));
+    dr->pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    v3 value;
+    if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0 && dr->pdf != 0) {
+        float r = 1.0f / dr->pdf; value = V(em->radiance[0] * r, em->radiance[1] * r, em->radiance[2] * r);   /* Spectrum / Float */
+    } else { dr->pdf = 0.0f; value = V(0, 0, 0); }
+    if (dr->pdf != 0) {
+        if (test_visibility) {
+            if (shadow_rays) ++*shadow_rays;
+            if (ray_occluded(s, ref, dr->d, EPSILON, dr->dist * (1 - SHADOW_EPSILON))) return V(0, 0, 0);
+        }
+        dr->emitter = (int32_t) ei;
+        dr->pdf *= emPdf;
+        { float r = 1.0f / emPdf; value = scale(value, r); }     /* Spectrum /= Float */
+        return value;
+    }
+    return V(0, 0, 0);
+}
+/* Scene::pdfEmitterDirect (scene.cpp:981-984) -> AreaLight::pdfDirect (area.cpp:178-184) -> Shape::pdfDirect (shape.cpp:117-126);
+ * pdfEmitterDiscrete (include/mitsuba/render/scene.h:848-850) */
+static float pdf_emitter_direct(const orc_scene *s, const direct_t *dr, v3 refN) {
+    float pdf;
+    if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0)
+        pdf = s->inv_area[dr->emitter] * (dr->dist * dr->dist) / fabsf(dot(dr->d, dr->n));
+    else pdf = 0.0f;
+    return pdf * (s->emitters[dr->emitter].weight * s->emitter_norm);
+}
+void orc_sample_emitter_direct(const orc_scene *s, const float *rp, const float *rn, float u, float v, float *o) {
+    direct_t dr; memset(&dr, 0, sizeof(dr));
+    v3 refN = V(rn[0], rn[1], rn[2]);
+    v3 val = sample_emitter_direct(s, V(rp[0], rp[1], rp[2]), refN, u, v, &dr, 1, NULL);
+    o[0] = val.x; o[1] = val.y; o[2] = val.z; o[3] = dr.p.x; o[4] = dr.p.y; o[5] = dr.p.z; o[6] = dr.d.x; o[7] = dr.d.y; o[8] = dr.d.z;
+    o[9] = dr.dist; o[10] = dr.pdf; o[11] = is_zero(val) ? 0.0f : pdf_emitter_direct(s, &dr, refN);
+}
+
+/* ------------------------------------------------------------------------------------------------ the Li loop */
+static inline float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   /* path.cpp:296-300 */
+
+/* src/integrators/path/path.cpp:119-294 MIPathTracer::Li (no media, no subsurface) */
+static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters) {
+    const int maxDepth = s->d.max_depth, rrDepth = s->d.rr_depth;
+    const int strict = s->d.strict_normals != 0, hide = s->d.hide_emitters != 0;
+    hit_t its; v3 Li = V(0, 0, 0); int scattered = 0; int depth = 1;
+    int emitted_radiance = 1;                           /* rRec.type & EEmittedRadiance; cleared after the first bounce (path.cpp:274) */
+    ++counters[0];
+    ray_intersect(s, o, d, mint, maxt, &its, 0);        /* records.inl:117-145 */
+    v3 throughput = V(1, 1, 1); float eta = 1.0f;
+    while (depth <= maxDepth || maxDepth < 0) {
+        if (!its.valid) break;                           /* no environment emitter on this path yet */
+        const orc_material *bsdf = &s->materials[its.material];
+        if (its.emitter >= 0 && emitted_radiance && (!hide || scattered))
+            Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
+        if ((depth >= maxDepth && maxDepth > 0) || (strict && dot(d, its.ng) * its.wi.z >= 0)) break;
+
+        /* direct illumination sampling (path.cpp:172-200); every supported BSDF is ESmooth */
+        v3 refN = material_has_backside(bsdf) ? V(0, 0, 0) : its.ns;      /* records.inl:160-164 */
+        direct_t dRec; memset(&dRec, 0, sizeof(dRec));
+        {
+            float sx, sy; next2D(sp, &sx, &sy);
+            v3 value = sample_emitter_direct(s, its.p, refN, sx, sy, &dRec, 1, &counters[1]);
+            if (!is_zero(value)) {
+                v3 wo = to_local(&its, dRec.d);
+                v3 bsdfVal = bsdf_eval(bsdf, its.wi, wo);
+                if (!is_zero(bsdfVal) && (!strict || dot(its.ng, dRec.d) * wo.z > 0)) {
+                    float bsdfPdf = bsdf_pdf(bsdf, its.wi, wo);
+                    float weight = mi_weight(dRec.pdf, bsdfPdf);
+                    Li = add(Li, scale(mul(mul(throughput, value), bsdfVal), weight));
+                }
+            }
+        }
+        /* BSDF sampling (path.cpp:207-219) */
+        float bsdfPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
+        float sx, sy; next2D(sp, &sx, &sy);
+        v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta);
+        if (is_zero(bsdfWeight)) break;
+        scattered = 1;
+        v3 wo = to_world(&its, woL);
+        float woDotGeoN = dot(its.ng, wo);
+        if (strict && woDotGeoN * woL.z <= 0) break;
+
+        int hitEmitter = 0; v3 value = V(0, 0, 0);
+        o = its.p; d = wo;
+        ++counters[0];
+        if (ray_intersect(s, o, d, EPSILON, INFINITY, &its, 0)) {      /* path.cpp:225-233 */
+            if (its.emitter >= 0) {
+                value = emitter_eval(s, its.emitter, its.ns, neg(d));
+                dRec.p = its.p; dRec.n = its.ns; dRec.d = d; dRec.dist = its.t; dRec.emitter = its.emitter;   /* records.inl:181-189 setQuery */
+                hitEmitter = 1;
+            }
+        } else break;                                    /* path.cpp:234-248 without an environment emitter */
+
+        throughput = mul(throughput, bsdfWeight); eta *= bEta;
+        if (hitEmitter) {                                /* path.cpp:257-264 */
+            float lumPdf = pdf_emitter_direct(s, &dRec, refN);
+            Li = add(Li, scale(mul(throughput, value), mi_weight(bsdfPdf, lumPdf)));
+        }
+        emitted_radiance = 0;                            /* rRec.type = ERadianceNoEmission */
+        if (depth++ >= rrDepth) {                        /* path.cpp:276-286 */
+            float q = minf(maxf(maxf(throughput.x, throughput.y), throughput.z) * eta * eta, 0.95f);
+            if (next1D(sp) >= q) break;
+            float r = 1.0f / q; throughput = scale(throughput, r);
+        }
+    }
+    counters[2] += (uint64_t) depth;
+    *out_depth = depth;
+    return Li;
+}
+
+/* one pixel sample: src/librender/integrator.cpp:171-186 (renderBlock body) */
+static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t sidx, float *pos, int *depth, uint64_t *counters, float *log, int *nlog) {
+    sampler_t sp; sampler_begin(&sp, s, px, py, sidx, log);
+    float jx, jy; next2D(&sp, &jx, &jy);
+    pos[0] = (float) (int32_t) px + jx; pos[1] = (float) (int32_t) py + jy;
+    v3 o, d; float mint, maxt; camera_ray(s, pos[0], pos[1], &o, &d, &mint, &maxt);
+    v3 li = path_li(s, o, d, mint, maxt, &sp, depth, counters);
+    if (nlog) *nlog = sp.nlog;
+    return li;
+}
+void orc_render_samples(const orc_scene *s, const uint32_t *pairs, uint64_t n, float *out_li, float *out_pos, int32_t *out_depth, int32_t *out_nvals, float *out_vals) {
+    uint64_t counters[3] = {0, 0, 0};
+    for (uint64_t i = 0; i < n; ++i) {
+        int depth = 0, nlog = 0; float pos[2];
+        if (out_vals) for (int k = 0; k < 64; ++k) out_vals[i * 64 + k] = -1.0f;
+        v3 li = pixel_sample(s, pairs[i * 3], pairs[i * 3 + 1], pairs[i * 3 + 2], pos, &depth, counters, out_vals ? &out_vals[i * 64] : NULL, &nlog);
+        out_li[i * 3] = li.x; out_li[i * 3 + 1] = li.y; out_li[i * 3 + 2] = li.z;
+        if (out_pos) { out_pos[i * 2] = pos[0]; out_pos[i * 2 + 1] = pos[1]; }
+        if (out_depth) out_depth[i] = depth;
+        if (out_nvals) out_nvals[i] = nlog;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ film */
+/* include/mitsuba/core/rfilter.h:76-77 evalDiscretized */
+float orc_filter_eval_discretized(const orc_scene *s, float x) {
+    int i = (int) fabsf(x * s->filter_scale); if (i > FILTER_RES) i = FILTER_RES; return s->filter_values[i];
+}
+void orc_filter_table(const orc_scene *s, float *o, float *radius, int *border) { memcpy(o, s->filter_values, sizeof(s->filter_values)); *radius = s->filter_radius; *border = s->border; }
+int orc_film_border(const orc_scene *s) { return s->border; }
+/* include/mitsuba/render/imageblock.h:161-221 ImageBlock::put for a film-sized block at offset 0, 5 channels (RGB, alpha, weight) */
+static void film_put(const orc_scene *s, float *film, float sxp, float syp, v3 value, float alpha) {
+    float vals[5] = {value.x, value.y, value.z, alpha, 1.0f};
+    for (int i = 0; i < 5; ++i) if (!isfinite(vals[i]) || vals[i] < 0) return;
+    const int W = (int) s->d.width + 2 * s->border, H = (int) s->d.height + 2 * s->border;
+    const float r = s->filter_radius;
+    float posx = sxp - 0.5f - (float) (0 - s->border), posy = syp - 0.5f - (float) (0 - s->border);
+    int minx = (int) ceilf(posx - r), miny = (int) ceilf(posy - r), maxx = (int) floorf(posx + r), maxy = (int) floorf(posy + r);
+    if (minx < 0) minx = 0;
+    if (miny < 0) miny = 0;
+    if (maxx > W - 1) maxx = W - 1;
+    if (maxy > H - 1) maxy = H - 1;
+    for (int y = miny; y <= maxy; ++y) {
+        float wy = orc_filter_eval_discretized(s, (float) y - posy);
+        for (int x = minx; x <= maxx; ++x) {
+            float w = orc_filter_eval_discretized(s, (float) x - posx) * wy;
+            float *dst = film + ((size_t) y * W + x) * 5;
+            for (int k = 0; k < 5; ++k) dst[k] += w * vals[k];
+        }
+    }
+}
+typedef struct { const orc_scene *s; uint32_t s0, s1, y0, y1; float *film; uint64_t counters[3]; int tid, nthreads; pthread_mutex_t *mtx; } job_t;
+static void *image_worker(void *arg) {
+    job_t *j = (job_t *) arg; const orc_scene *s = j->s;
+    /* each worker owns whole pixel rows; splats of neighbouring rows overlap only inside the filter footprint -> lock per put
+       for footprints > 1 pixel is avoided by giving every worker a private film that is summed at the end */
+    for (uint32_t y = j->y0 + (uint32_t) j->tid; y < j->y1; y += (uint32_t) j->nthreads)
+        for (uint32_t x = 0; x < s->d.width; ++x)
+            for (uint32_t k = j->s0; k < j->s1; ++k) {
+                float pos[2]; int depth;
+                v3 li = pixel_sample(s, x, y, k, pos, &depth, j->counters, NULL, NULL);
+                film_put(s, j->film, pos[0], pos[1], li, 1.0f);
+            }
+    return NULL;
+}
+void orc_render_image(const orc_scene *s, uint32_t s0, uint32_t s1, uint32_t y0, uint32_t y1, int n_threads, float *film, uint64_t *counters) {
+    size_t n = (size_t) (s->d.width + 2 * s->border) * (s->d.height + 2 * s->border) * 5;
+    if (n_threads < 1) n_threads = 1;
+    job_t *jobs = (job_t *) calloc((size_t) n_threads, sizeof(job_t)); pthread_t *th = (pthread_t *) calloc((size_t) n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t].s = s; jobs[t].s0 = s0; jobs[t].s1 = s1; jobs[t].y0 = y0; jobs[t].y1 = y1; jobs[t].tid = t; jobs[t].nthreads = n_threads;
+        jobs[t].film = t == 0 ? film : (float *) calloc(n, sizeof(float));
+        if (t > 0) pthread_create(&th[t], NULL, image_worker, &jobs[t]);
+    }
+    image_worker(&jobs[0]);
+    counters[0] = counters[1] = counters[2] = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        if (t > 0) { pthread_join(th[t], NULL); for (size_t i = 0; i < n; ++i) film[i] += jobs[t].film[i]; free(jobs[t].film); }
+        for (int c = 0; c < 3; ++c) counters[c] += jobs[t].counters[c];
+    }
+    free(jobs); free(th);
+}
+
+/* ------------------------------------------------------------------------------------------------ scene setup */
+static int build_bvh(orc_scene *s, uint32_t *tris, int first, int count, v3 *cent, v3 *tlo, v3 *thi) {
+    int id = s->n_nodes++; bvh_node *n = &s->nodes[id];
+    v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY), clo = lo, chi = hi;
+    for (int i = first; i < first + count; ++i) {
+        uint32_t t = tris[i];
+        lo = V(minf(lo.x, tlo[t].x), minf(lo.y, tlo[t].y), minf(lo.z, tlo[t].z)); hi = V(maxf(hi.x, thi[t].x), maxf(hi.y, thi[t].y), maxf(hi.z, thi[t].z));
+        clo = V(minf(clo.x, cent[t].x), minf(clo.y, cent[t].y), minf(clo.z, cent[t].z)); chi = V(maxf(chi.x, cent[t].x), maxf(chi.y, cent[t].y), maxf(chi.z, cent[t].z));
+    }
+    /* pad: the TriAccel test is not watertight w.r.t. the exact triangle, so boxes must only ever over-approximate */
+    v3 ext = sub(hi, lo); float pad = 1e-4f * maxf(maxf(ext.x, ext.y), ext.z) + 1e-4f * maxf(maxf(fabsf(lo.x) + fabsf(hi.x), fabsf(lo.y) + fabsf(hi.y)), fabsf(lo.z) + fabsf(hi.z)) + 1e-6f;
+    n->lo = V(lo.x - pad, lo.y - pad, lo.z - pad); n->hi = V(hi.x + pad, hi.y + pad, hi.z + pad);
+    if (count <= 4) { n->first = first; n->count = count; n->left = n->right = -1; return id; }
+    v3 ce = sub(chi, clo); int axis = ce.x > ce.y ? (ce.x > ce.z ? 0 : 2) : (ce.y > ce.z ? 1 : 2);
+    /* median split by sorting on the centroid coordinate (insertion sort is fine for test sizes; qsort for big ones) */
+    for (int i = first + 1; i < first + count; ++i) {
+        uint32_t t = tris[i]; float key = comp(cent[t], axis); int j = i - 1;
+        while (j >= first && comp(cent[tris[j]], axis) > key) { tris[j + 1] = tris[j]; --j; }
+        tris[j + 1] = t;
+    }
+    int half = count / 2;
+    n->count = 0; n->first = 0;
+    int l = build_bvh(s, tris, first, half, cent, tlo, thi);
+    int r = build_bvh(s, tris, first + half, count - half, cent, tlo, thi);
+    s->nodes[id].left = l; s->nodes[id].right = r;
+    return id;
+}
+static void *dup(const void *p, size_t n) { if (!p) return NULL; void *q = malloc(n ? n : 1); memcpy(q, p, n); return q; }
+
+orc_scene *orc_scene_create(const orc_scene_desc *d) {
+    orc_scene *s = (orc_scene *) calloc(1, sizeof(orc_scene));
+    s->d = *d;
+    s->pos = (float *) dup(d->pos, (size_t) d->n_verts * 12); s->nrm = (float *) dup(d->nrm, (size_t) d->n_verts * 12);
+    s->idx = (uint32_t *) dup(d->idx, (size_t) d->n_tris * 12);
+    s->shapes = (orc_shape *) dup(d->shapes, d->n_shapes * sizeof(orc_shape));
+    s->materials = (orc_material *) dup(d->materials, d->n_materials * sizeof(orc_material));
+    s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
+    s->tri_shape = (uint32_t *) calloc(d->n_tris, 4);
+    for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->tri_shape[s->shapes[i].first_tri + t] = i;
+    /* TriAccel table (skdtree.cpp:79-105) + scene box (union of mesh AABBs, enlarged as in gkdtree.h:1213-1220) */
+    s->accel = (triaccel *) calloc(d->n_tris, sizeof(triaccel));
+    v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY);
+    v3 *cent = (v3 *) calloc(d->n_tris, sizeof(v3)), *tlo = (v3 *) calloc(d->n_tris, sizeof(v3)), *thi = (v3 *) calloc(d->n_tris, sizeof(v3));
+    for (uint32_t t = 0; t < d->n_tris; ++t) {
+        v3 a = vert(s, s->idx[t * 3]), b = vert(s, s->idx[t * 3 + 1]), c = vert(s, s->idx[t * 3 + 2]);
+        triaccel_load(&s->accel[t], a, b, c);
+        tlo[t] = V(minf(minf(a.x, b.x), c.x), minf(minf(a.y, b.y), c.y), minf(minf(a.z, b.z), c.z));
+        thi[t] = V(maxf(maxf(a.x, b.x), c.x), maxf(maxf(a.y, b.y), c.y), maxf(maxf(a.z, b.z), c.z));
+        cent[t] = scale(add(tlo[t], thi[t]), 0.5f);
+    }
+    for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t v = 0; v < s->shapes[i].vert_count; ++v) {
+        v3 p = vert(s, s->shapes[i].first_vert + v);
+        lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
+    }
+    { const float eps = KD_AABB_EPSILON;
+      v3 e1 = sub(hi, lo); lo = sub(lo, V(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps));
+      v3 e2 = sub(hi, lo); hi = add(hi, V(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps)); }
+    s->aabb_lo = lo; s->aabb_hi = hi;
+    s->nodes = (bvh_node *) calloc(2 * (size_t) d->n_tris + 2, sizeof(bvh_node));
+    s->bvh_tris = (uint32_t *) calloc(d->n_tris + 1, 4);
+    for (uint32_t t = 0; t < d->n_tris; ++t) s->bvh_tris[t] = t;
+    s->n_nodes = 0; build_bvh(s, s->bvh_tris, 0, (int) d->n_tris, cent, tlo, thi);
+    free(cent); free(tlo); free(thi);
+    /* emitter selection PDF (scene.cpp:383-388; pmf.h:56-58 append, :103-116 normalize) */
+    uint32_t ne = d->n_emitters;
+    s->emitter_cdf = (float *) calloc(ne + 1, 4); s->area_cdf = (float **) calloc(ne ? ne : 1, sizeof(float *)); s->inv_area = (float *) calloc(ne ? ne : 1, 4);
+    for (uint32_t e = 0; e < ne; ++e) s->emitter_cdf[e + 1] = s->emitter_cdf[e] + s->emitters[e].weight;
+    if (ne) { float sum = s->emitter_cdf[ne]; s->emitter_norm = sum > 0 ? 1.0f / sum : 0.0f; for (uint32_t e = 1; e <= ne; ++e) s->emitter_cdf[e] *= s->emitter_norm; s->emitter_cdf[ne] = 1.0f; }
+    /* per-mesh area distribution (trimesh.cpp:389-402 prepareSamplingTable; triangle.cpp:61-67 surfaceArea) */
+    for (uint32_t e = 0; e < ne; ++e) {
+        const orc_shape *sh = &s->shapes[s->emitters[e].shape]; uint32_t nt = sh->tri_count;
+        float *cdf = (float *) calloc(nt + 1, 4);
+        for (uint32_t t = 0; t < nt; ++t) {
+            uint32_t prim = sh->first_tri + t;
+            v3 p0 = vert(s, s->idx[prim * 3]), p1 = vert(s, s->idx[prim * 3 + 1]), p2 = vert(s, s->idx[prim * 3 + 2]);
+            v3 c = cross(sub(p1, p0), sub(p2, p0));
+            cdf[t + 1] = cdf[t] + 0.5f * sqrtf(dot(c, c));
+        }
+        float sum = cdf[nt]; float norm = 1.0f / sum;
+        for (uint32_t t = 1; t <= nt; ++t) cdf[t] *= norm;
+        cdf[nt] = 1.0f;
+        s->area_cdf[e] = cdf; s->inv_area[e] = 1.0f / sum;
+    }
+    /* reconstruction filter table (src/libcore/rfilter.cpp:37-56; box.cpp:31-48; gaussian.cpp:30-57) */
+    {
+        float radius = d->filter == 0 ? d->filter_radius + 1e-5f : 4.0f * d->filter_stddev;
+        float alpha = -1.0f / (2.0f * d->filter_stddev * d->filter_stddev), bias = expf(alpha * radius * radius);
+        float sum = 0.0f;
+        for (int i = 0; i < FILTER_RES; ++i) {
+            float x = (radius * (float) i) / (float) FILTER_RES, v;
+            if (d->filter == 0) v = fabsf(x) <= radius ? 1.0f : 0.0f;
+            else v = maxf(0.0f, expf(alpha * x * x) - bias);
+            s->filter_values[i] = v; sum += v;
+        }
+        s->filter_values[FILTER_RES] = 0.0f;
+        s->filter_scale = (float) FILTER_RES / radius; s->filter_radius = radius;
+        s->border = (int) ceilf(radius - 0.5f);
+        sum *= 2 * radius / (float) FILTER_RES;
+        float norm = 1.0f / sum;
+        for (int i = 0; i < FILTER_RES; ++i) s->filter_values[i] *= norm;
+    }
+    /* Sobol film resolution (sobol.cpp:147-157 setFilmResolution, bucketed) */
+    { uint32_t r = d->width > d->height ? d->width : d->height, p = 1, l = 0; while (p < r) { p <<= 1; ++l; } s->resolution = (float) p; s->log_res = l; }
+    s->inv_res_x = 1.0f / (float) d->width; s->inv_res_y = 1.0f / (float) d->height;
+    return s;
+}
+void orc_scene_destroy(orc_scene *s) {
+    if (!s) return;
+    for (uint32_t e = 0; e < s->d.n_emitters; ++e) free(s->area_cdf[e]);
+    free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape);
+    free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->emitters); free(s);
+}
