@@ -1,0 +1,119 @@
+/* include/mi355pt.h -- C-ABI of libmi355pt.so: the MI355X (gfx950) wavefront path tracer behind the reference's
+ * Integrator / ResponsiveIntegrator boundary.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, every call returns an int status (0 = MI_OK) and leaves a
+ * message for mi_last_error().  No exceptions cross this boundary.  What each entry point replaces in the reference
+ * (paths relative to the reference tree) is cited next to it; the adapter plugin (mitsuba-im_amd/csrc/adapter_plugin.cpp,
+ * INTEGRATION.md) fills these calls from a live mitsuba::Scene.
+ */
+#ifndef MI355PT_H
+#define MI355PT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_INVALID 1     /* bad argument / call order            */
+#define MI_ERR_DEVICE 2      /* HIP error (message has the HIP text)  */
+#define MI_ERR_UNSUPPORTED 3 /* scene feature outside the hot path    */
+#define MI_CANCELLED 4       /* mi_render_cancel() was observed       */
+
+typedef struct mi_scene mi_scene;
+typedef struct mi_render mi_render;
+
+/* One mesh of the flattened scene = one mitsuba::TriMesh (include/mitsuba/render/trimesh.h:122-160). */
+typedef struct {
+    uint32_t first_tri, tri_count, first_vert, vert_count;
+    int32_t bsdf;        /* index into the material table (Shape::getBSDF, include/mitsuba/render/shape.h) */
+    int32_t emitter;     /* index into the emitter table or -1 (Shape::getEmitter)                          */
+    uint32_t flags;      /* bit0: face normals (TriMesh "faceNormals", src/librender/trimesh.cpp:70)        */
+    uint32_t pad;
+} mi_shape;
+
+#define MI_BSDF_DIFFUSE 0         /* src/bsdfs/diffuse.cpp                         */
+#define MI_BSDF_ROUGHCONDUCTOR 1  /* src/bsdfs/roughconductor.cpp + microfacet.h   */
+#define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
+#define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
+typedef struct {
+    uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx */
+    float alpha;
+    float reflectance[3], eta[3], k[3], specular[3];
+} mi_material;
+
+#define MI_EMITTER_AREA 0         /* src/emitters/area.cpp   */
+#define MI_EMITTER_ENVMAP 1       /* src/emitters/envmap.cpp */
+typedef struct { uint32_t type; int32_t shape; float radiance[3]; float weight; uint32_t pad[2]; } mi_emitter;
+
+/* Integrator + sampler parameters: MonteCarloIntegrator properties (src/librender/integrator.cpp:191-226),
+ * sampler properties (src/samplers/sobol.cpp:86-107; src/samplers/independent.cpp:51-60). */
+#define MI_SAMPLER_INDEPENDENT 0  /* build-defined counter-based stream, seedable */
+#define MI_SAMPLER_SOBOL 1
+typedef struct {
+    int32_t max_depth, rr_depth;
+    uint32_t strict_normals, hide_emitters;
+    uint32_t sampler, spp;
+    uint64_t seed;               /* independent: seed; sobol: scramble (must be 0) */
+    uint32_t device;             /* HIP device ordinal */
+    uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
+} mi_render_params;
+
+typedef struct { uint32_t x0, y0, x1, y1; } mi_tile;   /* pixel rectangle [x0,x1) x [y0,y1) in GLOBAL film coordinates */
+
+typedef struct {
+    uint64_t rays, shadow_rays, path_length_sum, samples;  /* = reference StatsCounters "Normal rays traced", "Shadow rays traced",
+                                                              avgPathLength (src/librender/skdtree.cpp:46-47, src/integrators/path/path.cpp:24) */
+    double render_ms;                                      /* device time of the last mi_render_run (HIP events) */
+    double extend_ms, shade_ms, shadow_ms, other_ms;       /* per-stage device time of the last run (0 unless profiling enabled) */
+    uint64_t extend_launches, extend_rays;                 /* launches / rays of the dominant kernel in the last run */
+} mi_stats;
+
+const char *mi_last_error(void);
+
+/* Sobol' tables (data): matrices32[dims][52], vdc[16][52], vdc_inv[16][52] (the tables of src/samplers/sobolseq.cpp:33,106537,107241).
+ * Must be called once before a Sobol render; mitsuba-im_amd loads them from mitsuba-im_amd/data/sobol_tables.bin. */
+int mi_set_sobol_tables(const uint32_t *matrices32, uint32_t dims, const uint64_t *vdc, const uint64_t *vdc_inv);
+
+/* -- scene: replaces Scene::initialize -> ShapeKDTree::build (src/librender/scene.cpp:330-392, src/librender/skdtree.cpp:68-105) -- */
+int mi_scene_create(mi_scene **out);
+void mi_scene_destroy(mi_scene *s);
+/* TriMesh::getVertexPositions/getVertexNormals/getVertexTexcoords/getTriangles of all meshes, concatenated; nrm/uv may be NULL */
+int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, const float *uv, const uint32_t *idx,
+                           uint32_t n_verts, uint32_t n_tris, const mi_shape *shapes, uint32_t n_shapes);
+int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
+int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
+int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);
+/* PerspectiveCameraImpl: m_sampleToCamera, world transform, clip planes (src/sensors/perspective.cpp:126-178) */
+int mi_scene_set_camera(mi_scene *s, const float *sample_to_camera16, const float *to_world16, float near_clip, float far_clip);
+/* Film crop size + reconstruction filter (src/librender/film.cpp:92; src/rfilters/box.cpp, gaussian.cpp): kind 0 box(radius), 1 gaussian(stddev) */
+int mi_scene_set_film(mi_scene *s, uint32_t width, uint32_t height, uint32_t filter_kind, float radius, float stddev);
+int mi_scene_commit(mi_scene *s, uint32_t device);   /* BVH build + TriAccel table + upload */
+
+/* -- render: replaces SamplingIntegrator::renderBlock / ImageOrderIntegrator::render over MIPathTracer::Li
+ *    (src/librender/integrator.cpp:141-189, :336-402, :469-486; src/integrators/path/path.cpp:119-294) -- */
+int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out);
+void mi_render_destroy(mi_render *r);
+/* Trace sample planes [sample_begin, sample_end) of every pixel of `tile` and accumulate them into the device film
+ * (ImageBlock::put, include/mitsuba/render/imageblock.h:161-221).  One caller per handle. */
+int mi_render_run(mi_render *r, mi_tile tile, uint32_t sample_begin, uint32_t sample_end);
+int mi_render_clear(mi_render *r);                  /* ImageBlock::clear */
+void mi_render_cancel(mi_render *r);                /* Integrator::cancel: thread-safe flag, observed between batches */
+/* Film read-back.  layout 0: raw ImageBlock sums (H+2b) x (W+2b) x 5 {R,G,B,alpha,weight} incl. border (classic, ESpectrumAlphaWeight);
+ * layout 1: (H+2b) x (W+2b) x 4 RGBA sums (responsive target, src/im-mts/scene.cpp:317-321); layout 2: H x W x 3 developed RGB = sum/weight. */
+int mi_render_film_size(mi_render *r, int layout, uint32_t *height, uint32_t *width, uint32_t *channels, uint32_t *border);
+int mi_render_read_film(mi_render *r, int layout, float *host_out);
+int mi_render_read_film_device(mi_render *r, int layout, void *device_out);   /* device pointer (e.g. a torch tensor) for the RCCL reduce */
+/* Debug / parity: Li of individual (px, py, sampleIndex) triples through the very same kernels; out_li[n*3] */
+int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *out_li);
+int mi_render_stats(mi_render *r, mi_stats *out);
+int mi_render_set_profiling(mi_render *r, int enabled);   /* per-stage HIP-event timing (serialises stages; off by default) */
+
+/* Unit-level device entry points used by the parity tests (each runs a small kernel over n items) */
+int mi_debug_intersect(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4);   /* t,u,v,prim (prim<0: miss) */
+int mi_debug_sobol(mi_scene *s, const uint32_t *px_py_k, uint64_t n, uint32_t ndims, uint64_t *out_index, float *out_values);
+int mi_debug_camera_rays(mi_scene *s, const float *sample_pos2, uint64_t n, float *out_rays8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

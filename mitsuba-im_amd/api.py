@@ -1,0 +1,227 @@
+"""ctypes binding of libmi355pt.so (C-ABI: include/mi355pt.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback on the product path."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
+SOBOL_PATH = os.path.join(_HERE, "data", "sobol_tables.bin")
+
+
+class MiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mi355pt error {code}: {msg}")
+        self.code = code
+
+
+class MiShape(C.Structure):
+    _fields_ = [("first_tri", C.c_uint32), ("tri_count", C.c_uint32), ("first_vert", C.c_uint32), ("vert_count", C.c_uint32),
+                ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class MiMaterial(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("flags", C.c_uint32), ("distr", C.c_uint32), ("alpha", C.c_float),
+                ("reflectance", C.c_float * 3), ("eta", C.c_float * 3), ("k", C.c_float * 3), ("specular", C.c_float * 3)]
+
+
+class MiEmitter(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("pad", C.c_uint32 * 2)]
+
+
+class MiRenderParams(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
+                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32)]
+
+
+class MiTile(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32)]
+
+
+class MiStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("path_length_sum", C.c_uint64), ("samples", C.c_uint64),
+                ("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double), ("other_ms", C.c_double),
+                ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64)]
+
+
+EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
+           "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_clear", "mi_render_cancel",
+           "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
+           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_sobol", "mi_debug_camera_rays"]
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+class Lib:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise MiError(-1, f"{path} is missing: build it with `make -C mitsuba-im_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(path)
+        self.L = L
+        L.mi_last_error.restype = C.c_char_p
+        vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+        L.mi_set_sobol_tables.argtypes = [vp, u32, vp, vp]
+        L.mi_scene_create.argtypes = [C.POINTER(vp)]
+        L.mi_scene_destroy.argtypes = [vp]; L.mi_scene_destroy.restype = None
+        L.mi_scene_set_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32]
+        L.mi_scene_set_materials.argtypes = [vp, vp, u32]
+        L.mi_scene_set_emitters.argtypes = [vp, vp, u32]
+        L.mi_scene_set_envmap.argtypes = [vp, vp, u32, u32, vp, f32]
+        L.mi_scene_set_camera.argtypes = [vp, vp, vp, f32, f32]
+        L.mi_scene_set_film.argtypes = [vp, u32, u32, u32, f32, f32]
+        L.mi_scene_commit.argtypes = [vp, u32]
+        L.mi_render_create.argtypes = [vp, C.POINTER(MiRenderParams), C.POINTER(vp)]
+        L.mi_render_destroy.argtypes = [vp]; L.mi_render_destroy.restype = None
+        L.mi_render_run.argtypes = [vp, MiTile, u32, u32]
+        L.mi_render_clear.argtypes = [vp]
+        L.mi_render_cancel.argtypes = [vp]; L.mi_render_cancel.restype = None
+        L.mi_render_film_size.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+        L.mi_render_read_film.argtypes = [vp, i32, vp]
+        L.mi_render_read_film_device.argtypes = [vp, i32, vp]
+        L.mi_render_samples.argtypes = [vp, vp, u64, vp]
+        L.mi_render_stats.argtypes = [vp, C.POINTER(MiStats)]
+        L.mi_render_set_profiling.argtypes = [vp, i32]
+        L.mi_debug_intersect.argtypes = [vp, vp, u64, i32, vp]
+        L.mi_debug_sobol.argtypes = [vp, vp, u64, u32, vp, vp]
+        L.mi_debug_camera_rays.argtypes = [vp, vp, u64, vp]
+
+    def check(self, rc):
+        if rc != 0:
+            raise MiError(rc, self.L.mi_last_error().decode())
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib()
+        load_sobol_tables(_LIB)
+    return _LIB
+
+
+def load_sobol_tables(L, path=SOBOL_PATH):
+    """mitsuba-im_amd/data/sobol_tables.bin: Sobol' direction matrices (first 128 dimensions) and the van-der-Corput
+    matrices for m = 1..16 -- numeric table DATA of the reference's sampler (src/samplers/sobolseq.cpp:33,106537,107241)."""
+    with open(path, "rb") as f:
+        assert f.read(8) == b"MISOBOL1"
+        dims, rows = struct.unpack("<2I", f.read(8))
+        m32 = np.frombuffer(f.read(dims * 52 * 4), dtype="<u4").copy()
+        vdc = np.frombuffer(f.read(rows * 52 * 8), dtype="<u8").copy()
+        vdci = np.frombuffer(f.read(rows * 52 * 8), dtype="<u8").copy()
+    L.check(L.L.mi_set_sobol_tables(m32.ctypes.data, dims, vdc.ctypes.data, vdci.ctypes.data))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class Scene:
+    """mi_scene handle filled from a flattened scene (mitsuba-im_amd/scenes.py)."""
+
+    def __init__(self, sc, device=0):
+        L = lib(); self.L = L; self.sc = sc
+        h = C.c_void_p(); L.check(L.L.mi_scene_create(C.byref(h))); self.h = h
+        shapes = (MiShape * len(sc.shapes))()
+        for i, s in enumerate(sc.shapes):
+            shapes[i] = MiShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, 0)
+        mats = (MiMaterial * len(sc.bsdfs))()
+        for i, b in enumerate(sc.bsdfs):
+            m = MiMaterial(b["type"], (b["twosided"] & 1) | ((b["sample_visible"] & 1) << 1), b["distr"], b["alpha"])
+            m.reflectance[:] = b["reflectance"]; m.eta[:] = b["eta"]; m.k[:] = b["k"]; m.specular[:] = b["specular"]
+            mats[i] = m
+        ems = (MiEmitter * max(1, len(sc.emitters)))()
+        for i, e in enumerate(sc.emitters):
+            em = MiEmitter(e["type"], e["shape"]); em.radiance[:] = e["radiance"]; em.weight = e["weight"]; ems[i] = em
+        L.check(L.L.mi_scene_set_triangles(h, _p(sc.pos), _p(sc.nrm), _p(sc.uv), _p(sc.idx), len(sc.pos), len(sc.idx), C.cast(shapes, C.c_void_p), len(sc.shapes)))
+        L.check(L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), len(sc.bsdfs)))
+        L.check(L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), len(sc.emitters)))
+        s2c = np.ascontiguousarray(sc.sample_to_camera, np.float32); c2w = np.ascontiguousarray(sc.cam_to_world, np.float32)
+        L.check(L.L.mi_scene_set_camera(h, _p(s2c), _p(c2w), sc.near, sc.far))
+        L.check(L.L.mi_scene_set_film(h, sc.width, sc.height, sc.filter, sc.filter_radius, sc.filter_stddev))
+        L.check(L.L.mi_scene_commit(h, device))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.L.mi_scene_destroy(self.h); self.h = None
+
+    def __del__(self):
+        self.close()
+
+    # unit-level device entry points
+    def intersect(self, rays8, any_hit=False):
+        rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8); out = np.zeros((len(rays8), 4), np.float32)
+        self.L.check(self.L.L.mi_debug_intersect(self.h, _p(rays8), len(rays8), int(any_hit), _p(out))); return out
+
+    def sobol(self, px_py_k, ndims):
+        a = np.ascontiguousarray(px_py_k, np.uint32).reshape(-1, 3); idx = np.zeros(len(a), np.uint64); vals = np.zeros((len(a), ndims), np.float32)
+        self.L.check(self.L.L.mi_debug_sobol(self.h, _p(a), len(a), ndims, _p(idx), _p(vals))); return idx, vals
+
+    def camera_rays(self, pos2):
+        a = np.ascontiguousarray(pos2, np.float32).reshape(-1, 2); out = np.zeros((len(a), 8), np.float32)
+        self.L.check(self.L.L.mi_debug_camera_rays(self.h, _p(a), len(a), _p(out))); return out
+
+
+class Render:
+    """mi_render handle: the integrator instance (MonteCarloIntegrator properties + sampler)."""
+
+    def __init__(self, scene, max_depth=None, rr_depth=None, sampler=None, spp=None, seed=None, device=0, planes_per_batch=0,
+                 strict_normals=None, hide_emitters=None):
+        sc = scene.sc; L = scene.L; self.L = L; self.scene = scene
+        p = MiRenderParams(sc.max_depth if max_depth is None else max_depth, sc.rr_depth if rr_depth is None else rr_depth,
+                           sc.strict_normals if strict_normals is None else int(strict_normals),
+                           sc.hide_emitters if hide_emitters is None else int(hide_emitters),
+                           sc.sampler if sampler is None else sampler, sc.spp if spp is None else spp,
+                           sc.seed if seed is None else seed, device, planes_per_batch)
+        self.params = p
+        h = C.c_void_p(); L.check(L.L.mi_render_create(scene.h, C.byref(p), C.byref(h))); self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.L.mi_render_destroy(self.h); self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, tile=None, s0=0, s1=None):
+        sc = self.scene.sc
+        t = MiTile(0, 0, sc.width, sc.height) if tile is None else MiTile(*tile)
+        self.L.check(self.L.L.mi_render_run(self.h, t, s0, self.params.spp if s1 is None else s1))
+
+    def clear(self):
+        self.L.check(self.L.L.mi_render_clear(self.h))
+
+    def cancel(self):
+        self.L.L.mi_render_cancel(self.h)
+
+    def set_profiling(self, on):
+        self.L.check(self.L.L.mi_render_set_profiling(self.h, int(on)))
+
+    def film_shape(self, layout=0):
+        h, w, c, b = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.check(self.L.L.mi_render_film_size(self.h, layout, C.byref(h), C.byref(w), C.byref(c), C.byref(b)))
+        return h.value, w.value, c.value, b.value
+
+    def read_film(self, layout=0):
+        h, w, c, _ = self.film_shape(layout); out = np.zeros((h, w, c), np.float32)
+        self.L.check(self.L.L.mi_render_read_film(self.h, layout, _p(out))); return out
+
+    def read_film_device(self, layout, device_ptr):
+        self.L.check(self.L.L.mi_render_read_film_device(self.h, layout, C.c_void_p(device_ptr)))
+
+    def samples(self, pairs):
+        a = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 3); out = np.zeros((len(a), 3), np.float32)
+        self.L.check(self.L.L.mi_render_samples(self.h, _p(a), len(a), _p(out))); return out
+
+    def stats(self):
+        s = MiStats(); self.L.check(self.L.L.mi_render_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in MiStats._fields_}

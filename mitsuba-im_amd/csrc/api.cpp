@@ -1,0 +1,398 @@
+// api.cpp -- C-ABI of libmi355pt.so (include/mi355pt.h): scene upload, wavefront batch scheduling, film read-back.
+// Host orchestration only; all arithmetic on the sample path lives in kernels.hip / pt_device.h.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "scene_host.h"
+#include "queues.h"
+
+extern "C" {
+void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
+void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
+void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
+void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
+void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, hipStream_t);
+void mi_launch_film_layout(const float *, float *, int, int, int, int, hipStream_t);
+void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float *, hipStream_t);
+void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, hipStream_t);
+void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
+void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
+}
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MI_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+static std::vector<uint32_t> g_sobolM32; static std::vector<uint64_t> g_sobolVdc, g_sobolVdcInv; static uint32_t g_sobolDims = 0;
+
+struct mi_scene { mi::SceneHost h; };
+
+struct mi_render {
+    mi_scene *scene = nullptr; mi_render_params p{}; RenderConst rc{};
+    Queues q{}; std::vector<void *> allocs; uint64_t poolPaths = 0; uint32_t grid = 0;
+    float *film = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr;
+    hipStream_t stream = nullptr; hipEvent_t evBegin = nullptr, evEnd = nullptr;
+    std::atomic<int> cancel{0};
+    bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
+    mi_stats stats{};
+    uint64_t samplesTotal = 0;
+};
+
+extern "C" {
+
+const char *mi_last_error(void) { return g_err.c_str(); }
+
+int mi_set_sobol_tables(const uint32_t *m32, uint32_t dims, const uint64_t *vdc, const uint64_t *vdcInv) {
+    if (!m32 || !vdc || !vdcInv || dims < 2) return fail(MI_ERR_INVALID, "mi_set_sobol_tables: null table or dims < 2");
+    g_sobolM32.assign(m32, m32 + (size_t) dims * MI_SOBOL_SIZE); g_sobolDims = dims;
+    g_sobolVdc.assign(vdc, vdc + 16 * MI_SOBOL_SIZE); g_sobolVdcInv.assign(vdcInv, vdcInv + 16 * MI_SOBOL_SIZE);
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+int mi_scene_create(mi_scene **out) { if (!out) return fail(MI_ERR_INVALID, "mi_scene_create: out is null"); *out = new mi_scene(); return MI_OK; }
+void mi_scene_destroy(mi_scene *s) { delete s; }
+
+int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, const float *uv, const uint32_t *idx,
+                           uint32_t nv, uint32_t nt, const mi_shape *shapes, uint32_t ns) {
+    if (!s || !pos || !idx || !shapes || !ns) return fail(MI_ERR_INVALID, "mi_scene_set_triangles: null argument");
+    for (uint32_t i = 0; i < ns; ++i) {
+        const mi_shape &sh = shapes[i];
+        if ((uint64_t) sh.first_tri + sh.tri_count > nt || (uint64_t) sh.first_vert + sh.vert_count > nv || sh.tri_count == 0)
+            return fail(MI_ERR_INVALID, "mi_scene_set_triangles: shape range outside the arrays (or an empty mesh)");
+    }
+    for (uint64_t i = 0; i < (uint64_t) nt * 3; ++i) if (idx[i] >= nv) return fail(MI_ERR_INVALID, "mi_scene_set_triangles: vertex index out of range");
+    if (uv) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_triangles: texture coordinates (UV tangents, textures) are outside the hot path of this round");
+    s->h.pos.assign(pos, pos + (size_t) nv * 3); s->h.idx.assign(idx, idx + (size_t) nt * 3);
+    if (nrm) s->h.nrm.assign(nrm, nrm + (size_t) nv * 3); else s->h.nrm.clear();
+    s->h.shapes.assign(shapes, shapes + ns); s->h.committed = false;
+    return MI_OK;
+}
+int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
+    if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
+    for (uint32_t i = 0; i < n; ++i) if (m[i].type != MI_BSDF_DIFFUSE) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: only `diffuse` (optionally `twosided`) is implemented so far");
+    s->h.materials.assign(m, m + n); s->h.committed = false; return MI_OK;
+}
+int mi_scene_set_emitters(mi_scene *s, const mi_emitter *e, uint32_t n) {
+    if (!s || (n && !e)) return fail(MI_ERR_INVALID, "mi_scene_set_emitters: null argument");
+    for (uint32_t i = 0; i < n; ++i) if (e[i].type != MI_EMITTER_AREA) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: only `area` emitters are implemented so far");
+    s->h.emitters.assign(e, e + n); s->h.committed = false; return MI_OK;
+}
+int mi_scene_set_envmap(mi_scene *, const float *, uint32_t, uint32_t, const float *, float) {
+    return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_envmap: environment emitter not implemented in this round (SURVEY.md §8 a10)");
+}
+int mi_scene_set_camera(mi_scene *s, const float *s2c, const float *c2w, float nearClip, float farClip) {
+    if (!s || !s2c || !c2w) return fail(MI_ERR_INVALID, "mi_scene_set_camera: null argument");
+    memcpy(s->h.s2c, s2c, 64); memcpy(s->h.c2w, c2w, 64); s->h.nearClip = nearClip; s->h.farClip = farClip; s->h.haveCamera = true; s->h.committed = false;
+    return MI_OK;
+}
+int mi_scene_set_film(mi_scene *s, uint32_t w, uint32_t h, uint32_t kind, float radius, float stddev) {
+    if (!s || !w || !h || kind > 1) return fail(MI_ERR_INVALID, "mi_scene_set_film: bad argument");
+    s->h.width = w; s->h.height = h; s->h.filterKind = kind; s->h.filterRadius = radius; s->h.filterStddev = stddev; s->h.haveFilm = true; s->h.committed = false;
+    return MI_OK;
+}
+
+}  // extern "C"
+
+namespace mi {
+template <typename T> static int up(void **dst, const std::vector<T> &v) {
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return 1;
+    if (!v.empty()) { e = hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) return 1; }
+    return 0;
+}
+void SceneHost::release() {
+    void **ps[] = {&dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv};
+    for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
+}
+int SceneHost::upload(int dev) {
+    release(); device = dev;
+    if (hipSetDevice(dev) != hipSuccess) return 1;
+    std::vector<MaterialD> mats(materials.size());
+    for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
+    std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
+    int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
+              up(&dEmitters, emittersD) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
+    if (bad) return 1;
+    d = DScene{};
+    if (g_sobolDims && logRes >= 1 && logRes <= 16) {
+        std::vector<uint64_t> vdc(g_sobolVdc.begin() + (logRes - 1) * MI_SOBOL_SIZE, g_sobolVdc.begin() + logRes * MI_SOBOL_SIZE);
+        std::vector<uint64_t> vdi(g_sobolVdcInv.begin() + (logRes - 1) * MI_SOBOL_SIZE, g_sobolVdcInv.begin() + logRes * MI_SOBOL_SIZE);
+        if (up(&dSobolM32, g_sobolM32) | up(&dSobolVdc, vdc) | up(&dSobolVdcInv, vdi)) return 1;
+        d.sobol_m32 = (const uint32_t *) dSobolM32; d.sobol_vdc = (const uint64_t *) dSobolVdc; d.sobol_vdc_inv = (const uint64_t *) dSobolVdcInv;
+        d.sobol_dims = g_sobolDims;
+    }
+    d.nodes = (const BvhNode *) dNodes; d.tris = (const TriAccelD *) dTris; d.shade = (const TriShade *) dShade; d.i2 = (const uint32_t *) dI2;
+    d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
+    d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
+    d.n_tris = (uint32_t) tris.size(); d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
+    d.emitter_norm = emitterNorm;
+    for (int i = 0; i < 3; ++i) { d.aabb_lo[i] = aabbLo[i]; d.aabb_hi[i] = aabbHi[i]; }
+    memcpy(d.s2c, s2c, 64); memcpy(d.c2w, c2w, 64);
+    d.near_clip = nearClip; d.far_clip = farClip; d.inv_res_x = 1.0f / (float) width; d.inv_res_y = 1.0f / (float) height;
+    d.width = width; d.height = height;
+    d.filter_radius = filterRadiusEff; d.filter_scale = filterScale; d.border = border;
+    d.log_res = logRes; d.resolution = resolution;
+    committed = true;
+    return 0;
+}
+static int bvhDepth(const std::vector<BvhNode> &nodes, int n) {
+    if (n < 0) return 0;
+    int a = bvhDepth(nodes, nodes[n].c0), b = bvhDepth(nodes, nodes[n].c1);
+    return 1 + (a > b ? a : b);
+}
+}  // namespace mi
+
+extern "C" {
+
+int mi_scene_commit(mi_scene *s, uint32_t device) {
+    if (!s) return fail(MI_ERR_INVALID, "mi_scene_commit: null scene");
+    if (s->h.idx.empty() || s->h.materials.empty() || !s->h.haveCamera || !s->h.haveFilm)
+        return fail(MI_ERR_INVALID, "mi_scene_commit: triangles, materials, camera and film must be set first");
+    for (const mi_shape &sh : s->h.shapes) {
+        if (sh.bsdf < 0 || (size_t) sh.bsdf >= s->h.materials.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: shape refers to a missing material");
+        if (sh.emitter >= (int32_t) s->h.emitters.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: shape refers to a missing emitter");
+        if (!(sh.flags & 1u) && s->h.nrm.empty()) return fail(MI_ERR_INVALID, "mi_scene_commit: smooth-shaded mesh without vertex normals (pass faceNormals or normals)");
+    }
+    for (const mi_emitter &e : s->h.emitters) if (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
+    if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
+    s->h.commitHost();
+    if (mi::bvhDepth(s->h.nodes, 0) > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
+    int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
+    if ((int) device >= devCount) return fail(MI_ERR_DEVICE, "mi_scene_commit: no such HIP device");
+    if (s->h.upload((int) device)) return fail(MI_ERR_DEVICE, std::string("mi_scene_commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ render
+static int allocQ(mi_render *r, void **p, size_t bytes) {
+    HIPCHK(hipMalloc(p, bytes)); r->allocs.push_back(*p); return MI_OK;
+}
+#define ALLOC(ptr, type, count) do { void *p_ = nullptr; int rc_ = allocQ(r, &p_, sizeof(type) * (size_t) (count)); if (rc_) return rc_; ptr = (type *) p_; } while (0)
+
+static int allocPool(mi_render *r, uint64_t paths) {
+    for (void *p : r->allocs) (void) hipFree(p);
+    r->allocs.clear();
+    const char *g = getenv("MI355PT_GRID");
+    uint32_t grid = g ? (uint32_t) atoi(g) : 1024u;
+    uint64_t minGrid = (paths + 255) / 256; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
+    uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 255) / 256 * 256;
+    r->grid = grid; r->q.cap = (uint32_t) cap; r->poolPaths = paths;
+    const uint64_t slots = cap * grid;
+    for (int b = 0; b < 2; ++b) {
+        ALLOC(r->q.rayO[b], float4, slots); ALLOC(r->q.rayD[b], float4, slots);
+        ALLOC(r->q.st0[b], uint4, slots); ALLOC(r->q.st1[b], float4, slots); ALLOC(r->q.st2[b], float, slots);
+        ALLOC(r->q.count[b], uint32_t, grid);
+    }
+    ALLOC(r->q.hit, float4, slots); ALLOC(r->q.shO, float4, slots); ALLOC(r->q.shD, float4, slots); ALLOC(r->q.shC, float4, slots);
+    ALLOC(r->q.acc, float4, slots); ALLOC(r->q.pos, float2, slots); ALLOC(r->q.shCount, uint32_t, grid);
+    ALLOC(r->q.counters, unsigned long long, 4);
+    HIPCHK(hipMemset(r->q.counters, 0, 32));
+    return MI_OK;
+}
+
+int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
+    if (!s || !p || !out) return fail(MI_ERR_INVALID, "mi_render_create: null argument");
+    if (!s->h.committed) return fail(MI_ERR_INVALID, "mi_render_create: scene not committed");
+    if (p->rr_depth <= 0) return fail(MI_ERR_INVALID, "'rrDepth' must be set to a value greater than zero!");                       // integrator.cpp:221-222
+    if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
+    if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
+    if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
+    if (p->sampler == MI_SAMPLER_SOBOL) {
+        if (!s->h.d.sobol_m32) return fail(MI_ERR_INVALID, "mi_render_create: Sobol tables not loaded before mi_scene_commit (mi_set_sobol_tables)");
+        if (p->seed != 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: Sobol scramble != 0 not implemented");
+        // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR) + the dim-4 skip (sobol.cpp:218-251 aborts beyond the table)
+        int depth = p->max_depth < 0 ? 250 : p->max_depth;
+        if (p->max_depth > 0 && (uint32_t) (3 + 5 * depth) > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "Lookup dimension exceeds the direction number table size! You may have to reduce the 'maxDepth' parameter of your integrator.");
+        if (p->max_depth < 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth = -1 with the Sobol sampler needs more dimensions than are loaded");
+    }
+    HIPCHK(hipSetDevice(s->h.device));
+    mi_render *r = new mi_render(); r->scene = s; r->p = *p;
+    r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters;
+    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u;
+    HIPCHK(hipStreamCreate(&r->stream)); HIPCHK(hipEventCreate(&r->evBegin)); HIPCHK(hipEventCreate(&r->evEnd));
+    const int W = (int) s->h.width + 2 * s->h.border, H = (int) s->h.height + 2 * s->h.border;
+    r->filmFloats = (size_t) W * H * 5;
+    HIPCHK(hipMalloc((void **) &r->film, r->filmFloats * 4)); HIPCHK(hipMemset(r->film, 0, r->filmFloats * 4));
+    HIPCHK(hipMalloc((void **) &r->layoutTmp, r->filmFloats * 4));
+    *out = r; return MI_OK;
+}
+void mi_render_destroy(mi_render *r) {
+    if (!r) return;
+    (void) hipSetDevice(r->scene->h.device);
+    for (void *p : r->allocs) (void) hipFree(p);
+    if (r->film) (void) hipFree(r->film);
+    if (r->layoutTmp) (void) hipFree(r->layoutTmp);
+    for (hipEvent_t e : r->evPool) (void) hipEventDestroy(e);
+    if (r->evBegin) (void) hipEventDestroy(r->evBegin);
+    if (r->evEnd) (void) hipEventDestroy(r->evEnd);
+    if (r->stream) (void) hipStreamDestroy(r->stream);
+    delete r;
+}
+int mi_render_clear(mi_render *r) {
+    if (!r) return fail(MI_ERR_INVALID, "mi_render_clear: null"); HIPCHK(hipSetDevice(r->scene->h.device));
+    HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream));
+    if (r->q.counters) HIPCHK(hipMemsetAsync(r->q.counters, 0, 32, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; return MI_OK;
+}
+void mi_render_cancel(mi_render *r) { if (r) r->cancel.store(1); }
+int mi_render_set_profiling(mi_render *r, int enabled) { if (!r) return fail(MI_ERR_INVALID, "null"); r->profiling = enabled != 0; return MI_OK; }
+
+static void mark(mi_render *r, int tag, size_t &used) {
+    if (!r->profiling) return;
+    if (used >= r->evPool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; r->evPool.push_back(e); r->evTag.push_back(0); }
+    (void) hipEventRecord(r->evPool[used], r->stream); r->evTag[used] = tag; ++used;
+}
+
+// trace one batch: paths = tile pixels x planes (or an explicit list), all bounces
+static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed) {
+    const DScene &sc = r->scene->h.d; hipStream_t st = r->stream;
+    (void) list;
+    mark(r, 0, evUsed);
+    mi_launch_generate(sc, r->rc, r->q, bd, r->grid, st);
+    int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
+    for (int depth = 1; depth <= maxDepth; ++depth) {
+        mark(r, 1, evUsed); mi_launch_extend(sc, r->q, buf, r->grid, st);
+        mark(r, 2, evUsed); mi_launch_shade(sc, r->rc, r->q, buf, r->grid, st);
+        if (depth < maxDepth) { mark(r, 3, evUsed); mi_launch_shadow(sc, r->q, r->grid, st); }
+        buf ^= 1;
+        if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
+            std::vector<uint32_t> cnt(r->grid);
+            HIPCHK(hipMemcpyAsync(cnt.data(), r->q.count[buf], r->grid * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+            uint64_t alive = 0; for (uint32_t c : cnt) alive += c;
+            if (!alive) break;
+        }
+    }
+    mark(r, 0, evUsed);
+    HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
+    if (!r) return fail(MI_ERR_INVALID, "mi_render_run: null");
+    const mi::SceneHost &h = r->scene->h;
+    if (tile.x1 <= tile.x0 || tile.y1 <= tile.y0 || tile.x1 > h.width || tile.y1 > h.height) return fail(MI_ERR_INVALID, "mi_render_run: tile outside the film");
+    if (s1 < s0 || s1 > r->p.spp) return fail(MI_ERR_INVALID, "mi_render_run: sample range outside [0, spp]");
+    if (r->p.sampler == MI_SAMPLER_INDEPENDENT && s1 > (1u << 24)) return fail(MI_ERR_INVALID, "mi_render_run: independent stream supports < 2^24 samples per pixel");
+    HIPCHK(hipSetDevice(h.device));
+    const uint32_t npix = (tile.x1 - tile.x0) * (tile.y1 - tile.y0);
+    uint32_t planes = r->p.planes_per_batch;
+    if (!planes) { const uint64_t target = 4u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }
+    if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
+    const uint64_t need = (uint64_t) npix * planes;
+    if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
+    if (need != r->poolPaths) { int rc = allocPool(r, need); if (rc) return rc; }
+    r->cancel.store(0);
+    size_t evUsed = 0;
+    HIPCHK(hipEventRecord(r->evBegin, r->stream));
+    for (uint32_t s = s0; s < s1; s += planes) {
+        if (r->cancel.load()) { HIPCHK(hipStreamSynchronize(r->stream)); return fail(MI_CANCELLED, "render cancelled"); }
+        BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr;
+        int rc = traceBatch(r, bd, nullptr, evUsed); if (rc) return rc;
+        mi_launch_film(h.d, r->q, bd, r->film, r->stream);
+        r->samplesTotal += bd.n_paths;
+    }
+    mark(r, 0, evUsed);
+    HIPCHK(hipEventRecord(r->evEnd, r->stream));
+    HIPCHK(hipStreamSynchronize(r->stream));
+    HIPCHK(hipGetLastError());
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, r->evBegin, r->evEnd)); r->stats.render_ms = ms;
+    r->stats.extend_ms = r->stats.shade_ms = r->stats.shadow_ms = r->stats.other_ms = 0; r->stats.extend_launches = 0;
+    if (r->profiling) {
+        for (size_t i = 0; i + 1 < evUsed; ++i) {
+            float t = 0; if (hipEventElapsedTime(&t, r->evPool[i], r->evPool[i + 1]) != hipSuccess) continue;
+            switch (r->evTag[i]) { case 1: r->stats.extend_ms += t; r->stats.extend_launches++; break; case 2: r->stats.shade_ms += t; break; case 3: r->stats.shadow_ms += t; break; default: r->stats.other_ms += t; }
+        }
+    }
+    return MI_OK;
+}
+
+int mi_render_stats(mi_render *r, mi_stats *out) {
+    if (!r || !out) return fail(MI_ERR_INVALID, "mi_render_stats: null");
+    HIPCHK(hipSetDevice(r->scene->h.device));
+    unsigned long long c[4] = {0, 0, 0, 0};
+    if (r->q.counters) HIPCHK(hipMemcpy(c, r->q.counters, 32, hipMemcpyDeviceToHost));
+    r->stats.rays = c[0]; r->stats.shadow_rays = c[1]; r->stats.path_length_sum = c[2]; r->stats.samples = r->samplesTotal; r->stats.extend_rays = c[0];
+    *out = r->stats; return MI_OK;
+}
+
+int mi_render_film_size(mi_render *r, int layout, uint32_t *height, uint32_t *width, uint32_t *channels, uint32_t *border) {
+    if (!r || layout < 0 || layout > 2) return fail(MI_ERR_INVALID, "mi_render_film_size: bad argument");
+    const mi::SceneHost &h = r->scene->h; const uint32_t b = (uint32_t) h.border;
+    if (height) *height = layout == 2 ? h.height : h.height + 2 * b;
+    if (width) *width = layout == 2 ? h.width : h.width + 2 * b;
+    if (channels) *channels = layout == 0 ? 5 : (layout == 1 ? 4 : 3);
+    if (border) *border = layout == 2 ? 0 : b;
+    return MI_OK;
+}
+static size_t layoutFloats(mi_render *r, int layout) { uint32_t hh, ww, cc, bb; mi_render_film_size(r, layout, &hh, &ww, &cc, &bb); return (size_t) hh * ww * cc; }
+int mi_render_read_film_device(mi_render *r, int layout, void *dev) {
+    if (!r || !dev || layout < 0 || layout > 2) return fail(MI_ERR_INVALID, "mi_render_read_film_device: bad argument");
+    const mi::SceneHost &h = r->scene->h; HIPCHK(hipSetDevice(h.device));
+    mi_launch_film_layout(r->film, (float *) dev, (int) h.width + 2 * h.border, (int) h.height + 2 * h.border, h.border, layout, r->stream);
+    HIPCHK(hipStreamSynchronize(r->stream)); HIPCHK(hipGetLastError());
+    return MI_OK;
+}
+int mi_render_read_film(mi_render *r, int layout, float *host) {
+    if (!r || !host) return fail(MI_ERR_INVALID, "mi_render_read_film: null");
+    int rc = mi_render_read_film_device(r, layout, r->layoutTmp); if (rc) return rc;
+    HIPCHK(hipMemcpy(host, r->layoutTmp, layoutFloats(r, layout) * 4, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *outLi) {
+    if (!r || !pairs || !outLi || !n) return fail(MI_ERR_INVALID, "mi_render_samples: null argument");
+    const mi::SceneHost &h = r->scene->h; HIPCHK(hipSetDevice(h.device));
+    for (uint64_t i = 0; i < n; ++i) if (pairs[i * 3] >= h.width || pairs[i * 3 + 1] >= h.height) return fail(MI_ERR_INVALID, "mi_render_samples: pixel outside the film");
+    if (n != r->poolPaths) { int rc = allocPool(r, n); if (rc) return rc; }
+    uint32_t *dList = nullptr; float *dOut = nullptr; uint32_t *dSlots = nullptr;
+    HIPCHK(hipMalloc((void **) &dList, n * 12)); HIPCHK(hipMalloc((void **) &dOut, n * 12)); HIPCHK(hipMalloc((void **) &dSlots, n * 4));
+    HIPCHK(hipMemcpy(dList, pairs, n * 12, hipMemcpyHostToDevice));
+    std::vector<uint32_t> slots(n); for (uint64_t i = 0; i < n; ++i) slots[i] = (uint32_t) i;
+    HIPCHK(hipMemcpy(dSlots, slots.data(), n * 4, hipMemcpyHostToDevice));
+    BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList;
+    size_t evUsed = 0; bool prof = r->profiling; r->profiling = false;
+    int rc = traceBatch(r, bd, dList, evUsed); r->profiling = prof;
+    if (!rc) { mi_launch_gather_samples(r->q, dSlots, n, dOut, r->stream); hipError_t e = hipStreamSynchronize(r->stream); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
+    if (!rc) { hipError_t e = hipMemcpy(outLi, dOut, n * 12, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
+    (void) hipFree(dList); (void) hipFree(dOut); (void) hipFree(dSlots);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ unit-level device entry points
+}  // extern "C"
+template <typename F> static int withBuffers(const void *in, size_t inBytes, void *out, size_t outBytes, F f) {
+    void *dIn = nullptr, *dOut = nullptr;
+    HIPCHK(hipMalloc(&dIn, inBytes)); HIPCHK(hipMalloc(&dOut, outBytes));
+    HIPCHK(hipMemcpy(dIn, in, inBytes, hipMemcpyHostToDevice));
+    f(dIn, dOut);
+    hipError_t e = hipDeviceSynchronize(); if (e == hipSuccess) e = hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost);
+    (void) hipFree(dIn); (void) hipFree(dOut);
+    if (e != hipSuccess) return fail(MI_ERR_DEVICE, hipGetErrorString(e));
+    return MI_OK;
+}
+extern "C" {
+int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) {
+    if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_intersect: bad argument");
+    HIPCHK(hipSetDevice(s->h.device));
+    return withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, nullptr); });
+}
+int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, uint64_t *outIdx, float *outVals) {
+    if (!s || !s->h.committed || !in || !outIdx || !outVals || !n || !s->h.d.sobol_m32 || ndims > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "mi_debug_sobol: bad argument");
+    HIPCHK(hipSetDevice(s->h.device));
+    void *dIdx = nullptr; HIPCHK(hipMalloc(&dIdx, n * 8));
+    int rc = withBuffers(in, n * 12, outVals, n * ndims * 4, [&](void *i, void *o) { mi_launch_debug_sobol(s->h.d, (const uint32_t *) i, n, ndims, (unsigned long long *) dIdx, (float *) o, nullptr); });
+    if (!rc) { hipError_t e = hipMemcpy(outIdx, dIdx, n * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
+    (void) hipFree(dIdx); return rc;
+}
+int mi_debug_camera_rays(mi_scene *s, const float *pos, uint64_t n, float *out) {
+    if (!s || !s->h.committed || !pos || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_camera_rays: bad argument");
+    HIPCHK(hipSetDevice(s->h.device));
+    return withBuffers(pos, n * 8, out, n * 32, [&](void *i, void *o) { mi_launch_debug_camera(s->h.d, (const float *) i, n, (float *) o, nullptr); });
+}
+
+}  // extern "C"

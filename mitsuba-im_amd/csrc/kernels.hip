@@ -1,0 +1,388 @@
+// kernels.hip -- gfx950 (MI355X) wavefront path tracer: the stage kernels.
+//
+// Replaces the per-sample loop SamplingIntegrator::renderBlock -> MIPathTracer::Li -> Scene::rayIntersect / BSDF / emitter /
+// sampler plugins (reference src/librender/integrator.cpp:141-189, src/integrators/path/path.cpp:119-294) by stages over
+// SoA queues in HBM:
+//     generate -> [ extend (closest hit) -> shade (MIS bookkeeping, RR, NEE sample, BSDF sample) -> shadow (any hit) ] x depth -> film
+// Work ownership: the path pool of a batch is cut into `gridDim.x` contiguous SEGMENTS; workgroup b owns segment b in every
+// stage (persistent ownership across launches).  Stream compaction therefore never leaves the workgroup: wave64 ballots +
+// one LDS exchange per 256-path chunk, no global atomics, fully coalesced queue reads/writes, and a workgroup re-reads what
+// it (= the same XCD's L2 under round-robin dispatch) wrote in the previous stage.
+#include <hip/hip_runtime.h>
+#include "pt_device.h"
+#include "queues.h"
+
+#define WG 256
+#define STACK_DEPTH 32   // >= BVH depth (scene_build.cpp caps it; mi_scene_commit refuses deeper trees)
+
+// ---------------------------------------------------------------------------------------------- BVH traversal
+// Conservative slab test against a (padded) child box; returns entry distance. NaN-free: zero direction components are
+// replaced by +-1e-30 before the reciprocal is taken.
+DEV bool slab(const float lo[3], const float hi[3], v3 o, v3 inv, float tmin, float tmax, float &tnear) {
+    float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = t0;
+    return t0 <= t1 * 1.0000005f + 1e-30f;
+}
+DEV float safeInv(float d) { float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; return 1.0f / a; }
+
+// Closest hit: minimum t, ties towards the lower original triangle index (order independent).  `stk`/`stkT` point at this
+// lane's column of the workgroup's LDS stack (stride WG).
+template <bool ANY>
+DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk,
+                  float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
+    v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
+    const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
+    const float4 *tris4 = reinterpret_cast<const float4 *>(sc.tris);
+    float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
+    int sp = 0; int cur = 0;
+    while (true) {
+        if (cur >= 0) {
+            float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
+            float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n1.x, n1.y, n1.z}, lo1[3] = {n2.x, n2.y, n2.z}, hi1[3] = {n3.x, n3.y, n3.z};
+            int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+            float t0, t1;
+            bool h0 = slab(lo0, hi0, o, inv, mint, best, t0), h1 = slab(lo1, hi1, o, inv, mint, best, t1);
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
+                stk[sp * WG] = farC; ++sp;
+                cur = nearC;
+                continue;
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t code = (uint32_t) ~cur; uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float4 a = tris4[(first + i) * 3 + 0], b = tris4[(first + i) * 3 + 1], c = tris4[(first + i) * 3 + 2];
+                TriAccelD ta; ta.k = __float_as_uint(a.x); ta.n_u = a.y; ta.n_v = a.z; ta.n_d = a.w;
+                ta.a_u = b.x; ta.a_v = b.y; ta.b_nu = b.z; ta.b_nv = b.w; ta.c_nu = c.x; ta.c_nv = c.y; ta.prim = __float_as_uint(c.z);
+                float u, v, t;
+                if (triIntersect(ta, o, d, mint, best, u, v, t)) {
+                    if (ANY) return true;
+                    if (!found || t < best || (t == best && ta.prim < bprim)) { best = t; bprim = ta.prim; bu = u; bv = v; found = true; }
+                }
+            }
+        }
+        // pop
+        if (sp == 0) break;
+        --sp; cur = stk[sp * WG];
+    }
+    bestT = best; bestPrim = bprim; bestU = bu; bestV = bv;
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------- generate
+// One camera sample per path: src/librender/integrator.cpp:166-181 (pixel offset + sensor ray), sampler set-up
+// src/samplers/sobol.cpp:171-216.  Path q of the batch = (plane q / npix, tile pixel q % npix).
+__global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queues q, BatchDesc bd) {
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint64_t segBase = (uint64_t) seg * q.cap;
+    uint64_t remaining = bd.n_paths > segBase ? bd.n_paths - segBase : 0;
+    const uint32_t n = remaining > q.cap ? q.cap : (uint32_t) remaining;
+    const uint32_t tw = bd.tile.x1 - bd.tile.x0;
+    for (uint32_t i = tid; i < n; i += WG) {
+        const uint64_t pid = segBase + i;
+        uint32_t plane = (uint32_t) (pid / bd.n_pix), pl = (uint32_t) (pid % bd.n_pix);
+        uint32_t px = bd.tile.x0 + pl % tw, py = bd.tile.y0 + pl / tw, sidx = bd.sample_begin + plane;
+        if (bd.list) { px = bd.list[pid * 3]; py = bd.list[pid * 3 + 1]; sidx = bd.list[pid * 3 + 2]; }
+        SamplerState ss; float jx, jy;
+        if (rc.sampler == 1) {
+            uint64_t idx = sc.log_res > 1 ? sobolLookUp(sc.sobol_vdc, sc.sobol_vdc_inv, sc.log_res, sidx, px, py) : (uint64_t) sidx;
+            ss.a = (uint32_t) idx; ss.b = (uint32_t) (idx >> 32); ss.dim = 0;
+            jx = sobolSample(sc.sobol_m32, idx, 0); jy = sobolSample(sc.sobol_m32, idx, 1); ss.dim = 2;
+            if (idx != (uint64_t) sidx) {      // sobol.cpp:239-245: rescale the first two dimensions to a pixel-relative offset
+                jx = jx * sc.resolution - (float) (int) px; jy = jy * sc.resolution - (float) (int) py;
+            }
+        } else {
+            ss.a = (py * sc.width + px) ^ rc.seed_mix; ss.b = sidx; ss.dim = 0;
+            next2D(ss, 0, nullptr, jx, jy);
+        }
+        float sx = (float) (int) px + jx, sy = (float) (int) py + jy;
+        v3 o, d; float mint, maxt; cameraRay(sc, sx, sy, o, d, mint, maxt);
+        const uint64_t slot = segBase + i;
+        q.rayO[0][slot] = make_float4(o.x, o.y, o.z, mint);
+        q.rayD[0][slot] = make_float4(d.x, d.y, d.z, maxt);
+        // packed: dim | depth << 8 | flags << 16   (flags bit0: facingRef of the previous vertex)
+        q.st0[0][slot] = make_uint4((uint32_t) pid, ss.a, ss.b, ss.dim | (1u << 8));
+        q.st1[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);      // throughput rgb, eta
+        q.st2[0][slot] = 0.0f;                                      // bsdfPdf of the segment that produced this ray
+        q.pos[pid] = make_float2(sx, sy);
+        q.acc[pid] = make_float4(0, 0, 0, 0);
+    }
+    if (tid == 0) q.count[0][seg] = n;
+}
+
+// ---------------------------------------------------------------------------------------------- extend
+// Scene::rayIntersect -> ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:112-142): closest hit (t, u, v, prim)
+__global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
+    __shared__ int s_stk[STACK_DEPTH * WG];
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = q.count[buf][seg];
+    const uint64_t segBase = (uint64_t) seg * q.cap;
+    for (uint32_t i = tid; i < n; i += WG) {
+        float4 ro = q.rayO[buf][segBase + i], rd = q.rayD[buf][segBase + i];
+        v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z);
+        float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
+        if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt))
+            hit = traverse<false>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+        q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
+    }
+    if (tid == 0 && n) atomicAdd(&q.counters[0], (unsigned long long) n);
+}
+
+// ---------------------------------------------------------------------------------------------- shade
+// One bounce of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for every live path of the segment:
+//   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
+//   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
+//   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
+__global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_wave[2][WG / 64];
+    __shared__ uint32_t s_base[2];
+    uint32_t *s_m32 = s_dyn;
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = q.count[buf][seg];
+    const uint64_t segBase = (uint64_t) seg * q.cap;
+    const int nb = buf ^ 1;
+    const uint32_t *m32 = sc.sobol_m32;
+    if (rc.sampler == 1) {   // stage the Sobol' direction matrices in LDS (one row of 52 words per dimension)
+        for (uint32_t i = tid; i < sc.sobol_dims * MI_SOBOL_SIZE; i += WG) s_m32[i] = sc.sobol_m32[i];
+        m32 = s_m32;
+    }
+    if (tid < 2) s_base[tid] = 0;
+    __syncthreads();
+    unsigned long long pathLen = 0, shadowRays = 0;
+    for (uint32_t base = 0; base < n; base += WG) {
+        const uint32_t i = base + tid;
+        bool alive = false, wantShadow = false;
+        float4 nrO, nrD, nS1, shO, shD, shC; uint4 nS0; float nS2 = 0;
+        if (i < n) {
+            const uint64_t slot = segBase + i;
+            float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
+            float prevPdf = q.st2[buf][slot];
+            const uint32_t pid = s0.x; SamplerState ss; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
+            int depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
+            v3 d = V(rd.x, rd.y, rd.z), T = V(s1.x, s1.y, s1.z); float eta = s1.w;
+            const uint32_t prim = __float_as_uint(hr.w);
+            v3 add = V(0, 0, 0); bool haveAdd = false;
+            do {
+                if (prim == 0xFFFFFFFFu) { pathLen += (unsigned) (depth > 1 ? depth - 1 : 1); break; }   // miss: path.cpp:136-143 / :246
+                Hit h; fillHit(sc, d, hr.x, prim, hr.y, hr.z, h);
+                if (depth > 1) {
+                    if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
+                        v3 value = emitterEval(sc, h.emitter, h.ns, -d);
+                        float lumPdf = pdfEmitterDirect(sc, h.emitter, d, h.ns, h.dist, facingRef);
+                        add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
+                    }
+                    const int prevDepth = depth - 1;                         // rRec.depth++ >= m_rrDepth (path.cpp:276)
+                    if (prevDepth >= rc.rr_depth) {
+                        float qq = minf(maxf(maxf(T.x, T.y), T.z) * eta * eta, 0.95f);
+                        if (next1D(ss, rc.sampler, m32) >= qq) { pathLen += (unsigned) depth; break; }
+                        float r = 1.0f / qq; T = T * r;
+                    }
+                }
+                if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
+                const MaterialD &bsdf = sc.materials[h.material];
+                if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
+                    add = T * emitterEval(sc, h.emitter, h.ns, -d); haveAdd = true;
+                }
+                if ((depth >= rc.max_depth && rc.max_depth > 0) || (rc.strict_normals && dot(d, h.ng) * h.wi.z >= 0)) { pathLen += (unsigned) depth; break; }
+                // emitter sampling (path.cpp:172-200)
+                v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;               // records.inl:160-164
+                {
+                    float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
+                    Direct dr; v3 value = sampleEmitterDirect(sc, h.p, refN, sx, sy, dr);
+                    if (dr.pdf != 0) {
+                        ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
+                        v3 wo = toLocal(h, dr.d);
+                        v3 bsdfVal = bsdfEval(bsdf, h.wi, wo);
+                        if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
+                            float bp = bsdfPdf(bsdf, h.wi, wo);
+                            float weight = miWeight(dr.pdf, bp);
+                            v3 c = ((T * value) * bsdfVal) * weight;
+                            wantShadow = true;
+                            shO = make_float4(h.p.x, h.p.y, h.p.z, dr.dist * (1 - MI_SHADOW_EPSILON));
+                            shD = make_float4(dr.d.x, dr.d.y, dr.d.z, __uint_as_float(pid));
+                            shC = make_float4(c.x, c.y, c.z, 0.0f);
+                        }
+                    }
+                }
+                // BSDF sampling (path.cpp:207-226)
+                float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
+                float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
+                v3 bw = bsdfSample(bsdf, h.wi, sx, sy, woL, bPdf, bEta);
+                if (isZero(bw)) { pathLen += (unsigned) depth; break; }
+                v3 wo = toWorld(h, woL);
+                if (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0) { pathLen += (unsigned) depth; break; }
+                T = T * bw; eta *= bEta;
+                alive = true;
+                nrO = make_float4(h.p.x, h.p.y, h.p.z, MI_EPSILON);
+                nrD = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                uint32_t fl = dot(wo, refN) >= 0 ? 1u : 0u;
+                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16));
+                nS1 = make_float4(T.x, T.y, T.z, eta); nS2 = bPdf;
+            } while (false);
+            if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
+        }
+        // wave64 ballots + one LDS exchange: order-preserving compaction inside the segment
+        const unsigned long long mA = __ballot(alive), mS = __ballot(wantShadow);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (lane == 0) { s_wave[0][wave] = (uint32_t) __popcll(mA); s_wave[1][wave] = (uint32_t) __popcll(mS); }
+        __syncthreads();
+        uint32_t offA = s_base[0], offS = s_base[1], totA = 0, totS = 0;
+#pragma unroll
+        for (int w = 0; w < WG / 64; ++w) { uint32_t a = s_wave[0][w], s = s_wave[1][w]; if (w < (int) wave) { offA += a; offS += s; } totA += a; totS += s; }
+        if (alive) {
+            const uint64_t o = segBase + offA + (uint32_t) __popcll(mA & lt);
+            q.rayO[nb][o] = nrO; q.rayD[nb][o] = nrD; q.st0[nb][o] = nS0; q.st1[nb][o] = nS1; q.st2[nb][o] = nS2;
+        }
+        if (wantShadow) {
+            const uint64_t o = segBase + offS + (uint32_t) __popcll(mS & lt);
+            q.shO[o] = shO; q.shD[o] = shD; q.shC[o] = shC;
+        }
+        __syncthreads();
+        if (tid == 0) { s_base[0] += totA; s_base[1] += totS; }
+        __syncthreads();
+    }
+    if (tid == 0) { q.count[nb][seg] = s_base[0]; q.shCount[seg] = s_base[1]; }
+    // counters: wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) { pathLen += __shfl_down(pathLen, off); shadowRays += __shfl_down(shadowRays, off); }
+    if (lane == 0) { if (pathLen) atomicAdd(&q.counters[2], pathLen); if (shadowRays) atomicAdd(&q.counters[1], shadowRays); }
+}
+
+// ---------------------------------------------------------------------------------------------- shadow
+// Visibility test of Scene::sampleEmitterDirect (src/librender/scene.cpp:871-875 -> skdtree.cpp:207-226, any hit) and the
+// deferred `Li += throughput * value * bsdfVal * weight` (path.cpp:196)
+__global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
+    __shared__ int s_stk[STACK_DEPTH * WG];
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = q.shCount[seg];
+    const uint64_t segBase = (uint64_t) seg * q.cap;
+    for (uint32_t i = tid; i < n; i += WG) {
+        float4 so = q.shO[segBase + i], sd = q.shD[segBase + i];
+        v3 o = V(so.x, so.y, so.z), d = V(sd.x, sd.y, sd.z);
+        float mint, maxt, t, u, v; uint32_t prim; bool occluded = false;
+        if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt))
+            occluded = traverse<true>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+        if (!occluded) {
+            float4 c = q.shC[segBase + i]; const uint32_t pid = __float_as_uint(sd.w);
+            float4 a = q.acc[pid]; a.x += c.x; a.y += c.y; a.z += c.z; q.acc[pid] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- film
+// ImageBlock::put (include/mitsuba/render/imageblock.h:161-221) of every sample of the batch, 5 channels (R,G,B,alpha,weight),
+// film planes are SoA.  One thread per tile pixel walks its planes in sample order; footprints that stay inside the own
+// pixel (box filter, all but ~4e-5 of the samples) are summed in registers and added once, spills use float atomics.
+__global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, float *film) {
+    const uint32_t pl = blockIdx.x * WG + threadIdx.x;
+    if (pl >= bd.n_pix) return;
+    const uint32_t tw = bd.tile.x1 - bd.tile.x0;
+    const int px = (int) (bd.tile.x0 + pl % tw), py = (int) (bd.tile.y0 + pl / tw);
+    const int W = (int) sc.width + 2 * sc.border, H = (int) sc.height + 2 * sc.border;
+    const size_t plane = (size_t) W * H;
+    const int ownX = px + sc.border, ownY = py + sc.border;
+    float own[5] = {0, 0, 0, 0, 0};
+    const float r = sc.filter_radius;
+    for (uint32_t s = 0; s < bd.n_planes; ++s) {
+        const uint64_t pid = (uint64_t) s * bd.n_pix + pl;
+        float4 li = q.acc[pid]; float2 sp = q.pos[pid];
+        float vals[5] = {li.x, li.y, li.z, 1.0f, 1.0f};
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) bad |= (!isfinite(vals[k]) || vals[k] < 0);
+        if (bad) continue;
+        float posx = sp.x - 0.5f - (float) (0 - sc.border), posy = sp.y - 0.5f - (float) (0 - sc.border);
+        int minx = (int) ceilf(posx - r), miny = (int) ceilf(posy - r), maxx = (int) floorf(posx + r), maxy = (int) floorf(posy + r);
+        minx = max(minx, 0); miny = max(miny, 0); maxx = min(maxx, W - 1); maxy = min(maxy, H - 1);
+        for (int y = miny; y <= maxy; ++y) {
+            float wy = filterEvalDiscretized(sc, (float) y - posy);
+            for (int x = minx; x <= maxx; ++x) {
+                float w = filterEvalDiscretized(sc, (float) x - posx) * wy;
+                if (x == ownX && y == ownY && sc.border <= 1) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) own[k] += w * vals[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) atomicAdd(&film[k * plane + (size_t) y * W + x], w * vals[k]);
+                }
+            }
+        }
+    }
+    if (sc.border <= 1) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) atomicAdd(&film[k * plane + (size_t) ownY * W + ownX], own[k]);
+    }
+}
+
+// film read-back helpers: SoA planes -> interleaved layouts of mi_render_read_film
+__global__ void k_film_layout(const float *film, float *out, int W, int H, int border, int layout) {
+    const size_t plane = (size_t) W * H;
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (layout == 0) { if (i < plane) for (int k = 0; k < 5; ++k) out[i * 5 + k] = film[k * plane + i]; }
+    else if (layout == 1) { if (i < plane) for (int k = 0; k < 4; ++k) out[i * 4 + k] = film[k * plane + i]; }
+    else {
+        const int w = W - 2 * border, h = H - 2 * border;
+        if (i < (size_t) w * h) {
+            const int x = (int) (i % w), y = (int) (i / w); const size_t src = (size_t) (y + border) * W + (x + border);
+            const float wgt = film[4 * plane + src], inv = wgt != 0 ? 1.0f / wgt : 0.0f;
+            for (int k = 0; k < 3; ++k) out[i * 3 + k] = film[k * plane + src] * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- parity / unit kernels
+__global__ void k_gather_samples(Queues q, const uint32_t *slots, uint64_t n, float *out) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float4 a = q.acc[slots[i]]; out[i * 3] = a.x; out[i * 3 + 1] = a.y; out[i * 3 + 2] = a.z; }
+}
+__global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *rays, uint64_t n, int anyHit, float *out) {
+    __shared__ int s_stk[STACK_DEPTH * WG];
+    const uint64_t i = (uint64_t) blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + i * 8;
+    v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
+    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
+    if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
+        if (anyHit) hit = traverse<true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
+        else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
+    }
+    out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
+}
+__global__ void k_debug_sobol(DScene sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *outIdx, float *outVals) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t idx = sc.log_res > 1 ? sobolLookUp(sc.sobol_vdc, sc.sobol_vdc_inv, sc.log_res, in[i * 3 + 2], in[i * 3], in[i * 3 + 1]) : in[i * 3 + 2];
+    outIdx[i] = idx;
+    for (uint32_t dmn = 0; dmn < ndims; ++dmn) outVals[i * ndims + dmn] = sobolSample(sc.sobol_m32, idx, dmn);
+}
+__global__ void k_debug_camera(DScene sc, const float *pos, uint64_t n, float *out) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v3 o, d; float mint, maxt; cameraRay(sc, pos[i * 2], pos[i * 2 + 1], o, d, mint, maxt);
+    float *r = out + i * 8; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = mint; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = maxt;
+}
+
+// ---------------------------------------------------------------------------------------------- launch wrappers (used by api.cpp)
+extern "C" {
+void mi_launch_generate(const DScene &sc, const RenderConst &rc, const Queues &q, const BatchDesc &bd, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(WG), 0, st, sc, rc, q, bd); }
+void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_extend, dim3(grid), dim3(WG), 0, st, sc, q, buf); }
+void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+    size_t lds = rc.sampler == 1 ? (size_t) sc.sobol_dims * MI_SOBOL_SIZE * 4 : 16;
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
+}
+void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(WG), 0, st, sc, q); }
+void mi_launch_film(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film); }
+void mi_launch_film_layout(const float *film, float *out, int W, int H, int border, int layout, hipStream_t st) {
+    size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, out, W, H, border, layout);
+}
+void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_gather_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, q, slots, n, out); }
+void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out); }
+void mi_launch_debug_sobol(const DScene &sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *oi, float *ov, hipStream_t st) { hipLaunchKernelGGL(k_debug_sobol, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, in, n, ndims, oi, ov); }
+void mi_launch_debug_camera(const DScene &sc, const float *pos, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_camera, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, pos, n, out); }
+}

@@ -1,0 +1,296 @@
+// pt_device.h -- device-side arithmetic of the path tracer (gfx950).  Each function names the reference code it
+// implements (paths relative to the reference tree).  Compiled with -ffp-contract=off and IEEE division / sqrt
+// (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt): together with the polynomial sin/cos below this makes
+// every radiance sample reproducible bit for bit against a strict-IEEE CPU evaluation of the same formulas
+// (DESIGN.md §"arithmetic contract"), which is what the parity tests check.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_types.h"
+
+#define DEV __device__ __forceinline__
+
+struct v3 { float x, y, z; };
+DEV v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEV v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEV v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+DEV v3 operator-(v3 a) { return V(-a.x, -a.y, -a.z); }
+DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV v3 cross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV v3 normalize(v3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }   // TVector3::operator/= : recip, then multiply
+DEV bool isZero(v3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+DEV float maxf(float a, float b) { return a > b ? a : b; }
+DEV float minf(float a, float b) { return a < b ? a : b; }
+DEV v3 ld3(const float *p) { return V(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------------------------------------- samplers
+// include/mitsuba/core/qmc.h:146-156 sampleTEA
+DEV uint64_t sampleTEA(uint32_t v0, uint32_t v1) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xC8013EA4u);
+        v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7E95761Eu);
+    }
+    return ((uint64_t) v1 << 32) + v0;
+}
+// src/libcore/random.cpp:626-634
+DEV float bitsToFloat(uint32_t b) { return __uint_as_float((b >> 9) | 0x3f800000u) - 1.0f; }
+
+// src/samplers/sobolseq.h:43-58 sampleSingle, scramble 0.  `m32` may point to LDS or global memory.
+DEV float sobolSample(const uint32_t *m32, uint64_t index, uint32_t dim) {
+    uint32_t result = 0;
+    for (uint32_t i = dim * MI_SOBOL_SIZE; index; index >>= 1, ++i)
+        if (index & 1) result ^= m32[i];
+    return minf((float) result * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
+}
+// src/samplers/sobolseq.h:99-131 look_up, scramble 0; vdc / vdcInv = row (m-1) of the tables
+DEV uint64_t sobolLookUp(const uint64_t *vdc, const uint64_t *vdcInv, uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
+    uint64_t index = (uint64_t) frame << (m << 1);
+    uint64_t delta = 0;
+    for (uint32_t c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= vdc[c];
+    uint64_t b = (((uint64_t) px << m) | py) ^ delta;
+    for (uint32_t c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= vdcInv[c];
+    return index;
+}
+
+// Sampler state carried by a path.  Sobol: src/samplers/sobol.cpp:204-251; independent: the build-defined TEA stream.
+struct SamplerState {
+    uint32_t a, b;      // sobol: index lo/hi; independent: v0 (pixel ^ seed mix), sample index
+    uint32_t dim;       // sobol: m_dimension; independent: call counter
+};
+DEV float next1D(SamplerState &s, uint32_t kind, const uint32_t *m32) {
+    if (kind == 1) return sobolSample(m32, ((uint64_t) s.b << 32) | s.a, s.dim++);
+    uint32_t v1 = (s.b << 8) | (s.dim++ & 0xFFu);
+    return bitsToFloat((uint32_t) sampleTEA(s.a, v1));
+}
+// `first` is true only for the pixel-offset request of a sample (dimension 0), see sobol.cpp:239-245
+DEV void next2D(SamplerState &s, uint32_t kind, const uint32_t *m32, float &x, float &y) {
+    if (kind == 1) {
+        if (s.dim + 1 >= 5 && s.dim < 5) s.dim = 5;                 // sobol.cpp:233-235 (m_arrayStartDim = m_arrayEndDim = 5)
+        uint64_t idx = ((uint64_t) s.b << 32) | s.a;
+        x = sobolSample(m32, idx, s.dim++); y = sobolSample(m32, idx, s.dim++);
+    } else {
+        uint32_t v1 = (s.b << 8) | (s.dim++ & 0xFFu);
+        uint64_t r = sampleTEA(s.a, v1);
+        x = bitsToFloat((uint32_t) r); y = bitsToFloat((uint32_t) (r >> 32));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- warps
+// sin/cos on [-pi/4, pi/4] by fixed polynomials (Cephes single-precision coefficients), evaluated without contraction
+DEV float sinp(float x) { float z = x * x; float y = -1.9515295891e-4f * z; y = y + 8.3321608736e-3f; y = y * z; y = y - 1.6666654611e-1f; y = y * z; y = y * x; return y + x; }
+DEV float cosp(float x) { float z = x * x; float y = 2.443315711809948e-5f * z; y = y - 1.388731625493765e-3f; y = y * z; y = y + 4.166664568298827e-2f; y = y * z; y = y * z; float h = 0.5f * z; y = y - h; return y + 1.0f; }
+// src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric (second branch through sin(pi/2-x) = cos x, cos(pi/2-x) = sin x)
+DEV void diskConcentric(float sx, float sy, float &ox, float &oy) {
+    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, sn, cs;
+    if (r1 == 0 && r2 == 0) { ox = 0; oy = 0; return; }
+    if (r1 * r1 > r2 * r2) { r = r1; float x = (MI_PI / 4.0f) * (r2 / r1); sn = sinp(x); cs = cosp(x); }
+    else { r = r2; float x = (r1 / r2) * (MI_PI / 4.0f); sn = cosp(x); cs = sinp(x); }
+    ox = r * cs; oy = r * sn;
+}
+// warp.cpp:43-52 squareToCosineHemisphere
+DEV v3 cosHemisphere(float sx, float sy) {
+    float px, py; diskConcentric(sx, sy, px, py);
+    float z = sqrtf(maxf(1.0f - px * px - py * py, 0.0f));
+    if (z == 0) z = 1e-10f;
+    return V(px, py, z);
+}
+// warp.cpp:76-79 squareToUniformTriangle
+DEV void uniformTriangle(float sx, float sy, float &bx, float &by) { float a = sqrtf(maxf(1.0f - sx, 0.0f)); bx = 1 - a; by = a * sy; }
+
+// ---------------------------------------------------------------------------------------------- camera
+// src/sensors/perspective.cpp:271-287 + include/mitsuba/core/transform.h:108-125
+DEV void cameraRay(const DScene &sc, float sx, float sy, v3 &o, v3 &d, float &mint, float &maxt) {
+    const float *m = sc.s2c;
+    float px = sx * sc.inv_res_x, py = sy * sc.inv_res_y, pz = 0.0f;
+    float x = m[0] * px + m[1] * py + m[2] * pz + m[3];
+    float y = m[4] * px + m[5] * py + m[6] * pz + m[7];
+    float z = m[8] * px + m[9] * py + m[10] * pz + m[11];
+    float w = m[12] * px + m[13] * py + m[14] * pz + m[15];
+    v3 nearP = V(x, y, z);
+    if (w != 1.0f) { float r = 1.0f / w; nearP = nearP * r; }
+    v3 dl = normalize(nearP);
+    float invZ = 1.0f / dl.z;
+    mint = sc.near_clip * invZ; maxt = sc.far_clip * invZ;
+    const float *c = sc.c2w;
+    o = V(c[3], c[7], c[11]);
+    d = V(c[0] * dl.x + c[1] * dl.y + c[2] * dl.z, c[4] * dl.x + c[5] * dl.y + c[6] * dl.z, c[8] * dl.x + c[9] * dl.y + c[10] * dl.z);
+}
+
+// ---------------------------------------------------------------------------------------------- ray / scene box
+// include/mitsuba/core/aabb.h:308-339 + src/librender/skdtree.cpp:112-142 (closest) / :207-226 (any hit): scene-box clip + adaptive epsilon
+DEV bool clipInterval(const DScene &sc, v3 o, v3 d, float rmint, float rmaxt, bool shadow, float &mint, float &maxt) {
+    float nt = -INFINITY, ft = INFINITY;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float origin = oo[i], minv = sc.aabb_lo[i], maxv = sc.aabb_hi[i], di = dd[i];
+        if (di == 0) { if (origin < minv || origin > maxv) return false; }
+        else {
+            float rcp = 1.0f / di;
+            float t1 = (minv - origin) * rcp, t2 = (maxv - origin) * rcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nt = maxf(t1, nt); ft = minf(t2, ft);
+            if (!(nt <= ft)) return false;
+        }
+    }
+    float rayMinT = rmint;
+    if (rayMinT == MI_EPSILON) {
+        float m = maxf(maxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+        if (!shadow) m = maxf(m, MI_EPSILON);
+        rayMinT *= m;
+    }
+    if (rayMinT > nt) nt = rayMinT;
+    if (rmaxt < ft) ft = rmaxt;
+    mint = nt; maxt = ft;
+    return ft > nt;
+}
+
+// include/mitsuba/render/triaccel.h:96-158 TriAccel::rayIntersect
+DEV bool triIntersect(const TriAccelD &ta, v3 o, v3 d, float mint, float maxt, float &u, float &v, float &t) {
+    float o_u, o_v, o_k, d_u, d_v, d_k;
+    if (ta.k == 0) { o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; }
+    else if (ta.k == 1) { o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; }
+    else if (ta.k == 2) { o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; }
+    else return false;
+    float tt = (ta.n_d - o_u * ta.n_u - o_v * ta.n_v - o_k) / (d_u * ta.n_u + d_v * ta.n_v + d_k);
+    if (tt < mint || tt > maxt) return false;
+    float hu = o_u + tt * d_u - ta.a_u, hv = o_v + tt * d_v - ta.a_v;
+    float uu = hv * ta.b_nu + hu * ta.b_nv, vv = hu * ta.c_nu + hv * ta.c_nv;
+    u = uu; v = vv; t = tt;
+    return uu >= 0 && vv >= 0 && uu + vv <= 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------- hit record
+struct Hit {
+    v3 p, ng, ns, s, t, wi; float dist; int material, emitter; uint32_t flags;
+};
+// include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610
+DEV void fillHit(const DScene &sc, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
+    const float4 *rec = reinterpret_cast<const float4 *>(&sc.shade[prim]);
+    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+    v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z), p2 = V(r2.x, r2.y, r2.z);
+    h.material = __float_as_int(r0.w); h.emitter = __float_as_int(r1.w); h.flags = __float_as_uint(r2.w);
+    float bx = 1 - u - v, by = u, bz = v;
+    h.dist = t;
+    h.p = (p0 * bx + p1 * by) + p2 * bz;
+    v3 fn = V(r3.x, r3.y, r3.z);
+    if (h.flags & 1u) {          // face normals: the precomputed face frame is the shading frame
+        h.ns = fn; h.ng = fn; h.s = V(r4.x, r4.y, r4.z); h.t = V(r5.x, r5.y, r5.z);
+    } else {
+        uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
+        v3 n = (ld3(sc.nrm + 3 * i0) * bx + ld3(sc.nrm + 3 * i1) * by) + ld3(sc.nrm + 3 * i2) * bz;
+        h.ns = normalize(n);
+        if (dot(fn, h.ns) < 0) fn = -fn;
+        h.ng = fn;
+        v3 dpdu = p1 - p0;
+        h.s = normalize(dpdu - h.ns * dot(h.ns, dpdu));
+        h.t = cross(h.ns, h.s);
+    }
+    v3 md = -d;
+    h.wi = V(dot(md, h.s), dot(md, h.t), dot(md, h.ns));
+}
+DEV v3 toWorld(const Hit &h, v3 w) { return (h.s * w.x + h.t * w.y) + h.ns * w.z; }
+DEV v3 toLocal(const Hit &h, v3 w) { return V(dot(w, h.s), dot(w, h.t), dot(w, h.ns)); }
+
+// ---------------------------------------------------------------------------------------------- BSDFs
+// src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side)
+DEV v3 bsdfEval(const MaterialD &m, v3 wi, v3 wo) {
+    if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    float f = MI_INV_PI * wo.z;
+    return V(m.reflectance[0] * f, m.reflectance[1] * f, m.reflectance[2] * f);
+}
+DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
+    if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    return MI_INV_PI * wo.z;
+}
+DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta) {
+    bool flipped = false;
+    if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; flipped = true; }
+    if (wi.z <= 0) return V(0, 0, 0);
+    wo = cosHemisphere(u, v); eta = 1.0f; pdf = MI_INV_PI * wo.z;
+    if (flipped) wo.z = -wo.z;
+    return V(m.reflectance[0], m.reflectance[1], m.reflectance[2]);
+}
+
+// ---------------------------------------------------------------------------------------------- emitters
+// include/mitsuba/core/pmf.h:124-137 DiscreteDistribution::sample
+DEV uint32_t cdfSample(const float *cdf, uint32_t n, float x) {
+    uint32_t lo = 0, hi = n + 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < x) lo = mid + 1; else hi = mid; }
+    uint32_t index = lo > 0 ? lo - 1 : 0; if (index > n - 1) index = n - 1;
+    while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
+    return index;
+}
+struct Direct { v3 p, n, d; float dist, pdf; int emitter; };
+// src/emitters/area.cpp:106-111
+DEV v3 emitterEval(const DScene &sc, int e, v3 ns, v3 d) {
+    if (dot(ns, d) <= 0) return V(0, 0, 0);
+    return ld3(sc.emitters[e].radiance);
+}
+// Scene::sampleEmitterDirect (src/librender/scene.cpp:860-884) without the visibility test (the shadow queue does it)
+// -> AreaLight::sampleDirect (src/emitters/area.cpp:160-176) -> Shape::sampleDirect (src/librender/shape.cpp:102-115)
+// -> TriMesh::samplePosition (src/librender/trimesh.cpp:413-425) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
+DEV v3 sampleEmitterDirect(const DScene &sc, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
+    uint32_t ei = cdfSample(sc.emitter_cdf, sc.n_emitters, sx);
+    float c0 = sc.emitter_cdf[ei], c1 = sc.emitter_cdf[ei + 1];
+    float emPdf = c1 - c0;
+    sx = (sx - c0) / (c1 - c0);
+    const EmitterD &em = sc.emitters[ei];
+    const float *acdf = sc.area_cdf + em.cdf_offset;
+    uint32_t ti = cdfSample(acdf, em.tri_count, sy);
+    float a0 = acdf[ti], a1 = acdf[ti + 1];
+    sy = (sy - a0) / (a1 - a0);
+    uint32_t prim = em.first_tri + ti;
+    const float4 *rec = reinterpret_cast<const float4 *>(&sc.shade[prim]);
+    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z), p2 = V(r2.x, r2.y, r2.z);
+    float bx, by; uniformTriangle(sx, sy, bx, by);
+    v3 sideA = p1 - p0, sideB = p2 - p0;
+    dr.p = (p0 + sideA * bx) + sideB * by;
+    if (__float_as_uint(r2.w) & 1u) dr.n = normalize(cross(sideA, sideB));
+    else {
+        float4 r4 = rec[4], r5 = rec[5];
+        uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
+        dr.n = normalize((ld3(sc.nrm + 3 * i0) * (1.0f - bx - by) + ld3(sc.nrm + 3 * i1) * bx) + ld3(sc.nrm + 3 * i2) * by);
+    }
+    dr.pdf = em.inv_area;
+    dr.d = dr.p - ref;
+    float distSquared = dot(dr.d, dr.d);
+    dr.dist = sqrtf(distSquared);
+    { float r = 1.0f / dr.dist; dr.d = dr.d * r; }
+    float dp = fabsf(dot(dr.d, dr.n));
+    dr.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    v3 value;
+    if (dot(dr.d, refN) >= 0 && dot(dr.d, dr.n) < 0 && dr.pdf != 0) {
+        float r = 1.0f / dr.pdf; value = V(em.radiance[0] * r, em.radiance[1] * r, em.radiance[2] * r);
+    } else { dr.pdf = 0.0f; value = V(0, 0, 0); }
+    if (dr.pdf != 0) {
+        dr.emitter = (int) ei;
+        dr.pdf *= emPdf;
+        float r = 1.0f / emPdf; value = value * r;
+        return value;
+    }
+    return V(0, 0, 0);
+}
+// Scene::pdfEmitterDirect (scene.cpp:981-984) -> AreaLight::pdfDirect (area.cpp:178-184) -> Shape::pdfDirect (shape.cpp:117-126);
+// `facingRef` = (dot(d, refN) >= 0) evaluated where refN was still known (the previous vertex)
+DEV float pdfEmitterDirect(const DScene &sc, int e, v3 d, v3 n, float dist, bool facingRef) {
+    float pdf;
+    if (facingRef && dot(d, n) < 0) pdf = sc.emitters[e].inv_area * (dist * dist) / fabsf(dot(d, n));
+    else pdf = 0.0f;
+    return pdf * (sc.emitters[e].weight * sc.emitter_norm);
+}
+DEV float miWeight(float a, float b) { a *= a; b *= b; return a / (a + b); }   // src/integrators/path/path.cpp:296-300
+
+// include/mitsuba/core/rfilter.h:76-77
+DEV float filterEvalDiscretized(const DScene &sc, float x) {
+    int i = (int) fabsf(x * sc.filter_scale); if (i > MI_FILTER_RES) i = MI_FILTER_RES; return sc.filter_values[i];
+}

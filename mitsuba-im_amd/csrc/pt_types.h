@@ -1,0 +1,72 @@
+// pt_types.h -- POD records shared by the host-side scene build and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#define MI_EPSILON 1e-4f                    // reference include/mitsuba/core/constants.h:28
+#define MI_SHADOW_EPSILON 1e-3f             // constants.h:29
+#define MI_INV_PI 0.31830988618379067154f   // constants.h:64
+#define MI_ONE_MINUS_EPS 0.999999940395355225f
+#define MI_PI 3.14159265358979323846f
+#define MI_FILTER_RES 31                    // include/mitsuba/core/rfilter.h:28
+#define MI_SOBOL_SIZE 52                    // src/samplers/sobolseq.h:31
+
+// Wald triangle record in BVH leaf order, 48 B = three 16-B loads (reference include/mitsuba/render/triaccel.h:37-52)
+struct TriAccelD {
+    uint32_t k; float n_u, n_v, n_d;
+    float a_u, a_v, b_nu, b_nv;
+    float c_nu, c_nv; uint32_t prim; uint32_t pad;
+};
+
+// BVH2 node, 64 B: both child boxes live in the parent, so one node fetch decides both descents.
+// child >= 0: inner node index; child < 0: leaf, ~child = first_tri * 8 + (count - 1), count <= 8.
+struct BvhNode {
+    float lo0[3]; int32_t c0;
+    float hi0[3]; int32_t c1;
+    float lo1[3]; int32_t pad0;
+    float hi1[3]; int32_t pad1;
+};
+
+// Per-triangle shading record in ORIGINAL triangle order, 96 B = six 16-B loads.
+// ng/s/t are the face frame (used as-is by face-normal meshes; recomputed at run time for smooth meshes).
+struct TriShade {
+    float p0[3]; int32_t material;
+    float p1[3]; int32_t emitter;
+    float p2[3]; uint32_t flags;          // bit0 face normals, bit1 material has a back side (twosided)
+    float ng[3]; uint32_t local_prim;
+    float s[3]; uint32_t i0;
+    float t[3]; uint32_t i1;              // i0,i1,i2: vertex indices for smooth normals (i2 in `i2` array)
+};
+
+struct MaterialD {                        // 64 B
+    uint32_t type, flags, distr; float alpha;
+    float reflectance[3], eta[3], k[3], specular[3];
+};
+
+struct EmitterD {                         // 48 B
+    float radiance[3]; float weight;
+    uint32_t first_tri, tri_count, cdf_offset; float inv_area;
+    uint32_t type; int32_t shape; uint32_t pad[2];
+};
+
+// Everything a kernel needs to know about the scene; passed by value.
+struct DScene {
+    const BvhNode *nodes; const TriAccelD *tris; const TriShade *shade; const uint32_t *i2; const float *nrm;
+    const MaterialD *materials; const EmitterD *emitters; const float *emitter_cdf; const float *area_cdf;
+    uint32_t n_tris, n_nodes, n_emitters, n_materials;
+    float emitter_norm;
+    float aabb_lo[3], aabb_hi[3];         // kd-tree root box of the reference incl. its enlargement (gkdtree.h:1213-1220)
+    float s2c[16], c2w[16];               // sampleToCamera, cameraToWorld
+    float near_clip, far_clip, inv_res_x, inv_res_y;
+    uint32_t width, height;
+    // film
+    const float *filter_values;           // [MI_FILTER_RES + 1], global memory (indexed per lane)
+    float filter_radius, filter_scale; int32_t border;
+    // sobol
+    const uint32_t *sobol_m32; const uint64_t *sobol_vdc, *sobol_vdc_inv;   // vdc rows for m = log_res only
+    uint32_t sobol_dims, log_res; float resolution;
+};
+
+struct RenderConst {
+    int32_t max_depth, rr_depth; uint32_t strict_normals, hide_emitters;
+    uint32_t sampler; uint32_t seed_mix;  // independent: seed * 0x9E3779B9
+};

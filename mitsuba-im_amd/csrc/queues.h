@@ -1,0 +1,25 @@
+// queues.h -- SoA wavefront queues in HBM (device pointers), shared by api.cpp and kernels.hip.
+// Layout per path slot (algorithmic bytes, DESIGN.md §"bytes per segment"):
+//   extension ray 32 B (rayO: o.xyz,mint | rayD: d.xyz,maxt), hit 16 B (t,u,v,prim), path state 36 B
+//   (st0: path id, sampler word a, sampler word b, dim|depth|flags; st1: throughput rgb, eta; st2: bsdfPdf),
+//   shadow record 48 B (shO: o.xyz,maxt | shD: d.xyz,path id | shC: contribution rgb), accumulator 16 B, film position 8 B.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mi355pt.h"
+
+struct Queues {
+    float4 *rayO[2], *rayD[2];
+    uint4 *st0[2]; float4 *st1[2]; float *st2[2];
+    float4 *hit;
+    float4 *shO, *shD, *shC;
+    float4 *acc; float2 *pos;
+    uint32_t *count[2]; uint32_t *shCount;      // per segment
+    unsigned long long *counters;               // [0] closest-hit rays, [1] shadow rays, [2] sum of path depths
+    uint32_t cap;                               // slots per segment (multiple of 256)
+};
+
+struct BatchDesc {
+    mi_tile tile; uint32_t n_pix; uint32_t n_planes; uint32_t sample_begin; uint64_t n_paths;
+    const uint32_t *list;   // optional explicit (px, py, sampleIndex) triples, one per path (parity entry point mi_render_samples)
+};

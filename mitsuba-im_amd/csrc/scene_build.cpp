@@ -1,0 +1,213 @@
+// scene_build.cpp -- host side of mi_scene_commit: Wald triangle table, per-triangle shading records, emitter CDFs,
+// reconstruction-filter table and a binned-SAH BVH2 laid out for the gfx950 traversal kernel.
+//
+// Replaces (reference): ShapeKDTree::build + TriAccel::load (src/librender/skdtree.cpp:68-105,
+// include/mitsuba/render/triaccel.h:61-94), Scene::initialize's emitter PDF (src/librender/scene.cpp:383-388),
+// TriMesh::prepareSamplingTable (src/librender/trimesh.cpp:389-402), ReconstructionFilter::configure
+// (src/libcore/rfilter.cpp:37-56).  The kd-tree itself is NOT reproduced: the contract is the nearest hit
+// (t, prim, u, v), not the tree layout.  Compiled with -ffp-contract=off: the values computed
+// here feed the bit-exact parity tests.
+#include "scene_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mi {
+
+struct V3 { float x, y, z; };
+static inline V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+static inline V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+static inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+static inline V3 normalize(V3 a) { float inv = 1.0f / std::sqrt(dot(a, a)); return a * inv; }
+static inline V3 vmin(V3 a, V3 b) { return mk(std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)); }
+static inline V3 vmax(V3 a, V3 b) { return mk(std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)); }
+
+// reference include/mitsuba/render/triaccel.h:61-94
+static void triaccelLoad(TriAccelD &ta, V3 A, V3 B, V3 C) {
+    static const int wald[4] = {1, 2, 0, 1};
+    V3 b = C - A, c = B - A, N = cross(c, b);
+    int k = 0;
+    for (int j = 0; j < 3; ++j) if (std::fabs(comp(N, j)) > std::fabs(comp(N, k))) k = j;
+    int u = wald[k], v = wald[k + 1];
+    float n_k = comp(N, k), denom = comp(b, u) * comp(c, v) - comp(b, v) * comp(c, u);
+    std::memset(&ta, 0, sizeof(ta));
+    if (denom == 0) { ta.k = 3; return; }
+    ta.k = (uint32_t) k;
+    ta.n_u = comp(N, u) / n_k; ta.n_v = comp(N, v) / n_k; ta.n_d = dot(A, N) / n_k;
+    ta.b_nu = comp(b, u) / denom; ta.b_nv = -comp(b, v) / denom;
+    ta.a_u = comp(A, u); ta.a_v = comp(A, v);
+    ta.c_nu = comp(c, v) / denom; ta.c_nv = -comp(c, u) / denom;
+}
+
+struct BuildNode { V3 lo, hi; int left = -1, right = -1, first = 0, count = 0; };
+struct Builder {
+    std::vector<BuildNode> nodes; std::vector<uint32_t> order; const std::vector<V3> *tlo, *thi, *cen;
+    int build(int first, int count, int depth) {
+        int id = (int) nodes.size(); nodes.emplace_back();
+        const float inf = std::numeric_limits<float>::infinity();
+        V3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf), clo = lo, chi = hi;
+        for (int i = first; i < first + count; ++i) { uint32_t t = order[i]; lo = vmin(lo, (*tlo)[t]); hi = vmax(hi, (*thi)[t]); clo = vmin(clo, (*cen)[t]); chi = vmax(chi, (*cen)[t]); }
+        nodes[id].lo = lo; nodes[id].hi = hi;
+        auto makeLeaf = [&]() { nodes[id].first = first; nodes[id].count = count; return id; };
+        if (count <= 2 || depth > 60) { if (count <= 8) return makeLeaf(); }
+        // binned SAH over the widest centroid axis, 16 bins
+        V3 ce = chi - clo; int axis = ce.x > ce.y ? (ce.x > ce.z ? 0 : 2) : (ce.y > ce.z ? 1 : 2);
+        float cmin = comp(clo, axis), cext = comp(ce, axis);
+        int mid = -1;
+        if (cext > 0) {
+            const int NB = 16; int cnt[NB] = {0}; V3 blo[NB], bhi[NB];
+            for (int b = 0; b < NB; ++b) { blo[b] = mk(inf, inf, inf); bhi[b] = mk(-inf, -inf, -inf); }
+            auto binOf = [&](uint32_t t) { int b = (int) ((comp((*cen)[t], axis) - cmin) / cext * NB); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };
+            for (int i = first; i < first + count; ++i) { uint32_t t = order[i]; int b = binOf(t); cnt[b]++; blo[b] = vmin(blo[b], (*tlo)[t]); bhi[b] = vmax(bhi[b], (*thi)[t]); }
+            auto area = [](V3 l, V3 h) { V3 e = h - l; return 2.0f * (e.x * e.y + e.y * e.z + e.z * e.x); };
+            float rightArea[NB]; int rightCnt[NB]; V3 rl = mk(inf, inf, inf), rh = mk(-inf, -inf, -inf); int rc = 0;
+            for (int b = NB - 1; b > 0; --b) { if (cnt[b]) { rl = vmin(rl, blo[b]); rh = vmax(rh, bhi[b]); } rc += cnt[b]; rightArea[b] = rc ? area(rl, rh) : 0; rightCnt[b] = rc; }
+            V3 ll = mk(inf, inf, inf), lh = mk(-inf, -inf, -inf); int lc = 0; float best = inf; int bestSplit = -1;
+            for (int b = 0; b < NB - 1; ++b) {
+                if (cnt[b]) { ll = vmin(ll, blo[b]); lh = vmax(lh, bhi[b]); } lc += cnt[b];
+                if (lc == 0 || rightCnt[b + 1] == 0) continue;
+                float cost = area(ll, lh) * lc + rightArea[b + 1] * rightCnt[b + 1];
+                if (cost < best) { best = cost; bestSplit = b; }
+            }
+            float leafCost = area(lo, hi) * count;
+            if (bestSplit >= 0 && (count > 4 ? true : best + area(lo, hi) * 1.0f < leafCost)) {
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) { return binOf(t) <= bestSplit; });
+                mid = (int) (it - order.begin());
+            } else if (count <= 8) return makeLeaf();
+        }
+        if (mid <= first || mid >= first + count) {   // degenerate: all centroids equal -> split in the middle
+            if (count <= 8) return makeLeaf();
+            mid = first + count / 2;
+        }
+        int l = build(first, mid - first, depth + 1);
+        int r = build(mid, first + count - mid, depth + 1);
+        nodes[id].left = l; nodes[id].right = r;
+        return id;
+    }
+};
+
+static inline int32_t leafCode(int first, int count) { return ~(int32_t) (first * 8 + (count - 1)); }
+
+void SceneHost::commitHost() {
+    const uint32_t nt = (uint32_t) (idx.size() / 3);
+    auto vert = [&](uint32_t i) { return mk(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]); };
+    triShape.assign(nt, 0);
+    for (uint32_t si = 0; si < shapes.size(); ++si) for (uint32_t t = 0; t < shapes[si].tri_count; ++t) triShape[shapes[si].first_tri + t] = si;
+
+    // --- triangle records
+    std::vector<TriAccelD> accel(nt); shade.assign(nt, TriShade{}); i2.assign(nt, 0);
+    std::vector<V3> tlo(nt), thi(nt), cen(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+        uint32_t a = idx[t * 3], b = idx[t * 3 + 1], c = idx[t * 3 + 2];
+        V3 p0 = vert(a), p1 = vert(b), p2 = vert(c);
+        triaccelLoad(accel[t], p0, p1, p2); accel[t].prim = t;
+        const mi_shape &sh = shapes[triShape[t]];
+        TriShade &ts = shade[t];
+        ts.p0[0] = p0.x; ts.p0[1] = p0.y; ts.p0[2] = p0.z; ts.p1[0] = p1.x; ts.p1[1] = p1.y; ts.p1[2] = p1.z; ts.p2[0] = p2.x; ts.p2[1] = p2.y; ts.p2[2] = p2.z;
+        ts.material = sh.bsdf; ts.emitter = sh.emitter;
+        bool faceN = (sh.flags & 1u) || nrm.empty();
+        bool backside = (materials[sh.bsdf].flags & MI_BSDF_FLAG_TWOSIDED) != 0;
+        ts.flags = (faceN ? 1u : 0u) | (backside ? 2u : 0u);
+        ts.local_prim = t - sh.first_tri; ts.i0 = a; ts.i1 = b; i2[t] = c;
+        // face frame: skdtree.h:367-371 (face normal), util.cpp:605-610 (computeShadingFrame with dpdu = p1 - p0)
+        V3 side1 = p1 - p0, side2 = p2 - p0, fn = cross(side1, side2);
+        float len = std::sqrt(dot(fn, fn));
+        if (!(fn.x == 0 && fn.y == 0 && fn.z == 0)) { float r = 1.0f / len; fn = fn * r; }
+        V3 s = normalize(side1 - fn * dot(fn, side1)), tt = cross(fn, s);
+        ts.ng[0] = fn.x; ts.ng[1] = fn.y; ts.ng[2] = fn.z; ts.s[0] = s.x; ts.s[1] = s.y; ts.s[2] = s.z; ts.t[0] = tt.x; ts.t[1] = tt.y; ts.t[2] = tt.z;
+        V3 lo = vmin(vmin(p0, p1), p2), hi = vmax(vmax(p0, p1), p2);
+        // conservative padding: the Wald test is evaluated in its own arithmetic, boxes may only over-approximate
+        V3 e = hi - lo; float mag = std::max(std::max(std::fabs(lo.x) + std::fabs(hi.x), std::fabs(lo.y) + std::fabs(hi.y)), std::fabs(lo.z) + std::fabs(hi.z));
+        float pad = 1e-4f * std::max(std::max(e.x, e.y), e.z) + 2e-5f * mag + 1e-7f;
+        tlo[t] = lo - mk(pad, pad, pad); thi[t] = hi + mk(pad, pad, pad); cen[t] = (lo + hi) * 0.5f;
+    }
+    // --- scene box = union of mesh AABBs, enlarged like the kd-tree root (gkdtree.h:1213-1220)
+    {
+        const float inf = std::numeric_limits<float>::infinity();
+        V3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf);
+        for (const mi_shape &sh : shapes) for (uint32_t v = 0; v < sh.vert_count; ++v) { V3 p = vert(sh.first_vert + v); lo = vmin(lo, p); hi = vmax(hi, p); }
+        const float eps = 1e-3f;
+        V3 e1 = hi - lo; lo = lo - mk(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps);
+        V3 e2 = hi - lo; hi = hi + mk(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps);
+        aabbLo[0] = lo.x; aabbLo[1] = lo.y; aabbLo[2] = lo.z; aabbHi[0] = hi.x; aabbHi[1] = hi.y; aabbHi[2] = hi.z;
+    }
+    // --- BVH
+    Builder bld; bld.order.resize(nt); for (uint32_t t = 0; t < nt; ++t) bld.order[t] = t;
+    bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.nodes.reserve(2 * nt + 2);
+    int root = nt ? bld.build(0, (int) nt, 0) : -1;
+    tris.resize(nt); for (uint32_t i = 0; i < nt; ++i) tris[i] = accel[bld.order[i]];
+    nodes.clear();
+    auto setBox = [](float *lo, float *hi, const BuildNode &n) { lo[0] = n.lo.x; lo[1] = n.lo.y; lo[2] = n.lo.z; hi[0] = n.hi.x; hi[1] = n.hi.y; hi[2] = n.hi.z; };
+    auto emptyBox = [](float *lo, float *hi) { for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::infinity(); hi[i] = -std::numeric_limits<float>::infinity(); } };
+    // inner build nodes -> device nodes (index map), leaves are encoded in their parent
+    std::vector<int> devIndex(bld.nodes.size(), -1); int nInner = 0;
+    for (size_t i = 0; i < bld.nodes.size(); ++i) if (bld.nodes[i].count == 0) devIndex[i] = nInner++;
+    auto childCode = [&](int c) { const BuildNode &n = bld.nodes[c]; return n.count > 0 ? leafCode(n.first, n.count) : (int32_t) devIndex[c]; };
+    if (root >= 0 && bld.nodes[root].count > 0) {      // the whole scene is one leaf: synthesise a root with one empty child
+        BvhNode n{}; setBox(n.lo0, n.hi0, bld.nodes[root]); n.c0 = leafCode(bld.nodes[root].first, bld.nodes[root].count);
+        emptyBox(n.lo1, n.hi1); n.c1 = leafCode(0, 1); nodes.push_back(n);
+    } else {
+        nodes.resize(std::max(nInner, 0));
+        for (size_t i = 0; i < bld.nodes.size(); ++i) {
+            const BuildNode &b = bld.nodes[i]; if (b.count > 0) continue;
+            BvhNode &n = nodes[devIndex[i]]; std::memset(&n, 0, sizeof(n));
+            setBox(n.lo0, n.hi0, bld.nodes[b.left]); setBox(n.lo1, n.hi1, bld.nodes[b.right]);
+            n.c0 = childCode(b.left); n.c1 = childCode(b.right);
+        }
+    }
+    if (nodes.empty()) { BvhNode n{}; emptyBox(n.lo0, n.hi0); emptyBox(n.lo1, n.hi1); n.c0 = n.c1 = leafCode(0, 1); nodes.push_back(n); }
+
+    // --- emitters (scene.cpp:383-388; pmf.h:56-58,103-116; trimesh.cpp:389-402; triangle.cpp:61-67)
+    const uint32_t ne = (uint32_t) emitters.size();
+    emitterCdf.assign(ne + 1, 0.0f); emittersD.assign(ne, EmitterD{}); areaCdf.clear(); emitterNorm = 0.0f;
+    for (uint32_t e = 0; e < ne; ++e) emitterCdf[e + 1] = emitterCdf[e] + emitters[e].weight;
+    if (ne) { float sum = emitterCdf[ne]; emitterNorm = sum > 0 ? 1.0f / sum : 0.0f; for (uint32_t e = 1; e <= ne; ++e) emitterCdf[e] *= emitterNorm; emitterCdf[ne] = 1.0f; }
+    for (uint32_t e = 0; e < ne; ++e) {
+        EmitterD &d = emittersD[e]; const mi_emitter &src = emitters[e];
+        d.radiance[0] = src.radiance[0]; d.radiance[1] = src.radiance[1]; d.radiance[2] = src.radiance[2]; d.weight = src.weight;
+        d.type = src.type; d.shape = src.shape;
+        if (src.type != MI_EMITTER_AREA) continue;
+        const mi_shape &sh = shapes[src.shape];
+        d.first_tri = sh.first_tri; d.tri_count = sh.tri_count; d.cdf_offset = (uint32_t) areaCdf.size();
+        size_t base = areaCdf.size(); areaCdf.resize(base + sh.tri_count + 1); areaCdf[base] = 0.0f;
+        for (uint32_t t = 0; t < sh.tri_count; ++t) {
+            uint32_t prim = sh.first_tri + t;
+            V3 p0 = vert(idx[prim * 3]), p1 = vert(idx[prim * 3 + 1]), p2 = vert(idx[prim * 3 + 2]);
+            V3 c = cross(p1 - p0, p2 - p0);
+            areaCdf[base + t + 1] = areaCdf[base + t] + 0.5f * std::sqrt(dot(c, c));
+        }
+        float sum = areaCdf[base + sh.tri_count], norm = 1.0f / sum;
+        for (uint32_t t = 1; t <= sh.tri_count; ++t) areaCdf[base + t] *= norm;
+        areaCdf[base + sh.tri_count] = 1.0f;
+        d.inv_area = 1.0f / sum;
+    }
+    if (areaCdf.empty()) areaCdf.push_back(0.0f);
+
+    // --- reconstruction filter table (rfilter.cpp:37-56; box.cpp:31-48; gaussian.cpp:30-57)
+    {
+        float radius = filterKind == 0 ? filterRadius + 1e-5f : 4.0f * filterStddev;
+        float alpha = -1.0f / (2.0f * filterStddev * filterStddev), bias = std::exp(alpha * radius * radius);
+        float sum = 0.0f;
+        for (int i = 0; i < MI_FILTER_RES; ++i) {
+            float x = (radius * (float) i) / (float) MI_FILTER_RES, v;
+            if (filterKind == 0) v = std::fabs(x) <= radius ? 1.0f : 0.0f;
+            else v = std::max(0.0f, std::exp(alpha * x * x) - bias);
+            filterValues[i] = v; sum += v;
+        }
+        filterValues[MI_FILTER_RES] = 0.0f;
+        filterScale = (float) MI_FILTER_RES / radius; filterRadiusEff = radius;
+        border = (int) std::ceil(radius - 0.5f);
+        sum *= 2 * radius / (float) MI_FILTER_RES;
+        float norm = 1.0f / sum;
+        for (int i = 0; i < MI_FILTER_RES; ++i) filterValues[i] *= norm;
+    }
+    // Sobol film resolution (src/samplers/sobol.cpp:147-157)
+    { uint32_t r = std::max(width, height), p = 1, l = 0; while (p < r) { p <<= 1; ++l; } resolution = (float) p; logRes = l; }
+}
+
+}  // namespace mi

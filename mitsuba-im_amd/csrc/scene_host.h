@@ -1,0 +1,35 @@
+// scene_host.h -- host-side scene object behind the mi_scene handle.
+#pragma once
+#include "../../include/mi355pt.h"
+#include "pt_types.h"
+#include <string>
+#include <vector>
+
+namespace mi {
+
+struct SceneHost {
+    // inputs (mi_scene_set_*)
+    std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx; std::vector<mi_shape> shapes;
+    std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
+    float s2c[16] = {0}, c2w[16] = {0}; float nearClip = 0, farClip = 0; bool haveCamera = false;
+    uint32_t width = 0, height = 0, filterKind = 0; float filterRadius = 0.5f, filterStddev = 0.5f; bool haveFilm = false;
+    std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16] = {0}, envScale = 1.0f;
+    // derived on the host (scene_build.cpp)
+    std::vector<uint32_t> triShape, i2; std::vector<TriAccelD> tris; std::vector<TriShade> shade; std::vector<BvhNode> nodes;
+    std::vector<EmitterD> emittersD; std::vector<float> emitterCdf, areaCdf; float emitterNorm = 0;
+    float aabbLo[3], aabbHi[3];
+    float filterValues[MI_FILTER_RES + 1]; float filterRadiusEff = 0, filterScale = 0; int border = 0;
+    float resolution = 1; uint32_t logRes = 0;
+    // device
+    bool committed = false; int device = 0;
+    void *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr, *dI2 = nullptr, *dNrm = nullptr, *dMaterials = nullptr, *dEmitters = nullptr,
+         *dEmitterCdf = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
+    DScene d{};
+
+    void commitHost();          // scene_build.cpp
+    int upload(int device);     // api.cpp
+    void release();
+    ~SceneHost() { release(); }
+};
+
+}  // namespace mi
