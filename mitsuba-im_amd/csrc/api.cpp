@@ -15,8 +15,8 @@ void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, con
 void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
-void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, hipStream_t);
-void mi_launch_film_layout(const float *, float *, int, int, int, int, hipStream_t);
+void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
+void mi_launch_film_layout(const float *, const float *, float *, int, int, int, int, hipStream_t);
 void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float *, hipStream_t);
 void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, hipStream_t);
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
@@ -34,7 +34,7 @@ struct mi_scene { mi::SceneHost h; };
 struct mi_render {
     mi_scene *scene = nullptr; mi_render_params p{}; RenderConst rc{};
     Queues q{}; std::vector<void *> allocs; uint64_t poolPaths = 0; uint32_t grid = 0;
-    float *film = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr;
+    float *film = nullptr, *spill = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr;   // film: own-pixel sums; spill: cross-pixel splats (atomics)
     hipStream_t stream = nullptr; hipEvent_t evBegin = nullptr, evEnd = nullptr;
     std::atomic<int> cancel{0};
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
@@ -119,9 +119,10 @@ int SceneHost::upload(int dev) {
               up(&dEmitters, emittersD) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
-    if (g_sobolDims && logRes >= 1 && logRes <= 16) {
-        std::vector<uint64_t> vdc(g_sobolVdc.begin() + (logRes - 1) * MI_SOBOL_SIZE, g_sobolVdc.begin() + logRes * MI_SOBOL_SIZE);
-        std::vector<uint64_t> vdi(g_sobolVdcInv.begin() + (logRes - 1) * MI_SOBOL_SIZE, g_sobolVdcInv.begin() + logRes * MI_SOBOL_SIZE);
+    if (g_sobolDims && logRes <= 16) {
+        const uint32_t row = logRes >= 1 ? logRes - 1 : 0;   // look_up is only used for logRes > 1 (sobol.cpp:209-215)
+        std::vector<uint64_t> vdc(g_sobolVdc.begin() + row * MI_SOBOL_SIZE, g_sobolVdc.begin() + (row + 1) * MI_SOBOL_SIZE);
+        std::vector<uint64_t> vdi(g_sobolVdcInv.begin() + row * MI_SOBOL_SIZE, g_sobolVdcInv.begin() + (row + 1) * MI_SOBOL_SIZE);
         if (up(&dSobolM32, g_sobolM32) | up(&dSobolVdc, vdc) | up(&dSobolVdcInv, vdi)) return 1;
         d.sobol_m32 = (const uint32_t *) dSobolM32; d.sobol_vdc = (const uint64_t *) dSobolVdc; d.sobol_vdc_inv = (const uint64_t *) dSobolVdcInv;
         d.sobol_dims = g_sobolDims;
@@ -218,6 +219,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     const int W = (int) s->h.width + 2 * s->h.border, H = (int) s->h.height + 2 * s->h.border;
     r->filmFloats = (size_t) W * H * 5;
     HIPCHK(hipMalloc((void **) &r->film, r->filmFloats * 4)); HIPCHK(hipMemset(r->film, 0, r->filmFloats * 4));
+    HIPCHK(hipMalloc((void **) &r->spill, r->filmFloats * 4)); HIPCHK(hipMemset(r->spill, 0, r->filmFloats * 4));
     HIPCHK(hipMalloc((void **) &r->layoutTmp, r->filmFloats * 4));
     *out = r; return MI_OK;
 }
@@ -226,6 +228,7 @@ void mi_render_destroy(mi_render *r) {
     (void) hipSetDevice(r->scene->h.device);
     for (void *p : r->allocs) (void) hipFree(p);
     if (r->film) (void) hipFree(r->film);
+    if (r->spill) (void) hipFree(r->spill);
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
     for (hipEvent_t e : r->evPool) (void) hipEventDestroy(e);
     if (r->evBegin) (void) hipEventDestroy(r->evBegin);
@@ -235,7 +238,7 @@ void mi_render_destroy(mi_render *r) {
 }
 int mi_render_clear(mi_render *r) {
     if (!r) return fail(MI_ERR_INVALID, "mi_render_clear: null"); HIPCHK(hipSetDevice(r->scene->h.device));
-    HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream));
+    HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream)); HIPCHK(hipMemsetAsync(r->spill, 0, r->filmFloats * 4, r->stream));
     if (r->q.counters) HIPCHK(hipMemsetAsync(r->q.counters, 0, 32, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; return MI_OK;
 }
@@ -293,7 +296,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
         if (r->cancel.load()) { HIPCHK(hipStreamSynchronize(r->stream)); return fail(MI_CANCELLED, "render cancelled"); }
         BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr;
         int rc = traceBatch(r, bd, nullptr, evUsed); if (rc) return rc;
-        mi_launch_film(h.d, r->q, bd, r->film, r->stream);
+        mi_launch_film(h.d, r->q, bd, r->film, r->spill, r->stream);
         r->samplesTotal += bd.n_paths;
     }
     mark(r, 0, evUsed);
@@ -333,7 +336,7 @@ static size_t layoutFloats(mi_render *r, int layout) { uint32_t hh, ww, cc, bb; 
 int mi_render_read_film_device(mi_render *r, int layout, void *dev) {
     if (!r || !dev || layout < 0 || layout > 2) return fail(MI_ERR_INVALID, "mi_render_read_film_device: bad argument");
     const mi::SceneHost &h = r->scene->h; HIPCHK(hipSetDevice(h.device));
-    mi_launch_film_layout(r->film, (float *) dev, (int) h.width + 2 * h.border, (int) h.height + 2 * h.border, h.border, layout, r->stream);
+    mi_launch_film_layout(r->film, r->spill, (float *) dev, (int) h.width + 2 * h.border, (int) h.height + 2 * h.border, h.border, layout, r->stream);
     HIPCHK(hipStreamSynchronize(r->stream)); HIPCHK(hipGetLastError());
     return MI_OK;
 }

@@ -277,9 +277,12 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
 
 // ---------------------------------------------------------------------------------------------- film
 // ImageBlock::put (include/mitsuba/render/imageblock.h:161-221) of every sample of the batch, 5 channels (R,G,B,alpha,weight),
-// film planes are SoA.  One thread per tile pixel walks its planes in sample order; footprints that stay inside the own
-// pixel (box filter, all but ~4e-5 of the samples) are summed in registers and added once, spills use float atomics.
-__global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, float *film) {
+// film planes are SoA.  One thread per tile pixel walks its planes in sample order.  The part of a footprint that lands on
+// the thread's own pixel is added to `film` with plain loads/stores, one sample after the other -- the same order of float
+// additions as the reference's per-pixel loop, independent of batch size and tiling.  Anything that spills into another pixel
+// (box filter: only samples within 1e-5 of a pixel edge; wider filters: most of the footprint) goes to the separate `spill`
+// planes with float atomics; read-back returns film + spill.
+__global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, float *film, float *spill) {
     const uint32_t pl = blockIdx.x * WG + threadIdx.x;
     if (pl >= bd.n_pix) return;
     const uint32_t tw = bd.tile.x1 - bd.tile.x0;
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, 
     const int W = (int) sc.width + 2 * sc.border, H = (int) sc.height + 2 * sc.border;
     const size_t plane = (size_t) W * H;
     const int ownX = px + sc.border, ownY = py + sc.border;
-    float own[5] = {0, 0, 0, 0, 0};
+    const size_t ownIdx = (size_t) ownY * W + ownX;
+    float own[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) own[k] = film[k * plane + ownIdx];
     const float r = sc.filter_radius;
     for (uint32_t s = 0; s < bd.n_planes; ++s) {
         const uint64_t pid = (uint64_t) s * bd.n_pix + pl;
@@ -304,34 +310,32 @@ __global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, 
             float wy = filterEvalDiscretized(sc, (float) y - posy);
             for (int x = minx; x <= maxx; ++x) {
                 float w = filterEvalDiscretized(sc, (float) x - posx) * wy;
-                if (x == ownX && y == ownY && sc.border <= 1) {
+                if (x == ownX && y == ownY) {
 #pragma unroll
                     for (int k = 0; k < 5; ++k) own[k] += w * vals[k];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) atomicAdd(&film[k * plane + (size_t) y * W + x], w * vals[k]);
+                    for (int k = 0; k < 5; ++k) atomicAdd(&spill[k * plane + (size_t) y * W + x], w * vals[k]);
                 }
             }
         }
     }
-    if (sc.border <= 1) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) atomicAdd(&film[k * plane + (size_t) ownY * W + ownX], own[k]);
-    }
+    for (int k = 0; k < 5; ++k) film[k * plane + ownIdx] = own[k];
 }
 
 // film read-back helpers: SoA planes -> interleaved layouts of mi_render_read_film
-__global__ void k_film_layout(const float *film, float *out, int W, int H, int border, int layout) {
+__global__ void k_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout) {
     const size_t plane = (size_t) W * H;
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (layout == 0) { if (i < plane) for (int k = 0; k < 5; ++k) out[i * 5 + k] = film[k * plane + i]; }
-    else if (layout == 1) { if (i < plane) for (int k = 0; k < 4; ++k) out[i * 4 + k] = film[k * plane + i]; }
+    if (layout == 0) { if (i < plane) for (int k = 0; k < 5; ++k) out[i * 5 + k] = film[k * plane + i] + spill[k * plane + i]; }
+    else if (layout == 1) { if (i < plane) for (int k = 0; k < 4; ++k) out[i * 4 + k] = film[k * plane + i] + spill[k * plane + i]; }
     else {
         const int w = W - 2 * border, h = H - 2 * border;
         if (i < (size_t) w * h) {
             const int x = (int) (i % w), y = (int) (i / w); const size_t src = (size_t) (y + border) * W + (x + border);
-            const float wgt = film[4 * plane + src], inv = wgt != 0 ? 1.0f / wgt : 0.0f;
-            for (int k = 0; k < 3; ++k) out[i * 3 + k] = film[k * plane + src] * inv;
+            const float wgt = film[4 * plane + src] + spill[4 * plane + src], inv = wgt != 0 ? 1.0f / wgt : 0.0f;
+            for (int k = 0; k < 3; ++k) out[i * 3 + k] = (film[k * plane + src] + spill[k * plane + src]) * inv;
         }
     }
 }
@@ -377,9 +381,9 @@ void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, i
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
 }
 void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(WG), 0, st, sc, q); }
-void mi_launch_film(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film); }
-void mi_launch_film_layout(const float *film, float *out, int W, int H, int border, int layout, hipStream_t st) {
-    size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, out, W, H, border, layout);
+void mi_launch_film(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
+void mi_launch_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout, hipStream_t st) {
+    size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, spill, out, W, H, border, layout);
 }
 void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_gather_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, q, slots, n, out); }
 void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out); }

@@ -1,0 +1,160 @@
+"""GPU (MI355X): the HIP path, called through the C-ABI (include/mi355pt.h via mitsuba-im_amd/api.py), against the oracle
+on the same seeded inputs, against the golden fixtures of the reference, and -- at BASELINE sizes -- through size-independent
+properties (tile/sample-range additivity, determinism, weight channel, ray counters)."""
+import os
+import numpy as np
+import pytest
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def scenes(mi):
+    S = mi.scenes
+    return {
+        "cornell_sobol": S.cornell_box(1920, 1080, 8),
+        "cornell_indep": S.cornell_box(1920, 1080, 8, sampler=S.SAMPLER_INDEPENDENT, seed=0),
+        "cornell_indep_seed5": S.cornell_box(640, 360, 4, sampler=S.SAMPLER_INDEPENDENT, seed=5),
+        "cornell_depth12": S.cornell_box(512, 288, 4, max_depth=12, rr_depth=3),
+        "closed_box": S.closed_box(),
+    }
+
+
+@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_indep_seed5", "cornell_depth12", "closed_box"])
+def test_li_samples_bit_exact_vs_oracle(mi, oracle, scenes, name):
+    """Bit-exact: integer sampler math AND the fp32 radiance (DESIGN.md arithmetic contract)."""
+    sc = scenes[name]; rng = np.random.default_rng(11); n = 30000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    pairs[:4] = [[0, 0, 0], [sc.width - 1, sc.height - 1, sc.spp - 1], [sc.width - 1, 0, 0], [0, sc.height - 1, sc.spp - 1]]
+    ref = oracle.Oracle(sc).render_samples(pairs)["li"]
+    r = mi.Render(mi.Scene(sc)); got = r.samples(pairs)
+    assert (bits(got) == bits(ref)).all()
+
+
+@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss"])
+def test_li_samples_vs_reference_golden(mi, golden_scenes, name):
+    """Against the REFERENCE's own Li (fixtures from the compiled reference): tolerance 2e-4 relative per sample (-ffast-math reference)."""
+    sc = golden_scenes[name]; gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    got = mi.Render(mi.Scene(sc)).samples(gd["pairs"])
+    err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
+    assert err.max() < 2e-4 and np.median(err) < 1e-6
+
+
+def test_sobol_and_camera_units(mi, oracle, scenes):
+    sc = scenes["cornell_sobol"]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); L = oracle.lib()
+    rng = np.random.default_rng(3); n = 4096
+    q = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, 256, n)], 1).astype(np.uint32)
+    idx, vals = gs.sobol(q, 40)
+    for i in range(0, n, 37):
+        ref_idx = L.orc_sobol_look_up(orc.h, 11, int(q[i, 2]), int(q[i, 0]), int(q[i, 1]))
+        assert idx[i] == ref_idx
+        for d in (0, 1, 4, 5, 17, 39):
+            assert vals[i, d] == np.float32(L.orc_sobol_sample(orc.h, ref_idx, d))
+    # golden Sobol vectors of the reference (m = 2, 7, 12 tables are exercised on the oracle side; here m = 11 via look_up above)
+    pos = rng.random((512, 2)).astype(np.float32) * np.array([sc.width, sc.height], np.float32)
+    rays = gs.camera_rays(pos)
+    for i in range(512):
+        assert (bits(rays[i]) == bits(orc.camera_ray(float(pos[i, 0]), float(pos[i, 1])))).all()
+
+
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box"])
+def test_intersection_bit_exact(mi, oracle, scenes, name):
+    sc = scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); rng = np.random.default_rng(5); n = 3000
+    lo, hi = sc.pos.min(0) - 5, sc.pos.max(0) + 5
+    o = (lo + rng.random((n, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:50, 0] = 0; d[50:100, 1] = 0; d[100:110] = [0, 0, 1]       # axis-parallel rays (zero components)
+    rays = np.concatenate([o, np.full((n, 1), 1e-4, np.float32), d, np.full((n, 1), np.inf, np.float32)], 1).astype(np.float32)
+    rays[200:400, 7] = rng.random(200) * 300                       # finite maxt
+    got = gs.intersect(rays); occ = gs.intersect(rays, any_hit=True)
+    nhit = 0
+    for i in range(n):
+        ok, h = orc.intersect(rays[i])
+        assert ok == (got[i, 3] >= 0)
+        if ok:
+            nhit += 1
+            # t, u, v bit-exact; prim = global triangle index
+            assert (bits(got[i, :3]) == bits(np.array([h[0], h[13], h[14]], np.float32))).all()
+            shape = int(h[19]); assert int(got[i, 3]) == sc.shapes[shape]["first_tri"] + int(h[18])
+        assert orc.occluded(rays[i]) == (occ[i, 3] >= 0)
+    assert nhit > n // 20
+
+
+@pytest.mark.parametrize("name,spp", [("cornell_small", 16), ("cornell_small_gauss", 4), ("closed_box", 16)])
+def test_film_vs_oracle_and_reference(mi, oracle, golden_scenes, name, spp):
+    sc = golden_scenes[name]
+    r = mi.Render(mi.Scene(sc)); r.run(); film = r.read_film(0); st = r.stats()
+    ofilm, cnt = oracle.Oracle(sc).render_image(threads=4)
+    assert film.shape == ofilm.shape
+    if sc.filter == 0:
+        # box filter: every pixel sums its own samples in sample order -> bit-exact, except pixels that received a spill from a
+        # neighbour's sample sitting within 1e-5 of the shared edge (added separately, float atomics): allow those 1e-6 relative
+        same = (bits(film) == bits(ofilm)).all(2)
+        assert same.mean() > 0.995 and np.allclose(film, ofilm, rtol=2e-6, atol=1e-7)
+    else:
+        assert np.allclose(film, ofilm, rtol=2e-5, atol=1e-6)       # gaussian: all splats are float atomics
+    assert (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
+    ref = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
+    assert rel < (2e-2 if name == "closed_box" else 1e-4), rel
+    # developed image = sum / weight (hdrfilm.cpp:352,396) and the responsive RGBA layout
+    dev = r.read_film(2); b = r.film_shape(0)[3]
+    inner = film[b:film.shape[0] - b, b:film.shape[1] - b]
+    assert np.allclose(dev, inner[..., :3] / inner[..., 4:5], rtol=1e-6)
+    assert (bits(r.read_film(1)) == bits(film[..., :4])).all()
+
+
+def test_full_size_properties(mi, scenes):
+    """BASELINE size (1920x1080, Sobol, depth 8): properties that need no CPU oracle."""
+    sc = scenes["cornell_sobol"]; gs = mi.Scene(sc); r = mi.Render(gs, spp=8)
+    r.run(); full = r.read_film(0); st = r.stats()
+    n = 1920 * 1080 * 8
+    assert st["samples"] == n and 3.5 < st["rays"] / n < 6.5 and 1.5 < st["shadow_rays"] / n < 4.0
+    assert np.isfinite(full).all() and (full >= 0).all()
+    # weight channel: every pixel received exactly spp samples of weight ~1 (box table value), border ~0
+    # (a sample within 1e-5 of a pixel edge splats into both pixels -- box radius 0.5+1e-5, src/rfilters/box.cpp:38; Sobol' points of low
+    # index sit exactly on dyadic pixel fractions, so ~0.2 % of the pixels hold one more)
+    w = full[1:-1, 1:-1, 4]; w0 = np.median(w)
+    assert abs(w0 / 8 - 1) < 1e-3 and np.isclose(w, w0, rtol=1e-4).mean() > 0.99
+    extra = np.round((w - w0) / (w0 / 8)); assert (extra >= 0).all() and extra.max() <= 3 and np.allclose(w, w0 + extra * (w0 / 8), rtol=1e-4)
+    # determinism
+    r.clear(); r.run(); again = r.read_film(0)
+    assert (bits(again[1:-1, 1:-1]) == bits(full[1:-1, 1:-1])).mean() > 0.995
+    # additivity over sample ranges and over tiles (global pixel coordinates in the sampler: SURVEY.md §7 look_up)
+    r.clear(); r.run(s0=0, s1=3); r.run(s0=3, s1=8); parts = r.read_film(0)
+    assert np.allclose(parts, full, rtol=1e-5, atol=1e-6)
+    r.clear()
+    for tile in [(0, 0, 1920, 500), (0, 500, 700, 1080), (700, 500, 1920, 1080)]:
+        r.run(tile=tile)
+    tiles = r.read_film(0)
+    assert (bits(tiles[1:-1, 1:-1]) == bits(full[1:-1, 1:-1])).mean() > 0.995 and np.allclose(tiles, full, rtol=1e-5, atol=1e-6)
+    # batching must not change the result
+    r2 = mi.Render(gs, spp=8, planes_per_batch=1); r2.run(); one = r2.read_film(0)
+    assert (bits(one[1:-1, 1:-1]) == bits(full[1:-1, 1:-1])).mean() > 0.995
+
+
+def test_edge_cases_and_errors(mi, scenes):
+    S = mi.scenes
+    # ragged tiny films, 1 sample, maxDepth 1
+    for w, h, spp, md in [(1, 1, 1, 8), (3, 2, 1, 1), (257, 3, 2, 2)]:
+        sc = S.cornell_box(w, h, spp, max_depth=md); r = mi.Render(mi.Scene(sc)); r.run(); f = r.read_film(0)
+        assert np.isfinite(f).all() and abs(f[1:-1, 1:-1, 4].mean() / spp - 1) < 1e-3
+        if md == 1:
+            assert r.stats()["shadow_rays"] == 0
+    sc = scenes["cornell_depth12"]; gs = mi.Scene(sc)
+    with pytest.raises(mi.MiError, match="rrDepth"):
+        mi.Render(gs, rr_depth=0)
+    with pytest.raises(mi.MiError, match="maxDepth"):
+        mi.Render(gs, max_depth=0)
+    r = mi.Render(gs)
+    with pytest.raises(mi.MiError, match="tile"):
+        r.run(tile=(0, 0, sc.width + 1, 10))
+    with pytest.raises(mi.MiError, match="sample range"):
+        r.run(s0=0, s1=sc.spp + 1)
+    # cancel flag is observed between batches and cleared by the next run
+    r.cancel(); r.run(); assert r.stats()["samples"] > 0
