@@ -13,6 +13,7 @@
 extern "C" {
 void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
+void mi_upload_packet(const TriAccelD *, uint32_t, hipStream_t);
 void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
@@ -40,6 +41,7 @@ struct mi_render {
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
     mi_stats stats{};
     uint64_t samplesTotal = 0;
+    uint32_t *dNib = nullptr;
 };
 
 extern "C" {
@@ -99,6 +101,11 @@ int mi_scene_set_film(mi_scene *s, uint32_t w, uint32_t h, uint32_t kind, float 
 }  // extern "C"
 
 namespace mi {
+static int bvhDepthOf(const std::vector<BvhNode> &nodes, int n) {
+    if (n < 0) return 0;
+    int a = bvhDepthOf(nodes, nodes[n].c0), b = bvhDepthOf(nodes, nodes[n].c1);
+    return 1 + (a > b ? a : b);
+}
 template <typename T> static int up(void **dst, const std::vector<T> &v) {
     size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
     hipError_t e = hipMalloc(dst, bytes); if (e != hipSuccess) return 1;
@@ -138,13 +145,11 @@ int SceneHost::upload(int dev) {
     d.width = width; d.height = height;
     d.filter_radius = filterRadiusEff; d.filter_scale = filterScale; d.border = border;
     d.log_res = logRes; d.resolution = resolution;
+    d.bvh_depth = (uint32_t) bvhDepthOf(nodes, 0);
+    const char *noPacket = getenv("MI355PT_NO_PACKET");
+    d.packet_n = (tris.size() <= MI_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;
     committed = true;
     return 0;
-}
-static int bvhDepth(const std::vector<BvhNode> &nodes, int n) {
-    if (n < 0) return 0;
-    int a = bvhDepth(nodes, nodes[n].c0), b = bvhDepth(nodes, nodes[n].c1);
-    return 1 + (a > b ? a : b);
 }
 }  // namespace mi
 
@@ -162,7 +167,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     for (const mi_emitter &e : s->h.emitters) if (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
     if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
     s->h.commitHost();
-    if (mi::bvhDepth(s->h.nodes, 0) > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
+    if (mi::bvhDepthOf(s->h.nodes, 0) > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
     int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
     if ((int) device >= devCount) return fail(MI_ERR_DEVICE, "mi_scene_commit: no such HIP device");
     if (s->h.upload((int) device)) return fail(MI_ERR_DEVICE, std::string("mi_scene_commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -215,6 +220,20 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters;
     r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u;
+    if (p->sampler == MI_SAMPLER_SOBOL) {
+        // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
+        uint32_t sppBits = 0; while ((1ull << sppBits) < p->spp) ++sppBits;
+        const uint32_t bits = (s->h.logRes > 1 ? 2 * s->h.logRes : 0) + sppBits + 1;
+        const uint32_t nibs = std::max<uint32_t>(1, (bits + 3) / 4), dims = std::min<uint32_t>(s->h.d.sobol_dims, (uint32_t) (4 + 5 * p->max_depth));
+        std::vector<uint32_t> nib((size_t) dims * nibs * 16);
+        for (uint32_t dmn = 0; dmn < dims; ++dmn) for (uint32_t n = 0; n < nibs; ++n) for (uint32_t v = 0; v < 16; ++v) {
+            uint32_t x = 0; for (uint32_t b = 0; b < 4; ++b) if (((v >> b) & 1u) && 4 * n + b < MI_SOBOL_SIZE) x ^= g_sobolM32[(size_t) dmn * MI_SOBOL_SIZE + 4 * n + b];
+            nib[((size_t) dmn * nibs + n) * 16 + v] = x;
+        }
+        if ((size_t) dims * nibs * 64 > 64 * 1024) { delete r; return fail(MI_ERR_UNSUPPORTED, "mi_render_create: Sobol lookup tables exceed the LDS budget (reduce maxDepth)"); }
+        HIPCHK(hipMalloc((void **) &r->dNib, nib.size() * 4)); HIPCHK(hipMemcpy(r->dNib, nib.data(), nib.size() * 4, hipMemcpyHostToDevice));
+        r->rc.sobol_nib = r->dNib; r->rc.nib_count = nibs; r->rc.nib_dims = dims;
+    }
     HIPCHK(hipStreamCreate(&r->stream)); HIPCHK(hipEventCreate(&r->evBegin)); HIPCHK(hipEventCreate(&r->evEnd));
     const int W = (int) s->h.width + 2 * s->h.border, H = (int) s->h.height + 2 * s->h.border;
     r->filmFloats = (size_t) W * H * 5;
@@ -230,6 +249,7 @@ void mi_render_destroy(mi_render *r) {
     if (r->film) (void) hipFree(r->film);
     if (r->spill) (void) hipFree(r->spill);
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
+    if (r->dNib) (void) hipFree(r->dNib);
     for (hipEvent_t e : r->evPool) (void) hipEventDestroy(e);
     if (r->evBegin) (void) hipEventDestroy(r->evBegin);
     if (r->evEnd) (void) hipEventDestroy(r->evEnd);
@@ -255,6 +275,7 @@ static void mark(mi_render *r, int tag, size_t &used) {
 static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed) {
     const DScene &sc = r->scene->h.d; hipStream_t st = r->stream;
     (void) list;
+    if (sc.packet_n) mi_upload_packet(r->scene->h.packet.data(), sc.packet_n, st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
     mark(r, 0, evUsed);
     mi_launch_generate(sc, r->rc, r->q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
@@ -382,6 +403,7 @@ extern "C" {
 int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) {
     if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_intersect: bad argument");
     HIPCHK(hipSetDevice(s->h.device));
+    if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), s->h.d.packet_n, nullptr); HIPCHK(hipDeviceSynchronize()); }
     return withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, nullptr); });
 }
 int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, uint64_t *outIdx, float *outVals) {

@@ -75,6 +75,25 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
     return found;
 }
 
+// Packet mode (scenes of <= MI_PACKET_MAX triangles): the scene is one triangle packet in constant memory, in ORIGINAL triangle
+// order.  The loop index is wave-uniform, so the Wald records arrive through the scalar cache as SGPR operands and the projection
+// axis `k` is a scalar branch: no per-lane loads, no stack, no divergence besides lanes that have left the loop.
+__constant__ TriAccelD c_packet[MI_PACKET_MAX];
+template <bool ANY>
+DEV bool packetIntersect(uint32_t n, v3 o, v3 d, float mint, float maxt, float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
+    float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const TriAccelD ta = c_packet[i];
+        float u, v, t;
+        if (triIntersect(ta, o, d, mint, best, u, v, t)) {
+            if (ANY) return true;
+            if (!found || t < best) { best = t; bprim = i; bu = u; bv = v; found = true; }   // ascending prim order: ties keep the lower index
+        }
+    }
+    bestT = best; bestPrim = bprim; bestU = bu; bestV = bv;
+    return found;
+}
+
 // ---------------------------------------------------------------------------------------------- generate
 // One camera sample per path: src/librender/integrator.cpp:166-181 (pixel offset + sensor ray), sampler set-up
 // src/samplers/sobol.cpp:171-216.  Path q of the batch = (plane q / npix, tile pixel q % npix).
@@ -93,13 +112,14 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
         if (rc.sampler == 1) {
             uint64_t idx = sc.log_res > 1 ? sobolLookUp(sc.sobol_vdc, sc.sobol_vdc_inv, sc.log_res, sidx, px, py) : (uint64_t) sidx;
             ss.a = (uint32_t) idx; ss.b = (uint32_t) (idx >> 32); ss.dim = 0;
-            jx = sobolSample(sc.sobol_m32, idx, 0); jy = sobolSample(sc.sobol_m32, idx, 1); ss.dim = 2;
+            const SobolTab gt{rc.sobol_nib, rc.nib_count};
+            jx = sobolSampleNib(gt, ss.a, ss.b, 0); jy = sobolSampleNib(gt, ss.a, ss.b, 1); ss.dim = 2;
             if (idx != (uint64_t) sidx) {      // sobol.cpp:239-245: rescale the first two dimensions to a pixel-relative offset
                 jx = jx * sc.resolution - (float) (int) px; jy = jy * sc.resolution - (float) (int) py;
             }
         } else {
             ss.a = (py * sc.width + px) ^ rc.seed_mix; ss.b = sidx; ss.dim = 0;
-            next2D(ss, 0, nullptr, jx, jy);
+            next2D(ss, 0, SobolTab{nullptr, 0}, jx, jy);
         }
         float sx = (float) (int) px + jx, sy = (float) (int) py + jy;
         v3 o, d; float mint, maxt; cameraRay(sc, sx, sy, o, d, mint, maxt);
@@ -118,8 +138,9 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
 
 // ---------------------------------------------------------------------------------------------- extend
 // Scene::rayIntersect -> ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:112-142): closest hit (t, u, v, prim)
+template <int STACK>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth)
 __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
-    __shared__ int s_stk[STACK_DEPTH * WG];
+    __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     const uint32_t seg = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
@@ -127,8 +148,10 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
         float4 ro = q.rayO[buf][segBase + i], rd = q.rayD[buf][segBase + i];
         v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z);
         float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
-        if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt))
-            hit = traverse<false>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+        if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt)) {
+            if (STACK == 0) hit = packetIntersect<false>(sc.packet_n, o, d, mint, maxt, t, prim, u, v);
+            else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+        }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
     }
     if (tid == 0 && n) atomicAdd(&q.counters[0], (unsigned long long) n);
@@ -143,15 +166,15 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_wave[2][WG / 64];
     __shared__ uint32_t s_base[2];
-    uint32_t *s_m32 = s_dyn;
+    uint32_t *s_nib = s_dyn;
     const uint32_t seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
     const int nb = buf ^ 1;
-    const uint32_t *m32 = sc.sobol_m32;
-    if (rc.sampler == 1) {   // stage the Sobol' direction matrices in LDS (one row of 52 words per dimension)
-        for (uint32_t i = tid; i < sc.sobol_dims * MI_SOBOL_SIZE; i += WG) s_m32[i] = sc.sobol_m32[i];
-        m32 = s_m32;
+    const SobolTabLds m32{(lds_u32_ptr) s_nib, rc.nib_count};   // always the LDS copy (ds_read lookups); unused by the independent stream
+    if (rc.sampler == 1) {   // stage the Sobol' nibble tables in LDS (nib_dims x nib_count x 16 words)
+        const uint32_t words = rc.nib_dims * rc.nib_count * 16u;
+        for (uint32_t i = tid; i < words; i += WG) s_nib[i] = rc.sobol_nib[i];
     }
     if (tid < 2) s_base[tid] = 0;
     __syncthreads();
@@ -257,8 +280,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 // ---------------------------------------------------------------------------------------------- shadow
 // Visibility test of Scene::sampleEmitterDirect (src/librender/scene.cpp:871-875 -> skdtree.cpp:207-226, any hit) and the
 // deferred `Li += throughput * value * bsdfVal * weight` (path.cpp:196)
+template <int STACK>
 __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
-    __shared__ int s_stk[STACK_DEPTH * WG];
+    __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     const uint32_t seg = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = q.shCount[seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
@@ -266,8 +290,10 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
         float4 so = q.shO[segBase + i], sd = q.shD[segBase + i];
         v3 o = V(so.x, so.y, so.z), d = V(sd.x, sd.y, sd.z);
         float mint, maxt, t, u, v; uint32_t prim; bool occluded = false;
-        if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt))
-            occluded = traverse<true>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+        if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt)) {
+            if (STACK == 0) occluded = packetIntersect<true>(sc.packet_n, o, d, mint, maxt, t, prim, u, v);
+            else occluded = traverse<true>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+        }
         if (!occluded) {
             float4 c = q.shC[segBase + i]; const uint32_t pid = __float_as_uint(sd.w);
             float4 a = q.acc[pid]; a.x += c.x; a.y += c.y; a.z += c.z; q.acc[pid] = a;
@@ -353,7 +379,8 @@ __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *
     v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
     if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
-        if (anyHit) hit = traverse<true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
+        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true>(sc.packet_n, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false>(sc.packet_n, o, d, mint, maxt, t, prim, u, v); }
+        else if (anyHit) hit = traverse<true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
         else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
     }
     out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
@@ -375,12 +402,23 @@ __global__ void k_debug_camera(DScene sc, const float *pos, uint64_t n, float *o
 // ---------------------------------------------------------------------------------------------- launch wrappers (used by api.cpp)
 extern "C" {
 void mi_launch_generate(const DScene &sc, const RenderConst &rc, const Queues &q, const BatchDesc &bd, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(WG), 0, st, sc, rc, q, bd); }
-void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_extend, dim3(grid), dim3(WG), 0, st, sc, q, buf); }
+void mi_upload_packet(const TriAccelD *tris, uint32_t n, hipStream_t st) { (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_packet), tris, n * sizeof(TriAccelD), 0, hipMemcpyHostToDevice, st); }
+void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+    if (sc.packet_n) hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
+    else if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_extend<16>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
+    else hipLaunchKernelGGL(k_extend<STACK_DEPTH>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
+}
 void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
-    size_t lds = rc.sampler == 1 ? (size_t) sc.sobol_dims * MI_SOBOL_SIZE * 4 : 16;
+    size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
 }
-void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(WG), 0, st, sc, q); }
+void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
+    if (sc.packet_n) hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(WG), 0, st, sc, q);
+    else if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, dim3(grid), dim3(WG), 0, st, sc, q);
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, dim3(grid), dim3(WG), 0, st, sc, q);
+    else hipLaunchKernelGGL(k_shadow<STACK_DEPTH>, dim3(grid), dim3(WG), 0, st, sc, q);
+}
 void mi_launch_film(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
 void mi_launch_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout, hipStream_t st) {
     size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, spill, out, W, H, border, layout);

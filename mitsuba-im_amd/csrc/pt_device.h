@@ -46,6 +46,21 @@ DEV float sobolSample(const uint32_t *m32, uint64_t index, uint32_t dim) {
         if (index & 1) result ^= m32[i];
     return minf((float) result * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
 }
+// The same XOR sum, four index bits per table lookup (tables built on the host from the same matrices: api.cpp buildNibbleTables).
+// XOR is associative, so the result is bit-identical to sampleSingle.  `tab` may point to LDS or global memory.
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;   // explicit LDS pointer: lookups compile to ds_read, not flat loads
+template <typename P> struct SobolTabT { P tab; uint32_t nibs; };
+typedef SobolTabT<const uint32_t *> SobolTab;       // global memory
+typedef SobolTabT<lds_u32_ptr> SobolTabLds;         // LDS copy
+template <typename P>
+DEV float sobolSampleNib(SobolTabT<P> st, uint32_t lo, uint32_t hi, uint32_t dim) {
+    P T = st.tab + dim * st.nibs * 16u;
+    uint32_t result = 0;
+    const uint32_t nlo = st.nibs < 8u ? st.nibs : 8u;
+    for (uint32_t n = 0; n < nlo; ++n) result ^= T[n * 16u + ((lo >> (4u * n)) & 15u)];
+    for (uint32_t n = 8; n < st.nibs; ++n) result ^= T[n * 16u + ((hi >> (4u * (n - 8u))) & 15u)];
+    return minf((float) result * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
+}
 // src/samplers/sobolseq.h:99-131 look_up, scramble 0; vdc / vdcInv = row (m-1) of the tables
 DEV uint64_t sobolLookUp(const uint64_t *vdc, const uint64_t *vdcInv, uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
     uint64_t index = (uint64_t) frame << (m << 1);
@@ -63,17 +78,18 @@ struct SamplerState {
     uint32_t a, b;      // sobol: index lo/hi; independent: v0 (pixel ^ seed mix), sample index
     uint32_t dim;       // sobol: m_dimension; independent: call counter
 };
-DEV float next1D(SamplerState &s, uint32_t kind, const uint32_t *m32) {
-    if (kind == 1) return sobolSample(m32, ((uint64_t) s.b << 32) | s.a, s.dim++);
+template <typename P>
+DEV float next1D(SamplerState &s, uint32_t kind, SobolTabT<P> st) {
+    if (kind == 1) return sobolSampleNib(st, s.a, s.b, s.dim++);
     uint32_t v1 = (s.b << 8) | (s.dim++ & 0xFFu);
     return bitsToFloat((uint32_t) sampleTEA(s.a, v1));
 }
 // `first` is true only for the pixel-offset request of a sample (dimension 0), see sobol.cpp:239-245
-DEV void next2D(SamplerState &s, uint32_t kind, const uint32_t *m32, float &x, float &y) {
+template <typename P>
+DEV void next2D(SamplerState &s, uint32_t kind, SobolTabT<P> st, float &x, float &y) {
     if (kind == 1) {
         if (s.dim + 1 >= 5 && s.dim < 5) s.dim = 5;                 // sobol.cpp:233-235 (m_arrayStartDim = m_arrayEndDim = 5)
-        uint64_t idx = ((uint64_t) s.b << 32) | s.a;
-        x = sobolSample(m32, idx, s.dim++); y = sobolSample(m32, idx, s.dim++);
+        x = sobolSampleNib(st, s.a, s.b, s.dim++); y = sobolSampleNib(st, s.a, s.b, s.dim++);
     } else {
         uint32_t v1 = (s.b << 8) | (s.dim++ & 0xFFu);
         uint64_t r = sampleTEA(s.a, v1);

@@ -64,9 +64,15 @@ struct DScene {
     // sobol
     const uint32_t *sobol_m32; const uint64_t *sobol_vdc, *sobol_vdc_inv;   // vdc rows for m = log_res only
     uint32_t sobol_dims, log_res; float resolution;
+    // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
+    // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
+    uint32_t packet_n, bvh_depth;
 };
+#define MI_PACKET_MAX 64
 
 struct RenderConst {
     int32_t max_depth, rr_depth; uint32_t strict_normals, hide_emitters;
     uint32_t sampler; uint32_t seed_mix;  // independent: seed * 0x9E3779B9
+    // Sobol' direction matrices folded into 4-bit lookup tables: nib[dim][n][v] = XOR of matrices32[dim*52 + 4n + b] over the bits b of v
+    const uint32_t *sobol_nib; uint32_t nib_count, nib_dims;
 };
