@@ -34,7 +34,7 @@ struct mi_scene { mi::SceneHost h; };
 
 struct mi_render {
     mi_scene *scene = nullptr; mi_render_params p{}; RenderConst rc{};
-    Queues q{}; std::vector<void *> allocs; uint64_t poolPaths = 0; uint32_t grid = 0;
+    Queues q{}; std::vector<void *> allocs; uint64_t poolPaths = 0; uint32_t grid = 0, gridExtend = 0, gridShade = 0, gridShadow = 0;
     float *film = nullptr, *spill = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr;   // film: own-pixel sums; spill: cross-pixel splats (atomics)
     hipStream_t stream = nullptr; hipEvent_t evBegin = nullptr, evEnd = nullptr;
     std::atomic<int> cancel{0};
@@ -183,11 +183,14 @@ static int allocQ(mi_render *r, void **p, size_t bytes) {
 static int allocPool(mi_render *r, uint64_t paths) {
     for (void *p : r->allocs) (void) hipFree(p);
     r->allocs.clear();
-    const char *g = getenv("MI355PT_GRID");
-    uint32_t grid = g ? (uint32_t) atoi(g) : 1024u;
+    auto envU = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v && v[0] ? (uint32_t) atoi(v) : dflt; };
+    uint32_t grid = envU("MI355PT_SEGMENTS", 4096u);                       // segments of the path pool
     uint64_t minGrid = (paths + 255) / 256; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 255) / 256 * 256;
-    r->grid = grid; r->q.cap = (uint32_t) cap; r->poolPaths = paths;
+    r->grid = grid; r->q.cap = (uint32_t) cap; r->q.n_seg = grid; r->poolPaths = paths;
+    // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
+    r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", 768u));
+    r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
     const uint64_t slots = cap * grid;
     for (int b = 0; b < 2; ++b) {
         ALLOC(r->q.rayO[b], float4, slots); ALLOC(r->q.rayD[b], float4, slots);
@@ -280,9 +283,9 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     mi_launch_generate(sc, r->rc, r->q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
-        mark(r, 1, evUsed); mi_launch_extend(sc, r->q, buf, r->grid, st);
-        mark(r, 2, evUsed); mi_launch_shade(sc, r->rc, r->q, buf, r->grid, st);
-        if (depth < maxDepth) { mark(r, 3, evUsed); mi_launch_shadow(sc, r->q, r->grid, st); }
+        mark(r, 1, evUsed); mi_launch_extend(sc, r->q, buf, r->gridExtend, st);
+        mark(r, 2, evUsed); mi_launch_shade(sc, r->rc, r->q, buf, r->gridShade, st);
+        if (depth < maxDepth) { mark(r, 3, evUsed); mi_launch_shadow(sc, r->q, r->gridShadow, st); }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
             std::vector<uint32_t> cnt(r->grid);
@@ -305,7 +308,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
     HIPCHK(hipSetDevice(h.device));
     const uint32_t npix = (tile.x1 - tile.x0) * (tile.y1 - tile.y0);
     uint32_t planes = r->p.planes_per_batch;
-    if (!planes) { const uint64_t target = 4u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }
+    if (!planes) { const uint64_t target = 16u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
     const uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");

@@ -4,8 +4,8 @@
 // sampler plugins (reference src/librender/integrator.cpp:141-189, src/integrators/path/path.cpp:119-294) by stages over
 // SoA queues in HBM:
 //     generate -> [ extend (closest hit) -> shade (MIS bookkeeping, RR, NEE sample, BSDF sample) -> shadow (any hit) ] x depth -> film
-// Work ownership: the path pool of a batch is cut into `gridDim.x` contiguous SEGMENTS; workgroup b owns segment b in every
-// stage (persistent ownership across launches).  Stream compaction therefore never leaves the workgroup: wave64 ballots +
+// Work ownership: the path pool of a batch is cut into `n_seg` contiguous SEGMENTS; a workgroup owns whole segments
+// (segments b, b + gridDim.x, ...) in every stage, so a segment is produced and consumed by one workgroup at a time.  Stream compaction therefore never leaves the workgroup: wave64 ballots +
 // one LDS exchange per 256-path chunk, no global atomics, fully coalesced queue reads/writes, and a workgroup re-reads what
 // it (= the same XCD's L2 under round-robin dispatch) wrote in the previous stage.
 #include <hip/hip_runtime.h>
@@ -98,7 +98,8 @@ DEV bool packetIntersect(uint32_t n, v3 o, v3 d, float mint, float maxt, float &
 // One camera sample per path: src/librender/integrator.cpp:166-181 (pixel offset + sensor ray), sampler set-up
 // src/samplers/sobol.cpp:171-216.  Path q of the batch = (plane q / npix, tile pixel q % npix).
 __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queues q, BatchDesc bd) {
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
     const uint64_t segBase = (uint64_t) seg * q.cap;
     uint64_t remaining = bd.n_paths > segBase ? bd.n_paths - segBase : 0;
     const uint32_t n = remaining > q.cap ? q.cap : (uint32_t) remaining;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
         q.acc[pid] = make_float4(0, 0, 0, 0);
     }
     if (tid == 0) q.count[0][seg] = n;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- extend
@@ -141,9 +143,12 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
 template <int STACK>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth)
 __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    unsigned long long rays = 0;
+    for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
+    rays += n;
     for (uint32_t i = tid; i < n; i += WG) {
         float4 ro = q.rayO[buf][segBase + i], rd = q.rayD[buf][segBase + i];
         v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z);
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
         }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
     }
-    if (tid == 0 && n) atomicAdd(&q.counters[0], (unsigned long long) n);
+    }
+    if (tid == 0 && rays) atomicAdd(&q.counters[0], rays);
 }
 
 // ---------------------------------------------------------------------------------------------- shade
@@ -167,18 +173,19 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     __shared__ uint32_t s_wave[2][WG / 64];
     __shared__ uint32_t s_base[2];
     uint32_t *s_nib = s_dyn;
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t n = q.count[buf][seg];
-    const uint64_t segBase = (uint64_t) seg * q.cap;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = buf ^ 1;
     const SobolTabLds m32{(lds_u32_ptr) s_nib, rc.nib_count};   // always the LDS copy (ds_read lookups); unused by the independent stream
     if (rc.sampler == 1) {   // stage the Sobol' nibble tables in LDS (nib_dims x nib_count x 16 words)
         const uint32_t words = rc.nib_dims * rc.nib_count * 16u;
         for (uint32_t i = tid; i < words; i += WG) s_nib[i] = rc.sobol_nib[i];
     }
+    unsigned long long pathLen = 0, shadowRays = 0;
+    for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
+    const uint32_t n = q.count[buf][seg];
+    const uint64_t segBase = (uint64_t) seg * q.cap;
     if (tid < 2) s_base[tid] = 0;
     __syncthreads();
-    unsigned long long pathLen = 0, shadowRays = 0;
     for (uint32_t base = 0; base < n; base += WG) {
         const uint32_t i = base + tid;
         bool alive = false, wantShadow = false;
@@ -272,6 +279,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         __syncthreads();
     }
     if (tid == 0) { q.count[nb][seg] = s_base[0]; q.shCount[seg] = s_base[1]; }
+    __syncthreads();
+    }
     // counters: wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) { pathLen += __shfl_down(pathLen, off); shadowRays += __shfl_down(shadowRays, off); }
     if (lane == 0) { if (pathLen) atomicAdd(&q.counters[2], pathLen); if (shadowRays) atomicAdd(&q.counters[1], shadowRays); }
@@ -283,7 +292,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 template <int STACK>
 __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
     const uint32_t n = q.shCount[seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
     for (uint32_t i = tid; i < n; i += WG) {
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
             float4 c = q.shC[segBase + i]; const uint32_t pid = __float_as_uint(sd.w);
             float4 a = q.acc[pid]; a.x += c.x; a.y += c.y; a.z += c.z; q.acc[pid] = a;
         }
+    }
     }
 }
 

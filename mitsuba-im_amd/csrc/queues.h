@@ -17,6 +17,7 @@ struct Queues {
     uint32_t *count[2]; uint32_t *shCount;      // per segment
     unsigned long long *counters;               // [0] closest-hit rays, [1] shadow rays, [2] sum of path depths
     uint32_t cap;                               // slots per segment (multiple of 256)
+    uint32_t n_seg;                             // number of segments
 };
 
 struct BatchDesc {

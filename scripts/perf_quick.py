@@ -9,5 +9,5 @@ r.run(s1=8); r.set_profiling(True)
 r.clear(); r.run(s1=spp); st = r.stats()
 n = 1920 * 1080 * spp
 print("grid=%s packet=%s planes=%s: %.1f Msamples/s | ms: total %.1f extend %.1f shade %.1f shadow %.1f other %.1f" % (
-    os.environ.get("MI355PT_GRID", "1024"), os.environ.get("MI355PT_NO_PACKET", "0") != "1", os.environ.get("PLANES", "auto"),
+    "seg=%s e=%s s=%s sh=%s" % tuple(os.environ.get(k, "-") for k in ("MI355PT_SEGMENTS", "MI355PT_GRID_EXTEND", "MI355PT_GRID_SHADE", "MI355PT_GRID_SHADOW")), os.environ.get("MI355PT_NO_PACKET", "0") != "1", os.environ.get("PLANES", "auto"),
     n / st["render_ms"] / 1e3, st["render_ms"], st["extend_ms"], st["shade_ms"], st["shadow_ms"], st["other_ms"]), flush=True)
