@@ -144,8 +144,17 @@ def main():
             dom = max(ms, key=ms.get)
             launches = stage["extend_launches"] if dom != "shadow" else stage["extend_launches"] * (args.max_depth - 1) / args.max_depth
             achieved = per_step[dom] * args.steps / (ms[dom] * 1e-3) / 1e9
+            # measured HBM bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of this very
+            # workload, committed under profiles/ (PMC cannot be collected from inside the timed run); valid for the default 1080p batches only
+            traffic = None
+            try:
+                if (args.width, args.height, args.max_depth) == (1920, 1080, 8):
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["k_" + dom]
+                    traffic = round(pmc["hbm_bytes_per_launch"], 1)
+            except Exception:
+                traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "avg_launch_us": round(ms[dom] * 1e3 / max(launches, 1), 2), "launches": int(launches),
                                "algorithmic_bytes_per_launch": round(per_step[dom] * args.steps / max(launches, 1), 1)}
             seg_bytes = 288.0 * rays + 16.0 * n
