@@ -3,7 +3,7 @@
  *
  * Plain C: opaque handles, plain pointers and sizes, every call returns an int status (0 = MI_OK) and leaves a
  * message for mi_last_error().  No exceptions cross this boundary.  What each entry point replaces in the reference
- * (paths relative to the reference tree) is cited next to it; the adapter plugin (mitsuba-im_amd/csrc/adapter_plugin.cpp,
+ * (paths relative to the reference tree) is cited next to it; the adapter plugin (mitsuba-im_amd/csrc/adapter/path_hip.cpp,
  * INTEGRATION.md) fills these calls from a live mitsuba::Scene.
  */
 #ifndef MI355PT_H
@@ -56,6 +56,9 @@ typedef struct {
     uint64_t seed;               /* independent: seed; sobol: scramble (must be 0) */
     uint32_t device;             /* HIP device ordinal */
     uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
+    uint32_t opacity;            /* 1: alpha = 1 where the camera ray hits a surface, else 0 (RadianceQueryRecord::EOpacity, records.inl:121-137:
+                                    the responsive drivers and films with an alpha channel); 0: alpha = 1 (classic film without alpha, integrator.cpp:160-161) */
+    uint32_t reserved;
 } mi_render_params;
 
 typedef struct { uint32_t x0, y0, x1, y1; } mi_tile;   /* pixel rectangle [x0,x1) x [y0,y1) in GLOBAL film coordinates */
@@ -73,6 +76,9 @@ const char *mi_last_error(void);
 /* Sobol' tables (data): matrices32[dims][52], vdc[16][52], vdc_inv[16][52] (the tables of src/samplers/sobolseq.cpp:33,106537,107241).
  * Must be called once before a Sobol render; mitsuba-im_amd loads them from mitsuba-im_amd/data/sobol_tables.bin. */
 int mi_set_sobol_tables(const uint32_t *matrices32, uint32_t dims, const uint64_t *vdc, const uint64_t *vdc_inv);
+/* Same from a file; mi_scene_commit loads <dir of libmi355pt.so>/data/sobol_tables.bin (or $MI355PT_DATA/sobol_tables.bin) by itself
+ * when no tables were set. */
+int mi_load_sobol_tables(const char *path);
 
 /* -- scene: replaces Scene::initialize -> ShapeKDTree::build (src/librender/scene.cpp:330-392, src/librender/skdtree.cpp:68-105) -- */
 int mi_scene_create(mi_scene **out);

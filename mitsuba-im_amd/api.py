@@ -33,7 +33,7 @@ class MiEmitter(C.Structure):
 
 class MiRenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
-                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32)]
+                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class MiTile(C.Structure):
@@ -46,11 +46,12 @@ class MiStats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64)]
 
 
-EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
+EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
            "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_sobol", "mi_debug_camera_rays"]
+HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
 
 
 def build(force=False):
@@ -175,13 +176,13 @@ class Render:
     """mi_render handle: the integrator instance (MonteCarloIntegrator properties + sampler)."""
 
     def __init__(self, scene, max_depth=None, rr_depth=None, sampler=None, spp=None, seed=None, device=0, planes_per_batch=0,
-                 strict_normals=None, hide_emitters=None):
+                 strict_normals=None, hide_emitters=None, opacity=False):
         sc = scene.sc; L = scene.L; self.L = L; self.scene = scene
         p = MiRenderParams(sc.max_depth if max_depth is None else max_depth, sc.rr_depth if rr_depth is None else rr_depth,
                            sc.strict_normals if strict_normals is None else int(strict_normals),
                            sc.hide_emitters if hide_emitters is None else int(hide_emitters),
                            sc.sampler if sampler is None else sampler, sc.spp if spp is None else spp,
-                           sc.seed if seed is None else seed, device, planes_per_batch)
+                           sc.seed if seed is None else seed, device, planes_per_batch, int(opacity), 0)
         self.params = p
         h = C.c_void_p(); L.check(L.L.mi_render_create(scene.h, C.byref(p), C.byref(h))); self.h = h
 

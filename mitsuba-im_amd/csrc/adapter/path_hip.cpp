@@ -1,0 +1,229 @@
+// adapter/path_hip.cpp -- the drop-in plugin: `path_hip.so` for Mitsuba-IM's plugin directory.
+//
+// Compiled AGAINST THE REFERENCE'S HEADERS with the reference's defines (include/mitsuba/core/cobject.h:102-110 plugin
+// entry points, src/integrators/mark_integrator.cpp:3 marker string).  It exposes the MI355X path tracer as
+//   * a classic mitsuba::Integrator ("path_hip", same properties as `path`: maxDepth, rrDepth, strictNormals, hideEmitters), and
+//   * a ResponsiveIntegrator through makeResponsiveIntegrator() (include/mitsuba/render/integrator2.h:49-100),
+// flattening the live mitsuba::Scene into the C-ABI of libmi355pt.so (include/mi355pt.h).  All GPU work runs on threadIdx 0.
+// HIP / C-ABI errors become Log(EError) (which throws std::runtime_error, as everywhere in the reference).
+#include <mitsuba/render/scene.h>
+#include <mitsuba/render/integrator.h>
+#include <mitsuba/render/integrator2.h>
+#include <mitsuba/render/trimesh.h>
+#include <mitsuba/render/sensor.h>
+#include <mitsuba/render/film.h>
+#include <mitsuba/render/emitter.h>
+#include <mitsuba/render/bsdf.h>
+#include <mitsuba/render/sampler.h>
+#include <mitsuba/render/imageblock.h>
+#include <mitsuba/render/renderqueue.h>
+#include <mitsuba/core/rfilter.h>
+#include <mitsuba/core/plugin.h>
+#include "../integrator_host.h"
+
+MTS_NAMESPACE_BEGIN
+
+namespace {
+
+struct FlatScene {
+    std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
+    bool anyNormals = false;
+};
+
+#define MI_CHECK(call) do { int rc_ = (call); if (rc_ != MI_OK) SLog(EError, "path_hip: %s failed: %s", #call, mi_last_error()); } while (0)
+
+/// BSDF -> mi_material.  Only what the hot path implements; anything else is reported, never silently approximated.
+static mi_material convertBSDF(const BSDF *bsdf) {
+    mi_material m; memset(&m, 0, sizeof(m));
+    bool backSide = false;
+    for (int i = 0; i < bsdf->getComponentCount(); ++i) {
+        unsigned int type = bsdf->getType(i);
+        if (!(type & BSDF::EDiffuseReflection))
+            SLog(EError, "path_hip: BSDF \"%s\" has a non-diffuse lobe; only diffuse (optionally twosided) is implemented", bsdf->getClass()->getName().c_str());
+        backSide |= (type & BSDF::EBackSide) != 0;
+    }
+    Intersection its; its.uv = Point2(0.5f); its.p = Point(0.0f); its.hasUVPartials = false;
+    Spectrum refl = bsdf->getDiffuseReflectance(its); Float r, g, b; refl.toLinearRGB(r, g, b);
+    m.type = MI_BSDF_DIFFUSE; m.flags = backSide ? MI_BSDF_FLAG_TWOSIDED : 0; m.reflectance[0] = r; m.reflectance[1] = g; m.reflectance[2] = b;
+    return m;
+}
+
+static void flatten(const Scene *scene, FlatScene &fs) {
+    const std::vector<TriMesh *> &meshes = scene->getMeshes();
+    if (meshes.size() != scene->getShapes().size())
+        SLog(EError, "path_hip: the scene contains analytic shapes / instances; only triangle meshes are implemented (SURVEY.md §8f)");
+    std::map<const BSDF *, int> bsdfIndex;
+    for (const TriMesh *mesh : meshes) fs.anyNormals |= mesh->getVertexNormals() != NULL;
+    for (size_t mi = 0; mi < meshes.size(); ++mi) {
+        const TriMesh *mesh = meshes[mi];
+        if (mesh->getVertexTexcoords() != NULL && (mesh->getBSDF()->usesRayDifferentials() || mesh->getUVTangents() != NULL))
+            SLog(EWarn, "path_hip: mesh \"%s\" carries UV tangents; the shading frame falls back to the triangle edge (no textures on this path)", mesh->getName().c_str());
+        mi_shape sh; memset(&sh, 0, sizeof(sh));
+        sh.first_tri = (uint32_t) (fs.idx.size() / 3); sh.tri_count = (uint32_t) mesh->getTriangleCount();
+        sh.first_vert = (uint32_t) (fs.pos.size() / 3); sh.vert_count = (uint32_t) mesh->getVertexCount();
+        const Point *p = mesh->getVertexPositions(); const Normal *n = mesh->getVertexNormals();
+        for (size_t v = 0; v < mesh->getVertexCount(); ++v) {
+            fs.pos.push_back(p[v].x); fs.pos.push_back(p[v].y); fs.pos.push_back(p[v].z);
+            if (fs.anyNormals) { fs.nrm.push_back(n ? n[v].x : 0); fs.nrm.push_back(n ? n[v].y : 0); fs.nrm.push_back(n ? n[v].z : 0); }
+        }
+        const Triangle *t = mesh->getTriangles();
+        for (size_t k = 0; k < mesh->getTriangleCount(); ++k) for (int c = 0; c < 3; ++c) fs.idx.push_back(sh.first_vert + t[k].idx[c]);
+        sh.flags = n ? 0u : 1u;
+        const BSDF *bsdf = mesh->getBSDF();
+        if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
+        sh.bsdf = bsdfIndex[bsdf]; sh.emitter = -1;
+        fs.shapes.push_back(sh);
+    }
+    // emitters in Scene::getEmitters() order (the order the emitter PDF is built in, scene.cpp:383-388)
+    const ref_vector<Emitter> &emitters = scene->getEmitters();
+    for (size_t e = 0; e < emitters.size(); ++e) {
+        const Emitter *em = emitters[e].get();
+        if (!em->isOnSurface() || em->isEnvironmentEmitter())
+            SLog(EError, "path_hip: emitter \"%s\" is not an area light; only area emitters are implemented", em->getClass()->getName().c_str());
+        const Shape *shape = em->getShape(); int shapeIdx = -1;
+        for (size_t mi = 0; mi < meshes.size(); ++mi) if (meshes[mi] == shape) shapeIdx = (int) mi;
+        if (shapeIdx < 0) SLog(EError, "path_hip: area emitter without a triangle mesh");
+        Intersection its; its.shFrame.n = Normal(0, 0, 1);
+        Spectrum rad = em->eval(its, Vector(0, 0, 1)); Float r, g, b; rad.toLinearRGB(r, g, b);      // AreaLight::eval = radiance on the lit side (area.cpp:106-111)
+        mi_emitter me; memset(&me, 0, sizeof(me));
+        me.type = MI_EMITTER_AREA; me.shape = shapeIdx; me.radiance[0] = r; me.radiance[1] = g; me.radiance[2] = b; me.weight = em->getSamplingWeight();
+        fs.shapes[shapeIdx].emitter = (int32_t) fs.emitters.size(); fs.emitters.push_back(me);
+    }
+}
+
+/// mi_scene built from a live scene; owns the handle
+struct GpuScene {
+    mi_scene *scene = nullptr; int border = 0; Vector2i size;
+    ~GpuScene() { if (scene) mi_scene_destroy(scene); }
+    void build(const Scene *s, const Sensor *sensor, uint32_t device) {
+        FlatScene fs; flatten(s, fs);
+        if (scene) { mi_scene_destroy(scene); scene = nullptr; }
+        MI_CHECK(mi_scene_create(&scene));
+        MI_CHECK(mi_scene_set_triangles(scene, fs.pos.data(), fs.anyNormals ? fs.nrm.data() : NULL, NULL, fs.idx.data(),
+                                        (uint32_t) (fs.pos.size() / 3), (uint32_t) (fs.idx.size() / 3), fs.shapes.data(), (uint32_t) fs.shapes.size()));
+        MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
+        MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
+        // camera: rebuild m_sampleToCamera exactly as PerspectiveCameraImpl::configure does (perspective.cpp:150-157); it is a protected member
+        if (!sensor->getClass()->derivesFrom(MTS_CLASS(PerspectiveCamera))) SLog(EError, "path_hip: only the perspective camera is implemented");
+        const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
+        const Film *film = sensor->getFilm();
+        const Vector2i &filmSize = film->getSize(), &cropSize = film->getCropSize(); const Point2i &cropOffset = film->getCropOffset();
+        if (cropSize != filmSize || cropOffset != Point2i(0)) SLog(EError, "path_hip: crop windows are not implemented");
+        Float aspect = cam->getAspect();
+        Transform cameraToSample = Transform::scale(Vector(-0.5f, -0.5f * aspect, 1.0f)) * Transform::translate(Vector(-1.0f, -1.0f / aspect, 0.0f))
+                                 * Transform::perspective(cam->getXFov(), cam->getNearClip(), cam->getFarClip());
+        Matrix4x4 s2c = cameraToSample.inverse().getMatrix(), c2w = cam->getWorldTransform(0.0f).getMatrix();
+        float a[16], w[16]; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i * 4 + j] = s2c(i, j); w[i * 4 + j] = c2w(i, j); }
+        MI_CHECK(mi_scene_set_camera(scene, a, w, cam->getNearClip(), cam->getFarClip()));
+        const ReconstructionFilter *rf = film->getReconstructionFilter(); std::string fname = rf->getClass()->getName();
+        if (fname == "BoxFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 0, rf->getRadius() - 1e-5f, 0.5f));
+        else if (fname == "GaussianFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 1, 0.5f, rf->getRadius() / 4.0f));
+        else SLog(EError, "path_hip: reconstruction filter \"%s\" is not implemented (box, gaussian)", fname.c_str());
+        MI_CHECK(mi_scene_commit(scene, device));
+        border = rf->getBorderSize(); size = cropSize;
+    }
+};
+
+static mi355::Properties convertProps(const Properties &props, const Sampler *sampler) {
+    mi355::Properties p;
+    p.maxDepth = props.getInteger("maxDepth", -1); p.rrDepth = props.getInteger("rrDepth", 5);
+    p.strictNormals = props.getBoolean("strictNormals", false); p.hideEmitters = props.getBoolean("hideEmitters", false);
+    p.device = (uint32_t) props.getInteger("device", 0); p.planesPerBatch = (uint32_t) props.getInteger("planesPerBatch", 0);
+    p.sampleCount = (uint32_t) sampler->getSampleCount();
+    std::string sname = sampler->getClass()->getName();
+    if (sname == "SobolSampler") { p.sampler = MI_SAMPLER_SOBOL; p.seed = (uint64_t) sampler->getProperties().getSize("scramble", 0); }
+    else {   // `independent` (time-seeded SFMT in the reference) and anything else map to the seedable counter stream
+        p.sampler = MI_SAMPLER_INDEPENDENT; p.seed = (uint64_t) props.getSize("seed", 0);
+        if (sname != "IndependentSampler") SLog(EWarn, "path_hip: sampler \"%s\" is replaced by the independent counter stream", sname.c_str());
+    }
+    return p;
+}
+
+}  // namespace
+
+/// Responsive face (Integrator2): the object im-mts / `mitsuba` (responsive mode) drive from their worker threads
+class PathTracerHIPResponsive : public ResponsiveIntegrator {
+public:
+    PathTracerHIPResponsive(const Properties &props) : ResponsiveIntegrator(props) { }
+    bool preprocess(const Scene *scene, const Sensor *sensor, const Sampler *sampler) override {
+        m_host.reset(new mi355::MIPathTracerHIP(convertProps(getProperties(), sampler)));   // throws on bad rrDepth / maxDepth like the reference
+        m_gpu.build(scene, sensor, m_host->getProperties().device);
+        return m_host->preprocess(m_gpu.scene);
+    }
+    bool allocate(const Scene &, Sampler *const *, ImageBlock *const *, int threadCount) override { return m_host && m_host->allocate(threadCount); }
+    int render(const Scene &scene, const Sensor &sensor, Sampler &sampler, ImageBlock &target, Controls controls, int threadIdx, int threadCount) override {
+        if (threadIdx != 0) return 0;
+        struct Bridge : mi355::Interrupt {
+            PathTracerHIPResponsive *self; const Scene *scene; const Sensor *sensor; Sampler *sampler; ImageBlock *target; Controls controls;
+            int progress(mi355::MIPathTracerHIP *, const float *rgba, double spp, mi355::Controls, int ti, int tc) override {
+                self->publish(rgba, *target);
+                return controls.interrupt ? controls.interrupt->progress(self, *scene, *sensor, *sampler, *target, spp, controls, ti, tc) : 0;
+            }
+        } bridge; bridge.self = this; bridge.scene = &scene; bridge.sensor = &sensor; bridge.sampler = &sampler; bridge.target = &target; bridge.controls = controls;
+        m_rgba.resize((size_t) (m_gpu.size.x + 2 * m_gpu.border) * (m_gpu.size.y + 2 * m_gpu.border) * 4);
+        mi355::Controls c{controls.continu, controls.abort, &bridge};
+        int rc;
+        try { rc = m_host->render(m_rgba.data(), c, threadIdx, threadCount); }
+        catch (const std::exception &e) { Log(EError, "%s", e.what()); return -1; }
+        publish(m_rgba.data(), target);
+        return rc;
+    }
+    char const *getRealtimeStatistics() override { return m_host ? m_host->getRealtimeStatistics() : nullptr; }
+    /// copy the (H+2b)x(W+2b)x4 sums into the caller's ImageBlock (its own border may differ), plain stores
+    void publish(const float *rgba, ImageBlock &target) {
+        Bitmap *bmp = target.getBitmap(); const int tb = target.getBorderSize(), ch = bmp->getChannelCount();
+        const int W = m_gpu.size.x, H = m_gpu.size.y, gb = m_gpu.border, GW = W + 2 * gb, TW = bmp->getSize().x;
+        Float *dst = bmp->getFloatData();
+        for (int y = -std::min(gb, tb); y < H + std::min(gb, tb); ++y) for (int x = -std::min(gb, tb); x < W + std::min(gb, tb); ++x) {
+            const float *s = rgba + ((size_t) (y + gb) * GW + (x + gb)) * 4; Float *d = dst + ((size_t) (y + tb) * TW + (x + tb)) * ch;
+            for (int k = 0; k < std::min(ch, 4); ++k) d[k] = s[k];
+        }
+    }
+    MTS_DECLARE_CLASS()
+private:
+    std::unique_ptr<mi355::MIPathTracerHIP> m_host; GpuScene m_gpu; std::vector<float> m_rgba;
+};
+
+/// Classic face: what Scene::render (scene.cpp:475-479) calls from the RenderJob thread
+class PathTracerHIP : public MonteCarloIntegrator {
+public:
+    PathTracerHIP(const Properties &props) : MonteCarloIntegrator(props) { }
+    PathTracerHIP(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager) { }
+    Spectrum Li(const RayDifferential &, RadianceQueryRecord &) const {
+        Log(EError, "path_hip traces whole sample planes on the GPU; per-ray Li() is not offered -- use render() or makeResponsiveIntegrator()");
+        return Spectrum(0.0f);
+    }
+    bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int, int, int) {
+        ref<Sensor> sensor = scene->getSensor(); ref<Film> film = sensor->getFilm();
+        mi355::Properties hp = convertProps(getProperties(), scene->getSampler());
+        hp.opacity = film->hasAlpha();                                                  // integrator.cpp:160-161
+        m_host.reset(new mi355::MIPathTracerHIP(hp));
+        m_gpu.build(scene, sensor, m_host->getProperties().device);
+        m_host->preprocess(m_gpu.scene);
+        int stop = 0; mi355::Controls c{nullptr, &stop, nullptr};
+        int rc;
+        try { rc = m_host->render(nullptr, c, 0, 1); } catch (const std::exception &e) { Log(EError, "%s", e.what()); return false; }
+        if (rc != 0) return false;                                                      // cancelled
+        // deliver the raw ImageBlock sums (R,G,B,alpha,weight incl. border) exactly as BlockedRenderProcess::processResult would: Film::put
+        ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), film->getReconstructionFilter());
+        block->setOffset(Point2i(0));
+        if (mi_render_read_film(m_host->handle(), 0, block->getBitmap()->getFloatData()) != MI_OK) Log(EError, "path_hip: %s", mi_last_error());
+        film->put(block);
+        if (queue && job) queue->signalRefresh(job);
+        return true;
+    }
+    void cancel() { if (m_host) m_host->cancel(); }
+    ref<ResponsiveIntegrator> makeResponsiveIntegrator() { return new PathTracerHIPResponsive(getProperties()); }
+    std::string toString() const { return m_host ? m_host->toString() : std::string("MIPathTracerHIP[]"); }
+    MTS_DECLARE_CLASS()
+private:
+    std::unique_ptr<mi355::MIPathTracerHIP> m_host; GpuScene m_gpu;
+};
+
+MTS_IMPLEMENT_CLASS(PathTracerHIPResponsive, false, ResponsiveIntegrator)
+MTS_IMPLEMENT_CLASS_S(PathTracerHIP, false, MonteCarloIntegrator)
+MTS_EXPORT_PLUGIN(PathTracerHIP, "MI355X wavefront path tracer (HIP)");
+MTS_NAMESPACE_END
+
+// im-mts lists integrators by scanning plugin binaries for this marker (src/libcore/plugin.cpp:256-309, src/integrators/mark_integrator.cpp:3)
+extern "C" { MTS_EXPORT const char *mitsuba_integrator_plugin = "(: mitsuba_integrator_plugin :)"; }

@@ -55,6 +55,32 @@ int mi_set_sobol_tables(const uint32_t *m32, uint32_t dims, const uint64_t *vdc,
     return MI_OK;
 }
 
+// Reads mitsuba-im_amd/data/sobol_tables.bin ("MISOBOL1", dims, rows, matrices32[dims][52], vdc[rows][52], vdc_inv[rows][52]).
+int mi_load_sobol_tables(const char *path) {
+    FILE *f = fopen(path, "rb"); if (!f) return fail(MI_ERR_INVALID, std::string("mi_load_sobol_tables: cannot open ") + path);
+    char magic[8]; uint32_t hd[2]; bool ok = fread(magic, 1, 8, f) == 8 && !memcmp(magic, "MISOBOL1", 8) && fread(hd, 4, 2, f) == 2 && hd[1] == 16;
+    std::vector<uint32_t> m32; std::vector<uint64_t> vdc, vdi;
+    if (ok) { m32.resize((size_t) hd[0] * MI_SOBOL_SIZE); vdc.resize(16 * MI_SOBOL_SIZE); vdi.resize(16 * MI_SOBOL_SIZE);
+              ok = fread(m32.data(), 4, m32.size(), f) == m32.size() && fread(vdc.data(), 8, vdc.size(), f) == vdc.size() && fread(vdi.data(), 8, vdi.size(), f) == vdi.size(); }
+    fclose(f);
+    if (!ok) return fail(MI_ERR_INVALID, std::string("mi_load_sobol_tables: malformed file ") + path);
+    return mi_set_sobol_tables(m32.data(), hd[0], vdc.data(), vdi.data());
+}
+}  // extern "C"
+#include <dlfcn.h>
+// hosts that never call mi_set_sobol_tables (the adapter plugin): look for data/sobol_tables.bin next to this shared library
+static void ensureSobolTables() {
+    if (g_sobolDims) return;
+    const char *env = getenv("MI355PT_DATA");
+    if (env && mi_load_sobol_tables((std::string(env) + "/sobol_tables.bin").c_str()) == MI_OK) return;
+    Dl_info info;
+    if (dladdr((void *) &mi_set_sobol_tables, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname); size_t slash = dir.rfind('/'); dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+        (void) mi_load_sobol_tables((dir + "/data/sobol_tables.bin").c_str());
+    }
+}
+extern "C" {
+
 // ------------------------------------------------------------------------------------------------ scene
 int mi_scene_create(mi_scene **out) { if (!out) return fail(MI_ERR_INVALID, "mi_scene_create: out is null"); *out = new mi_scene(); return MI_OK; }
 void mi_scene_destroy(mi_scene *s) { delete s; }
@@ -166,6 +192,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     }
     for (const mi_emitter &e : s->h.emitters) if (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
     if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
+    ensureSobolTables();
     s->h.commitHost();
     if (mi::bvhDepthOf(s->h.nodes, 0) > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
     int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
@@ -221,7 +248,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     }
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
-    r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters;
+    r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
     r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u;
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch

@@ -1,0 +1,91 @@
+// integrator_host.cpp -- see integrator_host.h
+#include "integrator_host.h"
+#include <cstdio>
+
+namespace mi355 {
+
+static void check(int rc, const char *what) {
+    if (rc != MI_OK) throw std::runtime_error(std::string(what) + ": " + mi_last_error());
+}
+
+MIPathTracerHIP::MIPathTracerHIP(const Properties &props) : m_props(props) {
+    if (m_props.rrDepth <= 0) throw std::runtime_error("'rrDepth' must be set to a value greater than zero!");                          // integrator.cpp:221-222
+    if (m_props.maxDepth <= 0 && m_props.maxDepth != -1)
+        throw std::runtime_error("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");                            // integrator.cpp:224-225
+}
+MIPathTracerHIP::~MIPathTracerHIP() { if (m_render) mi_render_destroy(m_render); }
+
+bool MIPathTracerHIP::preprocess(mi_scene *scene) {
+    if (m_render) { mi_render_destroy(m_render); m_render = nullptr; }
+    m_scene = scene;
+    mi_render_params p{};
+    p.max_depth = m_props.maxDepth; p.rr_depth = m_props.rrDepth; p.strict_normals = m_props.strictNormals; p.hide_emitters = m_props.hideEmitters;
+    p.sampler = (uint32_t) m_props.sampler; p.spp = m_props.sampleCount; p.seed = m_props.seed; p.device = m_props.device; p.planes_per_batch = m_props.planesPerBatch; p.opacity = m_props.opacity ? 1 : 0;
+    check(mi_render_create(scene, &p, &m_render), "MIPathTracerHIP::preprocess");
+    return true;
+}
+bool MIPathTracerHIP::allocate(int threadCount) { m_threads = threadCount; return m_render != nullptr; }
+
+int MIPathTracerHIP::render(float *target, Controls controls, int threadIdx, int threadCount) {
+    if (threadIdx != 0) return 0;
+    if (!m_render) throw std::runtime_error("MIPathTracerHIP::render: preprocess() was not called");
+    check(mi_render_clear(m_render), "MIPathTracerHIP::render");
+    uint32_t h, w, c, b; check(mi_render_film_size(m_render, 1, &h, &w, &c, &b), "MIPathTracerHIP::render");
+    const uint32_t spp = m_props.sampleCount;
+    uint32_t planes = m_props.planesPerBatch ? m_props.planesPerBatch : std::max<uint32_t>(1, (16u << 20) / ((w - 2 * b) * (h - 2 * b)));
+    mi_tile tile{0, 0, w - 2 * b, h - 2 * b};
+    for (uint32_t s = 0; s < spp; s += planes) {
+        if (controls.abort && *controls.abort) return -1;
+        if (controls.continu && !*controls.continu) return -2;
+        if (controls.interrupt) { int rc = controls.interrupt->progress(this, target, (double) s, controls, threadIdx, threadCount); if (rc != 0) return rc; }
+        int rc = mi_render_run(m_render, tile, s, std::min(spp, s + planes));
+        if (rc == MI_CANCELLED) return -1;
+        check(rc, "MIPathTracerHIP::render");
+        if (target) check(mi_render_read_film(m_render, 1, target), "MIPathTracerHIP::render");
+    }
+    return 0;
+}
+void MIPathTracerHIP::cancel() { if (m_render) mi_render_cancel(m_render); }
+
+const char *MIPathTracerHIP::getRealtimeStatistics() {
+    if (!m_render) return nullptr;
+    mi_stats st{}; if (mi_render_stats(m_render, &st) != MI_OK) return nullptr;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%.1f Msamples/s | %.2f rays/sample | %.2f shadow rays/sample | avg path length %.2f",
+             st.render_ms > 0 ? st.samples / st.render_ms * 1e-3 : 0.0, st.samples ? (double) st.rays / st.samples : 0.0,
+             st.samples ? (double) st.shadow_rays / st.samples : 0.0, st.samples ? (double) st.path_length_sum / st.samples : 0.0);
+    m_stats = buf; return m_stats.c_str();
+}
+std::string MIPathTracerHIP::toString() const {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "MIPathTracerHIP[\n  maxDepth = %d,\n  rrDepth = %d,\n  strictNormals = %d\n]", m_props.maxDepth, m_props.rrDepth, (int) m_props.strictNormals);
+    return buf;
+}
+
+}  // namespace mi355
+
+// C shim so the host mirror can be driven from the ctypes tests (no new functionality: thin calls into the class above)
+extern "C" {
+struct mi_host_integrator { mi355::MIPathTracerHIP *p; std::string err; };
+static thread_local std::string g_hostErr;
+const char *mi_host_last_error(void) { return g_hostErr.c_str(); }
+void *mi_host_create(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, uint32_t device, uint32_t planes) {
+    try {
+        mi355::Properties pr; pr.maxDepth = maxDepth; pr.rrDepth = rrDepth; pr.strictNormals = strictNormals != 0; pr.hideEmitters = hideEmitters != 0;
+        pr.sampler = sampler; pr.sampleCount = spp; pr.seed = seed; pr.device = device; pr.planesPerBatch = planes;
+        return new mi355::MIPathTracerHIP(pr);
+    } catch (const std::exception &e) { g_hostErr = e.what(); return nullptr; }
+}
+void mi_host_destroy(void *h) { delete (mi355::MIPathTracerHIP *) h; }
+int mi_host_preprocess(void *h, mi_scene *scene) { try { return ((mi355::MIPathTracerHIP *) h)->preprocess(scene) ? 0 : 1; } catch (const std::exception &e) { g_hostErr = e.what(); return 2; } }
+namespace { struct CbInterrupt : mi355::Interrupt { int (*cb)(double, void *); void *user; int progress(mi355::MIPathTracerHIP *, const float *, double spp, mi355::Controls, int, int) override { return cb ? cb(spp, user) : 0; } }; }
+int mi_host_render(void *h, float *target, const int *continu, const int *abortFlag, int (*progress)(double, void *), void *user, int threadIdx, int threadCount) {
+    try {
+        CbInterrupt in; in.cb = progress; in.user = user;
+        mi355::Controls c{continu, abortFlag, progress ? &in : nullptr};
+        return ((mi355::MIPathTracerHIP *) h)->render(target, c, threadIdx, threadCount);
+    } catch (const std::exception &e) { g_hostErr = e.what(); return 1000; }
+}
+void mi_host_cancel(void *h) { ((mi355::MIPathTracerHIP *) h)->cancel(); }
+const char *mi_host_statistics(void *h) { return ((mi355::MIPathTracerHIP *) h)->getRealtimeStatistics(); }
+}

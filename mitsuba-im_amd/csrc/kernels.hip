@@ -132,7 +132,7 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
         q.st1[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);      // throughput rgb, eta
         q.st2[0][slot] = 0.0f;                                      // bsdfPdf of the segment that produced this ray
         q.pos[pid] = make_float2(sx, sy);
-        q.acc[pid] = make_float4(0, 0, 0, 0);
+        q.acc[pid] = make_float4(0, 0, 0, 1.0f);        // Li rgb, alpha (newQuery: alpha = 1, integrator.h:223-229)
     }
     if (tid == 0) q.count[0][seg] = n;
     }
@@ -200,7 +200,11 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             const uint32_t prim = __float_as_uint(hr.w);
             v3 add = V(0, 0, 0); bool haveAdd = false;
             do {
-                if (prim == 0xFFFFFFFFu) { pathLen += (unsigned) (depth > 1 ? depth - 1 : 1); break; }   // miss: path.cpp:136-143 / :246
+                if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :246
+                    pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
+                    if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
+                    break;
+                }
                 Hit h; fillHit(sc, d, hr.x, prim, hr.y, hr.z, h);
                 if (depth > 1) {
                     if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, 
     for (uint32_t s = 0; s < bd.n_planes; ++s) {
         const uint64_t pid = (uint64_t) s * bd.n_pix + pl;
         float4 li = q.acc[pid]; float2 sp = q.pos[pid];
-        float vals[5] = {li.x, li.y, li.z, 1.0f, 1.0f};
+        float vals[5] = {li.x, li.y, li.z, li.w, 1.0f};
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < 5; ++k) bad |= (!isfinite(vals[k]) || vals[k] < 0);

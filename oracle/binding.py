@@ -30,7 +30,7 @@ class OrcSceneDesc(C.Structure):
                 ("sample_to_camera", C.c_float * 16), ("cam_to_world", C.c_float * 16),
                 ("near_clip", C.c_float), ("far_clip", C.c_float), ("width", C.c_uint32), ("height", C.c_uint32),
                 ("filter", C.c_uint32), ("filter_radius", C.c_float), ("filter_stddev", C.c_float),
-                ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
+                ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32), ("opacity", C.c_uint32),
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float)]
@@ -115,7 +115,7 @@ def pack_records(sc):
 class Oracle:
     """Owns an orc_scene built from a flattened scene."""
 
-    def __init__(self, sc):
+    def __init__(self, sc, opacity=False):
         L = lib()
         self.sc = sc
         self._keep = []
@@ -132,6 +132,7 @@ class Oracle:
         d.filter, d.filter_radius, d.filter_stddev = sc.filter, sc.filter_radius, sc.filter_stddev
         d.max_depth, d.rr_depth, d.strict_normals, d.hide_emitters = sc.max_depth, sc.rr_depth, sc.strict_normals, sc.hide_emitters
         d.sampler, d.spp, d.seed = sc.sampler, sc.spp, sc.seed
+        d.opacity = int(opacity)
         d.sobol_matrices32, d.sobol_dims, d.sobol_vdc, d.sobol_vdc_inv = _ptr(m32), m32.shape[0], _ptr(vdc), _ptr(vdci)
         if sc.envmap is not None:
             rgb = np.ascontiguousarray(sc.envmap["rgb"], dtype=np.float32); self._keep.append(rgb)

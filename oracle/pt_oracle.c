@@ -536,13 +536,14 @@ void orc_sample_emitter_direct(const orc_scene *s, const float *rp, const float 
 static inline float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   /* path.cpp:296-300 */
 
 /* src/integrators/path/path.cpp:119-294 MIPathTracer::Li (no media, no subsurface) */
-static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters) {
+static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters, float *alpha) {
     const int maxDepth = s->d.max_depth, rrDepth = s->d.rr_depth;
     const int strict = s->d.strict_normals != 0, hide = s->d.hide_emitters != 0;
     hit_t its; v3 Li = V(0, 0, 0); int scattered = 0; int depth = 1;
     int emitted_radiance = 1;                           /* rRec.type & EEmittedRadiance; cleared after the first bounce (path.cpp:274) */
     ++counters[0];
     ray_intersect(s, o, d, mint, maxt, &its, 0);        /* records.inl:117-145 */
+    *alpha = (s->d.opacity && !its.valid) ? 0.0f : 1.0f; /* records.inl:121-137 (no media): EOpacity -> 1 on a hit, 0 on a miss; else newQuery's 1 */
     v3 throughput = V(1, 1, 1); float eta = 1.0f;
     while (depth <= maxDepth || maxDepth < 0) {
         if (!its.valid) break;                           /* no environment emitter on this path yet */
@@ -606,21 +607,21 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
 }
 
 /* one pixel sample: src/librender/integrator.cpp:171-186 (renderBlock body) */
-static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t sidx, float *pos, int *depth, uint64_t *counters, float *log, int *nlog) {
+static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t sidx, float *pos, int *depth, uint64_t *counters, float *log, int *nlog, float *alpha) {
     sampler_t sp; sampler_begin(&sp, s, px, py, sidx, log);
     float jx, jy; next2D(&sp, &jx, &jy);
     pos[0] = (float) (int32_t) px + jx; pos[1] = (float) (int32_t) py + jy;
     v3 o, d; float mint, maxt; camera_ray(s, pos[0], pos[1], &o, &d, &mint, &maxt);
-    v3 li = path_li(s, o, d, mint, maxt, &sp, depth, counters);
+    v3 li = path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha);
     if (nlog) *nlog = sp.nlog;
     return li;
 }
 void orc_render_samples(const orc_scene *s, const uint32_t *pairs, uint64_t n, float *out_li, float *out_pos, int32_t *out_depth, int32_t *out_nvals, float *out_vals) {
     uint64_t counters[3] = {0, 0, 0};
     for (uint64_t i = 0; i < n; ++i) {
-        int depth = 0, nlog = 0; float pos[2];
+        int depth = 0, nlog = 0; float pos[2], alpha;
         if (out_vals) for (int k = 0; k < 64; ++k) out_vals[i * 64 + k] = -1.0f;
-        v3 li = pixel_sample(s, pairs[i * 3], pairs[i * 3 + 1], pairs[i * 3 + 2], pos, &depth, counters, out_vals ? &out_vals[i * 64] : NULL, &nlog);
+        v3 li = pixel_sample(s, pairs[i * 3], pairs[i * 3 + 1], pairs[i * 3 + 2], pos, &depth, counters, out_vals ? &out_vals[i * 64] : NULL, &nlog, &alpha);
         out_li[i * 3] = li.x; out_li[i * 3 + 1] = li.y; out_li[i * 3 + 2] = li.z;
         if (out_pos) { out_pos[i * 2] = pos[0]; out_pos[i * 2 + 1] = pos[1]; }
         if (out_depth) out_depth[i] = depth;
@@ -664,9 +665,9 @@ static void *image_worker(void *arg) {
     for (uint32_t y = j->y0 + (uint32_t) j->tid; y < j->y1; y += (uint32_t) j->nthreads)
         for (uint32_t x = 0; x < s->d.width; ++x)
             for (uint32_t k = j->s0; k < j->s1; ++k) {
-                float pos[2]; int depth;
-                v3 li = pixel_sample(s, x, y, k, pos, &depth, j->counters, NULL, NULL);
-                film_put(s, j->film, pos[0], pos[1], li, 1.0f);
+                float pos[2], alpha; int depth;
+                v3 li = pixel_sample(s, x, y, k, pos, &depth, j->counters, NULL, NULL, &alpha);
+                film_put(s, j->film, pos[0], pos[1], li, alpha);
             }
     return NULL;
 }

@@ -493,6 +493,45 @@ static void modeUnits(Built &b, const FScene &fs, const std::string &out) {
     save(out + "_bsdf.npy", "<f4", {bs.size() / 24, 24}, bs);
 }
 
+// Drop-in check: drive ANY integrator plugin (the reference's own `path`, or the MI355X adapter `path_hip`) through the responsive
+// interface exactly as src/mitsuba/im_render.cpp:103-222 does (preprocess -> allocate -> render(..., controls, threadIdx, threadCount)),
+// one thread, and dump the target ImageBlock (un-normalised RGBA sums) + the return code + the spp values progress() was called with.
+#include <mitsuba/render/integrator2.h>
+struct CountingInterrupt : ResponsiveIntegrator::Interrupt {
+    std::vector<double> calls; int stopAfter = -1;
+    int progress(ResponsiveIntegrator *, const Scene &, const Sensor &, Sampler &, ImageBlock &, double spp, ResponsiveIntegrator::Controls, int, int) override {
+        calls.push_back(spp); return (stopAfter >= 0 && (int) calls.size() > stopAfter) ? 101 : 0;
+    }
+};
+static void modeResponsive(Built &b, const FScene &fs, const std::string &plugin, int stopAfter, const std::string &out) {
+    Properties p(plugin); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
+    p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
+    if (fs.sampler == 0) p.setSize("seed", (size_t) fs.seed);
+    if (plugin != "path") p.setInteger("planesPerBatch", 4);   // several progress() calls on small films
+    ref<Integrator> integ = static_cast<Integrator *>(create(MTS_CLASS(Integrator), p));
+    integ->configure();
+    ref<ResponsiveIntegrator> resp = integ->makeResponsiveIntegrator();
+    if (!resp) { fprintf(stderr, "plugin %s has no responsive face\n", plugin.c_str()); _exit(3); }
+    ref<Sampler> sampler = b.sampler->clone();
+    integ->configureSampler(b.scene, sampler);
+    ref<ImageBlock> target = new ImageBlock(Bitmap::ESpectrumAlpha, b.film->getCropSize(), b.filter); target->clear();
+    Sampler *sp = sampler.get(); ImageBlock *tp = target.get();
+    ref<Timer> timer = new Timer();
+    resp->preprocess(b.scene, b.sensor, sampler);
+    resp->allocate(*b.scene, &sp, &tp, 1);
+    CountingInterrupt in; in.stopAfter = stopAfter; int continu = 1, abortFlag = 0;
+    ResponsiveIntegrator::Controls c{&continu, &abortFlag, &in};
+    int rc = resp->render(*b.scene, *b.sensor, *sampler, *target, c, 0, 1);
+    double sec = timer->getMicroseconds() * 1e-6;
+    const Bitmap *bmp = target->getBitmap();
+    std::vector<float> data(bmp->getFloatData(), bmp->getFloatData() + (size_t) bmp->getSize().x * bmp->getSize().y * bmp->getChannelCount());
+    save(out + "_target.npy", "<f4", {(size_t) bmp->getSize().y, (size_t) bmp->getSize().x, (size_t) bmp->getChannelCount()}, data);
+    std::vector<double> meta; meta.push_back(rc); meta.push_back(sec); meta.push_back((double) in.calls.size()); for (double v : in.calls) meta.push_back(v);
+    save(out + "_meta.npy", "<f8", {meta.size()}, meta);
+    const char *st = resp->getRealtimeStatistics();
+    printf("responsive[%s]: rc %d, %.3f s, %zu progress calls%s%s\n", plugin.c_str(), rc, sec, in.calls.size(), st ? ", " : "", st ? st : "");
+}
+
 int main(int argc, char **argv) {
     Class::staticInitialization();
     Object::staticInitialization();
@@ -505,7 +544,7 @@ int main(int argc, char **argv) {
     // Bitmap::staticInitialization() only initialises FormatConverter (fmtconv.cpp needs boost::mpl, absent) -> skipped; nothing here converts bitmaps.
     Scheduler::staticInitialization();
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
-    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out>\n"); _exit(1); }
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
     FScene fs = loadScene(argv[1]);
@@ -516,6 +555,7 @@ int main(int argc, char **argv) {
     else if (mode == "hits") modeHits(b, fs, atoi(argv[3]), argv[4]);
     else if (mode == "camera") modeCamera(b, fs, argv[3]);
     else if (mode == "units") modeUnits(b, fs, argv[3]);
+    else if (mode == "responsive") modeResponsive(b, fs, argv[3], atoi(argv[4]), argv[5]);
     else { fprintf(stderr, "unknown mode\n"); _exit(1); }
     fflush(stdout);
     _exit(0);   // skip the static shutdown sequence (the process hangs in thread cleanup otherwise)

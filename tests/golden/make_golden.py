@@ -57,6 +57,11 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
+        if name == "cornell_small":
+            # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
+            # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
+            run(path, "responsive", "path", -1, base + "_resp")
+            np.savez_compressed(os.path.join(OUT, name + "_responsive.npz"), target=np.load(base + "_resp_target.npy"), meta=np.load(base + "_resp_meta.npy"))
         if sc.width < 200:
             run(path, "image", 8, base)
             stats = open(base + "_stats.txt").read()

@@ -1,0 +1,64 @@
+"""GPU: the drop-in boundary end to end.  The adapter plugin (mitsuba-im_amd/csrc/adapter/path_hip.cpp, built against the reference's
+headers) is loaded by the REFERENCE's own PluginManager inside oracle/_ref/harness and driven through the reference's responsive interface
+(preprocess -> allocate -> render(..., Controls, threadIdx, threadCount)) exactly like `path`; its target ImageBlock must match the one the
+reference's `path` plugin produced through the same driver (fixture tests/golden/cornell_small_responsive.npz)."""
+import os
+import subprocess
+import numpy as np
+import pytest
+from tests.conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness")
+PLUGIN = os.path.join(ROOT, "oracle", "_ref", "plugins", "path_hip.so")
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
+def test_plugin_drop_in_through_reference_driver(mi, golden_scenes, tmp_path):
+    sc = golden_scenes["cornell_small"]
+    path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path)
+    out = str(tmp_path / "hip")
+    subprocess.run([HARNESS, path, "responsive", "path_hip", "-1", out], cwd=os.path.dirname(HARNESS), check=True, timeout=300)
+    got = np.load(out + "_target.npy"); meta = np.load(out + "_meta.npy")
+    ref = np.load(os.path.join(GOLDEN, "cornell_small_responsive.npz"))["target"]
+    assert meta[0] == 0                                   # return code 0 = all sample planes done (integrator.cpp:349-401)
+    assert meta[2] == 4 and list(meta[3:7]) == [0.0, 4.0, 8.0, 12.0]   # one per 4-plane batch;               # progress() called, first call at the start of plane 0
+    assert got.shape == ref.shape == (sc.height + 2, sc.width + 2, 4)
+    # interior without the last row/column: the reference's ImageOrderIntegrator also enumerates the bitmap's BORDER cells as pixels
+    # (integrator.cpp:337-338 takes the bordered bitmap size as resolution), whose samples can splat into the last row/column
+    g, r = got[1:-2, 1:-2], ref[1:-2, 1:-2]
+    rel = np.abs(g - r).max(2) / (np.abs(r).max(2) + 1e-6)
+    assert (rel < 1e-4).mean() > 0.995                    # a handful of paths fork under the reference's -ffast-math
+    assert np.linalg.norm(g[..., :3] - r[..., :3]) / np.linalg.norm(r[..., :3]) < 1e-2
+    assert np.allclose(g[..., 3], r[..., 3], rtol=1e-5)   # alpha sums = spp x table weight
+    # external control: stop after two progress() calls -> the interrupt's value comes back as the return code
+    subprocess.run([HARNESS, path, "responsive", "path_hip", "1", out + "_stop"], cwd=os.path.dirname(HARNESS), check=True, timeout=300)
+    assert np.load(out + "_stop_meta.npy")[0] == 101
+
+
+def test_host_mirror_controls(mi, golden_scenes):
+    """C++ host mirror (csrc/integrator_host.cpp) through its C shim: return codes and error strings of the reference interface."""
+    import ctypes as C
+    L = mi.lib().L
+    L.mi_host_create.restype = C.c_void_p; L.mi_host_last_error.restype = C.c_char_p; L.mi_host_statistics.restype = C.c_char_p
+    L.mi_host_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.mi_host_preprocess.argtypes = [C.c_void_p, C.c_void_p]; L.mi_host_destroy.argtypes = [C.c_void_p]; L.mi_host_statistics.argtypes = [C.c_void_p]
+    CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_void_p)
+    L.mi_host_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), CB, C.c_void_p, C.c_int, C.c_int]
+    assert L.mi_host_create(8, 0, 0, 0, 1, 4, 0, 0, 0) is None and b"rrDepth" in L.mi_host_last_error()
+    assert L.mi_host_create(0, 5, 0, 0, 1, 4, 0, 0, 0) is None and b"maxDepth" in L.mi_host_last_error()
+    sc = golden_scenes["cornell_small"]; gs = mi.Scene(sc)
+    h = L.mi_host_create(sc.max_depth, sc.rr_depth, 0, 0, sc.sampler, sc.spp, 0, 0, 4)      # 4 planes per batch -> 4 batches
+    assert h and L.mi_host_preprocess(h, gs.h) == 0
+    target = np.zeros((sc.height + 2, sc.width + 2, 4), np.float32)
+    calls = []
+    cont, abort = C.c_int(1), C.c_int(0)
+    rc = L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: calls.append(spp) or 0), None, 0, 1)
+    assert rc == 0 and calls == [0.0, 4.0, 8.0, 12.0]
+    r = mi.Render(gs, opacity=True); r.run(); assert (r.read_film(1).view(np.uint32) == target.view(np.uint32)).all()
+    assert b"rays/sample" in L.mi_host_statistics(h)
+    assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 1, 4) == 0     # non-zero threads idle
+    abort.value = 1; assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 0, 1) == -1
+    abort.value = 0; cont.value = 0; assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 0, 1) == -2
+    cont.value = 1; assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 100 if spp >= 4 else 0), None, 0, 1) == 100
+    L.mi_host_destroy(h)

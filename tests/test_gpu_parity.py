@@ -158,3 +158,14 @@ def test_edge_cases_and_errors(mi, scenes):
         r.run(s0=0, s1=sc.spp + 1)
     # cancel flag is observed between batches and cleared by the next run
     r.cancel(); r.run(); assert r.stats()["samples"] > 0
+
+
+def test_opacity_alpha_channel(mi, oracle, golden_scenes):
+    """EOpacity (records.inl:121-137): alpha = 1 where the camera ray hits, 0 where it leaves the scene; off -> alpha = 1 everywhere."""
+    sc = golden_scenes["cornell_small"]
+    r = mi.Render(mi.Scene(sc), opacity=True); r.run(); film = r.read_film(0)
+    ofilm, _ = oracle.Oracle(sc, opacity=True).render_image(threads=4)
+    assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (bits(film) == bits(ofilm)).all(2).mean() > 0.99
+    assert film[1:-1, 1:-1, 3].min() < 0.5 * film[1:-1, 1:-1, 4].max()      # some camera rays miss at the left/right film edge
+    r2 = mi.Render(mi.Scene(sc)); r2.run(); f2 = r2.read_film(0)
+    assert np.allclose(f2[..., 3], f2[..., 4]) and np.allclose(f2[..., :3], film[..., :3], rtol=2e-6, atol=1e-7)
