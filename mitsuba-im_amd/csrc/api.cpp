@@ -102,7 +102,11 @@ int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, cons
 }
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
-    for (uint32_t i = 0; i < n; ++i) if (m[i].type != MI_BSDF_DIFFUSE) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: only `diffuse` (optionally `twosided`) is implemented so far");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (m[i].type > MI_BSDF_ROUGHCONDUCTOR) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: only `diffuse` and `roughconductor` (optionally `twosided`) are implemented");
+        if (m[i].type == MI_BSDF_ROUGHCONDUCTOR && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE)))
+            return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: roughconductor supports beckmann / ggx with sampleVisible = true");
+    }
     s->h.materials.assign(m, m + n); s->h.committed = false; return MI_OK;
 }
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *e, uint32_t n) {
@@ -172,6 +176,7 @@ int SceneHost::upload(int dev) {
     d.filter_radius = filterRadiusEff; d.filter_scale = filterScale; d.border = border;
     d.log_res = logRes; d.resolution = resolution;
     d.bvh_depth = (uint32_t) bvhDepthOf(nodes, 0);
+    d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type == MI_BSDF_ROUGHCONDUCTOR) d.has_roughconductor = 1;
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (tris.size() <= MI_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;
     committed = true;

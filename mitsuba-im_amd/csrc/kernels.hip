@@ -168,6 +168,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
+template <bool RC>   // RC: the scene contains rough conductors (keeps the diffuse-only kernel lean: registers, occupancy)
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_wave[2][WG / 64];
@@ -227,15 +228,15 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 if ((depth >= rc.max_depth && rc.max_depth > 0) || (rc.strict_normals && dot(d, h.ng) * h.wi.z >= 0)) { pathLen += (unsigned) depth; break; }
                 // emitter sampling (path.cpp:172-200)
                 v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;               // records.inl:160-164
-                {
+                if (!(h.flags & 4u)) {                                       // bsdf->getType() & BSDF::ESmooth
                     float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
                     Direct dr; v3 value = sampleEmitterDirect(sc, h.p, refN, sx, sy, dr);
                     if (dr.pdf != 0) {
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
-                        v3 bsdfVal = bsdfEval(bsdf, h.wi, wo);
+                        v3 bsdfVal = bsdfEval<RC>(bsdf, h.wi, wo);
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = bsdfPdf(bsdf, h.wi, wo);
+                            float bp = bsdfPdf<RC>(bsdf, h.wi, wo);
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
                             wantShadow = true;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 // BSDF sampling (path.cpp:207-226)
                 float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
                 float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                v3 bw = bsdfSample(bsdf, h.wi, sx, sy, woL, bPdf, bEta);
+                v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, woL, bPdf, bEta);
                 if (isZero(bw)) { pathLen += (unsigned) depth; break; }
                 v3 wo = toWorld(h, woL);
                 if (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0) { pathLen += (unsigned) depth; break; }
@@ -426,7 +427,8 @@ void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid,
 }
 void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
+    if (sc.has_roughconductor) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
 }
 void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     if (sc.packet_n) hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(WG), 0, st, sc, q);

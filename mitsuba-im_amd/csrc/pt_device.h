@@ -214,22 +214,188 @@ DEV void fillHit(const DScene &sc, v3 d, float t, uint32_t prim, float u, float 
 DEV v3 toWorld(const Hit &h, v3 w) { return (h.s * w.x + h.t * w.y) + h.ns * w.z; }
 DEV v3 toLocal(const Hit &h, v3 w) { return V(dot(w, h.s), dot(w, h.t), dot(w, h.ns)); }
 
+// ---------------------------------------------------------------------------------------------- rough conductor
+// src/bsdfs/roughconductor.cpp:260-416 over src/bsdfs/microfacet.h (isotropic alpha, Beckmann / GGX, visible-normal sampling).
+// exp/log/acos/atan2/tan/sin/cos/pow come from the device math library: this BSDF is tolerance-pinned, not bit-pinned.
+DEV float fastexpf_(float x) { return (float) exp((double) x); }      // math::fastexp on Linux/x86_64 (include/mitsuba/core/math.h:185-199)
+DEV float fastlogf_(float x) { return (float) log((double) x); }
+// src/libcore/math.cpp:25-53 erfinv, :55-72 erf
+DEV float miErfinv(float x) {
+    float w = -fastlogf_((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f; p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w; p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3.0f; p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w; p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+DEV float miErf(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    float sign = copysignf(1.0f, x); x = fabsf(x);
+    float t = 1.0f / (1.0f + p * x);
+    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * fastexpf_(-x * x);
+    return sign * y;
+}
+// microfacet.h:190-237
+DEV float mfEval(uint32_t distr, float alpha, v3 m) {
+    if (m.z <= 0) return 0.0f;
+    float cosTheta2 = m.z * m.z;
+    float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
+    float result;
+    if (distr == 0) result = fastexpf_(-beckmannExponent) / (MI_PI * alpha * alpha * cosTheta2 * cosTheta2);
+    else { float root = (1.0f + beckmannExponent) * cosTheta2; result = 1.0f / (MI_PI * alpha * alpha * root * root); }
+    if (result * m.z < 1e-20f) result = 0;
+    return result;
+}
+// microfacet.h:476-517 (+ math::hypot2, src/libcore/math.cpp:74-88)
+DEV float mfSmithG1(uint32_t distr, float alpha, v3 v, v3 m) {
+    if (dot(v, m) * v.z <= 0) return 0.0f;
+    float temp = 1 - v.z * v.z;
+    float tanTheta = temp <= 0.0f ? 0.0f : fabsf(sqrtf(temp) / v.z);
+    if (tanTheta == 0.0f) return 1.0f;
+    if (distr == 0) {
+        float a = 1.0f / (alpha * tanTheta);
+        if (a >= 1.6f) return 1.0f;
+        float aSqr = a * a;
+        return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+    }
+    float root = alpha * tanTheta, r;
+    if (1.0f > fabsf(root)) { r = root / 1.0f; r = 1.0f * sqrtf(1.0f + r * r); }
+    else if (root != 0.0f) { r = 1.0f / root; r = fabsf(root) * sqrtf(1.0f + r * r); }
+    else r = 0.0f;
+    return 2.0f / (1.0f + r);
+}
+// microfacet.h:572-700
+DEV void mfSampleVisible11(uint32_t distr, float thetaI, float sx, float sy, float &slx, float &sly) {
+    const float SQRT_PI_INV = 1 / sqrtf(MI_PI);
+    if (distr == 0) {
+        if (thetaI < 1e-4f) { float r = sqrtf(-fastlogf_(1.0f - sx)), ph = 2 * MI_PI * sy; slx = r * cosf(ph); sly = r * sinf(ph); return; }
+        float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
+        float a = -1, c = miErf(cotThetaI);
+        float sample_x = maxf(sx, 1e-6f);
+        float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+        float b = c - (1 + c) * powf(1 - sample_x, fit);
+        float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+        int it = 0;
+        while (++it < 10) {
+            if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+            float invErf = miErfinv(b);
+            float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+            float derivative = normalization * (1 - invErf * tanThetaI);
+            if (fabsf(value) < 1e-5f) break;
+            if (value > 0) c = b; else a = b;
+            b -= value / derivative;
+        }
+        slx = miErfinv(b);
+        sly = miErfinv(2.0f * maxf(sy, 1e-6f) - 1.0f);
+    } else {
+        if (thetaI < 1e-4f) { float r = sqrtf(maxf(sx / (1 - sx), 0.0f)), ph = 2 * MI_PI * sy; slx = r * cosf(ph); sly = r * sinf(ph); return; }
+        float tanThetaI = tanf(thetaI), a = 1 / tanThetaI;
+        float G1 = 2.0f / (1.0f + sqrtf(maxf(1.0f + 1.0f / (a * a), 0.0f)));
+        float A = 2.0f * sx / G1 - 1.0f;
+        if (fabsf(A) == 1) A -= copysignf(1.0f, A) * MI_EPSILON;
+        float tmp = 1.0f / (A * A - 1.0f), B = tanThetaI;
+        float D = sqrtf(maxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+        float s1 = B * tmp - D, s2 = B * tmp + D;
+        slx = (A < 0.0f || s2 > 1.0f / tanThetaI) ? s1 : s2;
+        float S;
+        if (sy > 0.5f) { S = 1.0f; sy = 2.0f * (sy - 0.5f); } else { S = -1.0f; sy = 2.0f * (0.5f - sy); }
+        float z = (sy * (sy * (sy * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                  (sy * (sy * (sy * (sy * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+        sly = S * z * sqrtf(1.0f + slx * slx);
+    }
+}
+// microfacet.h:420-466, :469-473
+DEV v3 mfSampleVisible(uint32_t distr, float alpha, v3 wi_, float sx, float sy) {
+    v3 wi = normalize(V(alpha * wi_.x, alpha * wi_.y, wi_.z));
+    float theta = 0, phi = 0;
+    if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    float slx, sly; mfSampleVisible11(distr, theta, sx, sy, slx, sly);
+    float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+    rx *= alpha; ry *= alpha;
+    float normalization = 1.0f / sqrtf(rx * rx + ry * ry + 1.0f);
+    return V(-rx * normalization, -ry * normalization, normalization);
+}
+DEV float mfPdfVisible(uint32_t distr, float alpha, v3 wi, v3 m) {
+    if (wi.z == 0) return 0.0f;
+    return mfSmithG1(distr, alpha, wi, m) * fabsf(dot(wi, m)) * mfEval(distr, alpha, m) / fabsf(wi.z);
+}
+// src/libcore/util.cpp:741-763, per RGB channel
+DEV v3 fresnelConductorExact(float cosThetaI, const float *eta, const float *k) {
+    float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    float out[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float temp1 = eta[i] * eta[i] - k[i] * k[i] - sinThetaI2;
+        float a2pb2 = sqrtf(maxf(temp1 * temp1 + k[i] * k[i] * eta[i] * eta[i] * 4, 0.0f));
+        float a = sqrtf(maxf((a2pb2 + temp1) * 0.5f, 0.0f));
+        float term1 = a2pb2 + cosThetaI2, term2 = a * (2 * cosThetaI);
+        float Rs2 = (term1 - term2) / (term1 + term2);
+        float term3 = a2pb2 * cosThetaI2 + sinThetaI4, term4 = term2 * sinThetaI2;
+        float Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+        out[i] = 0.5f * (Rp2 + Rs2);
+    }
+    return V(out[0], out[1], out[2]);
+}
+DEV v3 rcEval(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    float alpha = maxf(m.alpha, 1e-4f);
+    v3 H = normalize(wo + wi);
+    float D = mfEval(m.distr, alpha, H);
+    if (D == 0) return V(0, 0, 0);
+    v3 F = fresnelConductorExact(dot(wi, H), m.eta, m.k) * ld3(m.specular);
+    float G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H);
+    float model = D * G / (4.0f * wi.z);
+    return F * model;
+}
+DEV float rcPdf(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    float alpha = maxf(m.alpha, 1e-4f);
+    v3 H = normalize(wo + wi);
+    return mfEval(m.distr, alpha, H) * mfSmithG1(m.distr, alpha, wi, H) / (4.0f * wi.z);
+}
+DEV v3 rcSample(const MaterialD &mt, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta) {
+    if (wi.z < 0) return V(0, 0, 0);
+    float alpha = maxf(mt.alpha, 1e-4f);
+    v3 m = mfSampleVisible(mt.distr, alpha, wi, u, v);
+    pdf = mfPdfVisible(mt.distr, alpha, wi, m);
+    if (pdf == 0) return V(0, 0, 0);
+    float c = 2 * dot(wi, m);
+    wo = m * c - wi;
+    eta = 1.0f;
+    if (wo.z <= 0) return V(0, 0, 0);
+    v3 F = fresnelConductorExact(dot(wi, m), mt.eta, mt.k) * ld3(mt.specular);
+    float weight = mfSmithG1(mt.distr, alpha, wo, m);
+    pdf /= 4.0f * dot(wo, m);
+    return F * weight;
+}
+
 // ---------------------------------------------------------------------------------------------- BSDFs
 // src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side)
-DEV v3 bsdfEval(const MaterialD &m, v3 wi, v3 wo) {
+template <bool RC> DEV v3 bsdfEval(const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (RC && m.type == 1) return rcEval(m, wi, wo);
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
     float f = MI_INV_PI * wo.z;
     return V(m.reflectance[0] * f, m.reflectance[1] * f, m.reflectance[2] * f);
 }
-DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
+template <bool RC> DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    if (RC && m.type == 1) return rcPdf(m, wi, wo);
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
     return MI_INV_PI * wo.z;
 }
-DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta) {
+template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta) {
     bool flipped = false;
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; flipped = true; }
+    if (RC && m.type == 1) {
+        v3 w = rcSample(m, wi, u, v, wo, pdf, eta);
+        if (flipped && !isZero(w) && pdf != 0) wo.z = -wo.z;      // twosided.cpp:176-180
+        return w;
+    }
     if (wi.z <= 0) return V(0, 0, 0);
     wo = cosHemisphere(u, v); eta = 1.0f; pdf = MI_INV_PI * wo.z;
     if (flipped) wo.z = -wo.z;

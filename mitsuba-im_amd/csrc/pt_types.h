@@ -31,7 +31,7 @@ struct BvhNode {
 struct TriShade {
     float p0[3]; int32_t material;
     float p1[3]; int32_t emitter;
-    float p2[3]; uint32_t flags;          // bit0 face normals, bit1 material has a back side (twosided)
+    float p2[3]; uint32_t flags;          // bit0 face normals, bit1 material has a back side (twosided), bit2 BSDF without a smooth component (no NEE)
     float ng[3]; uint32_t local_prim;
     float s[3]; uint32_t i0;
     float t[3]; uint32_t i1;              // i0,i1,i2: vertex indices for smooth normals (i2 in `i2` array)
@@ -67,6 +67,7 @@ struct DScene {
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
     uint32_t packet_n, bvh_depth;
+    uint32_t has_roughconductor;          // selects the shade kernel variant
 };
 #define MI_PACKET_MAX 64
 

@@ -112,7 +112,10 @@ void SceneHost::commitHost() {
         ts.material = sh.bsdf; ts.emitter = sh.emitter;
         bool faceN = (sh.flags & 1u) || nrm.empty();
         bool backside = (materials[sh.bsdf].flags & MI_BSDF_FLAG_TWOSIDED) != 0;
-        ts.flags = (faceN ? 1u : 0u) | (backside ? 2u : 0u);
+        // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176)
+        const mi_material &mat = materials[sh.bsdf];
+        bool smooth = mat.type != MI_BSDF_DIFFUSE || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0;
+        ts.flags = (faceN ? 1u : 0u) | (backside ? 2u : 0u) | (smooth ? 0u : 4u);
         ts.local_prim = t - sh.first_tri; ts.i0 = a; ts.i1 = b; i2[t] = c;
         // face frame: skdtree.h:367-371 (face normal), util.cpp:605-610 (computeShadingFrame with dpdu = p1 - p0)
         V3 side1 = p1 - p0, side2 = p2 - p0, fn = cross(side1, side2);

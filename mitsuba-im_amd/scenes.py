@@ -190,6 +190,56 @@ def closed_box(width=128, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=8
                         width, height, spp, sampler, max_depth, name="closed_box")
 
 
+# conductor eta / k as linear RGB, produced by the reference itself from data/ior/<name>.{eta,k}.spd (RoughConductor constructor,
+# src/bsdfs/roughconductor.cpp:177-189; dumped by oracle/_ref/harness `tables` -> tests/golden/conductor_ior_rgb.npy)
+CONDUCTOR_IOR = {
+    "Cu": ((0.20043588, 0.9240331, 1.1022109), (3.9129362, 2.452853, 2.1421824)),
+    "Al": ((1.6574619, 0.88036764, 0.5212283), (9.223862, 6.2695246, 4.8370023)),
+    "Au": ((0.14312422, 0.3749563, 1.4424754), (3.9831533, 2.3857234, 1.6032081)),
+}
+
+
+def _disc(b, center, normal, radius, n=32):
+    """Triangle fan of n triangles, wound so that cross(p1-p0, p2-p0) points along `normal`."""
+    c = np.asarray(center, np.float64); nrm = np.asarray(normal, np.float64); nrm = nrm / np.linalg.norm(nrm)
+    t = np.cross(nrm, [1.0, 0.0, 0.0]); t = t / np.linalg.norm(t); bt = np.cross(nrm, t)
+    base = len(b.verts)
+    b.verts.append(tuple(map(float, c)))
+    for i in range(n):
+        a = 2.0 * math.pi * i / n
+        b.verts.append(tuple(map(float, c + radius * (math.cos(a) * t + math.sin(a) * bt))))
+    for i in range(n):
+        b.tris.append((base, base + 1 + i, base + 1 + (i + 1) % n))
+
+
+def veach_mis(width=1920, height=1080, spp=512, sampler=SAMPLER_SOBOL, max_depth=12, rr_depth=5, filter_kind=FILTER_BOX):
+    """S2: Veach's multiple-importance-sampling test -- four tilted plates of increasing roughness
+    (`twosided(roughconductor)`, Beckmann alpha 0.005 / 0.02 / 0.05 and GGX 0.1) reflecting four disc lights of radii
+    0.03 / 0.1 / 0.3 / 0.9 with power-equalised radiance, over a diffuse floor and back wall; 140 triangles."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.4, 0.4, 0.4))
+    al, cu = CONDUCTOR_IOR["Al"], CONDUCTOR_IOR["Cu"]
+    plates = [
+        ([(4, -2.70651, 0.25609), (4, -2.08375, -0.526323), (-4, -2.08375, -0.526323), (-4, -2.70651, 0.25609)], 0.005, DISTR_BECKMANN, al),
+        ([(4, -3.28825, 1.36972), (4, -2.83856, 0.476536), (-4, -2.83856, 0.476536), (-4, -3.28825, 1.36972)], 0.02, DISTR_BECKMANN, al),
+        ([(4, -3.73096, 2.70046), (4, -3.43378, 1.74564), (-4, -3.43378, 1.74564), (-4, -3.73096, 2.70046)], 0.05, DISTR_BECKMANN, cu),
+        ([(4, -3.99615, 4.0667), (4, -3.82069, 3.08221), (-4, -3.82069, 3.08221), (-4, -3.99615, 4.0667)], 0.1, DISTR_GGX, cu),
+    ]
+    b.begin(); b.quad([(-10, -4.14615, -10), (-10, -4.14615, 10), (10, -4.14615, 10), (10, -4.14615, -10)]); b.end(grey)     # floor (+y)
+    b.begin(); b.quad([(-10, -10, -2), (10, -10, -2), (10, 10, -2), (-10, 10, -2)]); b.end(grey)                           # back wall (+z)
+    for pts, alpha, distr, (eta, k) in plates:
+        m = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, twosided=True, alpha=alpha, distr=distr, eta=eta, k=k)
+        b.begin(); b.quad(pts); b.end(m)
+    lightm = b.bsdf(reflectance=(0.0, 0.0, 0.0))
+    for x, r, tint in [(-3.75, 0.03, (1.0, 0.6, 0.6)), (-1.25, 0.1, (1.0, 1.0, 0.6)), (1.25, 0.3, (0.6, 1.0, 0.6)), (3.75, 0.9, (0.6, 0.6, 1.0))]:
+        rad = 8.0 / (math.pi * r * r)
+        b.begin(); _disc(b, (x, 0.0, 0.0), (0.0, -0.8, 0.6), r); b.end(lightm, radiance=tuple(rad * t for t in tint))
+    b.begin(); b.quad([(-3, 8, 0), (3, 8, 0), (3, 8, 6), (-3, 8, 6)]); b.end(lightm, radiance=(1.5, 1.5, 1.5))             # dim fill light (-y)
+    cam = look_at((0, 2, 15), (0, -2, 2.5), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 28.0, 0.1, 100.0,
+                        width, height, spp, sampler, max_depth, rr_depth, filter_kind, name="veach_mis")
+
+
 # ---------------------------------------------------------------------------------------------
 # binary container for the oracle-side harness
 # ---------------------------------------------------------------------------------------------

@@ -416,6 +416,12 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0; }
+/* BSDF::ESmooth: a `diffuse` whose reflectance is identically zero registers NO component (src/bsdfs/diffuse.cpp:99-102), so its type
+ * is 0 and MIPathTracer::Li skips emitter sampling -- and the sampler request that goes with it (path.cpp:174-176) */
+static int material_is_smooth(const orc_material *m) {
+    if (m->type == 0) return maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;
+    return 1;
+}
 
 /* src/bsdfs/diffuse.cpp:112-153 */
 static v3 diffuse_eval(const orc_material *m, v3 wi, v3 wo) {
@@ -429,20 +435,189 @@ static v3 diffuse_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo,
     *wo = cos_hemisphere(u, v); *eta = 1.0f; *pdf = INV_PI * wo->z;
     return V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
 }
+/* ---- rough conductor: src/bsdfs/roughconductor.cpp:260-416 over src/bsdfs/microfacet.h (isotropic alpha, Beckmann / GGX,
+ * visible-normal sampling).  Transcendentals come from libm here and from the GPU math library on the device, so this BSDF is
+ * tolerance-pinned (not bit-pinned) between oracle and HIP path; math::fastexp/fastlog are double exp/log in the reference
+ * (include/mitsuba/core/math.h:185-199). */
+static inline float fastexpf_(float x) { return (float) exp((double) x); }
+static inline float fastlogf_(float x) { return (float) log((double) x); }
+/* src/libcore/math.cpp:25-53 erfinv (Giles), :55-72 erf (A&S 7.1.26) */
+static float mi_erfinv(float x) {
+    float w = -fastlogf_((1.0f - x) * (1.0f + x)), p;
+    if (w < 5.0f) {
+        w = w - 2.5f; p = 2.81022636e-08f; p = 3.43273939e-07f + p * w; p = -3.5233877e-06f + p * w; p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w; p = -0.00125372503f + p * w; p = -0.00417768164f + p * w; p = 0.246640727f + p * w; p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3.0f; p = -0.000200214257f; p = 0.000100950558f + p * w; p = 0.00134934322f + p * w; p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w; p = -0.0076224613f + p * w; p = 0.00943887047f + p * w; p = 1.00167406f + p * w; p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+static float mi_erf(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    float sign = copysignf(1.0f, x); x = fabsf(x);
+    float t = 1.0f / (1.0f + p * x);
+    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * fastexpf_(-x * x);
+    return sign * y;
+}
+/* microfacet.h:190-237 eval (isotropic) */
+static float mf_eval(uint32_t distr, float alpha, v3 m) {
+    if (m.z <= 0) return 0.0f;
+    float cosTheta2 = m.z * m.z;
+    float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
+    float result;
+    if (distr == 0) result = fastexpf_(-beckmannExponent) / (M_PI_F * alpha * alpha * cosTheta2 * cosTheta2);
+    else { float root = (1.0f + beckmannExponent) * cosTheta2; result = 1.0f / (M_PI_F * alpha * alpha * root * root); }
+    if (result * m.z < 1e-20f) result = 0;
+    return result;
+}
+/* microfacet.h:476-517 smithG1 (isotropic: projectRoughness = alpha) */
+static float mf_smith_g1(uint32_t distr, float alpha, v3 v, v3 m) {
+    if (dot(v, m) * v.z <= 0) return 0.0f;
+    float temp = 1 - v.z * v.z;
+    float tanTheta = temp <= 0.0f ? 0.0f : fabsf(sqrtf(temp) / v.z);       /* frame.h:122-127 */
+    if (tanTheta == 0.0f) return 1.0f;
+    if (distr == 0) {
+        float a = 1.0f / (alpha * tanTheta);
+        if (a >= 1.6f) return 1.0f;
+        float aSqr = a * a;
+        return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+    } else {
+        float root = alpha * tanTheta;
+        /* math::hypot2(1, root), src/libcore/math.cpp:74-88 */
+        float r;
+        if (1.0f > fabsf(root)) { r = root / 1.0f; r = 1.0f * sqrtf(1.0f + r * r); }
+        else if (root != 0.0f) { r = 1.0f / root; r = fabsf(root) * sqrtf(1.0f + r * r); }
+        else r = 0.0f;
+        return 2.0f / (1.0f + r);
+    }
+}
+/* microfacet.h:572-700 sampleVisible11 */
+static void mf_sample_visible11(uint32_t distr, float thetaI, float sx, float sy, float *slx, float *sly) {
+    const float SQRT_PI_INV = 1 / sqrtf(M_PI_F);
+    if (distr == 0) {
+        if (thetaI < 1e-4f) {
+            float r = sqrtf(-fastlogf_(1.0f - sx)), ph = 2 * M_PI_F * sy;
+            *slx = r * cosf(ph); *sly = r * sinf(ph); return;
+        }
+        float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
+        float a = -1, c = mi_erf(cotThetaI);
+        float sample_x = maxf(sx, 1e-6f);
+        float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+        float b = c - (1 + c) * powf(1 - sample_x, fit);
+        float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+        int it = 0;
+        while (++it < 10) {
+            if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+            float invErf = mi_erfinv(b);
+            float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+            float derivative = normalization * (1 - invErf * tanThetaI);
+            if (fabsf(value) < 1e-5f) break;
+            if (value > 0) c = b; else a = b;
+            b -= value / derivative;
+        }
+        *slx = mi_erfinv(b);
+        *sly = mi_erfinv(2.0f * maxf(sy, 1e-6f) - 1.0f);
+    } else {
+        if (thetaI < 1e-4f) {
+            float r = sqrtf(maxf(sx / (1 - sx), 0.0f)), ph = 2 * M_PI_F * sy;
+            *slx = r * cosf(ph); *sly = r * sinf(ph); return;
+        }
+        float tanThetaI = tanf(thetaI), a = 1 / tanThetaI;
+        float G1 = 2.0f / (1.0f + sqrtf(maxf(1.0f + 1.0f / (a * a), 0.0f)));
+        float A = 2.0f * sx / G1 - 1.0f;
+        if (fabsf(A) == 1) A -= copysignf(1.0f, A) * EPSILON;
+        float tmp = 1.0f / (A * A - 1.0f), B = tanThetaI;
+        float D = sqrtf(maxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+        float slope_x_1 = B * tmp - D, slope_x_2 = B * tmp + D;
+        *slx = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+        float S;
+        if (sy > 0.5f) { S = 1.0f; sy = 2.0f * (sy - 0.5f); } else { S = -1.0f; sy = 2.0f * (0.5f - sy); }
+        float z = (sy * (sy * (sy * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                  (sy * (sy * (sy * (sy * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+        *sly = S * z * sqrtf(1.0f + *slx * *slx);
+    }
+}
+/* microfacet.h:420-466 sampleVisible */
+static v3 mf_sample_visible(uint32_t distr, float alpha, v3 wi_, float sx, float sy) {
+    v3 wi = normalize(V(alpha * wi_.x, alpha * wi_.y, wi_.z));
+    float theta = 0, phi = 0;
+    if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    float slx, sly; mf_sample_visible11(distr, theta, sx, sy, &slx, &sly);
+    float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+    rx *= alpha; ry *= alpha;
+    float normalization = 1.0f / sqrtf(rx * rx + ry * ry + 1.0f);
+    return V(-rx * normalization, -ry * normalization, normalization);
+}
+/* microfacet.h:469-473 pdfVisible */
+static float mf_pdf_visible(uint32_t distr, float alpha, v3 wi, v3 m) {
+    if (wi.z == 0) return 0.0f;
+    return mf_smith_g1(distr, alpha, wi, m) * fabsf(dot(wi, m)) * mf_eval(distr, alpha, m) / fabsf(wi.z);
+}
+/* src/libcore/util.cpp:741-763 fresnelConductorExact, per RGB channel */
+static v3 fresnel_conductor_exact(float cosThetaI, const float *eta, const float *k) {
+    float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    float out[3];
+    for (int i = 0; i < 3; ++i) {
+        float temp1 = eta[i] * eta[i] - k[i] * k[i] - sinThetaI2;
+        float a2pb2 = sqrtf(maxf(temp1 * temp1 + k[i] * k[i] * eta[i] * eta[i] * 4, 0.0f));
+        float a = sqrtf(maxf((a2pb2 + temp1) * 0.5f, 0.0f));
+        float term1 = a2pb2 + cosThetaI2, term2 = a * (2 * cosThetaI);
+        float Rs2 = (term1 - term2) / (term1 + term2);
+        float term3 = a2pb2 * cosThetaI2 + sinThetaI4, term4 = term2 * sinThetaI2;
+        float Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+        out[i] = 0.5f * (Rp2 + Rs2);
+    }
+    return V(out[0], out[1], out[2]);
+}
+static v3 rc_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    float alpha = maxf(m->alpha, 1e-4f);
+    v3 H = normalize(add(wo, wi));
+    float D = mf_eval(m->distr, alpha, H);
+    if (D == 0) return V(0, 0, 0);
+    v3 F = mul(fresnel_conductor_exact(dot(wi, H), m->eta, m->k), V(m->specular[0], m->specular[1], m->specular[2]));
+    float G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H);
+    float model = D * G / (4.0f * wi.z);
+    return scale(F, model);
+}
+static float rc_pdf(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    float alpha = maxf(m->alpha, 1e-4f);
+    v3 H = normalize(add(wo, wi));
+    return mf_eval(m->distr, alpha, H) * mf_smith_g1(m->distr, alpha, wi, H) / (4.0f * wi.z);
+}
+static v3 rc_sample(const orc_material *mt, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {
+    if (wi.z < 0) return V(0, 0, 0);
+    float alpha = maxf(mt->alpha, 1e-4f);
+    v3 m = mf_sample_visible(mt->distr, alpha, wi, u, v);
+    *pdf = mf_pdf_visible(mt->distr, alpha, wi, m);
+    if (*pdf == 0) return V(0, 0, 0);
+    float c = 2 * dot(wi, m);
+    *wo = sub(scale(m, c), wi);                                  /* reflect(wi, m) = 2 dot(wi,m) m - wi */
+    *eta = 1.0f;
+    if (wo->z <= 0) return V(0, 0, 0);
+    v3 F = mul(fresnel_conductor_exact(dot(wi, m), mt->eta, mt->k), V(mt->specular[0], mt->specular[1], mt->specular[2]));
+    float weight = mf_smith_g1(mt->distr, alpha, *wo, m);
+    *pdf /= 4.0f * dot(*wo, m);
+    return scale(F, weight);
+}
+
 /* dispatch incl. src/bsdfs/twosided.cpp:110-190 (flip wi/wo to the front side when wi.z < 0) */
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
-    return diffuse_eval(m, wi, wo);
+    return m->type == 1 ? rc_eval(m, wi, wo) : diffuse_eval(m, wi, wo);
 }
 static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
-    return diffuse_pdf(wi, wo);
+    return m->type == 1 ? rc_pdf(m, wi, wo) : diffuse_pdf(wi, wo);
 }
 static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {
     int flipped = 0;
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; flipped = 1; }
-    v3 w = diffuse_sample(m, wi, u, v, wo, pdf, eta);
-    if (flipped && !is_zero(w)) wo->z = -wo->z;
+    v3 w = m->type == 1 ? rc_sample(m, wi, u, v, wo, pdf, eta) : diffuse_sample(m, wi, u, v, wo, pdf, eta);
+    if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
     return w;
 }
 void orc_bsdf_sample(const orc_scene *s, uint32_t mi, const float *wi, float u, float v, float *o) {
@@ -552,10 +727,10 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
             Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
         if ((depth >= maxDepth && maxDepth > 0) || (strict && dot(d, its.ng) * its.wi.z >= 0)) break;
 
-        /* direct illumination sampling (path.cpp:172-200); every supported BSDF is ESmooth */
+        /* direct illumination sampling (path.cpp:172-200), only for BSDFs with a smooth component */
         v3 refN = material_has_backside(bsdf) ? V(0, 0, 0) : its.ns;      /* records.inl:160-164 */
         direct_t dRec; memset(&dRec, 0, sizeof(dRec));
-        {
+        if (material_is_smooth(bsdf)) {
             float sx, sy; next2D(sp, &sx, &sy);
             v3 value = sample_emitter_direct(s, its.p, refN, sx, sy, &dRec, 1, &counters[1]);
             if (!is_zero(value)) {

@@ -32,6 +32,7 @@
 #include <mitsuba/render/triaccel.h>
 #include <mitsuba/render/skdtree.h>
 #include <sobolseq.h>
+#include <mitsuba/core/fresolver.h>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
@@ -176,6 +177,7 @@ static Built buildScene(const FScene &fs) {
             p.setSpectrum("eta", rgb(fb.eta)); p.setSpectrum("k", rgb(fb.k));
             p.setSpectrum("specularReflectance", rgb(fb.spec));
             p.setBoolean("sampleVisible", fb.sampleVisible != 0);
+            p.setString("material", "none"); p.setFloat("extEta", 1.0f);   // eta / k are given as RGB, already relative to the exterior
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         }
         bsdf->configure();
@@ -303,6 +305,15 @@ static void modeTables(const std::string &out) {
     }
     save(out + "/sobol_lookup.npy", "<u8", {lu.size() / 5, 5}, lu);
     save(out + "/sobol_values.npy", "<f4", {sv.size() / 8, 8}, sv);
+    // conductor eta / k as linear RGB, exactly as RoughConductor's constructor derives them (src/bsdfs/roughconductor.cpp:177-189):
+    // data/ior/<name>.{eta,k}.spd -> InterpolatedSpectrum -> Spectrum::fromContinuousSpectrum (RGB mode).  Rows: Cu, Al, Au; cols eta rgb, k rgb
+    const char *names[3] = {"Cu", "Al", "Au"}; std::vector<float> ior;
+    for (int i = 0; i < 3; ++i) for (int part = 0; part < 2; ++part) {
+        std::string file = std::string(MI_REF_ROOT "/data/ior/") + names[i] + (part ? ".k.spd" : ".eta.spd");
+        Spectrum sp; sp.fromContinuousSpectrum(InterpolatedSpectrum(fs::pathstr(file)));
+        Float r, g, b; sp.toLinearRGB(r, g, b); ior.push_back(r); ior.push_back(g); ior.push_back(b);
+    }
+    save(out + "/conductor_ior_rgb.npy", "<f4", {3, 6}, ior);
 }
 
 static uint64_t g_rays = 0, g_shadow = 0;

@@ -38,7 +38,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
             assert np.float32(oracle.lib().orc_sobol_sample(orc.h, idx, d * 7)) == vals[d]
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -58,7 +58,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -120,7 +120,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
     assert (np.abs(got - ft[:321]) < 1e-6).mean() > 0.99 and orc.border == int(ft[-1])
 
 
-@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box"])
+@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
