@@ -146,6 +146,9 @@ class Scene:
         L.check(L.L.mi_scene_set_triangles(h, _p(sc.pos), _p(sc.nrm), _p(sc.uv), _p(sc.idx), len(sc.pos), len(sc.idx), C.cast(shapes, C.c_void_p), len(sc.shapes)))
         L.check(L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), len(sc.bsdfs)))
         L.check(L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), len(sc.emitters)))
+        if sc.envmap is not None:
+            rgb = np.ascontiguousarray(sc.envmap["rgb"], np.float32); tw = np.ascontiguousarray(sc.envmap["to_world"], np.float32)
+            L.check(L.L.mi_scene_set_envmap(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), float(sc.envmap["scale"])))
         s2c = np.ascontiguousarray(sc.sample_to_camera, np.float32); c2w = np.ascontiguousarray(sc.cam_to_world, np.float32)
         L.check(L.L.mi_scene_set_camera(h, _p(s2c), _p(c2w), sc.near, sc.far))
         L.check(L.L.mi_scene_set_film(h, sc.width, sc.height, sc.filter, sc.filter_radius, sc.filter_stddev))

@@ -111,11 +111,15 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
 }
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *e, uint32_t n) {
     if (!s || (n && !e)) return fail(MI_ERR_INVALID, "mi_scene_set_emitters: null argument");
-    for (uint32_t i = 0; i < n; ++i) if (e[i].type != MI_EMITTER_AREA) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: only `area` emitters are implemented so far");
+    uint32_t nEnv = 0;
+    for (uint32_t i = 0; i < n; ++i) { if (e[i].type > MI_EMITTER_ENVMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: only `area` and `envmap` emitters are implemented"); nEnv += e[i].type == MI_EMITTER_ENVMAP; }
+    if (nEnv > 1) return fail(MI_ERR_INVALID, "The scene may only contain one environment emitter");      // scene.cpp:542-543
     s->h.emitters.assign(e, e + n); s->h.committed = false; return MI_OK;
 }
-int mi_scene_set_envmap(mi_scene *, const float *, uint32_t, uint32_t, const float *, float) {
-    return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_envmap: environment emitter not implemented in this round (SURVEY.md §8 a10)");
+int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *toWorld, float scale) {
+    if (!s || !rgb || !toWorld || w < 2 || h < 2 || w > 0xFFFF || h > 0xFFFF) return fail(MI_ERR_INVALID, "mi_scene_set_envmap: bad argument (2..65535 texels per side)");
+    s->h.envRGB.assign(rgb, rgb + (size_t) w * h * 3); s->h.envW = w; s->h.envH = h; memcpy(s->h.envToWorld, toWorld, 64); s->h.envScale = scale; s->h.committed = false;
+    return MI_OK;
 }
 int mi_scene_set_camera(mi_scene *s, const float *s2c, const float *c2w, float nearClip, float farClip) {
     if (!s || !s2c || !c2w) return fail(MI_ERR_INVALID, "mi_scene_set_camera: null argument");
@@ -143,7 +147,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv};
+    void **ps[] = {&dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -175,6 +179,14 @@ int SceneHost::upload(int dev) {
     d.width = width; d.height = height;
     d.filter_radius = filterRadiusEff; d.filter_scale = filterScale; d.border = border;
     d.log_res = logRes; d.resolution = resolution;
+    d.env_index = envIndex;
+    if (envIndex >= 0) {
+        if (up(&dEnvRGB, envRGB) | up(&dEnvCols, envCdfCols) | up(&dEnvRows, envCdfRows) | up(&dEnvWeights, envRowWeights)) return 1;
+        d.env_rgb = (const float *) dEnvRGB; d.env_cdf_cols = (const float *) dEnvCols; d.env_cdf_rows = (const float *) dEnvRows; d.env_row_weights = (const float *) dEnvWeights;
+        d.env_w = (int) envW; d.env_h = (int) envH; d.env_normalization = envNormalization; d.env_scale = envScale;
+        d.env_pixel_w = 2 * MI_PI / (float) envW; d.env_pixel_h = MI_PI / (float) envH; d.env_bs_radius = envBsRadius;
+        memcpy(d.env_to_world, envToWorld3, 36); memcpy(d.env_to_local, envToLocal3, 36); memcpy(d.env_bs_center, envBsCenter, 12);
+    }
     d.bvh_depth = (uint32_t) bvhDepthOf(nodes, 0);
     d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type == MI_BSDF_ROUGHCONDUCTOR) d.has_roughconductor = 1;
     const char *noPacket = getenv("MI355PT_NO_PACKET");
@@ -195,7 +207,10 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         if (sh.emitter >= (int32_t) s->h.emitters.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: shape refers to a missing emitter");
         if (!(sh.flags & 1u) && s->h.nrm.empty()) return fail(MI_ERR_INVALID, "mi_scene_commit: smooth-shaded mesh without vertex normals (pass faceNormals or normals)");
     }
-    for (const mi_emitter &e : s->h.emitters) if (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
+    for (const mi_emitter &e : s->h.emitters) {
+        if (e.type == MI_EMITTER_AREA && (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size())) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
+        if (e.type == MI_EMITTER_ENVMAP && s->h.envRGB.empty()) return fail(MI_ERR_INVALID, "mi_scene_commit: envmap emitter listed but mi_scene_set_envmap was not called");
+    }
     if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
     ensureSobolTables();
     s->h.commitHost();

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC>   // RC: the scene contains rough conductors (keeps the diffuse-only kernel lean: registers, occupancy)
+template <bool RC, bool ENV>   // RC: the scene has rough conductors; ENV: it has an environment emitter (keeps the plain diffuse kernel lean)
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_wave[2][WG / 64];
@@ -201,9 +201,21 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             const uint32_t prim = __float_as_uint(hr.w);
             v3 add = V(0, 0, 0); bool haveAdd = false;
             do {
-                if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :246
+                if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :234-248
                     pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
                     if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
+                    if (ENV) {
+                        if (depth == 1) { if (!rc.hide_emitters) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141 (level-0 lookup)
+                        else {
+                            // BSDF ray left the scene: env->evalEnvironment + fillDirectSamplingRecord (envmap.cpp:362-378), MIS term path.cpp:257-264
+                            float4 ro = q.rayO[buf][slot]; float nearT, farT;
+                            if (bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {
+                                v3 value = envEval(sc, d);
+                                float lumPdf = envPdfDirection(sc, mat3(sc.env_to_local, d)) * (sc.emitters[sc.env_index].weight * sc.emitter_norm);
+                                add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
+                            }
+                        }
+                    }
                     break;
                 }
                 Hit h; fillHit(sc, d, hr.x, prim, hr.y, hr.z, h);
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;               // records.inl:160-164
                 if (!(h.flags & 4u)) {                                       // bsdf->getType() & BSDF::ESmooth
                     float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                    Direct dr; v3 value = sampleEmitterDirect(sc, h.p, refN, sx, sy, dr);
+                    Direct dr; v3 value = sampleEmitterDirect<ENV>(sc, h.p, refN, sx, sy, dr);
                     if (dr.pdf != 0) {
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
@@ -427,8 +439,9 @@ void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid,
 }
 void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
-    if (sc.has_roughconductor) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
+    const bool env = sc.env_index >= 0;
+    if (sc.has_roughconductor) { if (env) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else { if (env) hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     if (sc.packet_n) hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(WG), 0, st, sc, q);

@@ -402,6 +402,93 @@ template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v
     return V(m.reflectance[0], m.reflectance[1], m.reflectance[2]);
 }
 
+// ---------------------------------------------------------------------------------------------- environment emitter
+// src/emitters/envmap.cpp (level-0 bilinear lookups only; the reference EWA-filters camera rays that see the sky directly, :398-411).
+// atan2/acos/sin/cos come from the device math library: tolerance-pinned like the rough conductor.
+#define MI_INV_TWOPI 0.15915494309189533577f
+DEV v3 mat3(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z); }
+DEV float luminance(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
+// include/mitsuba/render/mipmap.h:504-560 evalTexel (u: ERepeat, v: EClamp)
+DEV v3 envTexel(const DScene &sc, int x, int y) {
+    if (x < 0 || x >= sc.env_w) { int r = x % sc.env_w; x = r < 0 ? r + sc.env_w : r; }
+    y = y < 0 ? 0 : (y >= sc.env_h ? sc.env_h - 1 : y);
+    return ld3(sc.env_rgb + ((size_t) y * sc.env_w + x) * 3);
+}
+// mipmap.h:576-597 evalBilinear(0, uv)
+DEV v3 envBilinear(const DScene &sc, float uvx, float uvy) {
+    if (!isfinite(uvx) || !isfinite(uvy)) return V(0, 0, 0);
+    float u = uvx * (float) sc.env_w - 0.5f, v = uvy * (float) sc.env_h - 0.5f;
+    int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    float dx1 = u - (float) xPos, dx2 = 1.0f - dx1, dy1 = v - (float) yPos, dy2 = 1.0f - dy1;
+    v3 r = (envTexel(sc, xPos, yPos) * dx2) * dy2;
+    r = r + (envTexel(sc, xPos, yPos + 1) * dx2) * dy1;
+    r = r + (envTexel(sc, xPos + 1, yPos) * dx1) * dy2;
+    r = r + (envTexel(sc, xPos + 1, yPos + 1) * dx1) * dy1;
+    return r;
+}
+// envmap.cpp:384-416 evalEnvironment, no differentials
+DEV v3 envEval(const DScene &sc, v3 d) {
+    v3 v = mat3(sc.env_to_local, d);
+    float uvx = atan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
+    return envBilinear(sc, uvx, uvy) * sc.env_scale;
+}
+// envmap.cpp:664-669 sampleReuse
+DEV uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
+    uint32_t lo = 0, hi = size + 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < sample) lo = mid + 1; else hi = mid; }
+    uint32_t index = lo > 0 ? lo - 1 : 0; if (index > size - 1) index = size - 1;
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+DEV float intervalToTent(float sample) {               // src/libcore/warp.cpp:142-155
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - sqrtf(sample));
+}
+DEV void envBilinearPair(const DScene &sc, float px, float py, v3 &value1, v3 &value2, int &yPos) {
+    int xPos = (int) floorf(px); yPos = (int) floorf(py);
+    float dx1 = px - (float) xPos, dx2 = 1.0f - dx1, dy1 = py - (float) yPos, dy2 = 1.0f - dy1;
+    value1 = (envTexel(sc, xPos, yPos) * dx2) * dy2 + (envTexel(sc, xPos + 1, yPos) * dx1) * dy2;
+    value2 = (envTexel(sc, xPos, yPos + 1) * dx2) * dy1 + (envTexel(sc, xPos + 1, yPos + 1) * dx1) * dy1;
+}
+DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// envmap.cpp:571-608 internalSampleDirection
+DEV void envSampleDirection(const DScene &sc, float sx, float sy, v3 &d, v3 &value, float &pdf) {
+    uint32_t row = envSampleReuse(sc.env_cdf_rows, (uint32_t) sc.env_h, sy);
+    uint32_t col = envSampleReuse(sc.env_cdf_cols + (size_t) row * (sc.env_w + 1), (uint32_t) sc.env_w, sx);
+    float px = (float) col + intervalToTent(sx), py = (float) row + intervalToTent(sy);
+    v3 v1, v2; int yPos; envBilinearPair(sc, px, py, v1, v2, yPos);
+    value = (v1 + v2) * sc.env_scale;
+    pdf = (luminance(v1) * sc.env_row_weights[clampi(yPos, 0, sc.env_h - 1)] + luminance(v2) * sc.env_row_weights[clampi(yPos + 1, 0, sc.env_h - 1)]) * sc.env_normalization;
+    float ph = sc.env_pixel_w * (px + 0.5f), th = sc.env_pixel_h * (py + 0.5f);
+    float sinPhi = sinf(ph), cosPhi = cosf(ph), sinTheta = sinf(th), cosTheta = cosf(th);
+    d = V(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= maxf(fabsf(sinTheta), MI_EPSILON);
+}
+// envmap.cpp:611-638 internalPdfDirection
+DEV float envPdfDirection(const DScene &sc, v3 d) {
+    float uvx = atan2f(d.x, -d.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, d.y))) * MI_INV_PI;
+    if (!isfinite(uvx) || !isfinite(uvy)) return 0.0f;
+    float u = uvx * (float) sc.env_w - 0.5f, v = uvy * (float) sc.env_h - 0.5f;
+    v3 v1, v2; int yPos; envBilinearPair(sc, u, v, v1, v2, yPos);
+    float sinTheta = sqrtf(maxf(1 - d.y * d.y, 0.0f));
+    return (luminance(v1) * sc.env_row_weights[clampi(yPos, 0, sc.env_h - 1)] + luminance(v2) * sc.env_row_weights[clampi(yPos + 1, 0, sc.env_h - 1)])
+           * sc.env_normalization / maxf(fabsf(sinTheta), MI_EPSILON);
+}
+// include/mitsuba/core/bsphere.h:88-95 + src/libcore/util.cpp:449-487 solveQuadratic
+DEV bool bsphereIntersect(const DScene &sc, v3 ro, v3 rd, float &nearT, float &farT) {
+    v3 o = ro - ld3(sc.env_bs_center);
+    float A = dot(rd, rd), B = 2 * dot(o, rd), C = dot(o, o) - sc.env_bs_radius * sc.env_bs_radius;
+    if (A == 0) { if (B != 0) { nearT = farT = -C / B; return true; } return false; }
+    float discrim = B * B - 4.0f * A * C;
+    if (discrim < 0) return false;
+    float temp, sqrtDiscrim = sqrtf(discrim);
+    if (B < 0) temp = -0.5f * (B - sqrtDiscrim); else temp = -0.5f * (B + sqrtDiscrim);
+    float x0 = temp / A, x1 = C / temp;
+    if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+    nearT = x0; farT = x1; return true;
+}
+
 // ---------------------------------------------------------------------------------------------- emitters
 // include/mitsuba/core/pmf.h:124-137 DiscreteDistribution::sample
 DEV uint32_t cdfSample(const float *cdf, uint32_t n, float x) {
@@ -420,12 +507,24 @@ DEV v3 emitterEval(const DScene &sc, int e, v3 ns, v3 d) {
 // Scene::sampleEmitterDirect (src/librender/scene.cpp:860-884) without the visibility test (the shadow queue does it)
 // -> AreaLight::sampleDirect (src/emitters/area.cpp:160-176) -> Shape::sampleDirect (src/librender/shape.cpp:102-115)
 // -> TriMesh::samplePosition (src/librender/trimesh.cpp:413-425) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
+template <bool ENV>
 DEV v3 sampleEmitterDirect(const DScene &sc, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
     uint32_t ei = cdfSample(sc.emitter_cdf, sc.n_emitters, sx);
     float c0 = sc.emitter_cdf[ei], c1 = sc.emitter_cdf[ei + 1];
     float emPdf = c1 - c0;
     sx = (sx - c0) / (c1 - c0);
     const EmitterD &em = sc.emitters[ei];
+    if (ENV && em.type == 1) {                                   // EnvironmentMap::sampleDirect (envmap.cpp:520-547)
+        v3 value, dl; float pdf, nearT, farT;
+        envSampleDirection(sc, sx, sy, dl, value, pdf);
+        v3 dw = mat3(sc.env_to_world, dl);
+        if (isZero(value) || pdf == 0 || !bsphereIntersect(sc, ref, dw, nearT, farT) || nearT >= 0 || farT <= 0) { dr.pdf = 0.0f; return V(0, 0, 0); }
+        dr.pdf = pdf; dr.p = ref + dw * farT; dr.n = normalize(ld3(sc.env_bs_center) - dr.p); dr.dist = farT; dr.d = dw;
+        { float r = 1.0f / pdf; value = value * r; }
+        dr.emitter = (int) ei; dr.pdf *= emPdf;
+        { float r = 1.0f / emPdf; value = value * r; }
+        return value;
+    }
     const float *acdf = sc.area_cdf + em.cdf_offset;
     uint32_t ti = cdfSample(acdf, em.tri_count, sy);
     float a0 = acdf[ti], a1 = acdf[ti + 1];

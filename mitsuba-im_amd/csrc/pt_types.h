@@ -68,6 +68,11 @@ struct DScene {
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
     uint32_t packet_n, bvh_depth;
     uint32_t has_roughconductor;          // selects the shade kernel variant
+    // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none
+    const float *env_rgb, *env_cdf_cols, *env_cdf_rows, *env_row_weights;
+    int32_t env_index, env_w, env_h;
+    float env_normalization, env_scale, env_pixel_w, env_pixel_h, env_bs_radius;
+    float env_to_world[9], env_to_local[9], env_bs_center[3];
 };
 #define MI_PACKET_MAX 64
 

@@ -210,6 +210,40 @@ void SceneHost::commitHost() {
         float norm = 1.0f / sum;
         for (int i = 0; i < MI_FILTER_RES; ++i) filterValues[i] *= norm;
     }
+    // --- environment emitter tables (envmap.cpp:264-330 configure, :336-347 createShape: sphere around kd-tree box + sensor position, x1.5)
+    envIndex = -1;
+    for (uint32_t e = 0; e < ne; ++e) if (emitters[e].type == MI_EMITTER_ENVMAP) envIndex = (int) e;
+    if (envIndex >= 0) {
+        const int W = (int) envW, H = (int) envH;
+        auto texel = [&](int x, int y) { const float *p = &envRGB[((size_t) y * W + x) * 3]; return mk(p[0], p[1], p[2]); };
+        auto lum = [](V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; };
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) envToWorld3[i * 3 + j] = envToWorld[i * 4 + j];
+        { const float *m = envToWorld3; float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]); float id = 1.0f / det;
+          float *o = envToLocal3;
+          o[0] = (m[4] * m[8] - m[5] * m[7]) * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+          o[3] = (m[5] * m[6] - m[3] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+          o[6] = (m[3] * m[7] - m[4] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id; }
+        envCdfCols.assign((size_t) (W + 1) * H, 0.0f); envCdfRows.assign((size_t) H + 1, 0.0f); envRowWeights.assign((size_t) H, 0.0f);
+        size_t colPos = 0, rowPos = 0; float rowSum = 0.0f;
+        envCdfRows[rowPos++] = 0;
+        for (int y = 0; y < H; ++y) {
+            float colSum = 0; envCdfCols[colPos++] = 0;
+            for (int x = 0; x < W; ++x) { colSum += lum(texel(x, y)); envCdfCols[colPos++] = colSum; }
+            float normalization = 1.0f / colSum;
+            for (int x = 1; x < W; ++x) envCdfCols[colPos - x - 1] *= normalization;
+            envCdfCols[colPos - 1] = 1.0f;
+            float weight = std::sin(((float) y + 0.5f) * MI_PI / (float) H);
+            envRowWeights[y] = weight; rowSum += colSum * weight; envCdfRows[rowPos++] = rowSum;
+        }
+        float normalization = 1.0f / rowSum;
+        for (int y = 1; y < H; ++y) envCdfRows[rowPos - y - 1] *= normalization;
+        envCdfRows[rowPos - 1] = 1.0f;
+        envNormalization = 1.0f / (rowSum * (2 * MI_PI / (float) W) * (MI_PI / (float) H));
+        V3 blo = mk(aabbLo[0], aabbLo[1], aabbLo[2]), bhi = mk(aabbHi[0], aabbHi[1], aabbHi[2]), cam = mk(c2w[3], c2w[7], c2w[11]);
+        blo = vmin(blo, cam); bhi = vmax(bhi, cam);
+        V3 c = (bhi + blo) * 0.5f, cm = c - bhi;
+        envBsCenter[0] = c.x; envBsCenter[1] = c.y; envBsCenter[2] = c.z; envBsRadius = std::max(MI_EPSILON, std::sqrt(dot(cm, cm)) * 1.5f);
+    }
     // Sobol film resolution (src/samplers/sobol.cpp:147-157)
     { uint32_t r = std::max(width, height), p = 1, l = 0; while (p < r) { p <<= 1; ++l; } resolution = (float) p; logRes = l; }
 }

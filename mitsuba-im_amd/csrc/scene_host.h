@@ -21,10 +21,11 @@ struct SceneHost {
     float aabbLo[3], aabbHi[3];
     float filterValues[MI_FILTER_RES + 1]; float filterRadiusEff = 0, filterScale = 0; int border = 0;
     float resolution = 1; uint32_t logRes = 0;
+    int envIndex = -1; std::vector<float> envCdfCols, envCdfRows, envRowWeights; float envNormalization = 0, envToWorld3[9], envToLocal3[9], envBsCenter[3], envBsRadius = 0;
     // device
     bool committed = false; int device = 0;
     void *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr, *dI2 = nullptr, *dNrm = nullptr, *dMaterials = nullptr, *dEmitters = nullptr,
-         *dEmitterCdf = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
+         *dEmitterCdf = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dEnvRGB = nullptr, *dEnvCols = nullptr, *dEnvRows = nullptr, *dEnvWeights = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
     DScene d{};
 
     void commitHost();          // scene_build.cpp

@@ -240,6 +240,98 @@ def veach_mis(width=1920, height=1080, spp=512, sampler=SAMPLER_SOBOL, max_depth
                         width, height, spp, sampler, max_depth, rr_depth, filter_kind, name="veach_mis")
 
 
+def procedural_sky(w=1024, h=512):
+    """Closed-form lat-long sky: blue-to-white gradient above the horizon, dim ground below, one sun lobe.  Texels are rounded to
+    half precision because the reference stores its environment MIP map in half floats (src/emitters/envmap.cpp:103-104)."""
+    v = (np.arange(h, dtype=np.float64) + 0.5) / h; u = (np.arange(w, dtype=np.float64) + 0.5) / w
+    theta = v[:, None] * math.pi; phi = u[None, :] * 2 * math.pi
+    d = np.stack([np.sin(phi) * np.sin(theta), np.cos(theta) * np.ones_like(phi), -np.cos(phi) * np.sin(theta)], -1)   # envmap.cpp:604
+    up = np.clip(d[..., 1], 0, 1)
+    sky = (1 - up[..., None]) * np.array([0.9, 0.95, 1.0]) + up[..., None] * np.array([0.25, 0.45, 0.9])
+    ground = np.array([0.08, 0.07, 0.06])
+    rgb = np.where(d[..., 1:2] > 0, sky, ground)
+    sun = np.array([0.35, 0.8, -0.45]); sun = sun / np.linalg.norm(sun)
+    c = np.clip((d * sun).sum(-1), 0, 1)
+    rgb = rgb + (60.0 * c ** 400 + 1.5 * c ** 30)[..., None] * np.array([1.0, 0.9, 0.75])
+    return rgb.astype(np.float16).astype(f32)
+
+
+def _lcg(seed):
+    state = [seed & 0xFFFFFFFF]
+    def nxt():
+        state[0] = (1664525 * state[0] + 1013904223) & 0xFFFFFFFF
+        return state[0] / 4294967296.0
+    return nxt
+
+
+def atrium(width=3840, height=2160, spp=64, sampler=SAMPLER_SOBOL, max_depth=8, detail=1.0, env_size=(1024, 512), sky_visible=True,
+           filter_kind=FILTER_BOX):
+    """S3: procedurally generated Sponza-class colonnade / atrium.  A 36 x 24 m tiled floor (per-tile diffuse colours from
+    an LCG seeded 1234, 16-colour palette), two rows of tessellated columns with SMOOTH vertex normals, four walls, a gallery slab with an
+    open roof, two emissive lanterns and a procedural sky environment map.  detail = 1 gives ~250 k triangles."""
+    rnd = _lcg(1234)
+    b = _Builder(); normals = []
+    def pad_normals():
+        while len(normals) < len(b.verts): normals.append((0.0, 0.0, 0.0))
+    palette = [b.bsdf(reflectance=(0.25 + 0.5 * rnd(), 0.25 + 0.5 * rnd(), 0.25 + 0.5 * rnd())) for _ in range(16)]
+    stone = b.bsdf(reflectance=(0.62, 0.58, 0.5)); wall = b.bsdf(reflectance=(0.7, 0.66, 0.6), twosided=True); lightm = b.bsdf(reflectance=(0.0, 0.0, 0.0))
+    X, Z, Hh = 18.0, 12.0, 9.0
+    # floor tiles grouped by palette entry (one mesh per colour)
+    nx, nz = max(2, int(round(144 * detail))), max(2, int(round(72 * detail)))
+    tiles = [[] for _ in palette]
+    for iz in range(nz):
+        for ix in range(nx):
+            tiles[int(rnd() * 16) % 16].append((ix, iz))
+    for pi, lst in enumerate(tiles):
+        if not lst: continue
+        b.begin()
+        for ix, iz in lst:
+            x0, x1 = -X + 2 * X * ix / nx, -X + 2 * X * (ix + 1) / nx; z0, z1 = -Z + 2 * Z * iz / nz, -Z + 2 * Z * (iz + 1) / nz
+            b.quad([(x1, 0, z0), (x0, 0, z0), (x0, 0, z1), (x1, 0, z1)])                       # +y
+        b.end(palette[pi]); pad_normals()
+    # walls (two-sided), gallery slab with a rectangular opening
+    b.begin()
+    b.quad([(-X, 0, -Z), (X, 0, -Z), (X, Hh, -Z), (-X, Hh, -Z)]); b.quad([(X, 0, Z), (-X, 0, Z), (-X, Hh, Z), (X, Hh, Z)])
+    b.quad([(-X, 0, Z), (-X, 0, -Z), (-X, Hh, -Z), (-X, Hh, Z)]); b.quad([(X, 0, -Z), (X, 0, Z), (X, Hh, Z), (X, Hh, -Z)])
+    ox, oz = (X * 0.55, Z * 0.45) if sky_visible else (0.0, 0.0)
+    if sky_visible:
+        for (x0, x1, z0, z1) in [(-X, X, -Z, -oz), (-X, X, oz, Z), (-X, -ox, -oz, oz), (ox, X, -oz, oz)]:
+            b.quad([(x0, Hh, z0), (x1, Hh, z0), (x1, Hh, z1), (x0, Hh, z1)])                   # ceiling ring (-y side visible from below, two-sided)
+    else:
+        b.quad([(-X, Hh, -Z), (X, Hh, -Z), (X, Hh, Z), (-X, Hh, Z)])
+    b.end(wall); pad_normals()
+    # columns: smooth cylinders
+    ncol = 10; seg = max(6, int(round(48 * detail))); rings = max(2, int(round(120 * detail)))
+    for row_z in (-Z * 0.55, Z * 0.55):
+        for c in range(ncol):
+            cx = -X * 0.85 + 2 * X * 0.85 * c / (ncol - 1); r = 0.55; h = Hh
+            b.begin(); base = len(b.verts)
+            for j in range(rings + 1):
+                y = h * j / rings; rr = r * (1.0 - 0.12 * (j / rings))                        # slight taper
+                for i in range(seg):
+                    a = 2 * math.pi * i / seg
+                    b.verts.append((cx + rr * math.cos(a), y, row_z + rr * math.sin(a)))
+                    n = np.array([math.cos(a), 0.12 * r / h, math.sin(a)]); n = n / np.linalg.norm(n); normals.append(tuple(map(float, n)))
+            for j in range(rings):
+                for i in range(seg):
+                    v00 = base + j * seg + i; v01 = base + j * seg + (i + 1) % seg; v10 = v00 + seg; v11 = v01 + seg
+                    b.tris.append((v00, v10, v11)); b.tris.append((v00, v11, v01))                # outward
+            b.end(stone, face_normals=False)
+    # lanterns
+    for lx in (-X * 0.5, X * 0.5):
+        b.begin(); b.quad([(lx - 0.6, Hh - 0.4, -0.6), (lx + 0.6, Hh - 0.4, -0.6), (lx + 0.6, Hh - 0.4, 0.6), (lx - 0.6, Hh - 0.4, 0.6)])   # -y
+        b.end(lightm, radiance=(18.0, 14.0, 9.0)); pad_normals()
+    cam = look_at((-X * 0.8, 3.2, 0.5), (X * 0.2, 1.2, -1.0), (0, 1, 0))
+    env = dict(rgb=procedural_sky(*env_size), to_world=np.eye(4, dtype=f32), scale=1.0)
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 60.0, 0.05, 500.0, width, height, spp, sampler, max_depth,
+                      5, filter_kind, normals=normals, envmap=env, name="atrium")
+    # the environment emitter is a scene-level emitter: it comes first in Scene::getEmitters() (added before the shapes are expanded)
+    sc.emitters.insert(0, dict(type=EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=1.0))
+    for sh in sc.shapes:
+        if sh["emitter"] >= 0: sh["emitter"] += 1
+    return sc
+
+
 # ---------------------------------------------------------------------------------------------
 # binary container for the oracle-side harness
 # ---------------------------------------------------------------------------------------------

@@ -63,6 +63,10 @@ struct orc_scene {
     float filter_values[FILTER_RES + 1]; float filter_radius, filter_scale; int border;
     uint32_t log_res; float resolution;
     float inv_res_x, inv_res_y;
+    /* environment emitter (src/emitters/envmap.cpp); env_index = its position in the emitter list or -1 */
+    int env_index; int env_w, env_h; float *env_rgb; float *env_cdf_cols, *env_cdf_rows, *env_row_weights;
+    float env_normalization, env_scale, env_to_world[9], env_to_local[9], env_pixel_w, env_pixel_h;
+    v3 env_bs_center; float env_bs_radius;
 };
 
 /* ------------------------------------------------------------------------------------------------ samplers */
@@ -629,6 +633,93 @@ void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float
     o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(&s->materials[mi], V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
 }
 
+/* ------------------------------------------------------------------------------------------------ environment emitter */
+#define INV_TWOPI 0.15915494309189533577f
+static inline v3 mat3(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z); }
+static inline float luminance(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }   /* include/mitsuba/core/spectrum.h:725-727 */
+/* include/mitsuba/render/mipmap.h:504-560 evalTexel, level 0, u: ERepeat, v: EClamp (envmap.cpp:181-183) */
+static v3 env_texel(const orc_scene *s, int x, int y) {
+    if (x < 0 || x >= s->env_w) { int r = x % s->env_w; x = r < 0 ? r + s->env_w : r; }
+    if (y < 0) y = 0; else if (y >= s->env_h) y = s->env_h - 1;
+    const float *p = s->env_rgb + ((size_t) y * s->env_w + x) * 3; return V(p[0], p[1], p[2]);
+}
+/* mipmap.h:576-597 evalBilinear(0, uv) */
+static v3 env_bilinear(const orc_scene *s, float uvx, float uvy) {
+    if (!isfinite(uvx) || !isfinite(uvy)) return V(0, 0, 0);
+    float u = uvx * (float) s->env_w - 0.5f, v = uvy * (float) s->env_h - 0.5f;
+    int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    float dx1 = u - (float) xPos, dx2 = 1.0f - dx1, dy1 = v - (float) yPos, dy2 = 1.0f - dy1;
+    v3 r = scale(scale(env_texel(s, xPos, yPos), dx2), dy2);
+    r = add(r, scale(scale(env_texel(s, xPos, yPos + 1), dx2), dy1));
+    r = add(r, scale(scale(env_texel(s, xPos + 1, yPos), dx1), dy2));
+    r = add(r, scale(scale(env_texel(s, xPos + 1, yPos + 1), dx1), dy1));
+    return r;
+}
+/* envmap.cpp:384-416 evalEnvironment without ray differentials (level-0 bilinear lookup) */
+static v3 env_eval(const orc_scene *s, v3 d) {
+    v3 v = mat3(s->env_to_local, d);
+    float uvx = atan2f(v.x, -v.z) * INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * INV_PI;
+    return scale(env_bilinear(s, uvx, uvy), s->env_scale);
+}
+/* envmap.cpp:664-669 sampleReuse over a float CDF */
+static uint32_t env_sample_reuse(const float *cdf, uint32_t size, float *sample) {
+    uint32_t lo = 0, hi = size + 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) / 2; if (cdf[mid] < *sample) lo = mid + 1; else hi = mid; }
+    int64_t e = (int64_t) lo - 1; if (e < 0) e = 0;
+    uint32_t index = (uint32_t) e; if (index > size - 1) index = size - 1;
+    *sample = (*sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+static inline float interval_to_tent(float sample) {                    /* src/libcore/warp.cpp:142-155 */
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - sqrtf(sample));
+}
+static void env_bilinear_pair(const orc_scene *s, float px, float py, v3 *value1, v3 *value2, int *yPosOut) {
+    int xPos = (int) floorf(px), yPos = (int) floorf(py);
+    float dx1 = px - (float) xPos, dx2 = 1.0f - dx1, dy1 = py - (float) yPos, dy2 = 1.0f - dy1;
+    *value1 = add(scale(scale(env_texel(s, xPos, yPos), dx2), dy2), scale(scale(env_texel(s, xPos + 1, yPos), dx1), dy2));
+    *value2 = add(scale(scale(env_texel(s, xPos, yPos + 1), dx2), dy1), scale(scale(env_texel(s, xPos + 1, yPos + 1), dx1), dy1));
+    *yPosOut = yPos;
+}
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* envmap.cpp:571-608 internalSampleDirection */
+static void env_sample_direction(const orc_scene *s, float sx, float sy, v3 *d, v3 *value, float *pdf) {
+    uint32_t row = env_sample_reuse(s->env_cdf_rows, (uint32_t) s->env_h, &sy);
+    uint32_t col = env_sample_reuse(s->env_cdf_cols + (size_t) row * (s->env_w + 1), (uint32_t) s->env_w, &sx);
+    float px = (float) col + interval_to_tent(sx), py = (float) row + interval_to_tent(sy);
+    v3 v1, v2; int yPos; env_bilinear_pair(s, px, py, &v1, &v2, &yPos);
+    *value = scale(add(v1, v2), s->env_scale);
+    *pdf = (luminance(v1) * s->env_row_weights[clampi(yPos, 0, s->env_h - 1)] + luminance(v2) * s->env_row_weights[clampi(yPos + 1, 0, s->env_h - 1)]) * s->env_normalization;
+    float ph = s->env_pixel_w * (px + 0.5f), th = s->env_pixel_h * (py + 0.5f);
+    float sinPhi = sinf(ph), cosPhi = cosf(ph), sinTheta = sinf(th), cosTheta = cosf(th);
+    *d = V(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    *pdf /= maxf(fabsf(sinTheta), EPSILON);
+}
+/* envmap.cpp:611-638 internalPdfDirection */
+static float env_pdf_direction(const orc_scene *s, v3 d) {
+    float uvx = atan2f(d.x, -d.z) * INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, d.y))) * INV_PI;
+    if (!isfinite(uvx) || !isfinite(uvy)) return 0.0f;
+    float u = uvx * (float) s->env_w - 0.5f, v = uvy * (float) s->env_h - 0.5f;
+    v3 v1, v2; int yPos; env_bilinear_pair(s, u, v, &v1, &v2, &yPos);
+    float sinTheta = sqrtf(maxf(1 - d.y * d.y, 0.0f));
+    return (luminance(v1) * s->env_row_weights[clampi(yPos, 0, s->env_h - 1)] + luminance(v2) * s->env_row_weights[clampi(yPos + 1, 0, s->env_h - 1)])
+           * s->env_normalization / maxf(fabsf(sinTheta), EPSILON);
+}
+/* include/mitsuba/core/bsphere.h:88-95 + src/libcore/util.cpp:449-487 solveQuadratic */
+static int bsphere_intersect(v3 center, float radius, v3 ro, v3 rd, float *nearT, float *farT) {
+    v3 o = sub(ro, center);
+    float A = dot(rd, rd), B = 2 * dot(o, rd), C = dot(o, o) - radius * radius;
+    if (A == 0) { if (B != 0) { *nearT = *farT = -C / B; return 1; } return 0; }
+    float discrim = B * B - 4.0f * A * C;
+    if (discrim < 0) return 0;
+    float temp, sqrtDiscrim = sqrtf(discrim);
+    if (B < 0) temp = -0.5f * (B - sqrtDiscrim); else temp = -0.5f * (B + sqrtDiscrim);
+    float x0 = temp / A, x1 = C / temp;
+    if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+    *nearT = x0; *farT = x1; return 1;
+}
+
 /* ------------------------------------------------------------------------------------------------ emitters */
 /* include/mitsuba/core/pmf.h:124-137 DiscreteDistribution::sample (lower_bound over cdf[0..n]) */
 static uint32_t cdf_sample(const float *cdf, uint32_t n, float x) {
@@ -655,6 +746,24 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
     float emPdf = s->emitter_cdf[ei + 1] - s->emitter_cdf[ei];
     sx = (sx - s->emitter_cdf[ei]) / (s->emitter_cdf[ei + 1] - s->emitter_cdf[ei]);
     const orc_emitter *em = &s->emitters[ei];
+    if (em->type == 1) {
+        /* EnvironmentMap::sampleDirect (src/emitters/envmap.cpp:520-547) */
+        v3 value, dl; float pdf, nearT, farT;
+        env_sample_direction(s, sx, sy, &dl, &value, &pdf);
+        v3 dw = mat3(s->env_to_world, dl);
+        if (is_zero(value) || pdf == 0 || !bsphere_intersect(s->env_bs_center, s->env_bs_radius, ref, dw, &nearT, &farT) || nearT >= 0 || farT <= 0) {
+            dr->pdf = 0.0f; return V(0, 0, 0);
+        }
+        dr->pdf = pdf; dr->p = add(ref, scale(dw, farT)); dr->n = normalize(sub(s->env_bs_center, dr->p)); dr->dist = farT; dr->d = dw;
+        { float r = 1.0f / pdf; value = scale(value, r); }
+        if (test_visibility) {
+            if (shadow_rays) ++*shadow_rays;
+            if (ray_occluded(s, ref, dr->d, EPSILON, dr->dist * (1 - SHADOW_EPSILON))) return V(0, 0, 0);
+        }
+        dr->emitter = (int32_t) ei; dr->pdf *= emPdf;
+        { float r = 1.0f / emPdf; value = scale(value, r); }
+        return value;
+    }
     const orc_shape *sh = &s->shapes[em->shape];
     uint32_t ti = cdf_sample(s->area_cdf[ei], sh->tri_count, sy);
     sy = (sy - s->area_cdf[ei][ti]) / (s->area_cdf[ei][ti + 1] - s->area_cdf[ei][ti]);
@@ -694,6 +803,8 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
  * pdfEmitterDiscrete (include/mitsuba/render/scene.h:848-850) */
 static float pdf_emitter_direct(const orc_scene *s, const direct_t *dr, v3 refN) {
     float pdf;
+    if (s->emitters[dr->emitter].type == 1)                                    /* EnvironmentMap::pdfDirect, measure = ESolidAngle (envmap.cpp:549-560) */
+        return env_pdf_direction(s, mat3(s->env_to_local, dr->d)) * (s->emitters[dr->emitter].weight * s->emitter_norm);
     if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0)
         pdf = s->inv_area[dr->emitter] * (dr->dist * dr->dist) / fabsf(dot(dr->d, dr->n));
     else pdf = 0.0f;
@@ -721,7 +832,11 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
     *alpha = (s->d.opacity && !its.valid) ? 0.0f : 1.0f; /* records.inl:121-137 (no media): EOpacity -> 1 on a hit, 0 on a miss; else newQuery's 1 */
     v3 throughput = V(1, 1, 1); float eta = 1.0f;
     while (depth <= maxDepth || maxDepth < 0) {
-        if (!its.valid) break;                           /* no environment emitter on this path yet */
+        if (!its.valid) {                                /* path.cpp:136-143 (reached by camera rays only; BSDF-ray misses are handled below) */
+            /* NB the reference filters this lookup with the camera ray's differentials (EWA, envmap.cpp:398-411); level-0 bilinear here */
+            if (s->env_index >= 0 && emitted_radiance && (!hide || scattered)) Li = add(Li, mul(throughput, env_eval(s, d)));
+            break;
+        }
         const orc_material *bsdf = &s->materials[its.material];
         if (its.emitter >= 0 && emitted_radiance && (!hide || scattered))
             Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
@@ -762,13 +877,22 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
                 dRec.p = its.p; dRec.n = its.ns; dRec.d = d; dRec.dist = its.t; dRec.emitter = its.emitter;   /* records.inl:181-189 setQuery */
                 hitEmitter = 1;
             }
-        } else break;                                    /* path.cpp:234-248 without an environment emitter */
+        } else {                                         /* path.cpp:234-248 */
+            if (s->env_index < 0) break;
+            if (hide && !scattered) break;
+            value = env_eval(s, d);
+            float nearT, farT;                           /* envmap.cpp:362-378 fillDirectSamplingRecord */
+            if (!bsphere_intersect(s->env_bs_center, s->env_bs_radius, o, d, &nearT, &farT) || nearT > 0 || farT < 0) break;
+            dRec.p = add(o, scale(d, farT)); dRec.n = normalize(sub(s->env_bs_center, dRec.p)); dRec.d = d; dRec.dist = farT; dRec.emitter = s->env_index;
+            hitEmitter = 1;
+        }
 
         throughput = mul(throughput, bsdfWeight); eta *= bEta;
         if (hitEmitter) {                                /* path.cpp:257-264 */
             float lumPdf = pdf_emitter_direct(s, &dRec, refN);
             Li = add(Li, scale(mul(throughput, value), mi_weight(bsdfPdf, lumPdf)));
         }
+        if (!its.valid) break;                           /* path.cpp:272 */
         emitted_radiance = 0;                            /* rRec.type = ERadianceNoEmission */
         if (depth++ >= rrDepth) {                        /* path.cpp:276-286 */
             float q = minf(maxf(maxf(throughput.x, throughput.y), throughput.z) * eta * eta, 0.95f);
@@ -865,6 +989,12 @@ void orc_render_image(const orc_scene *s, uint32_t s0, uint32_t s1, uint32_t y0,
 }
 
 /* ------------------------------------------------------------------------------------------------ scene setup */
+static const v3 *g_sort_cent; static int g_sort_axis;      /* scene construction is single-threaded */
+static int cmp_centroid(const void *a, const void *b) {
+    float x = comp(g_sort_cent[*(const uint32_t *) a], g_sort_axis), y = comp(g_sort_cent[*(const uint32_t *) b], g_sort_axis);
+    if (x < y) return -1; if (x > y) return 1;
+    return *(const uint32_t *) a < *(const uint32_t *) b ? -1 : 1;
+}
 static int build_bvh(orc_scene *s, uint32_t *tris, int first, int count, v3 *cent, v3 *tlo, v3 *thi) {
     int id = s->n_nodes++; bvh_node *n = &s->nodes[id];
     v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY), clo = lo, chi = hi;
@@ -878,12 +1008,9 @@ static int build_bvh(orc_scene *s, uint32_t *tris, int first, int count, v3 *cen
     n->lo = V(lo.x - pad, lo.y - pad, lo.z - pad); n->hi = V(hi.x + pad, hi.y + pad, hi.z + pad);
     if (count <= 4) { n->first = first; n->count = count; n->left = n->right = -1; return id; }
     v3 ce = sub(chi, clo); int axis = ce.x > ce.y ? (ce.x > ce.z ? 0 : 2) : (ce.y > ce.z ? 1 : 2);
-    /* median split by sorting on the centroid coordinate (insertion sort is fine for test sizes; qsort for big ones) */
-    for (int i = first + 1; i < first + count; ++i) {
-        uint32_t t = tris[i]; float key = comp(cent[t], axis); int j = i - 1;
-        while (j >= first && comp(cent[tris[j]], axis) > key) { tris[j + 1] = tris[j]; --j; }
-        tris[j + 1] = t;
-    }
+    /* median split by sorting on the centroid coordinate */
+    g_sort_cent = cent; g_sort_axis = axis;
+    qsort(tris + first, (size_t) count, sizeof(uint32_t), cmp_centroid);
     int half = count / 2;
     n->count = 0; n->first = 0;
     int l = build_bvh(s, tris, first, half, cent, tlo, thi);
@@ -934,6 +1061,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     if (ne) { float sum = s->emitter_cdf[ne]; s->emitter_norm = sum > 0 ? 1.0f / sum : 0.0f; for (uint32_t e = 1; e <= ne; ++e) s->emitter_cdf[e] *= s->emitter_norm; s->emitter_cdf[ne] = 1.0f; }
     /* per-mesh area distribution (trimesh.cpp:389-402 prepareSamplingTable; triangle.cpp:61-67 surfaceArea) */
     for (uint32_t e = 0; e < ne; ++e) {
+        if (s->emitters[e].type != 0) continue;
         const orc_shape *sh = &s->shapes[s->emitters[e].shape]; uint32_t nt = sh->tri_count;
         float *cdf = (float *) calloc(nt + 1, 4);
         for (uint32_t t = 0; t < nt; ++t) {
@@ -965,6 +1093,42 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
         float norm = 1.0f / sum;
         for (int i = 0; i < FILTER_RES; ++i) s->filter_values[i] *= norm;
     }
+    /* environment emitter tables (envmap.cpp:264-330 configure; :336-347 createShape: sphere around kd-tree box + sensor position, x1.5) */
+    s->env_index = -1;
+    for (uint32_t e = 0; e < ne; ++e) if (s->emitters[e].type == 1) s->env_index = (int) e;
+    if (s->env_index >= 0 && d->env_rgb) {
+        const int W = (int) d->env_w, H = (int) d->env_h; s->env_w = W; s->env_h = H; s->env_scale = d->env_scale;
+        s->env_rgb = (float *) dup(d->env_rgb, (size_t) W * H * 12);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s->env_to_world[i * 3 + j] = d->env_to_world[i * 4 + j];
+        /* inverse of a rotation (+ uniform scale) handed over by the caller as the transpose would be wrong in general: invert the 3x3 */
+        { const float *m = s->env_to_world; float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]); float id = 1.0f / det;
+          float *o = s->env_to_local;
+          o[0] = (m[4] * m[8] - m[5] * m[7]) * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+          o[3] = (m[5] * m[6] - m[3] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+          o[6] = (m[3] * m[7] - m[4] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id; }
+        s->env_cdf_cols = (float *) calloc((size_t) (W + 1) * H, 4); s->env_cdf_rows = (float *) calloc((size_t) H + 1, 4); s->env_row_weights = (float *) calloc((size_t) H, 4);
+        size_t colPos = 0, rowPos = 0; float rowSum = 0.0f;
+        s->env_cdf_rows[rowPos++] = 0;
+        for (int y = 0; y < H; ++y) {
+            float colSum = 0; s->env_cdf_cols[colPos++] = 0;
+            for (int x = 0; x < W; ++x) { colSum += luminance(env_texel(s, x, y)); s->env_cdf_cols[colPos++] = colSum; }
+            float normalization = 1.0f / colSum;
+            for (int x = 1; x < W; ++x) s->env_cdf_cols[colPos - x - 1] *= normalization;
+            s->env_cdf_cols[colPos - 1] = 1.0f;
+            float weight = sinf(((float) y + 0.5f) * M_PI_F / (float) H);
+            s->env_row_weights[y] = weight; rowSum += colSum * weight; s->env_cdf_rows[rowPos++] = rowSum;
+        }
+        float normalization = 1.0f / rowSum;
+        for (int y = 1; y < H; ++y) s->env_cdf_rows[rowPos - y - 1] *= normalization;
+        s->env_cdf_rows[rowPos - 1] = 1.0f;
+        s->env_normalization = 1.0f / (rowSum * (2 * M_PI_F / (float) W) * (M_PI_F / (float) H));
+        s->env_pixel_w = 2 * M_PI_F / (float) W; s->env_pixel_h = M_PI_F / (float) H;
+        /* Scene::initialize: m_aabb = kd-tree box, expanded by the sensor's position (scene.cpp:399-403); AABB::getBSphere (aabb.cpp:44-47) */
+        v3 blo = s->aabb_lo, bhi = s->aabb_hi; v3 cam = V(d->cam_to_world[3], d->cam_to_world[7], d->cam_to_world[11]);
+        blo = V(minf(blo.x, cam.x), minf(blo.y, cam.y), minf(blo.z, cam.z)); bhi = V(maxf(bhi.x, cam.x), maxf(bhi.y, cam.y), maxf(bhi.z, cam.z));
+        v3 c = scale(add(bhi, blo), 0.5f); v3 cm = sub(c, bhi);
+        s->env_bs_center = c; s->env_bs_radius = maxf(EPSILON, sqrtf(dot(cm, cm)) * 1.5f);
+    }
     /* Sobol film resolution (sobol.cpp:147-157 setFilmResolution, bucketed) */
     { uint32_t r = d->width > d->height ? d->width : d->height, p = 1, l = 0; while (p < r) { p <<= 1; ++l; } s->resolution = (float) p; s->log_res = l; }
     s->inv_res_x = 1.0f / (float) d->width; s->inv_res_y = 1.0f / (float) d->height;
@@ -972,7 +1136,8 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
 }
 void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
-    for (uint32_t e = 0; e < s->d.n_emitters; ++e) free(s->area_cdf[e]);
+    for (uint32_t e = 0; e < s->d.n_emitters; ++e) free(s->area_cdf[e]);   /* NULL for the environment emitter */
     free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape);
+    free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
     free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->emitters); free(s);
 }

@@ -29,6 +29,7 @@ def golden_scenes():
         "cornell_small_gauss": scenes.cornell_box(width=96, height=54, spp=4, sampler=scenes.SAMPLER_SOBOL, filter_kind=scenes.FILTER_GAUSSIAN),
         "closed_box": scenes.closed_box(width=64, height=64, spp=16),
         "veach_small": scenes.veach_mis(width=96, height=54, spp=16),
+        "atrium_small": scenes.atrium(width=96, height=54, spp=16, detail=0.08, env_size=(64, 32)),
     }
 
 
@@ -50,7 +51,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)

@@ -38,7 +38,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
             assert np.float32(oracle.lib().orc_sobol_sample(orc.h, idx, d * 7)) == vals[d]
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -49,7 +49,10 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     v, gv = r["vals"][:512], gd["vals"]
     same_vals = (v.view(np.uint32) == gv.view(np.uint32)).all(1)
     err = np.abs(r["li"] - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
-    if name == "closed_box":
+    if name == "atrium_small":
+        # coarse smooth-shaded columns (6 segments): the interpolated normal amplifies last-bit differences of (u, v) at grazing angles
+        assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6
+    elif name == "closed_box":
         # axis-aligned box with exactly representable coordinates: rays through shared edges / the quad diagonals tie exactly and the
         # kd-tree keeps the last-tested triangle (SURVEY.md §7 "nearest-hit tie-breaking") -> a handful of paths legitimately fork
         assert same_path.mean() > 0.995 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.995
@@ -120,7 +123,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
     assert (np.abs(got - ft[:321]) < 1e-6).mean() > 0.99 and orc.border == int(ft[-1])
 
 
-@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small"])
+@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
@@ -128,7 +131,7 @@ def test_film_vs_reference(oracle, golden_scenes, name):
     ref = gd["film"]
     assert film.shape == ref.shape
     rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
-    assert rel < (2e-2 if name == "closed_box" else 1e-4), rel
+    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3}.get(name, 1e-4), rel
     assert np.allclose(film[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)        # weight channel
     # the reference's own ray counters (StatsCounter "Normal rays traced" / "Shadow rays traced", skdtree.cpp:46-47)
     stats = str(gd["stats"])
