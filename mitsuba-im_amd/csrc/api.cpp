@@ -42,6 +42,9 @@ struct mi_render {
     mi_stats stats{};
     uint64_t samplesTotal = 0;
     uint32_t *dNib = nullptr;
+    // optional second path pool + stream: consecutive batches alternate between the two, so the ALU-bound traversal kernels of one batch
+    // overlap the latency-bound shading kernels of the other on the same CUs (MI355PT_STREAMS=2, default)
+    Queues q2{}; std::vector<void *> allocs2; hipStream_t stream2 = nullptr; hipEvent_t filmDone[2] = {nullptr, nullptr}, joinEv = nullptr; int nStreams = 1;
 };
 
 extern "C" {
@@ -222,32 +225,41 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
 }
 
 // ------------------------------------------------------------------------------------------------ render
-static int allocQ(mi_render *r, void **p, size_t bytes) {
-    HIPCHK(hipMalloc(p, bytes)); r->allocs.push_back(*p); return MI_OK;
+static int allocQ(std::vector<void *> &allocs, void **p, size_t bytes) {
+    HIPCHK(hipMalloc(p, bytes)); allocs.push_back(*p); return MI_OK;
 }
-#define ALLOC(ptr, type, count) do { void *p_ = nullptr; int rc_ = allocQ(r, &p_, sizeof(type) * (size_t) (count)); if (rc_) return rc_; ptr = (type *) p_; } while (0)
+#define ALLOC(ptr, type, count) do { void *p_ = nullptr; int rc_ = allocQ(allocs, &p_, sizeof(type) * (size_t) (count)); if (rc_) return rc_; ptr = (type *) p_; } while (0)
 
-static int allocPool(mi_render *r, uint64_t paths) {
-    for (void *p : r->allocs) (void) hipFree(p);
-    r->allocs.clear();
+static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void *> &allocs) {
+    for (void *p : allocs) (void) hipFree(p);
+    allocs.clear();
     auto envU = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v && v[0] ? (uint32_t) atoi(v) : dflt; };
     uint32_t grid = envU("MI355PT_SEGMENTS", 4096u);                       // segments of the path pool
     uint64_t minGrid = (paths + 255) / 256; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 255) / 256 * 256;
-    r->grid = grid; r->q.cap = (uint32_t) cap; r->q.n_seg = grid; r->poolPaths = paths;
+    r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
     // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
     r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", 768u));
     r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
     const uint64_t slots = cap * grid;
     for (int b = 0; b < 2; ++b) {
-        ALLOC(r->q.rayO[b], float4, slots); ALLOC(r->q.rayD[b], float4, slots);
-        ALLOC(r->q.st0[b], uint4, slots); ALLOC(r->q.st1[b], float4, slots); ALLOC(r->q.st2[b], float, slots);
-        ALLOC(r->q.count[b], uint32_t, grid);
+        ALLOC(Q.rayO[b], float4, slots); ALLOC(Q.rayD[b], float4, slots);
+        ALLOC(Q.st0[b], uint4, slots); ALLOC(Q.st1[b], float4, slots); ALLOC(Q.st2[b], float, slots);
+        ALLOC(Q.count[b], uint32_t, grid);
     }
-    ALLOC(r->q.hit, float4, slots); ALLOC(r->q.shO, float4, slots); ALLOC(r->q.shD, float4, slots); ALLOC(r->q.shC, float4, slots);
-    ALLOC(r->q.acc, float4, slots); ALLOC(r->q.pos, float2, slots); ALLOC(r->q.shCount, uint32_t, grid);
-    ALLOC(r->q.counters, unsigned long long, 4);
-    HIPCHK(hipMemset(r->q.counters, 0, 32));
+    ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, slots); ALLOC(Q.shD, float4, slots); ALLOC(Q.shC, float4, slots);
+    ALLOC(Q.acc, float4, slots); ALLOC(Q.pos, float2, slots); ALLOC(Q.shCount, uint32_t, grid);
+    ALLOC(Q.counters, unsigned long long, 4);
+    HIPCHK(hipMemset(Q.counters, 0, 32));
+    return MI_OK;
+}
+static int allocPool(mi_render *r, uint64_t paths) {
+    unsigned long long keep[4] = {0, 0, 0, 0}, keep2[4] = {0, 0, 0, 0};      // ray counters survive a re-allocation (they are cleared by mi_render_clear only)
+    if (r->q.counters) (void) hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost);
+    if (r->q2.counters) (void) hipMemcpy(keep2, r->q2.counters, 32, hipMemcpyDeviceToHost);
+    int rc = allocPoolQ(r, paths, r->q, r->allocs); if (rc) return rc;
+    HIPCHK(hipMemcpy(r->q.counters, keep, 32, hipMemcpyHostToDevice));
+    if (r->nStreams > 1) { rc = allocPoolQ(r, paths, r->q2, r->allocs2); if (rc) return rc; HIPCHK(hipMemcpy(r->q2.counters, keep2, 32, hipMemcpyHostToDevice)); }
     return MI_OK;
 }
 
@@ -285,6 +297,12 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         r->rc.sobol_nib = r->dNib; r->rc.nib_count = nibs; r->rc.nib_dims = dims;
     }
     HIPCHK(hipStreamCreate(&r->stream)); HIPCHK(hipEventCreate(&r->evBegin)); HIPCHK(hipEventCreate(&r->evEnd));
+    { const char *ns = getenv("MI355PT_STREAMS"); r->nStreams = (ns && ns[0] == '1') ? 1 : 2; }
+    if (r->nStreams > 1) {
+        HIPCHK(hipStreamCreate(&r->stream2));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&r->filmDone[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&r->joinEv, hipEventDisableTiming));
+    }
     const int W = (int) s->h.width + 2 * s->h.border, H = (int) s->h.height + 2 * s->h.border;
     r->filmFloats = (size_t) W * H * 5;
     HIPCHK(hipMalloc((void **) &r->film, r->filmFloats * 4)); HIPCHK(hipMemset(r->film, 0, r->filmFloats * 4));
@@ -296,6 +314,10 @@ void mi_render_destroy(mi_render *r) {
     if (!r) return;
     (void) hipSetDevice(r->scene->h.device);
     for (void *p : r->allocs) (void) hipFree(p);
+    for (void *p : r->allocs2) (void) hipFree(p);
+    for (int i = 0; i < 2; ++i) if (r->filmDone[i]) (void) hipEventDestroy(r->filmDone[i]);
+    if (r->joinEv) (void) hipEventDestroy(r->joinEv);
+    if (r->stream2) (void) hipStreamDestroy(r->stream2);
     if (r->film) (void) hipFree(r->film);
     if (r->spill) (void) hipFree(r->spill);
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
@@ -310,38 +332,39 @@ int mi_render_clear(mi_render *r) {
     if (!r) return fail(MI_ERR_INVALID, "mi_render_clear: null"); HIPCHK(hipSetDevice(r->scene->h.device));
     HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream)); HIPCHK(hipMemsetAsync(r->spill, 0, r->filmFloats * 4, r->stream));
     if (r->q.counters) HIPCHK(hipMemsetAsync(r->q.counters, 0, 32, r->stream));
+    if (r->q2.counters) HIPCHK(hipMemsetAsync(r->q2.counters, 0, 32, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; return MI_OK;
 }
 void mi_render_cancel(mi_render *r) { if (r) r->cancel.store(1); }
 int mi_render_set_profiling(mi_render *r, int enabled) { if (!r) return fail(MI_ERR_INVALID, "null"); r->profiling = enabled != 0; return MI_OK; }
 
-static void mark(mi_render *r, int tag, size_t &used) {
-    if (!r->profiling) return;
+static void mark(mi_render *r, int tag, size_t &used, hipStream_t st = nullptr) {
+    if (!r->profiling || (st && st != r->stream)) return;      // stage events are recorded on the first stream only
     if (used >= r->evPool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; r->evPool.push_back(e); r->evTag.push_back(0); }
     (void) hipEventRecord(r->evPool[used], r->stream); r->evTag[used] = tag; ++used;
 }
 
 // trace one batch: paths = tile pixels x planes (or an explicit list), all bounces
-static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed) {
-    const DScene &sc = r->scene->h.d; hipStream_t st = r->stream;
+static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed, int pool = 0) {
+    const DScene &sc = r->scene->h.d; hipStream_t st = pool ? r->stream2 : r->stream; Queues &Q = pool ? r->q2 : r->q;
     (void) list;
     if (sc.packet_n) mi_upload_packet(r->scene->h.packet.data(), sc.packet_n, st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
-    mark(r, 0, evUsed);
-    mi_launch_generate(sc, r->rc, r->q, bd, r->grid, st);
+    mark(r, 0, evUsed, st);
+    mi_launch_generate(sc, r->rc, Q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
-        mark(r, 1, evUsed); mi_launch_extend(sc, r->q, buf, r->gridExtend, st);
-        mark(r, 2, evUsed); mi_launch_shade(sc, r->rc, r->q, buf, r->gridShade, st);
-        if (depth < maxDepth) { mark(r, 3, evUsed); mi_launch_shadow(sc, r->q, r->gridShadow, st); }
+        mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st);
+        mark(r, 2, evUsed, st); mi_launch_shade(sc, r->rc, Q, buf, r->gridShade, st);
+        if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
             std::vector<uint32_t> cnt(r->grid);
-            HIPCHK(hipMemcpyAsync(cnt.data(), r->q.count[buf], r->grid * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpyAsync(cnt.data(), Q.count[buf], r->grid * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
             uint64_t alive = 0; for (uint32_t c : cnt) alive += c;
             if (!alive) break;
         }
     }
-    mark(r, 0, evUsed);
+    mark(r, 0, evUsed, st);
     HIPCHK(hipGetLastError());
     return MI_OK;
 }
@@ -355,7 +378,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
     HIPCHK(hipSetDevice(h.device));
     const uint32_t npix = (tile.x1 - tile.x0) * (tile.y1 - tile.y0);
     uint32_t planes = r->p.planes_per_batch;
-    if (!planes) { const uint64_t target = 16u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
+    if (!planes) { const uint64_t target = (16u << 20) / (uint64_t) r->nStreams; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
     const uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
@@ -363,13 +386,21 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
     r->cancel.store(0);
     size_t evUsed = 0;
     HIPCHK(hipEventRecord(r->evBegin, r->stream));
-    for (uint32_t s = s0; s < s1; s += planes) {
-        if (r->cancel.load()) { HIPCHK(hipStreamSynchronize(r->stream)); return fail(MI_CANCELLED, "render cancelled"); }
+    const bool dual = r->nStreams > 1 && (s1 - s0) > planes;          // more than one batch: alternate the two pools / streams
+    if (dual) { HIPCHK(hipEventRecord(r->joinEv, r->stream)); HIPCHK(hipStreamWaitEvent(r->stream2, r->joinEv, 0)); }
+    int batch = 0; bool filmPending[2] = {false, false};
+    for (uint32_t s = s0; s < s1; s += planes, ++batch) {
+        if (r->cancel.load()) { HIPCHK(hipDeviceSynchronize()); return fail(MI_CANCELLED, "render cancelled"); }
+        const int pool = dual ? (batch & 1) : 0; hipStream_t st = pool ? r->stream2 : r->stream;
         BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr;
-        int rc = traceBatch(r, bd, nullptr, evUsed); if (rc) return rc;
-        mi_launch_film(h.d, r->q, bd, r->film, r->spill, r->stream);
+        int rc = traceBatch(r, bd, nullptr, evUsed, pool); if (rc) return rc;
+        // film accumulation stays in batch order (own-pixel sums are plain read-modify-writes): wait for the other pool's film kernel
+        if (dual && filmPending[pool ^ 1]) HIPCHK(hipStreamWaitEvent(st, r->filmDone[pool ^ 1], 0));
+        mi_launch_film(h.d, pool ? r->q2 : r->q, bd, r->film, r->spill, st);
+        if (dual) { HIPCHK(hipEventRecord(r->filmDone[pool], st)); filmPending[pool] = true; }
         r->samplesTotal += bd.n_paths;
     }
+    if (dual) { HIPCHK(hipEventRecord(r->joinEv, r->stream2)); HIPCHK(hipStreamWaitEvent(r->stream, r->joinEv, 0)); }
     mark(r, 0, evUsed);
     HIPCHK(hipEventRecord(r->evEnd, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
@@ -390,6 +421,7 @@ int mi_render_stats(mi_render *r, mi_stats *out) {
     HIPCHK(hipSetDevice(r->scene->h.device));
     unsigned long long c[4] = {0, 0, 0, 0};
     if (r->q.counters) HIPCHK(hipMemcpy(c, r->q.counters, 32, hipMemcpyDeviceToHost));
+    if (r->q2.counters) { unsigned long long c2[4]; HIPCHK(hipMemcpy(c2, r->q2.counters, 32, hipMemcpyDeviceToHost)); for (int i = 0; i < 4; ++i) c[i] += c2[i]; }
     r->stats.rays = c[0]; r->stats.shadow_rays = c[1]; r->stats.path_length_sum = c[2]; r->stats.samples = r->samplesTotal; r->stats.extend_rays = c[0];
     *out = r->stats; return MI_OK;
 }
@@ -430,7 +462,9 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     HIPCHK(hipMemcpy(dSlots, slots.data(), n * 4, hipMemcpyHostToDevice));
     BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList;
     size_t evUsed = 0; bool prof = r->profiling; r->profiling = false;
+    unsigned long long keep[4]; HIPCHK(hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost));     // the parity entry point leaves the ray counters untouched
     int rc = traceBatch(r, bd, dList, evUsed); r->profiling = prof;
+    if (!rc) { hipError_t e = hipStreamSynchronize(r->stream); if (e == hipSuccess) e = hipMemcpy(r->q.counters, keep, 32, hipMemcpyHostToDevice); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
     if (!rc) { mi_launch_gather_samples(r->q, dSlots, n, dOut, r->stream); hipError_t e = hipStreamSynchronize(r->stream); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
     if (!rc) { hipError_t e = hipMemcpy(outLi, dOut, n * 12, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
     (void) hipFree(dList); (void) hipFree(dOut); (void) hipFree(dSlots);
