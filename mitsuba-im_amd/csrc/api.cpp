@@ -191,6 +191,9 @@ int SceneHost::upload(int dev) {
         memcpy(d.env_to_world, envToWorld3, 36); memcpy(d.env_to_local, envToLocal3, 36); memcpy(d.env_bs_center, envBsCenter, 12);
     }
     d.bvh_depth = (uint32_t) bvhDepthOf(nodes, 0);
+    d.area_cdf_len = (uint32_t) areaCdf.size();
+    { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
+      d.small_tables = (tris.size() <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
     d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type == MI_BSDF_ROUGHCONDUCTOR) d.has_roughconductor = 1;
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (tris.size() <= MI_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;
@@ -239,7 +242,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 255) / 256 * 256;
     r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
     // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
-    r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", 768u));
+    r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", 512u));
     r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
     const uint64_t slots = cap * grid;
     for (int b = 0; b < 2; ++b) {
@@ -378,7 +381,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
     HIPCHK(hipSetDevice(h.device));
     const uint32_t npix = (tile.x1 - tile.x0) * (tile.y1 - tile.y0);
     uint32_t planes = r->p.planes_per_batch;
-    if (!planes) { const uint64_t target = (16u << 20) / (uint64_t) r->nStreams; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
+    if (!planes) { const uint64_t target = 16u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
     const uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");

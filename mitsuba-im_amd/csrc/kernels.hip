@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC, bool ENV>   // RC: the scene has rough conductors; ENV: it has an environment emitter (keeps the plain diffuse kernel lean)
+template <bool RC, bool ENV, bool SMALL>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint32_t s_wave[2][WG / 64];
@@ -177,9 +177,28 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = buf ^ 1;
     const SobolTabLds m32{(lds_u32_ptr) s_nib, rc.nib_count};   // always the LDS copy (ds_read lookups); unused by the independent stream
+    const uint32_t nibWords = rc.sampler == 1 ? rc.nib_dims * rc.nib_count * 16u : 4u;
     if (rc.sampler == 1) {   // stage the Sobol' nibble tables in LDS (nib_dims x nib_count x 16 words)
-        const uint32_t words = rc.nib_dims * rc.nib_count * 16u;
-        for (uint32_t i = tid; i < words; i += WG) s_nib[i] = rc.sobol_nib[i];
+        for (uint32_t i = tid; i < nibWords; i += WG) s_nib[i] = rc.sobol_nib[i];
+    }
+    // Scene tables: shading records, materials, emitters, CDFs.  Small scenes (<= 128 triangles ...) are staged in LDS: the shading
+    // stage chases hit -> triangle record -> material -> emitter CDF -> light triangle, and each hop is an L2 round trip otherwise.
+    Tabs<SMALL> tb;
+    if (SMALL) {
+        uint32_t *base = s_dyn + ((nibWords + 3u) & ~3u);
+        const uint32_t wShade = sc.n_tris * 24u, wMat = sc.n_materials * 16u, wEm = sc.n_emitters * 12u, wEc = (sc.n_emitters + 1u + 3u) & ~3u, wAc = sc.area_cdf_len;
+        uint32_t *pS = base, *pM = pS + wShade, *pE = pM + wMat, *pEc = pE + wEm, *pAc = pEc + wEc;
+        const uint32_t *gS = (const uint32_t *) sc.shade, *gM = (const uint32_t *) sc.materials, *gE = (const uint32_t *) sc.emitters, *gEc = (const uint32_t *) sc.emitter_cdf, *gAc = (const uint32_t *) sc.area_cdf;
+        for (uint32_t i = tid; i < wShade; i += WG) pS[i] = gS[i];
+        for (uint32_t i = tid; i < wMat; i += WG) pM[i] = gM[i];
+        for (uint32_t i = tid; i < wEm; i += WG) pE[i] = gE[i];
+        for (uint32_t i = tid; i < sc.n_emitters + 1u; i += WG) pEc[i] = gEc[i];
+        for (uint32_t i = tid; i < wAc; i += WG) pAc[i] = gAc[i];
+        tb.shade4 = (typename AS<SMALL>::p4) pS; tb.materials4 = (typename AS<SMALL>::p4) pM; tb.emitters4 = (typename AS<SMALL>::p4) pE;
+        tb.emitter_cdf = (typename AS<SMALL>::pf) pEc; tb.area_cdf = (typename AS<SMALL>::pf) pAc;
+    } else {
+        tb.shade4 = (typename AS<SMALL>::p4) sc.shade; tb.materials4 = (typename AS<SMALL>::p4) sc.materials; tb.emitters4 = (typename AS<SMALL>::p4) sc.emitters;
+        tb.emitter_cdf = (typename AS<SMALL>::pf) sc.emitter_cdf; tb.area_cdf = (typename AS<SMALL>::pf) sc.area_cdf;
     }
     unsigned long long pathLen = 0, shadowRays = 0;
     for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
@@ -211,18 +230,18 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                             float4 ro = q.rayO[buf][slot]; float nearT, farT;
                             if (bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {
                                 v3 value = envEval(sc, d);
-                                float lumPdf = envPdfDirection(sc, mat3(sc.env_to_local, d)) * (sc.emitters[sc.env_index].weight * sc.emitter_norm);
+                                float lumPdf = envPdfDirection(sc, mat3(sc.env_to_local, d)) * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
                                 add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                             }
                         }
                     }
                     break;
                 }
-                Hit h; fillHit(sc, d, hr.x, prim, hr.y, hr.z, h);
+                Hit h; fillHit(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
                 if (depth > 1) {
                     if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
-                        v3 value = emitterEval(sc, h.emitter, h.ns, -d);
-                        float lumPdf = pdfEmitterDirect(sc, h.emitter, d, h.ns, h.dist, facingRef);
+                        v3 value = emitterEval(tb, h.emitter, h.ns, -d);
+                        float lumPdf = pdfEmitterDirect(sc, tb, h.emitter, d, h.ns, h.dist, facingRef);
                         add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                     }
                     const int prevDepth = depth - 1;                         // rRec.depth++ >= m_rrDepth (path.cpp:276)
@@ -233,16 +252,16 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     }
                 }
                 if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
-                const MaterialD &bsdf = sc.materials[h.material];
+                const MaterialD bsdf = loadMaterial(tb, h.material);
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
-                    add = T * emitterEval(sc, h.emitter, h.ns, -d); haveAdd = true;
+                    add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }
                 if ((depth >= rc.max_depth && rc.max_depth > 0) || (rc.strict_normals && dot(d, h.ng) * h.wi.z >= 0)) { pathLen += (unsigned) depth; break; }
                 // emitter sampling (path.cpp:172-200)
                 v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;               // records.inl:160-164
                 if (!(h.flags & 4u)) {                                       // bsdf->getType() & BSDF::ESmooth
                     float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                    Direct dr; v3 value = sampleEmitterDirect<ENV>(sc, h.p, refN, sx, sy, dr);
+                    Direct dr; v3 value = sampleEmitterDirect<ENV>(sc, tb, h.p, refN, sx, sy, dr);
                     if (dr.pdf != 0) {
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
@@ -439,9 +458,12 @@ void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid,
 }
 void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
-    const bool env = sc.env_index >= 0;
-    if (sc.has_roughconductor) { if (env) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
-    else { if (env) hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    const bool env = sc.env_index >= 0, small = sc.small_tables != 0;
+    if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
+#define MI_SHADE(RC, ENV, SM) hipLaunchKernelGGL((k_shade<RC, ENV, SM>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf)
+    if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
+    else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }
+#undef MI_SHADE
 }
 void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     if (sc.packet_n) hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(WG), 0, st, sc, q);

@@ -61,6 +61,31 @@ DEV float sobolSampleNib(SobolTabT<P> st, uint32_t lo, uint32_t hi, uint32_t dim
     for (uint32_t n = 8; n < st.nibs; ++n) result ^= T[n * 16u + ((hi >> (4u * (n - 8u))) & 15u)];
     return minf((float) result * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
 }
+// Scene tables as seen by the shading kernel: either the global-memory arrays or (small scenes) a copy staged in LDS.  The pointer types
+// carry the address space so that the LDS variant compiles to ds_read instead of flat loads.
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <bool L> struct AS { typedef const f4 *p4; typedef const float *pf; };
+template <> struct AS<true> { typedef const __attribute__((address_space(3))) f4 *p4; typedef const __attribute__((address_space(3))) float *pf; };
+template <bool L> struct Tabs {
+    typename AS<L>::p4 shade4;      // TriShade: 6 x 16 B per triangle
+    typename AS<L>::p4 materials4;  // MaterialD: 4 x 16 B
+    typename AS<L>::p4 emitters4;   // EmitterD: 3 x 16 B
+    typename AS<L>::pf emitter_cdf, area_cdf;
+};
+template <bool L> DEV MaterialD loadMaterial(const Tabs<L> &t, int id) {
+    f4 a = t.materials4[id * 4 + 0], b = t.materials4[id * 4 + 1], c = t.materials4[id * 4 + 2], e = t.materials4[id * 4 + 3];
+    MaterialD m; m.type = __float_as_uint(a.x); m.flags = __float_as_uint(a.y); m.distr = __float_as_uint(a.z); m.alpha = a.w;
+    m.reflectance[0] = b.x; m.reflectance[1] = b.y; m.reflectance[2] = b.z; m.eta[0] = b.w; m.eta[1] = c.x; m.eta[2] = c.y;
+    m.k[0] = c.z; m.k[1] = c.w; m.k[2] = e.x; m.specular[0] = e.y; m.specular[1] = e.z; m.specular[2] = e.w;
+    return m;
+}
+template <bool L> DEV EmitterD loadEmitter(const Tabs<L> &t, int id) {
+    f4 a = t.emitters4[id * 3 + 0], b = t.emitters4[id * 3 + 1], c = t.emitters4[id * 3 + 2];
+    EmitterD e; e.radiance[0] = a.x; e.radiance[1] = a.y; e.radiance[2] = a.z; e.weight = a.w;
+    e.first_tri = __float_as_uint(b.x); e.tri_count = __float_as_uint(b.y); e.cdf_offset = __float_as_uint(b.z); e.inv_area = b.w;
+    e.type = __float_as_uint(c.x); e.shape = __float_as_int(c.y);
+    return e;
+}
 // src/samplers/sobolseq.h:99-131 look_up, scramble 0; vdc / vdcInv = row (m-1) of the tables
 DEV uint64_t sobolLookUp(const uint64_t *vdc, const uint64_t *vdcInv, uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
     uint64_t index = (uint64_t) frame << (m << 1);
@@ -187,9 +212,10 @@ struct Hit {
     v3 p, ng, ns, s, t, wi; float dist; int material, emitter; uint32_t flags;
 };
 // include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610
-DEV void fillHit(const DScene &sc, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
-    const float4 *rec = reinterpret_cast<const float4 *>(&sc.shade[prim]);
-    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+template <bool L>
+DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
+    typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
+    f4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
     v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z), p2 = V(r2.x, r2.y, r2.z);
     h.material = __float_as_int(r0.w); h.emitter = __float_as_int(r1.w); h.flags = __float_as_uint(r2.w);
     float bx = 1 - u - v, by = u, bz = v;
@@ -491,7 +517,8 @@ DEV bool bsphereIntersect(const DScene &sc, v3 ro, v3 rd, float &nearT, float &f
 
 // ---------------------------------------------------------------------------------------------- emitters
 // include/mitsuba/core/pmf.h:124-137 DiscreteDistribution::sample
-DEV uint32_t cdfSample(const float *cdf, uint32_t n, float x) {
+template <typename P>
+DEV uint32_t cdfSample(P cdf, uint32_t n, float x) {
     uint32_t lo = 0, hi = n + 1;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < x) lo = mid + 1; else hi = mid; }
     uint32_t index = lo > 0 ? lo - 1 : 0; if (index > n - 1) index = n - 1;
@@ -500,20 +527,21 @@ DEV uint32_t cdfSample(const float *cdf, uint32_t n, float x) {
 }
 struct Direct { v3 p, n, d; float dist, pdf; int emitter; };
 // src/emitters/area.cpp:106-111
-DEV v3 emitterEval(const DScene &sc, int e, v3 ns, v3 d) {
+template <bool L>
+DEV v3 emitterEval(const Tabs<L> &tb, int e, v3 ns, v3 d) {
     if (dot(ns, d) <= 0) return V(0, 0, 0);
-    return ld3(sc.emitters[e].radiance);
+    f4 a = tb.emitters4[e * 3]; return V(a.x, a.y, a.z);
 }
 // Scene::sampleEmitterDirect (src/librender/scene.cpp:860-884) without the visibility test (the shadow queue does it)
 // -> AreaLight::sampleDirect (src/emitters/area.cpp:160-176) -> Shape::sampleDirect (src/librender/shape.cpp:102-115)
 // -> TriMesh::samplePosition (src/librender/trimesh.cpp:413-425) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
-template <bool ENV>
-DEV v3 sampleEmitterDirect(const DScene &sc, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
-    uint32_t ei = cdfSample(sc.emitter_cdf, sc.n_emitters, sx);
-    float c0 = sc.emitter_cdf[ei], c1 = sc.emitter_cdf[ei + 1];
+template <bool ENV, bool L>
+DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
+    uint32_t ei = cdfSample(tb.emitter_cdf, sc.n_emitters, sx);
+    float c0 = tb.emitter_cdf[ei], c1 = tb.emitter_cdf[ei + 1];
     float emPdf = c1 - c0;
     sx = (sx - c0) / (c1 - c0);
-    const EmitterD &em = sc.emitters[ei];
+    const EmitterD em = loadEmitter(tb, (int) ei);
     if (ENV && em.type == 1) {                                   // EnvironmentMap::sampleDirect (envmap.cpp:520-547)
         v3 value, dl; float pdf, nearT, farT;
         envSampleDirection(sc, sx, sy, dl, value, pdf);
@@ -525,20 +553,20 @@ DEV v3 sampleEmitterDirect(const DScene &sc, v3 ref, v3 refN, float sx, float sy
         { float r = 1.0f / emPdf; value = value * r; }
         return value;
     }
-    const float *acdf = sc.area_cdf + em.cdf_offset;
+    typename AS<L>::pf acdf = tb.area_cdf + em.cdf_offset;
     uint32_t ti = cdfSample(acdf, em.tri_count, sy);
     float a0 = acdf[ti], a1 = acdf[ti + 1];
     sy = (sy - a0) / (a1 - a0);
     uint32_t prim = em.first_tri + ti;
-    const float4 *rec = reinterpret_cast<const float4 *>(&sc.shade[prim]);
-    float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
+    f4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z), p2 = V(r2.x, r2.y, r2.z);
     float bx, by; uniformTriangle(sx, sy, bx, by);
     v3 sideA = p1 - p0, sideB = p2 - p0;
     dr.p = (p0 + sideA * bx) + sideB * by;
     if (__float_as_uint(r2.w) & 1u) dr.n = normalize(cross(sideA, sideB));
     else {
-        float4 r4 = rec[4], r5 = rec[5];
+        f4 r4 = rec[4], r5 = rec[5];
         uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
         dr.n = normalize((ld3(sc.nrm + 3 * i0) * (1.0f - bx - by) + ld3(sc.nrm + 3 * i1) * bx) + ld3(sc.nrm + 3 * i2) * by);
     }
@@ -563,11 +591,13 @@ DEV v3 sampleEmitterDirect(const DScene &sc, v3 ref, v3 refN, float sx, float sy
 }
 // Scene::pdfEmitterDirect (scene.cpp:981-984) -> AreaLight::pdfDirect (area.cpp:178-184) -> Shape::pdfDirect (shape.cpp:117-126);
 // `facingRef` = (dot(d, refN) >= 0) evaluated where refN was still known (the previous vertex)
-DEV float pdfEmitterDirect(const DScene &sc, int e, v3 d, v3 n, float dist, bool facingRef) {
+template <bool L>
+DEV float pdfEmitterDirect(const DScene &sc, const Tabs<L> &tb, int e, v3 d, v3 n, float dist, bool facingRef) {
+    f4 a = tb.emitters4[e * 3], b = tb.emitters4[e * 3 + 1];     // a.w = weight, b.w = inv_area
     float pdf;
-    if (facingRef && dot(d, n) < 0) pdf = sc.emitters[e].inv_area * (dist * dist) / fabsf(dot(d, n));
+    if (facingRef && dot(d, n) < 0) pdf = b.w * (dist * dist) / fabsf(dot(d, n));
     else pdf = 0.0f;
-    return pdf * (sc.emitters[e].weight * sc.emitter_norm);
+    return pdf * (a.w * sc.emitter_norm);
 }
 DEV float miWeight(float a, float b) { a *= a; b *= b; return a / (a + b); }   // src/integrators/path/path.cpp:296-300
 

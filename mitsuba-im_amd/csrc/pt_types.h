@@ -68,6 +68,7 @@ struct DScene {
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
     uint32_t packet_n, bvh_depth;
     uint32_t has_roughconductor;          // selects the shade kernel variant
+    uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none
     const float *env_rgb, *env_cdf_cols, *env_cdf_rows, *env_row_weights;
     int32_t env_index, env_w, env_h;
