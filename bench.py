@@ -106,7 +106,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    stage = {"extend_ms": 0.0, "shade_ms": 0.0, "shadow_ms": 0.0, "other_ms": 0.0, "render_ms": 0.0, "extend_launches": 0}
+    stage = {"extend_ms": 0.0, "shade_ms": 0.0, "shadow_ms": 0.0, "other_ms": 0.0, "render_ms": 0.0, "extend_launches": 0, "extend_launches_all": 0}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -142,8 +142,12 @@ def main():
             per_step = {"extend": 48.0 * rays, "shade": 68.0 * rays + 68.0 * survivors + 48.0 * shadow, "shadow": 48.0 * shadow}
             ms = {"extend": stage["extend_ms"], "shade": stage["shade_ms"], "shadow": stage["shadow_ms"]}
             dom = max(ms, key=ms.get)
-            launches = stage["extend_launches"] if dom != "shadow" else stage["extend_launches"] * (args.max_depth - 1) / args.max_depth
-            achieved = per_step[dom] * args.steps / (ms[dom] * 1e-3) / 1e9
+            # batches alternate between two path pools / HIP streams; the stage events sit on the first stream, so `ms` covers `timed` of
+            # the `total` launches (all launches move the same bytes on average): bytes per launch = step bytes / total launches
+            shrink = (args.max_depth - 1) / args.max_depth if dom == "shadow" else 1.0
+            launches = stage["extend_launches"] * shrink; total = stage["extend_launches_all"] * shrink
+            bytes_per_launch = per_step[dom] * args.steps / max(total, 1)
+            achieved = bytes_per_launch * launches / (ms[dom] * 1e-3) / 1e9
             # measured HBM bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) of this very
             # workload, committed under profiles/ (PMC cannot be collected from inside the timed run); valid for the default 1080p batches only
             traffic = None
@@ -156,7 +160,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "avg_launch_us": round(ms[dom] * 1e3 / max(launches, 1), 2), "launches": int(launches),
-                               "algorithmic_bytes_per_launch": round(per_step[dom] * args.steps / max(launches, 1), 1)}
+                               "algorithmic_bytes_per_launch": round(bytes_per_launch, 1), "streams": 2 if total > launches else 1,
+                               "note": "launch durations are measured while the other stream's kernels share the CUs"}
             seg_bytes = 288.0 * rays + 16.0 * n
             out["pipeline"] = {"bytes_per_sample": round(seg_bytes / n, 1), "achieved_GBs": round(seg_bytes * args.steps / (stage["render_ms"] * 1e-3) / 1e9, 2),
                                "frac_of_hbm_peak": round(seg_bytes * args.steps / (stage["render_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

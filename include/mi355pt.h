@@ -68,7 +68,8 @@ typedef struct {
                                                               avgPathLength (src/librender/skdtree.cpp:46-47, src/integrators/path/path.cpp:24) */
     double render_ms;                                      /* device time of the last mi_render_run (HIP events) */
     double extend_ms, shade_ms, shadow_ms, other_ms;       /* per-stage device time of the last run (0 unless profiling enabled) */
-    uint64_t extend_launches, extend_rays;                 /* launches / rays of the dominant kernel in the last run */
+    uint64_t extend_launches, extend_rays;                 /* extend launches TIMED in the last run (first stream only) / closest-hit rays since clear */
+    uint64_t extend_launches_all;                          /* extend launches of the last run on all streams */
 } mi_stats;
 
 const char *mi_last_error(void);

@@ -43,7 +43,7 @@ class MiTile(C.Structure):
 class MiStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("path_length_sum", C.c_uint64), ("samples", C.c_uint64),
                 ("render_ms", C.c_double), ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double), ("other_ms", C.c_double),
-                ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64)]
+                ("extend_launches", C.c_uint64), ("extend_rays", C.c_uint64), ("extend_launches_all", C.c_uint64)]
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",

@@ -40,7 +40,7 @@ struct mi_render {
     std::atomic<int> cancel{0};
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
     mi_stats stats{};
-    uint64_t samplesTotal = 0;
+    uint64_t samplesTotal = 0, launchesAll = 0;
     uint32_t *dNib = nullptr;
     // optional second path pool + stream: consecutive batches alternate between the two, so the ALU-bound traversal kernels of one batch
     // overlap the latency-bound shading kernels of the other on the same CUs (MI355PT_STREAMS=2, default)
@@ -356,7 +356,7 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     mi_launch_generate(sc, r->rc, Q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
-        mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st);
+        mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
         mark(r, 2, evUsed, st); mi_launch_shade(sc, r->rc, Q, buf, r->gridShade, st);
         if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
         buf ^= 1;
@@ -387,7 +387,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
     if (need != r->poolPaths) { int rc = allocPool(r, need); if (rc) return rc; }
     r->cancel.store(0);
-    size_t evUsed = 0;
+    size_t evUsed = 0; r->launchesAll = 0;
     HIPCHK(hipEventRecord(r->evBegin, r->stream));
     const bool dual = r->nStreams > 1 && (s1 - s0) > planes;          // more than one batch: alternate the two pools / streams
     if (dual) { HIPCHK(hipEventRecord(r->joinEv, r->stream)); HIPCHK(hipStreamWaitEvent(r->stream2, r->joinEv, 0)); }
@@ -425,7 +425,7 @@ int mi_render_stats(mi_render *r, mi_stats *out) {
     unsigned long long c[4] = {0, 0, 0, 0};
     if (r->q.counters) HIPCHK(hipMemcpy(c, r->q.counters, 32, hipMemcpyDeviceToHost));
     if (r->q2.counters) { unsigned long long c2[4]; HIPCHK(hipMemcpy(c2, r->q2.counters, 32, hipMemcpyDeviceToHost)); for (int i = 0; i < 4; ++i) c[i] += c2[i]; }
-    r->stats.rays = c[0]; r->stats.shadow_rays = c[1]; r->stats.path_length_sum = c[2]; r->stats.samples = r->samplesTotal; r->stats.extend_rays = c[0];
+    r->stats.rays = c[0]; r->stats.shadow_rays = c[1]; r->stats.path_length_sum = c[2]; r->stats.samples = r->samplesTotal; r->stats.extend_rays = c[0]; r->stats.extend_launches_all = r->launchesAll;
     *out = r->stats; return MI_OK;
 }
 

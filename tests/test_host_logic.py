@@ -36,7 +36,9 @@ def test_argument_validation_without_gpu(mi):
     mats = (mi.api.MiMaterial * 1)(mi.api.MiMaterial(7, 0, 0, 0.1))
     assert L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), 1) == 3          # MI_ERR_UNSUPPORTED
     assert L.L.mi_scene_commit(h, 0) == 1 and b"must be set first" in L.L.mi_last_error()
-    assert L.L.mi_scene_set_envmap(h, None, 0, 0, None, 1.0) == 3
+    assert L.L.mi_scene_set_envmap(h, None, 0, 0, None, 1.0) == 1 and b"mi_scene_set_envmap" in L.L.mi_last_error()
+    ems = (mi.api.MiEmitter * 2)(mi.api.MiEmitter(1, -1), mi.api.MiEmitter(1, -1))
+    assert L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), 2) == 1 and b"only contain one environment emitter" in L.L.mi_last_error()
     L.L.mi_scene_destroy(h)
     with pytest.raises(mi.MiError):
         mi.api.Lib("/nonexistent/libmi355pt.so")
