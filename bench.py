@@ -81,7 +81,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MI355PT_FORCE_DIST") == "1"      # the latter: exercise the RCCL calls on a single GPU
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     total_spp = args.spp * world                       # weak scaling: per-rank samples fixed
@@ -97,10 +99,11 @@ def main():
         render.clear()
         render.run(tile=tile, s0=0, s1=total_spp)
         render.read_film_device(0, film.data_ptr())
-        mi_dist.reduce_film(film, dist if world > 1 else None, dst=0)
+        if use_dist:
+            dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)      # the one exchange step of the path (mitsuba-im_amd/dist.py: reduce_film)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -116,7 +119,7 @@ def main():
             stage[k] += st[k]
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.item())
 
     st = render.stats()                                 # counters accumulate since the last clear = one step
@@ -170,7 +173,7 @@ def main():
             out["roofline"] = None
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(S, args.width, args.height, args.max_depth)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
 

@@ -19,6 +19,10 @@
 #include <mitsuba/render/renderqueue.h>
 #include <mitsuba/core/rfilter.h>
 #include <mitsuba/core/plugin.h>
+#include <mitsuba/core/fresolver.h>
+#include <mitsuba/core/bitmap.h>
+#include <mitsuba/core/half.h>
+#include <ior.h>   // src/bsdfs/ior.h: lookupIOR, as used by RoughConductor's constructor
 #include "../integrator_host.h"
 
 MTS_NAMESPACE_BEGIN
@@ -28,6 +32,7 @@ namespace {
 struct FlatScene {
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
     bool anyNormals = false;
+    std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16], envScale = 1.0f;
 };
 
 #define MI_CHECK(call) do { int rc_ = (call); if (rc_ != MI_OK) SLog(EError, "path_hip: %s failed: %s", #call, mi_last_error()); } while (0)
@@ -35,11 +40,36 @@ struct FlatScene {
 /// BSDF -> mi_material.  Only what the hot path implements; anything else is reported, never silently approximated.
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
+    if (bsdf->getClass()->getName() == "RoughConductor") {
+        // same derivation as RoughConductor's constructor (src/bsdfs/roughconductor.cpp:170-207): eta / k from the properties or from
+        // data/ior/<material>.{eta,k}.spd, divided by the exterior IOR; isotropic alpha; Beckmann / GGX with visible-normal sampling
+        const Properties &props = bsdf->getProperties();
+        std::string material = props.getString("material", "Cu"), distr = props.getString("distribution", "beckmann");
+        std::transform(material.begin(), material.end(), material.begin(), ::tolower); std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+        Spectrum intEta, intK;
+        if (material == "none") { intEta = Spectrum(0.0f); intK = Spectrum(1.0f); }
+        else {
+            ref<FileResolver> fr = Thread::getThread()->getFileResolver(); std::string name = props.getString("material", "Cu");
+            intEta.fromContinuousSpectrum(InterpolatedSpectrum(fr->resolve(fs::pathstr("data/ior/" + name + ".eta.spd"))));
+            intK.fromContinuousSpectrum(InterpolatedSpectrum(fr->resolve(fs::pathstr("data/ior/" + name + ".k.spd"))));
+        }
+        Float extEta = lookupIOR(props, "extEta", "air");
+        Spectrum eta = props.getSpectrum("eta", intEta) / extEta, k = props.getSpectrum("k", intK) / extEta, spec = props.getSpectrum("specularReflectance", Spectrum(1.0f));
+        if (props.hasProperty("alphaU") || props.hasProperty("alphaV") || (distr != "beckmann" && distr != "ggx") || !props.getBoolean("sampleVisible", true))
+            SLog(EError, "path_hip: roughconductor is implemented for isotropic beckmann / ggx with sampleVisible = true");
+        m.type = MI_BSDF_ROUGHCONDUCTOR; m.flags = MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr == "ggx" ? 1u : 0u; m.alpha = props.getFloat("alpha", 0.1f);
+        Float r, g, b;
+        eta.toLinearRGB(r, g, b); m.eta[0] = r; m.eta[1] = g; m.eta[2] = b;
+        k.toLinearRGB(r, g, b); m.k[0] = r; m.k[1] = g; m.k[2] = b;
+        spec.toLinearRGB(r, g, b); m.specular[0] = r; m.specular[1] = g; m.specular[2] = b;
+        return m;
+    }
     bool backSide = false;
     for (int i = 0; i < bsdf->getComponentCount(); ++i) {
         unsigned int type = bsdf->getType(i);
         if (!(type & BSDF::EDiffuseReflection))
-            SLog(EError, "path_hip: BSDF \"%s\" has a non-diffuse lobe; only diffuse (optionally twosided) is implemented", bsdf->getClass()->getName().c_str());
+            SLog(EError, "path_hip: BSDF \"%s\" has a non-diffuse lobe; implemented: diffuse (optionally twosided) and un-wrapped roughconductor "
+                         "(a twosided wrapper does not expose its nested BSDF's parameters)", bsdf->getClass()->getName().c_str());
         backSide |= (type & BSDF::EBackSide) != 0;
     }
     Intersection its; its.uv = Point2(0.5f); its.p = Point(0.0f); its.hasUVPartials = false;
@@ -78,8 +108,21 @@ static void flatten(const Scene *scene, FlatScene &fs) {
     const ref_vector<Emitter> &emitters = scene->getEmitters();
     for (size_t e = 0; e < emitters.size(); ++e) {
         const Emitter *em = emitters[e].get();
+        if (em->isEnvironmentEmitter() && em->getClass()->getName() == "EnvironmentMap") {
+            // level-0 texels of the (half precision) MIP map, world transform and scale (src/emitters/envmap.cpp)
+            ref<Bitmap> bmp = em->getBitmap(Vector2i(-1));
+            fs.envW = (uint32_t) bmp->getWidth(); fs.envH = (uint32_t) bmp->getHeight(); const size_t n = (size_t) fs.envW * fs.envH * 3;
+            if (bmp->getPixelFormat() != Bitmap::ERGB) SLog(EError, "path_hip: unexpected environment bitmap format");
+            if (bmp->getComponentFormat() == Bitmap::EFloat16) { const half *h = bmp->getFloat16Data(); fs.envRGB.resize(n); for (size_t i = 0; i < n; ++i) fs.envRGB[i] = (float) h[i]; }
+            else if (bmp->getComponentFormat() == Bitmap::EFloat32) fs.envRGB.assign(bmp->getFloat32Data(), bmp->getFloat32Data() + n);
+            else SLog(EError, "path_hip: unexpected environment bitmap component format");
+            Matrix4x4 tw = em->getWorldTransform()->eval(0.0f).getMatrix(); for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) fs.envToWorld[i * 4 + j] = tw(i, j);
+            fs.envScale = em->getProperties().getFloat("scale", 1.0f);
+            mi_emitter me; memset(&me, 0, sizeof(me)); me.type = MI_EMITTER_ENVMAP; me.shape = -1; me.weight = em->getSamplingWeight();
+            fs.emitters.push_back(me); continue;
+        }
         if (!em->isOnSurface() || em->isEnvironmentEmitter())
-            SLog(EError, "path_hip: emitter \"%s\" is not an area light; only area emitters are implemented", em->getClass()->getName().c_str());
+            SLog(EError, "path_hip: emitter \"%s\" is neither an area light nor an envmap", em->getClass()->getName().c_str());
         const Shape *shape = em->getShape(); int shapeIdx = -1;
         for (size_t mi = 0; mi < meshes.size(); ++mi) if (meshes[mi] == shape) shapeIdx = (int) mi;
         if (shapeIdx < 0) SLog(EError, "path_hip: area emitter without a triangle mesh");
@@ -103,6 +146,7 @@ struct GpuScene {
                                         (uint32_t) (fs.pos.size() / 3), (uint32_t) (fs.idx.size() / 3), fs.shapes.data(), (uint32_t) fs.shapes.size()));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
+        if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));
         // camera: rebuild m_sampleToCamera exactly as PerspectiveCameraImpl::configure does (perspective.cpp:150-157); it is a protected member
         if (!sensor->getClass()->derivesFrom(MTS_CLASS(PerspectiveCamera))) SLog(EError, "path_hip: only the perspective camera is implemented");
         const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
