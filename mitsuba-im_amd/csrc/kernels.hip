@@ -16,48 +16,52 @@
 #define STACK_DEPTH 32   // >= BVH depth (scene_build.cpp caps it; mi_scene_commit refuses deeper trees)
 
 // ---------------------------------------------------------------------------------------------- BVH traversal
-// Conservative slab test against a (padded) child box; returns entry distance. NaN-free: zero direction components are
-// replaced by +-1e-30 before the reciprocal is taken.
-DEV bool slab(const float lo[3], const float hi[3], v3 o, v3 inv, float tmin, float tmax, float &tnear) {
-    float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
-    float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
-    float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+// Conservative slab test against a (padded) child box; returns the entry distance.  Pure culling, so it is free to use fused
+// multiply-adds: t = lo * inv + (-o * inv).  NaN-free: zero direction components are replaced by +-1e-30 before the reciprocal.
+DEV bool slab(f4 lo, f4 hi, v3 inv, v3 oi, float tmin, float tmax, float &tnear) {
+    float ax = __builtin_fmaf(lo.x, inv.x, oi.x), bx = __builtin_fmaf(hi.x, inv.x, oi.x);
+    float ay = __builtin_fmaf(lo.y, inv.y, oi.y), by = __builtin_fmaf(hi.y, inv.y, oi.y);
+    float az = __builtin_fmaf(lo.z, inv.z, oi.z), bz = __builtin_fmaf(hi.z, inv.z, oi.z);
     float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     tnear = t0;
-    return t0 <= t1 * 1.0000005f + 1e-30f;
+    return t0 <= t1 * 1.000002f + 1e-30f;
 }
 DEV float safeInv(float d) { float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; return 1.0f / a; }
 
-// Closest hit: minimum t, ties towards the lower original triangle index (order independent).  `stk`/`stkT` point at this
-// lane's column of the workgroup's LDS stack (stride WG).
+// Closest hit: minimum t, ties towards the lower original triangle index (order independent).  `stk` points at this lane's column
+// of the workgroup's LDS stack (stride WG).  "while-while" shape: all lanes of a wave first descend through inner nodes until each
+// holds a leaf (or is done), then all test their leaf triangles -- the two code paths are not interleaved lane by lane.
+#define BVH_DONE 0x7FFFFFFF
 template <bool ANY>
 DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk,
                   float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
-    v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
-    const float4 *nodes4 = reinterpret_cast<const float4 *>(sc.nodes);
-    const float4 *tris4 = reinterpret_cast<const float4 *>(sc.tris);
+    const v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
+    const v3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    const f4 *nodes4 = reinterpret_cast<const f4 *>(sc.nodes);
+    const f4 *tris4 = reinterpret_cast<const f4 *>(sc.tris);
     float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
     int sp = 0; int cur = 0;
     while (true) {
-        if (cur >= 0) {
-            float4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
-            float lo0[3] = {n0.x, n0.y, n0.z}, hi0[3] = {n1.x, n1.y, n1.z}, lo1[3] = {n2.x, n2.y, n2.z}, hi1[3] = {n3.x, n3.y, n3.z};
+        while (cur >= 0 && cur != BVH_DONE) {
+            f4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
             int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
             float t0, t1;
-            bool h0 = slab(lo0, hi0, o, inv, mint, best, t0), h1 = slab(lo1, hi1, o, inv, mint, best, t1);
+            bool h0 = slab(n0, n1, inv, oi, mint, best, t0), h1 = slab(n2, n3, inv, oi, mint, best, t1);
             if (h0 && h1) {
                 bool swap = t1 < t0;
-                int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
-                stk[sp * WG] = farC; ++sp;
-                cur = nearC;
-                continue;
-            } else if (h0) { cur = c0; continue; }
-            else if (h1) { cur = c1; continue; }
-        } else {
+                stk[sp * WG] = swap ? c0 : c1; ++sp;
+                cur = swap ? c1 : c0;
+            } else if (h0) cur = c0;
+            else if (h1) cur = c1;
+            else if (sp > 0) { --sp; cur = stk[sp * WG]; }
+            else cur = BVH_DONE;
+        }
+        if (cur == BVH_DONE) break;
+        {
             uint32_t code = (uint32_t) ~cur; uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
             for (uint32_t i = 0; i < cnt; ++i) {
-                float4 a = tris4[(first + i) * 3 + 0], b = tris4[(first + i) * 3 + 1], c = tris4[(first + i) * 3 + 2];
+                f4 a = tris4[(first + i) * 3 + 0], b = tris4[(first + i) * 3 + 1], c = tris4[(first + i) * 3 + 2];
                 TriAccelD ta; ta.k = __float_as_uint(a.x); ta.n_u = a.y; ta.n_v = a.z; ta.n_d = a.w;
                 ta.a_u = b.x; ta.a_v = b.y; ta.b_nu = b.z; ta.b_nv = b.w; ta.c_nu = c.x; ta.c_nv = c.y; ta.prim = __float_as_uint(c.z);
                 float u, v, t;
@@ -66,10 +70,8 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
                     if (!found || t < best || (t == best && ta.prim < bprim)) { best = t; bprim = ta.prim; bu = u; bv = v; found = true; }
                 }
             }
+            if (sp > 0) { --sp; cur = stk[sp * WG]; } else cur = BVH_DONE;
         }
-        // pop
-        if (sp == 0) break;
-        --sp; cur = stk[sp * WG];
     }
     bestT = best; bestPrim = bprim; bestU = bu; bestV = bv;
     return found;
