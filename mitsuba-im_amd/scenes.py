@@ -133,7 +133,7 @@ class _Builder:
 
 
 def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5,
-                filter_kind=FILTER_BOX, seed=0):
+                filter_kind=FILTER_BOX, seed=0, strict_normals=False, hide_emitters=False):
     """S1: the classic Cornell box data (units 0..560), one-sided `diffuse` everywhere with
     consistent winding (face normals point into the room / out of the blocks), ceiling quad light lowered to
     y=548.3 so that no two surfaces coincide; block bottoms (coplanar with the floor) are left out => 32 triangles."""
@@ -165,7 +165,8 @@ def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth
     b.end(white)
     cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0,
-                        width, height, spp, sampler, max_depth, rr_depth, filter_kind, seed, name="cornell")
+                        width, height, spp, sampler, max_depth, rr_depth, filter_kind, seed, strict_normals=strict_normals,
+                        hide_emitters=hide_emitters, name="cornell")
 
 
 def closed_box(width=128, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=8):
@@ -265,7 +266,7 @@ def _lcg(seed):
 
 
 def atrium(width=3840, height=2160, spp=64, sampler=SAMPLER_SOBOL, max_depth=8, detail=1.0, env_size=(1024, 512), sky_visible=True,
-           filter_kind=FILTER_BOX):
+           filter_kind=FILTER_BOX, strict_normals=False, hide_emitters=False, rr_depth=5, seed=0):
     """S3: procedurally generated Sponza-class colonnade / atrium.  A 36 x 24 m tiled floor (per-tile diffuse colours from
     an LCG seeded 1234, 16-colour palette), two rows of tessellated columns with SMOOTH vertex normals, four walls, a gallery slab with an
     open roof, two emissive lanterns and a procedural sky environment map.  detail = 1 gives ~250 k triangles."""
@@ -324,7 +325,7 @@ def atrium(width=3840, height=2160, spp=64, sampler=SAMPLER_SOBOL, max_depth=8, 
     cam = look_at((-X * 0.8, 3.2, 0.5), (X * 0.2, 1.2, -1.0), (0, 1, 0))
     env = dict(rgb=procedural_sky(*env_size), to_world=np.eye(4, dtype=f32), scale=1.0)
     sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 60.0, 0.05, 500.0, width, height, spp, sampler, max_depth,
-                      5, filter_kind, normals=normals, envmap=env, name="atrium")
+                      rr_depth, filter_kind, seed, normals=normals, envmap=env, strict_normals=strict_normals, hide_emitters=hide_emitters, name="atrium")
     # the environment emitter is a scene-level emitter: it comes first in Scene::getEmitters() (added before the shapes are expanded)
     sc.emitters.insert(0, dict(type=EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=1.0))
     for sh in sc.shapes:

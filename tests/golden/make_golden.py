@@ -30,6 +30,11 @@ def golden_scenes():
         "closed_box": scenes.closed_box(width=64, height=64, spp=16),
         "veach_small": scenes.veach_mis(width=96, height=54, spp=16),
         "atrium_small": scenes.atrium(width=96, height=54, spp=16, detail=0.08, env_size=(64, 32)),
+        # integrator switches: strictNormals (smooth-shaded columns make it bite), hideEmitters, early Russian roulette, unbounded depth
+        "atrium_strict": scenes.atrium(width=96, height=54, spp=8, detail=0.08, env_size=(64, 32), strict_normals=True, rr_depth=2),
+        "atrium_hide_indep": scenes.atrium(width=96, height=54, spp=8, detail=0.08, env_size=(64, 32), hide_emitters=True, sampler=scenes.SAMPLER_INDEPENDENT,
+                                           max_depth=-1, rr_depth=3, seed=7),
+        "cornell_hide": scenes.cornell_box(width=96, height=54, spp=8, hide_emitters=True, max_depth=3, rr_depth=1),
     }
 
 

@@ -228,3 +228,22 @@ def test_large_scene_bvh_vs_oracle(mi, oracle):
             assert (bits(got[i, :3]) == bits(np.array([h[0], h[13], h[14]], np.float32))).all()
             assert int(got[i, 3]) == sc.shapes[int(h[19])]["first_tri"] + int(h[18])
         assert orc.occluded(rays[i]) == (occ[i, 3] >= 0)
+
+
+@pytest.mark.parametrize("name", ["atrium_strict", "atrium_hide_indep", "cornell_hide"])
+def test_integrator_switches(mi, oracle, golden_scenes, name):
+    """strictNormals, hideEmitters, early Russian roulette (rrDepth 1..3), unbounded depth (maxDepth = -1, independent stream)."""
+    sc = golden_scenes[name]; r = mi.Render(mi.Scene(sc))
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); pairs = gd["pairs"]
+    o = oracle.Oracle(sc).render_samples(pairs); got = r.samples(pairs)
+    if name == "cornell_hide":
+        assert (bits(got) == bits(o["li"])).all()
+        err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6); assert err.max() < 2e-4
+    else:
+        err = np.abs(got - o["li"]).max(1) / (np.abs(o["li"]).max(1) + 1e-6)
+        assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6
+        err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
+        assert (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.995
+    r.run(); film = r.read_film(0); ofilm, cnt = oracle.Oracle(sc).render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 3e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 2e-3 and abs(st["path_length_sum"] - int(cnt[2])) / cnt[2] < 2e-3
