@@ -202,18 +202,43 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         tb.shade4 = (typename AS<SMALL>::p4) sc.shade; tb.materials4 = (typename AS<SMALL>::p4) sc.materials; tb.emitters4 = (typename AS<SMALL>::p4) sc.emitters;
         tb.emitter_cdf = (typename AS<SMALL>::pf) sc.emitter_cdf; tb.area_cdf = (typename AS<SMALL>::pf) sc.area_cdf;
     }
+    // Material-sorted shading (scenes that mix BSDF classes): the paths of a segment are first ordered by the class of the surface
+    // they hit -- diffuse-like from the front, rough conductors from the back of an LDS index list (wave64 ballots, order preserving) --
+    // so a wave runs either the cheap diffuse code or the microfacet code, not both.  The queues are then read through that list.
+    uint16_t *s_order = reinterpret_cast<uint16_t *>(s_dyn + rc.order_offset_words);
+    const bool doSort = RC && rc.order_offset_words != 0 && q.cap <= 0xFFFFu;
     unsigned long long pathLen = 0, shadowRays = 0;
     for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
     if (tid < 2) s_base[tid] = 0;
     __syncthreads();
+    if (doSort) {
+        uint32_t done0 = 0, done1 = 0;                       // uniform running counts (front / back)
+        for (uint32_t base = 0; base < n; base += WG) {
+            const uint32_t i = base + tid; int cls = 2;
+            if (i < n) {
+                const uint32_t prim = __float_as_uint(q.hit[segBase + i].w);
+                cls = (prim != 0xFFFFFFFFu && (__float_as_uint(tb.shade4[prim * 6u + 2u].w) & 8u)) ? 1 : 0;
+            }
+            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), ltm = (1ull << lane) - 1ull;
+            if (lane == 0) { s_wave[0][wave] = (uint32_t) __popcll(m0); s_wave[1][wave] = (uint32_t) __popcll(m1); }
+            __syncthreads();
+            uint32_t o0 = done0, o1 = done1, t0 = 0, t1 = 0;
+#pragma unroll
+            for (int w = 0; w < WG / 64; ++w) { uint32_t a = s_wave[0][w], b = s_wave[1][w]; if (w < (int) wave) { o0 += a; o1 += b; } t0 += a; t1 += b; }
+            if (cls == 0) s_order[o0 + (uint32_t) __popcll(m0 & ltm)] = (uint16_t) i;
+            else if (cls == 1) s_order[n - 1u - (o1 + (uint32_t) __popcll(m1 & ltm))] = (uint16_t) i;
+            done0 += t0; done1 += t1;
+            __syncthreads();
+        }
+    }
     for (uint32_t base = 0; base < n; base += WG) {
         const uint32_t i = base + tid;
         bool alive = false, wantShadow = false;
         float4 nrO, nrD, nS1, shO, shD, shC; uint4 nS0; float nS2 = 0;
         if (i < n) {
-            const uint64_t slot = segBase + i;
+            const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
             float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
             float prevPdf = q.st2[buf][slot];
             const uint32_t pid = s0.x; SamplerState ss; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
@@ -462,7 +487,9 @@ void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, i
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
     const bool env = sc.env_index >= 0, small = sc.small_tables != 0;
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
-#define MI_SHADE(RC, ENV, SM) hipLaunchKernelGGL((k_shade<RC, ENV, SM>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf)
+    RenderConst rcl = rc; rcl.order_offset_words = 0;
+    if (sc.has_roughconductor && q.cap <= 0xFFFFu) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 + 16; }
+#define MI_SHADE(RC, ENV, SM) hipLaunchKernelGGL((k_shade<RC, ENV, SM>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf)
     if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
     else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }
 #undef MI_SHADE

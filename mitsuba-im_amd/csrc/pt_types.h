@@ -31,7 +31,7 @@ struct BvhNode {
 struct TriShade {
     float p0[3]; int32_t material;
     float p1[3]; int32_t emitter;
-    float p2[3]; uint32_t flags;          // bit0 face normals, bit1 material has a back side (twosided), bit2 BSDF without a smooth component (no NEE)
+    float p2[3]; uint32_t flags;          // bit0 face normals, bit1 material has a back side (twosided), bit2 BSDF without a smooth component (no NEE), bit3 rough conductor (material class for sorted shading)
     float ng[3]; uint32_t local_prim;
     float s[3]; uint32_t i0;
     float t[3]; uint32_t i1;              // i0,i1,i2: vertex indices for smooth normals (i2 in `i2` array)
@@ -82,4 +82,5 @@ struct RenderConst {
     uint32_t sampler; uint32_t seed_mix;  // independent: seed * 0x9E3779B9
     // Sobol' direction matrices folded into 4-bit lookup tables: nib[dim][n][v] = XOR of matrices32[dim*52 + 4n + b] over the bits b of v
     const uint32_t *sobol_nib; uint32_t nib_count, nib_dims;
+    uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
 };

@@ -115,7 +115,7 @@ void SceneHost::commitHost() {
         // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176)
         const mi_material &mat = materials[sh.bsdf];
         bool smooth = mat.type != MI_BSDF_DIFFUSE || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0;
-        ts.flags = (faceN ? 1u : 0u) | (backside ? 2u : 0u) | (smooth ? 0u : 4u);
+        ts.flags = (faceN ? 1u : 0u) | (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type == MI_BSDF_ROUGHCONDUCTOR ? 8u : 0u);
         ts.local_prim = t - sh.first_tri; ts.i0 = a; ts.i1 = b; i2[t] = c;
         // face frame: skdtree.h:367-371 (face normal), util.cpp:605-610 (computeShadingFrame with dpdu = p1 - p0)
         V3 side1 = p1 - p0, side2 = p2 - p0, fn = cross(side1, side2);
