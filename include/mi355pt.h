@@ -58,7 +58,9 @@ typedef struct {
     uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
     uint32_t opacity;            /* 1: alpha = 1 where the camera ray hits a surface, else 0 (RadianceQueryRecord::EOpacity, records.inl:121-137:
                                     the responsive drivers and films with an alpha channel); 0: alpha = 1 (classic film without alpha, integrator.cpp:160-161) */
-    uint32_t reserved;
+    uint32_t fast_math;          /* 0: strict IEEE kernels (no contraction, exact divide/sqrt): radiance bit-identical to the oracle;
+                                    1: the same kernels compiled with fused multiply-adds and approximate divide/sqrt (the reference's own
+                                    build is -ffast-math): results agree within float rounding, rare path forks aside */
 } mi_render_params;
 
 typedef struct { uint32_t x0, y0, x1, y1; } mi_tile;   /* pixel rectangle [x0,x1) x [y0,y1) in GLOBAL film coordinates */

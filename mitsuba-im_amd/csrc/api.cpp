@@ -22,7 +22,24 @@ void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float 
 void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, hipStream_t);
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
 void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
+// fast-arithmetic twins (kernels_fast.hip)
+void mi_launch_generate_fast(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
+void mi_launch_extend_fast(const DScene &, const Queues &, int, uint32_t, hipStream_t);
+void mi_upload_packet_fast(const TriAccelD *, uint32_t, hipStream_t);
+void mi_launch_shade_fast(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
+void mi_launch_shadow_fast(const DScene &, const Queues &, uint32_t, hipStream_t);
+void mi_launch_film_fast(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 }
+struct LaunchSet {
+    void (*generate)(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
+    void (*extend)(const DScene &, const Queues &, int, uint32_t, hipStream_t);
+    void (*packet)(const TriAccelD *, uint32_t, hipStream_t);
+    void (*shade)(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
+    void (*shadow)(const DScene &, const Queues &, uint32_t, hipStream_t);
+    void (*film)(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
+};
+static const LaunchSet kPrecise = {mi_launch_generate, mi_launch_extend, mi_upload_packet, mi_launch_shade, mi_launch_shadow, mi_launch_film};
+static const LaunchSet kFast = {mi_launch_generate_fast, mi_launch_extend_fast, mi_upload_packet_fast, mi_launch_shade_fast, mi_launch_shadow_fast, mi_launch_film_fast};
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -40,7 +57,7 @@ struct mi_render {
     std::atomic<int> cancel{0};
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
     mi_stats stats{};
-    uint64_t samplesTotal = 0, launchesAll = 0;
+    uint64_t samplesTotal = 0, launchesAll = 0; const LaunchSet *k = &kPrecise;
     uint32_t *dNib = nullptr;
     // optional second path pool + stream: consecutive batches alternate between the two, so the ALU-bound traversal kernels of one batch
     // overlap the latency-bound shading kernels of the other on the same CUs (MI355PT_STREAMS=2, default)
@@ -197,6 +214,7 @@ int SceneHost::upload(int dev) {
     d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type == MI_BSDF_ROUGHCONDUCTOR) d.has_roughconductor = 1;
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (tris.size() <= MI_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;
+    for (int i = 0; i < 3; ++i) d.packet_k[i] = packetK[i];
     committed = true;
     return 0;
 }
@@ -284,7 +302,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
-    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u;
+    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->k = p->fast_math ? &kFast : &kPrecise;
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
         uint32_t sppBits = 0; while ((1ull << sppBits) < p->spp) ++sppBits;
@@ -351,14 +369,14 @@ static void mark(mi_render *r, int tag, size_t &used, hipStream_t st = nullptr) 
 static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed, int pool = 0) {
     const DScene &sc = r->scene->h.d; hipStream_t st = pool ? r->stream2 : r->stream; Queues &Q = pool ? r->q2 : r->q;
     (void) list;
-    if (sc.packet_n) mi_upload_packet(r->scene->h.packet.data(), sc.packet_n, st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
+    if (sc.packet_n) r->k->packet(r->scene->h.packet.data(), (uint32_t) r->scene->h.packet.size(), st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
     mark(r, 0, evUsed, st);
-    mi_launch_generate(sc, r->rc, Q, bd, r->grid, st);
+    r->k->generate(sc, r->rc, Q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
-        mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
-        mark(r, 2, evUsed, st); mi_launch_shade(sc, r->rc, Q, buf, r->gridShade, st);
-        if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
+        mark(r, 1, evUsed, st); r->k->extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
+        mark(r, 2, evUsed, st); r->k->shade(sc, r->rc, Q, buf, r->gridShade, st);
+        if (depth < maxDepth) { mark(r, 3, evUsed, st); r->k->shadow(sc, Q, r->gridShadow, st); }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
             std::vector<uint32_t> cnt(r->grid);
@@ -399,7 +417,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
         int rc = traceBatch(r, bd, nullptr, evUsed, pool); if (rc) return rc;
         // film accumulation stays in batch order (own-pixel sums are plain read-modify-writes): wait for the other pool's film kernel
         if (dual && filmPending[pool ^ 1]) HIPCHK(hipStreamWaitEvent(st, r->filmDone[pool ^ 1], 0));
-        mi_launch_film(h.d, pool ? r->q2 : r->q, bd, r->film, r->spill, st);
+        r->k->film(h.d, pool ? r->q2 : r->q, bd, r->film, r->spill, st);
         if (dual) { HIPCHK(hipEventRecord(r->filmDone[pool], st)); filmPending[pool] = true; }
         r->samplesTotal += bd.n_paths;
     }
@@ -490,7 +508,7 @@ extern "C" {
 int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) {
     if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_intersect: bad argument");
     HIPCHK(hipSetDevice(s->h.device));
-    if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), s->h.d.packet_n, nullptr); HIPCHK(hipDeviceSynchronize()); }
+    if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), (uint32_t) s->h.packet.size(), nullptr); HIPCHK(hipDeviceSynchronize()); }
     return withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, nullptr); });
 }
 int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, uint64_t *outIdx, float *outVals) {

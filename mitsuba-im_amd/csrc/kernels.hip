@@ -12,6 +12,20 @@
 #include "pt_device.h"
 #include "queues.h"
 
+// This file is compiled twice into libmi355pt.so:
+//   precise TU (kernels.hip):       -ffp-contract=off, IEEE divide/sqrt  -> radiance bit-identical to the strict-IEEE oracle;
+//   fast TU (kernels_fast.hip):     -ffp-contract=fast, approximate divide/sqrt (the reference itself is built with -ffast-math)
+//                                   -> same code, results within float rounding (tests: <= 1e-4 relative, forks aside).
+// Everything lives in a per-TU namespace so the two sets of kernel / template instantiations cannot be merged by the linker.
+#ifdef MI_FAST_MATH
+#define MI_NS mi_fast
+#define MI_FN(x) x##_fast
+#else
+#define MI_NS mi_precise
+#define MI_FN(x) x
+#endif
+namespace MI_NS {
+
 #define WG 256
 #define STACK_DEPTH 32   // >= BVH depth (scene_build.cpp caps it; mi_scene_commit refuses deeper trees)
 
@@ -77,21 +91,40 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
     return found;
 }
 
-// Packet mode (scenes of <= MI_PACKET_MAX triangles): the scene is one triangle packet in constant memory, in ORIGINAL triangle
-// order.  The loop index is wave-uniform, so the Wald records arrive through the scalar cache as SGPR operands and the projection
-// axis `k` is a scalar branch: no per-lane loads, no stack, no divergence besides lanes that have left the loop.
+// Packet mode (scenes of <= MI_PACKET_MAX triangles): the scene is one triangle packet in constant memory.  The loop index is
+// wave-uniform, so the Wald records arrive through the scalar cache as SGPR operands: no per-lane loads, no stack, no divergence besides
+// lanes that have left the loop.  The one scalar unit of a CU serves all 32 resident waves, so scalar work per triangle is kept minimal:
+// the records are sorted by projection axis k on the host and each axis gets its own loop (compile-time component selection, no
+// per-triangle branch); ties in t are broken towards the lower ORIGINAL triangle index, which keeps the result order independent.
 __constant__ TriAccelD c_packet[MI_PACKET_MAX];
-template <bool ANY>
-DEV bool packetIntersect(uint32_t n, v3 o, v3 d, float mint, float maxt, float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
-    float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+template <int K> DEV bool triIntersectK(const TriAccelD &ta, v3 o, v3 d, float mint, float maxt, float &u, float &v, float &t) {
+    const float o_u = K == 0 ? o.y : (K == 1 ? o.z : o.x), o_v = K == 0 ? o.z : (K == 1 ? o.x : o.y), o_k = K == 0 ? o.x : (K == 1 ? o.y : o.z);
+    const float d_u = K == 0 ? d.y : (K == 1 ? d.z : d.x), d_v = K == 0 ? d.z : (K == 1 ? d.x : d.y), d_k = K == 0 ? d.x : (K == 1 ? d.y : d.z);
+    float tt = (ta.n_d - o_u * ta.n_u - o_v * ta.n_v - o_k) / (d_u * ta.n_u + d_v * ta.n_v + d_k);
+    if (tt < mint || tt > maxt) return false;
+    float hu = o_u + tt * d_u - ta.a_u, hv = o_v + tt * d_v - ta.a_v;
+    float uu = hv * ta.b_nu + hu * ta.b_nv, vv = hu * ta.c_nu + hv * ta.c_nv;
+    u = uu; v = vv; t = tt;
+    return uu >= 0 && vv >= 0 && uu + vv <= 1.0f;
+}
+template <bool ANY, int K>
+DEV bool packetLoop(uint32_t first, uint32_t last, v3 o, v3 d, float mint, float &best, uint32_t &bprim, float &bu, float &bv, bool &found) {
+    for (uint32_t i = first; i < last; ++i) {
         const TriAccelD ta = c_packet[i];
         float u, v, t;
-        if (triIntersect(ta, o, d, mint, best, u, v, t)) {
+        if (triIntersectK<K>(ta, o, d, mint, best, u, v, t)) {
             if (ANY) return true;
-            if (!found || t < best) { best = t; bprim = i; bu = u; bv = v; found = true; }   // ascending prim order: ties keep the lower index
+            if (!found || t < best || ta.prim < bprim) { best = t; bprim = ta.prim; bu = u; bv = v; found = true; }   // t <= best here: equal t -> lower prim wins
         }
     }
+    return false;
+}
+template <bool ANY>
+DEV bool packetIntersect(const DScene &sc, v3 o, v3 d, float mint, float maxt, float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
+    float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
+    if (packetLoop<ANY, 0>(0, sc.packet_k[0], o, d, mint, best, bprim, bu, bv, found)) return true;
+    if (packetLoop<ANY, 1>(sc.packet_k[0], sc.packet_k[1], o, d, mint, best, bprim, bu, bv, found)) return true;
+    if (packetLoop<ANY, 2>(sc.packet_k[1], sc.packet_k[2], o, d, mint, best, bprim, bu, bv, found)) return true;
     bestT = best; bestPrim = bprim; bestU = bu; bestV = bv;
     return found;
 }
@@ -156,7 +189,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
         v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z);
         float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
         if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt)) {
-            if (STACK == 0) hit = packetIntersect<false>(sc.packet_n, o, d, mint, maxt, t, prim, u, v);
+            if (STACK == 0) hit = packetIntersect<false>(sc, o, d, mint, maxt, t, prim, u, v);
             else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
         }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
         v3 o = V(so.x, so.y, so.z), d = V(sd.x, sd.y, sd.z);
         float mint, maxt, t, u, v; uint32_t prim; bool occluded = false;
         if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt)) {
-            if (STACK == 0) occluded = packetIntersect<true>(sc.packet_n, o, d, mint, maxt, t, prim, u, v);
+            if (STACK == 0) occluded = packetIntersect<true>(sc, o, d, mint, maxt, t, prim, u, v);
             else occluded = traverse<true>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
         }
         if (!occluded) {
@@ -453,7 +486,7 @@ __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *
     v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
     if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
-        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true>(sc.packet_n, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false>(sc.packet_n, o, d, mint, maxt, t, prim, u, v); }
+        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true>(sc, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false>(sc, o, d, mint, maxt, t, prim, u, v); }
         else if (anyHit) hit = traverse<true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
         else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
     }
@@ -473,17 +506,20 @@ __global__ void k_debug_camera(DScene sc, const float *pos, uint64_t n, float *o
     float *r = out + i * 8; r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = mint; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = maxt;
 }
 
+}  // namespace MI_NS
+using namespace MI_NS;
+
 // ---------------------------------------------------------------------------------------------- launch wrappers (used by api.cpp)
 extern "C" {
-void mi_launch_generate(const DScene &sc, const RenderConst &rc, const Queues &q, const BatchDesc &bd, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(WG), 0, st, sc, rc, q, bd); }
-void mi_upload_packet(const TriAccelD *tris, uint32_t n, hipStream_t st) { (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_packet), tris, n * sizeof(TriAccelD), 0, hipMemcpyHostToDevice, st); }
-void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+void MI_FN(mi_launch_generate)(const DScene &sc, const RenderConst &rc, const Queues &q, const BatchDesc &bd, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(WG), 0, st, sc, rc, q, bd); }
+void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, hipStream_t st) { (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_packet), tris, n * sizeof(TriAccelD), 0, hipMemcpyHostToDevice, st); }
+void MI_FN(mi_launch_extend)(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     if (sc.packet_n) hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
     else if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_extend<16>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
     else hipLaunchKernelGGL(k_extend<STACK_DEPTH>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
 }
-void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
     const bool env = sc.env_index >= 0, small = sc.small_tables != 0;
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
@@ -494,13 +530,14 @@ void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, i
     else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }
 #undef MI_SHADE
 }
-void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
+void MI_FN(mi_launch_shadow)(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     if (sc.packet_n) hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(WG), 0, st, sc, q);
     else if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, dim3(grid), dim3(WG), 0, st, sc, q);
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, dim3(grid), dim3(WG), 0, st, sc, q);
     else hipLaunchKernelGGL(k_shadow<STACK_DEPTH>, dim3(grid), dim3(WG), 0, st, sc, q);
 }
-void mi_launch_film(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
+void MI_FN(mi_launch_film)(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
+#ifndef MI_FAST_MATH
 void mi_launch_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout, hipStream_t st) {
     size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, spill, out, W, H, border, layout);
 }
@@ -508,4 +545,5 @@ void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n
 void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out); }
 void mi_launch_debug_sobol(const DScene &sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *oi, float *ov, hipStream_t st) { hipLaunchKernelGGL(k_debug_sobol, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, in, n, ndims, oi, ov); }
 void mi_launch_debug_camera(const DScene &sc, const float *pos, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_camera, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, pos, n, out); }
+#endif
 }

@@ -67,6 +67,7 @@ struct DScene {
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
     uint32_t packet_n, bvh_depth;
+    uint32_t packet_k[3];                 // packet records are sorted by projection axis: [0,k[0]) axis 0, [k[0],k[1]) axis 1, [k[1],k[2]) axis 2 (degenerate ones dropped)
     uint32_t has_roughconductor;          // selects the shade kernel variant
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none

@@ -144,7 +144,10 @@ void SceneHost::commitHost() {
     bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.nodes.reserve(2 * nt + 2);
     int root = nt ? bld.build(0, (int) nt, 0) : -1;
     tris.resize(nt); for (uint32_t i = 0; i < nt; ++i) tris[i] = accel[bld.order[i]];
-    packet = accel;
+    // packet mode: records sorted by projection axis (stable: original order inside an axis); degenerate triangles (k = 3) never hit -> dropped
+    packet.clear(); packetK[0] = packetK[1] = packetK[2] = 0;
+    for (uint32_t axis = 0; axis < 3; ++axis) { for (const TriAccelD &ta : accel) if (ta.k == axis) packet.push_back(ta); packetK[axis] = (uint32_t) packet.size(); }
+    if (packet.empty()) packet.push_back(TriAccelD{});
     nodes.clear();
     auto setBox = [](float *lo, float *hi, const BuildNode &n) { lo[0] = n.lo.x; lo[1] = n.lo.y; lo[2] = n.lo.z; hi[0] = n.hi.x; hi[1] = n.hi.y; hi[2] = n.hi.z; };
     auto emptyBox = [](float *lo, float *hi) { for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::infinity(); hi[i] = -std::numeric_limits<float>::infinity(); } };

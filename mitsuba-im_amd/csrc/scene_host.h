@@ -16,6 +16,7 @@ struct SceneHost {
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16] = {0}, envScale = 1.0f;
     // derived on the host (scene_build.cpp)
     std::vector<uint32_t> triShape, i2; std::vector<TriAccelD> tris; std::vector<TriShade> shade; std::vector<BvhNode> nodes;
+    uint32_t packetK[3] = {0, 0, 0};
     std::vector<TriAccelD> packet;   // Wald records in ORIGINAL triangle order (packet mode, <= MI_PACKET_MAX triangles)
     std::vector<EmitterD> emittersD; std::vector<float> emitterCdf, areaCdf; float emitterNorm = 0;
     float aabbLo[3], aabbHi[3];
