@@ -255,9 +255,9 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     for (void *p : allocs) (void) hipFree(p);
     allocs.clear();
     auto envU = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v && v[0] ? (uint32_t) atoi(v) : dflt; };
-    uint32_t grid = envU("MI355PT_SEGMENTS", 4096u);                       // segments of the path pool
-    uint64_t minGrid = (paths + 255) / 256; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
-    uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 255) / 256 * 256;
+    uint32_t grid = envU("MI355PT_SEGMENTS", 16384u);                      // segments of the path pool (each owned by one wave in the shade stage)
+    uint64_t minGrid = (paths + 63) / 64; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
+    uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 63) / 64 * 64;
     r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
     // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
     r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", 512u));

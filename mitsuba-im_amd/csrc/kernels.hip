@@ -206,8 +206,6 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 template <bool RC, bool ENV, bool SMALL>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
-    __shared__ uint32_t s_wave[2][WG / 64];
-    __shared__ uint32_t s_base[2];
     uint32_t *s_nib = s_dyn;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = buf ^ 1;
@@ -238,36 +236,34 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     // Material-sorted shading (scenes that mix BSDF classes): the paths of a segment are first ordered by the class of the surface
     // they hit -- diffuse-like from the front, rough conductors from the back of an LDS index list (wave64 ballots, order preserving) --
     // so a wave runs either the cheap diffuse code or the microfacet code, not both.  The queues are then read through that list.
-    uint16_t *s_order = reinterpret_cast<uint16_t *>(s_dyn + rc.order_offset_words);
+    // In this stage a SEGMENT IS OWNED BY ONE WAVE: compaction is a pair of wave64 ballots with the running output offsets kept in
+    // (uniform) registers -- no LDS exchange and no workgroup barrier anywhere in the loop; the four waves of a workgroup only share the
+    // LDS copies of the tables above.
+    uint16_t *s_order = reinterpret_cast<uint16_t *>(s_dyn + rc.order_offset_words) + (size_t) wave * q.cap;
     const bool doSort = RC && rc.order_offset_words != 0 && q.cap <= 0xFFFFu;
     unsigned long long pathLen = 0, shadowRays = 0;
-    for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
+    __syncthreads();                                         // tables staged
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t seg = blockIdx.x * (WG / 64) + wave; seg < q.n_seg; seg += gridDim.x * (WG / 64)) {
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
-    if (tid < 2) s_base[tid] = 0;
-    __syncthreads();
+    uint32_t outA = 0, outS = 0;                             // survivors / shadow records written so far (uniform)
     if (doSort) {
         uint32_t done0 = 0, done1 = 0;                       // uniform running counts (front / back)
-        for (uint32_t base = 0; base < n; base += WG) {
-            const uint32_t i = base + tid; int cls = 2;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane; int cls = 2;
             if (i < n) {
                 const uint32_t prim = __float_as_uint(q.hit[segBase + i].w);
                 cls = (prim != 0xFFFFFFFFu && (__float_as_uint(tb.shade4[prim * 6u + 2u].w) & 8u)) ? 1 : 0;
             }
-            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), ltm = (1ull << lane) - 1ull;
-            if (lane == 0) { s_wave[0][wave] = (uint32_t) __popcll(m0); s_wave[1][wave] = (uint32_t) __popcll(m1); }
-            __syncthreads();
-            uint32_t o0 = done0, o1 = done1, t0 = 0, t1 = 0;
-#pragma unroll
-            for (int w = 0; w < WG / 64; ++w) { uint32_t a = s_wave[0][w], b = s_wave[1][w]; if (w < (int) wave) { o0 += a; o1 += b; } t0 += a; t1 += b; }
-            if (cls == 0) s_order[o0 + (uint32_t) __popcll(m0 & ltm)] = (uint16_t) i;
-            else if (cls == 1) s_order[n - 1u - (o1 + (uint32_t) __popcll(m1 & ltm))] = (uint16_t) i;
-            done0 += t0; done1 += t1;
-            __syncthreads();
+            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
+            if (cls == 0) s_order[done0 + (uint32_t) __popcll(m0 & lt)] = (uint16_t) i;
+            else if (cls == 1) s_order[n - 1u - (done1 + (uint32_t) __popcll(m1 & lt))] = (uint16_t) i;
+            done0 += (uint32_t) __popcll(m0); done1 += (uint32_t) __popcll(m1);
         }
     }
-    for (uint32_t base = 0; base < n; base += WG) {
-        const uint32_t i = base + tid;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
         bool alive = false, wantShadow = false;
         float4 nrO, nrD, nS1, shO, shD, shC; uint4 nS0; float nS2 = 0;
         if (i < n) {
@@ -354,28 +350,19 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             } while (false);
             if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
         }
-        // wave64 ballots + one LDS exchange: order-preserving compaction inside the segment
+        // wave64 ballots: order-preserving compaction inside the (wave-owned) segment
         const unsigned long long mA = __ballot(alive), mS = __ballot(wantShadow);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        if (lane == 0) { s_wave[0][wave] = (uint32_t) __popcll(mA); s_wave[1][wave] = (uint32_t) __popcll(mS); }
-        __syncthreads();
-        uint32_t offA = s_base[0], offS = s_base[1], totA = 0, totS = 0;
-#pragma unroll
-        for (int w = 0; w < WG / 64; ++w) { uint32_t a = s_wave[0][w], s = s_wave[1][w]; if (w < (int) wave) { offA += a; offS += s; } totA += a; totS += s; }
         if (alive) {
-            const uint64_t o = segBase + offA + (uint32_t) __popcll(mA & lt);
+            const uint64_t o = segBase + outA + (uint32_t) __popcll(mA & lt);
             q.rayO[nb][o] = nrO; q.rayD[nb][o] = nrD; q.st0[nb][o] = nS0; q.st1[nb][o] = nS1; q.st2[nb][o] = nS2;
         }
         if (wantShadow) {
-            const uint64_t o = segBase + offS + (uint32_t) __popcll(mS & lt);
+            const uint64_t o = segBase + outS + (uint32_t) __popcll(mS & lt);
             q.shO[o] = shO; q.shD[o] = shD; q.shC[o] = shC;
         }
-        __syncthreads();
-        if (tid == 0) { s_base[0] += totA; s_base[1] += totS; }
-        __syncthreads();
+        outA += (uint32_t) __popcll(mA); outS += (uint32_t) __popcll(mS);
     }
-    if (tid == 0) { q.count[nb][seg] = s_base[0]; q.shCount[seg] = s_base[1]; }
-    __syncthreads();
+    if (lane == 0) { q.count[nb][seg] = outA; q.shCount[seg] = outS; }
     }
     // counters: wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) { pathLen += __shfl_down(pathLen, off); shadowRays += __shfl_down(shadowRays, off); }
@@ -524,7 +511,7 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
     const bool env = sc.env_index >= 0, small = sc.small_tables != 0;
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
     RenderConst rcl = rc; rcl.order_offset_words = 0;
-    if (sc.has_roughconductor && q.cap <= 0xFFFFu) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 + 16; }
+    if (sc.has_roughconductor && q.cap <= 8192u) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 * (WG / 64) + 16; }
 #define MI_SHADE(RC, ENV, SM) hipLaunchKernelGGL((k_shade<RC, ENV, SM>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf)
     if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
     else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }

@@ -16,7 +16,7 @@ struct Queues {
     float4 *acc; float2 *pos;
     uint32_t *count[2]; uint32_t *shCount;      // per segment
     unsigned long long *counters;               // [0] closest-hit rays, [1] shadow rays, [2] sum of path depths
-    uint32_t cap;                               // slots per segment (multiple of 256)
+    uint32_t cap;                               // slots per segment (multiple of 64)
     uint32_t n_seg;                             // number of segments
 };
 
