@@ -7,7 +7,7 @@ accumulate film -> read the raw film into a device tensor -> framebuffer reduce 
 once before the timed region; inputs are resident in HBM when timing starts.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling -- every rank traces the same number of camera
-samples as the single-GPU job: the frame is cut into row-band tiles (mitsuba-im_amd/dist.py) and the sample count grows to
+samples as the single-GPU job: the film rows are interleaved over the ranks (mitsuba-im_amd/dist.py) and the sample count grows to
 256*N spp, so each rank still traces 1920*1080*256 samples; value = all samples of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the render stream inside the timed region)
@@ -91,13 +91,13 @@ def main():
     scene = mi.Scene(sc, device=local)
     render = mi.Render(scene, device=local)
     render.set_profiling(not args.no_stage_timing)
-    tile = mi_dist.tile_of(sc.width, sc.height, rank, world)
+    tile, row_stride = mi_dist.interleaved_rows(sc.width, sc.height, rank, world)     # rank k owns rows k, k + N, ...
     fh, fw, fc, _ = render.film_shape(0)
     film = torch.empty((fh, fw, fc), dtype=torch.float32, device="cuda")
 
     def step():
         render.clear()
-        render.run(tile=tile, s0=0, s1=total_spp)
+        render.run(tile=tile, s0=0, s1=total_spp, row_stride=row_stride)
         render.read_film_device(0, film.data_ptr())
         if use_dist:
             dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)      # the one exchange step of the path (mitsuba-im_amd/dist.py: reduce_film)
@@ -123,7 +123,6 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dt = float(tmax.item())
 
     st = render.stats()                                 # counters accumulate since the last clear = one step
-    samples_rank = (tile[2] - tile[0]) * (tile[3] - tile[1]) * total_spp
     samples_all = sc.width * sc.height * total_spp
     value = samples_all * args.steps / dt / 1e6
     out = {

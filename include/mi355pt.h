@@ -105,6 +105,9 @@ void mi_render_destroy(mi_render *r);
 /* Trace sample planes [sample_begin, sample_end) of every pixel of `tile` and accumulate them into the device film
  * (ImageBlock::put, include/mitsuba/render/imageblock.h:161-221).  One caller per handle. */
 int mi_render_run(mi_render *r, mi_tile tile, uint32_t sample_begin, uint32_t sample_end);
+/* Same for the rows y0, y0 + row_stride, ... (< y1) of the tile only: interleaved row ownership across ranks for multi-GPU load balance
+ * (rank k of N renders tile {0, k, W, H} with row_stride N). */
+int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t row_stride, uint32_t sample_begin, uint32_t sample_end);
 int mi_render_clear(mi_render *r);                  /* ImageBlock::clear */
 void mi_render_cancel(mi_render *r);                /* Integrator::cancel: thread-safe flag, observed between batches */
 /* Film read-back.  layout 0: raw ImageBlock sums (H+2b) x (W+2b) x 5 {R,G,B,alpha,weight} incl. border (classic, ESpectrumAlphaWeight);

@@ -48,7 +48,7 @@ class MiStats(C.Structure):
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
            "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
-           "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_clear", "mi_render_cancel",
+           "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_sobol", "mi_debug_camera_rays"]
 HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
@@ -82,6 +82,7 @@ class Lib:
         L.mi_render_create.argtypes = [vp, C.POINTER(MiRenderParams), C.POINTER(vp)]
         L.mi_render_destroy.argtypes = [vp]; L.mi_render_destroy.restype = None
         L.mi_render_run.argtypes = [vp, MiTile, u32, u32]
+        L.mi_render_run_rows.argtypes = [vp, MiTile, u32, u32, u32]
         L.mi_render_clear.argtypes = [vp]
         L.mi_render_cancel.argtypes = [vp]; L.mi_render_cancel.restype = None
         L.mi_render_film_size.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -196,10 +197,10 @@ class Render:
     def __del__(self):
         self.close()
 
-    def run(self, tile=None, s0=0, s1=None):
+    def run(self, tile=None, s0=0, s1=None, row_stride=1):
         sc = self.scene.sc
         t = MiTile(0, 0, sc.width, sc.height) if tile is None else MiTile(*tile)
-        self.L.check(self.L.L.mi_render_run(self.h, t, s0, self.params.spp if s1 is None else s1))
+        self.L.check(self.L.L.mi_render_run_rows(self.h, t, row_stride, s0, self.params.spp if s1 is None else s1))
 
     def clear(self):
         self.L.check(self.L.L.mi_render_clear(self.h))

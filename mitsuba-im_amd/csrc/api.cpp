@@ -390,14 +390,18 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     return MI_OK;
 }
 
-int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
+int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) { return mi_render_run_rows(r, tile, 1, s0, s1); }
+
+int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t s0, uint32_t s1) {
     if (!r) return fail(MI_ERR_INVALID, "mi_render_run: null");
+    if (rowStride == 0) return fail(MI_ERR_INVALID, "mi_render_run_rows: row stride must be >= 1");
     const mi::SceneHost &h = r->scene->h;
     if (tile.x1 <= tile.x0 || tile.y1 <= tile.y0 || tile.x1 > h.width || tile.y1 > h.height) return fail(MI_ERR_INVALID, "mi_render_run: tile outside the film");
     if (s1 < s0 || s1 > r->p.spp) return fail(MI_ERR_INVALID, "mi_render_run: sample range outside [0, spp]");
     if (r->p.sampler == MI_SAMPLER_INDEPENDENT && s1 > (1u << 24)) return fail(MI_ERR_INVALID, "mi_render_run: independent stream supports < 2^24 samples per pixel");
     HIPCHK(hipSetDevice(h.device));
-    const uint32_t npix = (tile.x1 - tile.x0) * (tile.y1 - tile.y0);
+    const uint32_t nrows = (tile.y1 - tile.y0 + rowStride - 1) / rowStride;          // rows y0, y0 + stride, ... below y1
+    const uint32_t npix = (tile.x1 - tile.x0) * nrows;
     uint32_t planes = r->p.planes_per_batch;
     if (!planes) { const uint64_t target = 16u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
@@ -413,7 +417,7 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) {
     for (uint32_t s = s0; s < s1; s += planes, ++batch) {
         if (r->cancel.load()) { HIPCHK(hipDeviceSynchronize()); return fail(MI_CANCELLED, "render cancelled"); }
         const int pool = dual ? (batch & 1) : 0; hipStream_t st = pool ? r->stream2 : r->stream;
-        BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr;
+        BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr; bd.row_stride = rowStride;
         int rc = traceBatch(r, bd, nullptr, evUsed, pool); if (rc) return rc;
         // film accumulation stays in batch order (own-pixel sums are plain read-modify-writes): wait for the other pool's film kernel
         if (dual && filmPending[pool ^ 1]) HIPCHK(hipStreamWaitEvent(st, r->filmDone[pool ^ 1], 0));
@@ -481,7 +485,7 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     HIPCHK(hipMemcpy(dList, pairs, n * 12, hipMemcpyHostToDevice));
     std::vector<uint32_t> slots(n); for (uint64_t i = 0; i < n; ++i) slots[i] = (uint32_t) i;
     HIPCHK(hipMemcpy(dSlots, slots.data(), n * 4, hipMemcpyHostToDevice));
-    BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList;
+    BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList; bd.row_stride = 1;
     size_t evUsed = 0; bool prof = r->profiling; r->profiling = false;
     unsigned long long keep[4]; HIPCHK(hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost));     // the parity entry point leaves the ray counters untouched
     int rc = traceBatch(r, bd, dList, evUsed); r->profiling = prof;

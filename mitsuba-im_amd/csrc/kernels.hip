@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
     for (uint32_t i = tid; i < n; i += WG) {
         const uint64_t pid = segBase + i;
         uint32_t plane = (uint32_t) (pid / bd.n_pix), pl = (uint32_t) (pid % bd.n_pix);
-        uint32_t px = bd.tile.x0 + pl % tw, py = bd.tile.y0 + pl / tw, sidx = bd.sample_begin + plane;
+        uint32_t px = bd.tile.x0 + pl % tw, py = bd.tile.y0 + (pl / tw) * bd.row_stride, sidx = bd.sample_begin + plane;
         if (bd.list) { px = bd.list[pid * 3]; py = bd.list[pid * 3 + 1]; sidx = bd.list[pid * 3 + 2]; }
         SamplerState ss; float jx, jy;
         if (rc.sampler == 1) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, 
     const uint32_t pl = blockIdx.x * WG + threadIdx.x;
     if (pl >= bd.n_pix) return;
     const uint32_t tw = bd.tile.x1 - bd.tile.x0;
-    const int px = (int) (bd.tile.x0 + pl % tw), py = (int) (bd.tile.y0 + pl / tw);
+    const int px = (int) (bd.tile.x0 + pl % tw), py = (int) (bd.tile.y0 + (pl / tw) * bd.row_stride);
     const int W = (int) sc.width + 2 * sc.border, H = (int) sc.height + 2 * sc.border;
     const size_t plane = (size_t) W * H;
     const int ownX = px + sc.border, ownY = py + sc.border;

@@ -22,5 +22,6 @@ struct Queues {
 
 struct BatchDesc {
     mi_tile tile; uint32_t n_pix; uint32_t n_planes; uint32_t sample_begin; uint64_t n_paths;
+    uint32_t row_stride;    // film rows of the tile: y0, y0 + row_stride, ... (1 = contiguous rectangle; N = rows interleaved over N ranks)
     const uint32_t *list;   // optional explicit (px, py, sampleIndex) triples, one per path (parity entry point mi_render_samples)
 };

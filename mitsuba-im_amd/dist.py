@@ -1,7 +1,7 @@
 """Multi-GPU sharding of the hot path: image tiles across ranks, one final framebuffer exchange.
 
 Replaces the reference's image-space work splitting (spiral 32x32 blocks handed to workers, src/librender/imageproc.cpp:28-79)
-and its merge step Film::put(block) under a mutex (src/librender/renderproc.cpp:142-149) by: static row-band tiles per rank
+and its merge step Film::put(block) under a mutex (src/librender/renderproc.cpp:142-149) by: static tiles per rank (contiguous row bands, or rows interleaved over the ranks for load balance)
 (every rank holds a full scene replica), sampler state depending only on GLOBAL (px, py, sampleIndex), and ONE sum-reduce of
 the raw film (RCCL over xGMI via torch.distributed backend "nccl"; "gloo" in the CPU tests).  A sum is used rather than a
 gather because reconstruction filters wider than a pixel splat across tile borders.
@@ -19,6 +19,12 @@ def shard_rows(height, rank, world):
 def tile_of(width, height, rank, world):
     y0, y1 = shard_rows(height, rank, world)
     return (0, y0, width, y1)
+
+
+def interleaved_rows(width, height, rank, world):
+    """Row-interleaved ownership: rank k renders film rows k, k + world, ... -> (tile, row_stride) for mi_render_run_rows.  Every rank gets a
+    statistically identical slice of the image (walls, floor, light, blocks), which a contiguous band does not."""
+    return (0, rank, width, height), world
 
 
 def reduce_film(film, dist=None, dst=0):

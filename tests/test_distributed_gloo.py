@@ -27,6 +27,13 @@ def _worker(rank, world, port, out_dir):
 
     tile = mi_dist.render_sharded(render_tile, sc.width, sc.height, rank, world, 0, sc.spp)
     t = torch.from_numpy(film); mi_dist.reduce_film(t, dist, dst=0)
+    # second layout: rows interleaved over the ranks (what bench.py uses on the GPUs)
+    film2 = np.zeros_like(film); (tx0, ty0, tx1, ty1), stride = mi_dist.interleaved_rows(sc.width, sc.height, rank, world)
+    for y in range(ty0, ty1, stride):
+        f, _ = orc.render_image(0, sc.spp, y, y + 1, threads=1); film2 += f
+    t2 = torch.from_numpy(film2); mi_dist.reduce_film(t2, dist, dst=0)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "film_interleaved.npy"), t2.numpy())
     if rank == 0:
         np.save(os.path.join(out_dir, "film.npy"), t.numpy())
     np.save(os.path.join(out_dir, f"tile{rank}.npy"), np.array(tile))
@@ -49,3 +56,5 @@ def test_two_rank_tiles_reduce_to_single_rank_film(tmp_path):
     assert np.allclose(got, full, rtol=1e-6, atol=1e-7)
     inner = (got[1:-1, 1:-1].view(np.uint32) == full[1:-1, 1:-1].view(np.uint32))
     assert inner.mean() > 0.999
+    got2 = np.load(tmp_path / "film_interleaved.npy")
+    assert np.allclose(got2, full, rtol=1e-6, atol=1e-7) and (got2[1:-1, 1:-1].view(np.uint32) == full[1:-1, 1:-1].view(np.uint32)).mean() > 0.99

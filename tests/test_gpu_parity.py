@@ -133,6 +133,12 @@ def test_full_size_properties(mi, scenes):
         r.run(tile=tile)
     tiles = r.read_film(0)
     assert (bits(tiles[1:-1, 1:-1]) == bits(full[1:-1, 1:-1])).mean() > 0.995 and np.allclose(tiles, full, rtol=1e-5, atol=1e-6)
+    # rows interleaved over 3 "ranks" (mi_render_run_rows): the union is the full frame
+    r.clear()
+    for k in range(3):
+        r.run(tile=(0, k, 1920, 1080), row_stride=3)
+    inter = r.read_film(0)
+    assert (bits(inter[1:-1, 1:-1]) == bits(full[1:-1, 1:-1])).mean() > 0.995 and np.allclose(inter, full, rtol=1e-5, atol=1e-6)
     # batching must not change the result
     r2 = mi.Render(gs, spp=8, planes_per_batch=1); r2.run(); one = r2.read_film(0)
     assert (bits(one[1:-1, 1:-1]) == bits(full[1:-1, 1:-1])).mean() > 0.995
