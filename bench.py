@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--max-depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast-math", action="store_true", help="use the fast-arithmetic kernel build (fused multiply-add, approximate divide/sqrt); default: strict IEEE kernels, bit-identical to the oracle")
     ap.add_argument("--no-stage-timing", action="store_true", help="skip the per-kernel HIP events (roofline becomes null)")
     args = ap.parse_args()
 
@@ -89,7 +90,7 @@ def main():
     total_spp = args.spp * world                       # weak scaling: per-rank samples fixed
     sc = S.cornell_box(args.width, args.height, total_spp, sampler=S.SAMPLER_SOBOL, max_depth=args.max_depth)
     scene = mi.Scene(sc, device=local)
-    render = mi.Render(scene, device=local)
+    render = mi.Render(scene, device=local, fast_math=args.fast_math)
     render.set_profiling(not args.no_stage_timing)
     tile, row_stride = mi_dist.interleaved_rows(sc.width, sc.height, rank, world)     # rank k owns rows k, k + N, ...
     fh, fw, fc, _ = render.film_shape(0)
@@ -128,7 +129,7 @@ def main():
     out = {
         "metric": "Msamples/sec at 1920x1080 path-trace, max depth 8", "value": round(value, 2), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "arithmetic": "fast (fma, approximate divide/sqrt)" if args.fast_math else "strict IEEE (bit-identical to the oracle)",
         "config": {"workload": f"Cornell box (synthetic, 32 triangles), {sc.width}x{sc.height}, sobol sampler, {total_spp} spp "
                                f"({args.spp} per GPU-share), maxDepth {args.max_depth}, rrDepth 5, box filter, "
                                f"1xMI355X wavefront path tracer per rank", "parallelism": f"tiles{world}"},

@@ -55,6 +55,17 @@ def test_sobol_and_camera_units(mi, oracle, scenes):
         assert idx[i] == ref_idx
         for d in (0, 1, 4, 5, 17, 39):
             assert vals[i, d] == np.float32(L.orc_sobol_sample(orc.h, ref_idx, d))
+    # 4K film (BASELINE configs 4/5): resolution 4096 -> m = 12, 1024 spp -> 34-bit indices (9 nibble lookups)
+    sc4 = mi.scenes.cornell_box(3840, 2160, 1024); gs4 = mi.Scene(sc4); orc4 = oracle.Oracle(sc4)
+    q4 = np.stack([rng.integers(0, 3840, 2048), rng.integers(0, 2160, 2048), rng.integers(0, 1024, 2048)], 1).astype(np.uint32)
+    idx4, vals4 = gs4.sobol(q4, 44)
+    for i in range(0, 2048, 19):
+        ref_idx = L.orc_sobol_look_up(orc4.h, 12, int(q4[i, 2]), int(q4[i, 0]), int(q4[i, 1]))
+        assert idx4[i] == ref_idx and ref_idx < (1 << 34)
+        for d in (0, 1, 5, 43):
+            assert vals4[i, d] == np.float32(L.orc_sobol_sample(orc4.h, ref_idx, d))
+    li4 = mi.Render(gs4).samples(q4[:512]); ref4 = orc4.render_samples(q4[:512])["li"]
+    assert (bits(li4) == bits(ref4)).all()
     # golden Sobol vectors of the reference (m = 2, 7, 12 tables are exercised on the oracle side; here m = 11 via look_up above)
     pos = rng.random((512, 2)).astype(np.float32) * np.array([sc.width, sc.height], np.float32)
     rays = gs.camera_rays(pos)
