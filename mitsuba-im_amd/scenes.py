@@ -22,6 +22,10 @@ SAMPLER_INDEPENDENT = 0
 SAMPLER_SOBOL = 1
 DISTR_BECKMANN = 0
 DISTR_GGX = 1
+SHAPE_RECTANGLE = 0
+SHAPE_DISK = 1
+SHAPE_SPHERE = 2
+SHAPE_CYLINDER = 3
 
 f32 = np.float32
 
@@ -78,7 +82,7 @@ def sample_to_camera(xfov_deg, near, far, aspect):
 def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near, far, width, height,
                  spp, sampler, max_depth, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
                  normals=None, uvs=None, strict_normals=False, hide_emitters=False, envmap=None,
-                 name="scene"):
+                 name="scene", analytic=None):
     sc = Scene()
     sc.name = name
     sc.pos = np.ascontiguousarray(np.asarray(verts, dtype=f32).reshape(-1, 3))
@@ -99,6 +103,7 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
     sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)
     sc.envmap = envmap          # None or dict(rgb[h,w,3] f32, to_world[4,4], scale)
+    sc.analytic = list(analytic or [])   # analytic shapes (make_analytic); shape index of the i-th = len(shapes) + i; primitive index = len(idx) + i
     tri_shape = np.zeros(len(sc.idx), dtype=np.uint32)
     for si, s in enumerate(shapes):
         tri_shape[s["first_tri"]:s["first_tri"] + s["tri_count"]] = si
@@ -106,10 +111,72 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     return sc
 
 
+# ---------------------------------------------------------------------------------------------
+# analytic shapes: reference src/shapes/{rectangle,disk,sphere,cylinder}.cpp.  A record carries the shape's objectToWorld as the
+# reference holds it AFTER the constructor (sphere / cylinder: scale split off into radius / length) and its inverse.
+# ---------------------------------------------------------------------------------------------
+def translate(x, y, z):
+    m = np.eye(4); m[:3, 3] = (x, y, z); return m
+
+
+def scale(x, y=None, z=None):
+    y = x if y is None else y; z = x if z is None else z
+    return np.diag([x, y, z, 1.0])
+
+
+def rotate(axis, degrees):
+    a = np.asarray(axis, np.float64); a = a / np.linalg.norm(a); t = math.radians(degrees)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    m = np.eye(4); m[:3, :3] = np.eye(3) + math.sin(t) * K + (1 - math.cos(t)) * (K @ K)
+    return m
+
+
+def make_analytic(kind, to_world, bsdf, emitter=-1, flip=False, radius=1.0, length=1.0):
+    tw = np.ascontiguousarray(to_world, dtype=f32)
+    to = np.ascontiguousarray(np.linalg.inv(tw.astype(np.float64)), dtype=f32)
+    return dict(type=int(kind), bsdf=int(bsdf), emitter=int(emitter), flags=int(bool(flip)), to_world=tw, to_object=to,
+                radius=float(f32(radius)), length=float(f32(length)))
+
+
+def _coordinate_system(a):
+    """reference src/libcore/util.cpp:594-603 in float32: returns (b, c) with b = cross(c, a)."""
+    a = np.asarray(a, f32)
+    if abs(a[0]) > abs(a[1]):
+        inv = f32(1.0) / np.sqrt(a[0] * a[0] + a[2] * a[2], dtype=f32); c = np.array([a[2] * inv, 0.0, -a[0] * inv], f32)
+    else:
+        inv = f32(1.0) / np.sqrt(a[1] * a[1] + a[2] * a[2], dtype=f32); c = np.array([0.0, a[2] * inv, -a[1] * inv], f32)
+    b = np.array([c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]], f32)
+    return b, c
+
+
+def cylinder_to_world(p0, p1):
+    """translate(p0) * fromFrame(Frame(d / |d|)) (cylinder.cpp:88-92, scale split off); returns (matrix, length)."""
+    p0 = np.asarray(p0, f32); d = (np.asarray(p1, f32) - p0).astype(f32)
+    length = np.sqrt(np.dot(d, d), dtype=f32); n = (d / length).astype(f32)
+    s_, t_ = _coordinate_system(n)
+    m = np.eye(4, dtype=f32); m[:3, 0] = s_; m[:3, 1] = t_; m[:3, 2] = n; m[:3, 3] = p0
+    return m, float(length)
+
+
 class _Builder:
     def __init__(self):
         self.verts, self.tris, self.shapes, self.bsdfs, self.emitters = [], [], [], [], []
         self.normals = None
+        self.analytic = []
+
+    def add_analytic(self, kind, to_world, bsdf, radiance=None, flip=False, radius=1.0, length=1.0):
+        """call after all meshes: the shape index of an analytic shape is len(shapes) + its position."""
+        rec = make_analytic(kind, to_world, bsdf, -1, flip, radius, length)
+        rec["_radiance"] = None if radiance is None else tuple(map(float, radiance))
+        self.analytic.append(rec)
+
+    def resolve_analytic(self):
+        for i, rec in enumerate(self.analytic):
+            rad = rec.pop("_radiance", None)
+            if rad is not None:
+                self.emitters.append(dict(type=EMITTER_AREA, shape=len(self.shapes) + i, radiance=rad, weight=1.0))
+                rec["emitter"] = len(self.emitters) - 1
+        return self.analytic
 
     def bsdf(self, **kw):
         self.bsdfs.append(make_bsdf(**kw))
@@ -167,6 +234,57 @@ def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0,
                         width, height, spp, sampler, max_depth, rr_depth, filter_kind, seed, strict_normals=strict_normals,
                         hide_emitters=hide_emitters, name="cornell")
+
+
+def cbox_shapes(width=256, height=256, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
+                strict_normals=False, hide_emitters=False, disk_cap=True):
+    """Cornell room (mesh walls) furnished with analytic shapes: `rectangle` ceiling light, a diffuse `sphere`,
+    a rough-conductor `sphere`, an open `cylinder` (twosided diffuse) capped by a `disk` (disk_cap=False leaves it out: the reference's
+    Disk::fillIntersectionRecord never sets the geometric frame, so `strictNormals` reads a stale normal there -- DESIGN.md)."""
+    b = _Builder()
+    white = b.bsdf(reflectance=(0.725, 0.71, 0.68))
+    red = b.bsdf(reflectance=(0.63, 0.065, 0.05))
+    green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
+    lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78))
+    white2 = b.bsdf(reflectance=(0.725, 0.71, 0.68), twosided=True)
+    eta, k = CONDUCTOR_IOR["Cu"]
+    copper = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.15, distr=DISTR_GGX, eta=eta, k=k)
+    b.begin(); b.quad([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]); b.end(white)
+    b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)
+    b.begin(); b.quad([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]); b.end(white)
+    b.begin(); b.quad([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]); b.end(green)
+    b.begin(); b.quad([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]); b.end(red)
+    # rectangle light: [-1,1]^2, normal +z -> scaled to 130 x 105, turned to face down (-y), hung at y = 548.3
+    b.add_analytic(SHAPE_RECTANGLE, translate(278, 548.3, 279.5) @ rotate((1, 0, 0), 90) @ scale(65, 52.5, 1), lightm, radiance=(17.0, 12.0, 4.0))
+    b.add_analytic(SHAPE_SPHERE, translate(150, 90, 170) @ rotate((0.3, 1, 0.2), 35), white, radius=90.0)
+    b.add_analytic(SHAPE_SPHERE, translate(420, 70, 130), copper, radius=70.0)
+    m, length = cylinder_to_world((370, 0, 380), (370, 260, 380))
+    b.add_analytic(SHAPE_CYLINDER, m, white2, radius=80.0, length=length)
+    if disk_cap:
+        b.add_analytic(SHAPE_DISK, translate(370, 260, 380) @ rotate((1, 0, 0), -90) @ scale(80), white)
+    cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth,
+                        filter_kind, seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_shapes", analytic=b.resolve_analytic())
+
+
+def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
+    """Area lights on every analytic shape kind inside an inward-facing (`flipNormals`) sphere: a `sphere` light (cone sampling from
+    outside, sphere.cpp:275-346), a `cylinder` light, a `disk` light and a `rectangle` light over a mesh floor and a mesh blocker."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.6, 0.6, 0.6))
+    blue = b.bsdf(reflectance=(0.2, 0.3, 0.7), twosided=True)
+    lm = b.bsdf(reflectance=(0.5, 0.5, 0.5))
+    b.begin(); b.quad([(4, -1, -4), (-4, -1, -4), (-4, -1, 4), (4, -1, 4)]); b.end(grey)                        # floor (+y)
+    b.begin(); b.quad([(-0.2, -1, 0.9), (0.9, -1, 0.4), (0.9, 0.3, 0.4), (-0.2, 0.3, 0.9)]); b.end(blue)         # standing blocker
+    b.add_analytic(SHAPE_SPHERE, translate(0, 0.5, 0), grey, flip=True, radius=5.0)                              # the room
+    b.add_analytic(SHAPE_SPHERE, translate(-1.4, 0.2, 1.0), lm, radiance=(9.0, 7.0, 5.0), radius=0.35)
+    m, length = cylinder_to_world((1.2, -0.6, 1.6), (2.0, 0.9, 1.2))
+    b.add_analytic(SHAPE_CYLINDER, m, lm, radiance=(2.0, 6.0, 3.0), radius=0.12, length=length)
+    b.add_analytic(SHAPE_DISK, translate(0.3, 2.2, 0.5) @ rotate((1, 0, 0), 90) @ rotate((0, 0, 1), 20) @ scale(0.5), lm, radiance=(3.0, 3.0, 8.0))
+    b.add_analytic(SHAPE_RECTANGLE, translate(-2.5, 0.4, 2.8) @ rotate((0, 1, 0), 140) @ scale(0.6, 0.4, 1), lm, radiance=(6.0, 2.0, 2.0))
+    cam = look_at((0.2, 0.6, -3.6), (0.0, 0.1, 0.5), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 60.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, name="shape_lights", analytic=b.resolve_analytic())
 
 
 def closed_box(width=128, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=8):
@@ -366,3 +484,9 @@ def save_scene(sc, path):
             f.write(np.ascontiguousarray(sc.envmap["to_world"], dtype=f32).tobytes())
             f.write(struct.pack("<f", sc.envmap["scale"]))
             f.write(rgb.tobytes())
+        if sc.get("analytic"):
+            f.write(b"ANLY"); f.write(struct.pack("<I", len(sc.analytic)))
+            for a in sc.analytic:
+                f.write(struct.pack("<I2iI", a["type"], a["bsdf"], a["emitter"], a["flags"]))
+                f.write(a["to_world"].tobytes()); f.write(a["to_object"].tobytes())
+                f.write(struct.pack("<2f", a["radius"], a["length"]))

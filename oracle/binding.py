@@ -23,6 +23,11 @@ class OrcEmitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("pad", C.c_uint32 * 2)]
 
 
+class OrcAnalytic(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32),
+                ("to_world", C.c_float * 16), ("to_object", C.c_float * 16), ("radius", C.c_float), ("length", C.c_float), ("pad", C.c_float * 2)]
+
+
 class OrcSceneDesc(C.Structure):
     _fields_ = [("n_verts", C.c_uint32), ("n_tris", C.c_uint32), ("n_shapes", C.c_uint32), ("n_materials", C.c_uint32), ("n_emitters", C.c_uint32),
                 ("pos", C.c_void_p), ("nrm", C.c_void_p), ("uv", C.c_void_p), ("idx", C.c_void_p),
@@ -33,7 +38,8 @@ class OrcSceneDesc(C.Structure):
                 ("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32), ("opacity", C.c_uint32),
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
-                ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float)]
+                ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p)]
 
 
 def build():
@@ -112,6 +118,17 @@ def pack_records(sc):
     return shapes, mats, ems
 
 
+def pack_analytic(sc):
+    recs = sc.get("analytic") or []
+    arr = (OrcAnalytic * max(1, len(recs)))()
+    for i, a in enumerate(recs):
+        r = OrcAnalytic(a["type"], a["bsdf"], a["emitter"], a["flags"])
+        r.to_world[:] = a["to_world"].reshape(-1).tolist(); r.to_object[:] = a["to_object"].reshape(-1).tolist()
+        r.radius, r.length = a["radius"], a["length"]
+        arr[i] = r
+    return arr, len(recs)
+
+
 class Oracle:
     """Owns an orc_scene built from a flattened scene."""
 
@@ -138,6 +155,8 @@ class Oracle:
             rgb = np.ascontiguousarray(sc.envmap["rgb"], dtype=np.float32); self._keep.append(rgb)
             d.env_rgb, d.env_w, d.env_h, d.env_scale = _ptr(rgb), rgb.shape[1], rgb.shape[0], sc.envmap["scale"]
             d.env_to_world[:] = np.asarray(sc.envmap["to_world"], np.float32).reshape(-1).tolist()
+        an, n_an = pack_analytic(sc); self._keep.append(an)
+        d.n_analytic, d.analytic = n_an, C.cast(an, C.c_void_p)
         self.h = L.orc_scene_create(C.byref(d))
         self.border = L.orc_film_border(self.h)
 

@@ -53,6 +53,7 @@ struct orc_scene {
     orc_scene_desc d;
     float *pos, *nrm; uint32_t *idx; orc_shape *shapes; orc_material *materials; orc_emitter *emitters;
     uint32_t *tri_shape;
+    struct analytic_s *analytic; uint32_t n_analytic, n_prims;   /* primitive index space: [0, n_tris) triangles, then the analytic shapes */
     triaccel *accel;
     v3 aabb_lo, aabb_hi;            /* kd-tree root box incl. the reference's enlargement */
     bvh_node *nodes; uint32_t *bvh_tris; int n_nodes;
@@ -264,6 +265,267 @@ void orc_triaccel(const orc_scene *s, uint32_t tri, float *o) {
     o[0] = (float) a->k; o[1] = a->n_u; o[2] = a->n_v; o[3] = a->n_d; o[4] = a->a_u; o[5] = a->a_v; o[6] = a->b_nu; o[7] = a->b_nv; o[8] = a->c_nu; o[9] = a->c_nv;
 }
 
+/* ------------------------------------------------------------------------------------------------ analytic shapes */
+/* Non-triangle primitives behind Scene::rayIntersect: the kd-tree leaf redirects to Shape::rayIntersect for them
+ * (include/mitsuba/render/skdtree.h:292-301, :330-333) and to Shape::fillIntersectionRecord afterwards (:421-427).
+ * Transforms come with the descriptor (to_world = the shape's m_objectToWorld after its constructor, to_object = its inverse). */
+enum { SH_RECTANGLE = 0, SH_DISK = 1, SH_SPHERE = 2, SH_CYLINDER = 3 };
+typedef struct analytic_s {
+    orc_analytic a;
+    v3 n;            /* rectangle / disk: normalize(objectToWorld(Normal(0,0,1))) (rectangle.cpp:106, disk.cpp:185) */
+    v3 dpdu;         /* rectangle: objectToWorld(Vector(2,0,0)) (rectangle.cpp:104) */
+    v3 center;       /* sphere: objectToWorld(Point(0,0,0)) (sphere.cpp:127) */
+    float inv_area;
+    v3 lo, hi;       /* Shape::getAABB */
+} analytic_t;
+/* include/mitsuba/core/transform.h:126-135 transformAffine(Point), :172-181 operator()(Vector), :199-207 operator()(Normal) */
+static inline v3 xf_point(const float *m, v3 p) { return V(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]); }
+static inline v3 xf_vector(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
+static inline v3 xf_normal(const float *inv, v3 n) { return V(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
+static inline float length3(v3 a) { return sqrtf(dot(a, a)); }
+
+/* sin / cos of 2*pi*u for u in [0, 1]: quadrant reduction + the polynomial pair (the reference calls libm's sincosf on 2*pi*u;
+ * see the arithmetic contract -- CPU and GPU must agree bit for bit, the reference is matched within float rounding) */
+static void sincos_2pi(float u, float *sn, float *cs) {
+    float k = floorf(u * 4.0f + 0.5f);
+    float a = (u - k * 0.25f) * (2.0f * M_PI_F);
+    float sa = sinp(a), ca = cosp(a);
+    switch (((int) k) & 3) {
+        case 0: *sn = sa; *cs = ca; break;
+        case 1: *sn = ca; *cs = -sa; break;
+        case 2: *sn = -sa; *cs = -ca; break;
+        default: *sn = -ca; *cs = sa; break;
+    }
+}
+/* src/libcore/util.cpp:489-527 solveQuadraticDouble */
+static int solve_quadratic_double(double a, double b, double c, double *x0, double *x1) {
+    if (a == 0) { if (b != 0) { *x0 = *x1 = -c / b; return 1; } return 0; }
+    double discrim = b * b - 4.0 * a * c;
+    if (discrim < 0) return 0;
+    double temp, sqrtDiscrim = sqrt(discrim);
+    if (b < 0) temp = -0.5 * (b - sqrtDiscrim); else temp = -0.5 * (b + sqrtDiscrim);
+    *x0 = temp / a; *x1 = c / temp;
+    if (*x0 > *x1) { double t = *x0; *x0 = *x1; *x1 = t; }
+    return 1;
+}
+/* util.cpp:449-487 solveQuadratic */
+static int solve_quadratic(float a, float b, float c, float *x0, float *x1) {
+    if (a == 0) { if (b != 0) { *x0 = *x1 = -c / b; return 1; } return 0; }
+    float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return 0;
+    float temp, sqrtDiscrim = sqrtf(discrim);
+    if (b < 0) temp = -0.5f * (b - sqrtDiscrim); else temp = -0.5f * (b + sqrtDiscrim);
+    *x0 = temp / a; *x1 = c / temp;
+    if (*x0 > *x1) { float t = *x0; *x0 = *x1; *x1 = t; }
+    return 1;
+}
+/* util.cpp:594-603 coordinateSystem */
+static void coordinate_system(v3 a, v3 *b, v3 *c) {
+    if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z); *c = V(a.z * invLen, 0.0f, -a.x * invLen); }
+    else { float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z); *c = V(0.0f, a.z * invLen, -a.y * invLen); }
+    *b = cross(*c, a);
+}
+/* Shape::rayIntersect(ray, mint, maxt, t, temp): rectangle.cpp:125-148, disk.cpp:141-165, sphere.cpp:148-174, cylinder.cpp:128-166.
+ * any != 0 selects the shadow-ray overloads (rectangle.cpp:150-153, disk.cpp:167-170, sphere.cpp:176-194, cylinder.cpp:168-201),
+ * which differ from the closest-hit ones for the quadrics.  *u,*v = the temp data (local x, y) of rectangle / disk. */
+static int analytic_intersect(const analytic_t *sh, v3 o, v3 d, float mint, float maxt, int any, float *t, float *u, float *v) {
+    switch (sh->a.type) {
+    case SH_RECTANGLE: case SH_DISK: {
+        v3 ro = xf_point(sh->a.to_object, o), rd = xf_vector(sh->a.to_object, d);
+        float hit = -ro.z / rd.z;
+        if (!(hit >= mint && hit <= maxt)) return 0;
+        float lx = ro.x + hit * rd.x, ly = ro.y + hit * rd.y;                 /* Ray::operator()(t) = o + t * d */
+        if (sh->a.type == SH_RECTANGLE ? (fabsf(lx) <= 1 && fabsf(ly) <= 1) : (lx * lx + ly * ly <= 1)) { *t = hit; *u = lx; *v = ly; return 1; }
+        return 0;
+    }
+    case SH_SPHERE: {
+        double ox = (double) o.x - (double) sh->center.x, oy = (double) o.y - (double) sh->center.y, oz = (double) o.z - (double) sh->center.z;
+        double dx = d.x, dy = d.y, dz = d.z;
+        double A = dx * dx + dy * dy + dz * dz, B = 2 * (ox * dx + oy * dy + oz * dz), C = (ox * ox + oy * oy + oz * oz) - (double) (sh->a.radius * sh->a.radius);
+        double nearT, farT;
+        if (!solve_quadratic_double(A, B, C, &nearT, &farT)) return 0;
+        if (any) {
+            if (nearT > maxt || farT < mint) return 0;
+            if (nearT < mint && farT > maxt) return 0;
+            *t = 0; return 1;
+        }
+        if (!(nearT <= maxt && farT >= mint)) return 0;
+        if (nearT < mint) { if (farT > maxt) return 0; *t = (float) farT; } else *t = (float) nearT;
+        *u = 0; *v = 0; return 1;
+    }
+    case SH_CYLINDER: {
+        v3 ro = xf_point(sh->a.to_object, o), rd = xf_vector(sh->a.to_object, d);
+        double ox = ro.x, oy = ro.y, dx = rd.x, dy = rd.y;
+        double A = dx * dx + dy * dy, B = 2 * (dx * ox + dy * oy), C = ox * ox + oy * oy - (double) (sh->a.radius * sh->a.radius);
+        double nearT, farT;
+        if (!solve_quadratic_double(A, B, C, &nearT, &farT)) return 0;
+        if (any) { if (nearT > maxt || farT < mint) return 0; }
+        else if (!(nearT <= maxt && farT >= mint)) return 0;
+        double zPosNear = (double) ro.z + (double) rd.z * nearT, zPosFar = (double) ro.z + (double) rd.z * farT;
+        if (zPosNear >= 0 && zPosNear <= sh->a.length && nearT >= mint) { *t = (float) nearT; }
+        else if (zPosFar >= 0 && zPosFar <= sh->a.length) { if (farT > maxt) return 0; *t = (float) farT; }
+        else return 0;
+        *u = 0; *v = 0; return 1;
+    }
+    }
+    return 0;
+}
+/* Shape::fillIntersectionRecord: rectangle.cpp:155-168, disk.cpp:172-200, sphere.cpp:196-245, cylinder.cpp:203-233: p, normals and dpdu
+ * (uv / dpdv feed textures only and are not restated).  Disk::fillIntersectionRecord leaves geoFrame unset in the reference; it is
+ * defined as the shading normal here. */
+static void analytic_fill(const analytic_t *sh, v3 o, v3 d, float t, float lx, float ly, v3 *p, v3 *ng, v3 *ns, v3 *dpdu) {
+    *p = add(o, scale(d, t));
+    switch (sh->a.type) {
+    case SH_RECTANGLE: *ng = sh->n; *ns = sh->n; *dpdu = sh->dpdu; break;
+    case SH_DISK: {
+        float r = sqrtf(lx * lx + ly * ly), invR = (r == 0) ? 0.0f : (1.0f / r);
+        float cosPhi = lx * invR, sinPhi = ly * invR;
+        *dpdu = r != 0 ? xf_vector(sh->a.to_world, V(cosPhi, sinPhi, 0)) : xf_vector(sh->a.to_world, V(1, 0, 0));
+        *ns = sh->n; *ng = sh->n; break;
+    }
+    case SH_SPHERE: {
+        *p = add(sh->center, scale(normalize(sub(*p, sh->center)), sh->a.radius));           /* SINGLE_PRECISION re-projection */
+        v3 local = xf_vector(sh->a.to_object, sub(*p, sh->center));
+        *dpdu = xf_vector(sh->a.to_world, scale(V(-local.y, local.x, 0), 2 * M_PI_F));
+        v3 n = normalize(sub(*p, sh->center));
+        if (sh->a.flags & 1u) n = scale(n, -1.0f);
+        *ng = n; *ns = n; break;
+    }
+    default: {
+        v3 local = xf_point(sh->a.to_object, *p);
+        *dpdu = xf_vector(sh->a.to_world, scale(V(-local.y, local.x, 0), 2 * M_PI_F));
+        v3 dpdv = xf_vector(sh->a.to_world, V(0, 0, sh->a.length));
+        v3 n = cross(normalize(*dpdu), normalize(dpdv));
+        *p = add(*p, scale(n, sh->a.radius - sqrtf(local.x * local.x + local.y * local.y)));
+        if (sh->a.flags & 1u) n = scale(n, -1.0f);
+        *ng = n; *ns = n; break;
+    }
+    }
+}
+/* Shape::samplePosition: rectangle.cpp:215-221, disk.cpp:252-260, cylinder.cpp:235-250 (sphere: see analytic_sample_direct) */
+static void analytic_sample_position(const analytic_t *sh, float sx, float sy, v3 *p, v3 *n) {
+    switch (sh->a.type) {
+    case SH_RECTANGLE: *p = xf_point(sh->a.to_world, V(sx * 2 - 1, sy * 2 - 1, 0)); *n = sh->n; break;
+    case SH_DISK: { float px, py; disk_concentric(sx, sy, &px, &py); *p = xf_point(sh->a.to_world, V(px, py, 0)); *n = sh->n; break; }
+    default: {
+        float sinTheta, cosTheta; sincos_2pi(sy, &sinTheta, &cosTheta);
+        v3 pl = V(cosTheta * sh->a.radius, sinTheta * sh->a.radius, sx * sh->a.length), nl = V(cosTheta, sinTheta, 0.0f);
+        if (sh->a.flags & 1u) nl = scale(nl, -1.0f);
+        *p = xf_point(sh->a.to_world, pl); *n = normalize(xf_normal(sh->a.to_object, nl)); break;
+    }
+    }
+}
+/* warp.cpp:25-31 squareToUniformSphere, :54-63 squareToUniformCone */
+static v3 uniform_sphere(float sx, float sy) {
+    float z = 1.0f - 2.0f * sy, r = sqrtf(maxf(1.0f - z * z, 0.0f)), sinPhi, cosPhi;
+    sincos_2pi(sx, &sinPhi, &cosPhi);
+    return V(r * cosPhi, r * sinPhi, z);
+}
+static v3 uniform_cone(float cosCutoff, float sx, float sy) {
+    float cosTheta = (1 - sx) + sx * cosCutoff, sinTheta = sqrtf(maxf(1.0f - cosTheta * cosTheta, 0.0f)), sinPhi, cosPhi;
+    sincos_2pi(sy, &sinPhi, &cosPhi);
+    return V(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+}
+/* Shape::sampleDirect (src/librender/shape.cpp:102-115) for rectangle / disk / cylinder; Sphere::sampleDirect (sphere.cpp:275-346).
+ * Outputs the solid-angle density in *pdf. */
+static void analytic_sample_direct(const analytic_t *sh, v3 ref, float sx, float sy, v3 *p, v3 *n, v3 *dOut, float *dist, float *pdf) {
+    if (sh->a.type == SH_SPHERE) {
+        const float radius = sh->a.radius;
+        v3 refToCenter = sub(sh->center, ref);
+        float refDist2 = dot(refToCenter, refToCenter), invRefDist = 1.0f / sqrtf(refDist2);
+        float sinAlpha = radius * invRefDist;
+        if (sinAlpha < 1 - EPSILON) {
+            float cosAlpha = sqrtf(maxf(1.0f - sinAlpha * sinAlpha, 0.0f));
+            v3 fn = scale(refToCenter, invRefDist), fs, ft; coordinate_system(fn, &fs, &ft);        /* Frame(n), include/mitsuba/core/frame.h:53-55 */
+            v3 c = uniform_cone(cosAlpha, sx, sy);
+            v3 d = add(add(scale(fs, c.x), scale(ft, c.y)), scale(fn, c.z));
+            *pdf = (0.5f * INV_PI) / (1 - cosAlpha);                                                /* INV_TWOPI / (1 - cosCutoff), warp.h:74-76 */
+            float projDist = dot(refToCenter, d);
+            float baseT = refDist2 / projDist;
+            v3 query = add(ref, scale(d, baseT));
+            v3 queryToCenter = sub(sh->center, query);
+            float queryDist2 = dot(queryToCenter, queryToCenter), queryProjDist = dot(queryToCenter, d);
+            float A = 1.0f, B = -2 * queryProjDist, C = queryDist2 - radius * radius, nearT, farT;
+            if (!solve_quadratic(A, B, C, &nearT, &farT)) nearT = queryProjDist;
+            *dist = baseT + nearT;
+            *n = normalize(sub(scale(d, nearT), queryToCenter));
+            *p = add(sh->center, scale(*n, radius));
+            *dOut = d;
+        } else {
+            v3 dl = uniform_sphere(sx, sy);
+            *p = add(sh->center, scale(dl, radius)); *n = dl;
+            v3 d = sub(*p, ref);
+            float dist2 = dot(d, d); *dist = sqrtf(dist2);
+            { float r = 1.0f / *dist; d = scale(d, r); }
+            *dOut = d;
+            *pdf = sh->inv_area * dist2 / fabsf(dot(d, *n));
+        }
+        if (sh->a.flags & 1u) *n = scale(*n, -1.0f);
+        return;
+    }
+    analytic_sample_position(sh, sx, sy, p, n);
+    v3 d = sub(*p, ref);
+    float distSquared = dot(d, d); *dist = sqrtf(distSquared);
+    { float r = 1.0f / *dist; d = scale(d, r); }
+    float dp = fabsf(dot(d, *n));
+    *pdf = sh->inv_area * (dp != 0 ? (distSquared / dp) : 0.0f);
+    *dOut = d;
+}
+/* Shape::pdfDirect, measure = ESolidAngle (shape.cpp:117-126); Sphere::pdfDirect (sphere.cpp:348-379) */
+static float analytic_pdf_direct(const analytic_t *sh, v3 ref, v3 d, v3 n, float dist) {
+    if (sh->a.type == SH_SPHERE) {
+        v3 refToCenter = sub(sh->center, ref);
+        float invRefDist = 1.0f / length3(refToCenter), sinAlpha = sh->a.radius * invRefDist;
+        if (sinAlpha < 1 - EPSILON) { float cosAlpha = sqrtf(maxf(1 - sinAlpha * sinAlpha, 0.0f)); return (0.5f * INV_PI) / (1 - cosAlpha); }
+    }
+    if (sh->a.type == SH_SPHERE) return sh->inv_area * dist * dist / fabsf(dot(d, n));   /* sphere.cpp:370-372 (association as written there) */
+    return sh->inv_area * (dist * dist) / fabsf(dot(d, n));
+}
+/* derived constants + Shape::getAABB (rectangle.cpp:112-119, disk.cpp:118-130, sphere.cpp:137-142, cylinder.cpp:256-276) */
+static void analytic_prepare(analytic_t *sh) {
+    const float *M = sh->a.to_world; v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY);
+#define EXPAND(pt) do { v3 q_ = (pt); lo = V(minf(lo.x, q_.x), minf(lo.y, q_.y), minf(lo.z, q_.z)); hi = V(maxf(hi.x, q_.x), maxf(hi.y, q_.y), maxf(hi.z, q_.z)); } while (0)
+    sh->n = V(0, 0, 0); sh->dpdu = V(0, 0, 0); sh->center = V(0, 0, 0);
+    switch (sh->a.type) {
+    case SH_RECTANGLE: {
+        sh->dpdu = xf_vector(M, V(2, 0, 0)); v3 dpdv = xf_vector(M, V(0, 2, 0));
+        sh->n = normalize(xf_normal(sh->a.to_object, V(0, 0, 1)));
+        sh->inv_area = 1.0f / (length3(sh->dpdu) * length3(dpdv));
+        EXPAND(xf_point(M, V(-1, -1, 0))); EXPAND(xf_point(M, V(1, -1, 0))); EXPAND(xf_point(M, V(1, 1, 0))); EXPAND(xf_point(M, V(-1, 1, 0)));
+        break;
+    }
+    case SH_DISK: {
+        v3 dpdu = xf_vector(M, V(1, 0, 0));
+        sh->n = normalize(xf_normal(sh->a.to_object, V(0, 0, 1)));
+        sh->inv_area = 1.0f / (M_PI_F * length3(dpdu) * length3(dpdu));
+        EXPAND(xf_point(M, V(1, 0, 0))); EXPAND(xf_point(M, V(-1, 0, 0))); EXPAND(xf_point(M, V(0, 1, 0))); EXPAND(xf_point(M, V(0, -1, 0)));
+        break;
+    }
+    case SH_SPHERE: {
+        sh->center = xf_point(M, V(0, 0, 0));
+        sh->inv_area = 1 / (4 * M_PI_F * sh->a.radius * sh->a.radius);
+        lo = V(sh->center.x - sh->a.radius, sh->center.y - sh->a.radius, sh->center.z - sh->a.radius);
+        hi = V(sh->center.x + sh->a.radius, sh->center.y + sh->a.radius, sh->center.z + sh->a.radius);
+        break;
+    }
+    default: {
+        sh->inv_area = 1 / (2 * M_PI_F * sh->a.radius * sh->a.length);
+        v3 x1 = xf_vector(M, V(sh->a.radius, 0, 0)), x2 = xf_vector(M, V(0, sh->a.radius, 0));
+        v3 p0 = xf_point(M, V(0, 0, 0)), p1 = xf_point(M, V(0, 0, sh->a.length));
+        float l[3], h[3];
+        for (int i = 0; i < 3; ++i) {
+            float range = sqrtf(comp(x1, i) * comp(x1, i) + comp(x2, i) * comp(x2, i));
+            l[i] = minf(minf(INFINITY, comp(p0, i) - range), comp(p1, i) - range);
+            h[i] = maxf(maxf(-INFINITY, comp(p0, i) + range), comp(p1, i) + range);
+        }
+        lo = V(l[0], l[1], l[2]); hi = V(h[0], h[1], h[2]);
+        break;
+    }
+    }
+#undef EXPAND
+    sh->lo = lo; sh->hi = hi;
+}
+
 /* include/mitsuba/core/aabb.h:308-339 TAABB::rayIntersect(ray, nearT, farT) (dRcp = 1/d, include/mitsuba/core/ray.h:72-83) */
 static int aabb_ray(v3 lo, v3 hi, v3 o, v3 d, float *nearT, float *farT) {
     float nt = -INFINITY, ft = INFINITY;
@@ -319,7 +581,8 @@ static int traverse(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int 
         if (n->count > 0) {
             for (int i = 0; i < n->count; ++i) {
                 uint32_t prim = s->bvh_tris[n->first + i]; float u, v, t;
-                if (triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t)) {
+                if (prim < s->d.n_tris ? triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t)
+                                       : analytic_intersect(&s->analytic[prim - s->d.n_tris], o, d, mint, best, shadow, &t, &u, &v)) {
                     if (shadow) return 1;
                     if (!found || better(t, prim, best, bestPrim)) { best = t; bestPrim = prim; *bu = u; *bv = v; found = 1; }
                 }
@@ -329,19 +592,33 @@ static int traverse(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int 
     if (found) { *bt = best; *bprim = bestPrim; }
     return found;
 }
-static int traverse_brute(const orc_scene *s, v3 o, v3 d, float mint, float maxt, float *bt, uint32_t *bprim, float *bu, float *bv) {
+static int traverse_brute(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int shadow, float *bt, uint32_t *bprim, float *bu, float *bv) {
     int found = 0; float best = maxt; uint32_t bestPrim = 0xFFFFFFFFu;
-    for (uint32_t prim = 0; prim < s->d.n_tris; ++prim) {
+    for (uint32_t prim = 0; prim < s->n_prims; ++prim) {
         float u, v, t;
-        if (triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t))
+        if (prim < s->d.n_tris ? triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t)
+                               : analytic_intersect(&s->analytic[prim - s->d.n_tris], o, d, mint, best, shadow, &t, &u, &v)) {
+            if (shadow) return 1;
             if (!found || better(t, prim, best, bestPrim)) { best = t; bestPrim = prim; *bu = u; *bv = v; found = 1; }
+        }
     }
     if (found) { *bt = best; *bprim = bestPrim; }
     return found;
 }
 
 /* include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610 computeShadingFrame */
-static void fill_hit(const orc_scene *s, v3 d, float t, uint32_t prim, float u, float v, hit_t *h) {
+static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, float u, float v, hit_t *h) {
+    if (prim >= s->d.n_tris) {                       /* skdtree.h:421-427: shape->fillIntersectionRecord, computeShadingFrame, wi */
+        const analytic_t *sh = &s->analytic[prim - s->d.n_tris]; v3 dpdu;
+        h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
+        analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu);
+        h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
+        h->tt = cross(h->ns, h->s);
+        v3 md = neg(d);
+        h->wi = V(dot(md, h->s), dot(md, h->tt), dot(md, h->ns));
+        h->material = sh->a.bsdf; h->emitter = sh->a.emitter;
+        return;
+    }
     uint32_t shape = s->tri_shape[prim]; const orc_shape *sh = &s->shapes[shape];
     uint32_t i0 = s->idx[prim * 3], i1 = s->idx[prim * 3 + 1], i2 = s->idx[prim * 3 + 2];
     v3 p0 = vert(s, i0), p1 = vert(s, i1), p2 = vert(s, i2);
@@ -373,15 +650,15 @@ static int ray_intersect(const orc_scene *s, v3 o, v3 d, float rmint, float rmax
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0;
     h->valid = 0;
     if (!clip_interval(s, o, d, rmint, rmaxt, 0, &mint, &maxt)) return 0;
-    int found = brute ? traverse_brute(s, o, d, mint, maxt, &t, &prim, &u, &v) : traverse(s, o, d, mint, maxt, 0, &t, &prim, &u, &v);
+    int found = brute ? traverse_brute(s, o, d, mint, maxt, 0, &t, &prim, &u, &v) : traverse(s, o, d, mint, maxt, 0, &t, &prim, &u, &v);
     if (!found) return 0;
-    fill_hit(s, d, t, prim, u, v, h);
+    fill_hit(s, o, d, t, prim, u, v, h);
     return 1;
 }
 static int ray_occluded(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt) {
     float mint, maxt, t, u, v; uint32_t prim;
     if (!clip_interval(s, o, d, rmint, rmaxt, 1, &mint, &maxt)) return 0;
-    if (g_brute) return traverse_brute(s, o, d, mint, maxt, &t, &prim, &u, &v);
+    if (g_brute) return traverse_brute(s, o, d, mint, maxt, 1, &t, &prim, &u, &v);
     return traverse(s, o, d, mint, maxt, 1, &t, &prim, &u, &v);
 }
 static v3 to_world(const hit_t *h, v3 w) { return add(add(scale(h->s, w.x), scale(h->tt, w.y)), scale(h->ns, w.z)); }
@@ -730,7 +1007,7 @@ static uint32_t cdf_sample(const float *cdf, uint32_t n, float x) {
     while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
     return index;
 }
-typedef struct { v3 p, n, d; float dist, pdf; int32_t emitter; } direct_t;
+typedef struct { v3 ref, p, n, d; float dist, pdf; int32_t emitter; } direct_t;
 
 /* src/emitters/area.cpp:106-111 AreaLight::eval */
 static v3 emitter_eval(const orc_scene *s, int32_t e, v3 ns, v3 d) {
@@ -764,6 +1041,10 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
         { float r = 1.0f / emPdf; value = scale(value, r); }
         return value;
     }
+    dr->ref = ref;
+    if ((uint32_t) em->shape >= s->d.n_shapes) {       /* area light on an analytic shape: Shape::sampleDirect / Sphere::sampleDirect, no sample reuse */
+        analytic_sample_direct(&s->analytic[(uint32_t) em->shape - s->d.n_shapes], ref, sx, sy, &dr->p, &dr->n, &dr->d, &dr->dist, &dr->pdf);
+    } else {
     const orc_shape *sh = &s->shapes[em->shape];
     uint32_t ti = cdf_sample(s->area_cdf[ei], sh->tri_count, sy);
     sy = (sy - s->area_cdf[ei][ti]) / (s->area_cdf[ei][ti + 1] - s->area_cdf[ei][ti]);
@@ -783,6 +1064,7 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
     { float r = 1.0f / dr->dist; dr->d = scale(dr->d, r); }
     float dp = fabsf(dot(dr->d, dr->n));
     dr->pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    }
     v3 value;
     if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0 && dr->pdf != 0) {
         float r = 1.0f / dr->pdf; value = V(em->radiance[0] * r, em->radiance[1] * r, em->radiance[2] * r);   /* Spectrum / Float */
@@ -805,9 +1087,11 @@ static float pdf_emitter_direct(const orc_scene *s, const direct_t *dr, v3 refN)
     float pdf;
     if (s->emitters[dr->emitter].type == 1)                                    /* EnvironmentMap::pdfDirect, measure = ESolidAngle (envmap.cpp:549-560) */
         return env_pdf_direction(s, mat3(s->env_to_local, dr->d)) * (s->emitters[dr->emitter].weight * s->emitter_norm);
-    if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0)
-        pdf = s->inv_area[dr->emitter] * (dr->dist * dr->dist) / fabsf(dot(dr->d, dr->n));
-    else pdf = 0.0f;
+    if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0) {
+        int32_t shape = s->emitters[dr->emitter].shape;
+        if ((uint32_t) shape >= s->d.n_shapes) pdf = analytic_pdf_direct(&s->analytic[(uint32_t) shape - s->d.n_shapes], dr->ref, dr->d, dr->n, dr->dist);
+        else pdf = s->inv_area[dr->emitter] * (dr->dist * dr->dist) / fabsf(dot(dr->d, dr->n));
+    } else pdf = 0.0f;
     return pdf * (s->emitters[dr->emitter].weight * s->emitter_norm);
 }
 void orc_sample_emitter_direct(const orc_scene *s, const float *rp, const float *rn, float u, float v, float *o) {
@@ -844,7 +1128,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
 
         /* direct illumination sampling (path.cpp:172-200), only for BSDFs with a smooth component */
         v3 refN = material_has_backside(bsdf) ? V(0, 0, 0) : its.ns;      /* records.inl:160-164 */
-        direct_t dRec; memset(&dRec, 0, sizeof(dRec));
+        direct_t dRec; memset(&dRec, 0, sizeof(dRec)); dRec.ref = its.p;
         if (material_is_smooth(bsdf)) {
             float sx, sy; next2D(sp, &sx, &sy);
             v3 value = sample_emitter_direct(s, its.p, refN, sx, sy, &dRec, 1, &counters[1]);
@@ -1031,9 +1315,13 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     s->tri_shape = (uint32_t *) calloc(d->n_tris, 4);
     for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->tri_shape[s->shapes[i].first_tri + t] = i;
     /* TriAccel table (skdtree.cpp:79-105) + scene box (union of mesh AABBs, enlarged as in gkdtree.h:1213-1220) */
-    s->accel = (triaccel *) calloc(d->n_tris, sizeof(triaccel));
+    s->accel = (triaccel *) calloc(d->n_tris ? d->n_tris : 1, sizeof(triaccel));
+    s->n_analytic = d->analytic ? d->n_analytic : 0; s->n_prims = d->n_tris + s->n_analytic;
+    s->analytic = (analytic_t *) calloc(s->n_analytic ? s->n_analytic : 1, sizeof(analytic_t));
+    for (uint32_t i = 0; i < s->n_analytic; ++i) { s->analytic[i].a = d->analytic[i]; analytic_prepare(&s->analytic[i]); }
+    s->d.analytic = NULL;
     v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY);
-    v3 *cent = (v3 *) calloc(d->n_tris, sizeof(v3)), *tlo = (v3 *) calloc(d->n_tris, sizeof(v3)), *thi = (v3 *) calloc(d->n_tris, sizeof(v3));
+    v3 *cent = (v3 *) calloc(s->n_prims, sizeof(v3)), *tlo = (v3 *) calloc(s->n_prims, sizeof(v3)), *thi = (v3 *) calloc(s->n_prims, sizeof(v3));
     for (uint32_t t = 0; t < d->n_tris; ++t) {
         v3 a = vert(s, s->idx[t * 3]), b = vert(s, s->idx[t * 3 + 1]), c = vert(s, s->idx[t * 3 + 2]);
         triaccel_load(&s->accel[t], a, b, c);
@@ -1045,14 +1333,24 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
         v3 p = vert(s, s->shapes[i].first_vert + v);
         lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
     }
+    for (uint32_t i = 0; i < s->n_analytic; ++i) {                   /* ShapeKDTree::addShape: m_aabb.expandBy(shape->getAABB()) (skdtree.cpp:68-77) */
+        const analytic_t *a = &s->analytic[i]; uint32_t t = d->n_tris + i;
+        lo = V(minf(lo.x, a->lo.x), minf(lo.y, a->lo.y), minf(lo.z, a->lo.z)); hi = V(maxf(hi.x, a->hi.x), maxf(hi.y, a->hi.y), maxf(hi.z, a->hi.z));
+        tlo[t] = a->lo; thi[t] = a->hi;
+        if (a->a.type == SH_DISK) {      /* Disk::getAABB bounds four rim points only; the oracle's own BVH needs the whole rim */
+            v3 c = xf_point(a->a.to_world, V(0, 0, 0)); float r = length3(xf_vector(a->a.to_world, V(1, 0, 0)));
+            tlo[t] = V(minf(tlo[t].x, c.x - r), minf(tlo[t].y, c.y - r), minf(tlo[t].z, c.z - r)); thi[t] = V(maxf(thi[t].x, c.x + r), maxf(thi[t].y, c.y + r), maxf(thi[t].z, c.z + r));
+        }
+        cent[t] = scale(add(tlo[t], thi[t]), 0.5f);
+    }
     { const float eps = KD_AABB_EPSILON;
       v3 e1 = sub(hi, lo); lo = sub(lo, V(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps));
       v3 e2 = sub(hi, lo); hi = add(hi, V(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps)); }
     s->aabb_lo = lo; s->aabb_hi = hi;
-    s->nodes = (bvh_node *) calloc(2 * (size_t) d->n_tris + 2, sizeof(bvh_node));
-    s->bvh_tris = (uint32_t *) calloc(d->n_tris + 1, 4);
-    for (uint32_t t = 0; t < d->n_tris; ++t) s->bvh_tris[t] = t;
-    s->n_nodes = 0; build_bvh(s, s->bvh_tris, 0, (int) d->n_tris, cent, tlo, thi);
+    s->nodes = (bvh_node *) calloc(2 * (size_t) s->n_prims + 2, sizeof(bvh_node));
+    s->bvh_tris = (uint32_t *) calloc(s->n_prims + 1, 4);
+    for (uint32_t t = 0; t < s->n_prims; ++t) s->bvh_tris[t] = t;
+    s->n_nodes = 0; build_bvh(s, s->bvh_tris, 0, (int) s->n_prims, cent, tlo, thi);
     free(cent); free(tlo); free(thi);
     /* emitter selection PDF (scene.cpp:383-388; pmf.h:56-58 append, :103-116 normalize) */
     uint32_t ne = d->n_emitters;
@@ -1061,7 +1359,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     if (ne) { float sum = s->emitter_cdf[ne]; s->emitter_norm = sum > 0 ? 1.0f / sum : 0.0f; for (uint32_t e = 1; e <= ne; ++e) s->emitter_cdf[e] *= s->emitter_norm; s->emitter_cdf[ne] = 1.0f; }
     /* per-mesh area distribution (trimesh.cpp:389-402 prepareSamplingTable; triangle.cpp:61-67 surfaceArea) */
     for (uint32_t e = 0; e < ne; ++e) {
-        if (s->emitters[e].type != 0) continue;
+        if (s->emitters[e].type != 0 || (uint32_t) s->emitters[e].shape >= d->n_shapes) continue;
         const orc_shape *sh = &s->shapes[s->emitters[e].shape]; uint32_t nt = sh->tri_count;
         float *cdf = (float *) calloc(nt + 1, 4);
         for (uint32_t t = 0; t < nt; ++t) {
@@ -1137,7 +1435,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
 void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
     for (uint32_t e = 0; e < s->d.n_emitters; ++e) free(s->area_cdf[e]);   /* NULL for the environment emitter */
-    free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape);
+    free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic);
     free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
     free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->emitters); free(s);
 }

@@ -67,7 +67,9 @@ template <typename T> static void save(const std::string &p, const char *d, std:
 struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
 struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
 struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight; };
+struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
 struct FScene {
+    std::vector<FAnalytic> analytic;
     uint32_t nVerts, nTris, nShapes, nBsdfs, nEmitters, hasN, hasUV, hasEnv;
     std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx;
     std::vector<FShape> shapes; std::vector<FBsdf> bsdfs; std::vector<FEmitter> emitters;
@@ -96,6 +98,11 @@ static FScene loadScene(const char *path) {
     if (s.hasEnv) {
         rd(f, &s.envW, 8); rd(f, s.envToWorld, 64); rd(f, &s.envScale, 4);
         s.envRGB.resize((size_t) s.envW * s.envH * 3); rd(f, s.envRGB.data(), s.envRGB.size() * 4);
+    }
+    char tag[4];
+    if (fread(tag, 1, 4, f) == 4 && !memcmp(tag, "ANLY", 4)) {
+        uint32_t n; rd(f, &n, 4); s.analytic.resize(n);
+        for (FAnalytic &a : s.analytic) rd(f, &a, sizeof(FAnalytic));
     }
     fclose(f); return s;
 }
@@ -227,6 +234,29 @@ static Built buildScene(const FScene &fs) {
         }
         mesh->configure();
         b.scene->addChild(mesh); mesh->setParent(b.scene);
+    }
+    // analytic shapes (after the meshes: shape index = nShapes + i).  The descriptor holds the post-constructor objectToWorld; sphere and
+    // cylinder get their scale back through `toWorld` so that the reference's constructors split it off again (sphere.cpp:113-123, cylinder.cpp:85-106)
+    for (size_t ai = 0; ai < fs.analytic.size(); ++ai) {
+        const FAnalytic &a = fs.analytic[ai];
+        static const char *names[] = {"rectangle", "disk", "sphere", "cylinder"};
+        Properties p(names[a.type]);
+        Matrix4x4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = a.toWorld[i * 4 + j];
+        Transform tw(m);
+        if (a.type == 2) tw = tw * Transform::scale(Vector(a.radius));
+        if (a.type == 3) tw = tw * Transform::scale(Vector(a.radius, a.radius, a.length));
+        p.setTransform("toWorld", tw);
+        if (a.type >= 2) p.setBoolean("flipNormals", (a.flags & 1) != 0);
+        ref<Shape> shape = static_cast<Shape *>(create(MTS_CLASS(Shape), p));
+        shape->addChild(bsdfs[a.bsdf]); bsdfs[a.bsdf]->setParent(shape);
+        if (a.emitter >= 0) {
+            const FEmitter &fe = fs.emitters[a.emitter];
+            Properties ep("area"); ep.setSpectrum("radiance", rgb(fe.radiance)); ep.setFloat("samplingWeight", fe.weight);
+            ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), ep));
+            shape->addChild(em); em->setParent(shape); em->configure();
+        }
+        shape->configure();
+        b.scene->addChild(shape); shape->setParent(b.scene);
     }
     // film + filter
     {

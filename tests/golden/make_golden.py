@@ -35,12 +35,20 @@ def golden_scenes():
         "atrium_hide_indep": scenes.atrium(width=96, height=54, spp=8, detail=0.08, env_size=(64, 32), hide_emitters=True, sampler=scenes.SAMPLER_INDEPENDENT,
                                            max_depth=-1, rr_depth=3, seed=7),
         "cornell_hide": scenes.cornell_box(width=96, height=54, spp=8, hide_emitters=True, max_depth=3, rr_depth=1),
+        # analytic shapes behind rayIntersect (rectangle / disk / sphere / cylinder) as geometry and as area lights
+        "cbox_shapes": scenes.cbox_shapes(width=96, height=96, spp=16),
+        "shape_lights": scenes.shape_lights(width=96, height=64, spp=16),
+        "cbox_shapes_strict_indep": scenes.cbox_shapes(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=3, strict_normals=True, hide_emitters=True, rr_depth=2, disk_cap=False),
     }
 
 
 def main():
+    only = None                                          # --only a,b: regenerate just these scenes (the pair streams of all scenes are still drawn, in order)
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     tmp = tempfile.mkdtemp()
-    run("tables", OUT)
+    if only is None:
+        run("tables", OUT)
     rng = np.random.default_rng(20251004)
     for name, sc in golden_scenes().items():
         path = os.path.join(tmp, name + ".miscene")
@@ -49,6 +57,8 @@ def main():
         pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
         pairs[:8] = [[0, 0, 0], [sc.width - 1, sc.height - 1, sc.spp - 1], [sc.width // 2, sc.height // 2, 0], [1, 0, 1],
                      [0, 1, 2], [sc.width - 1, 0, 3], [0, sc.height - 1, 1], [sc.width // 3, sc.height // 3, sc.spp - 1]]
+        if only is not None and name not in only:
+            continue
         ppath = os.path.join(tmp, name + "_pairs.bin"); pairs.tofile(ppath)
         base = os.path.join(tmp, name)
         run(path, "samples", ppath, base)
@@ -56,7 +66,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)

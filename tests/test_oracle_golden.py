@@ -38,7 +38,8 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
             assert np.float32(oracle.lib().orc_sobol_sample(orc.h, idx, d * 7)) == vals[d]
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide",
+                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -52,6 +53,11 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     if name.startswith("atrium"):
         # coarse smooth-shaded columns (6 segments): the interpolated normal amplifies last-bit differences of (u, v) at grazing angles
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6
+    elif name in ("cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"):
+        # analytic shapes: the quadrics are solved in double precision on both sides; sin/cos of the cylinder / sphere / cone maps come from
+        # libm in the reference and from the polynomial pair here.  shape_lights holds the all-zero Sobol point whose first bounce leaves the
+        # inward sphere exactly along its tangent (a legitimate fork)
+        assert same_path.mean() > 0.999 and same_vals.mean() > 0.998 and (err < 1e-4).mean() > 0.995 and (err < 5e-3).mean() > 0.999 and np.median(err) < 1e-6
     elif name == "closed_box":
         # axis-aligned box with exactly representable coordinates: rays through shared edges / the quad diagonals tie exactly and the
         # kd-tree keeps the last-tested triangle (SURVEY.md §7 "nearest-hit tie-breaking") -> a handful of paths legitimately fork
@@ -61,7 +67,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -79,7 +85,8 @@ def test_units_vs_reference(oracle, golden_scenes, name):
             nhit += 1
             assert abs(h[0] - row[3]) <= 2e-5 * abs(row[3])
             assert np.allclose(h[1:4], row[4:7], atol=2e-3) and np.allclose(h[4:13], row[7:16], atol=2e-5)
-            assert np.allclose(h[15:18], row[18:21], atol=2e-5) and h[18] == row[21] and h[19] == row[22]
+            assert np.allclose(h[15:18], row[18:21], atol=2e-5) and h[19] == row[22]
+            assert h[19] >= len(sc.shapes) or h[18] == row[21]      # analytic shapes leave Intersection::primIndex untouched in the reference
             okb, hb = orc.intersect(ray, brute=True)
             assert okb and (hb.view(np.uint32) == h.view(np.uint32)).all()
     assert nhit > 20
@@ -97,8 +104,18 @@ def test_units_vs_reference(oracle, golden_scenes, name):
         assert ta[0] == row[0] and np.allclose(ta[1:], row[1:], rtol=2e-6, atol=1e-6)
     # emitter sampling (scene.cpp:860-884, area.cpp:160-184)
     o12 = np.zeros(12, np.float32)
-    for row in u["emitter"]:
-        p = np.ascontiguousarray(row[0:3]); n = np.ascontiguousarray(row[3:6])
+    # the harness took its reference points from camera rays through (x + .5, y + .5), x = 40, 40 + W/6, ..., four samples each; surfaces
+    # with a two-sided BSDF carry refN = 0 (records.inl:160-164)
+    twosided = []
+    for y in range(40, sc.height, sc.height // 6):
+        for x in range(40, sc.width, sc.width // 6):
+            ok, h = orc.intersect(orc.camera_ray(x + 0.5, y + 0.5))
+            if ok:
+                si = int(h[19]); mat = sc.shapes[si]["bsdf"] if si < len(sc.shapes) else sc.analytic[si - len(sc.shapes)]["bsdf"]
+                twosided += [sc.bsdfs[mat]["twosided"]] * 4
+    assert len(twosided) == len(u["emitter"])
+    for row, two in zip(u["emitter"], twosided):
+        p = np.ascontiguousarray(row[0:3]); n = np.ascontiguousarray(row[3:6] * (0.0 if two else 1.0))
         # the harness' reference point is the reference's own hit point: feed the same numbers
         L.orc_sample_emitter_direct(orc.h, p.ctypes.data, n.ctypes.data, float(row[6]), float(row[7]), o12.ctypes.data)
         assert np.allclose(o12[0:3], row[8:11], rtol=3e-5, atol=1e-7)
@@ -108,12 +125,12 @@ def test_units_vs_reference(oracle, golden_scenes, name):
     # BSDF sample / eval / pdf (diffuse.cpp:112-153)
     o8 = np.zeros(8, np.float32); o4 = np.zeros(4, np.float32)
     for row in u["bsdf"]:
-        si = int(row[0]); mat = sc.shapes[si]["bsdf"]
+        si = int(row[0]); mat = sc.shapes[si]["bsdf"] if si < len(sc.shapes) else sc.analytic[si - len(sc.shapes)]["bsdf"]
         wi = np.ascontiguousarray(row[1:4]); wo = np.ascontiguousarray(row[14:17])
         L.orc_bsdf_sample(orc.h, mat, wi.ctypes.data, float(row[4]), float(row[5]), o8.ctypes.data)
         assert np.allclose(o8[0:4], row[6:10], rtol=1e-5, atol=1e-7)
         if row[6:9].any():
-            assert np.allclose(o8[4:7], row[10:13], atol=3e-7) and o8[7] == row[13]
+            assert np.allclose(o8[4:7], row[10:13], atol=3e-7 if sc.bsdfs[mat]["type"] == 0 else 2e-6) and o8[7] == row[13]   # rough conductor: libm (atan/tan/erf) in the visible-normal sampler
         L.orc_bsdf_eval(orc.h, mat, wi.ctypes.data, wo.ctypes.data, o4.ctypes.data)
         assert np.allclose(o4[0:3], row[17:20], rtol=1e-5, atol=1e-8) and np.allclose(o4[3], row[20], rtol=1e-5, atol=1e-8)
     # filter table + border (rfilter.cpp:37-56)
@@ -123,7 +140,8 @@ def test_units_vs_reference(oracle, golden_scenes, name):
     assert (np.abs(got - ft[:321]) < 1e-6).mean() > 0.99 and orc.border == int(ft[-1])
 
 
-@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small"])
+@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
+                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
@@ -131,7 +149,8 @@ def test_film_vs_reference(oracle, golden_scenes, name):
     ref = gd["film"]
     assert film.shape == ref.shape
     rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
-    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3}.get(name, 1e-4), rel
+    # cbox_shapes_strict_indep: one of 73 728 samples forks at a strictNormals threshold (0.12 in one pixel)
+    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3}.get(name, 1e-4), rel
     assert np.allclose(film[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)        # weight channel
     # the reference's own ray counters (StatsCounter "Normal rays traced" / "Shadow rays traced", skdtree.cpp:46-47)
     stats = str(gd["stats"])
