@@ -43,7 +43,22 @@ typedef struct {
 
 #define MI_EMITTER_AREA 0         /* src/emitters/area.cpp   */
 #define MI_EMITTER_ENVMAP 1       /* src/emitters/envmap.cpp */
-typedef struct { uint32_t type; int32_t shape; float radiance[3]; float weight; uint32_t pad[2]; } mi_emitter;
+typedef struct { uint32_t type; int32_t shape; float radiance[3]; float weight; uint32_t pad[2]; } mi_emitter;   /* shape >= n_shapes: analytic shape (shape - n_shapes) */
+
+/* Analytic shapes behind Scene::rayIntersect (kd-tree leaf redirect, include/mitsuba/render/skdtree.h:292-301): src/shapes/rectangle.cpp,
+ * disk.cpp, sphere.cpp, cylinder.cpp.  to_world = the shape's objectToWorld AFTER its constructor (sphere.cpp:113-123 and
+ * cylinder.cpp:85-106 split the scale off into radius / length; rectangle.cpp:82-84 and disk.cpp:83-87 fold flipNormals into the
+ * transform), to_object = its inverse as the reference computes it; radius: sphere, cylinder; length: cylinder. */
+#define MI_SHAPE_RECTANGLE 0
+#define MI_SHAPE_DISK 1
+#define MI_SHAPE_SPHERE 2
+#define MI_SHAPE_CYLINDER 3
+#define MI_ANALYTIC_FLIP_NORMALS 1u   /* sphere / cylinder "flipNormals" */
+typedef struct {
+    uint32_t type; int32_t bsdf, emitter; uint32_t flags;
+    float to_world[16], to_object[16];
+    float radius, length; float pad[2];
+} mi_analytic;
 
 /* Integrator + sampler parameters: MonteCarloIntegrator properties (src/librender/integrator.cpp:191-226),
  * sampler properties (src/samplers/sobol.cpp:86-107; src/samplers/independent.cpp:51-60). */
@@ -89,6 +104,9 @@ void mi_scene_destroy(mi_scene *s);
 /* TriMesh::getVertexPositions/getVertexNormals/getVertexTexcoords/getTriangles of all meshes, concatenated; nrm/uv may be NULL */
 int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, const float *uv, const uint32_t *idx,
                            uint32_t n_verts, uint32_t n_tris, const mi_shape *shapes, uint32_t n_shapes);
+/* analytic shapes, numbered after the meshes: shape index n_shapes + i, primitive index n_tris + i (Scene::getShapes order with the
+ * meshes first).  Either call may be omitted, but a scene needs at least one primitive. */
+int mi_scene_set_analytic(mi_scene *s, const mi_analytic *shapes, uint32_t n);
 int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);

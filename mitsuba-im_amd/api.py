@@ -31,6 +31,11 @@ class MiEmitter(C.Structure):
     _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("pad", C.c_uint32 * 2)]
 
 
+class MiAnalytic(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32),
+                ("to_world", C.c_float * 16), ("to_object", C.c_float * 16), ("radius", C.c_float), ("length", C.c_float), ("pad", C.c_float * 2)]
+
+
 class MiRenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("fast_math", C.c_uint32)]
@@ -47,7 +52,7 @@ class MiStats(C.Structure):
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
-           "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_set_analytic", "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_sobol", "mi_debug_camera_rays"]
@@ -73,6 +78,7 @@ class Lib:
         L.mi_scene_create.argtypes = [C.POINTER(vp)]
         L.mi_scene_destroy.argtypes = [vp]; L.mi_scene_destroy.restype = None
         L.mi_scene_set_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32]
+        L.mi_scene_set_analytic.argtypes = [vp, vp, u32]
         L.mi_scene_set_materials.argtypes = [vp, vp, u32]
         L.mi_scene_set_emitters.argtypes = [vp, vp, u32]
         L.mi_scene_set_envmap.argtypes = [vp, vp, u32, u32, vp, f32]
@@ -145,6 +151,15 @@ class Scene:
         for i, e in enumerate(sc.emitters):
             em = MiEmitter(e["type"], e["shape"]); em.radiance[:] = e["radiance"]; em.weight = e["weight"]; ems[i] = em
         L.check(L.L.mi_scene_set_triangles(h, _p(sc.pos), _p(sc.nrm), _p(sc.uv), _p(sc.idx), len(sc.pos), len(sc.idx), C.cast(shapes, C.c_void_p), len(sc.shapes)))
+        recs = sc.get("analytic") or []
+        if recs:
+            an = (MiAnalytic * len(recs))()
+            for i, a in enumerate(recs):
+                r = MiAnalytic(a["type"], a["bsdf"], a["emitter"], a["flags"])
+                r.to_world[:] = a["to_world"].reshape(-1).tolist(); r.to_object[:] = a["to_object"].reshape(-1).tolist()
+                r.radius, r.length = a["radius"], a["length"]
+                an[i] = r
+            L.check(L.L.mi_scene_set_analytic(h, C.cast(an, C.c_void_p), len(recs)))
         L.check(L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), len(sc.bsdfs)))
         L.check(L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), len(sc.emitters)))
         if sc.envmap is not None:

@@ -13,7 +13,7 @@
 extern "C" {
 void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-void mi_upload_packet(const TriAccelD *, uint32_t, hipStream_t);
+void mi_upload_packet(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, hipStream_t);
 void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
@@ -25,7 +25,7 @@ void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hi
 // fast-arithmetic twins (kernels_fast.hip)
 void mi_launch_generate_fast(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend_fast(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-void mi_upload_packet_fast(const TriAccelD *, uint32_t, hipStream_t);
+void mi_upload_packet_fast(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, hipStream_t);
 void mi_launch_shade_fast(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow_fast(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film_fast(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
@@ -33,7 +33,7 @@ void mi_launch_film_fast(const DScene &, const Queues &, const BatchDesc &, floa
 struct LaunchSet {
     void (*generate)(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
     void (*extend)(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-    void (*packet)(const TriAccelD *, uint32_t, hipStream_t);
+    void (*packet)(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, hipStream_t);
     void (*shade)(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
     void (*shadow)(const DScene &, const Queues &, uint32_t, hipStream_t);
     void (*film)(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
@@ -107,6 +107,7 @@ void mi_scene_destroy(mi_scene *s) { delete s; }
 
 int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, const float *uv, const uint32_t *idx,
                            uint32_t nv, uint32_t nt, const mi_shape *shapes, uint32_t ns) {
+    if (s && nt == 0 && ns == 0) { s->h.pos.clear(); s->h.idx.clear(); s->h.nrm.clear(); s->h.shapes.clear(); s->h.committed = false; return MI_OK; }   // analytic-only scene
     if (!s || !pos || !idx || !shapes || !ns) return fail(MI_ERR_INVALID, "mi_scene_set_triangles: null argument");
     for (uint32_t i = 0; i < ns; ++i) {
         const mi_shape &sh = shapes[i];
@@ -119,6 +120,17 @@ int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, cons
     if (nrm) s->h.nrm.assign(nrm, nrm + (size_t) nv * 3); else s->h.nrm.clear();
     s->h.shapes.assign(shapes, shapes + ns); s->h.committed = false;
     return MI_OK;
+}
+int mi_scene_set_analytic(mi_scene *s, const mi_analytic *a, uint32_t n) {
+    if (!s || (n && !a)) return fail(MI_ERR_INVALID, "mi_scene_set_analytic: null argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (a[i].type > MI_SHAPE_CYLINDER) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_analytic: only rectangle, disk, sphere and cylinder are implemented");
+        if (a[i].type >= MI_SHAPE_SPHERE && !(a[i].radius > 0)) return fail(MI_ERR_INVALID, "Cannot create spheres of radius <= 0");      // sphere.cpp:130-131
+        if (a[i].type == MI_SHAPE_CYLINDER && !(a[i].length > 0)) return fail(MI_ERR_INVALID, "mi_scene_set_analytic: cylinder of length <= 0");
+        if (a[i].to_world[12] != 0 || a[i].to_world[13] != 0 || a[i].to_world[14] != 0 || a[i].to_world[15] != 1.0f)
+            return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_analytic: toWorld must be affine");
+    }
+    s->h.analytic.assign(a, a + n); s->h.committed = false; return MI_OK;
 }
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
@@ -167,7 +179,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -177,7 +189,7 @@ int SceneHost::upload(int dev) {
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
     int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
-              up(&dEmitters, emittersD) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
+              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
     if (g_sobolDims && logRes <= 16) {
@@ -191,7 +203,8 @@ int SceneHost::upload(int dev) {
     d.nodes = (const BvhNode *) dNodes; d.tris = (const TriAccelD *) dTris; d.shade = (const TriShade *) dShade; d.i2 = (const uint32_t *) dI2;
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
-    d.n_tris = (uint32_t) tris.size(); d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
+    d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
+    d.n_tris = nTris; d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
     d.emitter_norm = emitterNorm;
     for (int i = 0; i < 3; ++i) { d.aabb_lo[i] = aabbLo[i]; d.aabb_hi[i] = aabbHi[i]; }
     memcpy(d.s2c, s2c, 64); memcpy(d.c2w, c2w, 64);
@@ -210,10 +223,10 @@ int SceneHost::upload(int dev) {
     d.bvh_depth = (uint32_t) bvhDepthOf(nodes, 0);
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
-      d.small_tables = (tris.size() <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
+      d.small_tables = (nTris <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
     d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type == MI_BSDF_ROUGHCONDUCTOR) d.has_roughconductor = 1;
     const char *noPacket = getenv("MI355PT_NO_PACKET");
-    d.packet_n = (tris.size() <= MI_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;
+    d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     for (int i = 0; i < 3; ++i) d.packet_k[i] = packetK[i];
     committed = true;
     return 0;
@@ -224,15 +237,19 @@ extern "C" {
 
 int mi_scene_commit(mi_scene *s, uint32_t device) {
     if (!s) return fail(MI_ERR_INVALID, "mi_scene_commit: null scene");
-    if (s->h.idx.empty() || s->h.materials.empty() || !s->h.haveCamera || !s->h.haveFilm)
-        return fail(MI_ERR_INVALID, "mi_scene_commit: triangles, materials, camera and film must be set first");
+    if ((s->h.idx.empty() && s->h.analytic.empty()) || s->h.materials.empty() || !s->h.haveCamera || !s->h.haveFilm)
+        return fail(MI_ERR_INVALID, "mi_scene_commit: geometry (triangles and / or analytic shapes), materials, camera and film must be set first");
+    for (const mi_analytic &a : s->h.analytic) {
+        if (a.bsdf < 0 || (size_t) a.bsdf >= s->h.materials.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing material");
+        if (a.emitter >= (int32_t) s->h.emitters.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing emitter");
+    }
     for (const mi_shape &sh : s->h.shapes) {
         if (sh.bsdf < 0 || (size_t) sh.bsdf >= s->h.materials.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: shape refers to a missing material");
         if (sh.emitter >= (int32_t) s->h.emitters.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: shape refers to a missing emitter");
         if (!(sh.flags & 1u) && s->h.nrm.empty()) return fail(MI_ERR_INVALID, "mi_scene_commit: smooth-shaded mesh without vertex normals (pass faceNormals or normals)");
     }
     for (const mi_emitter &e : s->h.emitters) {
-        if (e.type == MI_EMITTER_AREA && (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size())) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
+        if (e.type == MI_EMITTER_AREA && (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size() + s->h.analytic.size())) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
         if (e.type == MI_EMITTER_ENVMAP && s->h.envRGB.empty()) return fail(MI_ERR_INVALID, "mi_scene_commit: envmap emitter listed but mi_scene_set_envmap was not called");
     }
     if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
@@ -369,7 +386,7 @@ static void mark(mi_render *r, int tag, size_t &used, hipStream_t st = nullptr) 
 static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed, int pool = 0) {
     const DScene &sc = r->scene->h.d; hipStream_t st = pool ? r->stream2 : r->stream; Queues &Q = pool ? r->q2 : r->q;
     (void) list;
-    if (sc.packet_n) r->k->packet(r->scene->h.packet.data(), (uint32_t) r->scene->h.packet.size(), st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
+    if (sc.packet_n) r->k->packet(r->scene->h.packet.data(), r->scene->h.packetK[2], r->scene->h.analyticD.data(), (uint32_t) r->scene->h.analyticD.size(), st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
     mark(r, 0, evUsed, st);
     r->k->generate(sc, r->rc, Q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
@@ -512,7 +529,7 @@ extern "C" {
 int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) {
     if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_intersect: bad argument");
     HIPCHK(hipSetDevice(s->h.device));
-    if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), (uint32_t) s->h.packet.size(), nullptr); HIPCHK(hipDeviceSynchronize()); }
+    if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), s->h.packetK[2], s->h.analyticD.data(), (uint32_t) s->h.analyticD.size(), nullptr); HIPCHK(hipDeviceSynchronize()); }
     return withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, nullptr); });
 }
 int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, uint64_t *outIdx, float *outVals) {

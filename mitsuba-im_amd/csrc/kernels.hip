@@ -47,7 +47,7 @@ DEV float safeInv(float d) { float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) 
 // of the workgroup's LDS stack (stride WG).  "while-while" shape: all lanes of a wave first descend through inner nodes until each
 // holds a leaf (or is done), then all test their leaf triangles -- the two code paths are not interleaved lane by lane.
 #define BVH_DONE 0x7FFFFFFF
-template <bool ANY>
+template <bool ANY, bool AN>
 DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk,
                   float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
     const v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
@@ -78,8 +78,10 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
                 f4 a = tris4[(first + i) * 3 + 0], b = tris4[(first + i) * 3 + 1], c = tris4[(first + i) * 3 + 2];
                 TriAccelD ta; ta.k = __float_as_uint(a.x); ta.n_u = a.y; ta.n_v = a.z; ta.n_d = a.w;
                 ta.a_u = b.x; ta.a_v = b.y; ta.b_nu = b.z; ta.b_nv = b.w; ta.c_nu = c.x; ta.c_nv = c.y; ta.prim = __float_as_uint(c.z);
-                float u, v, t;
-                if (triIntersect(ta, o, d, mint, best, u, v, t)) {
+                float u, v, t; bool ok;
+                if (AN && ta.k == MI_K_ANALYTIC) ok = analyticIntersect<ANY>(sc.analytic[ta.prim - sc.n_tris], o, d, mint, best, t, u, v);   // skdtree.h:292-301
+                else ok = triIntersect(ta, o, d, mint, best, u, v, t);
+                if (ok) {
                     if (ANY) return true;
                     if (!found || t < best || (t == best && ta.prim < bprim)) { best = t; bprim = ta.prim; bu = u; bv = v; found = true; }
                 }
@@ -97,6 +99,7 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
 // the records are sorted by projection axis k on the host and each axis gets its own loop (compile-time component selection, no
 // per-triangle branch); ties in t are broken towards the lower ORIGINAL triangle index, which keeps the result order independent.
 __constant__ TriAccelD c_packet[MI_PACKET_MAX];
+__constant__ AnalyticD c_analytic[MI_ANALYTIC_PACKET_MAX];   // analytic shapes of a packet-mode scene (wave-uniform records as well)
 template <int K> DEV bool triIntersectK(const TriAccelD &ta, v3 o, v3 d, float mint, float maxt, float &u, float &v, float &t) {
     const float o_u = K == 0 ? o.y : (K == 1 ? o.z : o.x), o_v = K == 0 ? o.z : (K == 1 ? o.x : o.y), o_k = K == 0 ? o.x : (K == 1 ? o.y : o.z);
     const float d_u = K == 0 ? d.y : (K == 1 ? d.z : d.x), d_v = K == 0 ? d.z : (K == 1 ? d.x : d.y), d_k = K == 0 ? d.x : (K == 1 ? d.y : d.z);
@@ -119,12 +122,21 @@ DEV bool packetLoop(uint32_t first, uint32_t last, v3 o, v3 d, float mint, float
     }
     return false;
 }
-template <bool ANY>
+template <bool ANY, bool AN>
 DEV bool packetIntersect(const DScene &sc, v3 o, v3 d, float mint, float maxt, float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
     float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
     if (packetLoop<ANY, 0>(0, sc.packet_k[0], o, d, mint, best, bprim, bu, bv, found)) return true;
     if (packetLoop<ANY, 1>(sc.packet_k[0], sc.packet_k[1], o, d, mint, best, bprim, bu, bv, found)) return true;
     if (packetLoop<ANY, 2>(sc.packet_k[1], sc.packet_k[2], o, d, mint, best, bprim, bu, bv, found)) return true;
+    if (AN) {
+        for (uint32_t i = 0; i < sc.n_analytic; ++i) {
+            float u, v, t; const uint32_t prim = sc.n_tris + i;
+            if (analyticIntersect<ANY>(c_analytic[i], o, d, mint, best, t, u, v)) {
+                if (ANY) return true;
+                if (!found || t < best || prim < bprim) { best = t; bprim = prim; bu = u; bv = v; found = true; }
+            }
+        }
+    }
     bestT = best; bestPrim = bprim; bestU = bu; bestV = bv;
     return found;
 }
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
 
 // ---------------------------------------------------------------------------------------------- extend
 // Scene::rayIntersect -> ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:112-142): closest hit (t, u, v, prim)
-template <int STACK>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth)
+template <int STACK, bool AN>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth); AN: the scene holds analytic shapes
 __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     const uint32_t tid = threadIdx.x;
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
         v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z);
         float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
         if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt)) {
-            if (STACK == 0) hit = packetIntersect<false>(sc, o, d, mint, maxt, t, prim, u, v);
-            else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+            if (STACK == 0) hit = packetIntersect<false, AN>(sc, o, d, mint, maxt, t, prim, u, v);
+            else hit = traverse<false, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
         }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
     }
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC, bool ENV, bool SMALL>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS
+template <bool RC, bool ENV, bool SMALL, bool AN>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN: analytic shapes present
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -254,7 +266,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             const uint32_t i = base + lane; int cls = 2;
             if (i < n) {
                 const uint32_t prim = __float_as_uint(q.hit[segBase + i].w);
-                cls = (prim != 0xFFFFFFFFu && (__float_as_uint(tb.shade4[prim * 6u + 2u].w) & 8u)) ? 1 : 0;
+                if (prim == 0xFFFFFFFFu) cls = 0;
+                else if (AN && prim >= sc.n_tris) cls = (sc.analytic[prim - sc.n_tris].flags & 8u) ? 1 : 0;
+                else cls = (__float_as_uint(tb.shade4[prim * 6u + 2u].w) & 8u) ? 1 : 0;
             }
             const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
             if (cls == 0) s_order[done0 + (uint32_t) __popcll(m0 & lt)] = (uint16_t) i;
@@ -293,11 +307,14 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     }
                     break;
                 }
-                Hit h; fillHit(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
+                Hit h; v3 ro3 = V(0, 0, 0);
+                if (AN) { float4 ro = q.rayO[buf][slot]; ro3 = V(ro.x, ro.y, ro.z); }      // analytic shapes: hit point = o + t d; sphere lights: reference point of pdfDirect
+                if (AN && prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], ro3, d, hr.x, hr.y, hr.z, h);
+                else fillHit(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
                 if (depth > 1) {
                     if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
                         v3 value = emitterEval(tb, h.emitter, h.ns, -d);
-                        float lumPdf = pdfEmitterDirect(sc, tb, h.emitter, d, h.ns, h.dist, facingRef);
+                        float lumPdf = pdfEmitterDirect<AN>(sc, tb, h.emitter, ro3, d, h.ns, h.dist, facingRef);
                         add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                     }
                     const int prevDepth = depth - 1;                         // rRec.depth++ >= m_rrDepth (path.cpp:276)
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;               // records.inl:160-164
                 if (!(h.flags & 4u)) {                                       // bsdf->getType() & BSDF::ESmooth
                     float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                    Direct dr; v3 value = sampleEmitterDirect<ENV>(sc, tb, h.p, refN, sx, sy, dr);
+                    Direct dr; v3 value = sampleEmitterDirect<ENV, AN>(sc, tb, h.p, refN, sx, sy, dr);
                     if (dr.pdf != 0) {
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 // ---------------------------------------------------------------------------------------------- shadow
 // Visibility test of Scene::sampleEmitterDirect (src/librender/scene.cpp:871-875 -> skdtree.cpp:207-226, any hit) and the
 // deferred `Li += throughput * value * bsdfVal * weight` (path.cpp:196)
-template <int STACK>
+template <int STACK, bool AN>
 __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     const uint32_t tid = threadIdx.x;
@@ -384,8 +401,8 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
         v3 o = V(so.x, so.y, so.z), d = V(sd.x, sd.y, sd.z);
         float mint, maxt, t, u, v; uint32_t prim; bool occluded = false;
         if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt)) {
-            if (STACK == 0) occluded = packetIntersect<true>(sc, o, d, mint, maxt, t, prim, u, v);
-            else occluded = traverse<true>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+            if (STACK == 0) occluded = packetIntersect<true, AN>(sc, o, d, mint, maxt, t, prim, u, v);
+            else occluded = traverse<true, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
         }
         if (!occluded) {
             float4 c = q.shC[segBase + i]; const uint32_t pid = __float_as_uint(sd.w);
@@ -473,9 +490,9 @@ __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *
     v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
     if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
-        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true>(sc, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false>(sc, o, d, mint, maxt, t, prim, u, v); }
-        else if (anyHit) hit = traverse<true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
-        else hit = traverse<false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
+        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true, true>(sc, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false, true>(sc, o, d, mint, maxt, t, prim, u, v); }
+        else if (anyHit) hit = traverse<true, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
+        else hit = traverse<false, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
     }
     out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
 }
@@ -499,12 +516,17 @@ using namespace MI_NS;
 // ---------------------------------------------------------------------------------------------- launch wrappers (used by api.cpp)
 extern "C" {
 void MI_FN(mi_launch_generate)(const DScene &sc, const RenderConst &rc, const Queues &q, const BatchDesc &bd, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(WG), 0, st, sc, rc, q, bd); }
-void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, hipStream_t st) { (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_packet), tris, n * sizeof(TriAccelD), 0, hipMemcpyHostToDevice, st); }
+void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, const AnalyticD *an, uint32_t na, hipStream_t st) {
+    if (n) (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_packet), tris, n * sizeof(TriAccelD), 0, hipMemcpyHostToDevice, st);
+    if (na) (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_analytic), an, na * sizeof(AnalyticD), 0, hipMemcpyHostToDevice, st);
+}
+#define MI_BY_STACK(KERNEL, AN, ...) do { \
+    if (sc.packet_n) hipLaunchKernelGGL((KERNEL<0, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 8) hipLaunchKernelGGL((KERNEL<8, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((KERNEL<16, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
 void MI_FN(mi_launch_extend)(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
-    if (sc.packet_n) hipLaunchKernelGGL(k_extend<0>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
-    else if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_extend<8>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_extend<16>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
-    else hipLaunchKernelGGL(k_extend<STACK_DEPTH>, dim3(grid), dim3(WG), 0, st, sc, q, buf);
+    if (sc.n_analytic) MI_BY_STACK(k_extend, true, sc, q, buf); else MI_BY_STACK(k_extend, false, sc, q, buf);
 }
 void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
@@ -512,17 +534,16 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
     RenderConst rcl = rc; rcl.order_offset_words = 0;
     if (sc.has_roughconductor && q.cap <= 8192u) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 * (WG / 64) + 16; }
-#define MI_SHADE(RC, ENV, SM) hipLaunchKernelGGL((k_shade<RC, ENV, SM>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf)
+#define MI_SHADE(RC, ENV, SM) do { if (sc.n_analytic) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
+                                   else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); } while (0)
     if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
     else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }
 #undef MI_SHADE
 }
 void MI_FN(mi_launch_shadow)(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
-    if (sc.packet_n) hipLaunchKernelGGL(k_shadow<0>, dim3(grid), dim3(WG), 0, st, sc, q);
-    else if (sc.bvh_depth <= 8) hipLaunchKernelGGL(k_shadow<8>, dim3(grid), dim3(WG), 0, st, sc, q);
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL(k_shadow<16>, dim3(grid), dim3(WG), 0, st, sc, q);
-    else hipLaunchKernelGGL(k_shadow<STACK_DEPTH>, dim3(grid), dim3(WG), 0, st, sc, q);
+    if (sc.n_analytic) MI_BY_STACK(k_shadow, true, sc, q); else MI_BY_STACK(k_shadow, false, sc, q);
 }
+#undef MI_BY_STACK
 void MI_FN(mi_launch_film)(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
 #ifndef MI_FAST_MATH
 void mi_launch_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout, hipStream_t st) {

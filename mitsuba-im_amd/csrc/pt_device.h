@@ -83,7 +83,7 @@ template <bool L> DEV EmitterD loadEmitter(const Tabs<L> &t, int id) {
     f4 a = t.emitters4[id * 3 + 0], b = t.emitters4[id * 3 + 1], c = t.emitters4[id * 3 + 2];
     EmitterD e; e.radiance[0] = a.x; e.radiance[1] = a.y; e.radiance[2] = a.z; e.weight = a.w;
     e.first_tri = __float_as_uint(b.x); e.tri_count = __float_as_uint(b.y); e.cdf_offset = __float_as_uint(b.z); e.inv_area = b.w;
-    e.type = __float_as_uint(c.x); e.shape = __float_as_int(c.y);
+    e.type = __float_as_uint(c.x); e.shape = __float_as_int(c.y); e.analytic = __float_as_int(c.z);
     return e;
 }
 // src/samplers/sobolseq.h:99-131 look_up, scramble 0; vdc / vdcInv = row (m-1) of the tables
@@ -239,6 +239,196 @@ DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t pr
 }
 DEV v3 toWorld(const Hit &h, v3 w) { return (h.s * w.x + h.t * w.y) + h.ns * w.z; }
 DEV v3 toLocal(const Hit &h, v3 w) { return V(dot(w, h.s), dot(w, h.t), dot(w, h.ns)); }
+
+// ---------------------------------------------------------------------------------------------- analytic shapes
+// Non-triangle primitives behind Scene::rayIntersect (kd-tree leaf redirect include/mitsuba/render/skdtree.h:292-301, :330-333, record
+// fill :421-427): src/shapes/rectangle.cpp, disk.cpp, sphere.cpp, cylinder.cpp.  The quadrics are solved in double precision like
+// the reference (solveQuadraticDouble, src/libcore/util.cpp:489-527).
+// include/mitsuba/core/transform.h:126-135 transformAffine(Point), :172-181 operator()(Vector), :199-207 operator()(Normal); m = rows 0..2 of the 4x4
+DEV v3 xfPoint(const float *m, v3 p) { return V(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]); }
+DEV v3 xfVector(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
+DEV v3 xfNormal(const float *inv, v3 n) { return V(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
+// sin / cos of 2*pi*u, u in [0, 1]: quadrant reduction + the polynomial pair (the reference calls sincosf(2*pi*u); arithmetic contract)
+DEV void sincos2pi(float u, float &sn, float &cs) {
+    float k = floorf(u * 4.0f + 0.5f);
+    float a = (u - k * 0.25f) * (2.0f * MI_PI);
+    float sa = sinp(a), ca = cosp(a);
+    int q = ((int) k) & 3;
+    sn = q == 0 ? sa : (q == 1 ? ca : (q == 2 ? -sa : -ca));
+    cs = q == 0 ? ca : (q == 1 ? -sa : (q == 2 ? -ca : sa));
+}
+DEV bool solveQuadraticDouble(double a, double b, double c, double &x0, double &x1) {
+    if (a == 0) { if (b != 0) { x0 = x1 = -c / b; return true; } return false; }
+    double discrim = b * b - 4.0 * a * c;
+    if (discrim < 0) return false;
+    double temp, sqrtDiscrim = sqrt(discrim);
+    if (b < 0) temp = -0.5 * (b - sqrtDiscrim); else temp = -0.5 * (b + sqrtDiscrim);
+    x0 = temp / a; x1 = c / temp;
+    if (x0 > x1) { double t = x0; x0 = x1; x1 = t; }
+    return true;
+}
+DEV bool solveQuadratic(float a, float b, float c, float &x0, float &x1) {          // util.cpp:449-487
+    if (a == 0) { if (b != 0) { x0 = x1 = -c / b; return true; } return false; }
+    float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return false;
+    float temp, sqrtDiscrim = sqrtf(discrim);
+    if (b < 0) temp = -0.5f * (b - sqrtDiscrim); else temp = -0.5f * (b + sqrtDiscrim);
+    x0 = temp / a; x1 = c / temp;
+    if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+    return true;
+}
+DEV void coordinateSystem(v3 a, v3 &b, v3 &c) {                                     // util.cpp:594-603
+    if (fabsf(a.x) > fabsf(a.y)) { float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z); c = V(a.z * invLen, 0.0f, -a.x * invLen); }
+    else { float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z); c = V(0.0f, a.z * invLen, -a.y * invLen); }
+    b = cross(c, a);
+}
+// Shape::rayIntersect: rectangle.cpp:125-148, disk.cpp:141-165, sphere.cpp:148-174, cylinder.cpp:128-166; ANY selects the shadow-ray
+// overloads (sphere.cpp:176-194, cylinder.cpp:168-201).  u, v = the temp data (local x, y) of rectangle / disk.
+template <bool ANY>
+DEV bool analyticIntersect(const AnalyticD &sh, v3 o, v3 d, float mint, float maxt, float &t, float &u, float &v) {
+    const uint32_t type = sh.type;
+    if (type == MI_SHAPE_RECTANGLE || type == MI_SHAPE_DISK) {
+        v3 ro = xfPoint(sh.to_object, o), rd = xfVector(sh.to_object, d);
+        float hit = -ro.z / rd.z;
+        if (!(hit >= mint && hit <= maxt)) return false;
+        float lx = ro.x + hit * rd.x, ly = ro.y + hit * rd.y;
+        if (type == MI_SHAPE_RECTANGLE ? (fabsf(lx) <= 1 && fabsf(ly) <= 1) : (lx * lx + ly * ly <= 1)) { t = hit; u = lx; v = ly; return true; }
+        return false;
+    }
+    double nearT, farT;
+    if (type == MI_SHAPE_SPHERE) {
+        double ox = (double) o.x - (double) sh.center[0], oy = (double) o.y - (double) sh.center[1], oz = (double) o.z - (double) sh.center[2];
+        double dx = d.x, dy = d.y, dz = d.z;
+        double A = dx * dx + dy * dy + dz * dz, B = 2 * (ox * dx + oy * dy + oz * dz), C = (ox * ox + oy * oy + oz * oz) - (double) (sh.radius * sh.radius);
+        if (!solveQuadraticDouble(A, B, C, nearT, farT)) return false;
+        if (ANY) {
+            if (nearT > maxt || farT < mint) return false;
+            if (nearT < mint && farT > maxt) return false;
+            t = 0; return true;
+        }
+        if (!(nearT <= maxt && farT >= mint)) return false;
+        if (nearT < mint) { if (farT > maxt) return false; t = (float) farT; } else t = (float) nearT;
+        u = 0; v = 0; return true;
+    }
+    v3 ro = xfPoint(sh.to_object, o), rd = xfVector(sh.to_object, d);
+    double ox = ro.x, oy = ro.y, dx = rd.x, dy = rd.y;
+    double A = dx * dx + dy * dy, B = 2 * (dx * ox + dy * oy), C = ox * ox + oy * oy - (double) (sh.radius * sh.radius);
+    if (!solveQuadraticDouble(A, B, C, nearT, farT)) return false;
+    if (ANY) { if (nearT > maxt || farT < mint) return false; }
+    else if (!(nearT <= maxt && farT >= mint)) return false;
+    double zPosNear = (double) ro.z + (double) rd.z * nearT, zPosFar = (double) ro.z + (double) rd.z * farT;
+    if (zPosNear >= 0 && zPosNear <= sh.length && nearT >= mint) t = (float) nearT;
+    else if (zPosFar >= 0 && zPosFar <= sh.length) { if (farT > maxt) return false; t = (float) farT; }
+    else return false;
+    u = 0; v = 0; return true;
+}
+// Shape::fillIntersectionRecord (rectangle.cpp:155-168, disk.cpp:172-200, sphere.cpp:196-245, cylinder.cpp:203-233) + computeShadingFrame
+// + wi (skdtree.h:421-427).  Disk: the reference leaves geoFrame unset; defined as the shading normal.
+DEV void fillHitAnalytic(const AnalyticD &sh, v3 o, v3 d, float t, float lx, float ly, Hit &h) {
+    h.material = sh.material; h.emitter = sh.emitter; h.flags = sh.flags & 14u; h.dist = t;
+    v3 p = o + d * t, n, dpdu;
+    const uint32_t type = sh.type;
+    if (type == MI_SHAPE_RECTANGLE) { n = ld3(sh.n); dpdu = ld3(sh.dpdu); }
+    else if (type == MI_SHAPE_DISK) {
+        float r = sqrtf(lx * lx + ly * ly), invR = (r == 0) ? 0.0f : (1.0f / r);
+        float cosPhi = lx * invR, sinPhi = ly * invR;
+        dpdu = r != 0 ? xfVector(sh.to_world, V(cosPhi, sinPhi, 0)) : xfVector(sh.to_world, V(1, 0, 0));
+        n = ld3(sh.n);
+    } else if (type == MI_SHAPE_SPHERE) {
+        const v3 c = ld3(sh.center);
+        p = c + normalize(p - c) * sh.radius;
+        v3 local = xfVector(sh.to_object, p - c);
+        dpdu = xfVector(sh.to_world, V(-local.y, local.x, 0) * (2 * MI_PI));
+        n = normalize(p - c);
+        if (sh.flags & 1u) n = n * -1.0f;
+    } else {
+        v3 local = xfPoint(sh.to_object, p);
+        dpdu = xfVector(sh.to_world, V(-local.y, local.x, 0) * (2 * MI_PI));
+        v3 dpdv = xfVector(sh.to_world, V(0, 0, sh.length));
+        n = cross(normalize(dpdu), normalize(dpdv));
+        p = p + n * (sh.radius - sqrtf(local.x * local.x + local.y * local.y));
+        if (sh.flags & 1u) n = n * -1.0f;
+    }
+    h.p = p; h.ng = n; h.ns = n;
+    h.s = normalize(dpdu - n * dot(n, dpdu));
+    h.t = cross(n, h.s);
+    v3 md = -d;
+    h.wi = V(dot(md, h.s), dot(md, h.t), dot(md, h.ns));
+}
+// warp.cpp:25-31 squareToUniformSphere, :54-63 squareToUniformCone
+DEV v3 uniformSphere(float sx, float sy) {
+    float z = 1.0f - 2.0f * sy, r = sqrtf(maxf(1.0f - z * z, 0.0f)), sinPhi, cosPhi;
+    sincos2pi(sx, sinPhi, cosPhi);
+    return V(r * cosPhi, r * sinPhi, z);
+}
+DEV v3 uniformCone(float cosCutoff, float sx, float sy) {
+    float cosTheta = (1 - sx) + sx * cosCutoff, sinTheta = sqrtf(maxf(1.0f - cosTheta * cosTheta, 0.0f)), sinPhi, cosPhi;
+    sincos2pi(sy, sinPhi, cosPhi);
+    return V(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+}
+// Shape::sampleDirect (src/librender/shape.cpp:102-115) over samplePosition of rectangle (rectangle.cpp:215-221), disk (disk.cpp:252-260),
+// cylinder (cylinder.cpp:235-250); Sphere::sampleDirect (sphere.cpp:275-346).  pdf = solid-angle density.
+DEV void analyticSampleDirect(const AnalyticD &sh, v3 ref, float sx, float sy, v3 &p, v3 &n, v3 &dOut, float &dist, float &pdf) {
+    const uint32_t type = sh.type;
+    if (type == MI_SHAPE_SPHERE) {
+        const float radius = sh.radius; const v3 center = ld3(sh.center);
+        v3 refToCenter = center - ref;
+        float refDist2 = dot(refToCenter, refToCenter), invRefDist = 1.0f / sqrtf(refDist2);
+        float sinAlpha = radius * invRefDist;
+        if (sinAlpha < 1 - MI_EPSILON) {
+            float cosAlpha = sqrtf(maxf(1.0f - sinAlpha * sinAlpha, 0.0f));
+            v3 fn = refToCenter * invRefDist, fs, ft; coordinateSystem(fn, fs, ft);
+            v3 c = uniformCone(cosAlpha, sx, sy);
+            v3 d = (fs * c.x + ft * c.y) + fn * c.z;
+            pdf = (0.5f * MI_INV_PI) / (1 - cosAlpha);
+            float projDist = dot(refToCenter, d);
+            float baseT = refDist2 / projDist;
+            v3 query = ref + d * baseT;
+            v3 queryToCenter = center - query;
+            float queryDist2 = dot(queryToCenter, queryToCenter), queryProjDist = dot(queryToCenter, d);
+            float A = 1.0f, B = -2 * queryProjDist, C = queryDist2 - radius * radius, nearT, farT;
+            if (!solveQuadratic(A, B, C, nearT, farT)) nearT = queryProjDist;
+            dist = baseT + nearT;
+            n = normalize(d * nearT - queryToCenter);
+            p = center + n * radius;
+            dOut = d;
+        } else {
+            v3 dl = uniformSphere(sx, sy);
+            p = center + dl * radius; n = dl;
+            v3 d = p - ref;
+            float dist2 = dot(d, d); dist = sqrtf(dist2);
+            { float r = 1.0f / dist; d = d * r; }
+            dOut = d;
+            pdf = sh.inv_area * dist2 / fabsf(dot(d, n));
+        }
+        if (sh.flags & 1u) n = n * -1.0f;
+        return;
+    }
+    if (type == MI_SHAPE_RECTANGLE) { p = xfPoint(sh.to_world, V(sx * 2 - 1, sy * 2 - 1, 0)); n = ld3(sh.n); }
+    else if (type == MI_SHAPE_DISK) { float px, py; diskConcentric(sx, sy, px, py); p = xfPoint(sh.to_world, V(px, py, 0)); n = ld3(sh.n); }
+    else {
+        float sinTheta, cosTheta; sincos2pi(sy, sinTheta, cosTheta);
+        v3 pl = V(cosTheta * sh.radius, sinTheta * sh.radius, sx * sh.length), nl = V(cosTheta, sinTheta, 0.0f);
+        if (sh.flags & 1u) nl = nl * -1.0f;
+        p = xfPoint(sh.to_world, pl); n = normalize(xfNormal(sh.to_object, nl));
+    }
+    v3 d = p - ref;
+    float distSquared = dot(d, d); dist = sqrtf(distSquared);
+    { float r = 1.0f / dist; d = d * r; }
+    float dp = fabsf(dot(d, n));
+    pdf = sh.inv_area * (dp != 0 ? (distSquared / dp) : 0.0f);
+    dOut = d;
+}
+// Shape::pdfDirect, ESolidAngle (shape.cpp:117-126); Sphere::pdfDirect (sphere.cpp:348-379)
+DEV float analyticPdfDirect(const AnalyticD &sh, v3 ref, v3 d, v3 n, float dist) {
+    if (sh.type == MI_SHAPE_SPHERE) {
+        v3 refToCenter = ld3(sh.center) - ref;
+        float invRefDist = 1.0f / sqrtf(dot(refToCenter, refToCenter)), sinAlpha = sh.radius * invRefDist;
+        if (sinAlpha < 1 - MI_EPSILON) { float cosAlpha = sqrtf(maxf(1 - sinAlpha * sinAlpha, 0.0f)); return (0.5f * MI_INV_PI) / (1 - cosAlpha); }
+        return sh.inv_area * dist * dist / fabsf(dot(d, n));
+    }
+    return sh.inv_area * (dist * dist) / fabsf(dot(d, n));
+}
 
 // ---------------------------------------------------------------------------------------------- rough conductor
 // src/bsdfs/roughconductor.cpp:260-416 over src/bsdfs/microfacet.h (isotropic alpha, Beckmann / GGX, visible-normal sampling).
@@ -535,7 +725,7 @@ DEV v3 emitterEval(const Tabs<L> &tb, int e, v3 ns, v3 d) {
 // Scene::sampleEmitterDirect (src/librender/scene.cpp:860-884) without the visibility test (the shadow queue does it)
 // -> AreaLight::sampleDirect (src/emitters/area.cpp:160-176) -> Shape::sampleDirect (src/librender/shape.cpp:102-115)
 // -> TriMesh::samplePosition (src/librender/trimesh.cpp:413-425) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
-template <bool ENV, bool L>
+template <bool ENV, bool AN, bool L>
 DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
     uint32_t ei = cdfSample(tb.emitter_cdf, sc.n_emitters, sx);
     float c0 = tb.emitter_cdf[ei], c1 = tb.emitter_cdf[ei + 1];
@@ -553,6 +743,9 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
         { float r = 1.0f / emPdf; value = value * r; }
         return value;
     }
+    if (AN && em.analytic >= 0) {                                // area light on an analytic shape: no sample reuse
+        analyticSampleDirect(sc.analytic[em.analytic], ref, sx, sy, dr.p, dr.n, dr.d, dr.dist, dr.pdf);
+    } else {
     typename AS<L>::pf acdf = tb.area_cdf + em.cdf_offset;
     uint32_t ti = cdfSample(acdf, em.tri_count, sy);
     float a0 = acdf[ti], a1 = acdf[ti + 1];
@@ -577,6 +770,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
     { float r = 1.0f / dr.dist; dr.d = dr.d * r; }
     float dp = fabsf(dot(dr.d, dr.n));
     dr.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    }
     v3 value;
     if (dot(dr.d, refN) >= 0 && dot(dr.d, dr.n) < 0 && dr.pdf != 0) {
         float r = 1.0f / dr.pdf; value = V(em.radiance[0] * r, em.radiance[1] * r, em.radiance[2] * r);
@@ -591,12 +785,15 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
 }
 // Scene::pdfEmitterDirect (scene.cpp:981-984) -> AreaLight::pdfDirect (area.cpp:178-184) -> Shape::pdfDirect (shape.cpp:117-126);
 // `facingRef` = (dot(d, refN) >= 0) evaluated where refN was still known (the previous vertex)
-template <bool L>
-DEV float pdfEmitterDirect(const DScene &sc, const Tabs<L> &tb, int e, v3 d, v3 n, float dist, bool facingRef) {
+template <bool AN, bool L>
+DEV float pdfEmitterDirect(const DScene &sc, const Tabs<L> &tb, int e, v3 ref, v3 d, v3 n, float dist, bool facingRef) {
     f4 a = tb.emitters4[e * 3], b = tb.emitters4[e * 3 + 1];     // a.w = weight, b.w = inv_area
     float pdf;
-    if (facingRef && dot(d, n) < 0) pdf = b.w * (dist * dist) / fabsf(dot(d, n));
-    else pdf = 0.0f;
+    if (facingRef && dot(d, n) < 0) {
+        int an = AN ? __float_as_int(tb.emitters4[e * 3 + 2].z) : -1;
+        if (AN && an >= 0) pdf = analyticPdfDirect(sc.analytic[an], ref, d, n, dist);
+        else pdf = b.w * (dist * dist) / fabsf(dot(d, n));
+    } else pdf = 0.0f;
     return pdf * (a.w * sc.emitter_norm);
 }
 DEV float miWeight(float a, float b) { a *= a; b *= b; return a / (a + b); }   // src/integrators/path/path.cpp:296-300

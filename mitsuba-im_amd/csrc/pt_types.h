@@ -45,13 +45,32 @@ struct MaterialD {                        // 64 B
 struct EmitterD {                         // 48 B
     float radiance[3]; float weight;
     uint32_t first_tri, tri_count, cdf_offset; float inv_area;
-    uint32_t type; int32_t shape; uint32_t pad[2];
+    uint32_t type; int32_t shape; int32_t analytic; uint32_t pad;   // analytic >= 0: area light on analytic shape `analytic` (no triangle CDF)
+};
+
+// Analytic shape (reference src/shapes/{rectangle,disk,sphere,cylinder}.cpp), 160 B = ten 16-B loads.  Primitive index of the i-th
+// analytic shape = n_tris + i; in BVH leaves it appears as a TriAccelD record with k = MI_K_ANALYTIC and prim = that index
+// (the reference marks such records with k = KNoTriangleFlag, include/mitsuba/render/skdtree.h:292-301).
+#define MI_SHAPE_RECTANGLE 0
+#define MI_SHAPE_DISK 1
+#define MI_SHAPE_SPHERE 2
+#define MI_SHAPE_CYLINDER 3
+#define MI_K_ANALYTIC 4u
+#define MI_ANALYTIC_PACKET_MAX 16
+struct AnalyticD {
+    float to_world[12];                   // rows 0..2 of objectToWorld
+    float to_object[12];                  // rows 0..2 of worldToObject
+    float n[3]; uint32_t type;            // rectangle / disk: world normal
+    float dpdu[3]; uint32_t flags;        // rectangle: dpdu; flags bit0 flipNormals, bit1 back side (twosided), bit2 BSDF without smooth component, bit3 rough conductor
+    float center[3]; float radius;        // sphere centre; sphere / cylinder radius
+    float length, inv_area; int32_t material, emitter;
 };
 
 // Everything a kernel needs to know about the scene; passed by value.
 struct DScene {
     const BvhNode *nodes; const TriAccelD *tris; const TriShade *shade; const uint32_t *i2; const float *nrm;
     const MaterialD *materials; const EmitterD *emitters; const float *emitter_cdf; const float *area_cdf;
+    const AnalyticD *analytic; uint32_t n_analytic, analytic_pad;
     uint32_t n_tris, n_nodes, n_emitters, n_materials;
     float emitter_norm;
     float aabb_lo[3], aabb_hi[3];         // kd-tree root box of the reference incl. its enlargement (gkdtree.h:1213-1220)

@@ -44,6 +44,61 @@ static void triaccelLoad(TriAccelD &ta, V3 A, V3 B, V3 C) {
     ta.c_nu = comp(c, v) / denom; ta.c_nv = -comp(c, u) / denom;
 }
 
+// Analytic shapes: derived constants + Shape::getAABB (rectangle.cpp:100-119, disk.cpp:100-130, sphere.cpp:127-142, cylinder.cpp:105-107, :256-276)
+static inline V3 xfPoint(const float *m, V3 p) { return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]); }
+static inline V3 xfVector(const float *m, V3 v) { return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
+static inline V3 xfNormal(const float *inv, V3 n) { return mk(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
+static inline float length3(V3 a) { return std::sqrt(dot(a, a)); }
+static void analyticPrepare(const mi_analytic &a, AnalyticD &d, V3 &lo, V3 &hi, V3 &tightLo, V3 &tightHi) {
+    const float inf = std::numeric_limits<float>::infinity();
+    std::memset(&d, 0, sizeof(d));
+    std::memcpy(d.to_world, a.to_world, 48); std::memcpy(d.to_object, a.to_object, 48);
+    d.type = a.type; d.radius = a.radius; d.length = a.length; d.material = a.bsdf; d.emitter = a.emitter;
+    const float *M = a.to_world;
+    lo = mk(inf, inf, inf); hi = mk(-inf, -inf, -inf);
+    auto expand = [&](V3 q) { lo = vmin(lo, q); hi = vmax(hi, q); };
+    V3 n = mk(0, 0, 0), dpdu = mk(0, 0, 0), center = mk(0, 0, 0);
+    switch (a.type) {
+    case MI_SHAPE_RECTANGLE: {
+        dpdu = xfVector(M, mk(2, 0, 0)); V3 dpdv = xfVector(M, mk(0, 2, 0));
+        n = normalize(xfNormal(a.to_object, mk(0, 0, 1)));
+        d.inv_area = 1.0f / (length3(dpdu) * length3(dpdv));
+        expand(xfPoint(M, mk(-1, -1, 0))); expand(xfPoint(M, mk(1, -1, 0))); expand(xfPoint(M, mk(1, 1, 0))); expand(xfPoint(M, mk(-1, 1, 0)));
+        tightLo = lo; tightHi = hi; break;
+    }
+    case MI_SHAPE_DISK: {
+        V3 du = xfVector(M, mk(1, 0, 0));
+        n = normalize(xfNormal(a.to_object, mk(0, 0, 1)));
+        d.inv_area = 1.0f / (MI_PI * length3(du) * length3(du));
+        expand(xfPoint(M, mk(1, 0, 0))); expand(xfPoint(M, mk(-1, 0, 0))); expand(xfPoint(M, mk(0, 1, 0))); expand(xfPoint(M, mk(0, -1, 0)));
+        // Disk::getAABB bounds four rim points only; the BVH needs the whole rim
+        V3 c = xfPoint(M, mk(0, 0, 0)); float r = length3(du);
+        tightLo = vmin(lo, c - mk(r, r, r)); tightHi = vmax(hi, c + mk(r, r, r)); break;
+    }
+    case MI_SHAPE_SPHERE: {
+        center = xfPoint(M, mk(0, 0, 0));
+        d.inv_area = 1 / (4 * MI_PI * a.radius * a.radius);
+        lo = center - mk(a.radius, a.radius, a.radius); hi = center + mk(a.radius, a.radius, a.radius);
+        tightLo = lo; tightHi = hi; break;
+    }
+    default: {
+        d.inv_area = 1 / (2 * MI_PI * a.radius * a.length);
+        V3 x1 = xfVector(M, mk(a.radius, 0, 0)), x2 = xfVector(M, mk(0, a.radius, 0));
+        V3 p0 = xfPoint(M, mk(0, 0, 0)), p1 = xfPoint(M, mk(0, 0, a.length));
+        float l[3], h[3];
+        for (int i = 0; i < 3; ++i) {
+            float range = std::sqrt(comp(x1, i) * comp(x1, i) + comp(x2, i) * comp(x2, i));
+            l[i] = std::min(std::min(inf, comp(p0, i) - range), comp(p1, i) - range);
+            h[i] = std::max(std::max(-inf, comp(p0, i) + range), comp(p1, i) + range);
+        }
+        lo = mk(l[0], l[1], l[2]); hi = mk(h[0], h[1], h[2]);
+        tightLo = lo; tightHi = hi; break;
+    }
+    }
+    d.n[0] = n.x; d.n[1] = n.y; d.n[2] = n.z; d.dpdu[0] = dpdu.x; d.dpdu[1] = dpdu.y; d.dpdu[2] = dpdu.z;
+    d.center[0] = center.x; d.center[1] = center.y; d.center[2] = center.z;
+}
+
 struct BuildNode { V3 lo, hi; int left = -1, right = -1, first = 0, count = 0; };
 struct Builder {
     std::vector<BuildNode> nodes; std::vector<uint32_t> order; const std::vector<V3> *tlo, *thi, *cen;
@@ -94,14 +149,22 @@ struct Builder {
 static inline int32_t leafCode(int first, int count) { return ~(int32_t) (first * 8 + (count - 1)); }
 
 void SceneHost::commitHost() {
-    const uint32_t nt = (uint32_t) (idx.size() / 3);
+    const uint32_t nt = (uint32_t) (idx.size() / 3), na = (uint32_t) analytic.size(), np = nt + na;
+    nTris = nt;
     auto vert = [&](uint32_t i) { return mk(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]); };
     triShape.assign(nt, 0);
     for (uint32_t si = 0; si < shapes.size(); ++si) for (uint32_t t = 0; t < shapes[si].tri_count; ++t) triShape[shapes[si].first_tri + t] = si;
 
     // --- triangle records
     std::vector<TriAccelD> accel(nt); shade.assign(nt, TriShade{}); i2.assign(nt, 0);
-    std::vector<V3> tlo(nt), thi(nt), cen(nt);
+    std::vector<V3> tlo(np), thi(np), cen(np);
+    auto materialFlags = [&](int bsdf) {
+        const mi_material &mat = materials[bsdf];
+        bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0;
+        // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176)
+        bool smooth = mat.type != MI_BSDF_DIFFUSE || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0;
+        return (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type == MI_BSDF_ROUGHCONDUCTOR ? 8u : 0u);
+    };
     for (uint32_t t = 0; t < nt; ++t) {
         uint32_t a = idx[t * 3], b = idx[t * 3 + 1], c = idx[t * 3 + 2];
         V3 p0 = vert(a), p1 = vert(b), p2 = vert(c);
@@ -111,11 +174,7 @@ void SceneHost::commitHost() {
         ts.p0[0] = p0.x; ts.p0[1] = p0.y; ts.p0[2] = p0.z; ts.p1[0] = p1.x; ts.p1[1] = p1.y; ts.p1[2] = p1.z; ts.p2[0] = p2.x; ts.p2[1] = p2.y; ts.p2[2] = p2.z;
         ts.material = sh.bsdf; ts.emitter = sh.emitter;
         bool faceN = (sh.flags & 1u) || nrm.empty();
-        bool backside = (materials[sh.bsdf].flags & MI_BSDF_FLAG_TWOSIDED) != 0;
-        // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176)
-        const mi_material &mat = materials[sh.bsdf];
-        bool smooth = mat.type != MI_BSDF_DIFFUSE || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0;
-        ts.flags = (faceN ? 1u : 0u) | (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type == MI_BSDF_ROUGHCONDUCTOR ? 8u : 0u);
+        ts.flags = (faceN ? 1u : 0u) | materialFlags(sh.bsdf);
         ts.local_prim = t - sh.first_tri; ts.i0 = a; ts.i1 = b; i2[t] = c;
         // face frame: skdtree.h:367-371 (face normal), util.cpp:605-610 (computeShadingFrame with dpdu = p1 - p0)
         V3 side1 = p1 - p0, side2 = p2 - p0, fn = cross(side1, side2);
@@ -129,21 +188,33 @@ void SceneHost::commitHost() {
         float pad = 1e-4f * std::max(std::max(e.x, e.y), e.z) + 2e-5f * mag + 1e-7f;
         tlo[t] = lo - mk(pad, pad, pad); thi[t] = hi + mk(pad, pad, pad); cen[t] = (lo + hi) * 0.5f;
     }
-    // --- scene box = union of mesh AABBs, enlarged like the kd-tree root (gkdtree.h:1213-1220)
+    // --- analytic shapes: device records, boxes
+    analyticD.assign(na, AnalyticD{});
+    std::vector<V3> alo(na), ahi(na);
+    for (uint32_t i = 0; i < na; ++i) {
+        V3 tl, th; analyticPrepare(analytic[i], analyticD[i], alo[i], ahi[i], tl, th);
+        analyticD[i].flags = (analytic[i].flags & 1u) | materialFlags(analytic[i].bsdf);
+        V3 e = th - tl; float mag = std::max(std::max(std::fabs(tl.x) + std::fabs(th.x), std::fabs(tl.y) + std::fabs(th.y)), std::fabs(tl.z) + std::fabs(th.z));
+        float pad = 1e-4f * std::max(std::max(e.x, e.y), e.z) + 2e-5f * mag + 1e-7f;
+        tlo[nt + i] = tl - mk(pad, pad, pad); thi[nt + i] = th + mk(pad, pad, pad); cen[nt + i] = (tl + th) * 0.5f;
+        TriAccelD rec{}; rec.k = MI_K_ANALYTIC; rec.prim = nt + i; accel.push_back(rec);
+    }
+    // --- scene box = union of the shape AABBs (ShapeKDTree::addShape, skdtree.cpp:68-77), enlarged like the kd-tree root (gkdtree.h:1213-1220)
     {
         const float inf = std::numeric_limits<float>::infinity();
         V3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf);
         for (const mi_shape &sh : shapes) for (uint32_t v = 0; v < sh.vert_count; ++v) { V3 p = vert(sh.first_vert + v); lo = vmin(lo, p); hi = vmax(hi, p); }
+        for (uint32_t i = 0; i < na; ++i) { lo = vmin(lo, alo[i]); hi = vmax(hi, ahi[i]); }
         const float eps = 1e-3f;
         V3 e1 = hi - lo; lo = lo - mk(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps);
         V3 e2 = hi - lo; hi = hi + mk(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps);
         aabbLo[0] = lo.x; aabbLo[1] = lo.y; aabbLo[2] = lo.z; aabbHi[0] = hi.x; aabbHi[1] = hi.y; aabbHi[2] = hi.z;
     }
     // --- BVH
-    Builder bld; bld.order.resize(nt); for (uint32_t t = 0; t < nt; ++t) bld.order[t] = t;
-    bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.nodes.reserve(2 * nt + 2);
-    int root = nt ? bld.build(0, (int) nt, 0) : -1;
-    tris.resize(nt); for (uint32_t i = 0; i < nt; ++i) tris[i] = accel[bld.order[i]];
+    Builder bld; bld.order.resize(np); for (uint32_t t = 0; t < np; ++t) bld.order[t] = t;
+    bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.nodes.reserve(2 * np + 2);
+    int root = np ? bld.build(0, (int) np, 0) : -1;
+    tris.resize(np); for (uint32_t i = 0; i < np; ++i) tris[i] = accel[bld.order[i]];
     // packet mode: records sorted by projection axis (stable: original order inside an axis); degenerate triangles (k = 3) never hit -> dropped
     packet.clear(); packetK[0] = packetK[1] = packetK[2] = 0;
     for (uint32_t axis = 0; axis < 3; ++axis) { for (const TriAccelD &ta : accel) if (ta.k == axis) packet.push_back(ta); packetK[axis] = (uint32_t) packet.size(); }
@@ -178,7 +249,11 @@ void SceneHost::commitHost() {
         EmitterD &d = emittersD[e]; const mi_emitter &src = emitters[e];
         d.radiance[0] = src.radiance[0]; d.radiance[1] = src.radiance[1]; d.radiance[2] = src.radiance[2]; d.weight = src.weight;
         d.type = src.type; d.shape = src.shape;
+        d.analytic = -1;
         if (src.type != MI_EMITTER_AREA) continue;
+        if ((size_t) src.shape >= shapes.size()) {               // area light on an analytic shape: no triangle CDF
+            d.analytic = src.shape - (int32_t) shapes.size(); d.inv_area = analyticD[d.analytic].inv_area; continue;
+        }
         const mi_shape &sh = shapes[src.shape];
         d.first_tri = sh.first_tri; d.tri_count = sh.tri_count; d.cdf_offset = (uint32_t) areaCdf.size();
         size_t base = areaCdf.size(); areaCdf.resize(base + sh.tri_count + 1); areaCdf[base] = 0.0f;

@@ -264,3 +264,53 @@ def test_integrator_switches(mi, oracle, golden_scenes, name):
     r.run(); film = r.read_film(0); ofilm, cnt = oracle.Oracle(sc).render_image(threads=4); st = r.stats()
     assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 3e-3
     assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 2e-3 and abs(st["path_length_sum"] - int(cnt[2])) / cnt[2] < 2e-3
+
+
+@pytest.mark.parametrize("name", ["cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_analytic_shapes(mi, oracle, golden_scenes, name, bvh, monkeypatch):
+    """rectangle / disk / sphere / cylinder behind rayIntersect, as geometry and as area lights (sphere: cone sampling),
+    in packet mode (records in constant memory) and through the BVH (k = analytic leaf records).  The quadrics are solved in double
+    precision on both sides and the cylinder / cone / sphere maps use the shared polynomial sin/cos, so everything that does not touch the
+    rough-conductor sphere is bit-exact against the oracle."""
+    if bvh:
+        monkeypatch.setenv("MI355PT_NO_PACKET", "1")
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    nt, ns = len(sc.idx), len(sc.shapes)
+    # closest hit / any hit for random rays
+    rng = np.random.default_rng(77); n = 3000
+    lo = np.array([min(sc.pos[:, k].min(), -6.0 if name == "shape_lights" else 0.0) for k in range(3)], np.float32); hi = -lo if name == "shape_lights" else sc.pos.max(0)
+    o = (lo + rng.random((n, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([o, np.full((n, 1), 1e-4, np.float32), d, np.full((n, 1), np.inf, np.float32)], 1).astype(np.float32)
+    rays[200:500, 7] = rng.random(300).astype(np.float32) * (4 if name == "shape_lights" else 300)
+    got = gs.intersect(rays); occ = gs.intersect(rays, any_hit=True); kinds = set()
+    for i in range(n):
+        ok, h = orc.intersect(rays[i])
+        assert ok == (got[i, 3] >= 0)
+        if ok:
+            assert (bits(got[i, :3]) == bits(np.array([h[0], h[13], h[14]], np.float32))).all()
+            shape = int(h[19]); prim = sc.shapes[shape]["first_tri"] + int(h[18]) if shape < ns else nt + shape - ns
+            assert int(got[i, 3]) == prim
+            kinds.add(-1 if shape < ns else sc.analytic[shape - ns]["type"])
+        assert orc.occluded(rays[i]) == (occ[i, 3] >= 0)
+    assert kinds >= ({-1, 0, 2, 3} if name != "cbox_shapes" else {-1, 0, 1, 2, 3})
+    # radiance samples: oracle (same arithmetic) and the reference's own Li
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); pairs = gd["pairs"]
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    if name == "shape_lights":
+        assert (bits(got) == bits(ref)).all()
+    else:
+        err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and (bits(got) == bits(ref)).all(1).mean() > 0.7
+    err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
+    assert (err < 1e-4).mean() > 0.99 and (err < 5e-3).mean() > 0.998 and np.median(err) < 1e-6
+    # whole film + the ray counters
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    rel = np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3])
+    if name == "shape_lights":
+        assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
+    else:
+        assert rel < 2e-3 and abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 3e-3
