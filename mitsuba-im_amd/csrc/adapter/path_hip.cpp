@@ -31,6 +31,7 @@ namespace {
 
 struct FlatScene {
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
+    std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes;
     bool anyNormals = false;
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16], envScale = 1.0f;
 };
@@ -78,11 +79,60 @@ static mi_material convertBSDF(const BSDF *bsdf) {
     return m;
 }
 
+/// Analytic shape -> mi_analytic.  The shapes keep their transforms private, so each record is rebuilt from the shape's Properties exactly
+/// as its constructor does (rectangle.cpp:80-85, disk.cpp:82-87, sphere.cpp:108-132, cylinder.cpp:83-107), with the reference's own Transform code.
+static bool convertAnalytic(const Shape *shape, mi_analytic &a) {
+    const std::string cls = shape->getClass()->getName(); const Properties &props = shape->getProperties();
+    memset(&a, 0, sizeof(a)); a.bsdf = -1; a.emitter = -1; a.radius = 1.0f; a.length = 1.0f;
+    Transform toWorld;
+    if (cls == "Rectangle") {
+        a.type = MI_SHAPE_RECTANGLE; toWorld = props.getTransform("toWorld", Transform());
+        if (props.getBoolean("flipNormals", false)) toWorld = toWorld * Transform::scale(Vector(1, 1, -1));
+    } else if (cls == "Disk") {
+        a.type = MI_SHAPE_DISK;
+        ref<const AnimatedTransform> at = props.getAnimatedTransform("toWorld", Transform());
+        if (!at->isStatic()) SLog(EError, "path_hip: animated transforms are not implemented");
+        toWorld = at->eval(0);
+        if (props.getBoolean("flipNormals", false)) toWorld = toWorld * Transform::scale(Vector(1, 1, -1));
+    } else if (cls == "Sphere") {
+        a.type = MI_SHAPE_SPHERE;
+        toWorld = Transform::translate(Vector(props.getPoint("center", Point(0.0f))));
+        Float radius = props.getFloat("radius", 1.0f);
+        if (props.hasProperty("toWorld")) {
+            Transform objectToWorld = props.getTransform("toWorld");
+            Float r = objectToWorld(Vector(1, 0, 0)).length();
+            toWorld = objectToWorld * Transform::scale(Vector(1 / r)) * toWorld;
+            radius *= r;
+        }
+        a.radius = radius; a.flags = props.getBoolean("flipNormals", false) ? MI_ANALYTIC_FLIP_NORMALS : 0u;
+    } else if (cls == "Cylinder") {
+        a.type = MI_SHAPE_CYLINDER;
+        Float radius = props.getFloat("radius", 1.0f);
+        Point p1 = props.getPoint("p0", Point(0.0f, 0.0f, 0.0f)), p2 = props.getPoint("p1", Point(0.0f, 0.0f, 1.0f));
+        Vector d = p2 - p1; Float length = d.length();
+        toWorld = Transform::translate(Vector(p1)) * Transform::fromFrame(Frame(d / length)) * Transform::scale(Vector(radius, radius, length));
+        if (props.hasProperty("toWorld")) toWorld = props.getTransform("toWorld") * toWorld;
+        a.radius = toWorld(Vector(1, 0, 0)).length(); a.length = toWorld(Vector(0, 0, 1)).length();
+        toWorld = toWorld * Transform::scale(Vector(1 / a.radius, 1 / a.radius, 1 / a.length));
+        a.flags = props.getBoolean("flipNormals", false) ? MI_ANALYTIC_FLIP_NORMALS : 0u;
+    } else return false;
+    const Matrix4x4 &m = toWorld.getMatrix(), &inv = toWorld.getInverseMatrix();
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a.to_world[i * 4 + j] = m(i, j); a.to_object[i * 4 + j] = inv(i, j); }
+    return true;
+}
+
 static void flatten(const Scene *scene, FlatScene &fs) {
     const std::vector<TriMesh *> &meshes = scene->getMeshes();
-    if (meshes.size() != scene->getShapes().size())
-        SLog(EError, "path_hip: the scene contains analytic shapes / instances; only triangle meshes are implemented (SURVEY.md §8f)");
     std::map<const BSDF *, int> bsdfIndex;
+    // non-mesh shapes: rectangle / disk / sphere / cylinder become analytic records (numbered after the meshes); anything else is refused
+    for (size_t si = 0; si < scene->getShapes().size(); ++si) {
+        const Shape *shape = scene->getShapes()[si].get();
+        if (shape->getClass()->derivesFrom(MTS_CLASS(TriMesh))) continue;
+        mi_analytic a;
+        if (!convertAnalytic(shape, a))
+            SLog(EError, "path_hip: shape \"%s\" is not implemented (triangle meshes, rectangle, disk, sphere, cylinder; no instances -- SURVEY.md §8f)", shape->getClass()->getName().c_str());
+        fs.analytic.push_back(a); fs.analyticShapes.push_back(shape);
+    }
     for (const TriMesh *mesh : meshes) fs.anyNormals |= mesh->getVertexNormals() != NULL;
     for (size_t mi = 0; mi < meshes.size(); ++mi) {
         const TriMesh *mesh = meshes[mi];
@@ -103,6 +153,12 @@ static void flatten(const Scene *scene, FlatScene &fs) {
         if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
         sh.bsdf = bsdfIndex[bsdf]; sh.emitter = -1;
         fs.shapes.push_back(sh);
+    }
+    for (size_t ai = 0; ai < fs.analytic.size(); ++ai) {
+        const BSDF *bsdf = fs.analyticShapes[ai]->getBSDF();
+        if (!bsdf) SLog(EError, "path_hip: analytic shape without a BSDF");
+        if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
+        fs.analytic[ai].bsdf = bsdfIndex[bsdf];
     }
     // emitters in Scene::getEmitters() order (the order the emitter PDF is built in, scene.cpp:383-388)
     const ref_vector<Emitter> &emitters = scene->getEmitters();
@@ -125,12 +181,15 @@ static void flatten(const Scene *scene, FlatScene &fs) {
             SLog(EError, "path_hip: emitter \"%s\" is neither an area light nor an envmap", em->getClass()->getName().c_str());
         const Shape *shape = em->getShape(); int shapeIdx = -1;
         for (size_t mi = 0; mi < meshes.size(); ++mi) if (meshes[mi] == shape) shapeIdx = (int) mi;
-        if (shapeIdx < 0) SLog(EError, "path_hip: area emitter without a triangle mesh");
+        for (size_t ai = 0; ai < fs.analyticShapes.size(); ++ai) if (fs.analyticShapes[ai] == shape) shapeIdx = (int) (meshes.size() + ai);
+        if (shapeIdx < 0) SLog(EError, "path_hip: area emitter without a supported shape");
         Intersection its; its.shFrame.n = Normal(0, 0, 1);
         Spectrum rad = em->eval(its, Vector(0, 0, 1)); Float r, g, b; rad.toLinearRGB(r, g, b);      // AreaLight::eval = radiance on the lit side (area.cpp:106-111)
         mi_emitter me; memset(&me, 0, sizeof(me));
         me.type = MI_EMITTER_AREA; me.shape = shapeIdx; me.radiance[0] = r; me.radiance[1] = g; me.radiance[2] = b; me.weight = em->getSamplingWeight();
-        fs.shapes[shapeIdx].emitter = (int32_t) fs.emitters.size(); fs.emitters.push_back(me);
+        if ((size_t) shapeIdx < meshes.size()) fs.shapes[shapeIdx].emitter = (int32_t) fs.emitters.size();
+        else fs.analytic[shapeIdx - meshes.size()].emitter = (int32_t) fs.emitters.size();
+        fs.emitters.push_back(me);
     }
 }
 
@@ -144,6 +203,7 @@ struct GpuScene {
         MI_CHECK(mi_scene_create(&scene));
         MI_CHECK(mi_scene_set_triangles(scene, fs.pos.data(), fs.anyNormals ? fs.nrm.data() : NULL, NULL, fs.idx.data(),
                                         (uint32_t) (fs.pos.size() / 3), (uint32_t) (fs.idx.size() / 3), fs.shapes.data(), (uint32_t) fs.shapes.size()));
+        if (!fs.analytic.empty()) MI_CHECK(mi_scene_set_analytic(scene, fs.analytic.data(), (uint32_t) fs.analytic.size()));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
         if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));
