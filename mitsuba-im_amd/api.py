@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
+LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(_HERE, "libmi355pt.so")   # MI355PT_LIB: A/B another build of the same library
 SOBOL_PATH = os.path.join(_HERE, "data", "sobol_tables.bin")
 
 

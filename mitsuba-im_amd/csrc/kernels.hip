@@ -278,15 +278,20 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     }
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
-        bool alive = false, wantShadow = false;
-        float4 nrO, nrD, nS1, shO, shD, shC; uint4 nS0; float nS2 = 0;
+        // Two phases per chunk, each closed by its own wave64 ballot, so that the 12 registers of a shadow record are written out before
+        // the BSDF-sampling code runs (register budget -> one more resident wave per SIMD):
+        //   A: tail of the previous bounce, emitted radiance, emitter sampling  -> shadow queue
+        //   B: BSDF sampling                                                     -> next ray / state
+        bool alive = false, wantShadow = false, toSample = false;
+        float4 shO, shD, shC;
+        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0;
         if (i < n) {
             const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
             float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
             float prevPdf = q.st2[buf][slot];
-            const uint32_t pid = s0.x; SamplerState ss; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
-            int depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
-            v3 d = V(rd.x, rd.y, rd.z), T = V(s1.x, s1.y, s1.z); float eta = s1.w;
+            pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
+            depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
+            v3 d = V(rd.x, rd.y, rd.z); T = V(s1.x, s1.y, s1.z); eta = s1.w;
             const uint32_t prim = __float_as_uint(hr.w);
             v3 add = V(0, 0, 0); bool haveAdd = false;
             do {
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     }
                     break;
                 }
-                Hit h; v3 ro3 = V(0, 0, 0);
+                v3 ro3 = V(0, 0, 0);
                 if (AN) { float4 ro = q.rayO[buf][slot]; ro3 = V(ro.x, ro.y, ro.z); }      // analytic shapes: hit point = o + t d; sphere lights: reference point of pdfDirect
                 if (AN && prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], ro3, d, hr.x, hr.y, hr.z, h);
                 else fillHit(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     }
                 }
                 if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
-                const MaterialD bsdf = loadMaterial(tb, h.material);
+                bsdf = loadMaterial(tb, h.material);
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }
@@ -350,34 +355,42 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                         }
                     }
                 }
-                // BSDF sampling (path.cpp:207-226)
-                float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
-                float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, woL, bPdf, bEta);
-                if (isZero(bw)) { pathLen += (unsigned) depth; break; }
-                v3 wo = toWorld(h, woL);
-                if (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0) { pathLen += (unsigned) depth; break; }
-                T = T * bw; eta *= bEta;
-                alive = true;
-                nrO = make_float4(h.p.x, h.p.y, h.p.z, MI_EPSILON);
-                nrD = make_float4(wo.x, wo.y, wo.z, INFINITY);
-                uint32_t fl = dot(wo, refN) >= 0 ? 1u : 0u;
-                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16));
-                nS1 = make_float4(T.x, T.y, T.z, eta); nS2 = bPdf;
+                toSample = true;
             } while (false);
             if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
         }
         // wave64 ballots: order-preserving compaction inside the (wave-owned) segment
-        const unsigned long long mA = __ballot(alive), mS = __ballot(wantShadow);
-        if (alive) {
-            const uint64_t o = segBase + outA + (uint32_t) __popcll(mA & lt);
-            q.rayO[nb][o] = nrO; q.rayD[nb][o] = nrD; q.st0[nb][o] = nS0; q.st1[nb][o] = nS1; q.st2[nb][o] = nS2;
-        }
+        const unsigned long long mS = __ballot(wantShadow);
         if (wantShadow) {
             const uint64_t o = segBase + outS + (uint32_t) __popcll(mS & lt);
             q.shO[o] = shO; q.shD[o] = shD; q.shC[o] = shC;
         }
-        outA += (uint32_t) __popcll(mA); outS += (uint32_t) __popcll(mS);
+        outS += (uint32_t) __popcll(mS);
+        float4 nrO, nrD, nS1; uint4 nS0; float nS2 = 0;
+        if (toSample) {
+            // BSDF sampling (path.cpp:207-226)
+            float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
+            float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
+            v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, woL, bPdf, bEta);
+            v3 wo = toWorld(h, woL);
+            if (isZero(bw) || (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0)) pathLen += (unsigned) depth;
+            else {
+                T = T * bw; eta *= bEta;
+                alive = true;
+                nrO = make_float4(h.p.x, h.p.y, h.p.z, MI_EPSILON);
+                nrD = make_float4(wo.x, wo.y, wo.z, INFINITY);
+                v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;           // records.inl:160-164
+                uint32_t fl = dot(wo, refN) >= 0 ? 1u : 0u;
+                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16));
+                nS1 = make_float4(T.x, T.y, T.z, eta); nS2 = bPdf;
+            }
+        }
+        const unsigned long long mA = __ballot(alive);
+        if (alive) {
+            const uint64_t o = segBase + outA + (uint32_t) __popcll(mA & lt);
+            q.rayO[nb][o] = nrO; q.rayD[nb][o] = nrD; q.st0[nb][o] = nS0; q.st1[nb][o] = nS1; q.st2[nb][o] = nS2;
+        }
+        outA += (uint32_t) __popcll(mA);
     }
     if (lane == 0) { q.count[nb][seg] = outA; q.shCount[seg] = outS; }
     }

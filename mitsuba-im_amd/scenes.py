@@ -5,7 +5,7 @@ scene is generated here, deterministically, as the flattened arrays the C-ABI co
 (include/mi355pt.h) -- the same content an adapter would pull out of a live mitsuba::Scene
 (TriMesh::getTriangles/getVertexPositions/..., reference include/mitsuba/render/trimesh.h:122-160).
 
-`save_scene` writes the arrays in a small binary container ("MISCENE1") that the oracle-side
+`save_scene` writes the arrays in a small binary container ("MISCENE2") that the oracle-side
 harness (oracle/ref_build/harness.cpp) reads to build the very same scene inside the reference.
 """
 import math
@@ -16,6 +16,10 @@ BSDF_DIFFUSE = 0
 BSDF_ROUGHCONDUCTOR = 1
 EMITTER_AREA = 0
 EMITTER_ENVMAP = 1
+EMITTER_CONSTANT = 2      # src/emitters/constant.cpp
+EMITTER_POINT = 3         # src/emitters/point.cpp
+EMITTER_SPOT = 4          # src/emitters/spot.cpp
+EMITTER_DIRECTIONAL = 5   # src/emitters/directional.cpp
 FILTER_BOX = 0
 FILTER_GAUSSIAN = 1
 SAMPLER_INDEPENDENT = 0
@@ -451,12 +455,74 @@ def atrium(width=3840, height=2160, spp=64, sampler=SAMPLER_SOBOL, max_depth=8, 
     return sc
 
 
+def add_scene_emitters(sc, emitters):
+    """Prepend scene-level emitters (envmap / constant / point / spot / directional): Scene::m_emitters lists them before the area lights of
+    the shapes when they are declared first (harness order), so the indices of the area lights shift."""
+    k = len(emitters)
+    for sh in sc.shapes:
+        if sh["emitter"] >= 0: sh["emitter"] += k
+    for a in sc.get("analytic") or []:
+        if a["emitter"] >= 0: a["emitter"] += k
+    sc.emitters[0:0] = emitters
+    return sc
+
+
+def constant_emitter(radiance, weight=1.0):
+    return dict(type=EMITTER_CONSTANT, shape=-1, radiance=tuple(map(float, radiance)), weight=float(weight))
+
+
+def point_emitter(position, intensity, weight=1.0):
+    return dict(type=EMITTER_POINT, shape=-1, radiance=tuple(map(float, intensity)), weight=float(weight), to_world=translate(*position).astype(f32))
+
+
+def spot_emitter(origin, target, intensity, cutoff=20.0, beam=None, up=(0, 1, 0), weight=1.0):
+    return dict(type=EMITTER_SPOT, shape=-1, radiance=tuple(map(float, intensity)), weight=float(weight), to_world=look_at(origin, target, up),
+                cutoff=float(cutoff), beam=float(cutoff * 0.75 if beam is None else beam))
+
+
+def directional_emitter(direction, irradiance, weight=1.0):
+    """direction = where the light travels; toWorld = lookAt(0, d, u) with u from coordinateSystem(d) (directional.cpp:64-67)."""
+    d = np.asarray(direction, f32); d = (d / np.sqrt(np.dot(d, d), dtype=f32)).astype(f32)
+    u, _ = _coordinate_system(d)
+    return dict(type=EMITTER_DIRECTIONAL, shape=-1, radiance=tuple(map(float, irradiance)), weight=float(weight), to_world=look_at((0, 0, 0), d, u))
+
+
+def cbox_lights(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, hide_emitters=False):
+    """Cornell box lit by its area light plus a `point` and a `spot` emitter (emitter selection over three kinds; delta lights: MIS weight 1)."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, hide_emitters=hide_emitters)
+    sc.name = "cbox_lights"
+    return add_scene_emitters(sc, [point_emitter((120, 420, 150), (4e5, 5e5, 9e5)),
+                                   spot_emitter((430, 500, 100), (300, 0, 330), (3e6, 2.2e6, 1.2e6), cutoff=28.0, beam=17.0)])
+
+
+def open_constant(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, hide_emitters=False):
+    """Open scene under a `constant` environment emitter and a `directional` light: floor + blocks (mesh), a rough-conductor sphere and a
+    twosided sheet (reference normal 0 -> uniform-sphere sampling of the constant emitter)."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.55, 0.5, 0.45)); red = b.bsdf(reflectance=(0.6, 0.15, 0.1))
+    sheet = b.bsdf(reflectance=(0.2, 0.5, 0.3), twosided=True)
+    eta, k = CONDUCTOR_IOR["Au"]; gold = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.2, distr=DISTR_BECKMANN, eta=eta, k=k)
+    b.begin(); b.quad([(6, 0, -6), (-6, 0, -6), (-6, 0, 6), (6, 0, 6)]); b.end(grey)
+    b.begin()
+    for (x0, z0, x1, z1, h) in [(-2.0, 0.5, -0.8, 1.7, 1.2)]:
+        b.quad([(x0, h, z0), (x0, h, z1), (x1, h, z1), (x1, h, z0)])
+        b.quad([(x0, 0, z0), (x0, h, z0), (x1, h, z0), (x1, 0, z0)]); b.quad([(x1, 0, z0), (x1, h, z0), (x1, h, z1), (x1, 0, z1)])
+        b.quad([(x1, 0, z1), (x1, h, z1), (x0, h, z1), (x0, 0, z1)]); b.quad([(x0, 0, z1), (x0, h, z1), (x0, h, z0), (x0, 0, z0)])
+    b.end(red)
+    b.begin(); b.quad([(0.3, 0.0, 2.4), (2.2, 0.0, 1.6), (2.2, 1.6, 1.6), (0.3, 1.6, 2.4)]); b.end(sheet)
+    b.add_analytic(SHAPE_SPHERE, translate(0.9, 0.6, 0.2), gold, radius=0.6)
+    cam = look_at((0.5, 2.2, -5.0), (0.0, 0.6, 0.8), (0, 1, 0))
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                      seed=seed, hide_emitters=hide_emitters, name="open_constant", analytic=b.resolve_analytic())
+    return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
+
+
 # ---------------------------------------------------------------------------------------------
 # binary container for the oracle-side harness
 # ---------------------------------------------------------------------------------------------
 def save_scene(sc, path):
     with open(path, "wb") as f:
-        f.write(b"MISCENE1")
+        f.write(b"MISCENE2")
         has_n = int(sc.nrm is not None); has_uv = int(sc.uv is not None)
         has_env = int(sc.envmap is not None)
         f.write(struct.pack("<8I", len(sc.pos), len(sc.idx), len(sc.shapes), len(sc.bsdfs),
@@ -473,6 +539,8 @@ def save_scene(sc, path):
             f.write(struct.pack("<13f", *b["reflectance"], b["alpha"], *b["eta"], *b["k"], *b["specular"]))
         for e in sc.emitters:
             f.write(struct.pack("<Ii4f", e["type"], e["shape"], *e["radiance"], e["weight"]))
+            f.write(struct.pack("<2f", e.get("cutoff", 20.0), e.get("beam", 15.0)))
+            f.write(np.ascontiguousarray(e.get("to_world", np.eye(4)), dtype=f32).tobytes())
         f.write(sc.cam_to_world.tobytes())
         f.write(struct.pack("<3f2I", sc.xfov, sc.near, sc.far, sc.width, sc.height))
         f.write(struct.pack("<I2f", sc.filter, sc.filter_radius, sc.filter_stddev))

@@ -20,7 +20,8 @@ class OrcMaterial(C.Structure):
 
 
 class OrcEmitter(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("pad", C.c_uint32 * 2)]
+    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("cutoff", C.c_float), ("beam", C.c_float),
+                ("to_world", C.c_float * 16)]
 
 
 class OrcAnalytic(C.Structure):
@@ -114,6 +115,8 @@ def pack_records(sc):
     ems = (OrcEmitter * max(1, len(sc.emitters)))()
     for i, e in enumerate(sc.emitters):
         em = OrcEmitter(e["type"], e["shape"]); em.radiance[:] = e["radiance"]; em.weight = e["weight"]
+        em.cutoff, em.beam = e.get("cutoff", 20.0), e.get("beam", 15.0)
+        em.to_world[:] = np.asarray(e.get("to_world", np.eye(4)), np.float32).reshape(-1).tolist()
         ems[i] = em
     return shapes, mats, ems
 

@@ -22,6 +22,7 @@
 #define EPSILON 1e-4f            /* include/mitsuba/core/constants.h:28 */
 #define SHADOW_EPSILON 1e-3f     /* constants.h:29 */
 #define INV_PI 0.31830988618379067154f  /* constants.h:64 */
+#define INV_FOURPI 0.07957747154594766788f /* constants.h:66 */
 #define ONE_MINUS_EPS 0.999999940395355225f /* constants.h:51 */
 #define M_PI_F 3.14159265358979323846f
 #define KD_AABB_EPSILON 1e-3f    /* include/mitsuba/render/gkdtree.h:50 */
@@ -68,6 +69,10 @@ struct orc_scene {
     int env_index; int env_w, env_h; float *env_rgb; float *env_cdf_cols, *env_cdf_rows, *env_row_weights;
     float env_normalization, env_scale, env_to_world[9], env_to_local[9], env_pixel_w, env_pixel_h;
     v3 env_bs_center; float env_bs_radius;
+    int env_constant;                     /* the environment emitter is `constant` (src/emitters/constant.cpp), radiance in emitters[env_index] */
+    /* delta emitters: spot constants (spot.cpp:91-96), directional bounding sphere (directional.cpp:87-93) */
+    float *spot_cos_beam, *spot_cos_cutoff, *spot_inv_transition, *spot_cutoff, *spot_to_local;   /* per emitter; to_local = 9 floats each */
+    v3 dir_bs_center; float dir_bs_radius;
 };
 
 /* ------------------------------------------------------------------------------------------------ samplers */
@@ -933,7 +938,12 @@ static v3 env_bilinear(const orc_scene *s, float uvx, float uvy) {
     return r;
 }
 /* envmap.cpp:384-416 evalEnvironment without ray differentials (level-0 bilinear lookup) */
-static v3 env_eval(const orc_scene *s, v3 d) {
+static v3 env_eval_map(const orc_scene *s, v3 d);
+static v3 env_eval(const orc_scene *s, v3 d) {                     /* ConstantBackgroundEmitter::evalEnvironment (constant.cpp:244-246) */
+    if (s->env_constant) { const float *r = s->emitters[s->env_index].radiance; return V(r[0], r[1], r[2]); }
+    return env_eval_map(s, d);
+}
+static v3 env_eval_map(const orc_scene *s, v3 d) {
     v3 v = mat3(s->env_to_local, d);
     float uvx = atan2f(v.x, -v.z) * INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * INV_PI;
     return scale(env_bilinear(s, uvx, uvy), s->env_scale);
@@ -1007,7 +1017,7 @@ static uint32_t cdf_sample(const float *cdf, uint32_t n, float x) {
     while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
     return index;
 }
-typedef struct { v3 ref, p, n, d; float dist, pdf; int32_t emitter; } direct_t;
+typedef struct { v3 ref, p, n, d; float dist, pdf; int32_t emitter; int delta; /* !isOnSurface: point / spot / directional */ } direct_t;
 
 /* src/emitters/area.cpp:106-111 AreaLight::eval */
 static v3 emitter_eval(const orc_scene *s, int32_t e, v3 ns, v3 d) {
@@ -1023,6 +1033,58 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
     float emPdf = s->emitter_cdf[ei + 1] - s->emitter_cdf[ei];
     sx = (sx - s->emitter_cdf[ei]) / (s->emitter_cdf[ei + 1] - s->emitter_cdf[ei]);
     const orc_emitter *em = &s->emitters[ei];
+    dr->delta = 0;
+    if (em->type >= 2) {
+        v3 value; dr->pdf = 0.0f;
+        if (em->type == 2) {
+            /* ConstantBackgroundEmitter::sampleDirect (constant.cpp:175-217) */
+            v3 d; float pdf, nearT, farT;
+            if (!is_zero(refN)) {
+                v3 l = cos_hemisphere(sx, sy); pdf = INV_PI * l.z;
+                v3 fs, ft; coordinate_system(refN, &fs, &ft);
+                d = add(add(scale(fs, l.x), scale(ft, l.y)), scale(refN, l.z));
+            } else { d = uniform_sphere(sx, sy); pdf = INV_FOURPI; }
+            if (!bsphere_intersect(s->env_bs_center, s->env_bs_radius, ref, d, &nearT, &farT)) return V(0, 0, 0);
+            if (!(nearT < 0 && farT > 0)) return V(0, 0, 0);
+            dr->p = add(ref, scale(d, farT)); dr->n = normalize(sub(s->env_bs_center, dr->p)); dr->d = d; dr->dist = farT; dr->pdf = pdf;
+            if (!is_zero(refN) && dot(d, refN) <= 0) value = V(0, 0, 0);       /* NB pdf stays non-zero: the shadow ray is still traced */
+            else { float r = 1.0f / pdf; value = V(em->radiance[0] * r, em->radiance[1] * r, em->radiance[2] * r); }
+        } else if (em->type == 3 || em->type == 4) {
+            /* PointEmitter::sampleDirect (point.cpp:133-149), SpotEmitter::sampleDirect (spot.cpp:187-203) + falloffCurve (:108-128) */
+            dr->delta = 1;
+            dr->p = V(em->to_world[3], em->to_world[7], em->to_world[11]);
+            dr->d = sub(dr->p, ref); dr->dist = length3(dr->d);
+            float invDist = 1.0f / dr->dist; dr->d = scale(dr->d, invDist); dr->n = V(0, 0, 0); dr->pdf = 1.0f;
+            v3 I = V(em->radiance[0], em->radiance[1], em->radiance[2]);
+            if (em->type == 4) {
+                v3 local = mat3(&s->spot_to_local[ei * 9], neg(dr->d)); float cosTheta = local.z, f;
+                if (cosTheta <= s->spot_cos_cutoff[ei]) f = 0.0f;
+                else if (cosTheta >= s->spot_cos_beam[ei]) f = 1.0f;
+                else f = (s->spot_cutoff[ei] - acosf(cosTheta)) * s->spot_inv_transition[ei];
+                I = scale(I, f);
+            }
+            value = scale(I, invDist * invDist);
+        } else {
+            /* DirectionalEmitter::sampleDirect (directional.cpp:159-180) */
+            dr->delta = 1;
+            v3 d = V(em->to_world[2], em->to_world[6], em->to_world[10]);
+            v3 diskCenter = sub(s->dir_bs_center, scale(d, s->dir_bs_radius));
+            float distance = dot(sub(ref, diskCenter), d);
+            if (distance < 0) return V(0, 0, 0);
+            dr->p = sub(ref, scale(d, distance)); dr->d = neg(d); dr->n = d; dr->dist = distance; dr->pdf = 1.0f;
+            value = V(em->radiance[0], em->radiance[1], em->radiance[2]);
+        }
+        if (dr->pdf != 0) {                                                     /* scene.cpp:870-883 */
+            if (test_visibility) {
+                if (shadow_rays) ++*shadow_rays;
+                if (ray_occluded(s, ref, dr->d, EPSILON, dr->dist * (1 - SHADOW_EPSILON))) return V(0, 0, 0);
+            }
+            dr->emitter = (int32_t) ei; dr->pdf *= emPdf;
+            { float r = 1.0f / emPdf; value = scale(value, r); }
+            return value;
+        }
+        return V(0, 0, 0);
+    }
     if (em->type == 1) {
         /* EnvironmentMap::sampleDirect (src/emitters/envmap.cpp:520-547) */
         v3 value, dl; float pdf, nearT, farT;
@@ -1085,6 +1147,12 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
  * pdfEmitterDiscrete (include/mitsuba/render/scene.h:848-850) */
 static float pdf_emitter_direct(const orc_scene *s, const direct_t *dr, v3 refN) {
     float pdf;
+    if (s->emitters[dr->emitter].type >= 3)                                    /* point / spot / directional pdfDirect with measure = EDiscrete (point.cpp:151-153) */
+        return 1.0f * (s->emitters[dr->emitter].weight * s->emitter_norm);
+    if (s->emitters[dr->emitter].type == 2) {                                  /* ConstantBackgroundEmitter::pdfDirect, ESolidAngle (constant.cpp:219-233) */
+        float pdfSA = !is_zero(refN) ? INV_PI * maxf(0.0f, dot(dr->d, refN)) : INV_FOURPI;
+        return pdfSA * (s->emitters[dr->emitter].weight * s->emitter_norm);
+    }
     if (s->emitters[dr->emitter].type == 1)                                    /* EnvironmentMap::pdfDirect, measure = ESolidAngle (envmap.cpp:549-560) */
         return env_pdf_direction(s, mat3(s->env_to_local, dr->d)) * (s->emitters[dr->emitter].weight * s->emitter_norm);
     if (dot(dr->d, refN) >= 0 && dot(dr->d, dr->n) < 0) {
@@ -1136,7 +1204,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
                 v3 wo = to_local(&its, dRec.d);
                 v3 bsdfVal = bsdf_eval(bsdf, its.wi, wo);
                 if (!is_zero(bsdfVal) && (!strict || dot(its.ng, dRec.d) * wo.z > 0)) {
-                    float bsdfPdf = bsdf_pdf(bsdf, its.wi, wo);
+                    float bsdfPdf = dRec.delta ? 0.0f : bsdf_pdf(bsdf, its.wi, wo);   /* emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192) */
                     float weight = mi_weight(dRec.pdf, bsdfPdf);
                     Li = add(Li, scale(mul(mul(throughput, value), bsdfVal), weight));
                 }
@@ -1393,8 +1461,30 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     }
     /* environment emitter tables (envmap.cpp:264-330 configure; :336-347 createShape: sphere around kd-tree box + sensor position, x1.5) */
     s->env_index = -1;
-    for (uint32_t e = 0; e < ne; ++e) if (s->emitters[e].type == 1) s->env_index = (int) e;
-    if (s->env_index >= 0 && d->env_rgb) {
+    for (uint32_t e = 0; e < ne; ++e) if (s->emitters[e].type == 1 || s->emitters[e].type == 2) { s->env_index = (int) e; s->env_constant = s->emitters[e].type == 2; }
+    if (s->env_constant) {   /* ConstantBackgroundEmitter::createShape (constant.cpp:69-74): scene AABB incl. the sensor, radius x 1.5 */
+        v3 blo = s->aabb_lo, bhi = s->aabb_hi; v3 cam = V(d->cam_to_world[3], d->cam_to_world[7], d->cam_to_world[11]);
+        blo = V(minf(blo.x, cam.x), minf(blo.y, cam.y), minf(blo.z, cam.z)); bhi = V(maxf(bhi.x, cam.x), maxf(bhi.y, cam.y), maxf(bhi.z, cam.z));
+        v3 c = scale(add(bhi, blo), 0.5f); v3 cm = sub(c, bhi);
+        s->env_bs_center = c; s->env_bs_radius = maxf(EPSILON, sqrtf(dot(cm, cm)) * 1.5f);
+    }
+    {   /* DirectionalEmitter::createShape (directional.cpp:87-93): kd-tree AABB bounding sphere x 1.1 */
+        v3 c = scale(add(s->aabb_hi, s->aabb_lo), 0.5f), cm = sub(c, s->aabb_hi);
+        s->dir_bs_center = c; s->dir_bs_radius = sqrtf(dot(cm, cm)) * 1.1f;
+    }
+    s->spot_cos_beam = (float *) calloc(ne ? ne : 1, 4); s->spot_cos_cutoff = (float *) calloc(ne ? ne : 1, 4); s->spot_inv_transition = (float *) calloc(ne ? ne : 1, 4);
+    s->spot_cutoff = (float *) calloc(ne ? ne : 1, 4); s->spot_to_local = (float *) calloc(ne ? ne : 1, 36);
+    for (uint32_t e = 0; e < ne; ++e) if (s->emitters[e].type == 4) {       /* SpotEmitter constructor + configure (spot.cpp:70-96); trafo.inverse() of a rigid toWorld */
+        float beam = s->emitters[e].beam * (M_PI_F / 180.0f), cutoff = s->emitters[e].cutoff * (M_PI_F / 180.0f);
+        s->spot_cos_beam[e] = cosf(beam); s->spot_cos_cutoff[e] = cosf(cutoff); s->spot_cutoff[e] = cutoff; s->spot_inv_transition[e] = 1.0f / (cutoff - beam);
+        const float *m = s->emitters[e].to_world; float *o = &s->spot_to_local[e * 9];
+        float a[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+        float det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]); float id = 1.0f / det;
+        o[0] = (a[4] * a[8] - a[5] * a[7]) * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+        o[3] = (a[5] * a[6] - a[3] * a[8]) * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+        o[6] = (a[3] * a[7] - a[4] * a[6]) * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    }
+    if (s->env_index >= 0 && !s->env_constant && d->env_rgb) {
         const int W = (int) d->env_w, H = (int) d->env_h; s->env_w = W; s->env_h = H; s->env_scale = d->env_scale;
         s->env_rgb = (float *) dup(d->env_rgb, (size_t) W * H * 12);
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s->env_to_world[i * 3 + j] = d->env_to_world[i * 4 + j];
@@ -1436,6 +1526,7 @@ void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
     for (uint32_t e = 0; e < s->d.n_emitters; ++e) free(s->area_cdf[e]);   /* NULL for the environment emitter */
     free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic);
+    free(s->spot_cos_beam); free(s->spot_cos_cutoff); free(s->spot_inv_transition); free(s->spot_cutoff); free(s->spot_to_local);
     free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
     free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->emitters); free(s);
 }

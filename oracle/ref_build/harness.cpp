@@ -1,7 +1,7 @@
 // oracle/ref_build/harness.cpp -- TEST INFRASTRUCTURE (checker), never shipped, never on the product path.
 //
 // Our own driver around the REFERENCE's compiled hot path (libmitsuba-core/-render + plugins built by the
-// Makefile next to this file from /root/reference).  It reads a flattened scene ("MISCENE1", written by
+// Makefile next to this file from /root/reference).  It reads a flattened scene ("MISCENE2", written by
 // mitsuba-im_amd/scenes.py), rebuilds the same scene inside the reference programmatically (the XML loader
 // needs pugixml/Xerces, absent here: SURVEY.md §8c) and dumps golden vectors as .npy files:
 //   tables  : Sobol direction matrices / vdc matrices, SFMT known answers, TEA values
@@ -66,7 +66,7 @@ template <typename T> static void save(const std::string &p, const char *d, std:
 // ------------------------------------------------------------------------------------------ scene file
 struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
 struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
-struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight; };
+struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight, cutoff, beam, toWorld[16]; };
 struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
 struct FScene {
     std::vector<FAnalytic> analytic;
@@ -82,7 +82,7 @@ struct FScene {
 static void rd(FILE *f, void *p, size_t n) { if (fread(p, 1, n, f) != n) { fprintf(stderr, "short read\n"); _exit(2); } }
 static FScene loadScene(const char *path) {
     FScene s; FILE *f = fopen(path, "rb"); if (!f) { fprintf(stderr, "cannot open %s\n", path); _exit(2); }
-    char magic[8]; rd(f, magic, 8); if (memcmp(magic, "MISCENE1", 8)) { fprintf(stderr, "bad magic\n"); _exit(2); }
+    char magic[8]; rd(f, magic, 8); if (memcmp(magic, "MISCENE2", 8)) { fprintf(stderr, "bad magic\n"); _exit(2); }
     rd(f, &s.nVerts, 32);
     s.pos.resize(s.nVerts * 3); rd(f, s.pos.data(), s.pos.size() * 4);
     if (s.hasN) { s.nrm.resize(s.nVerts * 3); rd(f, s.nrm.data(), s.nrm.size() * 4); }
@@ -195,8 +195,21 @@ static Built buildScene(const FScene &fs) {
         }
         bsdfs.push_back(bsdf);
     }
-    // scene-level emitters (envmap) first, as the XML loader would add them before shapes are expanded
+    // scene-level emitters first, as the XML loader would add them before shapes are expanded
     for (const FEmitter &fe : fs.emitters) {
+        if (fe.type >= 2) {      // constant / point / spot / directional
+            static const char *names[] = {"", "", "constant", "point", "spot", "directional"};
+            Properties p(names[fe.type]);
+            p.setFloat("samplingWeight", fe.weight);
+            Matrix4x4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = fe.toWorld[i * 4 + j];
+            if (fe.type == 2) p.setSpectrum("radiance", rgb(fe.radiance));
+            else if (fe.type == 5) { p.setSpectrum("irradiance", rgb(fe.radiance)); p.setTransform("toWorld", Transform(m)); }
+            else { p.setSpectrum("intensity", rgb(fe.radiance)); p.setTransform("toWorld", Transform(m)); }
+            if (fe.type == 4) { p.setFloat("cutoffAngle", fe.cutoff); p.setFloat("beamWidth", fe.beam); }
+            ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), p));
+            b.scene->addChild(em); em->setParent(b.scene); em->configure();
+            continue;
+        }
         if (fe.type != 1) continue;
         ref<Bitmap> bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(fs.envW, fs.envH));
         memcpy(bmp->getFloat32Data(), fs.envRGB.data(), fs.envRGB.size() * 4);

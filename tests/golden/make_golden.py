@@ -39,6 +39,10 @@ def golden_scenes():
         "cbox_shapes": scenes.cbox_shapes(width=96, height=96, spp=16),
         "shape_lights": scenes.shape_lights(width=96, height=64, spp=16),
         "cbox_shapes_strict_indep": scenes.cbox_shapes(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=3, strict_normals=True, hide_emitters=True, rr_depth=2, disk_cap=False),
+        # scene-level emitters: point + spot next to the area light; constant environment + directional light
+        "cbox_lights": scenes.cbox_lights(width=96, height=96, spp=16),
+        "open_constant": scenes.open_constant(width=96, height=64, spp=16),
+        "open_constant_hide_indep": scenes.open_constant(width=96, height=64, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=11, hide_emitters=True, rr_depth=2),
     }
 
 
@@ -66,7 +70,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)

@@ -39,7 +39,8 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
 
 
 @pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide",
-                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"])
+                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
+                                  "cbox_lights", "open_constant", "open_constant_hide_indep"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -53,6 +54,9 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     if name.startswith("atrium"):
         # coarse smooth-shaded columns (6 segments): the interpolated normal amplifies last-bit differences of (u, v) at grazing angles
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6
+    elif name == "cbox_lights":
+        # point + spot + area light: one sample sits on the spot cone's cutoff (cosTheta <= cosCutoff decided by the last bit)
+        assert same_path.all() and same_vals.all() and (err < 2e-4).mean() > 0.998 and np.median(err) < 1e-6
     elif name in ("cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"):
         # analytic shapes: the quadrics are solved in double precision on both sides; sin/cos of the cylinder / sphere / cone maps come from
         # libm in the reference and from the polynomial pair here.  shape_lights holds the all-zero Sobol point whose first bounce leaves the
@@ -67,7 +71,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -141,7 +145,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 
 
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
-                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep"])
+                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
