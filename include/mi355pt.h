@@ -43,7 +43,12 @@ typedef struct {
 
 #define MI_EMITTER_AREA 0         /* src/emitters/area.cpp   */
 #define MI_EMITTER_ENVMAP 1       /* src/emitters/envmap.cpp */
-typedef struct { uint32_t type; int32_t shape; float radiance[3]; float weight; uint32_t pad[2]; } mi_emitter;   /* shape >= n_shapes: analytic shape (shape - n_shapes) */
+#define MI_EMITTER_CONSTANT 2     /* src/emitters/constant.cpp: `radiance`                                                   */
+#define MI_EMITTER_POINT 3        /* src/emitters/point.cpp: `radiance` = intensity, position = translation of to_world     */
+#define MI_EMITTER_SPOT 4         /* src/emitters/spot.cpp: intensity, to_world, cutoff / beam = cutoffAngle / beamWidth in degrees (no texture) */
+#define MI_EMITTER_DIRECTIONAL 5  /* src/emitters/directional.cpp: `radiance` = irradiance, travel direction = to_world z axis */
+/* shape: area lights only (index into the shape list; >= n_shapes: analytic shape shape - n_shapes), else -1 */
+typedef struct { uint32_t type; int32_t shape; float radiance[3]; float weight; float cutoff, beam; float to_world[16]; } mi_emitter;
 
 /* Analytic shapes behind Scene::rayIntersect (kd-tree leaf redirect, include/mitsuba/render/skdtree.h:292-301): src/shapes/rectangle.cpp,
  * disk.cpp, sphere.cpp, cylinder.cpp.  to_world = the shape's objectToWorld AFTER its constructor (sphere.cpp:113-123 and

@@ -28,7 +28,8 @@ class MiMaterial(C.Structure):
 
 
 class MiEmitter(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("pad", C.c_uint32 * 2)]
+    _fields_ = [("type", C.c_uint32), ("shape", C.c_int32), ("radiance", C.c_float * 3), ("weight", C.c_float), ("cutoff", C.c_float), ("beam", C.c_float),
+                ("to_world", C.c_float * 16)]
 
 
 class MiAnalytic(C.Structure):
@@ -149,7 +150,9 @@ class Scene:
             mats[i] = m
         ems = (MiEmitter * max(1, len(sc.emitters)))()
         for i, e in enumerate(sc.emitters):
-            em = MiEmitter(e["type"], e["shape"]); em.radiance[:] = e["radiance"]; em.weight = e["weight"]; ems[i] = em
+            em = MiEmitter(e["type"], e["shape"]); em.radiance[:] = e["radiance"]; em.weight = e["weight"]
+            em.cutoff, em.beam = e.get("cutoff", 20.0), e.get("beam", 15.0)
+            em.to_world[:] = np.asarray(e.get("to_world", np.eye(4)), np.float32).reshape(-1).tolist(); ems[i] = em
         L.check(L.L.mi_scene_set_triangles(h, _p(sc.pos), _p(sc.nrm), _p(sc.uv), _p(sc.idx), len(sc.pos), len(sc.idx), C.cast(shapes, C.c_void_p), len(sc.shapes)))
         recs = sc.get("analytic") or []
         if recs:

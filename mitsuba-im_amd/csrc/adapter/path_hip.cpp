@@ -177,8 +177,27 @@ static void flatten(const Scene *scene, FlatScene &fs) {
             mi_emitter me; memset(&me, 0, sizeof(me)); me.type = MI_EMITTER_ENVMAP; me.shape = -1; me.weight = em->getSamplingWeight();
             fs.emitters.push_back(me); continue;
         }
+        {   // scene-level emitters of the other implemented kinds; parameters as their constructors read them (constant.cpp:49-52, point.cpp:59-71, spot.cpp:70-81, directional.cpp:54-72)
+            const std::string cls = em->getClass()->getName(); const Properties &ep = em->getProperties();
+            mi_emitter me; memset(&me, 0, sizeof(me)); me.shape = -1; me.weight = em->getSamplingWeight(); Spectrum value; bool known = true;
+            if (cls == "ConstantBackgroundEmitter") { me.type = MI_EMITTER_CONSTANT; value = ep.getSpectrum("radiance", Spectrum::getD65()); }
+            else if (cls == "PointEmitter") { me.type = MI_EMITTER_POINT; value = ep.getSpectrum("intensity", Spectrum::getD65()); }
+            else if (cls == "SpotEmitter") {
+                me.type = MI_EMITTER_SPOT; value = ep.getSpectrum("intensity", Spectrum(1.0f));
+                me.cutoff = ep.getFloat("cutoffAngle", 20); me.beam = ep.getFloat("beamWidth", me.cutoff * 3.0f / 4.0f);
+                if (ep.hasProperty("texture")) SLog(EError, "path_hip: spot emitters with a projection texture are not implemented");
+            } else if (cls == "DirectionalEmitter") { me.type = MI_EMITTER_DIRECTIONAL; value = ep.getSpectrum("irradiance", Spectrum::getD65()); }
+            else known = false;
+            if (known) {
+                if (em->getWorldTransform() && !em->getWorldTransform()->isStatic()) SLog(EError, "path_hip: animated transforms are not implemented");
+                Matrix4x4 tw = em->getWorldTransform() ? em->getWorldTransform()->eval(0.0f).getMatrix() : Transform().getMatrix();
+                for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) me.to_world[i * 4 + j] = tw(i, j);
+                Float r, g, b; value.toLinearRGB(r, g, b); me.radiance[0] = r; me.radiance[1] = g; me.radiance[2] = b;
+                fs.emitters.push_back(me); continue;
+            }
+        }
         if (!em->isOnSurface() || em->isEnvironmentEmitter())
-            SLog(EError, "path_hip: emitter \"%s\" is neither an area light nor an envmap", em->getClass()->getName().c_str());
+            SLog(EError, "path_hip: emitter \"%s\" is not implemented (area, envmap, constant, point, spot, directional)", em->getClass()->getName().c_str());
         const Shape *shape = em->getShape(); int shapeIdx = -1;
         for (size_t mi = 0; mi < meshes.size(); ++mi) if (meshes[mi] == shape) shapeIdx = (int) mi;
         for (size_t ai = 0; ai < fs.analyticShapes.size(); ++ai) if (fs.analyticShapes[ai] == shape) shapeIdx = (int) (meshes.size() + ai);

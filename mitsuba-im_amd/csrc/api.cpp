@@ -144,7 +144,11 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *e, uint32_t n) {
     if (!s || (n && !e)) return fail(MI_ERR_INVALID, "mi_scene_set_emitters: null argument");
     uint32_t nEnv = 0;
-    for (uint32_t i = 0; i < n; ++i) { if (e[i].type > MI_EMITTER_ENVMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: only `area` and `envmap` emitters are implemented"); nEnv += e[i].type == MI_EMITTER_ENVMAP; }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (e[i].type > MI_EMITTER_DIRECTIONAL) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: implemented emitters: area, envmap, constant, point, spot, directional");
+        nEnv += e[i].type == MI_EMITTER_ENVMAP || e[i].type == MI_EMITTER_CONSTANT;
+        if (e[i].type == MI_EMITTER_SPOT && !(e[i].cutoff >= e[i].beam && e[i].beam >= 0 && e[i].cutoff > 0)) return fail(MI_ERR_INVALID, "mi_scene_set_emitters: spot needs cutoffAngle >= beamWidth >= 0");   // spot.cpp:77
+    }
     if (nEnv > 1) return fail(MI_ERR_INVALID, "The scene may only contain one environment emitter");      // scene.cpp:542-543
     s->h.emitters.assign(e, e + n); s->h.committed = false; return MI_OK;
 }
@@ -179,7 +183,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -189,7 +193,7 @@ int SceneHost::upload(int dev) {
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
     int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
-              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
+              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
     if (g_sobolDims && logRes <= 16) {
@@ -204,6 +208,8 @@ int SceneHost::upload(int dev) {
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
     d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
+    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || hasDeltaEmitters) ? 1u : 0u;
+    memcpy(d.dir_bs_center, dirBsCenter, 12); d.dir_bs_radius = dirBsRadius;
     d.n_tris = nTris; d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
     d.emitter_norm = emitterNorm;
     for (int i = 0; i < 3; ++i) { d.aabb_lo[i] = aabbLo[i]; d.aabb_hi[i] = aabbHi[i]; }
@@ -213,7 +219,8 @@ int SceneHost::upload(int dev) {
     d.filter_radius = filterRadiusEff; d.filter_scale = filterScale; d.border = border;
     d.log_res = logRes; d.resolution = resolution;
     d.env_index = envIndex;
-    if (envIndex >= 0) {
+    d.env_bs_radius = envBsRadius; memcpy(d.env_bs_center, envBsCenter, 12);
+    if (envIndex >= 0 && !envConstant) {
         if (up(&dEnvRGB, envRGB) | up(&dEnvCols, envCdfCols) | up(&dEnvRows, envCdfRows) | up(&dEnvWeights, envRowWeights)) return 1;
         d.env_rgb = (const float *) dEnvRGB; d.env_cdf_cols = (const float *) dEnvCols; d.env_cdf_rows = (const float *) dEnvRows; d.env_row_weights = (const float *) dEnvWeights;
         d.env_w = (int) envW; d.env_h = (int) envH; d.env_normalization = envNormalization; d.env_scale = envScale;
@@ -283,6 +290,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     for (int b = 0; b < 2; ++b) {
         ALLOC(Q.rayO[b], float4, slots); ALLOC(Q.rayD[b], float4, slots);
         ALLOC(Q.st0[b], uint4, slots); ALLOC(Q.st1[b], float4, slots); ALLOC(Q.st2[b], float, slots);
+        if (r->scene->h.d.env_constant) ALLOC(Q.st3[b], float, slots); else Q.st3[b] = nullptr;
         ALLOC(Q.count[b], uint32_t, grid);
     }
     ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, slots); ALLOC(Q.shD, float4, slots); ALLOC(Q.shC, float4, slots);

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC, bool ENV, bool SMALL, bool AN>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN: analytic shapes present
+template <bool RC, bool ENV, bool SMALL, bool AN>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -305,7 +305,11 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                             float4 ro = q.rayO[buf][slot]; float nearT, farT;
                             if (bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {
                                 v3 value = envEval(sc, d);
-                                float lumPdf = envPdfDirection(sc, mat3(sc.env_to_local, d)) * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+                                float pdfSA;
+                                if (sc.env_constant) {      // ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233): needs the reference normal of the previous vertex
+                                    const float c = q.st3[buf][slot]; pdfSA = c != 2.0f ? MI_INV_PI * maxf(0.0f, c) : MI_INV_FOURPI;
+                                } else pdfSA = envPdfDirection(sc, mat3(sc.env_to_local, d));
+                                float lumPdf = pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
                                 add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                             }
                         }
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                         v3 wo = toLocal(h, dr.d);
                         v3 bsdfVal = bsdfEval<RC>(bsdf, h.wi, wo);
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = bsdfPdf<RC>(bsdf, h.wi, wo);
+                            float bp = dr.delta ? 0.0f : bsdfPdf<RC>(bsdf, h.wi, wo);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
                             wantShadow = true;
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             q.shO[o] = shO; q.shD[o] = shD; q.shC[o] = shC;
         }
         outS += (uint32_t) __popcll(mS);
-        float4 nrO, nrD, nS1; uint4 nS0; float nS2 = 0;
+        float4 nrO, nrD, nS1; uint4 nS0; float nS2 = 0, nS3 = 0;
         if (toSample) {
             // BSDF sampling (path.cpp:207-226)
             float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
@@ -380,7 +384,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 nrO = make_float4(h.p.x, h.p.y, h.p.z, MI_EPSILON);
                 nrD = make_float4(wo.x, wo.y, wo.z, INFINITY);
                 v3 refN = (h.flags & 2u) ? V(0, 0, 0) : h.ns;           // records.inl:160-164
-                uint32_t fl = dot(wo, refN) >= 0 ? 1u : 0u;
+                const float cosRef = dot(wo, refN);
+                uint32_t fl = cosRef >= 0 ? 1u : 0u;
+                nS3 = (h.flags & 2u) ? 2.0f : cosRef;
                 nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16));
                 nS1 = make_float4(T.x, T.y, T.z, eta); nS2 = bPdf;
             }
@@ -389,6 +395,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         if (alive) {
             const uint64_t o = segBase + outA + (uint32_t) __popcll(mA & lt);
             q.rayO[nb][o] = nrO; q.rayD[nb][o] = nrD; q.st0[nb][o] = nS0; q.st1[nb][o] = nS1; q.st2[nb][o] = nS2;
+            if (ENV && sc.env_constant) q.st3[nb][o] = nS3;
         }
         outA += (uint32_t) __popcll(mA);
     }
@@ -547,7 +554,7 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
     RenderConst rcl = rc; rcl.order_offset_words = 0;
     if (sc.has_roughconductor && q.cap <= 8192u) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 * (WG / 64) + 16; }
-#define MI_SHADE(RC, ENV, SM) do { if (sc.n_analytic) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
+#define MI_SHADE(RC, ENV, SM) do { if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
                                    else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); } while (0)
     if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
     else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }

@@ -644,6 +644,7 @@ DEV v3 envBilinear(const DScene &sc, float uvx, float uvy) {
 }
 // envmap.cpp:384-416 evalEnvironment, no differentials
 DEV v3 envEval(const DScene &sc, v3 d) {
+    if (sc.env_constant) return ld3(sc.emitters[sc.env_index].radiance);      // ConstantBackgroundEmitter::evalEnvironment (constant.cpp:244-246)
     v3 v = mat3(sc.env_to_local, d);
     float uvx = atan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
     return envBilinear(sc, uvx, uvy) * sc.env_scale;
@@ -715,7 +716,7 @@ DEV uint32_t cdfSample(P cdf, uint32_t n, float x) {
     while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
     return index;
 }
-struct Direct { v3 p, n, d; float dist, pdf; int emitter; };
+struct Direct { v3 p, n, d; float dist, pdf; int emitter; bool delta; /* !isOnSurface: point / spot / directional */ };
 // src/emitters/area.cpp:106-111
 template <bool L>
 DEV v3 emitterEval(const Tabs<L> &tb, int e, v3 ns, v3 d) {
@@ -732,6 +733,53 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
     float emPdf = c1 - c0;
     sx = (sx - c0) / (c1 - c0);
     const EmitterD em = loadEmitter(tb, (int) ei);
+    dr.delta = false;
+    if ((ENV || AN) && em.type >= 2) {
+        v3 value = V(0, 0, 0); dr.pdf = 0.0f;
+        if (ENV && em.type == 2) {                               // ConstantBackgroundEmitter::sampleDirect (constant.cpp:175-217)
+            v3 d; float pdf, nearT, farT;
+            if (!isZero(refN)) {
+                v3 l = cosHemisphere(sx, sy); pdf = MI_INV_PI * l.z;
+                v3 fs, ft; coordinateSystem(refN, fs, ft);
+                d = (fs * l.x + ft * l.y) + refN * l.z;
+            } else { d = uniformSphere(sx, sy); pdf = MI_INV_FOURPI; }
+            if (!bsphereIntersect(sc, ref, d, nearT, farT)) return V(0, 0, 0);
+            if (!(nearT < 0 && farT > 0)) return V(0, 0, 0);
+            dr.p = ref + d * farT; dr.n = normalize(ld3(sc.env_bs_center) - dr.p); dr.d = d; dr.dist = farT; dr.pdf = pdf;
+            if (!isZero(refN) && dot(d, refN) <= 0) value = V(0, 0, 0);          // pdf stays non-zero: the shadow ray is still traced
+            else { float r = 1.0f / pdf; value = V(em.radiance[0] * r, em.radiance[1] * r, em.radiance[2] * r); }
+        } else if (AN && (em.type == 3 || em.type == 4)) {       // PointEmitter / SpotEmitter::sampleDirect (point.cpp:133-149, spot.cpp:108-128, 187-203)
+            const float *x = sc.emitter_x + ei * 16u;
+            dr.delta = true;
+            dr.p = V(x[0], x[1], x[2]);
+            dr.d = dr.p - ref; dr.dist = sqrtf(dot(dr.d, dr.d));
+            float invDist = 1.0f / dr.dist; dr.d = dr.d * invDist; dr.n = V(0, 0, 0); dr.pdf = 1.0f;
+            v3 I = V(em.radiance[0], em.radiance[1], em.radiance[2]);
+            if (em.type == 4) {
+                v3 local = mat3(x + 4, -dr.d); float cosTheta = local.z, f;
+                if (cosTheta <= x[3]) f = 0.0f;
+                else if (cosTheta >= x[13]) f = 1.0f;
+                else f = (x[14] - acosf(cosTheta)) * x[15];
+                I = I * f;
+            }
+            value = I * (invDist * invDist);
+        } else if (AN && em.type == 5) {                         // DirectionalEmitter::sampleDirect (directional.cpp:159-180)
+            const float *x = sc.emitter_x + ei * 16u;
+            dr.delta = true;
+            v3 d = V(x[0], x[1], x[2]);
+            v3 diskCenter = ld3(sc.dir_bs_center) - d * sc.dir_bs_radius;
+            float distance = dot(ref - diskCenter, d);
+            if (distance < 0) return V(0, 0, 0);
+            dr.p = ref - d * distance; dr.d = -d; dr.n = d; dr.dist = distance; dr.pdf = 1.0f;
+            value = V(em.radiance[0], em.radiance[1], em.radiance[2]);
+        }
+        if (dr.pdf != 0) {
+            dr.emitter = (int) ei; dr.pdf *= emPdf;
+            float r = 1.0f / emPdf; value = value * r;
+            return value;
+        }
+        return V(0, 0, 0);
+    }
     if (ENV && em.type == 1) {                                   // EnvironmentMap::sampleDirect (envmap.cpp:520-547)
         v3 value, dl; float pdf, nearT, farT;
         envSampleDirection(sc, sx, sy, dl, value, pdf);

@@ -56,6 +56,7 @@ struct EmitterD {                         // 48 B
 #define MI_SHAPE_SPHERE 2
 #define MI_SHAPE_CYLINDER 3
 #define MI_K_ANALYTIC 4u
+#define MI_INV_FOURPI 0.07957747154594766788f   // constants.h:66
 #define MI_ANALYTIC_PACKET_MAX 16
 struct AnalyticD {
     float to_world[12];                   // rows 0..2 of objectToWorld
@@ -70,7 +71,12 @@ struct AnalyticD {
 struct DScene {
     const BvhNode *nodes; const TriAccelD *tris; const TriShade *shade; const uint32_t *i2; const float *nrm;
     const MaterialD *materials; const EmitterD *emitters; const float *emitter_cdf; const float *area_cdf;
-    const AnalyticD *analytic; uint32_t n_analytic, analytic_pad;
+    const AnalyticD *analytic; uint32_t n_analytic;
+    uint32_t ext;                         // analytic shapes or delta emitters present: selects the k_shade<..., EXT> variants
+    // scene-level emitters beyond envmap (src/emitters/constant.cpp, point.cpp, spot.cpp, directional.cpp): per emitter 16 floats
+    //   [0..2] position (point, spot) / travel direction (directional); spot: [3] cos(cutoff), [4..12] world->local 3x3, [13] cos(beam), [14] cutoff, [15] 1/(cutoff-beam)
+    const float *emitter_x; uint32_t env_constant;   // env_constant: the environment emitter (env_index) is `constant`; radiance in its EmitterD
+    float dir_bs_center[3], dir_bs_radius;           // DirectionalEmitter::createShape: kd-tree box bounding sphere x 1.1
     uint32_t n_tris, n_nodes, n_emitters, n_materials;
     float emitter_norm;
     float aabb_lo[3], aabb_hi[3];         // kd-tree root box of the reference incl. its enlargement (gkdtree.h:1213-1220)

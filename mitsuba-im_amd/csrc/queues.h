@@ -11,6 +11,7 @@
 struct Queues {
     float4 *rayO[2], *rayD[2];
     uint4 *st0[2]; float4 *st1[2]; float *st2[2];
+    float *st3[2];                              // only with a `constant` environment emitter: cos(wo, refN) of the vertex that spawned the ray (2 = no reference normal)
     float4 *hit;
     float4 *shO, *shD, *shC;
     float4 *acc; float2 *pos;

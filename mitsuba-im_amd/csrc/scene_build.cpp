@@ -243,6 +243,7 @@ void SceneHost::commitHost() {
     // --- emitters (scene.cpp:383-388; pmf.h:56-58,103-116; trimesh.cpp:389-402; triangle.cpp:61-67)
     const uint32_t ne = (uint32_t) emitters.size();
     emitterCdf.assign(ne + 1, 0.0f); emittersD.assign(ne, EmitterD{}); areaCdf.clear(); emitterNorm = 0.0f;
+    emitterX.assign((size_t) std::max(ne, 1u) * 16, 0.0f); hasDeltaEmitters = false;
     for (uint32_t e = 0; e < ne; ++e) emitterCdf[e + 1] = emitterCdf[e] + emitters[e].weight;
     if (ne) { float sum = emitterCdf[ne]; emitterNorm = sum > 0 ? 1.0f / sum : 0.0f; for (uint32_t e = 1; e <= ne; ++e) emitterCdf[e] *= emitterNorm; emitterCdf[ne] = 1.0f; }
     for (uint32_t e = 0; e < ne; ++e) {
@@ -250,6 +251,19 @@ void SceneHost::commitHost() {
         d.radiance[0] = src.radiance[0]; d.radiance[1] = src.radiance[1]; d.radiance[2] = src.radiance[2]; d.weight = src.weight;
         d.type = src.type; d.shape = src.shape;
         d.analytic = -1;
+        float *x = &emitterX[e * 16];
+        if (src.type == MI_EMITTER_POINT || src.type == MI_EMITTER_SPOT) { x[0] = src.to_world[3]; x[1] = src.to_world[7]; x[2] = src.to_world[11]; hasDeltaEmitters = true; }
+        if (src.type == MI_EMITTER_DIRECTIONAL) { x[0] = src.to_world[2]; x[1] = src.to_world[6]; x[2] = src.to_world[10]; hasDeltaEmitters = true; }
+        if (src.type == MI_EMITTER_SPOT) {                        // SpotEmitter constructor + configure (spot.cpp:70-96); trafo.inverse() of the rigid toWorld
+            float beam = src.beam * (MI_PI / 180.0f), cutoff = src.cutoff * (MI_PI / 180.0f);
+            x[13] = std::cos(beam); x[3] = std::cos(cutoff); x[14] = cutoff; x[15] = 1.0f / (cutoff - beam);
+            const float *m = src.to_world; float *o = x + 4;
+            float a[9] = {m[0], m[1], m[2], m[4], m[5], m[6], m[8], m[9], m[10]};
+            float det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]); float id = 1.0f / det;
+            o[0] = (a[4] * a[8] - a[5] * a[7]) * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+            o[3] = (a[5] * a[6] - a[3] * a[8]) * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+            o[6] = (a[3] * a[7] - a[4] * a[6]) * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+        }
         if (src.type != MI_EMITTER_AREA) continue;
         if ((size_t) src.shape >= shapes.size()) {               // area light on an analytic shape: no triangle CDF
             d.analytic = src.shape - (int32_t) shapes.size(); d.inv_area = analyticD[d.analytic].inv_area; continue;
@@ -289,9 +303,18 @@ void SceneHost::commitHost() {
         for (int i = 0; i < MI_FILTER_RES; ++i) filterValues[i] *= norm;
     }
     // --- environment emitter tables (envmap.cpp:264-330 configure, :336-347 createShape: sphere around kd-tree box + sensor position, x1.5)
-    envIndex = -1;
-    for (uint32_t e = 0; e < ne; ++e) if (emitters[e].type == MI_EMITTER_ENVMAP) envIndex = (int) e;
-    if (envIndex >= 0) {
+    envIndex = -1; envConstant = false;
+    for (uint32_t e = 0; e < ne; ++e) if (emitters[e].type == MI_EMITTER_ENVMAP || emitters[e].type == MI_EMITTER_CONSTANT) { envIndex = (int) e; envConstant = emitters[e].type == MI_EMITTER_CONSTANT; }
+    {   // bounding spheres: environment emitters (envmap.cpp:336-347, constant.cpp:69-74: scene box incl. the sensor, x 1.5); directional.cpp:87-93 (kd-tree box, x 1.1)
+        V3 blo = mk(aabbLo[0], aabbLo[1], aabbLo[2]), bhi = mk(aabbHi[0], aabbHi[1], aabbHi[2]);
+        V3 c0 = (bhi + blo) * 0.5f, cm0 = c0 - bhi;
+        dirBsCenter[0] = c0.x; dirBsCenter[1] = c0.y; dirBsCenter[2] = c0.z; dirBsRadius = std::sqrt(dot(cm0, cm0)) * 1.1f;
+        V3 cam = mk(c2w[3], c2w[7], c2w[11]);
+        blo = vmin(blo, cam); bhi = vmax(bhi, cam);
+        V3 c = (bhi + blo) * 0.5f, cm = c - bhi;
+        envBsCenter[0] = c.x; envBsCenter[1] = c.y; envBsCenter[2] = c.z; envBsRadius = std::max(MI_EPSILON, std::sqrt(dot(cm, cm)) * 1.5f);
+    }
+    if (envIndex >= 0 && !envConstant) {
         const int W = (int) envW, H = (int) envH;
         auto texel = [&](int x, int y) { const float *p = &envRGB[((size_t) y * W + x) * 3]; return mk(p[0], p[1], p[2]); };
         auto lum = [](V3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; };
@@ -317,10 +340,6 @@ void SceneHost::commitHost() {
         for (int y = 1; y < H; ++y) envCdfRows[rowPos - y - 1] *= normalization;
         envCdfRows[rowPos - 1] = 1.0f;
         envNormalization = 1.0f / (rowSum * (2 * MI_PI / (float) W) * (MI_PI / (float) H));
-        V3 blo = mk(aabbLo[0], aabbLo[1], aabbLo[2]), bhi = mk(aabbHi[0], aabbHi[1], aabbHi[2]), cam = mk(c2w[3], c2w[7], c2w[11]);
-        blo = vmin(blo, cam); bhi = vmax(bhi, cam);
-        V3 c = (bhi + blo) * 0.5f, cm = c - bhi;
-        envBsCenter[0] = c.x; envBsCenter[1] = c.y; envBsCenter[2] = c.z; envBsRadius = std::max(MI_EPSILON, std::sqrt(dot(cm, cm)) * 1.5f);
     }
     // Sobol film resolution (src/samplers/sobol.cpp:147-157)
     { uint32_t r = std::max(width, height), p = 1, l = 0; while (p < r) { p <<= 1; ++l; } resolution = (float) p; logRes = l; }

@@ -19,7 +19,8 @@ struct SceneHost {
     uint32_t packetK[3] = {0, 0, 0};
     std::vector<AnalyticD> analyticD; uint32_t nTris = 0;   // analytic shapes: primitive index nTris + i; `tris` (BVH leaf order) holds a k = MI_K_ANALYTIC record for each
     std::vector<TriAccelD> packet;   // Wald records in ORIGINAL triangle order (packet mode, <= MI_PACKET_MAX triangles)
-    std::vector<EmitterD> emittersD; std::vector<float> emitterCdf, areaCdf; float emitterNorm = 0;
+    std::vector<EmitterD> emittersD; std::vector<float> emitterCdf, areaCdf, emitterX; float emitterNorm = 0;
+    bool envConstant = false, hasDeltaEmitters = false; float dirBsCenter[3] = {0, 0, 0}, dirBsRadius = 0;
     float aabbLo[3], aabbHi[3];
     float filterValues[MI_FILTER_RES + 1]; float filterRadiusEff = 0, filterScale = 0; int border = 0;
     float resolution = 1; uint32_t logRes = 0;
@@ -27,7 +28,7 @@ struct SceneHost {
     // device
     bool committed = false; int device = 0;
     void *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr, *dI2 = nullptr, *dNrm = nullptr, *dMaterials = nullptr, *dEmitters = nullptr,
-         *dEmitterCdf = nullptr, *dAnalytic = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dEnvRGB = nullptr, *dEnvCols = nullptr, *dEnvRows = nullptr, *dEnvWeights = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
+         *dEmitterCdf = nullptr, *dAnalytic = nullptr, *dEmitterX = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dEnvRGB = nullptr, *dEnvCols = nullptr, *dEnvRows = nullptr, *dEnvWeights = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
     DScene d{};
 
     void commitHost();          // scene_build.cpp

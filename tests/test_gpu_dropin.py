@@ -62,6 +62,19 @@ def test_plugin_drop_in_analytic_shapes(mi, golden_scenes, tmp_path):
     assert (rel < 1e-3).mean() > 0.99 and np.linalg.norm(g[..., :3] - r[..., :3]) / np.linalg.norm(r[..., :3]) < 1e-2
 
 
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
+@pytest.mark.parametrize("name", ["cbox_lights", "open_constant"])
+def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
+    """Same driver; live PointEmitter / SpotEmitter / DirectionalEmitter / ConstantBackgroundEmitter objects flattened from their Properties."""
+    sc = golden_scenes[name]
+    path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path); out = str(tmp_path / "hip")
+    subprocess.run([HARNESS, path, "responsive", "path_hip", "-1", out], cwd=os.path.dirname(HARNESS), check=True, timeout=300)
+    got = np.load(out + "_target.npy"); ref = np.load(os.path.join(GOLDEN, name + "_responsive.npz"))["target"]
+    g, r = got[1:-2, 1:-2], ref[1:-2, 1:-2]
+    rel = np.abs(g - r).max(2) / (np.abs(r).max(2) + 1e-6)
+    assert (rel < 1e-3).mean() > 0.99 and np.linalg.norm(g[..., :3] - r[..., :3]) / np.linalg.norm(r[..., :3]) < 1e-2
+
+
 def test_host_mirror_controls(mi, golden_scenes):
     """C++ host mirror (csrc/integrator_host.cpp) through its C shim: return codes and error strings of the reference interface."""
     import ctypes as C

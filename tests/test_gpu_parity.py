@@ -314,3 +314,27 @@ def test_analytic_shapes(mi, oracle, golden_scenes, name, bvh, monkeypatch):
         assert rel < 2e-3 and abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 3e-3
+
+
+@pytest.mark.parametrize("name", ["cbox_lights", "open_constant", "open_constant_hide_indep"])
+def test_scene_level_emitters(mi, oracle, golden_scenes, name):
+    """SURVEY.md §8f-4 emitters: `point` + `spot` next to the area light (emitter selection, delta lights: MIS weight 1) and a `constant`
+    environment + `directional` light (cosine-hemisphere / uniform-sphere sampling, pdfDirect from the previous vertex' reference normal)."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); pairs = gd["pairs"]
+    rng = np.random.default_rng(5); n = 20000
+    more = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(more)["li"]; got = r.samples(more)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    if name == "cbox_lights":
+        # all-diffuse: only the spot's transition zone (acos) leaves the exact arithmetic
+        assert (bits(got) == bits(ref)).all(1).mean() > 0.9 and (err < 1e-5).mean() > 0.999
+    else:
+        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6          # rough-conductor sphere: tolerance-pinned
+    got = r.samples(pairs); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)   # the reference's own Li
+    assert (err < 2e-4).mean() > 0.998 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-3
