@@ -14,6 +14,9 @@ import numpy as np
 
 BSDF_DIFFUSE = 0
 BSDF_ROUGHCONDUCTOR = 1
+BSDF_CONDUCTOR = 2        # src/bsdfs/conductor.cpp: eta, k, specular
+BSDF_DIELECTRIC = 3       # src/bsdfs/dielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance
+BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
 EMITTER_ENVMAP = 1
 EMITTER_CONSTANT = 2      # src/emitters/constant.cpp
@@ -47,10 +50,33 @@ def _quad(verts, tris, shape_ranges, quad_pts):
     tris.append((base, base + 2, base + 3))
 
 
+def fresnel_dielectric_ext(cos_i, eta):
+    """reference src/libcore/util.cpp:653-683 (float64, vectorised over cos_i >= 0)."""
+    cos_i = np.asarray(cos_i, np.float64); scale = 1.0 / eta
+    ct2 = 1.0 - (1.0 - cos_i * cos_i) * scale * scale
+    ct = np.sqrt(np.maximum(ct2, 0.0))
+    rs = (cos_i - eta * ct) / (cos_i + eta * ct); rp = (eta * cos_i - ct) / (eta * cos_i + ct)
+    return np.where(ct2 <= 0.0, 1.0, 0.5 * (rs * rs + rp * rp))
+
+
+def fresnel_diffuse_reflectance(eta):
+    """fresnelDiffuseReflectance(eta, fast=false) = integral_0^1 F(sqrt(xi), eta) dxi (src/libcore/util.cpp:809-861; the reference runs an
+    adaptive Gauss-Lobatto rule to 1e-5).  Substituting xi = c^2: integral_0^1 2 c F(c) dc, composite Gauss-Legendre; pinned against the
+    reference's own values in tests/golden/fresnel_diffuse_reflectance.npy."""
+    x, w = np.polynomial.legendre.leggauss(64); total = 0.0; n = 256
+    for i in range(n):
+        a, b = i / n, (i + 1) / n; c = 0.5 * (b - a) * x + 0.5 * (b + a)
+        total += 0.5 * (b - a) * np.sum(w * 2.0 * c * fresnel_dielectric_ext(c, eta))
+    return float(total)
+
+
 def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
               distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
-              specular=(1.0, 1.0, 1.0), sample_visible=True):
-    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible),
+              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False):
+    if kind in (BSDF_DIELECTRIC, BSDF_PLASTIC):      # scalar relative index; plastic: k[0] = m_fdrInt = fresnelDiffuseReflectance(1 / eta) (plastic.cpp:200)
+        eta = (float(f32(ior)), 0.0, 0.0); distr = int(nonlinear)
+        k = (float(f32(fresnel_diffuse_reflectance(1.0 / float(f32(ior))))), 0.0, 0.0) if kind == BSDF_PLASTIC else (0.0, 0.0, 0.0)
+    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible), nonlinear=int(nonlinear),
                 reflectance=tuple(map(float, reflectance)), alpha=float(alpha),
                 eta=tuple(map(float, eta)), k=tuple(map(float, k)),
                 specular=tuple(map(float, specular)))
@@ -269,6 +295,38 @@ def cbox_shapes(width=256, height=256, spp=16, sampler=SAMPLER_SOBOL, max_depth=
     cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth,
                         filter_kind, seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_shapes", analytic=b.resolve_analytic())
+
+
+def cbox_materials(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=10, rr_depth=5, seed=0, strict_normals=False, hide_emitters=False):
+    """Cornell room with the smooth BSDF family: glass `dielectric` sphere, gold smooth `conductor` sphere, `plastic` tall
+    block, nonlinear `plastic` floor, a `twosided(conductor)` mirror sheet; the usual ceiling quad light."""
+    b = _Builder()
+    white = b.bsdf(reflectance=(0.725, 0.71, 0.68)); red = b.bsdf(reflectance=(0.63, 0.065, 0.05)); green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
+    lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78))
+    floor = b.bsdf(kind=BSDF_PLASTIC, reflectance=(0.6, 0.5, 0.35), specular=(1.0, 1.0, 1.0), ior=1.49, nonlinear=True)
+    blockm = b.bsdf(kind=BSDF_PLASTIC, reflectance=(0.15, 0.25, 0.6), specular=(0.9, 0.9, 0.9), ior=1.5046)
+    glass = b.bsdf(kind=BSDF_DIELECTRIC, reflectance=(0.95, 1.0, 0.97), specular=(1.0, 1.0, 1.0), ior=1.5046)
+    eta, k = CONDUCTOR_IOR["Au"]; gold = b.bsdf(kind=BSDF_CONDUCTOR, eta=eta, k=k)
+    eta, k = CONDUCTOR_IOR["Al"]; mirror = b.bsdf(kind=BSDF_CONDUCTOR, eta=eta, k=k, specular=(0.9, 0.9, 0.9), twosided=True)
+    b.begin(); b.quad([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]); b.end(floor)
+    b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)
+    b.begin(); b.quad([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]); b.end(white)
+    b.begin(); b.quad([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]); b.end(green)
+    b.begin(); b.quad([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]); b.end(red)
+    b.begin(); b.quad([(343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227)]); b.end(lightm, radiance=(17.0, 12.0, 4.0))
+    b.begin()
+    b.quad([(423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)])
+    b.quad([(423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)])
+    b.quad([(472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)])
+    b.quad([(314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)])
+    b.quad([(265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247)])
+    b.end(blockm)
+    b.begin(); b.quad([(20, 40, 420), (150, 40, 540), (150, 300, 540), (20, 300, 420)]); b.end(mirror)
+    b.add_analytic(SHAPE_SPHERE, translate(170, 100, 190), glass, radius=100.0)
+    b.add_analytic(SHAPE_SPHERE, translate(400, 60, 120), gold, radius=60.0)
+    cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_materials", analytic=b.resolve_analytic())
 
 
 def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):

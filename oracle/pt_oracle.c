@@ -701,11 +701,15 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0; }
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4 };
+#define BSDF_FLAG_NONLINEAR 4u
+/* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
+static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC; }
 /* BSDF::ESmooth: a `diffuse` whose reflectance is identically zero registers NO component (src/bsdfs/diffuse.cpp:99-102), so its type
  * is 0 and MIPathTracer::Li skips emitter sampling -- and the sampler request that goes with it (path.cpp:174-176) */
 static int material_is_smooth(const orc_material *m) {
-    if (m->type == 0) return maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;
+    if (m->type == BSDF_DIFFUSE) return maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;
+    if (m->type == BSDF_CONDUCTOR || m->type == BSDF_DIELECTRIC) return 0;     /* delta components only (conductor.cpp:201-202, dielectric.cpp:199-202) */
     return 1;
 }
 
@@ -891,23 +895,111 @@ static v3 rc_sample(const orc_material *mt, v3 wi, float u, float v, v3 *wo, flo
 }
 
 /* dispatch incl. src/bsdfs/twosided.cpp:110-190 (flip wi/wo to the front side when wi.z < 0) */
+static inline float luminance(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }   /* include/mitsuba/core/spectrum.h:725-727 */
+/* ---- smooth conductor / dielectric / plastic: src/bsdfs/conductor.cpp:212-286, dielectric.cpp:224-342, plastic.cpp:248-453.
+ * eval / pdf are the solid-angle-measure versions the integrator calls during emitter sampling (delta components contribute 0 there).
+ * Material fields: conductor eta[3], k[3], specular[3]; dielectric eta[0] = intIOR / extIOR, specular = specularReflectance,
+ * reflectance = specularTransmittance; plastic eta[0], specular, reflectance = diffuseReflectance, k[0] = fresnelDiffuseReflectance(1/eta)
+ * (m_fdrInt, plastic.cpp:200), flag bit2 = nonlinear. */
+/* src/libcore/util.cpp:653-683 fresnelDielectricExt */
+static float fresnel_dielectric_ext(float cosThetaI_, float *cosThetaT_, float eta) {
+    if (eta == 1) { *cosThetaT_ = -cosThetaI_; return 0.0f; }
+    float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { *cosThetaT_ = 0.0f; return 1.0f; }
+    float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtf(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    *cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+static v3 conductor_sample(const orc_material *m, v3 wi, v3 *wo, float *pdf, float *eta, int *delta) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    *wo = V(-wi.x, -wi.y, wi.z); *eta = 1.0f; *pdf = 1; *delta = 1;
+    return mul(V(m->specular[0], m->specular[1], m->specular[2]), fresnel_conductor_exact(wi.z, m->eta, m->k));
+}
+static v3 dielectric_sample(const orc_material *m, v3 wi, float sx, v3 *wo, float *pdf, float *etaOut, int *delta) {
+    const float eta = m->eta[0], invEta = 1 / eta; float cosThetaT;
+    float F = fresnel_dielectric_ext(wi.z, &cosThetaT, eta);
+    *delta = 1;
+    if (sx <= F) { *wo = V(-wi.x, -wi.y, wi.z); *etaOut = 1.0f; *pdf = F; return V(m->specular[0], m->specular[1], m->specular[2]); }
+    float scale_ = -(cosThetaT < 0 ? invEta : eta);
+    *wo = V(scale_ * wi.x, scale_ * wi.y, cosThetaT);
+    *etaOut = cosThetaT < 0 ? eta : invEta; *pdf = 1 - F;
+    float factor = cosThetaT < 0 ? invEta : eta;
+    return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), factor * factor);
+}
+static float plastic_spec_weight(const orc_material *m) {      /* plastic.cpp:204-207, Spectrum::getLuminance of the constant textures */
+    float dAvg = luminance(V(m->reflectance[0], m->reflectance[1], m->reflectance[2])), sAvg = luminance(V(m->specular[0], m->specular[1], m->specular[2]));
+    return sAvg / (dAvg + sAvg);
+}
+static v3 plastic_diffuse(const orc_material *m) {              /* diff /= 1 - fdrInt  (or the nonlinear form) */
+    v3 diff = V(m->reflectance[0], m->reflectance[1], m->reflectance[2]); const float fdrInt = m->k[0];
+    if (m->flags & BSDF_FLAG_NONLINEAR) return V(diff.x / (1.0f - diff.x * fdrInt), diff.y / (1.0f - diff.y * fdrInt), diff.z / (1.0f - diff.z * fdrInt));
+    float r = 1.0f / (1 - fdrInt); return scale(diff, r);
+}
+static v3 plastic_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wo.z <= 0 || wi.z <= 0) return V(0, 0, 0);
+    const float eta = m->eta[0], invEta2 = 1 / (eta * eta); float ct;
+    float Fi = fresnel_dielectric_ext(wi.z, &ct, eta), Fo = fresnel_dielectric_ext(wo.z, &ct, eta);
+    return scale(plastic_diffuse(m), INV_PI * wo.z * invEta2 * (1 - Fi) * (1 - Fo));
+}
+static float plastic_prob_specular(const orc_material *m, float Fi) { float w = plastic_spec_weight(m); return (Fi * w) / (Fi * w + (1 - Fi) * (1 - w)); }
+static float plastic_pdf(const orc_material *m, v3 wi, v3 wo) {
+    if (wo.z <= 0 || wi.z <= 0) return 0.0f;
+    float ct, Fi = fresnel_dielectric_ext(wi.z, &ct, m->eta[0]);
+    return INV_PI * wo.z * (1 - plastic_prob_specular(m, Fi));
+}
+static v3 plastic_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *etaOut, int *delta) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    const float eta = m->eta[0], invEta2 = 1 / (eta * eta); float ct;
+    float Fi = fresnel_dielectric_ext(wi.z, &ct, eta);
+    *etaOut = 1.0f;
+    float probSpecular = plastic_prob_specular(m, Fi);
+    if (sx < probSpecular) {
+        *wo = V(-wi.x, -wi.y, wi.z); *pdf = probSpecular; *delta = 1;
+        float r = 1.0f / probSpecular; return scale(scale(V(m->specular[0], m->specular[1], m->specular[2]), Fi), r);
+    }
+    *wo = cos_hemisphere((sx - probSpecular) / (1 - probSpecular), sy);
+    float Fo = fresnel_dielectric_ext(wo->z, &ct, eta);
+    *pdf = (1 - probSpecular) * (INV_PI * wo->z);
+    return scale(plastic_diffuse(m), invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
+}
+
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
-    return m->type == 1 ? rc_eval(m, wi, wo) : diffuse_eval(m, wi, wo);
+    switch (m->type) {
+        case BSDF_ROUGHCONDUCTOR: return rc_eval(m, wi, wo);
+        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: return V(0, 0, 0);
+        case BSDF_PLASTIC: return plastic_eval(m, wi, wo);
+        default: return diffuse_eval(m, wi, wo);
+    }
 }
 static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
-    return m->type == 1 ? rc_pdf(m, wi, wo) : diffuse_pdf(wi, wo);
+    switch (m->type) {
+        case BSDF_ROUGHCONDUCTOR: return rc_pdf(m, wi, wo);
+        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: return 0.0f;
+        case BSDF_PLASTIC: return plastic_pdf(m, wi, wo);
+        default: return diffuse_pdf(wi, wo);
+    }
 }
-static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {
-    int flipped = 0;
+/* *delta = the sampled component is a Dirac delta (bRec.sampledType & BSDF::EDelta, path.cpp:259-260) */
+static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta) {
+    int flipped = 0; *delta = 0;
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; flipped = 1; }
-    v3 w = m->type == 1 ? rc_sample(m, wi, u, v, wo, pdf, eta) : diffuse_sample(m, wi, u, v, wo, pdf, eta);
+    v3 w;
+    switch (m->type) {
+        case BSDF_ROUGHCONDUCTOR: w = rc_sample(m, wi, u, v, wo, pdf, eta); break;
+        case BSDF_CONDUCTOR: w = conductor_sample(m, wi, wo, pdf, eta, delta); break;
+        case BSDF_DIELECTRIC: w = dielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
+        case BSDF_PLASTIC: w = plastic_sample(m, wi, u, v, wo, pdf, eta, delta); break;
+        default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;
+    }
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
     return w;
 }
 void orc_bsdf_sample(const orc_scene *s, uint32_t mi, const float *wi, float u, float v, float *o) {
-    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; v3 w = bsdf_sample(&s->materials[mi], V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta);
+    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; v3 w = bsdf_sample(&s->materials[mi], V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta);
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = pdf; o[4] = wo.x; o[5] = wo.y; o[6] = wo.z; o[7] = eta;
 }
 void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float *wo, float *o) {
@@ -918,7 +1010,6 @@ void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float
 /* ------------------------------------------------------------------------------------------------ environment emitter */
 #define INV_TWOPI 0.15915494309189533577f
 static inline v3 mat3(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z); }
-static inline float luminance(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }   /* include/mitsuba/core/spectrum.h:725-727 */
 /* include/mitsuba/render/mipmap.h:504-560 evalTexel, level 0, u: ERepeat, v: EClamp (envmap.cpp:181-183) */
 static v3 env_texel(const orc_scene *s, int x, int y) {
     if (x < 0 || x >= s->env_w) { int r = x % s->env_w; x = r < 0 ? r + s->env_w : r; }
@@ -1213,7 +1304,8 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
         /* BSDF sampling (path.cpp:207-219) */
         float bsdfPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
         float sx, sy; next2D(sp, &sx, &sy);
-        v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta);
+        int sampledDelta = 0;
+        v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta);
         if (is_zero(bsdfWeight)) break;
         scattered = 1;
         v3 wo = to_world(&its, woL);
@@ -1241,7 +1333,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
 
         throughput = mul(throughput, bsdfWeight); eta *= bEta;
         if (hitEmitter) {                                /* path.cpp:257-264 */
-            float lumPdf = pdf_emitter_direct(s, &dRec, refN);
+            float lumPdf = sampledDelta ? 0.0f : pdf_emitter_direct(s, &dRec, refN);     /* !(bRec.sampledType & BSDF::EDelta) (path.cpp:259-260) */
             Li = add(Li, scale(mul(throughput, value), mi_weight(bsdfPdf, lumPdf)));
         }
         if (!its.valid) break;                           /* path.cpp:272 */

@@ -177,6 +177,22 @@ static Built buildScene(const FScene &fs) {
         if (fb.type == 0) {
             Properties p("diffuse"); p.setSpectrum("reflectance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 2) {
+            Properties p("conductor");
+            p.setSpectrum("eta", rgb(fb.eta)); p.setSpectrum("k", rgb(fb.k)); p.setSpectrum("specularReflectance", rgb(fb.spec));
+            p.setString("material", "none"); p.setFloat("extEta", 1.0f);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 3) {
+            Properties p("dielectric");
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
+            p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 4) {
+            Properties p("plastic");
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
+            p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("diffuseReflectance", rgb(fb.refl));
+            p.setBoolean("nonlinear", fb.distr == 1);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else {
             Properties p("roughconductor");
             p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx");
@@ -357,6 +373,10 @@ static void modeTables(const std::string &out) {
         Float r, g, b; sp.toLinearRGB(r, g, b); ior.push_back(r); ior.push_back(g); ior.push_back(b);
     }
     save(out + "/conductor_ior_rgb.npy", "<f4", {3, 6}, ior);
+    // diffuse Fresnel reflectances as SmoothPlastic::configure computes them (plastic.cpp:199-201): rows (eta, fdrInt = F_dr(1/eta), fdrExt = F_dr(eta))
+    std::vector<float> fdr;
+    for (float eta : {1.1f, 1.3f, 1.33f, 1.49f, 1.5046f, 1.7f, 2.0f, 2.419f}) { fdr.push_back(eta); fdr.push_back(fresnelDiffuseReflectance(1 / eta, false)); fdr.push_back(fresnelDiffuseReflectance(eta, false)); }
+    save(out + "/fresnel_diffuse_reflectance.npy", "<f4", {fdr.size() / 3, 3}, fdr);
 }
 
 static uint64_t g_rays = 0, g_shadow = 0;
