@@ -31,10 +31,15 @@ typedef struct {
     uint32_t pad;
 } mi_shape;
 
-#define MI_BSDF_DIFFUSE 0         /* src/bsdfs/diffuse.cpp                         */
-#define MI_BSDF_ROUGHCONDUCTOR 1  /* src/bsdfs/roughconductor.cpp + microfacet.h   */
+#define MI_BSDF_DIFFUSE 0         /* src/bsdfs/diffuse.cpp: reflectance                                                              */
+#define MI_BSDF_ROUGHCONDUCTOR 1  /* src/bsdfs/roughconductor.cpp + microfacet.h: alpha, distr, eta, k, specular                      */
+#define MI_BSDF_CONDUCTOR 2       /* src/bsdfs/conductor.cpp: eta, k (already divided by the exterior index), specular               */
+#define MI_BSDF_DIELECTRIC 3      /* src/bsdfs/dielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance */
+#define MI_BSDF_PLASTIC 4         /* src/bsdfs/plastic.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = diffuseReflectance,
+                                     k[0] = fresnelDiffuseReflectance(1 / eta, false) (SmoothPlastic::m_fdrInt, plastic.cpp:200)       */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
+#define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
 typedef struct {
     uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx */
     float alpha;

@@ -22,6 +22,8 @@
 #include <mitsuba/core/fresolver.h>
 #include <mitsuba/core/bitmap.h>
 #include <mitsuba/core/half.h>
+#include <mitsuba/core/mstream.h>
+#include <mitsuba/core/serialization.h>
 #include <ior.h>   // src/bsdfs/ior.h: lookupIOR, as used by RoughConductor's constructor
 #include "../integrator_host.h"
 
@@ -38,9 +40,53 @@ struct FlatScene {
 
 #define MI_CHECK(call) do { int rc_ = (call); if (rc_ != MI_OK) SLog(EError, "path_hip: %s failed: %s", #call, mi_last_error()); } while (0)
 
+/// `twosided` keeps its nested BSDF private (src/bsdfs/twosided.cpp:197-198) and the nested object's Properties are gone once it is configured
+/// from a parent, so the wrapper is read through the one public door that shows its content: serialisation.  TwoSidedBRDF::serialize
+/// (twosided.cpp:79-84) writes the nested objects through the InstanceManager (src/libcore/serialization.cpp:76-91: id, class name, then the
+/// object's own serialize()); the layouts parsed here are RoughConductor::serialize (roughconductor.cpp:219-229), SmoothConductor::serialize
+/// (conductor.cpp:204-209), SmoothPlastic::serialize (plastic.cpp:169-176), constant textures (src/librender/basictexture.cpp:29-49).
+struct NestedReader {
+    ref<MemoryStream> ms; std::map<uint32_t, std::vector<float> > seen;
+    /// a ConstantSpectrumTexture / ConstantFloatTexture reference -> its value(s); back-references resolve through `seen`
+    std::vector<float> texture() {
+        uint32_t id = ms->readUInt(); if (id == 0) SLog(EError, "path_hip: missing texture inside a twosided BSDF");
+        if (seen.count(id)) return seen[id];
+        std::string cls = ms->readString(); std::vector<float> v;
+        if (cls == "ConstantSpectrumTexture") { Spectrum sp(ms.get()); Float r, g, b; sp.toLinearRGB(r, g, b); v = {(float) r, (float) g, (float) b}; }
+        else if (cls == "ConstantFloatTexture") v = {(float) ms->readFloat()};
+        else SLog(EError, "path_hip: texture \"%s\" inside a twosided BSDF is not implemented (constant values only)", cls.c_str());
+        seen[id] = v; return v;
+    }
+    void rgb(float *dst) { Spectrum sp(ms.get()); Float r, g, b; sp.toLinearRGB(r, g, b); dst[0] = r; dst[1] = g; dst[2] = b; }
+};
+static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
+    NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
+    mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
+    rd.ms->readUInt(); if (rd.ms->readString() != "TwoSidedBRDF") return false;
+    rd.ms->readBool();                                                  // BSDF::serialize: m_ensureEnergyConservation (bsdf.cpp:43-46)
+    uint32_t id0 = rd.ms->readUInt(); std::string cls = rd.ms->readString(); rd.ms->readBool();
+    memset(&m, 0, sizeof(m)); m.flags = MI_BSDF_FLAG_TWOSIDED;
+    if (cls == "RoughConductor") {
+        uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
+        std::vector<float> au = rd.texture(), av = rd.texture(), spec = rd.texture();
+        if (distr > 1 || !sampleVisible || au[0] != av[0]) SLog(EError, "path_hip: roughconductor is implemented for isotropic beckmann / ggx with sampleVisible = true");
+        m.type = MI_BSDF_ROUGHCONDUCTOR; m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = au[0];
+        memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
+    } else if (cls == "SmoothConductor") {
+        std::vector<float> spec = rd.texture(); m.type = MI_BSDF_CONDUCTOR; memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
+    } else if (cls == "SmoothPlastic") {
+        m.type = MI_BSDF_PLASTIC; m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
+        std::vector<float> spec = rd.texture(), diff = rd.texture(); memcpy(m.specular, spec.data(), 12); memcpy(m.reflectance, diff.data(), 12);
+        m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
+    } else return false;                                                // twosided(diffuse) and anything else: the generic component check below
+    if (rd.ms->readUInt() != id0) SLog(EError, "path_hip: twosided with two different nested BSDFs is not implemented");
+    return true;
+}
+
 /// BSDF -> mi_material.  Only what the hot path implements; anything else is reported, never silently approximated.
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
+    if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
     if (bsdf->getClass()->getName() == "RoughConductor") {
         // same derivation as RoughConductor's constructor (src/bsdfs/roughconductor.cpp:170-207): eta / k from the properties or from
         // data/ior/<material>.{eta,k}.spd, divided by the exterior IOR; isotropic alpha; Beckmann / GGX with visible-normal sampling
@@ -65,12 +111,41 @@ static mi_material convertBSDF(const BSDF *bsdf) {
         spec.toLinearRGB(r, g, b); m.specular[0] = r; m.specular[1] = g; m.specular[2] = b;
         return m;
     }
+    {   // smooth conductor / dielectric / plastic: parameters as their constructors derive them (conductor.cpp:155-178, dielectric.cpp:150-167, plastic.cpp:147-168, 199-201)
+        const std::string cls = bsdf->getClass()->getName(); const Properties &props = bsdf->getProperties(); Float r, g, b;
+        auto rgb3 = [&](const Spectrum &sp, float *dst) { sp.toLinearRGB(r, g, b); dst[0] = r; dst[1] = g; dst[2] = b; };
+        if (cls == "SmoothConductor") {
+            std::string material = props.getString("material", "Cu"), lower = material; std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
+            Spectrum intEta, intK;
+            if (lower == "none") { intEta = Spectrum(0.0f); intK = Spectrum(1.0f); }
+            else {
+                ref<FileResolver> fr = Thread::getThread()->getFileResolver();
+                intEta.fromContinuousSpectrum(InterpolatedSpectrum(fr->resolve(fs::pathstr("data/ior/" + material + ".eta.spd"))));
+                intK.fromContinuousSpectrum(InterpolatedSpectrum(fr->resolve(fs::pathstr("data/ior/" + material + ".k.spd"))));
+            }
+            Float extEta = lookupIOR(props, "extEta", "air");
+            m.type = MI_BSDF_CONDUCTOR; rgb3(props.getSpectrum("eta", intEta) / extEta, m.eta); rgb3(props.getSpectrum("k", intK) / extEta, m.k);
+            rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular);
+            return m;
+        }
+        if (cls == "SmoothDielectric") {
+            m.type = MI_BSDF_DIELECTRIC; m.eta[0] = lookupIOR(props, "intIOR", "bk7") / lookupIOR(props, "extIOR", "air");
+            rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.reflectance);
+            return m;
+        }
+        if (cls == "SmoothPlastic") {
+            m.type = MI_BSDF_PLASTIC; m.eta[0] = lookupIOR(props, "intIOR", "polypropylene") / lookupIOR(props, "extIOR", "air");
+            m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
+            if (props.getBoolean("nonlinear", false)) m.flags |= MI_BSDF_FLAG_NONLINEAR;
+            rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("diffuseReflectance", Spectrum(0.5f)), m.reflectance);
+            return m;
+        }
+    }
     bool backSide = false;
     for (int i = 0; i < bsdf->getComponentCount(); ++i) {
         unsigned int type = bsdf->getType(i);
         if (!(type & BSDF::EDiffuseReflection))
-            SLog(EError, "path_hip: BSDF \"%s\" has a non-diffuse lobe; implemented: diffuse (optionally twosided) and un-wrapped roughconductor "
-                         "(a twosided wrapper does not expose its nested BSDF's parameters)", bsdf->getClass()->getName().c_str());
+            SLog(EError, "path_hip: BSDF \"%s\" is not implemented (diffuse, roughconductor, conductor, dielectric, plastic; all but dielectric optionally twosided)", bsdf->getClass()->getName().c_str());
         backSide |= (type & BSDF::EBackSide) != 0;
     }
     Intersection its; its.uv = Point2(0.5f); its.p = Point(0.0f); its.hasUVPartials = false;

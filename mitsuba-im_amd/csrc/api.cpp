@@ -135,7 +135,9 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *a, uint32_t n) {
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_ROUGHCONDUCTOR) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: only `diffuse` and `roughconductor` (optionally `twosided`) are implemented");
+        if (m[i].type > MI_BSDF_PLASTIC) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic (all but dielectric optionally twosided)");
+        if (m[i].type == MI_BSDF_DIELECTRIC && (m[i].flags & MI_BSDF_FLAG_TWOSIDED)) return fail(MI_ERR_INVALID, "Only BSDFs without a transmission component can be nested!");   // twosided.cpp:86-88
+        if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
         if (m[i].type == MI_BSDF_ROUGHCONDUCTOR && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE)))
             return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: roughconductor supports beckmann / ggx with sampleVisible = true");
     }
@@ -231,7 +233,7 @@ int SceneHost::upload(int dev) {
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
-    d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type == MI_BSDF_ROUGHCONDUCTOR) d.has_roughconductor = 1;
+    d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1;   // any non-diffuse material -> k_shade<RC = true>
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     for (int i = 0; i < 3; ++i) d.packet_k[i] = packetK[i];

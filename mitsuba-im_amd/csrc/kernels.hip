@@ -291,6 +291,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             float prevPdf = q.st2[buf][slot];
             pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
             depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
+            const bool prevDelta = RC && ((s0.w >> 17) & 1u) != 0;      // the BSDF sample that spawned this ray was a delta component -> lumPdf = 0 (path.cpp:259-260)
             v3 d = V(rd.x, rd.y, rd.z); T = V(s1.x, s1.y, s1.z); eta = s1.w;
             const uint32_t prim = __float_as_uint(hr.w);
             v3 add = V(0, 0, 0); bool haveAdd = false;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                                 if (sc.env_constant) {      // ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233): needs the reference normal of the previous vertex
                                     const float c = q.st3[buf][slot]; pdfSA = c != 2.0f ? MI_INV_PI * maxf(0.0f, c) : MI_INV_FOURPI;
                                 } else pdfSA = envPdfDirection(sc, mat3(sc.env_to_local, d));
-                                float lumPdf = pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+                                float lumPdf = prevDelta ? 0.0f : pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
                                 add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                             }
                         }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 if (depth > 1) {
                     if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
                         v3 value = emitterEval(tb, h.emitter, h.ns, -d);
-                        float lumPdf = pdfEmitterDirect<AN>(sc, tb, h.emitter, ro3, d, h.ns, h.dist, facingRef);
+                        float lumPdf = prevDelta ? 0.0f : pdfEmitterDirect<AN>(sc, tb, h.emitter, ro3, d, h.ns, h.dist, facingRef);
                         add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                     }
                     const int prevDepth = depth - 1;                         // rRec.depth++ >= m_rrDepth (path.cpp:276)
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             // BSDF sampling (path.cpp:207-226)
             float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
             float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-            v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, woL, bPdf, bEta);
+            bool sampledDelta;
+            v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, woL, bPdf, bEta, sampledDelta);
             v3 wo = toWorld(h, woL);
             if (isZero(bw) || (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0)) pathLen += (unsigned) depth;
             else {
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 const float cosRef = dot(wo, refN);
                 uint32_t fl = cosRef >= 0 ? 1u : 0u;
                 nS3 = (h.flags & 2u) ? 2.0f : cosRef;
-                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16));
+                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16) | ((RC && sampledDelta) ? (1u << 17) : 0u));
                 nS1 = make_float4(T.x, T.y, T.z, eta); nS2 = bPdf;
             }
         }

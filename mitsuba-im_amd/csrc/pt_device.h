@@ -589,26 +589,113 @@ DEV v3 rcSample(const MaterialD &mt, v3 wi, float u, float v, v3 &wo, float &pdf
     return F * weight;
 }
 
+// ---------------------------------------------------------------------------------------------- smooth conductor / dielectric / plastic
+// src/bsdfs/conductor.cpp:212-286, dielectric.cpp:224-342, plastic.cpp:248-453; eval / pdf are the solid-angle-measure versions the integrator
+// calls while sampling emitters (delta components contribute 0 there).  MaterialD fields: conductor eta[3], k[3], specular[3]; dielectric
+// eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance; plastic eta[0], specular, reflectance =
+// diffuseReflectance, k[0] = fresnelDiffuseReflectance(1 / eta) (m_fdrInt, plastic.cpp:200), flags bit2 = nonlinear.
+#define MI_BSDF_T_ROUGHCONDUCTOR 1u
+#define MI_BSDF_T_CONDUCTOR 2u
+#define MI_BSDF_T_DIELECTRIC 3u
+#define MI_BSDF_T_PLASTIC 4u
+// src/libcore/util.cpp:653-683 fresnelDielectricExt
+DEV float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtf(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+DEV v3 conductorSample(const MaterialD &m, v3 wi, v3 &wo, float &pdf, float &eta, bool &delta) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    wo = V(-wi.x, -wi.y, wi.z); eta = 1.0f; pdf = 1; delta = true;
+    return ld3(m.specular) * fresnelConductorExact(wi.z, m.eta, m.k);
+}
+DEV v3 dielectricSample(const MaterialD &m, v3 wi, float sx, v3 &wo, float &pdf, float &etaOut, bool &delta) {
+    const float eta = m.eta[0], invEta = 1 / eta; float cosThetaT;
+    float F = fresnelDielectricExt(wi.z, cosThetaT, eta);
+    delta = true;
+    if (sx <= F) { wo = V(-wi.x, -wi.y, wi.z); etaOut = 1.0f; pdf = F; return ld3(m.specular); }
+    float scale_ = -(cosThetaT < 0 ? invEta : eta);
+    wo = V(scale_ * wi.x, scale_ * wi.y, cosThetaT);
+    etaOut = cosThetaT < 0 ? eta : invEta; pdf = 1 - F;
+    float factor = cosThetaT < 0 ? invEta : eta;
+    return ld3(m.reflectance) * (factor * factor);
+}
+DEV float luminance3(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
+DEV float plasticProbSpecular(const MaterialD &m, float Fi) {       // plastic.cpp:204-207 + :301-304
+    float dAvg = luminance3(ld3(m.reflectance)), sAvg = luminance3(ld3(m.specular)), w = sAvg / (dAvg + sAvg);
+    return (Fi * w) / (Fi * w + (1 - Fi) * (1 - w));
+}
+DEV v3 plasticDiffuse(const MaterialD &m) {
+    v3 diff = ld3(m.reflectance); const float fdrInt = m.k[0];
+    if (m.flags & 4u) return V(diff.x / (1.0f - diff.x * fdrInt), diff.y / (1.0f - diff.y * fdrInt), diff.z / (1.0f - diff.z * fdrInt));
+    float r = 1.0f / (1 - fdrInt); return diff * r;
+}
+DEV v3 plasticEval(const MaterialD &m, v3 wi, v3 wo) {
+    if (wo.z <= 0 || wi.z <= 0) return V(0, 0, 0);
+    const float eta = m.eta[0], invEta2 = 1 / (eta * eta); float ct;
+    float Fi = fresnelDielectricExt(wi.z, ct, eta), Fo = fresnelDielectricExt(wo.z, ct, eta);
+    return plasticDiffuse(m) * (MI_INV_PI * wo.z * invEta2 * (1 - Fi) * (1 - Fo));
+}
+DEV float plasticPdf(const MaterialD &m, v3 wi, v3 wo) {
+    if (wo.z <= 0 || wi.z <= 0) return 0.0f;
+    float ct, Fi = fresnelDielectricExt(wi.z, ct, m.eta[0]);
+    return MI_INV_PI * wo.z * (1 - plasticProbSpecular(m, Fi));
+}
+DEV v3 plasticSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float &pdf, float &etaOut, bool &delta) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    const float eta = m.eta[0], invEta2 = 1 / (eta * eta); float ct;
+    float Fi = fresnelDielectricExt(wi.z, ct, eta);
+    etaOut = 1.0f;
+    float probSpecular = plasticProbSpecular(m, Fi);
+    if (sx < probSpecular) {
+        wo = V(-wi.x, -wi.y, wi.z); pdf = probSpecular; delta = true;
+        float r = 1.0f / probSpecular; return (ld3(m.specular) * Fi) * r;
+    }
+    wo = cosHemisphere((sx - probSpecular) / (1 - probSpecular), sy);
+    float Fo = fresnelDielectricExt(wo.z, ct, eta);
+    pdf = (1 - probSpecular) * (MI_INV_PI * wo.z);
+    return plasticDiffuse(m) * (invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
+}
+
 // ---------------------------------------------------------------------------------------------- BSDFs
-// src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side)
+// src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side).  RC = the scene holds non-diffuse materials
+// (rough conductor, conductor, dielectric, plastic): the diffuse-only kernel variants carry none of that code.
 template <bool RC> DEV v3 bsdfEval(const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
-    if (RC && m.type == 1) return rcEval(m, wi, wo);
+    if (RC && m.type != 0) {
+        if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) return rcEval(m, wi, wo);
+        if (m.type == MI_BSDF_T_PLASTIC) return plasticEval(m, wi, wo);
+        return V(0, 0, 0);
+    }
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
     float f = MI_INV_PI * wo.z;
     return V(m.reflectance[0] * f, m.reflectance[1] * f, m.reflectance[2] * f);
 }
 template <bool RC> DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
-    if (RC && m.type == 1) return rcPdf(m, wi, wo);
+    if (RC && m.type != 0) {
+        if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) return rcPdf(m, wi, wo);
+        if (m.type == MI_BSDF_T_PLASTIC) return plasticPdf(m, wi, wo);
+        return 0.0f;
+    }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
     return MI_INV_PI * wo.z;
 }
-template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta) {
-    bool flipped = false;
+// delta = the sampled component is a Dirac delta (bRec.sampledType & BSDF::EDelta, path.cpp:259-260)
+template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta, bool &delta) {
+    bool flipped = false; delta = false;
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; flipped = true; }
-    if (RC && m.type == 1) {
-        v3 w = rcSample(m, wi, u, v, wo, pdf, eta);
+    if (RC && m.type != 0) {
+        v3 w;
+        if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) w = rcSample(m, wi, u, v, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_CONDUCTOR) w = conductorSample(m, wi, wo, pdf, eta, delta);
+        else if (m.type == MI_BSDF_T_DIELECTRIC) w = dielectricSample(m, wi, u, wo, pdf, eta, delta);
+        else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);
         if (flipped && !isZero(w) && pdf != 0) wo.z = -wo.z;      // twosided.cpp:176-180
         return w;
     }

@@ -160,10 +160,13 @@ void SceneHost::commitHost() {
     std::vector<V3> tlo(np), thi(np), cen(np);
     auto materialFlags = [&](int bsdf) {
         const mi_material &mat = materials[bsdf];
-        bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0;
-        // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176)
-        bool smooth = mat.type != MI_BSDF_DIFFUSE || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0;
-        return (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type == MI_BSDF_ROUGHCONDUCTOR ? 8u : 0u);
+        // dRec.refN = 0 when the BSDF has ETransmission or EBackSide (records.inl:160-164): twosided wrapper, dielectric
+        bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC;
+        // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
+        // conductor / dielectric register delta components only
+        bool smooth = mat.type == MI_BSDF_DIFFUSE ? std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0
+                                                  : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC);
+        return (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type != MI_BSDF_DIFFUSE ? 8u : 0u);
     };
     for (uint32_t t = 0; t < nt; ++t) {
         uint32_t a = idx[t * 3], b = idx[t * 3 + 1], c = idx[t * 3 + 2];

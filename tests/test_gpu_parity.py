@@ -338,3 +338,22 @@ def test_scene_level_emitters(mi, oracle, golden_scenes, name):
     assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["cbox_materials", "cbox_materials_strict_indep"])
+def test_smooth_bsdfs(mi, oracle, golden_scenes, name):
+    """SURVEY.md §8f-2 BSDFs: `dielectric` (delta reflection + refraction, eta tracking for Russian roulette, radiance scaling), smooth
+    `conductor`, `plastic` (delta coat over a diffuse base, linear and nonlinear), `twosided(conductor)`.  None of them calls the math library
+    (Fresnel terms are +, *, /, sqrt), so the GPU equals the oracle bit for bit; vs the reference within float rounding."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(8); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    assert (bits(got) == bits(ref)).all()
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 2e-4).mean() > 0.995 and (np.abs(got - gd["li"]).max(1) < 1e-4 * (1 + np.abs(gd["li"]).max(1))).all()
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-4
