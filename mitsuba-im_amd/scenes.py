@@ -112,7 +112,7 @@ def sample_to_camera(xfov_deg, near, far, aspect):
 def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near, far, width, height,
                  spp, sampler, max_depth, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
                  normals=None, uvs=None, strict_normals=False, hide_emitters=False, envmap=None,
-                 name="scene", analytic=None):
+                 name="scene", analytic=None, instances=None):
     sc = Scene()
     sc.name = name
     sc.pos = np.ascontiguousarray(np.asarray(verts, dtype=f32).reshape(-1, 3))
@@ -133,6 +133,7 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
     sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)
     sc.envmap = envmap          # None or dict(rgb[h,w,3] f32, to_world[4,4], scale)
+    sc.instances = list(instances or [])  # placements of shape groups (make_instance); shapes carry "group" = g + 1 when they belong to group g
     sc.analytic = list(analytic or [])   # analytic shapes (make_analytic); shape index of the i-th = len(shapes) + i; primitive index = len(idx) + i
     tri_shape = np.zeros(len(sc.idx), dtype=np.uint32)
     for si, s in enumerate(shapes):
@@ -166,6 +167,12 @@ def make_analytic(kind, to_world, bsdf, emitter=-1, flip=False, radius=1.0, leng
     to = np.ascontiguousarray(np.linalg.inv(tw.astype(np.float64)), dtype=f32)
     return dict(type=int(kind), bsdf=int(bsdf), emitter=int(emitter), flags=int(bool(flip)), to_world=tw, to_object=to,
                 radius=float(f32(radius)), length=float(f32(length)))
+
+
+def make_instance(group, to_world):
+    """src/shapes/instance.cpp: placement of shape group `group` (0-based); to_object as the reference's Transform::inverse would hold it."""
+    tw = np.ascontiguousarray(to_world, dtype=f32)
+    return dict(group=int(group), to_world=tw, to_object=np.ascontiguousarray(np.linalg.inv(tw.astype(np.float64)), dtype=f32))
 
 
 def _coordinate_system(a):
@@ -218,7 +225,7 @@ class _Builder:
     def quad(self, pts):
         _quad(self.verts, self.tris, None, [tuple(map(float, p)) for p in pts])
 
-    def end(self, bsdf, radiance=None, face_normals=True):
+    def end(self, bsdf, radiance=None, face_normals=True, group=0):
         em = -1
         si = len(self.shapes)
         if radiance is not None:
@@ -226,7 +233,7 @@ class _Builder:
             em = len(self.emitters) - 1
         self.shapes.append(dict(first_tri=self._ft, tri_count=len(self.tris) - self._ft,
                                 first_vert=self._fv, vert_count=len(self.verts) - self._fv,
-                                bsdf=bsdf, emitter=em, face_normals=int(face_normals)))
+                                bsdf=bsdf, emitter=em, face_normals=int(face_normals), group=int(group)))
 
 
 def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5,
@@ -327,6 +334,66 @@ def cbox_materials(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth
     cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth,
                         seed=seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_materials", analytic=b.resolve_analytic())
+
+
+def instanced_garden(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, n_side=4, smooth=True):
+    """`shapegroup` + `instance`: two shape groups -- a smooth-shaded "bush" (octahedral blob with vertex normals) and a
+    face-normal "crate" with a rough-conductor lid -- placed n_side x n_side times with rotation, non-uniform scale and shear-free tilts,
+    over a mesh floor, lit by an area light and a constant sky."""
+    b = _Builder()
+    ground = b.bsdf(reflectance=(0.45, 0.5, 0.4)); leaf = b.bsdf(reflectance=(0.2, 0.55, 0.15), twosided=True); wood = b.bsdf(reflectance=(0.5, 0.33, 0.18))
+    eta, k = CONDUCTOR_IOR["Cu"]; lid = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.12, distr=DISTR_GGX, eta=eta, k=k)
+    lightm = b.bsdf(reflectance=(0.5, 0.5, 0.5))
+    b.begin(); b.quad([(8, 0, -8), (-8, 0, -8), (-8, 0, 8), (8, 0, 8)]); b.end(ground)
+    b.begin(); b.quad([(1.5, 6, -1.5), (1.5, 6, 1.5), (-1.5, 6, 1.5), (-1.5, 6, -1.5)]); b.end(lightm, radiance=(30.0, 28.0, 24.0))
+    normals = [(0.0, 1.0, 0.0)] * len(b.verts)
+    # group 0: bush = subdivided octahedron pushed to a bumpy sphere, vertex normals
+    b.begin(); base = len(b.verts)
+    P = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    F = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    pts = [np.asarray(p, np.float64) for p in P]; faces = list(F)
+    for _ in range(2):
+        nf = []; cache = {}
+        def mid(i, j):
+            key = (min(i, j), max(i, j))
+            if key not in cache:
+                m = pts[i] + pts[j]; pts.append(m / np.linalg.norm(m)); cache[key] = len(pts) - 1
+            return cache[key]
+        for (a, c, e) in faces:
+            ab, ce, ea = mid(a, c), mid(c, e), mid(e, a); nf += [(a, ab, ea), (ab, c, ce), (ea, ce, e), (ab, ce, ea)]
+        faces = nf
+    for p in pts:
+        r = 0.5 * (1.0 + 0.18 * math.sin(5 * p[0]) * math.cos(4 * p[1] + 1.0) + 0.1 * math.sin(7 * p[2]))
+        q = p * r + np.array([0.0, 0.5, 0.0]); b.verts.append(tuple(map(float, q))); normals.append(tuple(map(float, p)))
+    for (a, c, e) in faces: b.tris.append((base + a, base + c, base + e))
+    b.end(leaf, face_normals=False, group=1)
+    # group 1: crate (5 wooden faces) + metal lid
+    def box(x0, y0, z0, x1, y1, z1, top):
+        q = []
+        if top: q.append([(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)])
+        else:
+            q += [[(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)], [(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)],
+                  [(x1, y0, z1), (x1, y1, z1), (x0, y1, z1), (x0, y0, z1)], [(x0, y0, z1), (x0, y1, z1), (x0, y1, z0), (x0, y0, z0)]]
+        return q
+    b.begin()
+    for qd in box(-0.4, 0.0, -0.3, 0.4, 0.5, 0.3, False): b.quad(qd)
+    n0 = len(b.verts); b.end(wood, group=2)
+    b.begin()
+    for qd in box(-0.4, 0.0, -0.3, 0.4, 0.5, 0.3, True): b.quad(qd)
+    b.end(lid, group=2)
+    normals += [(0.0, 1.0, 0.0)] * (len(b.verts) - len(normals))
+    rng = np.random.default_rng(12345 + seed); inst = []
+    for iz in range(n_side):
+        for ix in range(n_side):
+            x = (ix - (n_side - 1) / 2) * 2.6 + rng.uniform(-0.4, 0.4); z = (iz - (n_side - 1) / 2) * 2.6 + rng.uniform(-0.4, 0.4)
+            g = int((ix + iz) % 2)
+            m = translate(x, 0.0, z) @ rotate((0, 1, 0), rng.uniform(0, 360)) @ rotate((1, 0, 0), rng.uniform(-8, 8) if g == 0 else 0.0) @ \
+                scale(rng.uniform(0.8, 1.5), rng.uniform(0.8, 1.6), rng.uniform(0.8, 1.5))
+            inst.append(make_instance(g, m))
+    cam = look_at((0.5, 4.5, -9.5), (0.0, 0.4, 0.0), (0, 1, 0))
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 45.0, 0.05, 200.0, width, height, spp, sampler, max_depth, rr_depth,
+                      seed=seed, normals=normals, name="instanced_garden", instances=inst)
+    return add_scene_emitters(sc, [constant_emitter((0.25, 0.3, 0.4))])
 
 
 def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
@@ -591,7 +658,7 @@ def save_scene(sc, path):
         f.write(sc.idx.tobytes())
         for s in sc.shapes:
             f.write(struct.pack("<4I2i2I", s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"],
-                                s["bsdf"], s["emitter"], s["face_normals"], 0))
+                                s["bsdf"], s["emitter"], s["face_normals"], s.get("group", 0)))
         for b in sc.bsdfs:
             f.write(struct.pack("<4I", b["type"], b["twosided"], b["distr"], b["sample_visible"]))
             f.write(struct.pack("<13f", *b["reflectance"], b["alpha"], *b["eta"], *b["k"], *b["specular"]))
@@ -616,3 +683,7 @@ def save_scene(sc, path):
                 f.write(struct.pack("<I2iI", a["type"], a["bsdf"], a["emitter"], a["flags"]))
                 f.write(a["to_world"].tobytes()); f.write(a["to_object"].tobytes())
                 f.write(struct.pack("<2f", a["radius"], a["length"]))
+        if sc.get("instances"):
+            f.write(b"INST"); f.write(struct.pack("<I", len(sc.instances)))
+            for a in sc.instances:
+                f.write(struct.pack("<4I", a["group"], 0, 0, 0)); f.write(a["to_world"].tobytes()); f.write(a["to_object"].tobytes())

@@ -11,7 +11,11 @@ GOLDEN = os.path.join(os.path.dirname(_HERE), "tests", "golden")
 
 class OrcShape(C.Structure):
     _fields_ = [("first_tri", C.c_uint32), ("tri_count", C.c_uint32), ("first_vert", C.c_uint32), ("vert_count", C.c_uint32),
-                ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32), ("pad", C.c_uint32)]
+                ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32), ("group", C.c_uint32)]
+
+
+class OrcInstance(C.Structure):
+    _fields_ = [("group", C.c_uint32), ("pad", C.c_uint32 * 3), ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
 
 
 class OrcMaterial(C.Structure):
@@ -40,7 +44,7 @@ class OrcSceneDesc(C.Structure):
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
-                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p)]
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p)]
 
 
 def build():
@@ -106,7 +110,7 @@ def pack_records(sc):
     """Flattened scene (mitsuba-im_amd/scenes.py Scene) -> arrays of the C records (same layout for oracle and product)."""
     shapes = (OrcShape * len(sc.shapes))()
     for i, s in enumerate(sc.shapes):
-        shapes[i] = OrcShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, 0)
+        shapes[i] = OrcShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, s.get("group", 0))
     mats = (OrcMaterial * len(sc.bsdfs))()
     for i, b in enumerate(sc.bsdfs):
         m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((b["sample_visible"] & 1) << 1) | ((b.get("nonlinear", 0) & 1) << 2), b["distr"], b["alpha"])
@@ -119,6 +123,14 @@ def pack_records(sc):
         em.to_world[:] = np.asarray(e.get("to_world", np.eye(4)), np.float32).reshape(-1).tolist()
         ems[i] = em
     return shapes, mats, ems
+
+
+def pack_instances(sc):
+    recs = sc.get("instances") or []
+    arr = (OrcInstance * max(1, len(recs)))()
+    for i, a in enumerate(recs):
+        r = OrcInstance(a["group"]); r.to_world[:] = a["to_world"].reshape(-1).tolist(); r.to_object[:] = a["to_object"].reshape(-1).tolist(); arr[i] = r
+    return arr, len(recs)
 
 
 def pack_analytic(sc):
@@ -160,6 +172,8 @@ class Oracle:
             d.env_to_world[:] = np.asarray(sc.envmap["to_world"], np.float32).reshape(-1).tolist()
         an, n_an = pack_analytic(sc); self._keep.append(an)
         d.n_analytic, d.analytic = n_an, C.cast(an, C.c_void_p)
+        ins, n_ins = pack_instances(sc); self._keep.append(ins)
+        d.n_instances, d.instances = n_ins, C.cast(ins, C.c_void_p)
         self.h = L.orc_scene_create(C.byref(d))
         self.border = L.orc_film_border(self.h)
 
@@ -185,7 +199,7 @@ class Oracle:
         o = np.zeros(8, np.float32); lib().orc_camera_ray(self.h, sx, sy, _ptr(o)); return o
 
     def intersect(self, ray8, brute=False):
-        ray8 = np.ascontiguousarray(ray8, np.float32); out = np.zeros(20, np.float32)
+        ray8 = np.ascontiguousarray(ray8, np.float32); out = np.zeros(24, np.float32)
         f = lib().orc_ray_intersect_brute if brute else lib().orc_ray_intersect
         ok = f(self.h, _ptr(ray8), _ptr(out)); return bool(ok), out
 

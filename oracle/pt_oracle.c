@@ -47,14 +47,16 @@ typedef struct { uint32_t k; float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_
 typedef struct { v3 lo, hi; int32_t left, right, first, count; } bvh_node;   /* leaf: count > 0 */
 
 typedef struct {
-    int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter;
+    int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter; int32_t instance;
 } hit_t;
 
 struct orc_scene {
     orc_scene_desc d;
     float *pos, *nrm; uint32_t *idx; orc_shape *shapes; orc_material *materials; orc_emitter *emitters;
     uint32_t *tri_shape;
-    struct analytic_s *analytic; uint32_t n_analytic, n_prims;   /* primitive index space: [0, n_tris) triangles, then the analytic shapes */
+    struct analytic_s *analytic; uint32_t n_analytic, n_prims;
+    orc_instance *instances; uint32_t n_instances, n_groups; int *group_root; v3 *group_lo, *group_hi;   /* per shape group: BVH root, kd-tree box (enlarged) */
+    uint32_t *group_first, *group_count;     /* per group: its range in group_prims (for the brute-force cross-check) */ uint32_t *group_prims;   /* primitive index space: [0, n_tris) triangles, then the analytic shapes */
     triaccel *accel;
     v3 aabb_lo, aabb_hi;            /* kd-tree root box incl. the reference's enlargement */
     bvh_node *nodes; uint32_t *bvh_tris; int n_nodes;
@@ -574,45 +576,71 @@ static inline int box_overlap(const bvh_node *n, v3 o, v3 inv, float mint, float
     }
     return t0 <= t1 * 1.0000005f + 1e-30f;
 }
-static inline int better(float t, uint32_t prim, float bt, uint32_t bprim) { return t < bt || (t == bt && prim < bprim); }
+static inline int better(float t, uint32_t prim, int32_t inst, float bt, uint32_t bprim, int32_t binst) { return t < bt || (t == bt && (prim < bprim || (prim == bprim && inst < binst))); }
 
-static int traverse(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int shadow, float *bt, uint32_t *bprim, float *bu, float *bv) {
-    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    int stack[128], sp = 0; stack[sp++] = 0;
-    int found = 0; float best = maxt; uint32_t bestPrim = 0xFFFFFFFFu;
-    while (sp) {
-        const bvh_node *n = &s->nodes[stack[--sp]];
-        if (!box_overlap(n, o, inv, mint, best)) continue;
-        if (n->count > 0) {
-            for (int i = 0; i < n->count; ++i) {
-                uint32_t prim = s->bvh_tris[n->first + i]; float u, v, t;
-                if (prim < s->d.n_tris ? triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t)
-                                       : analytic_intersect(&s->analytic[prim - s->d.n_tris], o, d, mint, best, shadow, &t, &u, &v)) {
-                    if (shadow) return 1;
-                    if (!found || better(t, prim, best, bestPrim)) { best = t; bestPrim = prim; *bu = u; *bv = v; found = 1; }
-                }
-            }
-        } else { stack[sp++] = n->left; stack[sp++] = n->right; }
-    }
-    if (found) { *bt = best; *bprim = bestPrim; }
-    return found;
+/* One primitive of a leaf: triangle (TriAccel), analytic shape or instance.  Instance::rayIntersect (src/shapes/instance.cpp:91-108): the ray
+ * goes to the group's object space (trafo.inverse()(ray)), then ShapeKDTree::rayIntersect(ray, mint, maxt, t, temp) / (ray, mint, maxt)
+ * (include/mitsuba/render/skdtree.h:431-452): clip [mint, maxt] against the group's kd-tree box, then walk the group's tree. */
+static int traverse_from(const orc_scene *s, int root, int brute_first, int brute_count, v3 o, v3 d, float mint, float maxt, int shadow,
+                         float *bt, uint32_t *bprim, int32_t *binst, float *bu, float *bv);
+static int prim_intersect(const orc_scene *s, uint32_t prim, v3 o, v3 d, float mint, float best, int shadow, int brute, float *t, uint32_t *hprim, int32_t *hinst, float *u, float *v) {
+    const uint32_t nt = s->d.n_tris, na = s->n_analytic;
+    *hprim = prim; *hinst = -1;
+    if (prim < nt) return triaccel_intersect(&s->accel[prim], o, d, mint, best, u, v, t);
+    if (prim < nt + na) return analytic_intersect(&s->analytic[prim - nt], o, d, mint, best, shadow, t, u, v);
+    const int32_t ii = (int32_t) (prim - nt - na); const orc_instance *in = &s->instances[ii]; const uint32_t g = in->group;
+    v3 o2 = xf_point(in->to_object, o), d2 = xf_vector(in->to_object, d);
+    float nearT, farT;
+    if (!aabb_ray(s->group_lo[g], s->group_hi[g], o2, d2, &nearT, &farT)) return 0;
+    float mi = mint > nearT ? mint : nearT, ma = best < farT ? best : farT;
+    if (!(ma > mi)) return 0;
+    int32_t dummy;
+    if (!traverse_from(s, brute ? -1 : s->group_root[g], (int) s->group_first[g], (int) s->group_count[g], o2, d2, mi, ma, shadow, t, hprim, &dummy, u, v)) return 0;
+    *hinst = ii; return 1;
 }
-static int traverse_brute(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int shadow, float *bt, uint32_t *bprim, float *bu, float *bv) {
-    int found = 0; float best = maxt; uint32_t bestPrim = 0xFFFFFFFFu;
-    for (uint32_t prim = 0; prim < s->n_prims; ++prim) {
-        float u, v, t;
-        if (prim < s->d.n_tris ? triaccel_intersect(&s->accel[prim], o, d, mint, best, &u, &v, &t)
-                               : analytic_intersect(&s->analytic[prim - s->d.n_tris], o, d, mint, best, shadow, &t, &u, &v)) {
-            if (shadow) return 1;
-            if (!found || better(t, prim, best, bestPrim)) { best = t; bestPrim = prim; *bu = u; *bv = v; found = 1; }
+/* root >= 0: walk the oracle's BVH from that node; root < 0: O(N) loop over group_prims[brute_first .. +brute_count) (cross-check) */
+static int traverse_from(const orc_scene *s, int root, int brute_first, int brute_count, v3 o, v3 d, float mint, float maxt, int shadow,
+                         float *bt, uint32_t *bprim, int32_t *binst, float *bu, float *bv) {
+    int found = 0; float best = maxt; uint32_t bestPrim = 0xFFFFFFFFu; int32_t bestInst = -1;
+    if (root < 0) {
+        for (int i = 0; i < brute_count; ++i) {
+            uint32_t prim = s->group_prims[brute_first + i], hp; int32_t hi; float u, v, t;
+            if (prim_intersect(s, prim, o, d, mint, best, shadow, 1, &t, &hp, &hi, &u, &v)) {
+                if (shadow) return 1;
+                if (!found || better(t, hp, hi, best, bestPrim, bestInst)) { best = t; bestPrim = hp; bestInst = hi; *bu = u; *bv = v; found = 1; }
+            }
+        }
+    } else {
+        v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        int stack[128], sp = 0; stack[sp++] = root;
+        while (sp) {
+            const bvh_node *n = &s->nodes[stack[--sp]];
+            if (!box_overlap(n, o, inv, mint, best)) continue;
+            if (n->count > 0) {
+                for (int i = 0; i < n->count; ++i) {
+                    uint32_t prim = s->bvh_tris[n->first + i], hp; int32_t hi; float u, v, t;
+                    if (prim_intersect(s, prim, o, d, mint, best, shadow, 0, &t, &hp, &hi, &u, &v)) {
+                        if (shadow) return 1;
+                        if (!found || better(t, hp, hi, best, bestPrim, bestInst)) { best = t; bestPrim = hp; bestInst = hi; *bu = u; *bv = v; found = 1; }
+                    }
+                }
+            } else { stack[sp++] = n->left; stack[sp++] = n->right; }
         }
     }
-    if (found) { *bt = best; *bprim = bestPrim; }
+    if (found) { *bt = best; *bprim = bestPrim; *binst = bestInst; }
     return found;
+}
+/* scene level: group 0 of the tables = the scene's own primitives */
+static int traverse(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int shadow, float *bt, uint32_t *bprim, int32_t *binst, float *bu, float *bv) {
+    return traverse_from(s, s->group_root[s->n_groups], 0, 0, o, d, mint, maxt, shadow, bt, bprim, binst, bu, bv);
+}
+static int traverse_brute(const orc_scene *s, v3 o, v3 d, float mint, float maxt, int shadow, float *bt, uint32_t *bprim, int32_t *binst, float *bu, float *bv) {
+    return traverse_from(s, -1, (int) s->group_first[s->n_groups], (int) s->group_count[s->n_groups], o, d, mint, maxt, shadow, bt, bprim, binst, bu, bv);
 }
 
 /* include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610 computeShadingFrame */
-static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, float u, float v, hit_t *h) {
+static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int32_t inst, float u, float v, hit_t *h) {
+    h->instance = inst;
     if (prim >= s->d.n_tris) {                       /* skdtree.h:421-427: shape->fillIntersectionRecord, computeShadingFrame, wi */
         const analytic_t *sh = &s->analytic[prim - s->d.n_tris]; v3 dpdu;
         h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
@@ -630,6 +658,11 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, flo
     float bx = 1 - u - v, by = u, bz = v;
     h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = prim - sh->first_tri; h->shape = shape;
     h->p = add(add(scale(p0, bx), scale(p1, by)), scale(p2, bz));
+    const orc_instance *in = inst >= 0 ? &s->instances[inst] : NULL;
+    if (in) {   /* Instance::fillIntersectionRecord (instance.cpp:126-141): fillIntersectionRecord<false> in object space -> p = ray(t) of the object-space ray */
+        v3 o2 = xf_point(in->to_object, o), d2 = xf_vector(in->to_object, d);
+        h->p = add(o2, scale(d2, t));
+    }
     v3 side1 = sub(p1, p0), side2 = sub(p2, p0);
     v3 fn = cross(side1, side2);
     float len = sqrtf(dot(fn, fn));
@@ -642,6 +675,10 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, flo
     } else h->ns = fn;
     h->ng = fn;
     v3 dpdu = side1;   /* no UV tangents: meshes on this path carry no texcoords (skdtree.h:373-380) */
+    if (in) {   /* instance.cpp:134-139: normals through the inverse transpose, dpdu / p through the forward transform; then the scene-level computeShadingFrame + wi */
+        h->ns = normalize(xf_normal(in->to_object, h->ns)); h->ng = normalize(xf_normal(in->to_object, h->ng));
+        dpdu = xf_vector(in->to_world, dpdu); h->p = xf_point(in->to_world, h->p);
+    }
     h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
     h->tt = cross(h->ns, h->s);
     v3 md = neg(d);
@@ -652,19 +689,19 @@ static int g_brute = 0;
 void orc_set_brute(int b) { g_brute = b; }
 static int ray_intersect(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt, hit_t *h, int brute) {
     brute |= g_brute;
-    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0;
+    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0; int32_t inst = -1;
     h->valid = 0;
     if (!clip_interval(s, o, d, rmint, rmaxt, 0, &mint, &maxt)) return 0;
-    int found = brute ? traverse_brute(s, o, d, mint, maxt, 0, &t, &prim, &u, &v) : traverse(s, o, d, mint, maxt, 0, &t, &prim, &u, &v);
+    int found = brute ? traverse_brute(s, o, d, mint, maxt, 0, &t, &prim, &inst, &u, &v) : traverse(s, o, d, mint, maxt, 0, &t, &prim, &inst, &u, &v);
     if (!found) return 0;
-    fill_hit(s, o, d, t, prim, u, v, h);
+    fill_hit(s, o, d, t, prim, inst, u, v, h);
     return 1;
 }
 static int ray_occluded(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt) {
-    float mint, maxt, t, u, v; uint32_t prim;
+    float mint, maxt, t, u, v; uint32_t prim; int32_t inst;
     if (!clip_interval(s, o, d, rmint, rmaxt, 1, &mint, &maxt)) return 0;
-    if (g_brute) return traverse_brute(s, o, d, mint, maxt, 1, &t, &prim, &u, &v);
-    return traverse(s, o, d, mint, maxt, 1, &t, &prim, &u, &v);
+    if (g_brute) return traverse_brute(s, o, d, mint, maxt, 1, &t, &prim, &inst, &u, &v);
+    return traverse(s, o, d, mint, maxt, 1, &t, &prim, &inst, &u, &v);
 }
 static v3 to_world(const hit_t *h, v3 w) { return add(add(scale(h->s, w.x), scale(h->tt, w.y)), scale(h->ns, w.z)); }
 static v3 to_local(const hit_t *h, v3 w) { return V(dot(w, h->s), dot(w, h->tt), dot(w, h->ns)); }
@@ -672,7 +709,7 @@ static v3 to_local(const hit_t *h, v3 w) { return V(dot(w, h->s), dot(w, h->tt),
 static void hit_out(const hit_t *h, float *o) {
     o[0] = h->t; o[1] = h->p.x; o[2] = h->p.y; o[3] = h->p.z; o[4] = h->ng.x; o[5] = h->ng.y; o[6] = h->ng.z;
     o[7] = h->ns.x; o[8] = h->ns.y; o[9] = h->ns.z; o[10] = h->s.x; o[11] = h->s.y; o[12] = h->s.z;
-    o[13] = h->u; o[14] = h->v; o[15] = h->wi.x; o[16] = h->wi.y; o[17] = h->wi.z; o[18] = (float) h->prim; o[19] = (float) h->shape;
+    o[13] = h->u; o[14] = h->v; o[15] = h->wi.x; o[16] = h->wi.y; o[17] = h->wi.z; o[18] = (float) h->prim; o[19] = (float) h->shape; o[20] = (float) h->instance;
 }
 int orc_ray_intersect(const orc_scene *s, const float *r, float *out) { hit_t h; int ok = ray_intersect(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7], &h, 0); if (ok) hit_out(&h, out); return ok; }
 int orc_ray_intersect_brute(const orc_scene *s, const float *r, float *out) { hit_t h; int ok = ray_intersect(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7], &h, 1); if (ok) hit_out(&h, out); return ok; }
@@ -1476,12 +1513,18 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->tri_shape[s->shapes[i].first_tri + t] = i;
     /* TriAccel table (skdtree.cpp:79-105) + scene box (union of mesh AABBs, enlarged as in gkdtree.h:1213-1220) */
     s->accel = (triaccel *) calloc(d->n_tris ? d->n_tris : 1, sizeof(triaccel));
-    s->n_analytic = d->analytic ? d->n_analytic : 0; s->n_prims = d->n_tris + s->n_analytic;
+    s->n_analytic = d->analytic ? d->n_analytic : 0; s->n_instances = d->instances ? d->n_instances : 0;
+    s->n_prims = d->n_tris + s->n_analytic + s->n_instances;
     s->analytic = (analytic_t *) calloc(s->n_analytic ? s->n_analytic : 1, sizeof(analytic_t));
     for (uint32_t i = 0; i < s->n_analytic; ++i) { s->analytic[i].a = d->analytic[i]; analytic_prepare(&s->analytic[i]); }
-    s->d.analytic = NULL;
-    v3 lo = V(INFINITY, INFINITY, INFINITY), hi = V(-INFINITY, -INFINITY, -INFINITY);
-    v3 *cent = (v3 *) calloc(s->n_prims, sizeof(v3)), *tlo = (v3 *) calloc(s->n_prims, sizeof(v3)), *thi = (v3 *) calloc(s->n_prims, sizeof(v3));
+    s->instances = (orc_instance *) dup(d->instances, s->n_instances * sizeof(orc_instance));
+    s->d.analytic = NULL; s->d.instances = NULL;
+    s->n_groups = 0;
+    for (uint32_t i = 0; i < d->n_shapes; ++i) if (s->shapes[i].group > s->n_groups) s->n_groups = s->shapes[i].group;
+    const uint32_t ng = s->n_groups;                                 /* table slot ng = the scene level */
+    s->group_root = (int *) calloc(ng + 1, sizeof(int)); s->group_lo = (v3 *) calloc(ng + 1, sizeof(v3)); s->group_hi = (v3 *) calloc(ng + 1, sizeof(v3));
+    s->group_first = (uint32_t *) calloc(ng + 1, 4); s->group_count = (uint32_t *) calloc(ng + 1, 4);
+    v3 *cent = (v3 *) calloc(s->n_prims ? s->n_prims : 1, sizeof(v3)), *tlo = (v3 *) calloc(s->n_prims ? s->n_prims : 1, sizeof(v3)), *thi = (v3 *) calloc(s->n_prims ? s->n_prims : 1, sizeof(v3));
     for (uint32_t t = 0; t < d->n_tris; ++t) {
         v3 a = vert(s, s->idx[t * 3]), b = vert(s, s->idx[t * 3 + 1]), c = vert(s, s->idx[t * 3 + 2]);
         triaccel_load(&s->accel[t], a, b, c);
@@ -1489,13 +1532,18 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
         thi[t] = V(maxf(maxf(a.x, b.x), c.x), maxf(maxf(a.y, b.y), c.y), maxf(maxf(a.z, b.z), c.z));
         cent[t] = scale(add(tlo[t], thi[t]), 0.5f);
     }
-    for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t v = 0; v < s->shapes[i].vert_count; ++v) {
-        v3 p = vert(s, s->shapes[i].first_vert + v);
-        lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
-    }
-    for (uint32_t i = 0; i < s->n_analytic; ++i) {                   /* ShapeKDTree::addShape: m_aabb.expandBy(shape->getAABB()) (skdtree.cpp:68-77) */
+    /* kd-tree boxes: per shape group and for the scene = union of the member shapes' AABBs (ShapeKDTree::addShape, skdtree.cpp:68-77),
+     * enlarged as in gkdtree.h:1213-1220 */
+    for (uint32_t g = 0; g <= ng; ++g) { s->group_lo[g] = V(INFINITY, INFINITY, INFINITY); s->group_hi[g] = V(-INFINITY, -INFINITY, -INFINITY); }
+#define GROW(g, q) do { v3 q_ = (q); s->group_lo[g] = V(minf(s->group_lo[g].x, q_.x), minf(s->group_lo[g].y, q_.y), minf(s->group_lo[g].z, q_.z)); s->group_hi[g] = V(maxf(s->group_hi[g].x, q_.x), maxf(s->group_hi[g].y, q_.y), maxf(s->group_hi[g].z, q_.z)); } while (0)
+#define ENLARGE(g) do { const float eps = KD_AABB_EPSILON; v3 lo_ = s->group_lo[g], hi_ = s->group_hi[g]; \
+      v3 e1 = sub(hi_, lo_); lo_ = sub(lo_, V(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps)); \
+      v3 e2 = sub(hi_, lo_); hi_ = add(hi_, V(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps)); s->group_lo[g] = lo_; s->group_hi[g] = hi_; } while (0)
+    for (uint32_t i = 0; i < d->n_shapes; ++i) { uint32_t g = s->shapes[i].group ? s->shapes[i].group - 1 : ng; for (uint32_t v = 0; v < s->shapes[i].vert_count; ++v) GROW(g, vert(s, s->shapes[i].first_vert + v)); }
+    for (uint32_t g = 0; g < ng; ++g) ENLARGE(g);
+    for (uint32_t i = 0; i < s->n_analytic; ++i) {
         const analytic_t *a = &s->analytic[i]; uint32_t t = d->n_tris + i;
-        lo = V(minf(lo.x, a->lo.x), minf(lo.y, a->lo.y), minf(lo.z, a->lo.z)); hi = V(maxf(hi.x, a->hi.x), maxf(hi.y, a->hi.y), maxf(hi.z, a->hi.z));
+        GROW(ng, a->lo); GROW(ng, a->hi);
         tlo[t] = a->lo; thi[t] = a->hi;
         if (a->a.type == SH_DISK) {      /* Disk::getAABB bounds four rim points only; the oracle's own BVH needs the whole rim */
             v3 c = xf_point(a->a.to_world, V(0, 0, 0)); float r = length3(xf_vector(a->a.to_world, V(1, 0, 0)));
@@ -1503,14 +1551,35 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
         }
         cent[t] = scale(add(tlo[t], thi[t]), 0.5f);
     }
-    { const float eps = KD_AABB_EPSILON;
-      v3 e1 = sub(hi, lo); lo = sub(lo, V(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps));
-      v3 e2 = sub(hi, lo); hi = add(hi, V(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps)); }
-    s->aabb_lo = lo; s->aabb_hi = hi;
-    s->nodes = (bvh_node *) calloc(2 * (size_t) s->n_prims + 2, sizeof(bvh_node));
-    s->bvh_tris = (uint32_t *) calloc(s->n_prims + 1, 4);
-    for (uint32_t t = 0; t < s->n_prims; ++t) s->bvh_tris[t] = t;
-    s->n_nodes = 0; build_bvh(s, s->bvh_tris, 0, (int) s->n_prims, cent, tlo, thi);
+    for (uint32_t i = 0; i < s->n_instances; ++i) {                  /* Instance::getAABB (instance.cpp:46-64): the 8 corners of the group's kd-tree box, transformed */
+        const orc_instance *in = &s->instances[i]; uint32_t t = d->n_tris + s->n_analytic + i, g = in->group;
+        v3 blo = V(INFINITY, INFINITY, INFINITY), bhi = V(-INFINITY, -INFINITY, -INFINITY);
+        for (int c = 0; c < 8; ++c) {
+            v3 q = xf_point(in->to_world, V(c & 1 ? s->group_hi[g].x : s->group_lo[g].x, c & 2 ? s->group_hi[g].y : s->group_lo[g].y, c & 4 ? s->group_hi[g].z : s->group_lo[g].z));
+            blo = V(minf(blo.x, q.x), minf(blo.y, q.y), minf(blo.z, q.z)); bhi = V(maxf(bhi.x, q.x), maxf(bhi.y, q.y), maxf(bhi.z, q.z));
+        }
+        GROW(ng, blo); GROW(ng, bhi); tlo[t] = blo; thi[t] = bhi; cent[t] = scale(add(blo, bhi), 0.5f);
+    }
+    ENLARGE(ng);
+#undef GROW
+#undef ENLARGE
+    s->aabb_lo = s->group_lo[ng]; s->aabb_hi = s->group_hi[ng];
+    /* the oracle's own BVHs: one per shape group plus the scene level, over disjoint segments of bvh_tris */
+    s->nodes = (bvh_node *) calloc(2 * (size_t) s->n_prims + 4 * (size_t) (ng + 2), sizeof(bvh_node));
+    s->bvh_tris = (uint32_t *) calloc(s->n_prims + 1, 4); s->group_prims = s->bvh_tris;
+    uint32_t fill = 0;
+    for (uint32_t g = 0; g <= ng; ++g) {
+        s->group_first[g] = fill;
+        for (uint32_t i = 0; i < d->n_shapes; ++i) if ((s->shapes[i].group ? s->shapes[i].group - 1 : ng) == g)
+            for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->bvh_tris[fill++] = s->shapes[i].first_tri + t;
+        if (g == ng) for (uint32_t t = d->n_tris; t < s->n_prims; ++t) s->bvh_tris[fill++] = t;
+        s->group_count[g] = fill - s->group_first[g];
+    }
+    s->n_nodes = 0;
+    for (uint32_t g = 0; g <= ng; ++g) {
+        if (s->group_count[g] == 0) { int id = s->n_nodes++; s->nodes[id].lo = V(INFINITY, INFINITY, INFINITY); s->nodes[id].hi = V(-INFINITY, -INFINITY, -INFINITY); s->nodes[id].count = 0; s->nodes[id].left = s->nodes[id].right = id; s->nodes[id].first = 0; s->group_root[g] = -2; continue; }
+        s->group_root[g] = build_bvh(s, s->bvh_tris, (int) s->group_first[g], (int) s->group_count[g], cent, tlo, thi);
+    }
     free(cent); free(tlo); free(thi);
     /* emitter selection PDF (scene.cpp:383-388; pmf.h:56-58 append, :103-116 normalize) */
     uint32_t ne = d->n_emitters;
@@ -1617,7 +1686,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
 void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
     for (uint32_t e = 0; e < s->d.n_emitters; ++e) free(s->area_cdf[e]);   /* NULL for the environment emitter */
-    free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic);
+    free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic); free(s->instances); free(s->group_root); free(s->group_lo); free(s->group_hi); free(s->group_first); free(s->group_count);
     free(s->spot_cos_beam); free(s->spot_cos_cutoff); free(s->spot_inv_transition); free(s->spot_cutoff); free(s->spot_to_local);
     free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
     free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->emitters); free(s);

@@ -67,9 +67,10 @@ template <typename T> static void save(const std::string &p, const char *d, std:
 struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
 struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
 struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight, cutoff, beam, toWorld[16]; };
+struct FInstance { uint32_t group, pad[3]; float toWorld[16], toObject[16]; };
 struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
 struct FScene {
-    std::vector<FAnalytic> analytic;
+    std::vector<FAnalytic> analytic; std::vector<FInstance> instances;
     uint32_t nVerts, nTris, nShapes, nBsdfs, nEmitters, hasN, hasUV, hasEnv;
     std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx;
     std::vector<FShape> shapes; std::vector<FBsdf> bsdfs; std::vector<FEmitter> emitters;
@@ -100,9 +101,11 @@ static FScene loadScene(const char *path) {
         s.envRGB.resize((size_t) s.envW * s.envH * 3); rd(f, s.envRGB.data(), s.envRGB.size() * 4);
     }
     char tag[4];
-    if (fread(tag, 1, 4, f) == 4 && !memcmp(tag, "ANLY", 4)) {
-        uint32_t n; rd(f, &n, 4); s.analytic.resize(n);
-        for (FAnalytic &a : s.analytic) rd(f, &a, sizeof(FAnalytic));
+    while (fread(tag, 1, 4, f) == 4) {
+        uint32_t n; rd(f, &n, 4);
+        if (!memcmp(tag, "ANLY", 4)) { s.analytic.resize(n); for (FAnalytic &a : s.analytic) rd(f, &a, sizeof(FAnalytic)); }
+        else if (!memcmp(tag, "INST", 4)) { s.instances.resize(n); for (FInstance &a : s.instances) rd(f, &a, sizeof(FInstance)); }
+        else { fprintf(stderr, "unknown section\n"); _exit(2); }
     }
     fclose(f); return s;
 }
@@ -240,6 +243,7 @@ static Built buildScene(const FScene &fs) {
         em->configure();
     }
     // shapes
+    std::vector<ref<Shape> > groups, instancesKeep;
     for (uint32_t si = 0; si < fs.nShapes; ++si) {
         const FShape &sh = fs.shapes[si];
         bool useN = fs.hasN && !sh.faceNormals;
@@ -262,7 +266,22 @@ static Built buildScene(const FScene &fs) {
             mesh->addChild(em); em->setParent(mesh); em->configure();
         }
         mesh->configure();
+        if (sh.pad) {                      // member of shape group sh.pad - 1 (FShape::pad carries the group id)
+            if (groups.size() < sh.pad) groups.resize(sh.pad);
+            if (!groups[sh.pad - 1]) groups[sh.pad - 1] = static_cast<Shape *>(create(MTS_CLASS(Shape), Properties("shapegroup")));
+            groups[sh.pad - 1]->addChild(mesh); mesh->setParent(groups[sh.pad - 1]);
+            continue;
+        }
         b.scene->addChild(mesh); mesh->setParent(b.scene);
+    }
+    for (ref<Shape> &g : groups) g->configure();               // builds the group's kd-tree (shapegroup.cpp:50-58)
+    for (const FInstance &fi : fs.instances) {
+        Properties p("instance");
+        Matrix4x4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = fi.toWorld[i * 4 + j];
+        p.setTransform("toWorld", Transform(m));
+        ref<Shape> inst = static_cast<Shape *>(create(MTS_CLASS(Shape), p));
+        inst->addChild(groups[fi.group]); inst->configure();
+        instancesKeep.push_back(inst);
     }
     // analytic shapes (after the meshes: shape index = nShapes + i).  The descriptor holds the post-constructor objectToWorld; sphere and
     // cylinder get their scale back through `toWorld` so that the reference's constructors split it off again (sphere.cpp:113-123, cylinder.cpp:85-106)
@@ -287,6 +306,7 @@ static Built buildScene(const FScene &fs) {
         shape->configure();
         b.scene->addChild(shape); shape->setParent(b.scene);
     }
+    for (ref<Shape> &inst : instancesKeep) { b.scene->addChild(inst); inst->setParent(b.scene); }
     // film + filter
     {
         Properties fp(fs.filter == 0 ? "box" : "gaussian");
@@ -543,6 +563,7 @@ static void modeUnits(Built &b, const FScene &fs, const std::string &out) {
     const ref_vector<Shape> &shapes = b.scene->getShapes();
     for (size_t si = 0; si < shapes.size(); ++si) {
         const BSDF *bsdf = const_cast<Shape *>(shapes[si].get())->getBSDF();
+        if (!bsdf) continue;      // instances carry no BSDF of their own
         Intersection its; its.shape = const_cast<Shape *>(shapes[si].get()); its.p = Point(0.0f); its.uv = Point2(0.5f); its.hasUVPartials = false; its.time = 0;
         its.shFrame = Frame(Normal(0, 0, 1)); its.geoFrame = its.shFrame;
         for (int a = 0; a < 5; ++a) for (int k = 0; k < 9; ++k) {

@@ -41,7 +41,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
 @pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
-                                  "cbox_materials", "cbox_materials_strict_indep"])
+                                  "cbox_materials", "cbox_materials_strict_indep", "instanced_garden"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -55,6 +55,9 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     if name.startswith("atrium"):
         # coarse smooth-shaded columns (6 segments): the interpolated normal amplifies last-bit differences of (u, v) at grazing angles
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6
+    elif name == "instanced_garden":
+        # shape groups + instances: object-space intersection, normals through the inverse transpose; smooth-shaded members
+        assert same_path.mean() > 0.999 and same_vals.mean() > 0.998 and (err < 2e-4).mean() > 0.995 and np.median(err) < 1e-6
     elif name.startswith("cbox_materials"):
         # dielectric / conductor / plastic: every path takes the same branches; values within float rounding (relative error is measured
         # against max |Li| + 1e-6, a 2e-8 sample against the reference's exact 0 shows as 2 %)
@@ -76,7 +79,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -93,8 +96,8 @@ def test_units_vs_reference(oracle, golden_scenes, name):
         if ok:
             nhit += 1
             assert abs(h[0] - row[3]) <= 2e-5 * abs(row[3])
-            assert np.allclose(h[1:4], row[4:7], atol=2e-3) and np.allclose(h[4:13], row[7:16], atol=2e-5)
-            assert np.allclose(h[15:18], row[18:21], atol=2e-5) and h[19] == row[22]
+            assert np.allclose(h[1:4], row[4:7], atol=2e-3) and np.allclose(h[4:13], row[7:16], atol=3e-5 if h[20] >= 0 else 2e-5)
+            assert np.allclose(h[15:18], row[18:21], atol=2e-5) and (h[19] == row[22] or h[20] >= 0)   # instanced hit: its.shape is the group member, not a scene shape
             assert h[19] >= len(sc.shapes) or h[18] == row[21]      # analytic shapes leave Intersection::primIndex untouched in the reference
             okb, hb = orc.intersect(ray, brute=True)
             assert okb and (hb.view(np.uint32) == h.view(np.uint32)).all()
@@ -151,7 +154,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
-                                  "cbox_materials", "cbox_materials_strict_indep"])
+                                  "cbox_materials", "cbox_materials_strict_indep", "instanced_garden"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
@@ -160,7 +163,7 @@ def test_film_vs_reference(oracle, golden_scenes, name):
     assert film.shape == ref.shape
     rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
     # cbox_shapes_strict_indep: one of 73 728 samples forks at a strictNormals threshold (0.12 in one pixel)
-    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3}.get(name, 1e-4), rel
+    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3, "instanced_garden": 2e-3}.get(name, 1e-4), rel
     assert np.allclose(film[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)        # weight channel
     # the reference's own ray counters (StatsCounter "Normal rays traced" / "Shadow rays traced", skdtree.cpp:46-47)
     stats = str(gd["stats"])
