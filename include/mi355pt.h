@@ -28,8 +28,13 @@ typedef struct {
     int32_t bsdf;        /* index into the material table (Shape::getBSDF, include/mitsuba/render/shape.h) */
     int32_t emitter;     /* index into the emitter table or -1 (Shape::getEmitter)                          */
     uint32_t flags;      /* bit0: face normals (TriMesh "faceNormals", src/librender/trimesh.cpp:70)        */
-    uint32_t pad;
+    uint32_t group;      /* 0: the mesh is a scene shape; g > 0: it is a member of shape group g - 1 (src/shapes/shapegroup.cpp) and
+                            appears in the scene only through mi_instance records; group members cannot be emitters (shapegroup.cpp:75-76) */
 } mi_shape;
+
+/* src/shapes/instance.cpp: one placement of shape group `group`; to_world = the instance transform, to_object = its inverse as the
+ * reference computes it.  Groups hold triangle meshes; nested instancing is not permitted (shapegroup.cpp:71-72). */
+typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[16]; } mi_instance;
 
 #define MI_BSDF_DIFFUSE 0         /* src/bsdfs/diffuse.cpp: reflectance                                                              */
 #define MI_BSDF_ROUGHCONDUCTOR 1  /* src/bsdfs/roughconductor.cpp + microfacet.h: alpha, distr, eta, k, specular                      */
@@ -117,6 +122,8 @@ int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, cons
 /* analytic shapes, numbered after the meshes: shape index n_shapes + i, primitive index n_tris + i (Scene::getShapes order with the
  * meshes first).  Either call may be omitted, but a scene needs at least one primitive. */
 int mi_scene_set_analytic(mi_scene *s, const mi_analytic *shapes, uint32_t n);
+/* instances of shape groups; primitive index of the i-th: n_tris + n_analytic + i (they come last in Scene::getShapes order here) */
+int mi_scene_set_instances(mi_scene *s, const mi_instance *instances, uint32_t n);
 int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);
@@ -150,6 +157,7 @@ int mi_render_set_profiling(mi_render *r, int enabled);   /* per-stage HIP-event
 
 /* Unit-level device entry points used by the parity tests (each runs a small kernel over n items) */
 int mi_debug_intersect(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4);   /* t,u,v,prim (prim<0: miss) */
+int mi_debug_intersect_inst(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4, int32_t *out_instance);   /* + instance index of the hit (-1: scene-level primitive) */
 int mi_debug_sobol(mi_scene *s, const uint32_t *px_py_k, uint64_t n, uint32_t ndims, uint64_t *out_index, float *out_values);
 int mi_debug_camera_rays(mi_scene *s, const float *sample_pos2, uint64_t n, float *out_rays8);
 

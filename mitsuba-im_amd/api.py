@@ -37,6 +37,10 @@ class MiAnalytic(C.Structure):
                 ("to_world", C.c_float * 16), ("to_object", C.c_float * 16), ("radius", C.c_float), ("length", C.c_float), ("pad", C.c_float * 2)]
 
 
+class MiInstance(C.Structure):
+    _fields_ = [("group", C.c_uint32), ("pad", C.c_uint32 * 3), ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
+
+
 class MiRenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("fast_math", C.c_uint32)]
@@ -53,10 +57,10 @@ class MiStats(C.Structure):
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
-           "mi_scene_set_analytic", "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
-           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_sobol", "mi_debug_camera_rays"]
+           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays"]
 HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
 
 
@@ -80,6 +84,7 @@ class Lib:
         L.mi_scene_destroy.argtypes = [vp]; L.mi_scene_destroy.restype = None
         L.mi_scene_set_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32]
         L.mi_scene_set_analytic.argtypes = [vp, vp, u32]
+        L.mi_scene_set_instances.argtypes = [vp, vp, u32]
         L.mi_scene_set_materials.argtypes = [vp, vp, u32]
         L.mi_scene_set_emitters.argtypes = [vp, vp, u32]
         L.mi_scene_set_envmap.argtypes = [vp, vp, u32, u32, vp, f32]
@@ -99,6 +104,7 @@ class Lib:
         L.mi_render_stats.argtypes = [vp, C.POINTER(MiStats)]
         L.mi_render_set_profiling.argtypes = [vp, i32]
         L.mi_debug_intersect.argtypes = [vp, vp, u64, i32, vp]
+        L.mi_debug_intersect_inst.argtypes = [vp, vp, u64, i32, vp, vp]
         L.mi_debug_sobol.argtypes = [vp, vp, u64, u32, vp, vp]
         L.mi_debug_camera_rays.argtypes = [vp, vp, u64, vp]
 
@@ -142,7 +148,7 @@ class Scene:
         h = C.c_void_p(); L.check(L.L.mi_scene_create(C.byref(h))); self.h = h
         shapes = (MiShape * len(sc.shapes))()
         for i, s in enumerate(sc.shapes):
-            shapes[i] = MiShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, 0)
+            shapes[i] = MiShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, s.get("group", 0))
         mats = (MiMaterial * len(sc.bsdfs))()
         for i, b in enumerate(sc.bsdfs):
             m = MiMaterial(b["type"], (b["twosided"] & 1) | ((b["sample_visible"] & 1) << 1) | ((b.get("nonlinear", 0) & 1) << 2), b["distr"], b["alpha"])
@@ -163,6 +169,12 @@ class Scene:
                 r.radius, r.length = a["radius"], a["length"]
                 an[i] = r
             L.check(L.L.mi_scene_set_analytic(h, C.cast(an, C.c_void_p), len(recs)))
+        insts = sc.get("instances") or []
+        if insts:
+            arr = (MiInstance * len(insts))()
+            for i, a in enumerate(insts):
+                r = MiInstance(a["group"]); r.to_world[:] = a["to_world"].reshape(-1).tolist(); r.to_object[:] = a["to_object"].reshape(-1).tolist(); arr[i] = r
+            L.check(L.L.mi_scene_set_instances(h, C.cast(arr, C.c_void_p), len(insts)))
         L.check(L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), len(sc.bsdfs)))
         L.check(L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), len(sc.emitters)))
         if sc.envmap is not None:
@@ -181,8 +193,11 @@ class Scene:
         self.close()
 
     # unit-level device entry points
-    def intersect(self, rays8, any_hit=False):
+    def intersect(self, rays8, any_hit=False, with_instance=False):
         rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8); out = np.zeros((len(rays8), 4), np.float32)
+        if with_instance:
+            inst = np.zeros(len(rays8), np.int32)
+            self.L.check(self.L.L.mi_debug_intersect_inst(self.h, _p(rays8), len(rays8), int(any_hit), _p(out), _p(inst))); return out, inst
         self.L.check(self.L.L.mi_debug_intersect(self.h, _p(rays8), len(rays8), int(any_hit), _p(out))); return out
 
     def sobol(self, px_py_k, ndims):

@@ -24,6 +24,7 @@
 #include <mitsuba/core/half.h>
 #include <mitsuba/core/mstream.h>
 #include <mitsuba/core/serialization.h>
+#include <instance.h>     // src/shapes/instance.h (pulls in shapegroup.h, which has no include guard): inline accessors only (getShapeGroup, getWorldTransform, getKDTree)
 #include <ior.h>   // src/bsdfs/ior.h: lookupIOR, as used by RoughConductor's constructor
 #include "../integrator_host.h"
 
@@ -33,7 +34,7 @@ namespace {
 
 struct FlatScene {
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
-    std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes;
+    std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances;
     bool anyNormals = false;
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16], envScale = 1.0f;
 };
@@ -198,19 +199,38 @@ static bool convertAnalytic(const Shape *shape, mi_analytic &a) {
 
 static void flatten(const Scene *scene, FlatScene &fs) {
     const std::vector<TriMesh *> &meshes = scene->getMeshes();
-    std::map<const BSDF *, int> bsdfIndex;
+    std::map<const BSDF *, int> bsdfIndex; std::vector<const Instance *> insts;
     // non-mesh shapes: rectangle / disk / sphere / cylinder become analytic records (numbered after the meshes); anything else is refused
     for (size_t si = 0; si < scene->getShapes().size(); ++si) {
         const Shape *shape = scene->getShapes()[si].get();
         if (shape->getClass()->derivesFrom(MTS_CLASS(TriMesh))) continue;
+        if (shape->getClass()->getName() == "Instance") { insts.push_back(static_cast<const Instance *>(shape)); continue; }
         mi_analytic a;
         if (!convertAnalytic(shape, a))
-            SLog(EError, "path_hip: shape \"%s\" is not implemented (triangle meshes, rectangle, disk, sphere, cylinder; no instances -- SURVEY.md §8f)", shape->getClass()->getName().c_str());
+            SLog(EError, "path_hip: shape \"%s\" is not implemented (triangle meshes, rectangle, disk, sphere, cylinder, instance / shapegroup of meshes)", shape->getClass()->getName().c_str());
         fs.analytic.push_back(a); fs.analyticShapes.push_back(shape);
     }
-    for (const TriMesh *mesh : meshes) fs.anyNormals |= mesh->getVertexNormals() != NULL;
-    for (size_t mi = 0; mi < meshes.size(); ++mi) {
-        const TriMesh *mesh = meshes[mi];
+    // shape groups reached through the instances (src/shapes/instance.cpp, shapegroup.cpp): their meshes follow the scene meshes, tagged with the group
+    std::map<const ShapeGroup *, uint32_t> groupIndex; std::vector<const TriMesh *> allMeshes(meshes.begin(), meshes.end()); std::vector<uint32_t> meshGroup(meshes.size(), 0);
+    for (const Instance *inst : insts) {
+        const ShapeGroup *grp = inst->getShapeGroup();
+        if (!groupIndex.count(grp)) {
+            uint32_t g = (uint32_t) groupIndex.size(); groupIndex[grp] = g;
+            for (const Shape *member : grp->getKDTree()->getShapes()) {
+                if (!member->getClass()->derivesFrom(MTS_CLASS(TriMesh))) SLog(EError, "path_hip: shape groups are implemented for triangle meshes (found \"%s\")", member->getClass()->getName().c_str());
+                allMeshes.push_back(static_cast<const TriMesh *>(member)); meshGroup.push_back(g + 1);
+            }
+        }
+        if (!inst->getWorldTransform()->isStatic()) SLog(EError, "path_hip: animated transforms are not implemented");
+        const Transform &trafo = inst->getWorldTransform()->eval(0);
+        mi_instance mi_; memset(&mi_, 0, sizeof(mi_)); mi_.group = groupIndex[grp];
+        const Matrix4x4 &m = trafo.getMatrix(), &inv = trafo.getInverseMatrix();
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { mi_.to_world[i * 4 + j] = m(i, j); mi_.to_object[i * 4 + j] = inv(i, j); }
+        fs.instances.push_back(mi_);
+    }
+    for (const TriMesh *mesh : allMeshes) fs.anyNormals |= mesh->getVertexNormals() != NULL;
+    for (size_t mi = 0; mi < allMeshes.size(); ++mi) {
+        const TriMesh *mesh = allMeshes[mi];
         if (mesh->getVertexTexcoords() != NULL && (mesh->getBSDF()->usesRayDifferentials() || mesh->getUVTangents() != NULL))
             SLog(EWarn, "path_hip: mesh \"%s\" carries UV tangents; the shading frame falls back to the triangle edge (no textures on this path)", mesh->getName().c_str());
         mi_shape sh; memset(&sh, 0, sizeof(sh));
@@ -226,7 +246,7 @@ static void flatten(const Scene *scene, FlatScene &fs) {
         sh.flags = n ? 0u : 1u;
         const BSDF *bsdf = mesh->getBSDF();
         if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
-        sh.bsdf = bsdfIndex[bsdf]; sh.emitter = -1;
+        sh.bsdf = bsdfIndex[bsdf]; sh.emitter = -1; sh.group = meshGroup[mi];
         fs.shapes.push_back(sh);
     }
     for (size_t ai = 0; ai < fs.analytic.size(); ++ai) {
@@ -298,6 +318,7 @@ struct GpuScene {
         MI_CHECK(mi_scene_set_triangles(scene, fs.pos.data(), fs.anyNormals ? fs.nrm.data() : NULL, NULL, fs.idx.data(),
                                         (uint32_t) (fs.pos.size() / 3), (uint32_t) (fs.idx.size() / 3), fs.shapes.data(), (uint32_t) fs.shapes.size()));
         if (!fs.analytic.empty()) MI_CHECK(mi_scene_set_analytic(scene, fs.analytic.data(), (uint32_t) fs.analytic.size()));
+        if (!fs.instances.empty()) MI_CHECK(mi_scene_set_instances(scene, fs.instances.data(), (uint32_t) fs.instances.size()));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
         if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));

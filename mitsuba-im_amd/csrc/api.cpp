@@ -19,7 +19,7 @@ void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 void mi_launch_film_layout(const float *, const float *, float *, int, int, int, int, hipStream_t);
 void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float *, hipStream_t);
-void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, hipStream_t);
+void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, int *, hipStream_t);
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
 void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
 // fast-arithmetic twins (kernels_fast.hip)
@@ -132,6 +132,12 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *a, uint32_t n) {
     }
     s->h.analytic.assign(a, a + n); s->h.committed = false; return MI_OK;
 }
+int mi_scene_set_instances(mi_scene *s, const mi_instance *a, uint32_t n) {
+    if (!s || (n && !a)) return fail(MI_ERR_INVALID, "mi_scene_set_instances: null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (a[i].to_world[12] != 0 || a[i].to_world[13] != 0 || a[i].to_world[14] != 0 || a[i].to_world[15] != 1.0f) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_instances: toWorld must be affine");
+    s->h.instances.assign(a, a + n); s->h.committed = false; return MI_OK;
+}
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
     for (uint32_t i = 0; i < n; ++i) {
@@ -185,7 +191,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -195,7 +201,7 @@ int SceneHost::upload(int dev) {
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
     int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
-              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
+              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
     if (g_sobolDims && logRes <= 16) {
@@ -210,7 +216,8 @@ int SceneHost::upload(int dev) {
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
     d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
-    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || hasDeltaEmitters) ? 1u : 0u;
+    d.instances = (const InstanceD *) dInstances; d.n_instances = (uint32_t) instancesD.size();
+    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters) ? 1u : 0u;
     memcpy(d.dir_bs_center, dirBsCenter, 12); d.dir_bs_radius = dirBsRadius;
     d.n_tris = nTris; d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
     d.emitter_norm = emitterNorm;
@@ -229,13 +236,13 @@ int SceneHost::upload(int dev) {
         d.env_pixel_w = 2 * MI_PI / (float) envW; d.env_pixel_h = MI_PI / (float) envH; d.env_bs_radius = envBsRadius;
         memcpy(d.env_to_world, envToWorld3, 36); memcpy(d.env_to_local, envToLocal3, 36); memcpy(d.env_bs_center, envBsCenter, 12);
     }
-    d.bvh_depth = (uint32_t) bvhDepthOf(nodes, 0);
+    d.bvh_depth = (uint32_t) bvhDepth;
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
     d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1;   // any non-diffuse material -> k_shade<RC = true>
     const char *noPacket = getenv("MI355PT_NO_PACKET");
-    d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
+    d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     for (int i = 0; i < 3; ++i) d.packet_k[i] = packetK[i];
     committed = true;
     return 0;
@@ -248,6 +255,10 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     if (!s) return fail(MI_ERR_INVALID, "mi_scene_commit: null scene");
     if ((s->h.idx.empty() && s->h.analytic.empty()) || s->h.materials.empty() || !s->h.haveCamera || !s->h.haveFilm)
         return fail(MI_ERR_INVALID, "mi_scene_commit: geometry (triangles and / or analytic shapes), materials, camera and film must be set first");
+    {   uint32_t ng = 0; for (const mi_shape &sh : s->h.shapes) ng = std::max(ng, sh.group);
+        for (const mi_shape &sh : s->h.shapes) if (sh.group && sh.emitter >= 0) return fail(MI_ERR_INVALID, "Instancing of emitters is not supported");   // shapegroup.cpp:75-76
+        for (const mi_instance &in : s->h.instances) if (in.group >= ng) return fail(MI_ERR_INVALID, "A reference to a 'shapegroup' must be specified!");   // instance.cpp:41-44
+    }
     for (const mi_analytic &a : s->h.analytic) {
         if (a.bsdf < 0 || (size_t) a.bsdf >= s->h.materials.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing material");
         if (a.emitter >= (int32_t) s->h.emitters.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing emitter");
@@ -264,7 +275,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
     ensureSobolTables();
     s->h.commitHost();
-    if (mi::bvhDepthOf(s->h.nodes, 0) > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
+    if (s->h.bvhDepth > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
     int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
     if ((int) device >= devCount) return fail(MI_ERR_DEVICE, "mi_scene_commit: no such HIP device");
     if (s->h.upload((int) device)) return fail(MI_ERR_DEVICE, std::string("mi_scene_commit: upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -295,6 +306,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
         if (r->scene->h.d.env_constant) ALLOC(Q.st3[b], float, slots); else Q.st3[b] = nullptr;
         ALLOC(Q.count[b], uint32_t, grid);
     }
+    if (r->scene->h.d.n_instances) ALLOC(Q.hitInst, int32_t, slots); else Q.hitInst = nullptr;
     ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, slots); ALLOC(Q.shD, float4, slots); ALLOC(Q.shC, float4, slots);
     ALLOC(Q.acc, float4, slots); ALLOC(Q.pos, float2, slots); ALLOC(Q.shCount, uint32_t, grid);
     ALLOC(Q.counters, unsigned long long, 4);
@@ -536,12 +548,17 @@ template <typename F> static int withBuffers(const void *in, size_t inBytes, voi
     return MI_OK;
 }
 extern "C" {
-int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) {
+int mi_debug_intersect_inst(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out, int32_t *outInst) {
     if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_intersect: bad argument");
     HIPCHK(hipSetDevice(s->h.device));
     if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), s->h.packetK[2], s->h.analyticD.data(), (uint32_t) s->h.analyticD.size(), nullptr); HIPCHK(hipDeviceSynchronize()); }
-    return withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, nullptr); });
+    void *dInst = nullptr; if (outInst) HIPCHK(hipMalloc(&dInst, n * 4));
+    int rc = withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, (int *) dInst, nullptr); });
+    if (!rc && outInst) { hipError_t e = hipMemcpy(outInst, dInst, n * 4, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
+    if (dInst) (void) hipFree(dInst);
+    return rc;
 }
+int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) { return mi_debug_intersect_inst(s, rays, n, anyHit, out, nullptr); }
 int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, uint64_t *outIdx, float *outVals) {
     if (!s || !s->h.committed || !in || !outIdx || !outVals || !n || !s->h.d.sobol_m32 || ndims > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "mi_debug_sobol: bad argument");
     HIPCHK(hipSetDevice(s->h.device));

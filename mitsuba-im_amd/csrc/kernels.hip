@@ -41,55 +41,105 @@ DEV bool slab(f4 lo, f4 hi, v3 inv, v3 oi, float tmin, float tmax, float &tnear)
     tnear = t0;
     return t0 <= t1 * 1.000002f + 1e-30f;
 }
+// include/mitsuba/core/aabb.h:308-339 TAABB::rayIntersect(ray, nearT, farT), exact arithmetic (used for the group box of an instance)
+DEV bool aabbRay(const float *lo, const float *hi, v3 o, v3 d, float &nearT, float &farT) {
+    float nt = -INFINITY, ft = INFINITY;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float origin = oo[i], minv = lo[i], maxv = hi[i], di = dd[i];
+        if (di == 0) { if (origin < minv || origin > maxv) return false; }
+        else {
+            float rcp = 1.0f / di;
+            float t1 = (minv - origin) * rcp, t2 = (maxv - origin) * rcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nt = maxf(t1, nt); ft = minf(t2, ft);
+            if (!(nt <= ft)) return false;
+        }
+    }
+    nearT = nt; farT = ft; return true;
+}
 DEV float safeInv(float d) { float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d; return 1.0f / a; }
 
 // Closest hit: minimum t, ties towards the lower original triangle index (order independent).  `stk` points at this lane's column
 // of the workgroup's LDS stack (stride WG).  "while-while" shape: all lanes of a wave first descend through inner nodes until each
 // holds a leaf (or is done), then all test their leaf triangles -- the two code paths are not interleaved lane by lane.
 #define BVH_DONE 0x7FFFFFFF
+#define BVH_RET 0x7FFFFFFE                  // stack marker: leave the current instance, back to the scene-level ray
+// AN ("extended" geometry): leaf records may be analytic shapes (k = MI_K_ANALYTIC) or instances of shape groups (k = MI_K_INSTANCE).
+// Instance::rayIntersect (src/shapes/instance.cpp:91-108): the ray is taken to the group's object space (direction NOT renormalised, so t keeps
+// its meaning), [mint, maxt] is clipped against the group's kd-tree box (skdtree.h:431-452), then the group's own BVH -- stored in the same
+// node array -- is walked with the same stack; a marker entry brings the walk back to the scene level.  Instances sit alone in their leaves.
 template <bool ANY, bool AN>
 DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk,
-                  float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
-    const v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
-    const v3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                  float &bestT, uint32_t &bestPrim, float &bestU, float &bestV, int &bestInst) {
+    v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
+    v3 oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+    const v3 o0 = o, d0 = d; const float mint0 = mint;
+    float cap = INFINITY;                       // inside an instance: far end of the group-box interval
+    int curInst = -1, binst = -1;
     const f4 *nodes4 = reinterpret_cast<const f4 *>(sc.nodes);
     const f4 *tris4 = reinterpret_cast<const f4 *>(sc.tris);
     float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
     int sp = 0; int cur = 0;
+#define BVH_POP() do { \
+        if (sp > 0) { --sp; cur = stk[sp * WG]; \
+            if (AN && cur == BVH_RET) { o = o0; d = d0; mint = mint0; cap = INFINITY; curInst = -1; \
+                inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z)); oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z); \
+                if (sp > 0) { --sp; cur = stk[sp * WG]; } else cur = BVH_DONE; } \
+        } else cur = BVH_DONE; } while (0)
     while (true) {
         while (cur >= 0 && cur != BVH_DONE) {
             f4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
             int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
             float t0, t1;
-            bool h0 = slab(n0, n1, inv, oi, mint, best, t0), h1 = slab(n2, n3, inv, oi, mint, best, t1);
+            const float far = AN ? fminf(best, cap) : best;
+            bool h0 = slab(n0, n1, inv, oi, mint, far, t0), h1 = slab(n2, n3, inv, oi, mint, far, t1);
             if (h0 && h1) {
                 bool swap = t1 < t0;
                 stk[sp * WG] = swap ? c0 : c1; ++sp;
                 cur = swap ? c1 : c0;
             } else if (h0) cur = c0;
             else if (h1) cur = c1;
-            else if (sp > 0) { --sp; cur = stk[sp * WG]; }
-            else cur = BVH_DONE;
+            else BVH_POP();
         }
         if (cur == BVH_DONE) break;
         {
             uint32_t code = (uint32_t) ~cur; uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            bool entered = false;
             for (uint32_t i = 0; i < cnt; ++i) {
                 f4 a = tris4[(first + i) * 3 + 0], b = tris4[(first + i) * 3 + 1], c = tris4[(first + i) * 3 + 2];
                 TriAccelD ta; ta.k = __float_as_uint(a.x); ta.n_u = a.y; ta.n_v = a.z; ta.n_d = a.w;
                 ta.a_u = b.x; ta.a_v = b.y; ta.b_nu = b.z; ta.b_nv = b.w; ta.c_nu = c.x; ta.c_nv = c.y; ta.prim = __float_as_uint(c.z);
                 float u, v, t; bool ok;
-                if (AN && ta.k == MI_K_ANALYTIC) ok = analyticIntersect<ANY>(sc.analytic[ta.prim - sc.n_tris], o, d, mint, best, t, u, v);   // skdtree.h:292-301
-                else ok = triIntersect(ta, o, d, mint, best, u, v, t);
+                if (AN && ta.k == MI_K_INSTANCE) {
+                    const InstanceD &in = sc.instances[ta.prim];
+                    v3 o2 = xfPoint(in.to_object, o0), d2 = xfVector(in.to_object, d0);
+                    float nearT, farT;
+                    if (aabbRay(in.glo, in.ghi, o2, d2, nearT, farT)) {
+                        const float mi = mint0 > nearT ? mint0 : nearT, ma = best < farT ? best : farT;
+                        if (ma > mi) {
+                            stk[sp * WG] = BVH_RET; ++sp;
+                            o = o2; d = d2; mint = mi; cap = farT; curInst = (int) ta.prim;
+                            inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z)); oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z);
+                            cur = in.root; entered = true;
+                        }
+                    }
+                    break;                                                             // an instance is alone in its leaf
+                }
+                const float far = AN ? fminf(best, cap) : best;
+                if (AN && ta.k == MI_K_ANALYTIC) ok = analyticIntersect<ANY>(sc.analytic[ta.prim - sc.n_tris], o, d, mint, far, t, u, v);   // skdtree.h:292-301
+                else ok = triIntersect(ta, o, d, mint, far, u, v, t);
                 if (ok) {
                     if (ANY) return true;
-                    if (!found || t < best || (t == best && ta.prim < bprim)) { best = t; bprim = ta.prim; bu = u; bv = v; found = true; }
+                    if (!found || t < best || (t == best && (ta.prim < bprim || (ta.prim == bprim && curInst < binst)))) { best = t; bprim = ta.prim; binst = curInst; bu = u; bv = v; found = true; }
                 }
             }
-            if (sp > 0) { --sp; cur = stk[sp * WG]; } else cur = BVH_DONE;
+            if (!entered) BVH_POP();
         }
     }
-    bestT = best; bestPrim = bprim; bestU = bu; bestV = bv;
+#undef BVH_POP
+    bestT = best; bestPrim = bprim; bestU = bu; bestV = bv; bestInst = binst;
     return found;
 }
 
@@ -199,12 +249,13 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
     for (uint32_t i = tid; i < n; i += WG) {
         float4 ro = q.rayO[buf][segBase + i], rd = q.rayD[buf][segBase + i];
         v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z);
-        float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
+        float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
         if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt)) {
             if (STACK == 0) hit = packetIntersect<false, AN>(sc, o, d, mint, maxt, t, prim, u, v);
-            else hit = traverse<false, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+            else hit = traverse<false, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
         }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
+        if (AN && q.hitInst) q.hitInst[segBase + i] = inst;
     }
     }
     if (tid == 0 && rays) atomicAdd(&q.counters[0], rays);
@@ -319,7 +370,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 v3 ro3 = V(0, 0, 0);
                 if (AN) { float4 ro = q.rayO[buf][slot]; ro3 = V(ro.x, ro.y, ro.z); }      // analytic shapes: hit point = o + t d; sphere lights: reference point of pdfDirect
-                if (AN && prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], ro3, d, hr.x, hr.y, hr.z, h);
+                const int inst = (AN && q.hitInst) ? q.hitInst[slot] : -1;
+                if (AN && inst >= 0) fillHitInstanced(sc, tb, sc.instances[inst], ro3, d, hr.x, prim, hr.y, hr.z, h);
+                else if (AN && prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], ro3, d, hr.x, hr.y, hr.z, h);
                 else fillHit(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
                 if (depth > 1) {
                     if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
@@ -421,10 +474,10 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
     for (uint32_t i = tid; i < n; i += WG) {
         float4 so = q.shO[segBase + i], sd = q.shD[segBase + i];
         v3 o = V(so.x, so.y, so.z), d = V(sd.x, sd.y, sd.z);
-        float mint, maxt, t, u, v; uint32_t prim; bool occluded = false;
+        float mint, maxt, t, u, v; uint32_t prim; bool occluded = false; int inst;
         if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt)) {
             if (STACK == 0) occluded = packetIntersect<true, AN>(sc, o, d, mint, maxt, t, prim, u, v);
-            else occluded = traverse<true, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v);
+            else occluded = traverse<true, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
         }
         if (!occluded) {
             float4 c = q.shC[segBase + i]; const uint32_t pid = __float_as_uint(sd.w);
@@ -504,18 +557,19 @@ __global__ void k_gather_samples(Queues q, const uint32_t *slots, uint64_t n, fl
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { float4 a = q.acc[slots[i]]; out[i * 3] = a.x; out[i * 3 + 1] = a.y; out[i * 3 + 2] = a.z; }
 }
-__global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *rays, uint64_t n, int anyHit, float *out) {
+__global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst) {
     __shared__ int s_stk[STACK_DEPTH * WG];
     const uint64_t i = (uint64_t) blockIdx.x * WG + threadIdx.x;
     if (i >= n) return;
     const float *r = rays + i * 8;
     v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
-    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false;
+    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
     if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
         if (sc.packet_n) { if (anyHit) hit = packetIntersect<true, true>(sc, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false, true>(sc, o, d, mint, maxt, t, prim, u, v); }
-        else if (anyHit) hit = traverse<true, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
-        else hit = traverse<false, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v);
+        else if (anyHit) hit = traverse<true, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        else hit = traverse<false, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
     }
+    if (outInst) outInst[i] = hit ? inst : -1;
     out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
 }
 __global__ void k_debug_sobol(DScene sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *outIdx, float *outVals) {
@@ -548,7 +602,7 @@ void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, const AnalyticD 
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((KERNEL<16, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
 void MI_FN(mi_launch_extend)(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
-    if (sc.n_analytic) MI_BY_STACK(k_extend, true, sc, q, buf); else MI_BY_STACK(k_extend, false, sc, q, buf);
+    if (sc.n_analytic || sc.n_instances) MI_BY_STACK(k_extend, true, sc, q, buf); else MI_BY_STACK(k_extend, false, sc, q, buf);
 }
 void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
@@ -563,7 +617,7 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
 #undef MI_SHADE
 }
 void MI_FN(mi_launch_shadow)(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
-    if (sc.n_analytic) MI_BY_STACK(k_shadow, true, sc, q); else MI_BY_STACK(k_shadow, false, sc, q);
+    if (sc.n_analytic || sc.n_instances) MI_BY_STACK(k_shadow, true, sc, q); else MI_BY_STACK(k_shadow, false, sc, q);
 }
 #undef MI_BY_STACK
 void MI_FN(mi_launch_film)(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
@@ -572,7 +626,7 @@ void mi_launch_film_layout(const float *film, const float *spill, float *out, in
     size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, spill, out, W, H, border, layout);
 }
 void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_gather_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, q, slots, n, out); }
-void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out); }
+void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out, outInst); }
 void mi_launch_debug_sobol(const DScene &sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *oi, float *ov, hipStream_t st) { hipLaunchKernelGGL(k_debug_sobol, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, in, n, ndims, oi, ov); }
 void mi_launch_debug_camera(const DScene &sc, const float *pos, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_camera, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, pos, n, out); }
 #endif

@@ -208,6 +208,10 @@ DEV bool triIntersect(const TriAccelD &ta, v3 o, v3 d, float mint, float maxt, f
 }
 
 // ---------------------------------------------------------------------------------------------- hit record
+// include/mitsuba/core/transform.h:126-135 transformAffine(Point), :172-181 operator()(Vector), :199-207 operator()(Normal); m = rows 0..2 of the 4x4
+DEV v3 xfPoint(const float *m, v3 p) { return V(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]); }
+DEV v3 xfVector(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
+DEV v3 xfNormal(const float *inv, v3 n) { return V(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
 struct Hit {
     v3 p, ng, ns, s, t, wi; float dist; int material, emitter; uint32_t flags;
 };
@@ -237,6 +241,35 @@ DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t pr
     v3 md = -d;
     h.wi = V(dot(md, h.s), dot(md, h.t), dot(md, h.ns));
 }
+// Instance::fillIntersectionRecord (src/shapes/instance.cpp:126-141): the group member is filled in object space by
+// fillIntersectionRecord<false> (p = ray(t) of the object-space ray, skdtree.h:361-365), then normals go through the inverse transpose,
+// dpdu and p through the forward transform; the scene level recomputes the shading frame and wi (skdtree.h:425-426).
+template <bool L>
+DEV void fillHitInstanced(const DScene &sc, const Tabs<L> &tb, const InstanceD &in, v3 o, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
+    typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
+    f4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+    v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z);
+    h.material = __float_as_int(r0.w); h.emitter = __float_as_int(r1.w); h.flags = __float_as_uint(r2.w);
+    float bx = 1 - u - v, by = u, bz = v;
+    h.dist = t;
+    v3 o2 = xfPoint(in.to_object, o), d2 = xfVector(in.to_object, d);
+    v3 pObj = o2 + d2 * t;
+    v3 fn = V(r3.x, r3.y, r3.z), ns;
+    if (h.flags & 1u) ns = fn;
+    else {
+        uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
+        v3 n = (ld3(sc.nrm + 3 * i0) * bx + ld3(sc.nrm + 3 * i1) * by) + ld3(sc.nrm + 3 * i2) * bz;
+        ns = normalize(n);
+        if (dot(fn, ns) < 0) fn = -fn;
+    }
+    h.ns = normalize(xfNormal(in.to_object, ns)); h.ng = normalize(xfNormal(in.to_object, fn));
+    v3 dpdu = xfVector(in.to_world, p1 - p0);
+    h.p = xfPoint(in.to_world, pObj);
+    h.s = normalize(dpdu - h.ns * dot(h.ns, dpdu));
+    h.t = cross(h.ns, h.s);
+    v3 md = -d;
+    h.wi = V(dot(md, h.s), dot(md, h.t), dot(md, h.ns));
+}
 DEV v3 toWorld(const Hit &h, v3 w) { return (h.s * w.x + h.t * w.y) + h.ns * w.z; }
 DEV v3 toLocal(const Hit &h, v3 w) { return V(dot(w, h.s), dot(w, h.t), dot(w, h.ns)); }
 
@@ -245,9 +278,6 @@ DEV v3 toLocal(const Hit &h, v3 w) { return V(dot(w, h.s), dot(w, h.t), dot(w, h
 // fill :421-427): src/shapes/rectangle.cpp, disk.cpp, sphere.cpp, cylinder.cpp.  The quadrics are solved in double precision like
 // the reference (solveQuadraticDouble, src/libcore/util.cpp:489-527).
 // include/mitsuba/core/transform.h:126-135 transformAffine(Point), :172-181 operator()(Vector), :199-207 operator()(Normal); m = rows 0..2 of the 4x4
-DEV v3 xfPoint(const float *m, v3 p) { return V(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7], m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]); }
-DEV v3 xfVector(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
-DEV v3 xfNormal(const float *inv, v3 n) { return V(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
 // sin / cos of 2*pi*u, u in [0, 1]: quadrant reduction + the polynomial pair (the reference calls sincosf(2*pi*u); arithmetic contract)
 DEV void sincos2pi(float u, float &sn, float &cs) {
     float k = floorf(u * 4.0f + 0.5f);

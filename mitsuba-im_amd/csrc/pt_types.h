@@ -56,8 +56,17 @@ struct EmitterD {                         // 48 B
 #define MI_SHAPE_SPHERE 2
 #define MI_SHAPE_CYLINDER 3
 #define MI_K_ANALYTIC 4u
+#define MI_K_INSTANCE 5u                      // leaf record of an instance (src/shapes/instance.cpp): prim = instance index; always alone in its leaf
 #define MI_INV_FOURPI 0.07957747154594766788f   // constants.h:66
 #define MI_ANALYTIC_PACKET_MAX 16
+// One placement of a shape group (reference src/shapes/instance.cpp + shapegroup.cpp), 128 B.  The group's own BVH lives in the same node array.
+struct InstanceD {
+    float to_world[12];                   // rows 0..2 of the instance transform
+    float to_object[12];                  // rows 0..2 of its inverse
+    float glo[3]; int32_t root;           // the group's kd-tree box (enlarged, gkdtree.h:1213-1220); root node of the group's BVH
+    float ghi[3]; uint32_t group;
+};
+
 struct AnalyticD {
     float to_world[12];                   // rows 0..2 of objectToWorld
     float to_object[12];                  // rows 0..2 of worldToObject
@@ -72,6 +81,7 @@ struct DScene {
     const BvhNode *nodes; const TriAccelD *tris; const TriShade *shade; const uint32_t *i2; const float *nrm;
     const MaterialD *materials; const EmitterD *emitters; const float *emitter_cdf; const float *area_cdf;
     const AnalyticD *analytic; uint32_t n_analytic;
+    const InstanceD *instances; uint32_t n_instances;   // hit records of instanced triangles carry the instance index in Queues::hitInst
     uint32_t ext;                         // analytic shapes or delta emitters present: selects the k_shade<..., EXT> variants
     // scene-level emitters beyond envmap (src/emitters/constant.cpp, point.cpp, spot.cpp, directional.cpp): per emitter 16 floats
     //   [0..2] position (point, spot) / travel direction (directional); spot: [3] cos(cutoff), [4..12] world->local 3x3, [13] cos(beam), [14] cutoff, [15] 1/(cutoff-beam)

@@ -13,6 +13,7 @@ struct Queues {
     uint4 *st0[2]; float4 *st1[2]; float *st2[2];
     float *st3[2];                              // only with a `constant` environment emitter: cos(wo, refN) of the vertex that spawned the ray (2 = no reference normal)
     float4 *hit;
+    int32_t *hitInst;                           // only in scenes with instances: instance index of the hit (-1: a scene-level primitive)
     float4 *shO, *shD, *shC;
     float4 *acc; float2 *pos;
     uint32_t *count[2]; uint32_t *shCount;      // per segment

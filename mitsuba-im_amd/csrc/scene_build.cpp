@@ -102,6 +102,7 @@ static void analyticPrepare(const mi_analytic &a, AnalyticD &d, V3 &lo, V3 &hi, 
 struct BuildNode { V3 lo, hi; int left = -1, right = -1, first = 0, count = 0; };
 struct Builder {
     std::vector<BuildNode> nodes; std::vector<uint32_t> order; const std::vector<V3> *tlo, *thi, *cen;
+    const std::vector<uint8_t> *single = nullptr;   // primitives that must sit alone in their leaf (instances: the traversal enters them one at a time)
     int build(int first, int count, int depth) {
         int id = (int) nodes.size(); nodes.emplace_back();
         const float inf = std::numeric_limits<float>::infinity();
@@ -109,6 +110,15 @@ struct Builder {
         for (int i = first; i < first + count; ++i) { uint32_t t = order[i]; lo = vmin(lo, (*tlo)[t]); hi = vmax(hi, (*thi)[t]); clo = vmin(clo, (*cen)[t]); chi = vmax(chi, (*cen)[t]); }
         nodes[id].lo = lo; nodes[id].hi = hi;
         auto makeLeaf = [&]() { nodes[id].first = first; nodes[id].count = count; return id; };
+        bool mustSplit = false;
+        if (single && count > 1) for (int i = first; i < first + count; ++i) mustSplit |= (*single)[order[i]] != 0;
+        if (mustSplit) {              // keep splitting (object median) until the singleton primitives are alone
+            V3 ce0 = chi - clo; int ax = ce0.x > ce0.y ? (ce0.x > ce0.z ? 0 : 2) : (ce0.y > ce0.z ? 1 : 2);
+            std::sort(order.begin() + first, order.begin() + first + count, [&](uint32_t a, uint32_t b) { float x = comp((*cen)[a], ax), y = comp((*cen)[b], ax); return x < y || (x == y && a < b); });
+            int m = first + count / 2;
+            int l = build(first, m - first, depth + 1), r = build(m, first + count - m, depth + 1);
+            nodes[id].left = l; nodes[id].right = r; return id;
+        }
         if (count <= 2 || depth > 60) { if (count <= 8) return makeLeaf(); }
         // binned SAH over the widest centroid axis, 16 bins
         V3 ce = chi - clo; int axis = ce.x > ce.y ? (ce.x > ce.z ? 0 : 2) : (ce.y > ce.z ? 1 : 2);
@@ -149,7 +159,7 @@ struct Builder {
 static inline int32_t leafCode(int first, int count) { return ~(int32_t) (first * 8 + (count - 1)); }
 
 void SceneHost::commitHost() {
-    const uint32_t nt = (uint32_t) (idx.size() / 3), na = (uint32_t) analytic.size(), np = nt + na;
+    const uint32_t nt = (uint32_t) (idx.size() / 3), na = (uint32_t) analytic.size(), ni = (uint32_t) instances.size(), np = nt + na + ni;
     nTris = nt;
     auto vert = [&](uint32_t i) { return mk(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]); };
     triShape.assign(nt, 0);
@@ -202,46 +212,80 @@ void SceneHost::commitHost() {
         tlo[nt + i] = tl - mk(pad, pad, pad); thi[nt + i] = th + mk(pad, pad, pad); cen[nt + i] = (tl + th) * 0.5f;
         TriAccelD rec{}; rec.k = MI_K_ANALYTIC; rec.prim = nt + i; accel.push_back(rec);
     }
-    // --- scene box = union of the shape AABBs (ShapeKDTree::addShape, skdtree.cpp:68-77), enlarged like the kd-tree root (gkdtree.h:1213-1220)
-    {
-        const float inf = std::numeric_limits<float>::infinity();
-        V3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf);
-        for (const mi_shape &sh : shapes) for (uint32_t v = 0; v < sh.vert_count; ++v) { V3 p = vert(sh.first_vert + v); lo = vmin(lo, p); hi = vmax(hi, p); }
-        for (uint32_t i = 0; i < na; ++i) { lo = vmin(lo, alo[i]); hi = vmax(hi, ahi[i]); }
-        const float eps = 1e-3f;
-        V3 e1 = hi - lo; lo = lo - mk(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps);
-        V3 e2 = hi - lo; hi = hi + mk(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps);
-        aabbLo[0] = lo.x; aabbLo[1] = lo.y; aabbLo[2] = lo.z; aabbHi[0] = hi.x; aabbHi[1] = hi.y; aabbHi[2] = hi.z;
+    // --- kd-tree boxes of the shape groups and of the scene = union of the member shapes' AABBs (ShapeKDTree::addShape, skdtree.cpp:68-77),
+    //     enlarged like the kd-tree root (gkdtree.h:1213-1220); instance boxes = the 8 transformed corners of the group box (instance.cpp:46-64)
+    const float inf = std::numeric_limits<float>::infinity();
+    uint32_t ng = 0; for (const mi_shape &sh : shapes) ng = std::max(ng, sh.group);
+    std::vector<V3> glo(ng + 1, mk(inf, inf, inf)), ghi(ng + 1, mk(-inf, -inf, -inf));      // slot ng = the scene level
+    auto slotOf = [&](const mi_shape &sh) { return sh.group ? sh.group - 1 : ng; };
+    auto enlarge = [](V3 &lo, V3 &hi) { const float eps = 1e-3f; V3 e1 = hi - lo; lo = lo - mk(e1.x * eps + eps, e1.y * eps + eps, e1.z * eps + eps);
+                                        V3 e2 = hi - lo; hi = hi + mk(e2.x * eps + eps, e2.y * eps + eps, e2.z * eps + eps); };
+    for (const mi_shape &sh : shapes) { uint32_t g = slotOf(sh); for (uint32_t v = 0; v < sh.vert_count; ++v) { V3 p = vert(sh.first_vert + v); glo[g] = vmin(glo[g], p); ghi[g] = vmax(ghi[g], p); } }
+    for (uint32_t g = 0; g < ng; ++g) enlarge(glo[g], ghi[g]);
+    for (uint32_t i = 0; i < na; ++i) { glo[ng] = vmin(glo[ng], alo[i]); ghi[ng] = vmax(ghi[ng], ahi[i]); }
+    instancesD.assign(ni, InstanceD{});
+    for (uint32_t i = 0; i < ni; ++i) {
+        const mi_instance &in = instances[i]; const uint32_t g = in.group; V3 blo = mk(inf, inf, inf), bhi = mk(-inf, -inf, -inf);
+        for (int c = 0; c < 8; ++c) {
+            V3 q = xfPoint(in.to_world, mk(c & 1 ? ghi[g].x : glo[g].x, c & 2 ? ghi[g].y : glo[g].y, c & 4 ? ghi[g].z : glo[g].z));
+            blo = vmin(blo, q); bhi = vmax(bhi, q);
+        }
+        glo[ng] = vmin(glo[ng], blo); ghi[ng] = vmax(ghi[ng], bhi);
+        V3 e = bhi - blo; float mag = std::max(std::max(std::fabs(blo.x) + std::fabs(bhi.x), std::fabs(blo.y) + std::fabs(bhi.y)), std::fabs(blo.z) + std::fabs(bhi.z));
+        float pad = 1e-4f * std::max(std::max(e.x, e.y), e.z) + 2e-5f * mag + 1e-7f;
+        tlo[nt + na + i] = blo - mk(pad, pad, pad); thi[nt + na + i] = bhi + mk(pad, pad, pad); cen[nt + na + i] = (blo + bhi) * 0.5f;
+        TriAccelD rec{}; rec.k = MI_K_INSTANCE; rec.prim = i; accel.push_back(rec);
+        InstanceD &d = instancesD[i]; std::memcpy(d.to_world, in.to_world, 48); std::memcpy(d.to_object, in.to_object, 48);
+        d.glo[0] = glo[g].x; d.glo[1] = glo[g].y; d.glo[2] = glo[g].z; d.ghi[0] = ghi[g].x; d.ghi[1] = ghi[g].y; d.ghi[2] = ghi[g].z; d.group = g; d.root = 0;
     }
-    // --- BVH
-    Builder bld; bld.order.resize(np); for (uint32_t t = 0; t < np; ++t) bld.order[t] = t;
-    bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.nodes.reserve(2 * np + 2);
-    int root = np ? bld.build(0, (int) np, 0) : -1;
-    tris.resize(np); for (uint32_t i = 0; i < np; ++i) tris[i] = accel[bld.order[i]];
-    // packet mode: records sorted by projection axis (stable: original order inside an axis); degenerate triangles (k = 3) never hit -> dropped
-    packet.clear(); packetK[0] = packetK[1] = packetK[2] = 0;
-    for (uint32_t axis = 0; axis < 3; ++axis) { for (const TriAccelD &ta : accel) if (ta.k == axis) packet.push_back(ta); packetK[axis] = (uint32_t) packet.size(); }
-    if (packet.empty()) packet.push_back(TriAccelD{});
-    nodes.clear();
+    enlarge(glo[ng], ghi[ng]);
+    aabbLo[0] = glo[ng].x; aabbLo[1] = glo[ng].y; aabbLo[2] = glo[ng].z; aabbHi[0] = ghi[ng].x; aabbHi[1] = ghi[ng].y; aabbHi[2] = ghi[ng].z;
+
+    // --- BVHs: one per shape group, then the scene level (root = node 0 of its own range; the scene level is built LAST but must be node 0,
+    //     so its nodes are emitted first and the groups appended)
+    std::vector<uint8_t> single(np, 0); for (uint32_t i = 0; i < ni; ++i) single[nt + na + i] = 1;
     auto setBox = [](float *lo, float *hi, const BuildNode &n) { lo[0] = n.lo.x; lo[1] = n.lo.y; lo[2] = n.lo.z; hi[0] = n.hi.x; hi[1] = n.hi.y; hi[2] = n.hi.z; };
     auto emptyBox = [](float *lo, float *hi) { for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::infinity(); hi[i] = -std::numeric_limits<float>::infinity(); } };
-    // inner build nodes -> device nodes (index map), leaves are encoded in their parent
-    std::vector<int> devIndex(bld.nodes.size(), -1); int nInner = 0;
-    for (size_t i = 0; i < bld.nodes.size(); ++i) if (bld.nodes[i].count == 0) devIndex[i] = nInner++;
-    auto childCode = [&](int c) { const BuildNode &n = bld.nodes[c]; return n.count > 0 ? leafCode(n.first, n.count) : (int32_t) devIndex[c]; };
-    if (root >= 0 && bld.nodes[root].count > 0) {      // the whole scene is one leaf: synthesise a root with one empty child
-        BvhNode n{}; setBox(n.lo0, n.hi0, bld.nodes[root]); n.c0 = leafCode(bld.nodes[root].first, bld.nodes[root].count);
-        emptyBox(n.lo1, n.hi1); n.c1 = leafCode(0, 1); nodes.push_back(n);
-    } else {
-        nodes.resize(std::max(nInner, 0));
+    nodes.clear(); tris.clear();
+    std::vector<int> depthOf;     // depth of each emitted tree
+    // builds the tree over `prims`, appends its nodes / leaf records, returns the device index of its root (always an inner node)
+    auto emitTree = [&](const std::vector<uint32_t> &prims) -> int {
+        Builder bld; bld.order = prims; bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.single = &single; bld.nodes.reserve(2 * prims.size() + 2);
+        const int nodeBase = (int) nodes.size(), triBase = (int) tris.size();
+        int root = prims.empty() ? -1 : bld.build(0, (int) prims.size(), 0);
+        for (uint32_t i = 0; i < prims.size(); ++i) tris.push_back(accel[bld.order[i]]);
+        std::vector<int> devIndex(bld.nodes.size(), -1); int nInner = 0;
+        for (size_t i = 0; i < bld.nodes.size(); ++i) if (bld.nodes[i].count == 0) devIndex[i] = nodeBase + nInner++;
+        auto childCode = [&](int c) { const BuildNode &n = bld.nodes[c]; return n.count > 0 ? leafCode(triBase + n.first, n.count) : (int32_t) devIndex[c]; };
+        if (root < 0) { BvhNode n{}; emptyBox(n.lo0, n.hi0); emptyBox(n.lo1, n.hi1); n.c0 = n.c1 = leafCode(0, 1); nodes.push_back(n); return nodeBase; }
+        if (bld.nodes[root].count > 0) {      // the whole tree is one leaf: synthesise a root with one empty child
+            BvhNode n{}; setBox(n.lo0, n.hi0, bld.nodes[root]); n.c0 = leafCode(triBase + bld.nodes[root].first, bld.nodes[root].count);
+            emptyBox(n.lo1, n.hi1); n.c1 = n.c0; nodes.push_back(n); return nodeBase;
+        }
+        nodes.resize(nodeBase + nInner);
         for (size_t i = 0; i < bld.nodes.size(); ++i) {
             const BuildNode &b = bld.nodes[i]; if (b.count > 0) continue;
             BvhNode &n = nodes[devIndex[i]]; std::memset(&n, 0, sizeof(n));
             setBox(n.lo0, n.hi0, bld.nodes[b.left]); setBox(n.lo1, n.hi1, bld.nodes[b.right]);
             n.c0 = childCode(b.left); n.c1 = childCode(b.right);
         }
-    }
-    if (nodes.empty()) { BvhNode n{}; emptyBox(n.lo0, n.hi0); emptyBox(n.lo1, n.hi1); n.c0 = n.c1 = leafCode(0, 1); nodes.push_back(n); }
+        return devIndex[root];
+    };
+    std::vector<std::vector<uint32_t> > members(ng + 1);
+    for (const mi_shape &sh : shapes) { uint32_t g = slotOf(sh); for (uint32_t t = 0; t < sh.tri_count; ++t) members[g].push_back(sh.first_tri + t); }
+    for (uint32_t t = nt; t < np; ++t) members[ng].push_back(t);
+    emitTree(members[ng]);                 // the scene level first: a tree's root is the first node it emits, so the scene root is node 0
+    std::vector<int> groupRoot(ng, 0);
+    for (uint32_t g = 0; g < ng; ++g) groupRoot[g] = emitTree(members[g]);
+    for (uint32_t i = 0; i < ni; ++i) instancesD[i].root = groupRoot[instances[i].group];
+    // traversal stack need: scene tree + one return marker + the deepest group tree
+    struct Depth { const std::vector<BvhNode> &n; int of(int i) const { if (i < 0) return 0; int a = of(n[i].c0), b = of(n[i].c1); return 1 + (a > b ? a : b); } } dep{nodes};
+    int groupDepth = 0; for (uint32_t g = 0; g < ng; ++g) groupDepth = std::max(groupDepth, dep.of(groupRoot[g]));
+    bvhDepth = dep.of(0) + (ni ? 1 + groupDepth : 0);
+    // packet mode (no instances): records sorted by projection axis (stable: original order inside an axis); degenerate triangles (k = 3) never hit -> dropped
+    packet.clear(); packetK[0] = packetK[1] = packetK[2] = 0;
+    for (uint32_t axis = 0; axis < 3; ++axis) { for (const TriAccelD &ta : accel) if (ta.k == axis) packet.push_back(ta); packetK[axis] = (uint32_t) packet.size(); }
+    if (packet.empty()) packet.push_back(TriAccelD{});
 
     // --- emitters (scene.cpp:383-388; pmf.h:56-58,103-116; trimesh.cpp:389-402; triangle.cpp:61-67)
     const uint32_t ne = (uint32_t) emitters.size();

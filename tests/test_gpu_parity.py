@@ -357,3 +357,37 @@ def test_smooth_bsdfs(mi, oracle, golden_scenes, name):
     assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-4
+
+
+def test_instances(mi, oracle, golden_scenes):
+    """`shapegroup` + `instance`.  The scene-level BVH holds one leaf record per instance; entering it takes the ray to the
+    group's object space and walks the group's BVH with the same LDS stack.  Closest / any hit, the instance index and the radiance of
+    every path that does not touch the rough-conductor lids are bit-exact against the oracle."""
+    name = "instanced_garden"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    rng = np.random.default_rng(99); n = 4000
+    o = np.stack([rng.uniform(-7, 7, n), rng.uniform(0.05, 5, n), rng.uniform(-7, 7, n)], 1).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d[:, 1] -= 0.5; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([o, np.full((n, 1), 1e-4, np.float32), d, np.full((n, 1), np.inf, np.float32)], 1).astype(np.float32)
+    rays[100:600, 7] = rng.random(500).astype(np.float32) * 6
+    (got, inst), occ = gs.intersect(rays, with_instance=True), gs.intersect(rays, any_hit=True); n_inst = 0
+    for i in range(n):
+        ok, h = orc.intersect(rays[i])
+        assert ok == (got[i, 3] >= 0)
+        if ok:
+            assert (bits(got[i, :3]) == bits(np.array([h[0], h[13], h[14]], np.float32))).all()
+            shape = int(h[19]); assert int(got[i, 3]) == sc.shapes[shape]["first_tri"] + int(h[18]) and inst[i] == int(h[20])
+            n_inst += h[20] >= 0
+        assert orc.occluded(rays[i]) == (occ[i, 3] >= 0)
+    assert n_inst > n // 20
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    pairs = np.stack([rng.integers(0, sc.width, 20000), rng.integers(0, sc.height, 20000), rng.integers(0, sc.spp, 20000)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (bits(got) == bits(ref)).all(1).mean() > 0.9 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 3e-3
