@@ -16,6 +16,8 @@ BSDF_DIFFUSE = 0
 BSDF_ROUGHCONDUCTOR = 1
 BSDF_CONDUCTOR = 2        # src/bsdfs/conductor.cpp: eta, k, specular
 BSDF_DIELECTRIC = 3       # src/bsdfs/dielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance
+BSDF_ROUGHDIELECTRIC = 5  # src/bsdfs/roughdielectric.cpp: alpha, distr, eta[0], specular = specularReflectance, reflectance = specularTransmittance
+BSDF_DIFFTRANS = 6        # src/bsdfs/difftrans.cpp: reflectance = transmittance
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
 EMITTER_ENVMAP = 1
@@ -73,6 +75,8 @@ def fresnel_diffuse_reflectance(eta):
 def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
               distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
               specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False):
+    if kind == BSDF_ROUGHDIELECTRIC:
+        eta = (float(f32(ior)), 0.0, 0.0)
     if kind in (BSDF_DIELECTRIC, BSDF_PLASTIC):      # scalar relative index; plastic: k[0] = m_fdrInt = fresnelDiffuseReflectance(1 / eta) (plastic.cpp:200)
         eta = (float(f32(ior)), 0.0, 0.0); distr = int(nonlinear)
         k = (float(f32(fresnel_diffuse_reflectance(1.0 / float(f32(ior))))), 0.0, 0.0) if kind == BSDF_PLASTIC else (0.0, 0.0, 0.0)
@@ -394,6 +398,34 @@ def instanced_garden(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_dep
     sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 45.0, 0.05, 200.0, width, height, spp, sampler, max_depth, rr_depth,
                       seed=seed, normals=normals, name="instanced_garden", instances=inst)
     return add_scene_emitters(sc, [constant_emitter((0.25, 0.3, 0.4))])
+
+
+def cbox_translucent(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=10, rr_depth=5, seed=0, strict_normals=False, hide_emitters=False):
+    """Cornell room with `roughdielectric` (frosted Beckmann sphere, GGX slab -- microfacet refraction, draws one extra sampler dimension per
+    bounce) and a `difftrans` sheet in front of the back wall."""
+    b = _Builder()
+    white = b.bsdf(reflectance=(0.725, 0.71, 0.68)); red = b.bsdf(reflectance=(0.63, 0.065, 0.05)); green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
+    lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78))
+    frost = b.bsdf(kind=BSDF_ROUGHDIELECTRIC, alpha=0.15, distr=DISTR_BECKMANN, ior=1.5046, reflectance=(0.97, 1.0, 0.95), specular=(1.0, 1.0, 1.0))
+    slab = b.bsdf(kind=BSDF_ROUGHDIELECTRIC, alpha=0.3, distr=DISTR_GGX, ior=1.33, reflectance=(0.8, 0.9, 1.0), specular=(0.9, 0.9, 0.9))
+    shade = b.bsdf(kind=BSDF_DIFFTRANS, reflectance=(0.7, 0.55, 0.3))
+    b.begin(); b.quad([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]); b.end(white)
+    b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)
+    b.begin(); b.quad([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]); b.end(white)
+    b.begin(); b.quad([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]); b.end(green)
+    b.begin(); b.quad([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]); b.end(red)
+    b.begin(); b.quad([(343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227)]); b.end(lightm, radiance=(17.0, 12.0, 4.0))
+    b.begin()                                                              # closed slab (6 faces) so that rays enter and leave the medium
+    x0, y0, z0, x1, y1, z1 = 330.0, 0.5, 200.0, 500.0, 240.0, 260.0
+    b.quad([(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)]); b.quad([(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)])
+    b.quad([(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)]); b.quad([(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)])
+    b.quad([(x1, y0, z1), (x1, y1, z1), (x0, y1, z1), (x0, y0, z1)]); b.quad([(x0, y0, z1), (x0, y1, z1), (x0, y1, z0), (x0, y0, z0)])
+    b.end(slab)
+    b.begin(); b.quad([(60, 60, 500), (300, 60, 520), (300, 420, 520), (60, 420, 500)]); b.end(shade)
+    b.add_analytic(SHAPE_SPHERE, translate(170, 100, 190), frost, radius=100.0)
+    cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_translucent", analytic=b.resolve_analytic())
 
 
 def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):

@@ -738,10 +738,10 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
-static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC; }
+static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS; }
 /* BSDF::ESmooth: a `diffuse` whose reflectance is identically zero registers NO component (src/bsdfs/diffuse.cpp:99-102), so its type
  * is 0 and MIPathTracer::Li skips emitter sampling -- and the sampler request that goes with it (path.cpp:174-176) */
 static int material_is_smooth(const orc_material *m) {
@@ -1002,12 +1002,83 @@ static v3 plastic_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *w
     return scale(plastic_diffuse(m), invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
 }
 
+/* ---- rough dielectric: src/bsdfs/roughdielectric.cpp:274-617 over microfacet.h (isotropic alpha, Beckmann / GGX, sampleVisible = true).
+ * Fields: alpha, distr, eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance.  sample() draws one more
+ * number from the path's sampler to choose reflection / refraction (EUsesSampler, roughdielectric.cpp:480-481). */
+static inline float signum_(float v) { return copysignf(1.0f, v); }
+static v3 rd_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z == 0) return V(0, 0, 0);
+    const float etaM = m->eta[0], invEta = 1 / etaM, alpha = maxf(m->alpha, 1e-4f); const int reflect = wi.z * wo.z > 0; v3 H;
+    if (reflect) H = normalize(add(wo, wi));
+    else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(add(wi, scale(wo, eta))); }
+    H = scale(H, signum_(H.z));
+    float D = mf_eval(m->distr, alpha, H); if (D == 0) return V(0, 0, 0);
+    float ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, etaM);
+    float G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H);
+    if (reflect) { float value = F * D * G / (4.0f * fabsf(wi.z)); return scale(V(m->specular[0], m->specular[1], m->specular[2]), value); }
+    float eta = wi.z > 0.0f ? etaM : invEta;
+    float sqrtDenom = dot(wi, H) + eta * dot(wo, H);
+    float value = ((1 - F) * D * G * eta * eta * dot(wi, H) * dot(wo, H)) / (wi.z * sqrtDenom * sqrtDenom);
+    float factor = wi.z > 0 ? invEta : etaM;
+    return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), fabsf(value * factor * factor));
+}
+static float rd_pdf(const orc_material *m, v3 wi, v3 wo) {
+    const float etaM = m->eta[0], invEta = 1 / etaM, alpha = maxf(m->alpha, 1e-4f); const int reflect = wi.z * wo.z > 0; v3 H; float dwh_dwo;
+    if (reflect) { H = normalize(add(wo, wi)); dwh_dwo = 1.0f / (4.0f * dot(wo, H)); }
+    else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(add(wi, scale(wo, eta))); float sqrtDenom = dot(wi, H) + eta * dot(wo, H); dwh_dwo = (eta * eta * dot(wo, H)) / (sqrtDenom * sqrtDenom); }
+    H = scale(H, signum_(H.z));
+    float prob = mf_pdf_visible(m->distr, alpha, scale(wi, signum_(wi.z)), H);
+    float ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, etaM);
+    prob *= reflect ? F : (1 - F);
+    return fabsf(prob * dwh_dwo);
+}
+static v3 rd_sample(const orc_material *mt, v3 wi, float sx, float sy, float extra, v3 *wo, float *pdf, float *etaOut) {
+    const float etaM = mt->eta[0], invEta = 1 / etaM, alpha = maxf(mt->alpha, 1e-4f);
+    v3 wiS = scale(wi, signum_(wi.z));
+    v3 m = mf_sample_visible(mt->distr, alpha, wiS, sx, sy);
+    float microfacetPDF = mf_pdf_visible(mt->distr, alpha, wiS, m);
+    if (microfacetPDF == 0) return V(0, 0, 0);
+    *pdf = microfacetPDF;
+    float cosThetaT, F = fresnel_dielectric_ext(dot(wi, m), &cosThetaT, etaM);
+    int sampleReflection = 1; v3 weight = V(1, 1, 1); float dwh_dwo;
+    if (extra > F) { sampleReflection = 0; *pdf *= 1 - F; } else *pdf *= F;
+    if (sampleReflection) {
+        float c = 2 * dot(wi, m); *wo = sub(scale(m, c), wi); *etaOut = 1.0f;
+        if (wi.z * wo->z <= 0) return V(0, 0, 0);
+        weight = mul(weight, V(mt->specular[0], mt->specular[1], mt->specular[2]));
+        dwh_dwo = 1.0f / (4.0f * dot(*wo, m));
+    } else {
+        if (cosThetaT == 0) return V(0, 0, 0);
+        float e = cosThetaT < 0 ? 1 / etaM : etaM;                                   /* refract(wi, n, eta, cosThetaT), src/libcore/util.cpp:769-774 */
+        *wo = sub(scale(m, dot(wi, m) * e + cosThetaT), scale(wi, e));
+        *etaOut = cosThetaT < 0 ? etaM : invEta;
+        if (wi.z * wo->z >= 0) return V(0, 0, 0);
+        float factor = cosThetaT < 0 ? invEta : etaM;
+        weight = mul(weight, scale(V(mt->reflectance[0], mt->reflectance[1], mt->reflectance[2]), factor * factor));
+        float sqrtDenom = dot(wi, m) + *etaOut * dot(*wo, m);
+        dwh_dwo = (*etaOut * *etaOut * dot(*wo, m)) / (sqrtDenom * sqrtDenom);
+    }
+    weight = scale(weight, mf_smith_g1(mt->distr, alpha, *wo, m));
+    *pdf *= fabsf(dwh_dwo);
+    return weight;
+}
+/* ---- diffuse transmitter: src/bsdfs/difftrans.cpp:78-120; reflectance = transmittance */
+static v3 dt_eval(const orc_material *m, v3 wi, v3 wo) { if (wi.z * wo.z >= 0) return V(0, 0, 0); return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), INV_PI * fabsf(wo.z)); }
+static float dt_pdf(v3 wi, v3 wo) { if (wi.z * wo.z >= 0) return 0.0f; return fabsf(wo.z) * INV_PI; }
+static v3 dt_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *eta) {
+    *wo = cos_hemisphere(sx, sy); if (wi.z > 0) wo->z *= -1;
+    *eta = 1.0f; *pdf = fabsf(wo->z) * INV_PI;
+    return V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
+}
+
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
         case BSDF_ROUGHCONDUCTOR: return rc_eval(m, wi, wo);
         case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: return V(0, 0, 0);
         case BSDF_PLASTIC: return plastic_eval(m, wi, wo);
+        case BSDF_ROUGHDIELECTRIC: return rd_eval(m, wi, wo);
+        case BSDF_DIFFTRANS: return dt_eval(m, wi, wo);
         default: return diffuse_eval(m, wi, wo);
     }
 }
@@ -1017,11 +1088,15 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_ROUGHCONDUCTOR: return rc_pdf(m, wi, wo);
         case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: return 0.0f;
         case BSDF_PLASTIC: return plastic_pdf(m, wi, wo);
+        case BSDF_ROUGHDIELECTRIC: return rd_pdf(m, wi, wo);
+        case BSDF_DIFFTRANS: return dt_pdf(wi, wo);
         default: return diffuse_pdf(wi, wo);
     }
 }
 /* *delta = the sampled component is a Dirac delta (bRec.sampledType & BSDF::EDelta, path.cpp:259-260) */
-static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta) {
+/* sp: the path's sampler, used by BSDFs with EUsesSampler (may be NULL for the unit entry point: then `extra_unit` stands in) */
+static float g_extra_unit = 0.5f;
+static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
     int flipped = 0; *delta = 0;
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; flipped = 1; }
     v3 w;
@@ -1030,13 +1105,15 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_CONDUCTOR: w = conductor_sample(m, wi, wo, pdf, eta, delta); break;
         case BSDF_DIELECTRIC: w = dielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
         case BSDF_PLASTIC: w = plastic_sample(m, wi, u, v, wo, pdf, eta, delta); break;
+        case BSDF_ROUGHDIELECTRIC: w = rd_sample(m, wi, u, v, sp ? next1D(sp) : g_extra_unit, wo, pdf, eta); break;
+        case BSDF_DIFFTRANS: w = dt_sample(m, wi, u, v, wo, pdf, eta); break;
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;
     }
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
     return w;
 }
 void orc_bsdf_sample(const orc_scene *s, uint32_t mi, const float *wi, float u, float v, float *o) {
-    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; v3 w = bsdf_sample(&s->materials[mi], V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta);
+    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; v3 w = bsdf_sample(&s->materials[mi], V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta, NULL);
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = pdf; o[4] = wo.x; o[5] = wo.y; o[6] = wo.z; o[7] = eta;
 }
 void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float *wo, float *o) {
@@ -1342,7 +1419,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
         float bsdfPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
         float sx, sy; next2D(sp, &sx, &sy);
         int sampledDelta = 0;
-        v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta);
+        v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta, sp);
         if (is_zero(bsdfWeight)) break;
         scattered = 1;
         v3 wo = to_world(&its, woL);

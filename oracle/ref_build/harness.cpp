@@ -159,6 +159,18 @@ private:
 };
 MTS_IMPLEMENT_CLASS(RecordingSampler, false, Sampler)
 
+// BSDFs with EUsesSampler (roughdielectric) draw from bRec.sampler: the unit mode hands them this constant stream (0.5)
+class ConstSampler : public Sampler {
+public:
+    ConstSampler() : Sampler(Properties()) { m_sampleCount = 1; }
+    ref<Sampler> clone() { return new ConstSampler(); }
+    Float next1D() { return 0.5f; }
+    Point2 next2D() { return Point2(0.5f); }
+    std::string toString() const { return "ConstSampler[]"; }
+    MTS_DECLARE_CLASS()
+};
+MTS_IMPLEMENT_CLASS(ConstSampler, false, Sampler)
+
 // ------------------------------------------------------------------------------------------ scene construction
 static ConfigurableObject *create(const Class *cls, const Properties &p) {
     return PluginManager::getInstance()->createObject(cls, p);
@@ -189,6 +201,15 @@ static Built buildScene(const FScene &fs) {
             Properties p("dielectric");
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 5) {
+            Properties p("roughdielectric");
+            p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx"); p.setFloat("alpha", fb.alpha);
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", fb.sampleVisible != 0);
+            p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 6) {
+            Properties p("difftrans"); p.setSpectrum("transmittance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 4) {
             Properties p("plastic");
@@ -559,7 +580,7 @@ static void modeUnits(Built &b, const FScene &fs, const std::string &out) {
     }
     save(out + "_emitter.npy", "<f4", {em.size() / 20, 20}, em);
     // BSDF eval/pdf/sample for every BSDF at a hit (local frame), wi/u grids
-    std::vector<float> bs;
+    std::vector<float> bs; ref<Sampler> constSampler = new ConstSampler();
     const ref_vector<Shape> &shapes = b.scene->getShapes();
     for (size_t si = 0; si < shapes.size(); ++si) {
         const BSDF *bsdf = const_cast<Shape *>(shapes[si].get())->getBSDF();
@@ -572,7 +593,7 @@ static void modeUnits(Built &b, const FScene &fs, const std::string &out) {
             if (a == 4) wi.z = -wi.z;   // back side
             Point2 u(0.07f + 0.11f * k, 0.93f - 0.1f * k);
             its.wi = wi;
-            BSDFSamplingRecord bRec(its, NULL, ERadiance);
+            BSDFSamplingRecord bRec(its, constSampler.get(), ERadiance);
             Float pdf = 0; Spectrum wgt = bsdf->sample(bRec, pdf, u);
             Float R, G, B; wgt.toLinearRGB(R, G, B);
             float rowv[24] = {(float) si, wi.x, wi.y, wi.z, u.x, u.y, R, G, B, pdf, bRec.wo.x, bRec.wo.y, bRec.wo.z, bRec.eta, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

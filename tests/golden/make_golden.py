@@ -48,6 +48,9 @@ def golden_scenes():
         "cbox_materials_strict_indep": scenes.cbox_materials(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=4, strict_normals=True, hide_emitters=True, rr_depth=3, max_depth=-1),
         # shapegroup + instance (two groups, 16 placements with rotation / non-uniform scale), smooth-shaded and rough-conductor members
         "instanced_garden": scenes.instanced_garden(width=96, height=64, spp=16),
+        # roughdielectric (extra sampler dimension per bounce) + difftrans
+        "cbox_translucent": scenes.cbox_translucent(width=96, height=96, spp=16),
+        "cbox_translucent_indep": scenes.cbox_translucent(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=9, rr_depth=2, strict_normals=True),
     }
 
 
@@ -75,7 +78,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)
@@ -83,7 +86,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden"):
+        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", "path", -1, base + "_resp")

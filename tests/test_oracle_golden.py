@@ -41,7 +41,8 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
 @pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
-                                  "cbox_materials", "cbox_materials_strict_indep", "instanced_garden"])
+                                  "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
+                                  "cbox_translucent", "cbox_translucent_indep"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -55,6 +56,9 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     if name.startswith("atrium"):
         # coarse smooth-shaded columns (6 segments): the interpolated normal amplifies last-bit differences of (u, v) at grazing angles
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6
+    elif name.startswith("cbox_translucent"):
+        # roughdielectric: one more sampler value per bounce (EUsesSampler) -- the value streams still agree bit for bit; libm in the microfacet code
+        assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.995 and (err < 5e-3).all() and np.median(err) < 1e-6
     elif name == "instanced_garden":
         # shape groups + instances: object-space intersection, normals through the inverse transpose; smooth-shaded members
         assert same_path.mean() > 0.999 and same_vals.mean() > 0.998 and (err < 2e-4).mean() > 0.995 and np.median(err) < 1e-6
@@ -79,7 +83,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -124,7 +128,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
             ok, h = orc.intersect(orc.camera_ray(x + 0.5, y + 0.5))
             if ok:
                 si = int(h[19]); mat = sc.shapes[si]["bsdf"] if si < len(sc.shapes) else sc.analytic[si - len(sc.shapes)]["bsdf"]
-                twosided += [sc.bsdfs[mat]["twosided"]] * 4
+                twosided += [sc.bsdfs[mat]["twosided"] or sc.bsdfs[mat]["type"] in (3, 5, 6)] * 4        # + BSDFs with a transmission component
     assert len(twosided) == len(u["emitter"])
     for row, two in zip(u["emitter"], twosided):
         p = np.ascontiguousarray(row[0:3]); n = np.ascontiguousarray(row[3:6] * (0.0 if two else 1.0))
@@ -154,7 +158,8 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
-                                  "cbox_materials", "cbox_materials_strict_indep", "instanced_garden"])
+                                  "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
+                                  "cbox_translucent", "cbox_translucent_indep"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
@@ -163,7 +168,7 @@ def test_film_vs_reference(oracle, golden_scenes, name):
     assert film.shape == ref.shape
     rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
     # cbox_shapes_strict_indep: one of 73 728 samples forks at a strictNormals threshold (0.12 in one pixel)
-    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3, "instanced_garden": 2e-3}.get(name, 1e-4), rel
+    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3, "instanced_garden": 2e-3, "cbox_translucent_indep": 5e-4}.get(name, 1e-4), rel
     assert np.allclose(film[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)        # weight channel
     # the reference's own ray counters (StatsCounter "Normal rays traced" / "Shadow rays traced", skdtree.cpp:46-47)
     stats = str(gd["stats"])
