@@ -42,6 +42,8 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 #define MI_BSDF_DIELECTRIC 3      /* src/bsdfs/dielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance */
 #define MI_BSDF_PLASTIC 4         /* src/bsdfs/plastic.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = diffuseReflectance,
                                      k[0] = fresnelDiffuseReflectance(1 / eta, false) (SmoothPlastic::m_fdrInt, plastic.cpp:200)       */
+#define MI_BSDF_ROUGHDIELECTRIC 5 /* src/bsdfs/roughdielectric.cpp: alpha, distr, eta[0], specular = specularReflectance, reflectance = specularTransmittance */
+#define MI_BSDF_DIFFTRANS 6       /* src/bsdfs/difftrans.cpp: reflectance = transmittance                                            */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

@@ -134,6 +134,19 @@ static mi_material convertBSDF(const BSDF *bsdf) {
             rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.reflectance);
             return m;
         }
+        if (cls == "RoughDielectric") {
+            std::string distr = props.getString("distribution", "beckmann"); std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+            if (props.hasProperty("alphaU") || props.hasProperty("alphaV") || (distr != "beckmann" && distr != "ggx") || !props.getBoolean("sampleVisible", true))
+                SLog(EError, "path_hip: roughdielectric is implemented for isotropic beckmann / ggx with sampleVisible = true");
+            m.type = MI_BSDF_ROUGHDIELECTRIC; m.flags = MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr == "ggx" ? 1u : 0u; m.alpha = props.getFloat("alpha", 0.1f);
+            m.eta[0] = lookupIOR(props, "intIOR", "bk7") / lookupIOR(props, "extIOR", "air");
+            rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.reflectance);
+            return m;
+        }
+        if (cls == "DiffuseTransmitter") {
+            m.type = MI_BSDF_DIFFTRANS; rgb3(props.getSpectrum("transmittance", Spectrum(.5f)), m.reflectance);
+            return m;
+        }
         if (cls == "SmoothPlastic") {
             m.type = MI_BSDF_PLASTIC; m.eta[0] = lookupIOR(props, "intIOR", "polypropylene") / lookupIOR(props, "extIOR", "air");
             m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);

@@ -429,8 +429,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             // BSDF sampling (path.cpp:207-226)
             float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
             float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-            bool sampledDelta;
-            v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, woL, bPdf, bEta, sampledDelta);
+            bool sampledDelta; float extra = 0.0f;
+            if (RC && bsdfUsesSampler(bsdf)) extra = next1D(ss, rc.sampler, m32);      // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler)
+            v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta);
             v3 wo = toWorld(h, woL);
             if (isZero(bw) || (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0)) pathLen += (unsigned) depth;
             else {

@@ -692,6 +692,77 @@ DEV v3 plasticSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, floa
     return plasticDiffuse(m) * (invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
 }
 
+// ---------------------------------------------------------------------------------------------- rough dielectric, diffuse transmitter
+// src/bsdfs/roughdielectric.cpp:274-617 over microfacet.h (isotropic alpha, Beckmann / GGX, sampleVisible = true): alpha, distr, eta[0] = intIOR / extIOR,
+// specular = specularReflectance, reflectance = specularTransmittance.  sample() takes one more number from the path's sampler to choose between
+// reflection and refraction (EUsesSampler, roughdielectric.cpp:480-481).  src/bsdfs/difftrans.cpp:78-120: reflectance = transmittance.
+#define MI_BSDF_T_ROUGHDIELECTRIC 5u
+#define MI_BSDF_T_DIFFTRANS 6u
+DEV float signum_(float v) { return copysignf(1.0f, v); }
+DEV v3 rdEval(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z == 0) return V(0, 0, 0);
+    const float etaM = m.eta[0], invEta = 1 / etaM, alpha = maxf(m.alpha, 1e-4f); const bool reflect = wi.z * wo.z > 0; v3 H;
+    if (reflect) H = normalize(wo + wi);
+    else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(wi + wo * eta); }
+    H = H * signum_(H.z);
+    float D = mfEval(m.distr, alpha, H); if (D == 0) return V(0, 0, 0);
+    float ct, F = fresnelDielectricExt(dot(wi, H), ct, etaM);
+    float G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H);
+    if (reflect) { float value = F * D * G / (4.0f * fabsf(wi.z)); return ld3(m.specular) * value; }
+    float eta = wi.z > 0.0f ? etaM : invEta;
+    float sqrtDenom = dot(wi, H) + eta * dot(wo, H);
+    float value = ((1 - F) * D * G * eta * eta * dot(wi, H) * dot(wo, H)) / (wi.z * sqrtDenom * sqrtDenom);
+    float factor = wi.z > 0 ? invEta : etaM;
+    return ld3(m.reflectance) * fabsf(value * factor * factor);
+}
+DEV float rdPdf(const MaterialD &m, v3 wi, v3 wo) {
+    const float etaM = m.eta[0], invEta = 1 / etaM, alpha = maxf(m.alpha, 1e-4f); const bool reflect = wi.z * wo.z > 0; v3 H; float dwh_dwo;
+    if (reflect) { H = normalize(wo + wi); dwh_dwo = 1.0f / (4.0f * dot(wo, H)); }
+    else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(wi + wo * eta); float sqrtDenom = dot(wi, H) + eta * dot(wo, H); dwh_dwo = (eta * eta * dot(wo, H)) / (sqrtDenom * sqrtDenom); }
+    H = H * signum_(H.z);
+    float prob = mfPdfVisible(m.distr, alpha, wi * signum_(wi.z), H);
+    float ct, F = fresnelDielectricExt(dot(wi, H), ct, etaM);
+    prob *= reflect ? F : (1 - F);
+    return fabsf(prob * dwh_dwo);
+}
+DEV v3 rdSample(const MaterialD &mt, v3 wi, float sx, float sy, float extra, v3 &wo, float &pdf, float &etaOut) {
+    const float etaM = mt.eta[0], invEta = 1 / etaM, alpha = maxf(mt.alpha, 1e-4f);
+    v3 wiS = wi * signum_(wi.z);
+    v3 m = mfSampleVisible(mt.distr, alpha, wiS, sx, sy);
+    float microfacetPDF = mfPdfVisible(mt.distr, alpha, wiS, m);
+    if (microfacetPDF == 0) return V(0, 0, 0);
+    pdf = microfacetPDF;
+    float cosThetaT, F = fresnelDielectricExt(dot(wi, m), cosThetaT, etaM);
+    bool sampleReflection = true; v3 weight = V(1, 1, 1); float dwh_dwo;
+    if (extra > F) { sampleReflection = false; pdf *= 1 - F; } else pdf *= F;
+    if (sampleReflection) {
+        float c = 2 * dot(wi, m); wo = m * c - wi; etaOut = 1.0f;
+        if (wi.z * wo.z <= 0) return V(0, 0, 0);
+        weight = weight * ld3(mt.specular);
+        dwh_dwo = 1.0f / (4.0f * dot(wo, m));
+    } else {
+        if (cosThetaT == 0) return V(0, 0, 0);
+        float e = cosThetaT < 0 ? 1 / etaM : etaM;                                   // refract(wi, n, eta, cosThetaT), src/libcore/util.cpp:769-774
+        wo = m * (dot(wi, m) * e + cosThetaT) - wi * e;
+        etaOut = cosThetaT < 0 ? etaM : invEta;
+        if (wi.z * wo.z >= 0) return V(0, 0, 0);
+        float factor = cosThetaT < 0 ? invEta : etaM;
+        weight = weight * (ld3(mt.reflectance) * (factor * factor));
+        float sqrtDenom = dot(wi, m) + etaOut * dot(wo, m);
+        dwh_dwo = (etaOut * etaOut * dot(wo, m)) / (sqrtDenom * sqrtDenom);
+    }
+    weight = weight * mfSmithG1(mt.distr, alpha, wo, m);
+    pdf *= fabsf(dwh_dwo);
+    return weight;
+}
+DEV v3 dtEval(const MaterialD &m, v3 wi, v3 wo) { if (wi.z * wo.z >= 0) return V(0, 0, 0); return ld3(m.reflectance) * (MI_INV_PI * fabsf(wo.z)); }
+DEV float dtPdf(v3 wi, v3 wo) { if (wi.z * wo.z >= 0) return 0.0f; return fabsf(wo.z) * MI_INV_PI; }
+DEV v3 dtSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float &pdf, float &eta) {
+    wo = cosHemisphere(sx, sy); if (wi.z > 0) wo.z *= -1;
+    eta = 1.0f; pdf = fabsf(wo.z) * MI_INV_PI;
+    return ld3(m.reflectance);
+}
+
 // ---------------------------------------------------------------------------------------------- BSDFs
 // src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side).  RC = the scene holds non-diffuse materials
 // (rough conductor, conductor, dielectric, plastic): the diffuse-only kernel variants carry none of that code.
@@ -700,6 +771,8 @@ template <bool RC> DEV v3 bsdfEval(const MaterialD &m, v3 wi, v3 wo) {
     if (RC && m.type != 0) {
         if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) return rcEval(m, wi, wo);
         if (m.type == MI_BSDF_T_PLASTIC) return plasticEval(m, wi, wo);
+        if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) return rdEval(m, wi, wo);
+        if (m.type == MI_BSDF_T_DIFFTRANS) return dtEval(m, wi, wo);
         return V(0, 0, 0);
     }
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
@@ -711,13 +784,17 @@ template <bool RC> DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
     if (RC && m.type != 0) {
         if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) return rcPdf(m, wi, wo);
         if (m.type == MI_BSDF_T_PLASTIC) return plasticPdf(m, wi, wo);
+        if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) return rdPdf(m, wi, wo);
+        if (m.type == MI_BSDF_T_DIFFTRANS) return dtPdf(wi, wo);
         return 0.0f;
     }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
     return MI_INV_PI * wo.z;
 }
 // delta = the sampled component is a Dirac delta (bRec.sampledType & BSDF::EDelta, path.cpp:259-260)
-template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta, bool &delta) {
+// `extra`: one more value from the path's sampler, drawn by the caller iff bsdfUsesSampler(m) (BSDF::EUsesSampler)
+DEV bool bsdfUsesSampler(const MaterialD &m) { return m.type == MI_BSDF_T_ROUGHDIELECTRIC; }
+template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, float extra, v3 &wo, float &pdf, float &eta, bool &delta) {
     bool flipped = false; delta = false;
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; flipped = true; }
     if (RC && m.type != 0) {
@@ -725,6 +802,8 @@ template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v
         if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) w = rcSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_CONDUCTOR) w = conductorSample(m, wi, wo, pdf, eta, delta);
         else if (m.type == MI_BSDF_T_DIELECTRIC) w = dielectricSample(m, wi, u, wo, pdf, eta, delta);
+        else if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) w = rdSample(m, wi, u, v, extra, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_DIFFTRANS) w = dtSample(m, wi, u, v, wo, pdf, eta);
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);
         if (flipped && !isZero(w) && pdf != 0) wo.z = -wo.z;      // twosided.cpp:176-180
         return w;

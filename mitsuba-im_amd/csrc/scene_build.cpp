@@ -171,7 +171,7 @@ void SceneHost::commitHost() {
     auto materialFlags = [&](int bsdf) {
         const mi_material &mat = materials[bsdf];
         // dRec.refN = 0 when the BSDF has ETransmission or EBackSide (records.inl:160-164): twosided wrapper, dielectric
-        bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC;
+        bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS;
         // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
         // conductor / dielectric register delta components only
         bool smooth = mat.type == MI_BSDF_DIFFUSE ? std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0

@@ -391,3 +391,23 @@ def test_instances(mi, oracle, golden_scenes):
     assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 3e-3
+
+
+@pytest.mark.parametrize("name", ["cbox_translucent", "cbox_translucent_indep"])
+def test_rough_dielectric_and_difftrans(mi, oracle, golden_scenes, name):
+    """`roughdielectric` (microfacet reflection / refraction with visible-normal sampling; draws one more sampler dimension per bounce, which
+    shifts every later dimension of the path) and `difftrans`.  Microfacet code calls the math library -> tolerance-pinned like roughconductor."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(18); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6 and (bits(got) == bits(ref)).all(1).mean() > 0.5
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
