@@ -144,7 +144,7 @@ static mi_material convertBSDF(const BSDF *bsdf) {
             return m;
         }
         if (cls == "DiffuseTransmitter") {
-            m.type = MI_BSDF_DIFFTRANS; rgb3(props.getSpectrum("transmittance", Spectrum(.5f)), m.reflectance);
+            m.type = MI_BSDF_DIFFTRANS; rgb3(props.getSpectrum(props.hasProperty("transmittance") ? "transmittance" : "diffuseTransmittance", Spectrum(.5f)), m.reflectance);   // difftrans.cpp:52-57
             return m;
         }
         if (cls == "SmoothPlastic") {

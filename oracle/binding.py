@@ -44,7 +44,7 @@ class OrcSceneDesc(C.Structure):
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
-                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p)]
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p)]
 
 
 def build():
@@ -113,7 +113,7 @@ def pack_records(sc):
         shapes[i] = OrcShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, s.get("group", 0))
     mats = (OrcMaterial * len(sc.bsdfs))()
     for i, b in enumerate(sc.bsdfs):
-        m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((b["sample_visible"] & 1) << 1) | ((b.get("nonlinear", 0) & 1) << 2), b["distr"], b["alpha"])
+        m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((1 if b["sample_visible"] else 0) << 1) | ((b.get("nonlinear", 0) & 1) << 2), b["distr"], b["alpha"])
         m.reflectance[:] = b["reflectance"]; m.eta[:] = b["eta"]; m.k[:] = b["k"]; m.specular[:] = b["specular"]
         mats[i] = m
     ems = (OrcEmitter * max(1, len(sc.emitters)))()
@@ -174,6 +174,9 @@ class Oracle:
         d.n_analytic, d.analytic = n_an, C.cast(an, C.c_void_p)
         ins, n_ins = pack_instances(sc); self._keep.append(ins)
         d.n_instances, d.instances = n_ins, C.cast(ins, C.c_void_p)
+        mt = sc.get("material_tables")
+        if mt is not None:
+            self._keep.append(mt); d.n_material_tables, d.material_tables = len(mt), _ptr(mt)
         self.h = L.orc_scene_create(C.byref(d))
         self.border = L.orc_film_border(self.h)
 

@@ -50,9 +50,11 @@ typedef struct {
     int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter; int32_t instance;
 } hit_t;
 
+/* a material + the table it refers to (roughplastic); bsdf_* functions receive &mat->m and may cast back */
+typedef struct mat_s { orc_material m; const float *table; } mat_t;
 struct orc_scene {
     orc_scene_desc d;
-    float *pos, *nrm; uint32_t *idx; orc_shape *shapes; orc_material *materials; orc_emitter *emitters;
+    float *pos, *nrm; uint32_t *idx; orc_shape *shapes; struct mat_s *materials; orc_emitter *emitters; float *material_tables;
     uint32_t *tri_shape;
     struct analytic_s *analytic; uint32_t n_analytic, n_prims;
     orc_instance *instances; uint32_t n_instances, n_groups; int *group_root; v3 *group_lo, *group_hi;   /* per shape group: BVH root, kd-tree box (enlarged) */
@@ -738,7 +740,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS; }
@@ -1071,6 +1073,72 @@ static v3 dt_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo, fl
     return V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
 }
 
+/* ---- rough plastic: src/bsdfs/roughplastic.cpp:333-500; RoughTransmittance::eval with eta and alpha fixed (src/bsdfs/rtrans.h:183-193, :232) over
+ * evalCubicInterp1D (src/libcore/spline.cpp:23-60).  Fields: alpha, distr, eta[0], specular, reflectance = diffuseReflectance, flag bit2 nonlinear,
+ * k[0] = internal diffuse transmittance (m_internalRoughTransmittance->evalDiffuse(alpha), roughplastic.cpp:372), k[1] / k[2] = offset / length of
+ * the external transmittance slice in the scene's material tables (setEta(eta) + setAlpha(alpha), roughplastic.cpp:291-299). */
+static float cubic_interp_1d(float x, const float *values, size_t size, float min, float max) {
+    if (!(x >= min && x <= max)) return 0.0f;
+    float t = ((x - min) * (float) (size - 1)) / (max - min);
+    size_t k = (size_t) t; if (k > size - 2) k = size - 2;
+    float f0 = values[k], f1 = values[k + 1], d0, d1;
+    if (k > 0) d0 = 0.5f * (values[k + 1] - values[k - 1]); else d0 = values[k + 1] - values[k];
+    if (k + 2 < size) d1 = 0.5f * (values[k + 2] - values[k]); else d1 = values[k + 1] - values[k];
+    t = t - (float) k;
+    float t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+static float rp_transmittance(const orc_material *m, float cosTheta) {
+    if (!(cosTheta >= 0)) return 0.0f;
+    float warped = powf(fabsf(cosTheta), 0.25f);
+    float result = cubic_interp_1d(warped, ((const mat_t *) m)->table, (size_t) m->k[2], 0.0f, 1.0f);
+    return minf(1.0f, maxf(0.0f, result));
+}
+static float rp_prob_specular(const orc_material *m, float cosThetaI) {
+    float probSpecular = 1 - rp_transmittance(m, cosThetaI), w = plastic_spec_weight(m);
+    return (probSpecular * w) / (probSpecular * w + (1 - probSpecular) * (1 - w));
+}
+static v3 rp_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    const float eta = m->eta[0], alpha = maxf(m->alpha, 1e-4f), invEta2 = 1.0f / (eta * eta);
+    v3 H = normalize(add(wo, wi));
+    float D = mf_eval(m->distr, alpha, H), ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, eta);
+    float G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H);
+    float value = F * D * G / (4.0f * wi.z);
+    v3 result = scale(V(m->specular[0], m->specular[1], m->specular[2]), value);
+    v3 diff = V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
+    float T12 = rp_transmittance(m, wi.z), T21 = rp_transmittance(m, wo.z), Fdr = 1 - m->k[0];
+    if (m->flags & BSDF_FLAG_NONLINEAR) diff = V(diff.x / (1.0f - diff.x * Fdr), diff.y / (1.0f - diff.y * Fdr), diff.z / (1.0f - diff.z * Fdr));
+    else { float r = 1.0f / (1 - Fdr); diff = scale(diff, r); }
+    return add(result, scale(diff, INV_PI * wo.z * T12 * T21 * invEta2));
+}
+static float rp_pdf(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    const float alpha = maxf(m->alpha, 1e-4f);
+    v3 H = normalize(add(wo, wi));
+    float probSpecular = rp_prob_specular(m, wi.z), probDiffuse = 1 - probSpecular;
+    float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+    float prob = mf_pdf_visible(m->distr, alpha, wi, H);
+    float result = prob * dwh_dwo * probSpecular;
+    result += probDiffuse * (INV_PI * wo.z);
+    return result;
+}
+static v3 rp_sample(const orc_material *mt, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *etaOut) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    const float alpha = maxf(mt->alpha, 1e-4f);
+    float probSpecular = rp_prob_specular(mt, wi.z); int choseSpecular = 1;
+    if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = 0; }
+    if (choseSpecular) {
+        v3 m = mf_sample_visible(mt->distr, alpha, wi, sx, sy);
+        float c = 2 * dot(wi, m); *wo = sub(scale(m, c), wi);
+        if (wo->z <= 0) return V(0, 0, 0);
+    } else *wo = cos_hemisphere(sx, sy);
+    *etaOut = 1.0f;
+    *pdf = rp_pdf(mt, wi, *wo);
+    if (*pdf == 0) return V(0, 0, 0);
+    float r = 1.0f / *pdf; return scale(rp_eval(mt, wi, *wo), r);       /* Spectrum / Float */
+}
+
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
@@ -1079,6 +1147,7 @@ static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_PLASTIC: return plastic_eval(m, wi, wo);
         case BSDF_ROUGHDIELECTRIC: return rd_eval(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_eval(m, wi, wo);
+        case BSDF_ROUGHPLASTIC: return rp_eval(m, wi, wo);
         default: return diffuse_eval(m, wi, wo);
     }
 }
@@ -1090,6 +1159,7 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_PLASTIC: return plastic_pdf(m, wi, wo);
         case BSDF_ROUGHDIELECTRIC: return rd_pdf(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_pdf(wi, wo);
+        case BSDF_ROUGHPLASTIC: return rp_pdf(m, wi, wo);
         default: return diffuse_pdf(wi, wo);
     }
 }
@@ -1107,18 +1177,19 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_PLASTIC: w = plastic_sample(m, wi, u, v, wo, pdf, eta, delta); break;
         case BSDF_ROUGHDIELECTRIC: w = rd_sample(m, wi, u, v, sp ? next1D(sp) : g_extra_unit, wo, pdf, eta); break;
         case BSDF_DIFFTRANS: w = dt_sample(m, wi, u, v, wo, pdf, eta); break;
+        case BSDF_ROUGHPLASTIC: w = rp_sample(m, wi, u, v, wo, pdf, eta); break;
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;
     }
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
     return w;
 }
 void orc_bsdf_sample(const orc_scene *s, uint32_t mi, const float *wi, float u, float v, float *o) {
-    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; v3 w = bsdf_sample(&s->materials[mi], V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta, NULL);
+    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; v3 w = bsdf_sample(&s->materials[mi].m, V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta, NULL);
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = pdf; o[4] = wo.x; o[5] = wo.y; o[6] = wo.z; o[7] = eta;
 }
 void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float *wo, float *o) {
-    v3 e = bsdf_eval(&s->materials[mi], V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
-    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(&s->materials[mi], V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
+    v3 e = bsdf_eval(&s->materials[mi].m, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
+    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(&s->materials[mi].m, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
 }
 
 /* ------------------------------------------------------------------------------------------------ environment emitter */
@@ -1394,7 +1465,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
             if (s->env_index >= 0 && emitted_radiance && (!hide || scattered)) Li = add(Li, mul(throughput, env_eval(s, d)));
             break;
         }
-        const orc_material *bsdf = &s->materials[its.material];
+        const orc_material *bsdf = &s->materials[its.material].m;
         if (its.emitter >= 0 && emitted_radiance && (!hide || scattered))
             Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
         if ((depth >= maxDepth && maxDepth > 0) || (strict && dot(d, its.ng) * its.wi.z >= 0)) break;
@@ -1584,7 +1655,10 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     s->pos = (float *) dup(d->pos, (size_t) d->n_verts * 12); s->nrm = (float *) dup(d->nrm, (size_t) d->n_verts * 12);
     s->idx = (uint32_t *) dup(d->idx, (size_t) d->n_tris * 12);
     s->shapes = (orc_shape *) dup(d->shapes, d->n_shapes * sizeof(orc_shape));
-    s->materials = (orc_material *) dup(d->materials, d->n_materials * sizeof(orc_material));
+    s->material_tables = (float *) dup(d->material_tables, (size_t) (d->material_tables ? d->n_material_tables : 0) * 4);
+    s->materials = (mat_t *) calloc(d->n_materials ? d->n_materials : 1, sizeof(mat_t));
+    for (uint32_t i = 0; i < d->n_materials; ++i) { s->materials[i].m = d->materials[i]; s->materials[i].table = s->material_tables ? s->material_tables + (size_t) d->materials[i].k[1] : NULL; }
+    s->d.material_tables = NULL;
     s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
     s->tri_shape = (uint32_t *) calloc(d->n_tris, 4);
     for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->tri_shape[s->shapes[i].first_tri + t] = i;
@@ -1766,5 +1840,5 @@ void orc_scene_destroy(orc_scene *s) {
     free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic); free(s->instances); free(s->group_root); free(s->group_lo); free(s->group_hi); free(s->group_first); free(s->group_count);
     free(s->spot_cos_beam); free(s->spot_cos_cutoff); free(s->spot_inv_transition); free(s->spot_cutoff); free(s->spot_to_local);
     free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
-    free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->emitters); free(s);
+    free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->material_tables); free(s->emitters); free(s);
 }

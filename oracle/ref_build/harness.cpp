@@ -63,6 +63,12 @@ template <typename T> static void save(const std::string &p, const char *d, std:
     save_npy(p, d, shape, v.data(), v.size() * sizeof(T));
 }
 
+#include <rtrans.h>   // src/bsdfs/rtrans.h: RoughTransmittance (tables for the `tables` mode)
+struct RTAccess : RoughTransmittance {   // its slices are protected members
+    RTAccess(MicrofacetDistribution::EType t) : RoughTransmittance(t) { }
+    const Float *trans() const { return m_trans; } size_t thetaSamples() const { return m_thetaSamples; }
+};
+
 // ------------------------------------------------------------------------------------------ scene file
 struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
 struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
@@ -201,6 +207,13 @@ static Built buildScene(const FScene &fs) {
             Properties p("dielectric");
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 7) {
+            Properties p("roughplastic");
+            p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx"); p.setFloat("alpha", fb.alpha);
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", true);
+            p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("diffuseReflectance", rgb(fb.refl));
+            p.setBoolean("nonlinear", fb.sampleVisible == 2);          // FBsdf::sampleVisible carries the nonlinear flag for roughplastic (2)
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 5) {
             Properties p("roughdielectric");
@@ -418,6 +431,19 @@ static void modeTables(const std::string &out) {
     std::vector<float> fdr;
     for (float eta : {1.1f, 1.3f, 1.33f, 1.49f, 1.5046f, 1.7f, 2.0f, 2.419f}) { fdr.push_back(eta); fdr.push_back(fresnelDiffuseReflectance(1 / eta, false)); fdr.push_back(fresnelDiffuseReflectance(eta, false)); }
     save(out + "/fresnel_diffuse_reflectance.npy", "<f4", {fdr.size() / 3, 3}, fdr);
+    // RoughPlastic::configure (roughplastic.cpp:281-299): the external rough transmittance reduced to a 1-D slice over the incidence angle
+    // (setEta(eta), setAlpha(alpha)) and the internal diffuse transmittance (setEta(1/eta), evalDiffuse(alpha)); rows: distr, eta, alpha, Tdiff_int, T[100]
+    std::vector<float> rt;
+    for (int distr = 0; distr < 2; ++distr) for (float eta : {1.49f, 1.5046f, 1.9f}) for (float alpha : {0.05f, 0.1f, 0.3f}) {
+        ref<RTAccess> ext = new RTAccess(distr == 0 ? MicrofacetDistribution::EBeckmann : MicrofacetDistribution::EGGX);
+        ext->checkEta(eta); ext->checkAlpha(alpha);
+        ref<RoughTransmittance> internal = ext->clone();
+        ext->setEta(eta); internal->setEta(1 / eta); ext->setAlpha(alpha);
+        rt.push_back((float) distr); rt.push_back(eta); rt.push_back(alpha); rt.push_back(internal->evalDiffuse(alpha));
+        if (ext->thetaSamples() != 100) { fprintf(stderr, "unexpected table size\n"); _exit(2); }
+        for (size_t i = 0; i < 100; ++i) rt.push_back(ext->trans()[i]);
+    }
+    save(out + "/rough_transmittance_slices.npy", "<f4", {rt.size() / 104, 104}, rt);
 }
 
 static uint64_t g_rays = 0, g_shadow = 0;
@@ -660,6 +686,7 @@ int main(int argc, char **argv) {
     // Bitmap::staticInitialization() only initialises FormatConverter (fmtconv.cpp needs boost::mpl, absent) -> skipped; nothing here converts bitmaps.
     Scheduler::staticInitialization();
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
+    Thread::getThread()->getFileResolver()->appendPath(fs::pathstr(MI_REF_ROOT));   // data/microfacet/*.dat, data/ior/*.spd (roughplastic, named conductors)
     if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }

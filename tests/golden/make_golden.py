@@ -51,6 +51,8 @@ def golden_scenes():
         # roughdielectric (extra sampler dimension per bounce) + difftrans
         "cbox_translucent": scenes.cbox_translucent(width=96, height=96, spp=16),
         "cbox_translucent_indep": scenes.cbox_translucent(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=9, rr_depth=2, strict_normals=True),
+        # roughplastic (rough-transmittance slices of the reference's data/microfacet tables as material input)
+        "cbox_roughplastic": scenes.cbox_roughplastic(width=96, height=96, spp=16),
     }
 
 
@@ -78,7 +80,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)
