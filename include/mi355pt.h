@@ -44,6 +44,10 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
                                      k[0] = fresnelDiffuseReflectance(1 / eta, false) (SmoothPlastic::m_fdrInt, plastic.cpp:200)       */
 #define MI_BSDF_ROUGHDIELECTRIC 5 /* src/bsdfs/roughdielectric.cpp: alpha, distr, eta[0], specular = specularReflectance, reflectance = specularTransmittance */
 #define MI_BSDF_DIFFTRANS 6       /* src/bsdfs/difftrans.cpp: reflectance = transmittance                                            */
+#define MI_BSDF_ROUGHPLASTIC 7    /* src/bsdfs/roughplastic.cpp: alpha, distr, eta[0], specular, reflectance = diffuseReflectance; k[0] = internal diffuse rough
+                                     transmittance (m_internalRoughTransmittance->evalDiffuse(alpha), roughplastic.cpp:372), k[1] / k[2] = offset / length of the
+                                     external rough-transmittance slice (RoughTransmittance after setEta + setAlpha, src/bsdfs/rtrans.h:292-388) in the table
+                                     buffer of mi_scene_set_material_tables */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
@@ -127,6 +131,7 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *shapes, uint32_t n);
 /* instances of shape groups; primitive index of the i-th: n_tris + n_analytic + i (they come last in Scene::getShapes order here) */
 int mi_scene_set_instances(mi_scene *s, const mi_instance *instances, uint32_t n);
 int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
+int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n);   /* float tables the materials refer to by offset (roughplastic) */
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);
 /* PerspectiveCameraImpl: m_sampleToCamera, world transform, clip planes (src/sensors/perspective.cpp:126-178) */

@@ -25,6 +25,7 @@
 #include <mitsuba/core/mstream.h>
 #include <mitsuba/core/serialization.h>
 #include <instance.h>     // src/shapes/instance.h (pulls in shapegroup.h, which has no include guard): inline accessors only (getShapeGroup, getWorldTransform, getKDTree)
+#include <rtrans.h>       // src/bsdfs/rtrans.h: RoughTransmittance, as RoughPlastic::configure uses it
 #include <ior.h>   // src/bsdfs/ior.h: lookupIOR, as used by RoughConductor's constructor
 #include "../integrator_host.h"
 
@@ -34,12 +35,28 @@ namespace {
 
 struct FlatScene {
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
-    std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances;
+    std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances; std::vector<float> materialTables;
     bool anyNormals = false;
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16], envScale = 1.0f;
 };
 
 #define MI_CHECK(call) do { int rc_ = (call); if (rc_ != MI_OK) SLog(EError, "path_hip: %s failed: %s", #call, mi_last_error()); } while (0)
+
+/// RoughPlastic::configure (src/bsdfs/roughplastic.cpp:281-299): external rough transmittance reduced to a 1-D slice (setEta, setAlpha), internal
+/// diffuse transmittance; the slice is appended to `tables` and referenced from the material (k[1] offset, k[2] length, k[0] Tdiff_int)
+struct RTAccess : RoughTransmittance {
+    RTAccess(MicrofacetDistribution::EType t) : RoughTransmittance(t) { }
+    const Float *trans() const { return m_trans; } size_t thetaSamples() const { return m_thetaSamples; }
+};
+static std::vector<float> *g_tables = NULL;      // FlatScene::materialTables of the flatten() in progress (single-threaded: preprocess)
+static void roughPlasticTables(mi_material &m) {
+    ref<RTAccess> ext = new RTAccess(m.distr == 1 ? MicrofacetDistribution::EGGX : MicrofacetDistribution::EBeckmann);
+    ext->checkEta(m.eta[0]); ext->checkAlpha(m.alpha);
+    ref<RoughTransmittance> internal = ext->clone();
+    ext->setEta(m.eta[0]); internal->setEta(1 / m.eta[0]); ext->setAlpha(m.alpha);
+    m.k[0] = internal->evalDiffuse(m.alpha); m.k[1] = (float) g_tables->size(); m.k[2] = (float) ext->thetaSamples();
+    g_tables->insert(g_tables->end(), ext->trans(), ext->trans() + ext->thetaSamples());
+}
 
 /// `twosided` keeps its nested BSDF private (src/bsdfs/twosided.cpp:197-198) and the nested object's Properties are gone once it is configured
 /// from a parent, so the wrapper is read through the one public door that shows its content: serialisation.  TwoSidedBRDF::serialize
@@ -75,6 +92,14 @@ static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
         memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
     } else if (cls == "SmoothConductor") {
         std::vector<float> spec = rd.texture(); m.type = MI_BSDF_CONDUCTOR; memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
+    } else if (cls == "RoughPlastic") {                                 // roughplastic.cpp:247-257
+        uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
+        std::vector<float> spec = rd.texture(), diff = rd.texture(), alpha = rd.texture();
+        if (distr > 1 || !sampleVisible) SLog(EError, "path_hip: roughplastic is implemented for beckmann / ggx with sampleVisible = true");
+        m.type = MI_BSDF_ROUGHPLASTIC; m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = alpha[0];
+        memcpy(m.specular, spec.data(), 12); memcpy(m.reflectance, diff.data(), 12);
+        m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
+        roughPlasticTables(m);
     } else if (cls == "SmoothPlastic") {
         m.type = MI_BSDF_PLASTIC; m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
         std::vector<float> spec = rd.texture(), diff = rd.texture(); memcpy(m.specular, spec.data(), 12); memcpy(m.reflectance, diff.data(), 12);
@@ -147,6 +172,16 @@ static mi_material convertBSDF(const BSDF *bsdf) {
             m.type = MI_BSDF_DIFFTRANS; rgb3(props.getSpectrum(props.hasProperty("transmittance") ? "transmittance" : "diffuseTransmittance", Spectrum(.5f)), m.reflectance);   // difftrans.cpp:52-57
             return m;
         }
+        if (cls == "RoughPlastic") {
+            std::string distr = props.getString("distribution", "beckmann"); std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+            if ((distr != "beckmann" && distr != "ggx") || !props.getBoolean("sampleVisible", true)) SLog(EError, "path_hip: roughplastic is implemented for beckmann / ggx with sampleVisible = true");
+            m.type = MI_BSDF_ROUGHPLASTIC; m.flags = MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr == "ggx" ? 1u : 0u; m.alpha = props.getFloat("alpha", 0.1f);
+            m.eta[0] = lookupIOR(props, "intIOR", "polypropylene") / lookupIOR(props, "extIOR", "air");
+            if (props.getBoolean("nonlinear", false)) m.flags |= MI_BSDF_FLAG_NONLINEAR;
+            rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("diffuseReflectance", Spectrum(0.5f)), m.reflectance);
+            roughPlasticTables(m);
+            return m;
+        }
         if (cls == "SmoothPlastic") {
             m.type = MI_BSDF_PLASTIC; m.eta[0] = lookupIOR(props, "intIOR", "polypropylene") / lookupIOR(props, "extIOR", "air");
             m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
@@ -211,6 +246,7 @@ static bool convertAnalytic(const Shape *shape, mi_analytic &a) {
 }
 
 static void flatten(const Scene *scene, FlatScene &fs) {
+    g_tables = &fs.materialTables;
     const std::vector<TriMesh *> &meshes = scene->getMeshes();
     std::map<const BSDF *, int> bsdfIndex; std::vector<const Instance *> insts;
     // non-mesh shapes: rectangle / disk / sphere / cylinder become analytic records (numbered after the meshes); anything else is refused
@@ -333,6 +369,7 @@ struct GpuScene {
         if (!fs.analytic.empty()) MI_CHECK(mi_scene_set_analytic(scene, fs.analytic.data(), (uint32_t) fs.analytic.size()));
         if (!fs.instances.empty()) MI_CHECK(mi_scene_set_instances(scene, fs.instances.data(), (uint32_t) fs.instances.size()));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
+        if (!fs.materialTables.empty()) MI_CHECK(mi_scene_set_material_tables(scene, fs.materialTables.data(), (uint32_t) fs.materialTables.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
         if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));
         // camera: rebuild m_sampleToCamera exactly as PerspectiveCameraImpl::configure does (perspective.cpp:150-157); it is a protected member

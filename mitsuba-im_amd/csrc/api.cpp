@@ -132,6 +132,10 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *a, uint32_t n) {
     }
     s->h.analytic.assign(a, a + n); s->h.committed = false; return MI_OK;
 }
+int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n) {
+    if (!s || (n && !data)) return fail(MI_ERR_INVALID, "mi_scene_set_material_tables: null argument");
+    s->h.materialTables.assign(data, data + n); s->h.committed = false; return MI_OK;
+}
 int mi_scene_set_instances(mi_scene *s, const mi_instance *a, uint32_t n) {
     if (!s || (n && !a)) return fail(MI_ERR_INVALID, "mi_scene_set_instances: null argument");
     for (uint32_t i = 0; i < n; ++i)
@@ -141,10 +145,10 @@ int mi_scene_set_instances(mi_scene *s, const mi_instance *a, uint32_t n) {
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_DIFFTRANS) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_ROUGHPLASTIC) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic (those without transmission optionally twosided)");
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_DIFFTRANS) && (m[i].flags & MI_BSDF_FLAG_TWOSIDED)) return fail(MI_ERR_INVALID, "Only BSDFs without a transmission component can be nested!");   // twosided.cpp:86-88
-        if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
-        if ((m[i].type == MI_BSDF_ROUGHCONDUCTOR || m[i].type == MI_BSDF_ROUGHDIELECTRIC) && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE)))
+        if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
+        if ((m[i].type == MI_BSDF_ROUGHCONDUCTOR || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC) && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE)))
             return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: roughconductor / roughdielectric support beckmann / ggx with sampleVisible = true");
     }
     s->h.materials.assign(m, m + n); s->h.committed = false; return MI_OK;
@@ -191,7 +195,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -201,7 +205,7 @@ int SceneHost::upload(int dev) {
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
     int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
-              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
+              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dMaterialTables, materialTables) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
     if (g_sobolDims && logRes <= 16) {
@@ -216,6 +220,7 @@ int SceneHost::upload(int dev) {
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
     d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
+    d.material_tables = (const float *) dMaterialTables;
     d.instances = (const InstanceD *) dInstances; d.n_instances = (uint32_t) instancesD.size();
     d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters) ? 1u : 0u;
     memcpy(d.dir_bs_center, dirBsCenter, 12); d.dir_bs_radius = dirBsRadius;
@@ -259,6 +264,9 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         for (const mi_shape &sh : s->h.shapes) if (sh.group && sh.emitter >= 0) return fail(MI_ERR_INVALID, "Instancing of emitters is not supported");   // shapegroup.cpp:75-76
         for (const mi_instance &in : s->h.instances) if (in.group >= ng) return fail(MI_ERR_INVALID, "A reference to a 'shapegroup' must be specified!");   // instance.cpp:41-44
     }
+    for (const mi_material &m : s->h.materials)
+        if (m.type == MI_BSDF_ROUGHPLASTIC && (m.k[2] < 2 || m.k[1] < 0 || (size_t) m.k[1] + (size_t) m.k[2] > s->h.materialTables.size()))
+            return fail(MI_ERR_INVALID, "mi_scene_commit: roughplastic material without its rough-transmittance slice (mi_scene_set_material_tables)");
     for (const mi_analytic &a : s->h.analytic) {
         if (a.bsdf < 0 || (size_t) a.bsdf >= s->h.materials.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing material");
         if (a.emitter >= (int32_t) s->h.emitters.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing emitter");

@@ -401,9 +401,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     if (dr.pdf != 0) {
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
-                        v3 bsdfVal = bsdfEval<RC>(bsdf, h.wi, wo);
+                        v3 bsdfVal = bsdfEval<RC>(sc, bsdf, h.wi, wo);
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = dr.delta ? 0.0f : bsdfPdf<RC>(bsdf, h.wi, wo);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
+                            float bp = dr.delta ? 0.0f : bsdfPdf<RC>(sc, bsdf, h.wi, wo);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
                             wantShadow = true;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
             bool sampledDelta; float extra = 0.0f;
             if (RC && bsdfUsesSampler(bsdf)) extra = next1D(ss, rc.sampler, m32);      // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler)
-            v3 bw = bsdfSample<RC>(bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta);
+            v3 bw = bsdfSample<RC>(sc, bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta);
             v3 wo = toWorld(h, woL);
             if (isZero(bw) || (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0)) pathLen += (unsigned) depth;
             else {

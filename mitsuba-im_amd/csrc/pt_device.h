@@ -763,29 +763,99 @@ DEV v3 dtSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float &pd
     return ld3(m.reflectance);
 }
 
+// ---------------------------------------------------------------------------------------------- rough plastic
+// src/bsdfs/roughplastic.cpp:333-500; RoughTransmittance::eval with eta and alpha fixed (src/bsdfs/rtrans.h:183-193, :232) over evalCubicInterp1D
+// (src/libcore/spline.cpp:23-60).  alpha, distr, eta[0], specular, reflectance = diffuseReflectance, flag bit2 nonlinear, k[0] = internal diffuse
+// transmittance (roughplastic.cpp:372), k[1] / k[2] = offset / length of the external transmittance slice in DScene::material_tables.
+#define MI_BSDF_T_ROUGHPLASTIC 7u
+DEV float cubicInterp1D(float x, const float *values, uint32_t size, float mn, float mx) {
+    if (!(x >= mn && x <= mx)) return 0.0f;
+    float t = ((x - mn) * (float) (size - 1)) / (mx - mn);
+    uint32_t k = (uint32_t) t; if (k > size - 2) k = size - 2;
+    float f0 = values[k], f1 = values[k + 1], d0, d1;
+    if (k > 0) d0 = 0.5f * (values[k + 1] - values[k - 1]); else d0 = values[k + 1] - values[k];
+    if (k + 2 < size) d1 = 0.5f * (values[k + 2] - values[k]); else d1 = values[k + 1] - values[k];
+    t = t - (float) k;
+    float t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+DEV float rpTransmittance(const DScene &sc, const MaterialD &m, float cosTheta) {
+    if (!(cosTheta >= 0)) return 0.0f;
+    float warped = powf(fabsf(cosTheta), 0.25f);
+    float result = cubicInterp1D(warped, sc.material_tables + (uint32_t) m.k[1], (uint32_t) m.k[2], 0.0f, 1.0f);
+    return minf(1.0f, maxf(0.0f, result));
+}
+DEV float rpProbSpecular(const DScene &sc, const MaterialD &m, float cosThetaI) {
+    float probSpecular = 1 - rpTransmittance(sc, m, cosThetaI);
+    float dAvg = luminance3(ld3(m.reflectance)), sAvg = luminance3(ld3(m.specular)), w = sAvg / (dAvg + sAvg);
+    return (probSpecular * w) / (probSpecular * w + (1 - probSpecular) * (1 - w));
+}
+DEV v3 rpEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    const float eta = m.eta[0], alpha = maxf(m.alpha, 1e-4f), invEta2 = 1.0f / (eta * eta);
+    v3 H = normalize(wo + wi);
+    float D = mfEval(m.distr, alpha, H), ct, F = fresnelDielectricExt(dot(wi, H), ct, eta);
+    float G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H);
+    float value = F * D * G / (4.0f * wi.z);
+    v3 result = ld3(m.specular) * value;
+    v3 diff = ld3(m.reflectance);
+    float T12 = rpTransmittance(sc, m, wi.z), T21 = rpTransmittance(sc, m, wo.z), Fdr = 1 - m.k[0];
+    if (m.flags & 4u) diff = V(diff.x / (1.0f - diff.x * Fdr), diff.y / (1.0f - diff.y * Fdr), diff.z / (1.0f - diff.z * Fdr));
+    else { float r = 1.0f / (1 - Fdr); diff = diff * r; }
+    return result + diff * (MI_INV_PI * wo.z * T12 * T21 * invEta2);
+}
+DEV float rpPdf(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    const float alpha = maxf(m.alpha, 1e-4f);
+    v3 H = normalize(wo + wi);
+    float probSpecular = rpProbSpecular(sc, m, wi.z), probDiffuse = 1 - probSpecular;
+    float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+    float prob = mfPdfVisible(m.distr, alpha, wi, H);
+    float result = prob * dwh_dwo * probSpecular;
+    result += probDiffuse * (MI_INV_PI * wo.z);
+    return result;
+}
+DEV v3 rpSample(const DScene &sc, const MaterialD &mt, v3 wi, float sx, float sy, v3 &wo, float &pdf, float &etaOut) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    const float alpha = maxf(mt.alpha, 1e-4f);
+    float probSpecular = rpProbSpecular(sc, mt, wi.z); bool choseSpecular = true;
+    if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = false; }
+    if (choseSpecular) {
+        v3 m = mfSampleVisible(mt.distr, alpha, wi, sx, sy);
+        float c = 2 * dot(wi, m); wo = m * c - wi;
+        if (wo.z <= 0) return V(0, 0, 0);
+    } else wo = cosHemisphere(sx, sy);
+    etaOut = 1.0f;
+    pdf = rpPdf(sc, mt, wi, wo);
+    if (pdf == 0) return V(0, 0, 0);
+    float r = 1.0f / pdf; return rpEval(sc, mt, wi, wo) * r;
+}
+
 // ---------------------------------------------------------------------------------------------- BSDFs
 // src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side).  RC = the scene holds non-diffuse materials
 // (rough conductor, conductor, dielectric, plastic): the diffuse-only kernel variants carry none of that code.
-template <bool RC> DEV v3 bsdfEval(const MaterialD &m, v3 wi, v3 wo) {
+template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     if (RC && m.type != 0) {
         if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) return rcEval(m, wi, wo);
         if (m.type == MI_BSDF_T_PLASTIC) return plasticEval(m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) return rdEval(m, wi, wo);
         if (m.type == MI_BSDF_T_DIFFTRANS) return dtEval(m, wi, wo);
+        if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpEval(sc, m, wi, wo);
         return V(0, 0, 0);
     }
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
     float f = MI_INV_PI * wo.z;
     return V(m.reflectance[0] * f, m.reflectance[1] * f, m.reflectance[2] * f);
 }
-template <bool RC> DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
+template <bool RC> DEV float bsdfPdf(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     if (RC && m.type != 0) {
         if (m.type == MI_BSDF_T_ROUGHCONDUCTOR) return rcPdf(m, wi, wo);
         if (m.type == MI_BSDF_T_PLASTIC) return plasticPdf(m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) return rdPdf(m, wi, wo);
         if (m.type == MI_BSDF_T_DIFFTRANS) return dtPdf(wi, wo);
+        if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpPdf(sc, m, wi, wo);
         return 0.0f;
     }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
@@ -794,7 +864,7 @@ template <bool RC> DEV float bsdfPdf(const MaterialD &m, v3 wi, v3 wo) {
 // delta = the sampled component is a Dirac delta (bRec.sampledType & BSDF::EDelta, path.cpp:259-260)
 // `extra`: one more value from the path's sampler, drawn by the caller iff bsdfUsesSampler(m) (BSDF::EUsesSampler)
 DEV bool bsdfUsesSampler(const MaterialD &m) { return m.type == MI_BSDF_T_ROUGHDIELECTRIC; }
-template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v, float extra, v3 &wo, float &pdf, float &eta, bool &delta) {
+template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi, float u, float v, float extra, v3 &wo, float &pdf, float &eta, bool &delta) {
     bool flipped = false; delta = false;
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; flipped = true; }
     if (RC && m.type != 0) {
@@ -804,6 +874,7 @@ template <bool RC> DEV v3 bsdfSample(const MaterialD &m, v3 wi, float u, float v
         else if (m.type == MI_BSDF_T_DIELECTRIC) w = dielectricSample(m, wi, u, wo, pdf, eta, delta);
         else if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) w = rdSample(m, wi, u, v, extra, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_DIFFTRANS) w = dtSample(m, wi, u, v, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_ROUGHPLASTIC) w = rpSample(sc, m, wi, u, v, wo, pdf, eta);
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);
         if (flipped && !isZero(w) && pdf != 0) wo.z = -wo.z;      // twosided.cpp:176-180
         return w;

@@ -85,6 +85,7 @@ struct DScene {
     uint32_t ext;                         // analytic shapes or delta emitters present: selects the k_shade<..., EXT> variants
     // scene-level emitters beyond envmap (src/emitters/constant.cpp, point.cpp, spot.cpp, directional.cpp): per emitter 16 floats
     //   [0..2] position (point, spot) / travel direction (directional); spot: [3] cos(cutoff), [4..12] world->local 3x3, [13] cos(beam), [14] cutoff, [15] 1/(cutoff-beam)
+    const float *material_tables;                    // float tables referenced by materials (roughplastic: k[1] = offset, k[2] = length)
     const float *emitter_x; uint32_t env_constant;   // env_constant: the environment emitter (env_index) is `constant`; radiance in its EmitterD
     float dir_bs_center[3], dir_bs_radius;           // DirectionalEmitter::createShape: kd-tree box bounding sphere x 1.1
     uint32_t n_tris, n_nodes, n_emitters, n_materials;

@@ -411,3 +411,24 @@ def test_rough_dielectric_and_difftrans(mi, oracle, golden_scenes, name):
     assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
+
+
+def test_roughplastic(mi, oracle, golden_scenes):
+    """`roughplastic`: glossy microfacet coat over a diffuse base; the rough-transmittance slice (100 values, Catmull-Rom lookup over the warped
+    incidence angle) is material input data taken from the reference's own tables.  Microfacet code + powf -> tolerance-pinned."""
+    name = "cbox_roughplastic"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(28); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
+    with pytest.raises(mi.MiError, match="rough-transmittance"):
+        bad = mi.scenes.cbox_roughplastic(32, 32, 1); bad.material_tables = None; mi.Scene(bad)

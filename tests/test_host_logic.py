@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu(mi):
     assert rc == 1 and b"index out of range" in L.L.mi_last_error()
     assert L.L.mi_scene_set_film(h, 0, 10, 0, 0.5, 0.5) == 1
     assert L.L.mi_scene_set_materials(h, None, 0) == 1
-    mats = (mi.api.MiMaterial * 1)(mi.api.MiMaterial(7, 0, 0, 0.1))
+    mats = (mi.api.MiMaterial * 1)(mi.api.MiMaterial(99, 0, 0, 0.1))
     assert L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), 1) == 3          # MI_ERR_UNSUPPORTED
     assert L.L.mi_scene_commit(h, 0) == 1 and b"must be set first" in L.L.mi_last_error()
     assert L.L.mi_scene_set_envmap(h, None, 0, 0, None, 1.0) == 1 and b"mi_scene_set_envmap" in L.L.mi_last_error()
