@@ -136,7 +136,8 @@ int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n); 
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);
 /* PerspectiveCameraImpl: m_sampleToCamera, world transform, clip planes (src/sensors/perspective.cpp:126-178) */
 int mi_scene_set_camera(mi_scene *s, const float *sample_to_camera16, const float *to_world16, float near_clip, float far_clip);
-/* Film crop size + reconstruction filter (src/librender/film.cpp:92; src/rfilters/box.cpp, gaussian.cpp): kind 0 box(radius), 1 gaussian(stddev) */
+/* Film crop size + reconstruction filter (src/librender/film.cpp:92; src/rfilters/*.cpp): kind 0 box(radius), 1 gaussian(stddev), 2 tent,
+ * 3 mitchell (B in `radius`, C in `stddev`), 4 catmullrom, 5 lanczos (lobes in `radius`) */
 int mi_scene_set_film(mi_scene *s, uint32_t width, uint32_t height, uint32_t filter_kind, float radius, float stddev);
 int mi_scene_commit(mi_scene *s, uint32_t device);   /* BVH build + TriAccel table + upload */
 

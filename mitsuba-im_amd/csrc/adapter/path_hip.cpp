@@ -387,7 +387,11 @@ struct GpuScene {
         const ReconstructionFilter *rf = film->getReconstructionFilter(); std::string fname = rf->getClass()->getName();
         if (fname == "BoxFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 0, rf->getRadius() - 1e-5f, 0.5f));
         else if (fname == "GaussianFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 1, 0.5f, rf->getRadius() / 4.0f));
-        else SLog(EError, "path_hip: reconstruction filter \"%s\" is not implemented (box, gaussian)", fname.c_str());
+        else if (fname == "TentFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 2, 1.0f, 0.5f));
+        else if (fname == "MitchellNetravaliFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 3, rf->getProperties().getFloat("B", 1.0f / 3.0f), rf->getProperties().getFloat("C", 1.0f / 3.0f)));
+        else if (fname == "CatmullRomFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 4, 2.0f, 0.5f));
+        else if (fname == "LanczosSincFilter") MI_CHECK(mi_scene_set_film(scene, cropSize.x, cropSize.y, 5, rf->getRadius(), 0.5f));
+        else SLog(EError, "path_hip: reconstruction filter \"%s\" is not implemented (box, gaussian, tent, mitchell, catmullrom, lanczos)", fname.c_str());
         MI_CHECK(mi_scene_commit(scene, device));
         border = rf->getBorderSize(); size = cropSize;
     }

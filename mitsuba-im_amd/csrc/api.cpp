@@ -175,7 +175,7 @@ int mi_scene_set_camera(mi_scene *s, const float *s2c, const float *c2w, float n
     return MI_OK;
 }
 int mi_scene_set_film(mi_scene *s, uint32_t w, uint32_t h, uint32_t kind, float radius, float stddev) {
-    if (!s || !w || !h || kind > 1) return fail(MI_ERR_INVALID, "mi_scene_set_film: bad argument");
+    if (!s || !w || !h || kind > 5 || (kind == 5 && !(radius >= 1))) return fail(MI_ERR_INVALID, "mi_scene_set_film: bad argument");
     s->h.width = w; s->h.height = h; s->h.filterKind = kind; s->h.filterRadius = radius; s->h.filterStddev = stddev; s->h.haveFilm = true; s->h.committed = false;
     return MI_OK;
 }

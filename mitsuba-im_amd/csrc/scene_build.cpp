@@ -331,15 +331,30 @@ void SceneHost::commitHost() {
     }
     if (areaCdf.empty()) areaCdf.push_back(0.0f);
 
-    // --- reconstruction filter table (rfilter.cpp:37-56; box.cpp:31-48; gaussian.cpp:30-57)
+    /* --- reconstruction filter table (src/libcore/rfilter.cpp:37-56; eval of src/rfilters/box.cpp:31-48, gaussian.cpp:30-57, tent.cpp:36-38,
+     * mitchell.cpp:49-61, catmullrom.cpp:36-49, lanczos.cpp:36-46).  filter_radius / filter_stddev carry: box radius; gaussian stddev (in
+     * filter_stddev); mitchell B, C; lanczos lobes (in filter_radius) */
     {
-        float radius = filterKind == 0 ? filterRadius + 1e-5f : 4.0f * filterStddev;
+        const uint32_t kind = filterKind;
+        float radius = kind == 0 ? filterRadius + 1e-5f : kind == 1 ? 4.0f * filterStddev : kind == 2 ? 1.0f : kind == 5 ? (float) (int) filterRadius : 2.0f;
         float alpha = -1.0f / (2.0f * filterStddev * filterStddev), bias = std::exp(alpha * radius * radius);
+        const float B = kind == 3 ? filterRadius : 0.0f, C = kind == 3 ? filterStddev : 0.5f;
         float sum = 0.0f;
         for (int i = 0; i < MI_FILTER_RES; ++i) {
             float x = (radius * (float) i) / (float) MI_FILTER_RES, v;
-            if (filterKind == 0) v = std::fabs(x) <= radius ? 1.0f : 0.0f;
-            else v = std::max(0.0f, std::exp(alpha * x * x) - bias);
+            if (kind == 0) v = std::fabs(x) <= radius ? 1.0f : 0.0f;
+            else if (kind == 1) v = std::max(0.0f, std::exp(alpha * x * x) - bias);
+            else if (kind == 2) v = std::max(0.0f, 1.0f - std::fabs(x / radius));
+            else if (kind == 5) {
+                float ax = std::fabs(x);
+                if (ax < 1e-4f) v = 1.0f; else if (ax > radius) v = 0.0f;
+                else { float x1 = MI_PI * ax, x2 = x1 / radius; v = (std::sin(x1) * std::sin(x2)) / (x1 * x2); }
+            } else {
+                float ax = std::fabs(x), x2 = ax * ax, x3 = x2 * ax;
+                if (ax < 1) v = 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+                else if (ax < 2) v = 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * ax + (8 * B + 24 * C));
+                else v = 0.0f;
+            }
             filterValues[i] = v; sum += v;
         }
         filterValues[MI_FILTER_RES] = 0.0f;

@@ -28,6 +28,10 @@ EMITTER_SPOT = 4          # src/emitters/spot.cpp
 EMITTER_DIRECTIONAL = 5   # src/emitters/directional.cpp
 FILTER_BOX = 0
 FILTER_GAUSSIAN = 1
+FILTER_TENT = 2
+FILTER_MITCHELL = 3        # B in filter_radius, C in filter_stddev
+FILTER_CATMULLROM = 4
+FILTER_LANCZOS = 5         # lobes in filter_radius
 SAMPLER_INDEPENDENT = 0
 SAMPLER_SOBOL = 1
 DISTR_BECKMANN = 0
@@ -154,8 +158,8 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     sc.width = int(width); sc.height = int(height)
     sc.sample_to_camera = sample_to_camera(xfov, near, far, width / height)
     sc.filter = filter_kind
-    sc.filter_radius = 0.5 if filter_kind == FILTER_BOX else 2.0
-    sc.filter_stddev = 0.5
+    sc.filter_radius = {FILTER_BOX: 0.5, FILTER_MITCHELL: 1.0 / 3.0, FILTER_LANCZOS: 3.0}.get(filter_kind, 2.0)
+    sc.filter_stddev = 1.0 / 3.0 if filter_kind == FILTER_MITCHELL else 0.5
     sc.max_depth = int(max_depth); sc.rr_depth = int(rr_depth)
     sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
     sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)

@@ -1753,15 +1753,30 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
         cdf[nt] = 1.0f;
         s->area_cdf[e] = cdf; s->inv_area[e] = 1.0f / sum;
     }
-    /* reconstruction filter table (src/libcore/rfilter.cpp:37-56; box.cpp:31-48; gaussian.cpp:30-57) */
+    /* reconstruction filter table (src/libcore/rfilter.cpp:37-56; eval of src/rfilters/box.cpp:31-48, gaussian.cpp:30-57, tent.cpp:36-38,
+     * mitchell.cpp:49-61, catmullrom.cpp:36-49, lanczos.cpp:36-46).  filter_radius / filter_stddev carry: box radius; gaussian stddev (in
+     * filter_stddev); mitchell B, C; lanczos lobes (in filter_radius) */
     {
-        float radius = d->filter == 0 ? d->filter_radius + 1e-5f : 4.0f * d->filter_stddev;
+        const uint32_t kind = d->filter;
+        float radius = kind == 0 ? d->filter_radius + 1e-5f : kind == 1 ? 4.0f * d->filter_stddev : kind == 2 ? 1.0f : kind == 5 ? (float) (int) d->filter_radius : 2.0f;
         float alpha = -1.0f / (2.0f * d->filter_stddev * d->filter_stddev), bias = expf(alpha * radius * radius);
+        const float B = kind == 3 ? d->filter_radius : 0.0f, C = kind == 3 ? d->filter_stddev : 0.5f;
         float sum = 0.0f;
         for (int i = 0; i < FILTER_RES; ++i) {
             float x = (radius * (float) i) / (float) FILTER_RES, v;
-            if (d->filter == 0) v = fabsf(x) <= radius ? 1.0f : 0.0f;
-            else v = maxf(0.0f, expf(alpha * x * x) - bias);
+            if (kind == 0) v = fabsf(x) <= radius ? 1.0f : 0.0f;
+            else if (kind == 1) v = maxf(0.0f, expf(alpha * x * x) - bias);
+            else if (kind == 2) v = maxf(0.0f, 1.0f - fabsf(x / radius));
+            else if (kind == 5) {
+                float ax = fabsf(x);
+                if (ax < 1e-4f) v = 1.0f; else if (ax > radius) v = 0.0f;
+                else { float x1 = M_PI_F * ax, x2 = x1 / radius; v = (sinf(x1) * sinf(x2)) / (x1 * x2); }
+            } else {
+                float ax = fabsf(x), x2 = ax * ax, x3 = x2 * ax;
+                if (ax < 1) v = 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+                else if (ax < 2) v = 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * ax + (8 * B + 24 * C));
+                else v = 0.0f;
+            }
             s->filter_values[i] = v; sum += v;
         }
         s->filter_values[FILTER_RES] = 0.0f;

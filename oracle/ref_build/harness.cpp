@@ -343,8 +343,11 @@ static Built buildScene(const FScene &fs) {
     for (ref<Shape> &inst : instancesKeep) { b.scene->addChild(inst); inst->setParent(b.scene); }
     // film + filter
     {
-        Properties fp(fs.filter == 0 ? "box" : "gaussian");
+        static const char *fnames[] = {"box", "gaussian", "tent", "mitchell", "catmullrom", "lanczos"};
+        Properties fp(fnames[fs.filter]);
         if (fs.filter == 1) fp.setFloat("stddev", fs.filterStddev);
+        if (fs.filter == 3) { fp.setFloat("B", fs.filterRadius); fp.setFloat("C", fs.filterStddev); }
+        if (fs.filter == 5) fp.setInteger("lobes", (int) fs.filterRadius);
         b.filter = static_cast<ReconstructionFilter *>(create(MTS_CLASS(ReconstructionFilter), fp));
         b.filter->configure();
         Properties p("hdrfilm"); p.setInteger("width", fs.W); p.setInteger("height", fs.H); p.setBoolean("banner", false);

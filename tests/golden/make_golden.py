@@ -53,6 +53,11 @@ def golden_scenes():
         "cbox_translucent_indep": scenes.cbox_translucent(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=9, rr_depth=2, strict_normals=True),
         # roughplastic (rough-transmittance slices of the reference's data/microfacet tables as material input)
         "cbox_roughplastic": scenes.cbox_roughplastic(width=96, height=96, spp=16),
+        # the other reconstruction filters (negative lobes: mitchell, catmullrom, lanczos)
+        "cornell_small_tent": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_TENT),
+        "cornell_small_mitchell": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_MITCHELL),
+        "cornell_small_catmullrom": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_CATMULLROM),
+        "cornell_small_lanczos": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_LANCZOS),
     }
 
 

@@ -96,7 +96,8 @@ def test_intersection_bit_exact(mi, oracle, scenes, name):
     assert nhit > n // 20
 
 
-@pytest.mark.parametrize("name,spp", [("cornell_small", 16), ("cornell_small_gauss", 4), ("closed_box", 16)])
+@pytest.mark.parametrize("name,spp", [("cornell_small", 16), ("cornell_small_gauss", 4), ("closed_box", 16), ("cornell_small_tent", 4),
+                                      ("cornell_small_mitchell", 4), ("cornell_small_catmullrom", 4), ("cornell_small_lanczos", 4)])
 def test_film_vs_oracle_and_reference(mi, oracle, golden_scenes, name, spp):
     sc = golden_scenes[name]
     r = mi.Render(mi.Scene(sc)); r.run(); film = r.read_film(0); st = r.stats()
@@ -108,7 +109,7 @@ def test_film_vs_oracle_and_reference(mi, oracle, golden_scenes, name, spp):
         same = (bits(film) == bits(ofilm)).all(2)
         assert same.mean() > 0.995 and np.allclose(film, ofilm, rtol=2e-6, atol=1e-7)
     else:
-        assert np.allclose(film, ofilm, rtol=2e-5, atol=1e-6)       # gaussian: all splats are float atomics
+        assert np.allclose(film, ofilm, rtol=2e-5, atol=2e-6)       # wider filters: all splats are float atomics (negative lobes cancel: absolute tolerance)
     assert (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
     ref = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
