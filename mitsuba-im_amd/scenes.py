@@ -107,7 +107,7 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         k = (float(f32(fresnel_diffuse_reflectance(1.0 / float(f32(ior))))), 0.0, 0.0) if kind == BSDF_PLASTIC else (0.0, 0.0, 0.0)
     if kind == BSDF_ROUGHPLASTIC:
         sample_visible = 2 if nonlinear else 1          # container field: the harness reads the nonlinear flag of roughplastic from here
-    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible), nonlinear=int(nonlinear), table=table,
+    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible), nonlinear=int(nonlinear), table=table, texture=-1,
                 reflectance=tuple(map(float, reflectance)), alpha=float(alpha),
                 eta=tuple(map(float, eta)), k=tuple(map(float, k)),
                 specular=tuple(map(float, specular)))
@@ -143,7 +143,7 @@ def sample_to_camera(xfov_deg, near, far, aspect):
 def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near, far, width, height,
                  spp, sampler, max_depth, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
                  normals=None, uvs=None, strict_normals=False, hide_emitters=False, envmap=None,
-                 name="scene", analytic=None, instances=None):
+                 name="scene", analytic=None, instances=None, textures=None):
     sc = Scene()
     sc.name = name
     sc.pos = np.ascontiguousarray(np.asarray(verts, dtype=f32).reshape(-1, 3))
@@ -164,6 +164,8 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
     sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)
     sc.envmap = envmap          # None or dict(rgb[h,w,3] f32, to_world[4,4], scale)
+    sc.textures = list(textures or [])             # 2-D procedural textures (make_texture); a bsdf dict binds one to its reflectance through "texture" = index
+    for sh in shapes: sh.setdefault("has_uv", int(uvs is not None))
     tabs = []                                       # float tables referenced by materials (roughplastic): k[1] = offset into sc.material_tables
     for bd in bsdfs:
         if bd.get("table") is not None:
@@ -203,6 +205,15 @@ def make_analytic(kind, to_world, bsdf, emitter=-1, flip=False, radius=1.0, leng
     to = np.ascontiguousarray(np.linalg.inv(tw.astype(np.float64)), dtype=f32)
     return dict(type=int(kind), bsdf=int(bsdf), emitter=int(emitter), flags=int(bool(flip)), to_world=tw, to_object=to,
                 radius=float(f32(radius)), length=float(f32(length)))
+
+
+TEXTURE_CHECKERBOARD = 0   # src/textures/checkerboard.cpp
+TEXTURE_GRID = 1           # src/textures/gridtexture.cpp
+
+
+def make_texture(kind, color0, color1, line_width=0.01, uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0):
+    return dict(type=int(kind), color0=tuple(map(float, color0)), color1=tuple(map(float, color1)), line_width=float(line_width),
+                uoffset=float(uoffset), voffset=float(voffset), uscale=float(uscale), vscale=float(vscale))
 
 
 def make_instance(group, to_world):
@@ -477,6 +488,41 @@ def cbox_roughplastic(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_de
     return sc
 
 
+def textured_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
+    """Meshes WITH texture coordinates (shading frames from the UV tangents, TriMesh::computeUVTangents) and procedural 2-D textures on diffuse
+    BSDFs: `checkerboard` floor (scaled / offset uv), `gridtexture` wall, a smooth-shaded textured mound, one mesh without texture; area light."""
+    b = _Builder(); uvs = []; normals = []
+    def quad_uv(pts, uv, n=(0.0, 1.0, 0.0)):
+        b.quad(pts); uvs.extend(uv); normals.extend([n] * 4)
+    tex = [make_texture(TEXTURE_CHECKERBOARD, (0.8, 0.75, 0.6), (0.15, 0.2, 0.3), uscale=6.0, vscale=4.0, uoffset=0.13, voffset=-0.2),
+           make_texture(TEXTURE_GRID, (0.7, 0.3, 0.25), (0.05, 0.05, 0.05), line_width=0.06, uscale=5.0, vscale=5.0),
+           make_texture(TEXTURE_CHECKERBOARD, (0.2, 0.6, 0.25), (0.9, 0.9, 0.2), uscale=3.0, vscale=3.0)]
+    floor = b.bsdf(reflectance=(0.5, 0.5, 0.5)); b.bsdfs[floor]["texture"] = 0
+    wall = b.bsdf(reflectance=(0.5, 0.5, 0.5), twosided=True); b.bsdfs[wall]["texture"] = 1
+    mound = b.bsdf(reflectance=(0.5, 0.5, 0.5)); b.bsdfs[mound]["texture"] = 2
+    plain = b.bsdf(reflectance=(0.6, 0.6, 0.65)); lightm = b.bsdf(reflectance=(0.5, 0.5, 0.5))
+    b.begin(); quad_uv([(4, 0, -4), (-4, 0, -4), (-4, 0, 4), (4, 0, 4)], [(1, 0), (0, 0), (0, 1), (1, 1)]); b.end(floor)
+    b.begin(); quad_uv([(-4, 0, 4), (-4, 3, 4), (4, 3, 4), (4, 0, 4)], [(0, 0), (0, 0.7), (1.3, 0.9), (1.1, 0.1)], (0, 0, -1)); b.end(wall)   # sheared uv: non-orthogonal tangents
+    b.begin(); base = len(b.verts); nu, nv = 10, 6                                                                                        # mound: smooth normals + uv
+    for j in range(nv + 1):
+        for i in range(nu + 1):
+            u, v = i / nu, j / nv; x = -1.5 + 3.0 * u; z = -0.5 + 2.0 * v; y = 0.9 * math.sin(math.pi * u) * math.sin(math.pi * v) + 0.01
+            dydx = 0.9 * math.pi / 3.0 * math.cos(math.pi * u) * math.sin(math.pi * v); dydz = 0.9 * math.pi / 2.0 * math.sin(math.pi * u) * math.cos(math.pi * v)
+            nn = np.array([-dydx, 1.0, -dydz]); nn /= np.linalg.norm(nn)
+            b.verts.append((x, y, z)); uvs.append((u, v)); normals.append(tuple(map(float, nn)))
+    for j in range(nv):
+        for i in range(nu):
+            a = base + j * (nu + 1) + i; c = a + 1; d_ = a + nu + 1; e = d_ + 1
+            b.tris.append((a, d_, c)); b.tris.append((c, d_, e))
+    b.end(mound, face_normals=False)
+    b.begin(); quad_uv([(2.0, 0.0, -1.0), (2.0, 1.2, -1.0), (3.2, 1.2, -0.2), (3.2, 0.0, -0.2)], [(0, 0)] * 4, (0, 0, -1)); b.end(plain)
+    b.shapes[-1]["has_uv"] = 0
+    b.begin(); quad_uv([(1, 2.9, -1), (1, 2.9, 1), (-1, 2.9, 1), (-1, 2.9, -1)], [(0, 0), (1, 0), (1, 1), (0, 1)], (0, -1, 0)); b.end(lightm, radiance=(12.0, 11.0, 9.0))
+    cam = look_at((0.3, 1.8, -5.5), (0.0, 0.7, 0.5), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, normals=normals, uvs=uvs, name="textured_room", textures=tex)
+
+
 def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
     """Area lights on every analytic shape kind inside an inward-facing (`flipNormals`) sphere: a `sphere` light (cone sampling from
     outside, sphere.cpp:275-346), a `cylinder` light, a `disk` light and a `rectangle` light over a mesh floor and a mesh blocker."""
@@ -739,7 +785,7 @@ def save_scene(sc, path):
         f.write(sc.idx.tobytes())
         for s in sc.shapes:
             f.write(struct.pack("<4I2i2I", s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"],
-                                s["bsdf"], s["emitter"], s["face_normals"], s.get("group", 0)))
+                                s["bsdf"], s["emitter"], (s["face_normals"] & 1) | ((s.get("has_uv", 0) & 1) << 1), s.get("group", 0)))
         for b in sc.bsdfs:
             f.write(struct.pack("<4I", b["type"], b["twosided"], b["distr"], b["sample_visible"]))
             f.write(struct.pack("<13f", *b["reflectance"], b["alpha"], *b["eta"], *b["k"], *b["specular"]))
@@ -764,6 +810,11 @@ def save_scene(sc, path):
                 f.write(struct.pack("<I2iI", a["type"], a["bsdf"], a["emitter"], a["flags"]))
                 f.write(a["to_world"].tobytes()); f.write(a["to_object"].tobytes())
                 f.write(struct.pack("<2f", a["radius"], a["length"]))
+        if sc.get("textures"):
+            f.write(b"TEXR"); f.write(struct.pack("<I", len(sc.textures)))
+            for t in sc.textures:
+                f.write(struct.pack("<I11f", t["type"], *t["color0"], *t["color1"], t["line_width"], t["uoffset"], t["voffset"], t["uscale"], t["vscale"]))
+            f.write(struct.pack("<%di" % len(sc.bsdfs), *[b.get("texture", -1) for b in sc.bsdfs]))
         if sc.get("instances"):
             f.write(b"INST"); f.write(struct.pack("<I", len(sc.instances)))
             for a in sc.instances:

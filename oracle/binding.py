@@ -14,6 +14,11 @@ class OrcShape(C.Structure):
                 ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32), ("group", C.c_uint32)]
 
 
+class OrcTexture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
+                ("uoffset", C.c_float), ("voffset", C.c_float), ("uscale", C.c_float), ("vscale", C.c_float)]
+
+
 class OrcInstance(C.Structure):
     _fields_ = [("group", C.c_uint32), ("pad", C.c_uint32 * 3), ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
 
@@ -44,7 +49,7 @@ class OrcSceneDesc(C.Structure):
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
-                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p)]
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p)]
 
 
 def build():
@@ -110,10 +115,10 @@ def pack_records(sc):
     """Flattened scene (mitsuba-im_amd/scenes.py Scene) -> arrays of the C records (same layout for oracle and product)."""
     shapes = (OrcShape * len(sc.shapes))()
     for i, s in enumerate(sc.shapes):
-        shapes[i] = OrcShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], s["face_normals"] & 1, s.get("group", 0))
+        shapes[i] = OrcShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], (s["face_normals"] & 1) | ((s.get("has_uv", 0) & 1) << 1), s.get("group", 0))
     mats = (OrcMaterial * len(sc.bsdfs))()
     for i, b in enumerate(sc.bsdfs):
-        m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((1 if b["sample_visible"] else 0) << 1) | ((b.get("nonlinear", 0) & 1) << 2), b["distr"], b["alpha"])
+        m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((1 if b["sample_visible"] else 0) << 1) | ((b.get("nonlinear", 0) & 1) << 2) | ((b.get("texture", -1) + 1) << 8), b["distr"], b["alpha"])
         m.reflectance[:] = b["reflectance"]; m.eta[:] = b["eta"]; m.k[:] = b["k"]; m.specular[:] = b["specular"]
         mats[i] = m
     ems = (OrcEmitter * max(1, len(sc.emitters)))()
@@ -174,6 +179,13 @@ class Oracle:
         d.n_analytic, d.analytic = n_an, C.cast(an, C.c_void_p)
         ins, n_ins = pack_instances(sc); self._keep.append(ins)
         d.n_instances, d.instances = n_ins, C.cast(ins, C.c_void_p)
+        texs = sc.get("textures") or []
+        if texs:
+            ta = (OrcTexture * len(texs))()
+            for i, t in enumerate(texs):
+                r = OrcTexture(t["type"]); r.color0[:] = t["color0"]; r.color1[:] = t["color1"]; r.line_width = t["line_width"]
+                r.uoffset, r.voffset, r.uscale, r.vscale = t["uoffset"], t["voffset"], t["uscale"], t["vscale"]; ta[i] = r
+            self._keep.append(ta); d.n_textures, d.textures = len(texs), C.cast(ta, C.c_void_p)
         mt = sc.get("material_tables")
         if mt is not None:
             self._keep.append(mt); d.n_material_tables, d.material_tables = len(mt), _ptr(mt)

@@ -47,6 +47,7 @@ typedef struct { uint32_t k; float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_
 typedef struct { v3 lo, hi; int32_t left, right, first, count; } bvh_node;   /* leaf: count > 0 */
 
 typedef struct {
+    float uvx, uvy;   /* its.uv: interpolated texture coordinates (meshes with texcoords), else the barycentrics */
     int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter; int32_t instance;
 } hit_t;
 
@@ -54,6 +55,7 @@ typedef struct {
 typedef struct mat_s { orc_material m; const float *table; } mat_t;
 struct orc_scene {
     orc_scene_desc d;
+    float *uv; float *tangents; /* per triangle: dpdu xyz, dpdv xyz (TriMesh::computeUVTangents) */ orc_texture *textures;
     float *pos, *nrm; uint32_t *idx; orc_shape *shapes; struct mat_s *materials; orc_emitter *emitters; float *material_tables;
     uint32_t *tri_shape;
     struct analytic_s *analytic; uint32_t n_analytic, n_prims;
@@ -645,7 +647,7 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     h->instance = inst;
     if (prim >= s->d.n_tris) {                       /* skdtree.h:421-427: shape->fillIntersectionRecord, computeShadingFrame, wi */
         const analytic_t *sh = &s->analytic[prim - s->d.n_tris]; v3 dpdu;
-        h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
+        h->valid = 1; h->t = t; h->u = u; h->v = v; h->uvx = h->uvy = 0; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
         analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu);
         h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
         h->tt = cross(h->ns, h->s);
@@ -676,7 +678,13 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
         if (dot(fn, h->ns) < 0) fn = neg(fn);
     } else h->ns = fn;
     h->ng = fn;
-    v3 dpdu = side1;   /* no UV tangents: meshes on this path carry no texcoords (skdtree.h:373-380) */
+    v3 dpdu = side1;   /* skdtree.h:373-380: the UV tangent of the triangle when the mesh has texcoords, else the first edge */
+    h->uvx = by; h->uvy = bz;                                   /* skdtree.h:402-408 */
+    if (s->uv && (sh->flags & 2u)) {
+        const float *t0 = &s->uv[i0 * 2], *t1 = &s->uv[i1 * 2], *t2 = &s->uv[i2 * 2];
+        h->uvx = (t0[0] * bx + t1[0] * by) + t2[0] * bz; h->uvy = (t0[1] * bx + t1[1] * by) + t2[1] * bz;
+        dpdu = V(s->tangents[prim * 6], s->tangents[prim * 6 + 1], s->tangents[prim * 6 + 2]);
+    }
     if (in) {   /* instance.cpp:134-139: normals through the inverse transpose, dpdu / p through the forward transform; then the scene-level computeShadingFrame + wi */
         h->ns = normalize(xf_normal(in->to_object, h->ns)); h->ng = normalize(xf_normal(in->to_object, h->ng));
         dpdu = xf_vector(in->to_world, dpdu); h->p = xf_point(in->to_world, h->p);
@@ -711,7 +719,7 @@ static v3 to_local(const hit_t *h, v3 w) { return V(dot(w, h->s), dot(w, h->tt),
 static void hit_out(const hit_t *h, float *o) {
     o[0] = h->t; o[1] = h->p.x; o[2] = h->p.y; o[3] = h->p.z; o[4] = h->ng.x; o[5] = h->ng.y; o[6] = h->ng.z;
     o[7] = h->ns.x; o[8] = h->ns.y; o[9] = h->ns.z; o[10] = h->s.x; o[11] = h->s.y; o[12] = h->s.z;
-    o[13] = h->u; o[14] = h->v; o[15] = h->wi.x; o[16] = h->wi.y; o[17] = h->wi.z; o[18] = (float) h->prim; o[19] = (float) h->shape; o[20] = (float) h->instance;
+    o[13] = h->u; o[14] = h->v; o[15] = h->wi.x; o[16] = h->wi.y; o[17] = h->wi.z; o[18] = (float) h->prim; o[19] = (float) h->shape; o[20] = (float) h->instance; o[21] = h->uvx; o[22] = h->uvy;
 }
 int orc_ray_intersect(const orc_scene *s, const float *r, float *out) { hit_t h; int ok = ray_intersect(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7], &h, 0); if (ok) hit_out(&h, out); return ok; }
 int orc_ray_intersect_brute(const orc_scene *s, const float *r, float *out) { hit_t h; int ok = ray_intersect(s, V(r[0], r[1], r[2]), V(r[4], r[5], r[6]), r[3], r[7], &h, 1); if (ok) hit_out(&h, out); return ok; }
@@ -1446,6 +1454,23 @@ void orc_sample_emitter_direct(const orc_scene *s, const float *rp, const float 
     o[9] = dr.dist; o[10] = dr.pdf; o[11] = is_zero(val) ? 0.0f : pdf_emitter_direct(s, &dr, refN);
 }
 
+/* ---- 2-D procedural textures: Texture2D::eval (src/librender/texture.cpp:112-121, no filtering: usesRayDifferentials() = false), Checkerboard::eval
+ * (src/textures/checkerboard.cpp:68-76), GridTexture::eval (src/textures/gridtexture.cpp:63-77) */
+static v3 texture_eval(const orc_texture *t, float u, float v) {
+    float uvx = u * t->uscale + t->uoffset, uvy = v * t->vscale + t->voffset;
+    int first;
+    if (t->type == 0) {
+        int a = (int) (uvx * 2) % 2, b = (int) (uvy * 2) % 2; if (a < 0) a += 2; if (b < 0) b += 2;
+        int x = 2 * a - 1, y = 2 * b - 1;
+        first = x * y == 1;
+    } else {
+        float x = uvx - (float) (int) floorf(uvx), y = uvy - (float) (int) floorf(uvy);
+        if (x > .5) x -= 1;
+        if (y > .5) y -= 1;
+        first = !(fabsf(x) < t->line_width || fabsf(y) < t->line_width);
+    }
+    return first ? V(t->color0[0], t->color0[1], t->color0[2]) : V(t->color1[0], t->color1[1], t->color1[2]);
+}
 /* ------------------------------------------------------------------------------------------------ the Li loop */
 static inline float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   /* path.cpp:296-300 */
 
@@ -1465,7 +1490,10 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
             if (s->env_index >= 0 && emitted_radiance && (!hide || scattered)) Li = add(Li, mul(throughput, env_eval(s, d)));
             break;
         }
-        const orc_material *bsdf = &s->materials[its.material].m;
+        mat_t bsdf_local = s->materials[its.material];        /* textured reflectance: evaluated at the hit's uv (diffuse.cpp:112-121: m_reflectance->eval(bRec.its)) */
+        { uint32_t tex = (bsdf_local.m.flags >> 8) & 0xFFFFu;
+          if (tex) { v3 c = texture_eval(&s->textures[tex - 1], its.uvx, its.uvy); bsdf_local.m.reflectance[0] = c.x; bsdf_local.m.reflectance[1] = c.y; bsdf_local.m.reflectance[2] = c.z; } }
+        const orc_material *bsdf = &bsdf_local.m;
         if (its.emitter >= 0 && emitted_radiance && (!hide || scattered))
             Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
         if ((depth >= maxDepth && maxDepth > 0) || (strict && dot(d, its.ng) * its.wi.z >= 0)) break;
@@ -1660,10 +1688,33 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_materials; ++i) { s->materials[i].m = d->materials[i]; s->materials[i].table = s->material_tables ? s->material_tables + (size_t) d->materials[i].k[1] : NULL; }
     s->d.material_tables = NULL;
     s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
+    s->uv = (float *) dup(d->uv, (size_t) d->n_verts * 8);
+    s->textures = (orc_texture *) dup(d->textures, (size_t) (d->textures ? d->n_textures : 0) * sizeof(orc_texture)); s->d.textures = NULL;
     s->tri_shape = (uint32_t *) calloc(d->n_tris, 4);
     for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->tri_shape[s->shapes[i].first_tri + t] = i;
     /* TriAccel table (skdtree.cpp:79-105) + scene box (union of mesh AABBs, enlarged as in gkdtree.h:1213-1220) */
     s->accel = (triaccel *) calloc(d->n_tris ? d->n_tris : 1, sizeof(triaccel));
+    /* TriMesh::computeUVTangents (src/librender/trimesh.cpp:683-736) for meshes with texcoords */
+    s->tangents = NULL;
+    if (s->uv) {
+        s->tangents = (float *) calloc((size_t) (d->n_tris ? d->n_tris : 1) * 6, 4);
+        for (uint32_t t = 0; t < d->n_tris; ++t) {
+            if (!(s->shapes[s->tri_shape[t]].flags & 2u)) continue;
+            uint32_t i0 = s->idx[t * 3], i1 = s->idx[t * 3 + 1], i2 = s->idx[t * 3 + 2];
+            v3 dP1 = sub(vert(s, i1), vert(s, i0)), dP2 = sub(vert(s, i2), vert(s, i0));
+            float du1 = s->uv[i1 * 2] - s->uv[i0 * 2], dv1 = s->uv[i1 * 2 + 1] - s->uv[i0 * 2 + 1], du2 = s->uv[i2 * 2] - s->uv[i0 * 2], dv2 = s->uv[i2 * 2 + 1] - s->uv[i0 * 2 + 1];
+            v3 n = cross(dP1, dP2); float length = sqrtf(dot(n, n)); v3 dpdu, dpdv;
+            if (length == 0) continue;
+            float determinant = du1 * dv2 - dv1 * du2;
+            if (determinant == 0) { float r = 1.0f / length; coordinate_system(scale(n, r), &dpdu, &dpdv); }
+            else {
+                float invDet = 1.0f / determinant;
+                dpdu = scale(sub(scale(dP1, dv2), scale(dP2, dv1)), invDet);
+                dpdv = scale(add(scale(dP1, -du2), scale(dP2, du1)), invDet);
+            }
+            float *o = &s->tangents[t * 6]; o[0] = dpdu.x; o[1] = dpdu.y; o[2] = dpdu.z; o[3] = dpdv.x; o[4] = dpdv.y; o[5] = dpdv.z;
+        }
+    }
     s->n_analytic = d->analytic ? d->n_analytic : 0; s->n_instances = d->instances ? d->n_instances : 0;
     s->n_prims = d->n_tris + s->n_analytic + s->n_instances;
     s->analytic = (analytic_t *) calloc(s->n_analytic ? s->n_analytic : 1, sizeof(analytic_t));
@@ -1855,5 +1906,5 @@ void orc_scene_destroy(orc_scene *s) {
     free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic); free(s->instances); free(s->group_root); free(s->group_lo); free(s->group_hi); free(s->group_first); free(s->group_count);
     free(s->spot_cos_beam); free(s->spot_cos_cutoff); free(s->spot_inv_transition); free(s->spot_cutoff); free(s->spot_to_local);
     free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
-    free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->material_tables); free(s->emitters); free(s);
+    free(s->uv); free(s->tangents); free(s->textures); free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->material_tables); free(s->emitters); free(s);
 }

@@ -73,10 +73,11 @@ struct RTAccess : RoughTransmittance {   // its slices are protected members
 struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
 struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
 struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight, cutoff, beam, toWorld[16]; };
+struct FTexture { uint32_t type; float color0[3], color1[3], lineWidth, uoffset, voffset, uscale, vscale; };
 struct FInstance { uint32_t group, pad[3]; float toWorld[16], toObject[16]; };
 struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
 struct FScene {
-    std::vector<FAnalytic> analytic; std::vector<FInstance> instances;
+    std::vector<FAnalytic> analytic; std::vector<FInstance> instances; std::vector<FTexture> textures; std::vector<int32_t> bsdfTexture;
     uint32_t nVerts, nTris, nShapes, nBsdfs, nEmitters, hasN, hasUV, hasEnv;
     std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx;
     std::vector<FShape> shapes; std::vector<FBsdf> bsdfs; std::vector<FEmitter> emitters;
@@ -110,6 +111,7 @@ static FScene loadScene(const char *path) {
     while (fread(tag, 1, 4, f) == 4) {
         uint32_t n; rd(f, &n, 4);
         if (!memcmp(tag, "ANLY", 4)) { s.analytic.resize(n); for (FAnalytic &a : s.analytic) rd(f, &a, sizeof(FAnalytic)); }
+        else if (!memcmp(tag, "TEXR", 4)) { s.textures.resize(n); rd(f, s.textures.data(), n * sizeof(FTexture)); s.bsdfTexture.resize(s.nBsdfs); rd(f, s.bsdfTexture.data(), s.nBsdfs * 4); }
         else if (!memcmp(tag, "INST", 4)) { s.instances.resize(n); for (FInstance &a : s.instances) rd(f, &a, sizeof(FInstance)); }
         else { fprintf(stderr, "unknown section\n"); _exit(2); }
     }
@@ -240,6 +242,16 @@ static Built buildScene(const FScene &fs) {
             p.setString("material", "none"); p.setFloat("extEta", 1.0f);   // eta / k are given as RGB, already relative to the exterior
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         }
+        { size_t bi = bsdfs.size();
+          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0) {      // 2-D procedural texture bound to the diffuse reflectance
+              const FTexture &ft = fs.textures[fs.bsdfTexture[bi]];
+              Properties tp(ft.type == 0 ? "checkerboard" : "gridtexture");
+              tp.setSpectrum("color0", rgb(ft.color0)); tp.setSpectrum("color1", rgb(ft.color1));
+              if (ft.type == 1) tp.setFloat("lineWidth", ft.lineWidth);
+              tp.setFloat("uoffset", ft.uoffset); tp.setFloat("voffset", ft.voffset); tp.setFloat("uscale", ft.uscale); tp.setFloat("vscale", ft.vscale);
+              ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp)); tex->configure();
+              bsdf->addChild("reflectance", tex); tex->setParent(bsdf);
+          } }
         bsdf->configure();
         if (fb.twosided) {
             ref<BSDF> ts = static_cast<BSDF *>(create(MTS_CLASS(BSDF), Properties("twosided")));
@@ -280,14 +292,14 @@ static Built buildScene(const FScene &fs) {
     std::vector<ref<Shape> > groups, instancesKeep;
     for (uint32_t si = 0; si < fs.nShapes; ++si) {
         const FShape &sh = fs.shapes[si];
-        bool useN = fs.hasN && !sh.faceNormals;
-        ref<TriMesh> mesh = new TriMesh("shape" + std::to_string(si), sh.triCount, sh.vertCount, useN, fs.hasUV != 0, false, false,
-                                        sh.faceNormals != 0);
+        bool useN = fs.hasN && !(sh.faceNormals & 1); const bool useUV = fs.hasUV && (sh.faceNormals & 2);
+        ref<TriMesh> mesh = new TriMesh("shape" + std::to_string(si), sh.triCount, sh.vertCount, useN, useUV, false, false,
+                                        (sh.faceNormals & 1) != 0);
         for (uint32_t v = 0; v < sh.vertCount; ++v) {
             const float *p = &fs.pos[(sh.firstVert + v) * 3];
             mesh->getVertexPositions()[v] = Point(p[0], p[1], p[2]);
             if (useN) { const float *n = &fs.nrm[(sh.firstVert + v) * 3]; mesh->getVertexNormals()[v] = Normal(n[0], n[1], n[2]); }
-            if (fs.hasUV) { const float *t = &fs.uv[(sh.firstVert + v) * 2]; mesh->getVertexTexcoords()[v] = Point2(t[0], t[1]); }
+            if (useUV) { const float *t = &fs.uv[(sh.firstVert + v) * 2]; mesh->getVertexTexcoords()[v] = Point2(t[0], t[1]); }
         }
         for (uint32_t t = 0; t < sh.triCount; ++t)
             for (int k = 0; k < 3; ++k)

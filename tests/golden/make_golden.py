@@ -58,6 +58,8 @@ def golden_scenes():
         "cornell_small_mitchell": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_MITCHELL),
         "cornell_small_catmullrom": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_CATMULLROM),
         "cornell_small_lanczos": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_LANCZOS),
+        # meshes with texture coordinates (UV tangents) + procedural textures
+        "textured_room": scenes.textured_room(width=96, height=64, spp=16),
     }
 
 
@@ -85,7 +87,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)
@@ -93,7 +95,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent"):
+        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", "path", -1, base + "_resp")
