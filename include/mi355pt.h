@@ -27,7 +27,9 @@ typedef struct {
     uint32_t first_tri, tri_count, first_vert, vert_count;
     int32_t bsdf;        /* index into the material table (Shape::getBSDF, include/mitsuba/render/shape.h) */
     int32_t emitter;     /* index into the emitter table or -1 (Shape::getEmitter)                          */
-    uint32_t flags;      /* bit0: face normals (TriMesh "faceNormals", src/librender/trimesh.cpp:70)        */
+    uint32_t flags;      /* bit0: face normals (TriMesh "faceNormals", src/librender/trimesh.cpp:70); bit1: the mesh has texture coordinates
+                            (`uv` of mi_scene_set_triangles): its.uv is interpolated from them and the triangle's UV tangent replaces the first
+                            edge as dpdu (TriMesh::computeUVTangents, trimesh.cpp:683-736; skdtree.h:373-376, 402-408) */
     uint32_t group;      /* 0: the mesh is a scene shape; g > 0: it is a member of shape group g - 1 (src/shapes/shapegroup.cpp) and
                             appears in the scene only through mi_instance records; group members cannot be emitters (shapegroup.cpp:75-76) */
 } mi_shape;
@@ -51,6 +53,12 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
+#define MI_BSDF_TEXTURE(i) (((uint32_t) (i) + 1u) << 8)   /* flags bits 8..23: texture i (mi_scene_set_textures) bound to `reflectance`; diffuse only */
+
+/* 2-D procedural textures over Texture2D (src/librender/texture.cpp:81-121: uv * scale + offset): src/textures/checkerboard.cpp, gridtexture.cpp */
+#define MI_TEXTURE_CHECKERBOARD 0
+#define MI_TEXTURE_GRID 1
+typedef struct { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale; } mi_texture;
 typedef struct {
     uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx */
     float alpha;
@@ -131,6 +139,7 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *shapes, uint32_t n);
 /* instances of shape groups; primitive index of the i-th: n_tris + n_analytic + i (they come last in Scene::getShapes order here) */
 int mi_scene_set_instances(mi_scene *s, const mi_instance *instances, uint32_t n);
 int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
+int mi_scene_set_textures(mi_scene *s, const mi_texture *textures, uint32_t n);
 int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n);   /* float tables the materials refer to by offset (roughplastic) */
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);

@@ -37,6 +37,11 @@ class MiAnalytic(C.Structure):
                 ("to_world", C.c_float * 16), ("to_object", C.c_float * 16), ("radius", C.c_float), ("length", C.c_float), ("pad", C.c_float * 2)]
 
 
+class MiTexture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
+                ("uoffset", C.c_float), ("voffset", C.c_float), ("uscale", C.c_float), ("vscale", C.c_float)]
+
+
 class MiInstance(C.Structure):
     _fields_ = [("group", C.c_uint32), ("pad", C.c_uint32 * 3), ("to_world", C.c_float * 16), ("to_object", C.c_float * 16)]
 
@@ -57,7 +62,7 @@ class MiStats(C.Structure):
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
-           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays"]
@@ -86,6 +91,7 @@ class Lib:
         L.mi_scene_set_analytic.argtypes = [vp, vp, u32]
         L.mi_scene_set_instances.argtypes = [vp, vp, u32]
         L.mi_scene_set_material_tables.argtypes = [vp, vp, u32]
+        L.mi_scene_set_textures.argtypes = [vp, vp, u32]
         L.mi_scene_set_materials.argtypes = [vp, vp, u32]
         L.mi_scene_set_emitters.argtypes = [vp, vp, u32]
         L.mi_scene_set_envmap.argtypes = [vp, vp, u32, u32, vp, f32]
@@ -177,6 +183,13 @@ class Scene:
                 r = MiInstance(a["group"]); r.to_world[:] = a["to_world"].reshape(-1).tolist(); r.to_object[:] = a["to_object"].reshape(-1).tolist(); arr[i] = r
             L.check(L.L.mi_scene_set_instances(h, C.cast(arr, C.c_void_p), len(insts)))
         L.check(L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), len(sc.bsdfs)))
+        texs = sc.get("textures") or []
+        if texs:
+            ta = (MiTexture * len(texs))()
+            for i, t in enumerate(texs):
+                r = MiTexture(t["type"]); r.color0[:] = t["color0"]; r.color1[:] = t["color1"]; r.line_width = t["line_width"]
+                r.uoffset, r.voffset, r.uscale, r.vscale = t["uoffset"], t["voffset"], t["uscale"], t["vscale"]; ta[i] = r
+            L.check(L.L.mi_scene_set_textures(h, C.cast(ta, C.c_void_p), len(texs)))
         if sc.get("material_tables") is not None:
             L.check(L.L.mi_scene_set_material_tables(h, _p(sc.material_tables), len(sc.material_tables)))
         L.check(L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), len(sc.emitters)))

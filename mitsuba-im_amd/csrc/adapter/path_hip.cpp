@@ -34,6 +34,7 @@ MTS_NAMESPACE_BEGIN
 namespace {
 
 struct FlatScene {
+    std::vector<float> uv; bool anyUV = false; std::vector<mi_texture> textures;
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
     std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances; std::vector<float> materialTables;
     bool anyNormals = false;
@@ -106,6 +107,26 @@ static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
         m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
     } else return false;                                                // twosided(diffuse) and anything else: the generic component check below
     if (rd.ms->readUInt() != id0) SLog(EError, "path_hip: twosided with two different nested BSDFs is not implemented");
+    return true;
+}
+
+/// A spatially varying `diffuse` (optionally inside `twosided`): its reflectance texture is private as well, so it is read from the serialised form
+/// (SmoothDiffuse::serialize, diffuse.cpp:163-167; Texture2D::serialize, src/librender/texture.cpp:106-110; Checkerboard / GridTexture::serialize)
+static std::vector<mi_texture> *g_textures = NULL;
+static bool convertTexturedDiffuse(const BSDF *bsdf, mi_material &m) {
+    NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
+    mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
+    rd.ms->readUInt(); std::string cls = rd.ms->readString(); rd.ms->readBool();
+    memset(&m, 0, sizeof(m)); m.type = MI_BSDF_DIFFUSE;
+    if (cls == "TwoSidedBRDF") { m.flags |= MI_BSDF_FLAG_TWOSIDED; rd.ms->readUInt(); cls = rd.ms->readString(); rd.ms->readBool(); }
+    if (cls != "SmoothDiffuse") return false;
+    rd.ms->readUInt(); std::string tcls = rd.ms->readString();
+    if (tcls != "Checkerboard" && tcls != "GridTexture") SLog(EError, "path_hip: texture \"%s\" is not implemented (checkerboard, gridtexture)", tcls.c_str());
+    mi_texture t; memset(&t, 0, sizeof(t)); t.type = tcls == "GridTexture" ? MI_TEXTURE_GRID : MI_TEXTURE_CHECKERBOARD;
+    t.uoffset = rd.ms->readFloat(); t.voffset = rd.ms->readFloat(); t.uscale = rd.ms->readFloat(); t.vscale = rd.ms->readFloat();
+    rd.rgb(t.color0); rd.rgb(t.color1); if (t.type == MI_TEXTURE_GRID) t.line_width = rd.ms->readFloat();
+    m.flags |= MI_BSDF_TEXTURE(g_textures->size()); m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;
+    g_textures->push_back(t);
     return true;
 }
 
@@ -190,6 +211,10 @@ static mi_material convertBSDF(const BSDF *bsdf) {
             return m;
         }
     }
+    if (bsdf->getType() & BSDF::ESpatiallyVarying) {
+        if (convertTexturedDiffuse(bsdf, m)) return m;
+        SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on the reflectance of `diffuse` only", bsdf->getClass()->getName().c_str());
+    }
     bool backSide = false;
     for (int i = 0; i < bsdf->getComponentCount(); ++i) {
         unsigned int type = bsdf->getType(i);
@@ -246,7 +271,7 @@ static bool convertAnalytic(const Shape *shape, mi_analytic &a) {
 }
 
 static void flatten(const Scene *scene, FlatScene &fs) {
-    g_tables = &fs.materialTables;
+    g_tables = &fs.materialTables; g_textures = &fs.textures;
     const std::vector<TriMesh *> &meshes = scene->getMeshes();
     std::map<const BSDF *, int> bsdfIndex; std::vector<const Instance *> insts;
     // non-mesh shapes: rectangle / disk / sphere / cylinder become analytic records (numbered after the meshes); anything else is refused
@@ -277,11 +302,9 @@ static void flatten(const Scene *scene, FlatScene &fs) {
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { mi_.to_world[i * 4 + j] = m(i, j); mi_.to_object[i * 4 + j] = inv(i, j); }
         fs.instances.push_back(mi_);
     }
-    for (const TriMesh *mesh : allMeshes) fs.anyNormals |= mesh->getVertexNormals() != NULL;
+    for (const TriMesh *mesh : allMeshes) { fs.anyNormals |= mesh->getVertexNormals() != NULL; fs.anyUV |= mesh->getVertexTexcoords() != NULL; }
     for (size_t mi = 0; mi < allMeshes.size(); ++mi) {
         const TriMesh *mesh = allMeshes[mi];
-        if (mesh->getVertexTexcoords() != NULL && (mesh->getBSDF()->usesRayDifferentials() || mesh->getUVTangents() != NULL))
-            SLog(EWarn, "path_hip: mesh \"%s\" carries UV tangents; the shading frame falls back to the triangle edge (no textures on this path)", mesh->getName().c_str());
         mi_shape sh; memset(&sh, 0, sizeof(sh));
         sh.first_tri = (uint32_t) (fs.idx.size() / 3); sh.tri_count = (uint32_t) mesh->getTriangleCount();
         sh.first_vert = (uint32_t) (fs.pos.size() / 3); sh.vert_count = (uint32_t) mesh->getVertexCount();
@@ -289,10 +312,11 @@ static void flatten(const Scene *scene, FlatScene &fs) {
         for (size_t v = 0; v < mesh->getVertexCount(); ++v) {
             fs.pos.push_back(p[v].x); fs.pos.push_back(p[v].y); fs.pos.push_back(p[v].z);
             if (fs.anyNormals) { fs.nrm.push_back(n ? n[v].x : 0); fs.nrm.push_back(n ? n[v].y : 0); fs.nrm.push_back(n ? n[v].z : 0); }
+            if (fs.anyUV) { const Point2 *tc = mesh->getVertexTexcoords(); fs.uv.push_back(tc ? tc[v].x : 0); fs.uv.push_back(tc ? tc[v].y : 0); }
         }
         const Triangle *t = mesh->getTriangles();
         for (size_t k = 0; k < mesh->getTriangleCount(); ++k) for (int c = 0; c < 3; ++c) fs.idx.push_back(sh.first_vert + t[k].idx[c]);
-        sh.flags = n ? 0u : 1u;
+        sh.flags = (n ? 0u : 1u) | (mesh->getVertexTexcoords() ? 2u : 0u);
         const BSDF *bsdf = mesh->getBSDF();
         if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
         sh.bsdf = bsdfIndex[bsdf]; sh.emitter = -1; sh.group = meshGroup[mi];
@@ -364,11 +388,12 @@ struct GpuScene {
         FlatScene fs; flatten(s, fs);
         if (scene) { mi_scene_destroy(scene); scene = nullptr; }
         MI_CHECK(mi_scene_create(&scene));
-        MI_CHECK(mi_scene_set_triangles(scene, fs.pos.data(), fs.anyNormals ? fs.nrm.data() : NULL, NULL, fs.idx.data(),
+        MI_CHECK(mi_scene_set_triangles(scene, fs.pos.data(), fs.anyNormals ? fs.nrm.data() : NULL, fs.anyUV ? fs.uv.data() : NULL, fs.idx.data(),
                                         (uint32_t) (fs.pos.size() / 3), (uint32_t) (fs.idx.size() / 3), fs.shapes.data(), (uint32_t) fs.shapes.size()));
         if (!fs.analytic.empty()) MI_CHECK(mi_scene_set_analytic(scene, fs.analytic.data(), (uint32_t) fs.analytic.size()));
         if (!fs.instances.empty()) MI_CHECK(mi_scene_set_instances(scene, fs.instances.data(), (uint32_t) fs.instances.size()));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
+        if (!fs.textures.empty()) MI_CHECK(mi_scene_set_textures(scene, fs.textures.data(), (uint32_t) fs.textures.size()));
         if (!fs.materialTables.empty()) MI_CHECK(mi_scene_set_material_tables(scene, fs.materialTables.data(), (uint32_t) fs.materialTables.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
         if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));

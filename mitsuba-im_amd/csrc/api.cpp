@@ -115,9 +115,9 @@ int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, cons
             return fail(MI_ERR_INVALID, "mi_scene_set_triangles: shape range outside the arrays (or an empty mesh)");
     }
     for (uint64_t i = 0; i < (uint64_t) nt * 3; ++i) if (idx[i] >= nv) return fail(MI_ERR_INVALID, "mi_scene_set_triangles: vertex index out of range");
-    if (uv) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_triangles: texture coordinates (UV tangents, textures) are outside the hot path of this round");
     s->h.pos.assign(pos, pos + (size_t) nv * 3); s->h.idx.assign(idx, idx + (size_t) nt * 3);
     if (nrm) s->h.nrm.assign(nrm, nrm + (size_t) nv * 3); else s->h.nrm.clear();
+    if (uv) s->h.uv.assign(uv, uv + (size_t) nv * 2); else s->h.uv.clear();
     s->h.shapes.assign(shapes, shapes + ns); s->h.committed = false;
     return MI_OK;
 }
@@ -131,6 +131,11 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *a, uint32_t n) {
             return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_analytic: toWorld must be affine");
     }
     s->h.analytic.assign(a, a + n); s->h.committed = false; return MI_OK;
+}
+int mi_scene_set_textures(mi_scene *s, const mi_texture *t, uint32_t n) {
+    if (!s || (n && !t)) return fail(MI_ERR_INVALID, "mi_scene_set_textures: null argument");
+    for (uint32_t i = 0; i < n; ++i) if (t[i].type > MI_TEXTURE_GRID) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_textures: implemented textures: checkerboard, gridtexture");
+    s->h.textures.assign(t, t + n); s->h.committed = false; return MI_OK;
 }
 int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n) {
     if (!s || (n && !data)) return fail(MI_ERR_INVALID, "mi_scene_set_material_tables: null argument");
@@ -195,7 +200,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -205,7 +210,7 @@ int SceneHost::upload(int dev) {
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
     int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
-              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dMaterialTables, materialTables) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
+              up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dMaterialTables, materialTables) | up(&dTriUV, triuv) | up(&dTextures, textures) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
     if (g_sobolDims && logRes <= 16) {
@@ -220,9 +225,9 @@ int SceneHost::upload(int dev) {
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
     d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
-    d.material_tables = (const float *) dMaterialTables;
+    d.material_tables = (const float *) dMaterialTables; d.triuv = (const TriUV *) dTriUV; d.textures = (const TextureD *) dTextures; d.n_textures = (uint32_t) textures.size();
     d.instances = (const InstanceD *) dInstances; d.n_instances = (uint32_t) instancesD.size();
-    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters) ? 1u : 0u;
+    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters || anyUV || !textures.empty()) ? 1u : 0u;
     memcpy(d.dir_bs_center, dirBsCenter, 12); d.dir_bs_radius = dirBsRadius;
     d.n_tris = nTris; d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
     d.emitter_norm = emitterNorm;
@@ -264,6 +269,12 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         for (const mi_shape &sh : s->h.shapes) if (sh.group && sh.emitter >= 0) return fail(MI_ERR_INVALID, "Instancing of emitters is not supported");   // shapegroup.cpp:75-76
         for (const mi_instance &in : s->h.instances) if (in.group >= ng) return fail(MI_ERR_INVALID, "A reference to a 'shapegroup' must be specified!");   // instance.cpp:41-44
     }
+    for (const mi_material &m : s->h.materials) {
+        const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
+        if (tex && (tex > s->h.textures.size() || m.type != MI_BSDF_DIFFUSE)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to the reflectance of `diffuse` BSDFs only (and must exist)");
+    }
+    for (const mi_analytic &a : s->h.analytic) if (a.bsdf >= 0 && (size_t) a.bsdf < s->h.materials.size() && ((s->h.materials[a.bsdf].flags >> 8) & 0xFFFFu))
+        return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textured materials on analytic shapes are not implemented");
     for (const mi_material &m : s->h.materials)
         if (m.type == MI_BSDF_ROUGHPLASTIC && (m.k[2] < 2 || m.k[1] < 0 || (size_t) m.k[1] + (size_t) m.k[2] > s->h.materialTables.size()))
             return fail(MI_ERR_INVALID, "mi_scene_commit: roughplastic material without its rough-transmittance slice (mi_scene_set_material_tables)");

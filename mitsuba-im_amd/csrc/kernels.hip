@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 const int inst = (AN && q.hitInst) ? q.hitInst[slot] : -1;
                 if (AN && inst >= 0) fillHitInstanced(sc, tb, sc.instances[inst], ro3, d, hr.x, prim, hr.y, hr.z, h);
                 else if (AN && prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], ro3, d, hr.x, hr.y, hr.z, h);
-                else fillHit(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
+                else fillHit<SMALL, AN>(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
                 if (depth > 1) {
                     if (h.emitter >= 0) {                                    // path.cpp:229-233, 257-264
                         v3 value = emitterEval(tb, h.emitter, h.ns, -d);
@@ -389,6 +389,10 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
                 bsdf = loadMaterial(tb, h.material);
+                if (AN) {                                                    // textured diffuse reflectance: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121)
+                    const uint32_t tex = (bsdf.flags >> 8) & 0xFFFFu;
+                    if (tex) { v3 c = textureEval(sc.textures[tex - 1], h.uvx, h.uvy); bsdf.reflectance[0] = c.x; bsdf.reflectance[1] = c.y; bsdf.reflectance[2] = c.z; }
+                }
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }

@@ -213,10 +213,26 @@ DEV v3 xfPoint(const float *m, v3 p) { return V(m[0] * p.x + m[1] * p.y + m[2] *
 DEV v3 xfVector(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z); }
 DEV v3 xfNormal(const float *inv, v3 n) { return V(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
 struct Hit {
-    v3 p, ng, ns, s, t, wi; float dist; int material, emitter; uint32_t flags;
+    v3 p, ng, ns, s, t, wi; float dist; int material, emitter; uint32_t flags; float uvx, uvy;   // uvx, uvy: its.uv (texcoords; set by the EXT paths only)
 };
 // include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610
-template <bool L>
+// Checkerboard::eval (src/textures/checkerboard.cpp:68-76), GridTexture::eval (src/textures/gridtexture.cpp:63-77) under Texture2D::eval
+// (src/librender/texture.cpp:112-121; these textures do not filter: usesRayDifferentials() = false)
+DEV v3 textureEval(const TextureD &t, float u, float v) {
+    float uvx = u * t.uscale + t.uoffset, uvy = v * t.vscale + t.voffset; bool first;
+    if (t.type == 0) {
+        int a = (int) (uvx * 2) % 2, b = (int) (uvy * 2) % 2; if (a < 0) a += 2; if (b < 0) b += 2;
+        first = (2 * a - 1) * (2 * b - 1) == 1;
+    } else {
+        float x = uvx - (float) (int) floorf(uvx), y = uvy - (float) (int) floorf(uvy);
+        if (x > .5) x -= 1;
+        if (y > .5) y -= 1;
+        first = !(fabsf(x) < t.line_width || fabsf(y) < t.line_width);
+    }
+    return first ? ld3(t.color0) : ld3(t.color1);
+}
+// UVT: honour texture coordinates (the EXT kernel variants): its.uv and dpdu = UV tangent for triangles whose mesh has texcoords
+template <bool L, bool UVT = false>
 DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
     typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
     f4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
@@ -226,7 +242,15 @@ DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t pr
     h.dist = t;
     h.p = (p0 * bx + p1 * by) + p2 * bz;
     v3 fn = V(r3.x, r3.y, r3.z);
-    if (h.flags & 1u) {          // face normals: the precomputed face frame is the shading frame
+    h.uvx = by; h.uvy = bz;
+    const bool hasUV = UVT && (h.flags & 16u);
+    v3 tangent = V(0, 0, 0);
+    if (hasUV) {
+        const TriUV &tu = sc.triuv[prim];
+        h.uvx = (tu.uv0[0] * bx + tu.uv1[0] * by) + tu.uv2[0] * bz; h.uvy = (tu.uv0[1] * bx + tu.uv1[1] * by) + tu.uv2[1] * bz;
+        tangent = ld3(tu.dpdu);
+    }
+    if (h.flags & 1u) {          // face normals: the precomputed face frame (built from the UV tangent where there is one) is the shading frame
         h.ns = fn; h.ng = fn; h.s = V(r4.x, r4.y, r4.z); h.t = V(r5.x, r5.y, r5.z);
     } else {
         uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
@@ -234,7 +258,7 @@ DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t pr
         h.ns = normalize(n);
         if (dot(fn, h.ns) < 0) fn = -fn;
         h.ng = fn;
-        v3 dpdu = p1 - p0;
+        v3 dpdu = hasUV ? tangent : p1 - p0;
         h.s = normalize(dpdu - h.ns * dot(h.ns, dpdu));
         h.t = cross(h.ns, h.s);
     }
@@ -263,7 +287,13 @@ DEV void fillHitInstanced(const DScene &sc, const Tabs<L> &tb, const InstanceD &
         if (dot(fn, ns) < 0) fn = -fn;
     }
     h.ns = normalize(xfNormal(in.to_object, ns)); h.ng = normalize(xfNormal(in.to_object, fn));
-    v3 dpdu = xfVector(in.to_world, p1 - p0);
+    v3 dpduObj = p1 - p0; h.uvx = by; h.uvy = bz;
+    if (h.flags & 16u) {
+        const TriUV &tu = sc.triuv[prim];
+        h.uvx = (tu.uv0[0] * bx + tu.uv1[0] * by) + tu.uv2[0] * bz; h.uvy = (tu.uv0[1] * bx + tu.uv1[1] * by) + tu.uv2[1] * bz;
+        dpduObj = ld3(tu.dpdu);
+    }
+    v3 dpdu = xfVector(in.to_world, dpduObj);
     h.p = xfPoint(in.to_world, pObj);
     h.s = normalize(dpdu - h.ns * dot(h.ns, dpdu));
     h.t = cross(h.ns, h.s);
@@ -355,7 +385,7 @@ DEV bool analyticIntersect(const AnalyticD &sh, v3 o, v3 d, float mint, float ma
 // Shape::fillIntersectionRecord (rectangle.cpp:155-168, disk.cpp:172-200, sphere.cpp:196-245, cylinder.cpp:203-233) + computeShadingFrame
 // + wi (skdtree.h:421-427).  Disk: the reference leaves geoFrame unset; defined as the shading normal.
 DEV void fillHitAnalytic(const AnalyticD &sh, v3 o, v3 d, float t, float lx, float ly, Hit &h) {
-    h.material = sh.material; h.emitter = sh.emitter; h.flags = sh.flags & 14u; h.dist = t;
+    h.material = sh.material; h.emitter = sh.emitter; h.flags = sh.flags & 14u; h.dist = t; h.uvx = h.uvy = 0;
     v3 p = o + d * t, n, dpdu;
     const uint32_t type = sh.type;
     if (type == MI_SHAPE_RECTANGLE) { n = ld3(sh.n); dpdu = ld3(sh.dpdu); }

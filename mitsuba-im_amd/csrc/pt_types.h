@@ -31,13 +31,19 @@ struct BvhNode {
 struct TriShade {
     float p0[3]; int32_t material;
     float p1[3]; int32_t emitter;
-    float p2[3]; uint32_t flags;          // bit0 face normals, bit1 material has a back side (twosided), bit2 BSDF without a smooth component (no NEE), bit3 rough conductor (material class for sorted shading)
+    float p2[3]; uint32_t flags;          // bit4: the mesh has texture coordinates (TriUV record: uv + UV tangents); bit0 face normals, bit1 material has a back side (twosided), bit2 BSDF without a smooth component (no NEE), bit3 rough conductor (material class for sorted shading)
     float ng[3]; uint32_t local_prim;
     float s[3]; uint32_t i0;
     float t[3]; uint32_t i1;              // i0,i1,i2: vertex indices for smooth normals (i2 in `i2` array)
 };
 
-struct MaterialD {                        // 64 B
+// Per-triangle texture-coordinate record (meshes with texcoords only), 48 B: its.uv interpolation (skdtree.h:402-408) and the UV tangents of
+// TriMesh::computeUVTangents (src/librender/trimesh.cpp:683-736), which replace the first edge as dpdu (skdtree.h:373-376)
+struct TriUV { float uv0[2], uv1[2], uv2[2]; float dpdu[3], dpdv[3]; };
+// 2-D procedural texture (src/textures/checkerboard.cpp, gridtexture.cpp over Texture2D), 48 B
+struct TextureD { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale; };
+
+struct MaterialD {                        // 64 B; flags bits 8..23: texture index + 1 bound to `reflectance`
     uint32_t type, flags, distr; float alpha;
     float reflectance[3], eta[3], k[3], specular[3];
 };
@@ -85,6 +91,7 @@ struct DScene {
     uint32_t ext;                         // analytic shapes or delta emitters present: selects the k_shade<..., EXT> variants
     // scene-level emitters beyond envmap (src/emitters/constant.cpp, point.cpp, spot.cpp, directional.cpp): per emitter 16 floats
     //   [0..2] position (point, spot) / travel direction (directional); spot: [3] cos(cutoff), [4..12] world->local 3x3, [13] cos(beam), [14] cutoff, [15] 1/(cutoff-beam)
+    const TriUV *triuv; const TextureD *textures; uint32_t n_textures, tex_pad;
     const float *material_tables;                    // float tables referenced by materials (roughplastic: k[1] = offset, k[2] = length)
     const float *emitter_x; uint32_t env_constant;   // env_constant: the environment emitter (env_index) is `constant`; radiance in its EmitterD
     float dir_bs_center[3], dir_bs_radius;           // DirectionalEmitter::createShape: kd-tree box bounding sphere x 1.1

@@ -167,6 +167,7 @@ void SceneHost::commitHost() {
 
     // --- triangle records
     std::vector<TriAccelD> accel(nt); shade.assign(nt, TriShade{}); i2.assign(nt, 0);
+    triuv.assign(uv.empty() ? 0 : nt, TriUV{}); anyUV = false;
     std::vector<V3> tlo(np), thi(np), cen(np);
     auto materialFlags = [&](int bsdf) {
         const mi_material &mat = materials[bsdf];
@@ -187,13 +188,36 @@ void SceneHost::commitHost() {
         ts.p0[0] = p0.x; ts.p0[1] = p0.y; ts.p0[2] = p0.z; ts.p1[0] = p1.x; ts.p1[1] = p1.y; ts.p1[2] = p1.z; ts.p2[0] = p2.x; ts.p2[1] = p2.y; ts.p2[2] = p2.z;
         ts.material = sh.bsdf; ts.emitter = sh.emitter;
         bool faceN = (sh.flags & 1u) || nrm.empty();
-        ts.flags = (faceN ? 1u : 0u) | materialFlags(sh.bsdf);
+        const bool hasUV = (sh.flags & 2u) && !uv.empty();
+        ts.flags = (faceN ? 1u : 0u) | materialFlags(sh.bsdf) | (hasUV ? 16u : 0u);
         ts.local_prim = t - sh.first_tri; ts.i0 = a; ts.i1 = b; i2[t] = c;
         // face frame: skdtree.h:367-371 (face normal), util.cpp:605-610 (computeShadingFrame with dpdu = p1 - p0)
         V3 side1 = p1 - p0, side2 = p2 - p0, fn = cross(side1, side2);
         float len = std::sqrt(dot(fn, fn));
         if (!(fn.x == 0 && fn.y == 0 && fn.z == 0)) { float r = 1.0f / len; fn = fn * r; }
-        V3 s = normalize(side1 - fn * dot(fn, side1)), tt = cross(fn, s);
+        V3 dpdu = side1;
+        if (hasUV) {                                             // TriMesh::computeUVTangents (trimesh.cpp:683-736)
+            TriUV &tu = triuv[t]; anyUV = true;
+            tu.uv0[0] = uv[a * 2]; tu.uv0[1] = uv[a * 2 + 1]; tu.uv1[0] = uv[b * 2]; tu.uv1[1] = uv[b * 2 + 1]; tu.uv2[0] = uv[c * 2]; tu.uv2[1] = uv[c * 2 + 1];
+            float du1 = tu.uv1[0] - tu.uv0[0], dv1 = tu.uv1[1] - tu.uv0[1], du2 = tu.uv2[0] - tu.uv0[0], dv2 = tu.uv2[1] - tu.uv0[1];
+            V3 n = cross(side1, side2); float length = std::sqrt(dot(n, n)); V3 tdu = mk(0, 0, 0), tdv = mk(0, 0, 0);
+            if (length != 0) {
+                float determinant = du1 * dv2 - dv1 * du2;
+                if (determinant == 0) {                         // coordinateSystem(n / length, dpdu, dpdv), util.cpp:594-603
+                    float r = 1.0f / length; V3 an = n * r;
+                    if (std::fabs(an.x) > std::fabs(an.y)) { float invLen = 1.0f / std::sqrt(an.x * an.x + an.z * an.z); tdv = mk(an.z * invLen, 0.0f, -an.x * invLen); }
+                    else { float invLen = 1.0f / std::sqrt(an.y * an.y + an.z * an.z); tdv = mk(0.0f, an.z * invLen, -an.y * invLen); }
+                    tdu = cross(tdv, an);
+                } else {
+                    float invDet = 1.0f / determinant;
+                    tdu = (side1 * dv2 - side2 * dv1) * invDet;
+                    tdv = (side1 * (-du2) + side2 * du1) * invDet;
+                }
+            }
+            tu.dpdu[0] = tdu.x; tu.dpdu[1] = tdu.y; tu.dpdu[2] = tdu.z; tu.dpdv[0] = tdv.x; tu.dpdv[1] = tdv.y; tu.dpdv[2] = tdv.z;
+            dpdu = tdu;
+        }
+        V3 s = normalize(dpdu - fn * dot(fn, dpdu)), tt = cross(fn, s);
         ts.ng[0] = fn.x; ts.ng[1] = fn.y; ts.ng[2] = fn.z; ts.s[0] = s.x; ts.s[1] = s.y; ts.s[2] = s.z; ts.t[0] = tt.x; ts.t[1] = tt.y; ts.t[2] = tt.z;
         V3 lo = vmin(vmin(p0, p1), p2), hi = vmax(vmax(p0, p1), p2);
         // conservative padding: the Wald test is evaluated in its own arithmetic, boxes may only over-approximate

@@ -433,3 +433,20 @@ def test_roughplastic(mi, oracle, golden_scenes):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
     with pytest.raises(mi.MiError, match="rough-transmittance"):
         bad = mi.scenes.cbox_roughplastic(32, 32, 1); bad.material_tables = None; mi.Scene(bad)
+
+
+def test_texture_coordinates_and_procedural_textures(mi, oracle, golden_scenes):
+    """Meshes with texture coordinates: its.uv interpolation and shading frames from the UV tangents (TriMesh::computeUVTangents), `checkerboard`
+    and `gridtexture` bound to diffuse reflectances (no filtering in the reference either).  All-diffuse -> bit-exact against the oracle."""
+    name = "textured_room"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(38); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    assert (bits(got) == bits(ref)).all()
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 2e-4).mean() > 0.998 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 5e-4
