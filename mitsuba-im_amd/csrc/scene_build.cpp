@@ -175,7 +175,7 @@ void SceneHost::commitHost() {
         bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS;
         // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
         // conductor / dielectric register delta components only
-        bool smooth = mat.type == MI_BSDF_DIFFUSE ? std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0
+        bool smooth = mat.type == MI_BSDF_DIFFUSE ? (((mat.flags >> 8) & 0xFFFFu) != 0 || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0)
                                                   : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC);
         return (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type != MI_BSDF_DIFFUSE ? 8u : 0u);
     };

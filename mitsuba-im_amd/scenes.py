@@ -164,6 +164,15 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
     sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)
     sc.envmap = envmap          # None or dict(rgb[h,w,3] f32, to_world[4,4], scale)
+    lv = []; tx = []                                # MIP pyramids of the bitmap textures, concatenated: texture_levels[n][3] = (w, h, offset), texture_texels
+    for t in (textures or []):
+        if t.get("pyramid") is not None:
+            levels = t["pyramid"]["levels"] if t["filter"] >= MIP_TRILINEAR else t["pyramid"]["levels"][:1]      # mipmap.h:183-191: one level without trilinear / EWA
+            t["first_level"] = len(lv); t["n_levels"] = len(levels)
+            for (w, h, data) in levels:
+                lv.append((w, h, sum(len(a) for a in tx))); tx.append(data)
+    sc.texture_levels = np.asarray(lv, np.uint32).reshape(-1, 3) if lv else None
+    sc.texture_texels = np.concatenate(tx).astype(f32) if tx else None
     sc.textures = list(textures or [])             # 2-D procedural textures (make_texture); a bsdf dict binds one to its reflectance through "texture" = index
     for sh in shapes: sh.setdefault("has_uv", int(uvs is not None))
     tabs = []                                       # float tables referenced by materials (roughplastic): k[1] = offset into sc.material_tables
@@ -209,11 +218,28 @@ def make_analytic(kind, to_world, bsdf, emitter=-1, flip=False, radius=1.0, leng
 
 TEXTURE_CHECKERBOARD = 0   # src/textures/checkerboard.cpp
 TEXTURE_GRID = 1           # src/textures/gridtexture.cpp
+TEXTURE_BITMAP = 2         # src/textures/bitmap.cpp over TMIPMap (include/mitsuba/render/mipmap.h); the MIP pyramid is input data
+WRAP_CLAMP, WRAP_REPEAT, WRAP_MIRROR, WRAP_ZERO, WRAP_ONE = 0, 1, 2, 3, 4          # ReconstructionFilter::EBoundaryCondition
+MIP_NEAREST, MIP_BILINEAR, MIP_TRILINEAR, MIP_EWA = 0, 1, 2, 3                       # EMIPFilterType
 
 
-def make_texture(kind, color0, color1, line_width=0.01, uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0):
+def load_texture_pyramid(name="texture_pyramid_48x40.npz"):
+    """A MIP pyramid as the reference builds it (TMIPMap<Color3, Color3h>, 2-lobed Lanczos, repeat): dumped by `oracle/_ref/harness mipmap` from
+    the procedural base image stored alongside.  Returns dict(base[h,w,3], levels=[(w, h, texels[h*w*3])...])."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name))
+    levels = []; off = 0
+    for w, h in d["sizes"]:
+        n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
+    return dict(base=np.ascontiguousarray(d["base"], f32), levels=levels)
+
+
+def make_texture(kind, color0=(0, 0, 0), color1=(0, 0, 0), line_width=0.01, uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0,
+                 pyramid=None, wrap_u=WRAP_REPEAT, wrap_v=WRAP_REPEAT, filter_type=MIP_EWA, max_anisotropy=20.0):
     return dict(type=int(kind), color0=tuple(map(float, color0)), color1=tuple(map(float, color1)), line_width=float(line_width),
-                uoffset=float(uoffset), voffset=float(voffset), uscale=float(uscale), vscale=float(vscale))
+                uoffset=float(uoffset), voffset=float(voffset), uscale=float(uscale), vscale=float(vscale), pyramid=pyramid,
+                wrap_u=int(wrap_u), wrap_v=int(wrap_v), filter=int(filter_type), max_anisotropy=float(max_anisotropy if filter_type == MIP_EWA else 1.0),
+                first_level=0, n_levels=0)
 
 
 def make_instance(group, to_world):
@@ -523,6 +549,24 @@ def textured_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=
                         seed=seed, normals=normals, uvs=uvs, name="textured_room", textures=tex)
 
 
+def bitmap_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
+    """The textured room with `bitmap` textures: EWA-filtered floor seen at grazing angles (anisotropic footprints, clamped anisotropy), trilinear
+    wall with mirror / clamp wrapping, bilinear mound, nearest-neighbour panel.  Camera hits filter with the ray differentials
+    (Intersection::computePartials); every later bounce reads level 0."""
+    sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed)
+    pyr = load_texture_pyramid()
+    tex = [make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=3.0, vscale=2.0, uoffset=0.1, filter_type=MIP_EWA),
+           make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=1.7, vscale=1.3, wrap_u=WRAP_MIRROR, wrap_v=WRAP_CLAMP, filter_type=MIP_TRILINEAR),
+           make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=1.0, vscale=1.0, filter_type=MIP_BILINEAR),
+           make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=0.5, vscale=0.5, filter_type=MIP_NEAREST, wrap_u=WRAP_ZERO, wrap_v=WRAP_ONE)]
+    sc.shapes[3]["has_uv"] = 1                     # the plain panel gets texcoords + the nearest-neighbour texture
+    sc.uv[sc.shapes[3]["first_vert"]:sc.shapes[3]["first_vert"] + 4] = np.array([(-0.3, -0.2), (-0.3, 1.4), (1.6, 1.4), (1.6, -0.2)], f32)
+    sc.bsdfs[3]["texture"] = 3
+    out = finish_scene(sc.pos, sc.idx, sc.shapes, sc.bsdfs, sc.emitters, sc.cam_to_world, sc.xfov, sc.near, sc.far, width, height, spp, sampler, max_depth, rr_depth,
+                       seed=seed, normals=sc.nrm, uvs=sc.uv, name="bitmap_room", textures=tex)
+    return out
+
+
 def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
     """Area lights on every analytic shape kind inside an inward-facing (`flipNormals`) sphere: a `sphere` light (cone sampling from
     outside, sphere.cpp:275-346), a `cylinder` light, a `disk` light and a `rectangle` light over a mesh floor and a mesh blocker."""
@@ -814,6 +858,9 @@ def save_scene(sc, path):
             f.write(b"TEXR"); f.write(struct.pack("<I", len(sc.textures)))
             for t in sc.textures:
                 f.write(struct.pack("<I11f", t["type"], *t["color0"], *t["color1"], t["line_width"], t["uoffset"], t["voffset"], t["uscale"], t["vscale"]))
+                f.write(struct.pack("<3If2I", t["wrap_u"], t["wrap_v"], t["filter"], t["max_anisotropy"], 0, 0))
+                if t["type"] == TEXTURE_BITMAP:              # the harness builds the reference's own BitmapTexture (and MIP pyramid) from the base image
+                    base = t["pyramid"]["base"]; f.write(struct.pack("<2I", base.shape[1], base.shape[0])); f.write(base.tobytes())
             f.write(struct.pack("<%di" % len(sc.bsdfs), *[b.get("texture", -1) for b in sc.bsdfs]))
         if sc.get("instances"):
             f.write(b"INST"); f.write(struct.pack("<I", len(sc.instances)))

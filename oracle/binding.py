@@ -16,7 +16,8 @@ class OrcShape(C.Structure):
 
 class OrcTexture(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
-                ("uoffset", C.c_float), ("voffset", C.c_float), ("uscale", C.c_float), ("vscale", C.c_float)]
+                ("uoffset", C.c_float), ("voffset", C.c_float), ("uscale", C.c_float), ("vscale", C.c_float),
+                ("wrap_u", C.c_uint32), ("wrap_v", C.c_uint32), ("filter", C.c_uint32), ("max_anisotropy", C.c_float), ("first_level", C.c_uint32), ("n_levels", C.c_uint32)]
 
 
 class OrcInstance(C.Structure):
@@ -49,7 +50,7 @@ class OrcSceneDesc(C.Structure):
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
-                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p)]
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_texture_levels", C.c_uint32), ("texture_levels", C.c_void_p), ("n_texture_texels", C.c_uint32), ("texture_texels", C.c_void_p)]
 
 
 def build():
@@ -184,8 +185,12 @@ class Oracle:
             ta = (OrcTexture * len(texs))()
             for i, t in enumerate(texs):
                 r = OrcTexture(t["type"]); r.color0[:] = t["color0"]; r.color1[:] = t["color1"]; r.line_width = t["line_width"]
-                r.uoffset, r.voffset, r.uscale, r.vscale = t["uoffset"], t["voffset"], t["uscale"], t["vscale"]; ta[i] = r
+                r.uoffset, r.voffset, r.uscale, r.vscale = t["uoffset"], t["voffset"], t["uscale"], t["vscale"]
+                r.wrap_u, r.wrap_v, r.filter, r.max_anisotropy, r.first_level, r.n_levels = t.get("wrap_u", 1), t.get("wrap_v", 1), t.get("filter", 3), t.get("max_anisotropy", 20.0), t.get("first_level", 0), t.get("n_levels", 0); ta[i] = r
             self._keep.append(ta); d.n_textures, d.textures = len(texs), C.cast(ta, C.c_void_p)
+            if sc.get("texture_levels") is not None:
+                self._keep += [sc.texture_levels, sc.texture_texels]
+                d.n_texture_levels, d.texture_levels, d.n_texture_texels, d.texture_texels = len(sc.texture_levels), _ptr(sc.texture_levels), len(sc.texture_texels), _ptr(sc.texture_texels)
         mt = sc.get("material_tables")
         if mt is not None:
             self._keep.append(mt); d.n_material_tables, d.material_tables = len(mt), _ptr(mt)

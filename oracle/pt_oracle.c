@@ -47,6 +47,7 @@ typedef struct { uint32_t k; float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_
 typedef struct { v3 lo, hi; int32_t left, right, first, count; } bvh_node;   /* leaf: count > 0 */
 
 typedef struct {
+    v3 dpdu, dpdv;    /* its.dpdu / its.dpdv (world space): feed Intersection::computePartials */
     float uvx, uvy;   /* its.uv: interpolated texture coordinates (meshes with texcoords), else the barycentrics */
     int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter; int32_t instance;
 } hit_t;
@@ -55,6 +56,7 @@ typedef struct {
 typedef struct mat_s { orc_material m; const float *table; } mat_t;
 struct orc_scene {
     orc_scene_desc d;
+    uint32_t *tex_levels; float *tex_texels; float mip_lut[64]; v3 cam_dx, cam_dy;   /* MIP pyramids (input data); EWA weight table; perspective.cpp:159-163 */
     float *uv; float *tangents; /* per triangle: dpdu xyz, dpdv xyz (TriMesh::computeUVTangents) */ orc_texture *textures;
     float *pos, *nrm; uint32_t *idx; orc_shape *shapes; struct mat_s *materials; orc_emitter *emitters; float *material_tables;
     uint32_t *tri_shape;
@@ -648,7 +650,7 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     if (prim >= s->d.n_tris) {                       /* skdtree.h:421-427: shape->fillIntersectionRecord, computeShadingFrame, wi */
         const analytic_t *sh = &s->analytic[prim - s->d.n_tris]; v3 dpdu;
         h->valid = 1; h->t = t; h->u = u; h->v = v; h->uvx = h->uvy = 0; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
-        analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu);
+        analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu); h->dpdu = dpdu; h->dpdv = V(0, 0, 0);
         h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
         h->tt = cross(h->ns, h->s);
         v3 md = neg(d);
@@ -680,15 +682,18 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     h->ng = fn;
     v3 dpdu = side1;   /* skdtree.h:373-380: the UV tangent of the triangle when the mesh has texcoords, else the first edge */
     h->uvx = by; h->uvy = bz;                                   /* skdtree.h:402-408 */
+    v3 dpdv = side2;
     if (s->uv && (sh->flags & 2u)) {
         const float *t0 = &s->uv[i0 * 2], *t1 = &s->uv[i1 * 2], *t2 = &s->uv[i2 * 2];
         h->uvx = (t0[0] * bx + t1[0] * by) + t2[0] * bz; h->uvy = (t0[1] * bx + t1[1] * by) + t2[1] * bz;
         dpdu = V(s->tangents[prim * 6], s->tangents[prim * 6 + 1], s->tangents[prim * 6 + 2]);
+        dpdv = V(s->tangents[prim * 6 + 3], s->tangents[prim * 6 + 4], s->tangents[prim * 6 + 5]);
     }
     if (in) {   /* instance.cpp:134-139: normals through the inverse transpose, dpdu / p through the forward transform; then the scene-level computeShadingFrame + wi */
         h->ns = normalize(xf_normal(in->to_object, h->ns)); h->ng = normalize(xf_normal(in->to_object, h->ng));
-        dpdu = xf_vector(in->to_world, dpdu); h->p = xf_point(in->to_world, h->p);
+        dpdu = xf_vector(in->to_world, dpdu); dpdv = xf_vector(in->to_world, dpdv); h->p = xf_point(in->to_world, h->p);
     }
+    h->dpdu = dpdu; h->dpdv = dpdv;
     h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
     h->tt = cross(h->ns, h->s);
     v3 md = neg(d);
@@ -743,6 +748,22 @@ static void camera_ray(const orc_scene *s, float sx, float sy, v3 *o, v3 *d, flo
     *o = V(c[3], c[7], c[11]);
     *d = V(c[0] * dl.x + c[1] * dl.y + c[2] * dl.z, c[4] * dl.x + c[5] * dl.y + c[6] * dl.z, c[8] * dl.x + c[9] * dl.y + c[10] * dl.z);
 }
+/* ray differentials of the sensor ray: perspective.cpp:290-295 (rxDirection / ryDirection through nearP + m_dx / m_dy, :159-163), then
+ * RayDifferential::scaleDifferential(1 / sqrt(spp)) (include/mitsuba/core/ray.h:163-168; integrator.cpp:145-146, 182 / :403-405, 425) */
+static void camera_differentials(const orc_scene *s, float sx, float sy, v3 d, v3 *rxd, v3 *ryd) {
+    const float *m = s->d.sample_to_camera;
+    float px = sx * s->inv_res_x, py = sy * s->inv_res_y;
+    float x = m[0] * px + m[1] * py + m[3], y = m[4] * px + m[5] * py + m[7], z = m[8] * px + m[9] * py + m[11], w = m[12] * px + m[13] * py + m[15];
+    x = m[0] * px + m[1] * py + m[2] * 0.0f + m[3]; y = m[4] * px + m[5] * py + m[6] * 0.0f + m[7]; z = m[8] * px + m[9] * py + m[10] * 0.0f + m[11]; w = m[12] * px + m[13] * py + m[14] * 0.0f + m[15];
+    v3 nearP = V(x, y, z);
+    if (w != 1.0f) { float r = 1.0f / w; nearP = scale(nearP, r); }
+    const float *c = s->d.cam_to_world;
+    v3 a = normalize(add(nearP, s->cam_dx)), b = normalize(add(nearP, s->cam_dy));
+    v3 rx = V(c[0] * a.x + c[1] * a.y + c[2] * a.z, c[4] * a.x + c[5] * a.y + c[6] * a.z, c[8] * a.x + c[9] * a.y + c[10] * a.z);
+    v3 ry = V(c[0] * b.x + c[1] * b.y + c[2] * b.z, c[4] * b.x + c[5] * b.y + c[6] * b.z, c[8] * b.x + c[9] * b.y + c[10] * b.z);
+    const float amount = 1.0f / sqrtf((float) s->d.spp);
+    *rxd = add(d, scale(sub(rx, d), amount)); *ryd = add(d, scale(sub(ry, d), amount));
+}
 void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d; camera_ray(s, sx, sy, &o, &d, &o8[3], &o8[7]); o8[0] = o.x; o8[1] = o.y; o8[2] = o.z; o8[4] = d.x; o8[5] = d.y; o8[6] = d.z; }
 
 /* ------------------------------------------------------------------------------------------------ BSDFs */
@@ -755,7 +776,7 @@ static int material_has_backside(const orc_material *m) { return (m->flags & BSD
 /* BSDF::ESmooth: a `diffuse` whose reflectance is identically zero registers NO component (src/bsdfs/diffuse.cpp:99-102), so its type
  * is 0 and MIPathTracer::Li skips emitter sampling -- and the sampler request that goes with it (path.cpp:174-176) */
 static int material_is_smooth(const orc_material *m) {
-    if (m->type == BSDF_DIFFUSE) return maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;
+    if (m->type == BSDF_DIFFUSE) return ((m->flags >> 8) & 0xFFFFu) != 0 || maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;   /* a textured reflectance always registers the component */
     if (m->type == BSDF_CONDUCTOR || m->type == BSDF_DIELECTRIC) return 0;     /* delta components only (conductor.cpp:201-202, dielectric.cpp:199-202) */
     return 1;
 }
@@ -1454,10 +1475,130 @@ void orc_sample_emitter_direct(const orc_scene *s, const float *rp, const float 
     o[9] = dr.dist; o[10] = dr.pdf; o[11] = is_zero(val) ? 0.0f : pdf_emitter_direct(s, &dr, refN);
 }
 
+/* ---- bitmap textures: TMIPMap (include/mitsuba/render/mipmap.h): evalTexel :504-560, evalBox :562-566, evalBilinear :572-596, eval :625-705,
+ * evalEWA :746-818; the pyramid itself is input data (the reference resamples with Bitmap::resample; fixtures come from oracle/_ref/harness mipmap) */
+static inline int imod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
+static v3 mip_texel(const orc_scene *s, const orc_texture *t, int level, int x, int y) {
+    const uint32_t *L = &s->tex_levels[(t->first_level + (uint32_t) level) * 3]; const int w = (int) L[0], h = (int) L[1];
+    if (x < 0 || x >= w) switch (t->wrap_u) {
+        case 1: x = imod(x, w); break;
+        case 0: x = x < 0 ? 0 : w - 1; break;
+        case 2: x = imod(x, 2 * w); if (x >= w) x = 2 * w - x - 1; break;
+        case 3: return V(0, 0, 0);
+        default: return V(1, 1, 1);
+    }
+    if (y < 0 || y >= h) switch (t->wrap_v) {
+        case 1: y = imod(y, h); break;
+        case 0: y = y < 0 ? 0 : h - 1; break;
+        case 2: y = imod(y, 2 * h); if (y >= h) y = 2 * h - y - 1; break;
+        case 3: return V(0, 0, 0);
+        default: return V(1, 1, 1);
+    }
+    const float *p = &s->tex_texels[L[2] + ((size_t) y * w + x) * 3]; return V(p[0], p[1], p[2]);
+}
+static v3 mip_box(const orc_scene *s, const orc_texture *t, int level, float u, float v) {
+    const uint32_t *L = &s->tex_levels[(t->first_level + (uint32_t) level) * 3];
+    return mip_texel(s, t, level, (int) floorf(u * (float) (int) L[0]), (int) floorf(v * (float) (int) L[1]));
+}
+static v3 mip_bilinear(const orc_scene *s, const orc_texture *t, int level, float uvx, float uvy) {
+    if (!isfinite(uvx) || !isfinite(uvy)) return V(0, 0, 0);
+    if (level >= (int) t->n_levels) return mip_box(s, t, (int) t->n_levels - 1, uvx, uvy);
+    const uint32_t *L = &s->tex_levels[(t->first_level + (uint32_t) level) * 3];
+    float u = uvx * (float) (int) L[0] - 0.5f, v = uvy * (float) (int) L[1] - 0.5f;
+    int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    float dx1 = u - (float) xPos, dx2 = 1.0f - dx1, dy1 = v - (float) yPos, dy2 = 1.0f - dy1;
+    v3 r = scale(scale(mip_texel(s, t, level, xPos, yPos), dx2), dy2);
+    r = add(r, scale(scale(mip_texel(s, t, level, xPos, yPos + 1), dx2), dy1));
+    r = add(r, scale(scale(mip_texel(s, t, level, xPos + 1, yPos), dx1), dy2));
+    r = add(r, scale(scale(mip_texel(s, t, level, xPos + 1, yPos + 1), dx1), dy1));
+    return r;
+}
+static v3 mip_ewa(const orc_scene *s, const orc_texture *t, int level, float uvx, float uvy, float A, float B, float C) {
+    if (!isfinite(A + B + C + uvx + uvy)) return V(0, 0, 0);
+    if (level >= (int) t->n_levels) return mip_box(s, t, (int) t->n_levels - 1, uvx, uvy);
+    const uint32_t *L = &s->tex_levels[(t->first_level + (uint32_t) level) * 3], *L0 = &s->tex_levels[t->first_level * 3];
+    float u = uvx * (float) (int) L[0] - 0.5f, v = uvy * (float) (int) L[1] - 0.5f;
+    const float rx = (float) (int) L[0] / (float) (int) L0[0], ry = (float) (int) L[1] / (float) (int) L0[1];     /* m_sizeRatio[level] */
+    A /= rx * rx; B /= rx * ry; C /= ry * ry;
+    float invDet = 1.0f / (-B * B + 4.0f * A * C), deltaU = 2.0f * sqrtf(C * invDet), deltaV = 2.0f * sqrtf(A * invDet);
+    int u0 = (int) ceilf(u - deltaU), u1 = (int) floorf(u + deltaU), v0 = (int) ceilf(v - deltaV), v1 = (int) floorf(v + deltaV);
+    float As = A * 64, Bs = B * 64, Cs = C * 64;
+    v3 result = V(0, 0, 0); float denominator = 0.0f, ddq = 2 * As, uu0 = (float) u0 - u;
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vv = (float) vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv, dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < 64.0f) {
+                uint32_t qi = (uint32_t) q;
+                if (qi < 64) { const float weight = s->mip_lut[(int) q]; result = add(result, scale(mip_texel(s, t, level, ut, vt), weight)); denominator += weight; }
+            }
+            q += dq; dq += ddq;
+        }
+    }
+    if (denominator == 0) return mip_bilinear(s, t, level, uvx, uvy);
+    { float r = 1.0f / denominator; return scale(result, r); }
+}
+static float hypot2f(float a, float b) {                       /* src/libcore/math.cpp:74-86 */
+    float r;
+    if (fabsf(a) > fabsf(b)) { r = b / a; r = fabsf(a) * sqrtf(1.0f + r * r); }
+    else if (b != 0.0f) { r = a / b; r = fabsf(b) * sqrtf(1.0f + r * r); }
+    else r = 0.0f;
+    return r;
+}
+static inline float mi_log2(float v) { const float invLn2 = 1.0f / logf(2.0f); return (float) log((double) v) * invLn2; }   /* math.cpp:103-106 */
+static v3 mip_eval(const orc_scene *s, const orc_texture *t, float uvx, float uvy, float d0x, float d0y, float d1x, float d1y) {
+    if (t->filter == 0) return mip_box(s, t, 0, uvx, uvy);
+    if (t->filter == 1) return mip_bilinear(s, t, 0, uvx, uvy);
+    const uint32_t *L0 = &s->tex_levels[t->first_level * 3]; const float sx = (float) (int) L0[0], sy = (float) (int) L0[1];
+    float du0 = d0x * sx, dv0 = d0y * sy, du1 = d1x * sx, dv1 = d1y * sy;
+    float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+    float root = hypot2f(A - C, B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root),
+          majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0, minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
+    if (t->filter == 2 || !(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        float level = mi_log2(maxf(majorRadius, EPSILON)); int ilevel = (int) floorf(level);
+        if (ilevel < 0) return mip_bilinear(s, t, 0, uvx, uvy);
+        float a = level - (float) ilevel;
+        return add(scale(mip_bilinear(s, t, ilevel, uvx, uvy), 1.0f - a), scale(mip_bilinear(s, t, ilevel + 1, uvx, uvy), a));
+    }
+    if (minorRadius * t->max_anisotropy < majorRadius) {
+        minorRadius = majorRadius / t->max_anisotropy;
+        float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
+    }
+    float sc = 1.0f / F; A *= sc; B *= sc; C *= sc;
+    float level = maxf(0.0f, mi_log2(minorRadius)); int ilevel = (int) level; float a = level - (float) ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0)) return mip_bilinear(s, t, ilevel, uvx, uvy);
+    return add(scale(mip_ewa(s, t, ilevel, uvx, uvy, A, B, C), 1.0f - a), scale(mip_ewa(s, t, ilevel + 1, uvx, uvy, A, B, C), a));
+}
+/* Intersection::computePartials (src/librender/intersection.cpp:5-76) for a hit of the CAMERA ray (rx/ry: its differentials, common origin o) */
+static int compute_partials(const hit_t *h, v3 o, v3 rxd, v3 ryd, float *dudx, float *dvdx, float *dudy, float *dvdy) {
+    *dudx = *dvdx = *dudy = *dvdy = 0.0f;
+    if (is_zero(h->dpdu) && is_zero(h->dpdv)) return 1;
+    const float pp = dot(h->ng, h->p), pox = dot(h->ng, o), poy = dot(h->ng, o), prx = dot(h->ng, rxd), pry = dot(h->ng, ryd);
+    if (prx == 0 || pry == 0) return 1;
+    const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    float absX = fabsf(h->ng.x), absY = fabsf(h->ng.y), absZ = fabsf(h->ng.z); int a0, a1;
+    if (absX > absY && absX > absZ) { a0 = 1; a1 = 2; } else if (absY > absZ) { a0 = 0; a1 = 2; } else { a0 = 0; a1 = 1; }
+    float A00 = comp(h->dpdu, a0), A01 = comp(h->dpdv, a0), A10 = comp(h->dpdu, a1), A11 = comp(h->dpdv, a1);
+    v3 px = add(o, scale(rxd, tx)), py = add(o, scale(ryd, ty));
+    float Bx0 = comp(px, a0) - comp(h->p, a0), Bx1 = comp(px, a1) - comp(h->p, a1), By0 = comp(py, a0) - comp(h->p, a0), By1 = comp(py, a1) - comp(h->p, a1);
+    float det = A00 * A11 - A01 * A10;
+    if (fabsf(det) <= 0x1p-128f) { *dudx = 1; *dvdx = 0; *dudy = 0; *dudy = 1; return 1; }       /* solveLinearSystem2x2 fails (util.cpp:529-541); NB the reference's second fallback assigns dudy twice */
+    float inverse = 1.0f / det;
+    *dudx = (A11 * Bx0 - A01 * Bx1) * inverse; *dvdx = (A00 * Bx1 - A10 * Bx0) * inverse;
+    *dudy = (A11 * By0 - A01 * By1) * inverse; *dvdy = (A00 * By1 - A10 * By0) * inverse;
+    return 1;
+}
 /* ---- 2-D procedural textures: Texture2D::eval (src/librender/texture.cpp:112-121, no filtering: usesRayDifferentials() = false), Checkerboard::eval
  * (src/textures/checkerboard.cpp:68-76), GridTexture::eval (src/textures/gridtexture.cpp:63-77) */
-static v3 texture_eval(const orc_texture *t, float u, float v) {
+/* partials: NULL (no ray differentials: every hit but the camera ray's) or {dudx, dvdx, dudy, dvdy} */
+static v3 texture_eval(const orc_scene *s, const orc_texture *t, float u, float v, const float *partials) {
     float uvx = u * t->uscale + t->uoffset, uvy = v * t->vscale + t->voffset;
+    if (t->type == 2) {                                           /* BitmapTexture::eval (src/textures/bitmap.cpp:434-502) */
+        if (partials) return mip_eval(s, t, uvx, uvy, partials[0] * t->uscale, partials[1] * t->vscale, partials[2] * t->uscale, partials[3] * t->vscale);
+        return t->filter != 0 ? mip_bilinear(s, t, 0, uvx, uvy) : mip_box(s, t, 0, uvx, uvy);
+    }
     int first;
     if (t->type == 0) {
         int a = (int) (uvx * 2) % 2, b = (int) (uvy * 2) % 2; if (a < 0) a += 2; if (b < 0) b += 2;
@@ -1475,7 +1616,7 @@ static v3 texture_eval(const orc_texture *t, float u, float v) {
 static inline float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   /* path.cpp:296-300 */
 
 /* src/integrators/path/path.cpp:119-294 MIPathTracer::Li (no media, no subsurface) */
-static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters, float *alpha) {
+static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters, float *alpha, const v3 *rxd, const v3 *ryd) {
     const int maxDepth = s->d.max_depth, rrDepth = s->d.rr_depth;
     const int strict = s->d.strict_normals != 0, hide = s->d.hide_emitters != 0;
     hit_t its; v3 Li = V(0, 0, 0); int scattered = 0; int depth = 1;
@@ -1492,7 +1633,9 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
         }
         mat_t bsdf_local = s->materials[its.material];        /* textured reflectance: evaluated at the hit's uv (diffuse.cpp:112-121: m_reflectance->eval(bRec.its)) */
         { uint32_t tex = (bsdf_local.m.flags >> 8) & 0xFFFFu;
-          if (tex) { v3 c = texture_eval(&s->textures[tex - 1], its.uvx, its.uvy); bsdf_local.m.reflectance[0] = c.x; bsdf_local.m.reflectance[1] = c.y; bsdf_local.m.reflectance[2] = c.z; } }
+          float pa[4]; const float *partials = NULL;            /* its.getBSDF(ray) -> computePartials: only the camera ray carries differentials (records.inl:68-75) */
+          if (tex && depth == 1 && !scattered && s->textures[tex - 1].type == 2) { compute_partials(&its, o, *rxd, *ryd, &pa[0], &pa[1], &pa[2], &pa[3]); partials = pa; }
+          if (tex) { v3 c = texture_eval(s, &s->textures[tex - 1], its.uvx, its.uvy, partials); bsdf_local.m.reflectance[0] = c.x; bsdf_local.m.reflectance[1] = c.y; bsdf_local.m.reflectance[2] = c.z; } }
         const orc_material *bsdf = &bsdf_local.m;
         if (its.emitter >= 0 && emitted_radiance && (!hide || scattered))
             Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
@@ -1568,7 +1711,8 @@ static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t si
     float jx, jy; next2D(&sp, &jx, &jy);
     pos[0] = (float) (int32_t) px + jx; pos[1] = (float) (int32_t) py + jy;
     v3 o, d; float mint, maxt; camera_ray(s, pos[0], pos[1], &o, &d, &mint, &maxt);
-    v3 li = path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha);
+    v3 rxd, ryd; camera_differentials(s, pos[0], pos[1], d, &rxd, &ryd);
+    v3 li = path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd);
     if (nlog) *nlog = sp.nlog;
     return li;
 }
@@ -1690,6 +1834,18 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
     s->uv = (float *) dup(d->uv, (size_t) d->n_verts * 8);
     s->textures = (orc_texture *) dup(d->textures, (size_t) (d->textures ? d->n_textures : 0) * sizeof(orc_texture)); s->d.textures = NULL;
+    s->tex_levels = (uint32_t *) dup(d->texture_levels, (size_t) (d->texture_levels ? d->n_texture_levels : 0) * 12);
+    s->tex_texels = (float *) dup(d->texture_texels, (size_t) (d->texture_texels ? d->n_texture_texels : 0) * 4);
+    s->d.texture_levels = NULL; s->d.texture_texels = NULL;
+    for (int i = 0; i < 64; ++i) { float r2 = (float) i / 63.0f; s->mip_lut[i] = fastexpf_(-2.0f * r2) - fastexpf_(-2.0f); }   /* mipmap.h:297-302 */
+    {   /* PerspectiveCameraImpl::configure (perspective.cpp:159-163): m_dx / m_dy = sampleToCamera(1/w, 0, 0) - sampleToCamera(0), w-divided points */
+        const float *m = d->sample_to_camera; float irx = 1.0f / (float) d->width, iry = 1.0f / (float) d->height;
+        v3 p0, px, py; float w;
+        w = m[15]; p0 = V(m[3], m[7], m[11]); if (w != 1.0f) { float r = 1.0f / w; p0 = scale(p0, r); }
+        w = m[12] * irx + m[13] * 0.0f + m[14] * 0.0f + m[15]; px = V(m[0] * irx + m[1] * 0.0f + m[2] * 0.0f + m[3], m[4] * irx + m[5] * 0.0f + m[6] * 0.0f + m[7], m[8] * irx + m[9] * 0.0f + m[10] * 0.0f + m[11]); if (w != 1.0f) { float r = 1.0f / w; px = scale(px, r); }
+        w = m[12] * 0.0f + m[13] * iry + m[14] * 0.0f + m[15]; py = V(m[0] * 0.0f + m[1] * iry + m[2] * 0.0f + m[3], m[4] * 0.0f + m[5] * iry + m[6] * 0.0f + m[7], m[8] * 0.0f + m[9] * iry + m[10] * 0.0f + m[11]); if (w != 1.0f) { float r = 1.0f / w; py = scale(py, r); }
+        s->cam_dx = sub(px, p0); s->cam_dy = sub(py, p0);
+    }
     s->tri_shape = (uint32_t *) calloc(d->n_tris, 4);
     for (uint32_t i = 0; i < d->n_shapes; ++i) for (uint32_t t = 0; t < s->shapes[i].tri_count; ++t) s->tri_shape[s->shapes[i].first_tri + t] = i;
     /* TriAccel table (skdtree.cpp:79-105) + scene box (union of mesh AABBs, enlarged as in gkdtree.h:1213-1220) */
@@ -1906,5 +2062,5 @@ void orc_scene_destroy(orc_scene *s) {
     free(s->area_cdf); free(s->inv_area); free(s->emitter_cdf); free(s->nodes); free(s->bvh_tris); free(s->accel); free(s->tri_shape); free(s->analytic); free(s->instances); free(s->group_root); free(s->group_lo); free(s->group_hi); free(s->group_first); free(s->group_count);
     free(s->spot_cos_beam); free(s->spot_cos_cutoff); free(s->spot_inv_transition); free(s->spot_cutoff); free(s->spot_to_local);
     free(s->env_rgb); free(s->env_cdf_cols); free(s->env_cdf_rows); free(s->env_row_weights);
-    free(s->uv); free(s->tangents); free(s->textures); free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->material_tables); free(s->emitters); free(s);
+    free(s->tex_levels); free(s->tex_texels); free(s->uv); free(s->tangents); free(s->textures); free(s->pos); free(s->nrm); free(s->idx); free(s->shapes); free(s->materials); free(s->material_tables); free(s->emitters); free(s);
 }

@@ -73,7 +73,7 @@ struct RTAccess : RoughTransmittance {   // its slices are protected members
 struct FShape { uint32_t firstTri, triCount, firstVert, vertCount; int32_t bsdf, emitter; uint32_t faceNormals, pad; };
 struct FBsdf { uint32_t type, twosided, distr, sampleVisible; float refl[3], alpha, eta[3], k[3], spec[3]; };
 struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight, cutoff, beam, toWorld[16]; };
-struct FTexture { uint32_t type; float color0[3], color1[3], lineWidth, uoffset, voffset, uscale, vscale; };
+struct FTexture { uint32_t type; float color0[3], color1[3], lineWidth, uoffset, voffset, uscale, vscale; uint32_t wrapU, wrapV, filter; float maxAnisotropy; uint32_t baseW, baseH; std::vector<float> base; };
 struct FInstance { uint32_t group, pad[3]; float toWorld[16], toObject[16]; };
 struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
 struct FScene {
@@ -111,7 +111,14 @@ static FScene loadScene(const char *path) {
     while (fread(tag, 1, 4, f) == 4) {
         uint32_t n; rd(f, &n, 4);
         if (!memcmp(tag, "ANLY", 4)) { s.analytic.resize(n); for (FAnalytic &a : s.analytic) rd(f, &a, sizeof(FAnalytic)); }
-        else if (!memcmp(tag, "TEXR", 4)) { s.textures.resize(n); rd(f, s.textures.data(), n * sizeof(FTexture)); s.bsdfTexture.resize(s.nBsdfs); rd(f, s.bsdfTexture.data(), s.nBsdfs * 4); }
+        else if (!memcmp(tag, "TEXR", 4)) {
+            s.textures.resize(n);
+            for (FTexture &t : s.textures) {
+                rd(f, &t.type, 48); rd(f, &t.wrapU, 24);
+                if (t.type == 2) { rd(f, &t.baseW, 8); t.base.resize((size_t) t.baseW * t.baseH * 3); rd(f, t.base.data(), t.base.size() * 4); }
+            }
+            s.bsdfTexture.resize(s.nBsdfs); rd(f, s.bsdfTexture.data(), s.nBsdfs * 4);
+        }
         else if (!memcmp(tag, "INST", 4)) { s.instances.resize(n); for (FInstance &a : s.instances) rd(f, &a, sizeof(FInstance)); }
         else { fprintf(stderr, "unknown section\n"); _exit(2); }
     }
@@ -245,8 +252,15 @@ static Built buildScene(const FScene &fs) {
         { size_t bi = bsdfs.size();
           if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0) {      // 2-D procedural texture bound to the diffuse reflectance
               const FTexture &ft = fs.textures[fs.bsdfTexture[bi]];
-              Properties tp(ft.type == 0 ? "checkerboard" : "gridtexture");
-              tp.setSpectrum("color0", rgb(ft.color0)); tp.setSpectrum("color1", rgb(ft.color1));
+              Properties tp(ft.type == 0 ? "checkerboard" : ft.type == 1 ? "gridtexture" : "bitmap");
+              ref<Bitmap> bmp;
+              if (ft.type == 2) {          // BitmapTexture from an in-memory bitmap (bitmap.cpp:95-96); it builds its own MIP pyramid (2-lobed Lanczos)
+                  static const char *wraps[] = {"clamp", "repeat", "mirror", "zero", "one"}; static const char *filters[] = {"nearest", "bilinear", "trilinear", "ewa"};
+                  bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(ft.baseW, ft.baseH)); memcpy(bmp->getFloat32Data(), ft.base.data(), ft.base.size() * 4);
+                  tp.setData("bitmap", Properties::Data{(uint8_t *) bmp.get(), sizeof(Bitmap)});
+                  tp.setString("wrapModeU", wraps[ft.wrapU]); tp.setString("wrapModeV", wraps[ft.wrapV]); tp.setString("filterType", filters[ft.filter]);
+                  tp.setFloat("maxAnisotropy", ft.maxAnisotropy);
+              } else { tp.setSpectrum("color0", rgb(ft.color0)); tp.setSpectrum("color1", rgb(ft.color1)); }
               if (ft.type == 1) tp.setFloat("lineWidth", ft.lineWidth);
               tp.setFloat("uoffset", ft.uoffset); tp.setFloat("voffset", ft.voffset); tp.setFloat("uscale", ft.uscale); tp.setFloat("vscale", ft.vscale);
               ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp)); tex->configure();
@@ -399,6 +413,27 @@ static Built buildScene(const FScene &fs) {
     b.scene->configure();      // picks sensor/sampler, integrator->configureSampler (Sobol: setFilmResolution)
     b.scene->initialize();     // kd-tree build + emitter PDF
     return b;
+}
+
+// ------------------------------------------------------------------------------------------ MIP pyramid of a bitmap texture
+// BitmapTexture builds TMIPMap<Color3, Color3h> with a 2-lobed Lanczos filter (src/textures/bitmap.cpp:193-214).  This mode builds the very same
+// pyramid from raw RGB floats and dumps every level (half-precision texels widened to float): texture input data for the build's scenes.
+#include <mitsuba/render/mipmap.h>
+static void modeMipmap(const std::string &in, int w, int h, int bcu, int bcv, const std::string &out) {
+    typedef TSpectrum<Float, 3> Color3; typedef TSpectrum<half, 3> Color3h; typedef TMIPMap<Color3, Color3h> MIPMap3;
+    ref<Bitmap> bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(w, h));
+    FILE *f = fopen(in.c_str(), "rb"); if (!f || fread(bmp->getFloat32Data(), 4, (size_t) w * h * 3, f) != (size_t) w * h * 3) { fprintf(stderr, "cannot read %s\n", in.c_str()); _exit(2); } fclose(f);
+    Properties rp("lanczos"); rp.setInteger("lobes", 2);
+    ref<ReconstructionFilter> rf = static_cast<ReconstructionFilter *>(create(MTS_CLASS(ReconstructionFilter), rp)); rf->configure();
+    ref<MIPMap3> mip = new MIPMap3(bmp, Bitmap::ERGB, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) bcu, (ReconstructionFilter::EBoundaryCondition) bcv, EEWA, 20.0f);
+    std::vector<float> texels; std::vector<int32_t> sizes;
+    for (int l = 0; l < mip->getLevels(); ++l) {
+        ref<Bitmap> lb = mip->toBitmap(l); const half *hp = lb->getFloat16Data(); const size_t n = (size_t) lb->getWidth() * lb->getHeight() * 3;
+        sizes.push_back(lb->getWidth()); sizes.push_back(lb->getHeight());
+        for (size_t i = 0; i < n; ++i) texels.push_back((float) hp[i]);
+    }
+    save(out + "_texels.npy", "<f4", {texels.size()}, texels);
+    save(out + "_sizes.npy", "<i4", {sizes.size() / 2, 2}, sizes);
 }
 
 // ------------------------------------------------------------------------------------------ modes
@@ -702,7 +737,8 @@ int main(int argc, char **argv) {
     Scheduler::staticInitialization();
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
     Thread::getThread()->getFileResolver()->appendPath(fs::pathstr(MI_REF_ROOT));   // data/microfacet/*.dat, data/ior/*.spd (roughplastic, named conductors)
-    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
+    if (argc >= 8 && std::string(argv[1]) == "mipmap") { modeMipmap(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7]); fflush(NULL); _exit(0); }
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
     FScene fs = loadScene(argv[1]);

@@ -17,7 +17,7 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "harness")
 
 
 def run(*args):
-    subprocess.check_call([HARNESS] + [str(a) for a in args], cwd=os.path.join(ROOT, "oracle", "_ref"))
+    subprocess.check_call([HARNESS] + [str(a) for a in args], cwd=os.path.join(ROOT, "oracle", "_ref"), timeout=600)
 
 
 def golden_scenes():
@@ -60,6 +60,8 @@ def golden_scenes():
         "cornell_small_lanczos": scenes.cornell_box(width=96, height=54, spp=4, filter_kind=scenes.FILTER_LANCZOS),
         # meshes with texture coordinates (UV tangents) + procedural textures
         "textured_room": scenes.textured_room(width=96, height=64, spp=16),
+        # bitmap textures: MIP pyramid (input data = the reference's own), EWA / trilinear / bilinear / nearest, wrap modes, ray differentials
+        "bitmap_room": scenes.bitmap_room(width=96, height=64, spp=16),
     }
 
 
@@ -87,7 +89,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)
