@@ -58,7 +58,13 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 /* 2-D procedural textures over Texture2D (src/librender/texture.cpp:81-121: uv * scale + offset): src/textures/checkerboard.cpp, gridtexture.cpp */
 #define MI_TEXTURE_CHECKERBOARD 0
 #define MI_TEXTURE_GRID 1
-typedef struct { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale; } mi_texture;
+#define MI_TEXTURE_BITMAP 2       /* src/textures/bitmap.cpp over TMIPMap (include/mitsuba/render/mipmap.h).  The MIP pyramid is INPUT DATA: levels
+                                     [first_level, first_level + n_levels) of mi_scene_set_texture_data, exactly as the reference builds them (Bitmap::resample
+                                     with a 2-lobed Lanczos filter, texels rounded to half; the adapter obtains them from the reference's own code).
+                                     wrap_u / wrap_v: 0 clamp, 1 repeat, 2 mirror, 3 zero, 4 one (ReconstructionFilter::EBoundaryCondition); filter: 0 nearest,
+                                     1 bilinear, 2 trilinear, 3 ewa (EMIPFilterType); camera hits filter through Intersection::computePartials */
+typedef struct { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale;
+                 uint32_t wrap_u, wrap_v, filter; float max_anisotropy; uint32_t first_level, n_levels; } mi_texture;
 typedef struct {
     uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx */
     float alpha;
@@ -140,6 +146,8 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *shapes, uint32_t n);
 int mi_scene_set_instances(mi_scene *s, const mi_instance *instances, uint32_t n);
 int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
 int mi_scene_set_textures(mi_scene *s, const mi_texture *textures, uint32_t n);
+/* MIP levels of the bitmap textures: levels[n_levels][3] = (width, height, offset of the level's first float in `texels`), RGB floats row-major */
+int mi_scene_set_texture_data(mi_scene *s, const uint32_t *levels, uint32_t n_levels, const float *texels, uint64_t n_texels);
 int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n);   /* float tables the materials refer to by offset (roughplastic) */
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);

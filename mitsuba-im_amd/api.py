@@ -39,7 +39,8 @@ class MiAnalytic(C.Structure):
 
 class MiTexture(C.Structure):
     _fields_ = [("type", C.c_uint32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
-                ("uoffset", C.c_float), ("voffset", C.c_float), ("uscale", C.c_float), ("vscale", C.c_float)]
+                ("uoffset", C.c_float), ("voffset", C.c_float), ("uscale", C.c_float), ("vscale", C.c_float),
+                ("wrap_u", C.c_uint32), ("wrap_v", C.c_uint32), ("filter", C.c_uint32), ("max_anisotropy", C.c_float), ("first_level", C.c_uint32), ("n_levels", C.c_uint32)]
 
 
 class MiInstance(C.Structure):
@@ -62,7 +63,7 @@ class MiStats(C.Structure):
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
-           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays"]
@@ -92,6 +93,7 @@ class Lib:
         L.mi_scene_set_instances.argtypes = [vp, vp, u32]
         L.mi_scene_set_material_tables.argtypes = [vp, vp, u32]
         L.mi_scene_set_textures.argtypes = [vp, vp, u32]
+        L.mi_scene_set_texture_data.argtypes = [vp, vp, u32, vp, u64]
         L.mi_scene_set_materials.argtypes = [vp, vp, u32]
         L.mi_scene_set_emitters.argtypes = [vp, vp, u32]
         L.mi_scene_set_envmap.argtypes = [vp, vp, u32, u32, vp, f32]
@@ -188,8 +190,11 @@ class Scene:
             ta = (MiTexture * len(texs))()
             for i, t in enumerate(texs):
                 r = MiTexture(t["type"]); r.color0[:] = t["color0"]; r.color1[:] = t["color1"]; r.line_width = t["line_width"]
-                r.uoffset, r.voffset, r.uscale, r.vscale = t["uoffset"], t["voffset"], t["uscale"], t["vscale"]; ta[i] = r
+                r.uoffset, r.voffset, r.uscale, r.vscale = t["uoffset"], t["voffset"], t["uscale"], t["vscale"]
+                r.wrap_u, r.wrap_v, r.filter, r.max_anisotropy, r.first_level, r.n_levels = t.get("wrap_u", 1), t.get("wrap_v", 1), t.get("filter", 3), t.get("max_anisotropy", 20.0), t.get("first_level", 0), t.get("n_levels", 0); ta[i] = r
             L.check(L.L.mi_scene_set_textures(h, C.cast(ta, C.c_void_p), len(texs)))
+            if sc.get("texture_levels") is not None:
+                L.check(L.L.mi_scene_set_texture_data(h, _p(sc.texture_levels), len(sc.texture_levels), _p(sc.texture_texels), len(sc.texture_texels)))
         if sc.get("material_tables") is not None:
             L.check(L.L.mi_scene_set_material_tables(h, _p(sc.material_tables), len(sc.material_tables)))
         L.check(L.L.mi_scene_set_emitters(h, C.cast(ems, C.c_void_p), len(sc.emitters)))

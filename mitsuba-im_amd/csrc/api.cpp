@@ -2,6 +2,7 @@
 // Host orchestration only; all arithmetic on the sample path lives in kernels.hip / pt_device.h.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -134,8 +135,17 @@ int mi_scene_set_analytic(mi_scene *s, const mi_analytic *a, uint32_t n) {
 }
 int mi_scene_set_textures(mi_scene *s, const mi_texture *t, uint32_t n) {
     if (!s || (n && !t)) return fail(MI_ERR_INVALID, "mi_scene_set_textures: null argument");
-    for (uint32_t i = 0; i < n; ++i) if (t[i].type > MI_TEXTURE_GRID) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_textures: implemented textures: checkerboard, gridtexture");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (t[i].type > MI_TEXTURE_BITMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_textures: implemented textures: checkerboard, gridtexture, bitmap");
+        if (t[i].type == MI_TEXTURE_BITMAP && (t[i].wrap_u > 4 || t[i].wrap_v > 4 || t[i].filter > 3 || !t[i].n_levels)) return fail(MI_ERR_INVALID, "mi_scene_set_textures: bad wrap mode / filter type / level count");
+    }
     s->h.textures.assign(t, t + n); s->h.committed = false; return MI_OK;
+}
+int mi_scene_set_texture_data(mi_scene *s, const uint32_t *levels, uint32_t nLevels, const float *texels, uint64_t nTexels) {
+    if (!s || !levels || !texels || !nLevels || !nTexels) return fail(MI_ERR_INVALID, "mi_scene_set_texture_data: null argument");
+    for (uint32_t i = 0; i < nLevels; ++i)
+        if (!levels[i * 3] || !levels[i * 3 + 1] || (uint64_t) levels[i * 3 + 2] + (uint64_t) levels[i * 3] * levels[i * 3 + 1] * 3 > nTexels) return fail(MI_ERR_INVALID, "mi_scene_set_texture_data: MIP level outside the texel buffer");
+    s->h.texLevels.assign(levels, levels + (size_t) nLevels * 3); s->h.texTexels.assign(texels, texels + nTexels); s->h.committed = false; return MI_OK;
 }
 int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n) {
     if (!s || (n && !data)) return fail(MI_ERR_INVALID, "mi_scene_set_material_tables: null argument");
@@ -200,7 +210,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -225,6 +235,18 @@ int SceneHost::upload(int dev) {
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
     d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
+    {   // EWA weight table (mipmap.h:297-302; math::fastexp on Linux/x86_64 = (float) exp((double) x)); PerspectiveCameraImpl::m_dx / m_dy (perspective.cpp:159-163)
+        std::vector<float> lut(64); for (int i = 0; i < 64; ++i) { float r2 = (float) i / 63.0f; lut[i] = (float) std::exp((double) (-2.0f * r2)) - (float) std::exp((double) -2.0f); }
+        if (up(&dTexLevels, texLevels) | up(&dTexTexels, texTexels) | up(&dMipLut, lut)) return 1;
+        d.tex_levels = (const uint32_t *) dTexLevels; d.tex_texels = (const float *) dTexTexels; d.mip_lut = (const float *) dMipLut;
+        const float *m = s2c; const float irx = 1.0f / (float) width, iry = 1.0f / (float) height;
+        auto pt = [&](float px, float py, float *o) {
+            float x = m[0] * px + m[1] * py + m[2] * 0.0f + m[3], y = m[4] * px + m[5] * py + m[6] * 0.0f + m[7], z = m[8] * px + m[9] * py + m[10] * 0.0f + m[11], w = m[12] * px + m[13] * py + m[14] * 0.0f + m[15];
+            if (w != 1.0f) { float r = 1.0f / w; x *= r; y *= r; z *= r; }
+            o[0] = x; o[1] = y; o[2] = z; };
+        float p0[3], px[3], py[3]; pt(0.0f, 0.0f, p0); pt(irx, 0.0f, px); pt(0.0f, iry, py);
+        for (int i = 0; i < 3; ++i) { d.cam_dx[i] = px[i] - p0[i]; d.cam_dy[i] = py[i] - p0[i]; }
+    }
     d.material_tables = (const float *) dMaterialTables; d.triuv = (const TriUV *) dTriUV; d.textures = (const TextureD *) dTextures; d.n_textures = (uint32_t) textures.size();
     d.instances = (const InstanceD *) dInstances; d.n_instances = (uint32_t) instancesD.size();
     d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters || anyUV || !textures.empty()) ? 1u : 0u;
@@ -271,6 +293,8 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     }
     for (const mi_material &m : s->h.materials) {
         const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
+        if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
+            (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
         if (tex && (tex > s->h.textures.size() || m.type != MI_BSDF_DIFFUSE)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to the reflectance of `diffuse` BSDFs only (and must exist)");
     }
     for (const mi_analytic &a : s->h.analytic) if (a.bsdf >= 0 && (size_t) a.bsdf < s->h.materials.size() && ((s->h.materials[a.bsdf].flags >> 8) & 0xFFFFu))
@@ -360,7 +384,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
-    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->k = p->fast_math ? &kFast : &kPrecise;
+    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u)); r->k = p->fast_math ? &kFast : &kPrecise;
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
         uint32_t sppBits = 0; while ((1ull << sppBits) < p->spp) ++sppBits;

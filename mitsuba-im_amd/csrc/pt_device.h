@@ -216,6 +216,132 @@ struct Hit {
     v3 p, ng, ns, s, t, wi; float dist; int material, emitter; uint32_t flags; float uvx, uvy;   // uvx, uvy: its.uv (texcoords; set by the EXT paths only)
 };
 // include/mitsuba/render/skdtree.h:343-428 fillIntersectionRecord<true> + src/libcore/util.cpp:605-610
+// ---- bitmap textures: TMIPMap (include/mitsuba/render/mipmap.h): evalTexel :504-560, evalBox :562-566, evalBilinear :572-596, eval :625-705,
+// evalEWA :746-818.  The pyramid is input data (the reference's Bitmap::resample output, half-precision texels widened to float).
+DEV int imod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
+DEV v3 mipTexel(const DScene &sc, const TextureD &t, int level, int x, int y) {
+    const uint32_t *L = sc.tex_levels + (t.first_level + (uint32_t) level) * 3u; const int w = (int) L[0], h = (int) L[1];
+    if (x < 0 || x >= w) {
+        if (t.wrap_u == 1u) x = imod(x, w);
+        else if (t.wrap_u == 0u) x = x < 0 ? 0 : w - 1;
+        else if (t.wrap_u == 2u) { x = imod(x, 2 * w); if (x >= w) x = 2 * w - x - 1; }
+        else return t.wrap_u == 3u ? V(0, 0, 0) : V(1, 1, 1);
+    }
+    if (y < 0 || y >= h) {
+        if (t.wrap_v == 1u) y = imod(y, h);
+        else if (t.wrap_v == 0u) y = y < 0 ? 0 : h - 1;
+        else if (t.wrap_v == 2u) { y = imod(y, 2 * h); if (y >= h) y = 2 * h - y - 1; }
+        else return t.wrap_v == 3u ? V(0, 0, 0) : V(1, 1, 1);
+    }
+    return ld3(sc.tex_texels + L[2] + ((size_t) y * w + x) * 3);
+}
+DEV v3 mipBox(const DScene &sc, const TextureD &t, int level, float u, float v) {
+    const uint32_t *L = sc.tex_levels + (t.first_level + (uint32_t) level) * 3u;
+    return mipTexel(sc, t, level, (int) floorf(u * (float) (int) L[0]), (int) floorf(v * (float) (int) L[1]));
+}
+DEV v3 mipBilinear(const DScene &sc, const TextureD &t, int level, float uvx, float uvy) {
+    if (!isfinite(uvx) || !isfinite(uvy)) return V(0, 0, 0);
+    if (level >= (int) t.n_levels) return mipBox(sc, t, (int) t.n_levels - 1, uvx, uvy);
+    const uint32_t *L = sc.tex_levels + (t.first_level + (uint32_t) level) * 3u;
+    float u = uvx * (float) (int) L[0] - 0.5f, v = uvy * (float) (int) L[1] - 0.5f;
+    int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    float dx1 = u - (float) xPos, dx2 = 1.0f - dx1, dy1 = v - (float) yPos, dy2 = 1.0f - dy1;
+    v3 r = (mipTexel(sc, t, level, xPos, yPos) * dx2) * dy2;
+    r = r + (mipTexel(sc, t, level, xPos, yPos + 1) * dx2) * dy1;
+    r = r + (mipTexel(sc, t, level, xPos + 1, yPos) * dx1) * dy2;
+    r = r + (mipTexel(sc, t, level, xPos + 1, yPos + 1) * dx1) * dy1;
+    return r;
+}
+DEV v3 mipEwa(const DScene &sc, const TextureD &t, int level, float uvx, float uvy, float A, float B, float C) {
+    if (!isfinite(A + B + C + uvx + uvy)) return V(0, 0, 0);
+    if (level >= (int) t.n_levels) return mipBox(sc, t, (int) t.n_levels - 1, uvx, uvy);
+    const uint32_t *L = sc.tex_levels + (t.first_level + (uint32_t) level) * 3u, *L0 = sc.tex_levels + t.first_level * 3u;
+    float u = uvx * (float) (int) L[0] - 0.5f, v = uvy * (float) (int) L[1] - 0.5f;
+    const float rx = (float) (int) L[0] / (float) (int) L0[0], ry = (float) (int) L[1] / (float) (int) L0[1];
+    A /= rx * rx; B /= rx * ry; C /= ry * ry;
+    float invDet = 1.0f / (-B * B + 4.0f * A * C), deltaU = 2.0f * sqrtf(C * invDet), deltaV = 2.0f * sqrtf(A * invDet);
+    int u0 = (int) ceilf(u - deltaU), u1 = (int) floorf(u + deltaU), v0 = (int) ceilf(v - deltaV), v1 = (int) floorf(v + deltaV);
+    float As = A * 64, Bs = B * 64, Cs = C * 64;
+    v3 result = V(0, 0, 0); float denominator = 0.0f, ddq = 2 * As, uu0 = (float) u0 - u;
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vv = (float) vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vv) * vv, dq = As * (2 * uu0 + 1) + Bs * vv;
+        for (int ut = u0; ut <= u1; ++ut) {
+            if (q < 64.0f) {
+                uint32_t qi = (uint32_t) q;
+                if (qi < 64u) { const float weight = sc.mip_lut[(int) q]; result = result + mipTexel(sc, t, level, ut, vt) * weight; denominator += weight; }
+            }
+            q += dq; dq += ddq;
+        }
+    }
+    if (denominator == 0) return mipBilinear(sc, t, level, uvx, uvy);
+    float r = 1.0f / denominator; return result * r;
+}
+DEV float hypot2f(float a, float b) {                          // src/libcore/math.cpp:74-86
+    float r;
+    if (fabsf(a) > fabsf(b)) { r = b / a; r = fabsf(a) * sqrtf(1.0f + r * r); }
+    else if (b != 0.0f) { r = a / b; r = fabsf(b) * sqrtf(1.0f + r * r); }
+    else r = 0.0f;
+    return r;
+}
+DEV float miLog2(float v) { const float invLn2 = 1.4426950408889634f; return (float) log((double) v) * invLn2; }   // math.cpp:103-106 (1 / logf(2))
+DEV v3 mipEval(const DScene &sc, const TextureD &t, float uvx, float uvy, float d0x, float d0y, float d1x, float d1y) {
+    if (t.filter == 0u) return mipBox(sc, t, 0, uvx, uvy);
+    if (t.filter == 1u) return mipBilinear(sc, t, 0, uvx, uvy);
+    const uint32_t *L0 = sc.tex_levels + t.first_level * 3u; const float sx = (float) (int) L0[0], sy = (float) (int) L0[1];
+    float du0 = d0x * sx, dv0 = d0y * sy, du1 = d1x * sx, dv1 = d1y * sy;
+    float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+    float root = hypot2f(A - C, B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root),
+          majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0, minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
+    if (t.filter == 2u || !(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        float level = miLog2(maxf(majorRadius, MI_EPSILON)); int ilevel = (int) floorf(level);
+        if (ilevel < 0) return mipBilinear(sc, t, 0, uvx, uvy);
+        float a = level - (float) ilevel;
+        return mipBilinear(sc, t, ilevel, uvx, uvy) * (1.0f - a) + mipBilinear(sc, t, ilevel + 1, uvx, uvy) * a;
+    }
+    if (minorRadius * t.max_anisotropy < majorRadius) {
+        minorRadius = majorRadius / t.max_anisotropy;
+        float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
+    }
+    float scl = 1.0f / F; A *= scl; B *= scl; C *= scl;
+    float level = maxf(0.0f, miLog2(minorRadius)); int ilevel = (int) level; float a = level - (float) ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0)) return mipBilinear(sc, t, ilevel, uvx, uvy);
+    return mipEwa(sc, t, ilevel, uvx, uvy, A, B, C) * (1.0f - a) + mipEwa(sc, t, ilevel + 1, uvx, uvy, A, B, C) * a;
+}
+// Intersection::computePartials (src/librender/intersection.cpp:5-76) for the hit of a CAMERA ray; rxd / ryd: its differentials (common origin o)
+DEV void computePartials(v3 p, v3 ng, v3 dpdu, v3 dpdv, v3 o, v3 rxd, v3 ryd, float *pa) {
+    pa[0] = pa[1] = pa[2] = pa[3] = 0.0f;
+    if (isZero(dpdu) && isZero(dpdv)) return;
+    const float pp = dot(ng, p), pox = dot(ng, o), poy = dot(ng, o), prx = dot(ng, rxd), pry = dot(ng, ryd);
+    if (prx == 0 || pry == 0) return;
+    const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    float absX = fabsf(ng.x), absY = fabsf(ng.y), absZ = fabsf(ng.z); int a0, a1;
+    if (absX > absY && absX > absZ) { a0 = 1; a1 = 2; } else if (absY > absZ) { a0 = 0; a1 = 2; } else { a0 = 0; a1 = 1; }
+    auto cmp = [](v3 q, int i) { return i == 0 ? q.x : (i == 1 ? q.y : q.z); };
+    float A00 = cmp(dpdu, a0), A01 = cmp(dpdv, a0), A10 = cmp(dpdu, a1), A11 = cmp(dpdv, a1);
+    v3 px = o + rxd * tx, py = o + ryd * ty;
+    float Bx0 = cmp(px, a0) - cmp(p, a0), Bx1 = cmp(px, a1) - cmp(p, a1), By0 = cmp(py, a0) - cmp(p, a0), By1 = cmp(py, a1) - cmp(p, a1);
+    float det = A00 * A11 - A01 * A10;
+    if (fabsf(det) <= 0x1p-128f) { pa[0] = 1; pa[1] = 0; pa[2] = 1; return; }      // solveLinearSystem2x2 fails (util.cpp:529-541); the reference's second fallback assigns dudy twice
+    float inverse = 1.0f / det;
+    pa[0] = (A11 * Bx0 - A01 * Bx1) * inverse; pa[1] = (A00 * Bx1 - A10 * Bx0) * inverse;
+    pa[2] = (A11 * By0 - A01 * By1) * inverse; pa[3] = (A00 * By1 - A10 * By0) * inverse;
+}
+// ray differentials of the sensor ray: perspective.cpp:290-295 + RayDifferential::scaleDifferential(1 / sqrt(spp)) (ray.h:163-168)
+DEV void cameraDifferentials(const DScene &sc, float invSqrtSpp, float sx, float sy, v3 d, v3 &rxd, v3 &ryd) {
+    const float *m = sc.s2c;
+    float px = sx * sc.inv_res_x, py = sy * sc.inv_res_y, pz = 0.0f;
+    float x = m[0] * px + m[1] * py + m[2] * pz + m[3], y = m[4] * px + m[5] * py + m[6] * pz + m[7], z = m[8] * px + m[9] * py + m[10] * pz + m[11], w = m[12] * px + m[13] * py + m[14] * pz + m[15];
+    v3 nearP = V(x, y, z);
+    if (w != 1.0f) { float r = 1.0f / w; nearP = nearP * r; }
+    const float *c = sc.c2w;
+    v3 a = normalize(nearP + ld3(sc.cam_dx)), b = normalize(nearP + ld3(sc.cam_dy));
+    v3 rx = V(c[0] * a.x + c[1] * a.y + c[2] * a.z, c[4] * a.x + c[5] * a.y + c[6] * a.z, c[8] * a.x + c[9] * a.y + c[10] * a.z);
+    v3 ry = V(c[0] * b.x + c[1] * b.y + c[2] * b.z, c[4] * b.x + c[5] * b.y + c[6] * b.z, c[8] * b.x + c[9] * b.y + c[10] * b.z);
+    rxd = d + (rx - d) * invSqrtSpp; ryd = d + (ry - d) * invSqrtSpp;
+}
 // Checkerboard::eval (src/textures/checkerboard.cpp:68-76), GridTexture::eval (src/textures/gridtexture.cpp:63-77) under Texture2D::eval
 // (src/librender/texture.cpp:112-121; these textures do not filter: usesRayDifferentials() = false)
 DEV v3 textureEval(const TextureD &t, float u, float v) {

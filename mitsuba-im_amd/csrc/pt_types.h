@@ -41,7 +41,10 @@ struct TriShade {
 // TriMesh::computeUVTangents (src/librender/trimesh.cpp:683-736), which replace the first edge as dpdu (skdtree.h:373-376)
 struct TriUV { float uv0[2], uv1[2], uv2[2]; float dpdu[3], dpdv[3]; };
 // 2-D procedural texture (src/textures/checkerboard.cpp, gridtexture.cpp over Texture2D), 48 B
-struct TextureD { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale; };
+// type 2 = bitmap (src/textures/bitmap.cpp over TMIPMap, include/mitsuba/render/mipmap.h): MIP levels [first_level, first_level + n_levels) of
+// DScene::tex_levels (w, h, offset into tex_texels), wrap = ReconstructionFilter::EBoundaryCondition, filter = EMIPFilterType; 72 B
+struct TextureD { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale;
+                  uint32_t wrap_u, wrap_v, filter; float max_anisotropy; uint32_t first_level, n_levels; };
 
 struct MaterialD {                        // 64 B; flags bits 8..23: texture index + 1 bound to `reflectance`
     uint32_t type, flags, distr; float alpha;
@@ -92,6 +95,8 @@ struct DScene {
     // scene-level emitters beyond envmap (src/emitters/constant.cpp, point.cpp, spot.cpp, directional.cpp): per emitter 16 floats
     //   [0..2] position (point, spot) / travel direction (directional); spot: [3] cos(cutoff), [4..12] world->local 3x3, [13] cos(beam), [14] cutoff, [15] 1/(cutoff-beam)
     const TriUV *triuv; const TextureD *textures; uint32_t n_textures, tex_pad;
+    const uint32_t *tex_levels; const float *tex_texels; const float *mip_lut;   // MIP pyramids (input data); EWA weight table (mipmap.h:297-302)
+    float cam_dx[3], cam_dy[3];           // PerspectiveCameraImpl::m_dx / m_dy (perspective.cpp:159-163)
     const float *material_tables;                    // float tables referenced by materials (roughplastic: k[1] = offset, k[2] = length)
     const float *emitter_x; uint32_t env_constant;   // env_constant: the environment emitter (env_index) is `constant`; radiance in its EmitterD
     float dir_bs_center[3], dir_bs_radius;           // DirectionalEmitter::createShape: kd-tree box bounding sphere x 1.1
@@ -126,5 +131,6 @@ struct RenderConst {
     uint32_t sampler; uint32_t seed_mix;  // independent: seed * 0x9E3779B9
     // Sobol' direction matrices folded into 4-bit lookup tables: nib[dim][n][v] = XOR of matrices32[dim*52 + 4n + b] over the bits b of v
     const uint32_t *sobol_nib; uint32_t nib_count, nib_dims;
+    float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)
     uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
 };

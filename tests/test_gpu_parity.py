@@ -450,3 +450,25 @@ def test_texture_coordinates_and_procedural_textures(mi, oracle, golden_scenes):
     assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 5e-4
+
+
+def test_bitmap_textures(mi, oracle, golden_scenes):
+    """`bitmap` textures: MIP pyramid as input data, EWA (anisotropic footprints on the floor, clamped anisotropy), trilinear, bilinear and
+    nearest lookups, repeat / mirror / clamp / zero / one wrapping; the camera hit filters with Intersection::computePartials, later bounces read
+    level 0.  log / atan / sin / cos of the level selection come from the device math library -> tolerance-pinned."""
+    name = "bitmap_room"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(48); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-4).mean() > 0.998 and np.median(err) < 1e-6 and (bits(got) == bits(ref)).all(1).mean() > 0.6
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 2e-4).mean() > 0.998 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 5e-4
+    assert (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 5e-4
+    with pytest.raises(mi.MiError, match="MIP levels"):
+        bad = mi.scenes.bitmap_room(32, 32, 1); bad.texture_levels = None; mi.Scene(bad)
