@@ -25,6 +25,7 @@
 #include <mitsuba/core/mstream.h>
 #include <mitsuba/core/serialization.h>
 #include <instance.h>     // src/shapes/instance.h (pulls in shapegroup.h, which has no include guard): inline accessors only (getShapeGroup, getWorldTransform, getKDTree)
+#include <mitsuba/render/mipmap.h>
 #include <rtrans.h>       // src/bsdfs/rtrans.h: RoughTransmittance, as RoughPlastic::configure uses it
 #include <ior.h>   // src/bsdfs/ior.h: lookupIOR, as used by RoughConductor's constructor
 #include "../integrator_host.h"
@@ -34,7 +35,7 @@ MTS_NAMESPACE_BEGIN
 namespace {
 
 struct FlatScene {
-    std::vector<float> uv; bool anyUV = false; std::vector<mi_texture> textures;
+    std::vector<float> uv; bool anyUV = false; std::vector<mi_texture> textures; std::vector<uint32_t> texLevels; std::vector<float> texTexels;
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
     std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances; std::vector<float> materialTables;
     bool anyNormals = false;
@@ -112,7 +113,7 @@ static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
 
 /// A spatially varying `diffuse` (optionally inside `twosided`): its reflectance texture is private as well, so it is read from the serialised form
 /// (SmoothDiffuse::serialize, diffuse.cpp:163-167; Texture2D::serialize, src/librender/texture.cpp:106-110; Checkerboard / GridTexture::serialize)
-static std::vector<mi_texture> *g_textures = NULL;
+static std::vector<mi_texture> *g_textures = NULL; static std::vector<uint32_t> *g_texLevels = NULL; static std::vector<float> *g_texTexels = NULL;
 static bool convertTexturedDiffuse(const BSDF *bsdf, mi_material &m) {
     NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
     mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
@@ -121,10 +122,33 @@ static bool convertTexturedDiffuse(const BSDF *bsdf, mi_material &m) {
     if (cls == "TwoSidedBRDF") { m.flags |= MI_BSDF_FLAG_TWOSIDED; rd.ms->readUInt(); cls = rd.ms->readString(); rd.ms->readBool(); }
     if (cls != "SmoothDiffuse") return false;
     rd.ms->readUInt(); std::string tcls = rd.ms->readString();
-    if (tcls != "Checkerboard" && tcls != "GridTexture") SLog(EError, "path_hip: texture \"%s\" is not implemented (checkerboard, gridtexture)", tcls.c_str());
-    mi_texture t; memset(&t, 0, sizeof(t)); t.type = tcls == "GridTexture" ? MI_TEXTURE_GRID : MI_TEXTURE_CHECKERBOARD;
+    if (tcls != "Checkerboard" && tcls != "GridTexture" && tcls != "BitmapTexture") SLog(EError, "path_hip: texture \"%s\" is not implemented (checkerboard, gridtexture, bitmap)", tcls.c_str());
+    mi_texture t; memset(&t, 0, sizeof(t)); t.type = tcls == "GridTexture" ? MI_TEXTURE_GRID : tcls == "BitmapTexture" ? MI_TEXTURE_BITMAP : MI_TEXTURE_CHECKERBOARD;
     t.uoffset = rd.ms->readFloat(); t.voffset = rd.ms->readFloat(); t.uscale = rd.ms->readFloat(); t.vscale = rd.ms->readFloat();
-    rd.rgb(t.color0); rd.rgb(t.color1); if (t.type == MI_TEXTURE_GRID) t.line_width = rd.ms->readFloat();
+    if (t.type == MI_TEXTURE_BITMAP) {
+        // BitmapTexture::serialize (src/textures/bitmap.cpp:404-432): parameters + the image file's bytes; the MIP pyramid is rebuilt with the reference's
+        // own code exactly as BitmapTexture's constructors do (2-lobed Lanczos, TMIPMap<Color3, Color3h>; :193-214, :363-401)
+        rd.ms->readString(); t.filter = rd.ms->readUInt(); t.wrap_u = rd.ms->readUInt(); t.wrap_v = rd.ms->readUInt();
+        Float gamma = rd.ms->readFloat(); t.max_anisotropy = rd.ms->readFloat(); std::string channel = rd.ms->readString();
+        if (!channel.empty()) SLog(EError, "path_hip: bitmap textures restricted to one channel are not implemented");
+        size_t size = rd.ms->readSize(); ref<MemoryStream> img = new MemoryStream(size); rd.ms->copyTo(img, size); img->seek(0);
+        ref<Bitmap> bitmap = new Bitmap(Bitmap::EAuto, img); if (gamma != 0) bitmap->setGamma(gamma);
+        Properties rp("lanczos"); rp.setInteger("lobes", 2);
+        ref<ReconstructionFilter> rf = static_cast<ReconstructionFilter *>(PluginManager::getInstance()->createObject(MTS_CLASS(ReconstructionFilter), rp)); rf->configure();
+        typedef TSpectrum<Float, 3> Color3; typedef TSpectrum<half, 3> Color3h; typedef TSpectrum<Float, 1> Color1; typedef TSpectrum<half, 1> Color1h;
+        const bool lum = bitmap->getPixelFormat() == Bitmap::ELuminance || bitmap->getPixelFormat() == Bitmap::ELuminanceAlpha;
+        if (!lum && bitmap->getPixelFormat() != Bitmap::ERGB && bitmap->getPixelFormat() != Bitmap::ERGBA) SLog(EError, "path_hip: The input image has an unsupported pixel format!");
+        t.first_level = (uint32_t) (g_texLevels->size() / 3);
+        auto pushLevel = [&](const Bitmap *lb, int ch) {
+            g_texLevels->push_back((uint32_t) lb->getWidth()); g_texLevels->push_back((uint32_t) lb->getHeight()); g_texLevels->push_back((uint32_t) g_texTexels->size());
+            const half *hp = lb->getFloat16Data(); const size_t n = (size_t) lb->getWidth() * lb->getHeight();
+            for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) g_texTexels->push_back((float) hp[i * ch + (ch == 3 ? c : 0)]);
+        };
+        if (lum) { ref<TMIPMap<Color1, Color1h> > mip = new TMIPMap<Color1, Color1h>(bitmap, Bitmap::ELuminance, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) t.wrap_u, (ReconstructionFilter::EBoundaryCondition) t.wrap_v, (EMIPFilterType) t.filter, t.max_anisotropy);
+                   t.n_levels = (uint32_t) mip->getLevels(); for (int l = 0; l < mip->getLevels(); ++l) pushLevel(mip->toBitmap(l), 1); }
+        else { ref<TMIPMap<Color3, Color3h> > mip = new TMIPMap<Color3, Color3h>(bitmap, Bitmap::ERGB, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) t.wrap_u, (ReconstructionFilter::EBoundaryCondition) t.wrap_v, (EMIPFilterType) t.filter, t.max_anisotropy);
+               t.n_levels = (uint32_t) mip->getLevels(); for (int l = 0; l < mip->getLevels(); ++l) pushLevel(mip->toBitmap(l), 3); }
+    } else { rd.rgb(t.color0); rd.rgb(t.color1); if (t.type == MI_TEXTURE_GRID) t.line_width = rd.ms->readFloat(); }
     m.flags |= MI_BSDF_TEXTURE(g_textures->size()); m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;
     g_textures->push_back(t);
     return true;
@@ -271,7 +295,7 @@ static bool convertAnalytic(const Shape *shape, mi_analytic &a) {
 }
 
 static void flatten(const Scene *scene, FlatScene &fs) {
-    g_tables = &fs.materialTables; g_textures = &fs.textures;
+    g_tables = &fs.materialTables; g_textures = &fs.textures; g_texLevels = &fs.texLevels; g_texTexels = &fs.texTexels;
     const std::vector<TriMesh *> &meshes = scene->getMeshes();
     std::map<const BSDF *, int> bsdfIndex; std::vector<const Instance *> insts;
     // non-mesh shapes: rectangle / disk / sphere / cylinder become analytic records (numbered after the meshes); anything else is refused
@@ -394,6 +418,7 @@ struct GpuScene {
         if (!fs.instances.empty()) MI_CHECK(mi_scene_set_instances(scene, fs.instances.data(), (uint32_t) fs.instances.size()));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
         if (!fs.textures.empty()) MI_CHECK(mi_scene_set_textures(scene, fs.textures.data(), (uint32_t) fs.textures.size()));
+        if (!fs.texLevels.empty()) MI_CHECK(mi_scene_set_texture_data(scene, fs.texLevels.data(), (uint32_t) (fs.texLevels.size() / 3), fs.texTexels.data(), fs.texTexels.size()));
         if (!fs.materialTables.empty()) MI_CHECK(mi_scene_set_material_tables(scene, fs.materialTables.data(), (uint32_t) fs.materialTables.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
         if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));
