@@ -266,7 +266,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC, bool ENV, bool SMALL, bool AN>   // RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
+template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
                 bsdf = loadMaterial(tb, h.material);
-                if (AN) {                                                    // textured diffuse reflectance: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121)
+                if (TEX) {                                                   // textured diffuse reflectance: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121)
                     const uint32_t tex = (bsdf.flags >> 8) & 0xFFFFu;
                     if (tex) {
                         const TextureD &tx = sc.textures[tex - 1]; v3 c;
@@ -630,8 +630,9 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
     RenderConst rcl = rc; rcl.order_offset_words = 0;
     if (sc.has_roughconductor && q.cap <= 8192u) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 * (WG / 64) + 16; }
-#define MI_SHADE(RC, ENV, SM) do { if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
-                                   else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); } while (0)
+#define MI_SHADE(RC, ENV, SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
+                                   else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
+                                   else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); } while (0)
     if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
     else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }
 #undef MI_SHADE

@@ -472,3 +472,26 @@ def test_bitmap_textures(mi, oracle, golden_scenes):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 5e-4
     with pytest.raises(mi.MiError, match="MIP levels"):
         bad = mi.scenes.bitmap_room(32, 32, 1); bad.texture_levels = None; mi.Scene(bad)
+
+
+@pytest.mark.parametrize("config", ["C3_veach_1080p", "C4_atrium_4k"])
+def test_full_size_other_configs(mi, config):
+    """BASELINE configs 3 and 4 at their full film sizes (fewer sample planes than quoted, the planes are independent): properties that need no
+    CPU oracle -- finite non-negative film, weight channel = spp, additivity over sample ranges and interleaved rows, ray counters in range."""
+    S = mi.scenes
+    if config == "C3_veach_1080p":
+        sc = S.veach_mis(1920, 1080, 512, max_depth=12); spp = 8; lo, hi = 2.0, 4.5
+    else:
+        sc = S.atrium(3840, 2160, 64); spp = 4; lo, hi = 3.0, 7.0
+    gs = mi.Scene(sc); r = mi.Render(gs)
+    r.run(s0=0, s1=spp); full = r.read_film(0); st = r.stats(); n = sc.width * sc.height * spp
+    assert st["samples"] == n and lo < st["rays"] / n < hi
+    assert np.isfinite(full).all() and (full >= 0).all()
+    w = full[1:-1, 1:-1, 4]; w0 = np.median(w); assert abs(w0 / spp - 1) < 1e-3 and np.isclose(w, w0, rtol=1e-3).mean() > 0.98
+    r.clear(); r.run(s0=0, s1=spp // 2); r.run(s0=spp // 2, s1=spp); parts = r.read_film(0)
+    assert np.allclose(parts, full, rtol=1e-5, atol=1e-6)
+    r.clear()
+    for k in range(2):
+        r.run(tile=(0, k, sc.width, sc.height), s0=0, s1=spp, row_stride=2)
+    inter = r.read_film(0)
+    assert np.allclose(inter, full, rtol=1e-5, atol=1e-6)
