@@ -1,0 +1,524 @@
+"""Triangle-mesh readers for the scene front end: Wavefront OBJ, Stanford PLY, Mitsuba `.serialized`, and the
+unit cube -- what the reference's shape plugins hand to its kd-tree, here handed to the HIP scene builder.
+
+Every loader returns a list of `Mesh` (positions / normals / uv as float32, triangles as uint32) already in world space, and
+`configure_mesh()` applies what TriMesh::configure() does afterwards (face normals, normal flipping, generated vertex normals).
+
+Reference behaviour followed (file:line, reference = /root/reference):
+  * OBJ: src/shapes/obj.cpp:192-365 (statement parser, `g` / `usemtl` splitting, n-gon fans, negative indices, flipTexCoords),
+    :610-717 (vertex merge on exact (p, n, uv) equality in first-use order)
+  * PLY: src/shapes/ply.cpp:182-303 (recognised vertex properties, triangle / quad faces; quads split as (0,1,2) (3,0,2))
+  * serialized: src/librender/trimesh.cpp:176-253 (v3 / v4 zlib streams, flags), :273-330 (offset dictionary at the end of
+    the file), :1131-1175 (writer); src/shapes/serialized.cpp:153-203 (toWorld, winding swap on negative determinant)
+  * generated normals: src/librender/trimesh.cpp:608-683 (angle-weighted, Thuermer & Wuethrich)
+  * cube: src/shapes/cube.cpp:74-103 (fixed 24-vertex mesh; the table is data, mitsuba-im_amd/data/cube_mesh.npz)
+Checked against the compiled reference plugins by tests/test_oracle_golden.py (fixtures: tests/golden/mesh_*.npz).  The reference's
+PLY plugin cannot be built here (its parser needs boost::mpl): the PLY reader is pinned through the same mesh written as OBJ.
+"""
+import os
+import struct
+import zlib
+
+import numpy as np
+
+F = np.float32
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+FLAG_NORMALS, FLAG_TEXCOORDS, FLAG_COLORS, FLAG_FACE_NORMALS, FLAG_SINGLE, FLAG_DOUBLE = 0x0001, 0x0002, 0x0008, 0x0010, 0x1000, 0x2000
+FILEFORMAT_HEADER, VERSION_V3, VERSION_V4 = 0x041C, 0x0003, 0x0004
+
+
+class MeshError(ValueError):
+    pass
+
+
+class Mesh:
+    def __init__(self, name, positions, triangles, normals=None, uv=None, material="", face_normals=False):
+        self.name = name
+        self.positions = np.ascontiguousarray(positions, F).reshape(-1, 3)
+        self.triangles = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, F).reshape(-1, 3)
+        self.uv = None if uv is None else np.ascontiguousarray(uv, F).reshape(-1, 2)
+        self.material = material
+        self.face_normals = face_normals
+        if self.triangles.size and int(self.triangles.max()) >= len(self.positions):
+            raise MeshError(f"mesh '{name}': triangle index out of range")
+
+    def __repr__(self):
+        return f"Mesh({self.name!r}, {len(self.positions)} vertices, {len(self.triangles)} triangles, normals={self.normals is not None}, uv={self.uv is not None})"
+
+
+# ---- Transform::operator()(Point / Normal), include/mitsuba/core/transform.h:108-125, :203-211 -----------------------------------
+def _inverse(m):
+    return np.linalg.inv(np.asarray(m, np.float64)).astype(F)
+
+
+def transform_points(m, p):
+    m = np.asarray(m, F); p = np.asarray(p, F).reshape(-1, 3)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    rows = [((m[r, 0] * x + m[r, 1] * y) + m[r, 2] * z) + m[r, 3] for r in range(4)]
+    out = np.stack(rows[:3], axis=1)
+    w = rows[3]
+    if np.any(w != 1):
+        out = np.where((w != 1)[:, None], out / w[:, None], out)
+    return out.astype(F)
+
+
+def transform_normals(m_inv, n):
+    mi = np.asarray(m_inv, F); n = np.asarray(n, F).reshape(-1, 3)
+    x, y, z = n[:, 0], n[:, 1], n[:, 2]
+    return np.stack([(mi[0, c] * x + mi[1, c] * y) + mi[2, c] * z for c in range(3)], axis=1).astype(F)
+
+
+def _normalize_rows(v, keep_zero=False):
+    l = np.sqrt((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]).astype(F)
+    safe = np.where(l == 0, F(1), l)
+    out = (v / safe[:, None]).astype(F)
+    return np.where((l == 0)[:, None], v, out) if keep_zero else out
+
+
+def _is_identity(m):
+    return m is None or np.array_equal(np.asarray(m, F), np.eye(4, dtype=F))
+
+
+# ---- TriMesh::computeNormals ---------------------------------------------------------------------------------------------------
+def _unit_angle(u, v):
+    """include/mitsuba/core/util.h:321 -- numerically robust angle between unit vectors."""
+    d = (u[:, 0] * v[:, 0] + u[:, 1] * v[:, 1]) + u[:, 2] * v[:, 2]
+    s = v + u; t = v - u
+    ls = np.sqrt((s[:, 0] * s[:, 0] + s[:, 1] * s[:, 1]) + s[:, 2] * s[:, 2]).astype(F)
+    lt = np.sqrt((t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1]) + t[:, 2] * t[:, 2]).astype(F)
+    with np.errstate(invalid="ignore"):
+        a = np.where(d < 0, F(np.pi) - F(2) * np.arcsin(np.minimum(F(0.5) * ls, F(1))), F(2) * np.arcsin(np.minimum(F(0.5) * lt, F(1))))
+    return a.astype(F)
+
+
+def generate_vertex_normals(positions, triangles, flip=False):
+    """Angle-weighted vertex normals (trimesh.cpp:631-676).  Contributions are accumulated in triangle order like the reference's loop."""
+    p = np.asarray(positions, F); t = np.asarray(triangles, np.int64)
+    v0, v1, v2 = p[t[:, 0]], p[t[:, 1]], p[t[:, 2]]
+    n = np.cross(v1 - v0, v2 - v0).astype(F)
+    ln = np.sqrt((n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1]) + n[:, 2] * n[:, 2]).astype(F)
+    ok = ln != 0
+    n = np.where(ok[:, None], n / np.where(ok, ln, F(1))[:, None], F(0)).astype(F)
+    contrib = np.zeros((len(t), 3, 3), F)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for i in range(3):
+            a = p[t[:, i]]; b = p[t[:, (i + 1) % 3]]; c = p[t[:, (i + 2) % 3]]
+            sa, sb = (b - a).astype(F), (c - a).astype(F)
+            ang = _unit_angle(_normalize_rows(sa), _normalize_rows(sb))
+            contrib[:, i, :] = np.where(ok[:, None], n * ang[:, None], F(0))
+    out = np.zeros((len(p), 3), F)
+    np.add.at(out, t.reshape(-1), contrib.reshape(-1, 3))
+    l = np.sqrt((out[:, 0] * out[:, 0] + out[:, 1] * out[:, 1]) + out[:, 2] * out[:, 2]).astype(F)
+    if flip:
+        l = -l
+    bad = l == 0
+    out = np.where(bad[:, None], np.array([1, 0, 0], F), out / np.where(bad, F(1), l)[:, None]).astype(F)
+    return out
+
+
+def configure_mesh(mesh, face_normals=False, flip_normals=False):
+    """TriMesh::configure() -> computeNormals() (trimesh.cpp:608-683)."""
+    if face_normals:
+        mesh.normals = None
+        mesh.face_normals = True
+        if flip_normals:
+            mesh.triangles = np.ascontiguousarray(mesh.triangles[:, [1, 0, 2]])
+    elif mesh.normals is not None:
+        if flip_normals:
+            mesh.normals = (-mesh.normals).astype(F)
+    else:
+        mesh.normals = generate_vertex_normals(mesh.positions, mesh.triangles, flip_normals)
+    return mesh
+
+
+# ---- Wavefront OBJ ---------------------------------------------------------------------------------------------------------------
+def _obj_lines(path):
+    with open(path, "r", errors="replace") as f:
+        pending = None
+        for raw in f:
+            line = raw.rstrip("\r\n\t ")
+            if pending is not None:
+                line = pending + line; pending = None
+            if line.endswith("\\"):
+                pending = line[:-1]; continue
+            yield line
+        if pending is not None:
+            yield pending
+
+
+def _atoi(s):
+    """C atoi: optional sign + leading digits, 0 when there are none."""
+    i = 0; n = len(s)
+    while i < n and s[i] in " \t":
+        i += 1
+    j = i
+    if j < n and s[j] in "+-":
+        j += 1
+    k = j
+    while k < n and s[k].isdigit():
+        k += 1
+    return int(s[i:k]) if k > j else 0
+
+
+def _parse_corner(tok):
+    parts = [t for t in tok.split("/") if t != ""]          # tokenize(str, "/") drops empty tokens
+    if len(parts) == 1:
+        return _atoi(parts[0]), 0, 0
+    if len(parts) == 2:
+        if "//" in tok:
+            return _atoi(parts[0]), 0, _atoi(parts[1])
+        return _atoi(parts[0]), _atoi(parts[1]), 0
+    if len(parts) == 3:
+        return _atoi(parts[0]), _atoi(parts[1]), _atoi(parts[2])
+    raise MeshError("Invalid OBJ face format!")
+
+
+def _obj_create_mesh(name, material, vertices, normals, texcoords, corners, to_world, to_world_inv):
+    c = np.asarray(corners, np.int64).reshape(-1, 3)         # per corner: position, uv, normal ids (1-based, 0 = absent, < 0 relative)
+    if len(c) == 0:
+        return None
+    pid, uid, nid = c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy()
+    pid[pid < 0] += len(vertices) + 1; uid[uid < 0] += len(texcoords) + 1; nid[nid < 0] += len(normals) + 1
+    if np.any(pid > len(vertices)) or np.any(pid <= 0):
+        bad = int(pid[(pid > len(vertices)) | (pid <= 0)][0])
+        raise MeshError(f"Out of bounds: tried to access vertex {bad} (max: {len(vertices)})")
+    if np.any(nid > len(normals)) or np.any(nid < 0):
+        raise MeshError(f"Out of bounds: tried to access normal {int(nid[(nid > len(normals)) | (nid < 0)][0])} (max: {len(normals)})")
+    if np.any(uid > len(texcoords)) or np.any(uid < 0):
+        raise MeshError(f"Out of bounds: tried to access uv {int(uid[(uid > len(texcoords)) | (uid < 0)][0])} (max: {len(texcoords)})")
+    V = np.asarray(vertices, F).reshape(-1, 3)
+    P = transform_points(to_world, V) if to_world is not None else V
+    has_n, has_uv = bool(np.any(nid != 0)), bool(np.any(uid != 0))
+    key = np.zeros((len(c), 8), F)
+    key[:, 0:3] = P[pid - 1]
+    if has_n:
+        N = np.asarray(normals, F).reshape(-1, 3)
+        N = transform_normals(to_world_inv, N) if to_world is not None else N
+        N = _normalize_rows(N, keep_zero=True)
+        key[:, 3:6] = np.where((nid != 0)[:, None], N[np.maximum(nid, 1) - 1], F(0))
+    if has_uv:
+        T = np.asarray(texcoords, F).reshape(-1, 2)
+        key[:, 6:8] = np.where((uid != 0)[:, None], T[np.maximum(uid, 1) - 1], F(0))
+    canon = key + F(0)                                       # -0 -> +0: the reference's map compares values, not bits
+    _, first, inverse = np.unique(np.ascontiguousarray(canon).view(np.dtype((np.void, 32))).ravel(), return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")                 # vertices are numbered in order of first use
+    rank = np.empty(len(order), np.int64); rank[order] = np.arange(len(order))
+    idx = rank[inverse.ravel()].astype(np.uint32).reshape(-1, 3)
+    verts = key[first[order]]
+    return Mesh(name, verts[:, 0:3], idx, verts[:, 3:6] if has_n else None, verts[:, 6:8] if has_uv else None, material=material)
+
+
+def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_tex_coords=True, collapse=False, shape_index=-1):
+    """All meshes of a Wavefront OBJ file (one per `g` / `usemtl` run unless `collapse`), configured."""
+    if not os.path.exists(path):
+        raise MeshError(f"Wavefront OBJ file '{path}' not found!")
+    base = os.path.splitext(os.path.basename(path))[0]
+    tw = None if _is_identity(to_world) else np.asarray(to_world, F)
+    twi = None if tw is None else _inverse(tw)
+    vertices, normals, texcoords, corners = [], [], [], []
+    meshes, geom_names, state = [], set(), {"geom_index": 0}
+    name, material, name_before_geometry = base, "", False
+
+    def flush(target):
+        if target in geom_names:
+            target = f"{target}_{state['geom_index']}"
+        state["geom_index"] += 1
+        geom_names.add(target)
+        if shape_index < 0 or state["geom_index"] - 1 == shape_index:
+            m = _obj_create_mesh(target, material, vertices, normals, texcoords, corners, tw, twi)
+            if m is not None:
+                meshes.append(m)
+        corners.clear()
+
+    def fl(tok):
+        try:
+            return float(tok)
+        except ValueError:
+            return 0.0
+
+    for line in _obj_lines(path):
+        parts = line.split()
+        if not parts:
+            continue
+        cmd = parts[0]
+        if cmd == "v":
+            vertices.append([fl(t) for t in (parts[1:4] + ["0"] * 3)[:3]])
+        elif cmd == "vn":
+            normals.append([fl(t) for t in (parts[1:4] + ["0"] * 3)[:3]])
+        elif cmd == "vt":
+            u = fl(parts[1]) if len(parts) > 1 else 0.0
+            v = fl(parts[2]) if len(parts) > 2 else 0.0
+            texcoords.append([u, float(F(1) - F(v)) if flip_tex_coords else v])
+        elif cmd == "g" and not collapse:
+            new_name = line[1:].strip()
+            target = name if name_before_geometry else new_name
+            if corners:
+                flush(target)
+            else:
+                name_before_geometry = True
+            name = new_name
+        elif cmd == "usemtl":
+            if corners and not collapse:
+                flush(name)
+                name = base
+            material = line[6:].strip()
+        elif cmd == "f":
+            toks = parts[1:]
+            if len(toks) < 3:
+                toks = toks + [""] * (3 - len(toks))
+            c0, c1, c2 = _parse_corner(toks[0]) if toks[0] else (0, 0, 0), _parse_corner(toks[1]) if toks[1] else (0, 0, 0), _parse_corner(toks[2]) if toks[2] else (0, 0, 0)
+            corners.extend([c0, c1, c2])
+            for tok in toks[3:]:                              # n-gons: a fan, assuming a convex polygon
+                c1 = c2; c2 = _parse_corner(tok)
+                corners.extend([c0, c1, c2])
+    if name in geom_names:
+        name = f"{base}_{state['geom_index']}"
+    if shape_index < 0 or state["geom_index"] - 1 == shape_index:
+        m = _obj_create_mesh(name, material, vertices, normals, texcoords, corners, tw, twi)
+        if m is not None:
+            meshes.append(m)
+    return [configure_mesh(m, face_normals, flip_normals) for m in meshes]
+
+
+# ---- Stanford PLY ----------------------------------------------------------------------------------------------------------------
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def load_ply(path, to_world=None, face_normals=False, flip_normals=False):
+    if not os.path.exists(path):
+        raise MeshError(f"PLY file \"{path}\" could not be found!")
+    with open(path, "rb") as f:
+        data = f.read()
+    end = data.find(b"end_header")
+    if not data.startswith(b"ply") or end < 0:
+        raise MeshError(f"\"{path}\" is not a PLY file")
+    header_end = data.index(b"\n", end) + 1
+    fmt, elements = None, []
+    for line in data[:header_end].decode("ascii", "replace").splitlines():
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "element":
+            elements.append({"name": t[1], "count": int(t[2]), "props": []})
+        elif t[0] == "property":
+            if t[1] == "list":
+                elements[-1]["props"].append((t[4], "list", _PLY_TYPES[t[2]], _PLY_TYPES[t[3]]))
+            else:
+                elements[-1]["props"].append((t[2], _PLY_TYPES[t[1]]))
+    if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+        raise MeshError(f"\"{path}\": unsupported PLY format {fmt}")
+    order = "<" if fmt != "binary_big_endian" else ">"
+    body = data[header_end:]
+    pos = 0
+    tokens = body.split() if fmt == "ascii" else None
+    vert, faces = None, []
+    for el in elements:
+        scalar_only = all(p[1] != "list" for p in el["props"])
+        if fmt == "ascii":
+            if scalar_only:
+                n = el["count"] * len(el["props"])
+                arr = np.array(tokens[pos:pos + n], dtype=np.float64).reshape(el["count"], len(el["props"])); pos += n
+                rec = {p[0]: arr[:, i] for i, p in enumerate(el["props"])}
+            else:
+                rec = None
+                for _ in range(el["count"]):
+                    for p in el["props"]:
+                        if p[1] == "list":
+                            k = int(tokens[pos]); pos += 1
+                            vals = [int(float(x)) for x in tokens[pos:pos + k]]; pos += k
+                            if el["name"] == "face" and p[0] in ("vertex_indices", "vertex_index"):
+                                faces.append(vals)
+                        else:
+                            pos += 1
+        else:
+            if scalar_only:
+                dt = np.dtype([(p[0], order + p[1]) for p in el["props"]])
+                arr = np.frombuffer(body, dt, el["count"], pos); pos += dt.itemsize * el["count"]
+                rec = {p[0]: arr[p[0]] for p in el["props"]}
+            else:
+                rec = None
+                # fast path: a single list property whose count is the same for every row
+                if len(el["props"]) == 1 and el["count"] > 0:
+                    p = el["props"][0]
+                    k = int(np.frombuffer(body, order + p[2], 1, pos)[0])
+                    dt = np.dtype([("n", order + p[2]), ("v", order + p[3], (k,))])
+                    if pos + dt.itemsize * el["count"] <= len(body):
+                        arr = np.frombuffer(body, dt, el["count"], pos)
+                        if np.all(arr["n"] == k):
+                            pos += dt.itemsize * el["count"]
+                            if el["name"] == "face" and p[0] in ("vertex_indices", "vertex_index"):
+                                faces = arr["v"].astype(np.int64)
+                            continue
+                for _ in range(el["count"]):
+                    for p in el["props"]:
+                        if p[1] == "list":
+                            k = int(np.frombuffer(body, order + p[2], 1, pos)[0]); pos += np.dtype(p[2]).itemsize
+                            vals = np.frombuffer(body, order + p[3], k, pos).astype(np.int64); pos += np.dtype(p[3]).itemsize * k
+                            if el["name"] == "face" and p[0] in ("vertex_indices", "vertex_index"):
+                                faces.append(vals.tolist())
+                        else:
+                            pos += np.dtype(p[1]).itemsize
+        if el["name"] == "vertex" and rec is not None:
+            vert = rec
+    if vert is None or not all(k in vert for k in "xyz"):
+        raise MeshError(f"Unable to load \"{path}\" (no triangles or vertices found)!")
+    P = np.stack([vert["x"], vert["y"], vert["z"]], axis=1).astype(F)
+    N = np.stack([vert["nx"], vert["ny"], vert["nz"]], axis=1).astype(F) if "nx" in vert else None
+    uk = next((k for k in ("u", "texture_u", "s") if k in vert), None); vk = next((k for k in ("v", "texture_v", "t") if k in vert), None)
+    UV = np.stack([vert[uk], vert[vk]], axis=1).astype(F) if uk and vk else None
+    tris = []
+    if isinstance(faces, np.ndarray):
+        if faces.shape[1] == 3:
+            tris = faces
+        elif faces.shape[1] == 4:
+            tris = np.stack([faces[:, [0, 1, 2]], faces[:, [3, 0, 2]]], axis=1).reshape(-1, 3)
+        else:
+            raise MeshError("Only triangle and quad-based PLY meshes are supported for now.")
+    else:
+        for fc in faces:
+            if len(fc) == 3:
+                tris.append(fc)
+            elif len(fc) == 4:
+                tris.append([fc[0], fc[1], fc[2]]); tris.append([fc[3], fc[0], fc[2]])
+            else:
+                raise MeshError(f"Encountered a face with {len(fc)} vertices! Only triangle and quad-based PLY meshes are supported for now.")
+    tris = np.asarray(tris, np.int64).reshape(-1, 3)
+    if len(tris) == 0 or len(P) == 0:
+        raise MeshError(f"Unable to load \"{path}\" (no triangles or vertices found)!")
+    if tris.min() < 0 or tris.max() >= len(P):
+        raise MeshError(f"\"{path}\": face index out of range")
+    if not _is_identity(to_world):
+        tw = np.asarray(to_world, F)
+        P = transform_points(tw, P)
+        if N is not None:
+            N = transform_normals(_inverse(tw), N)
+    if N is not None:
+        N = _normalize_rows(N)
+    m = Mesh(os.path.splitext(os.path.basename(path))[0], P, tris, N, UV)
+    return [configure_mesh(m, face_normals, flip_normals)]
+
+
+# ---- Mitsuba .serialized ---------------------------------------------------------------------------------------------------------
+def _serialized_offsets(data, version):
+    """Offset dictionary at the end of the file (trimesh.cpp:296-330); None when the file has no valid dictionary."""
+    if len(data) < 8:
+        return None
+    count = struct.unpack_from("<I", data, len(data) - 4)[0]
+    min_size = 4 + count * (2 * 2 + 4 + 1 + 2 * 8 + 3 * 4 + 3 * 4)
+    if count == 0 or len(data) < min_size:
+        return None
+    if version == VERSION_V4:
+        return list(struct.unpack_from(f"<{count}Q", data, len(data) - 8 * count - 4))
+    return list(struct.unpack_from(f"<{count}I", data, len(data) - 4 * (count + 1)))
+
+
+def load_serialized(path, shape_index=0, to_world=None, face_normals=False, flip_normals=False, name=None):
+    if shape_index < 0:
+        raise MeshError("Shape index must be nonnegative!")
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 4:
+        raise MeshError("Encountered an invalid file format!")
+    fmt, version = struct.unpack_from("<HH", data, 0)
+    if fmt != FILEFORMAT_HEADER:
+        raise MeshError("Encountered an invalid file format!")
+    if version not in (VERSION_V3, VERSION_V4):
+        raise MeshError("Encountered an incompatible file version!")
+    offsets = _serialized_offsets(data, version) or [0]
+    if shape_index >= len(offsets):
+        raise MeshError(f"Unable to unserialize mesh, shape index is out of range! (requested {shape_index} out of 0..{len(offsets) - 1})")
+    off = offsets[shape_index]
+    if off + 4 > len(data) or struct.unpack_from("<HH", data, off) != (fmt, version):
+        if shape_index == 0 and off != 0:
+            off = 0                                            # a trailing count that only looks like a dictionary
+        else:
+            raise MeshError("Encountered an invalid file format!")
+    raw = zlib.decompressobj().decompress(data[off + 4:])
+    pos = 0
+    flags = struct.unpack_from("<I", raw, pos)[0]; pos += 4
+    mesh_name = ""
+    if version == VERSION_V4:
+        z = raw.index(b"\0", pos); mesh_name = raw[pos:z].decode("utf-8", "replace"); pos = z + 1
+    nv, nt = struct.unpack_from("<QQ", raw, pos); pos += 16
+    ft = "<f8" if flags & FLAG_DOUBLE else "<f4"
+    fs = 8 if flags & FLAG_DOUBLE else 4
+
+    def take(n, width):
+        nonlocal pos
+        a = np.frombuffer(raw, ft, n * width, pos).astype(F).reshape(n, width); pos += n * width * fs
+        return a
+    P = take(nv, 3)
+    N = take(nv, 3) if flags & FLAG_NORMALS else None
+    UV = take(nv, 2) if flags & FLAG_TEXCOORDS else None
+    if flags & FLAG_COLORS:
+        take(nv, 3)
+    T = np.frombuffer(raw, "<u4", nt * 3, pos).reshape(nt, 3).copy()
+    if not _is_identity(to_world):
+        tw = np.asarray(to_world, F)
+        P = transform_points(tw, P)
+        if N is not None:
+            N = _normalize_rows(transform_normals(_inverse(tw), N))
+        if np.linalg.det(np.asarray(tw, np.float64)[:3, :3]) < 0:
+            T = np.ascontiguousarray(T[:, [1, 0, 2]])
+    base = os.path.splitext(os.path.basename(path))[0]
+    m = Mesh(mesh_name or name or f"{base}@{shape_index}", P, T, N, UV)
+    return [configure_mesh(m, face_normals, flip_normals)]
+
+
+def save_serialized(path, meshes):
+    """Write meshes as a v4 `.serialized` file with the offset dictionary the reference's loader expects."""
+    blobs, offsets, pos = [], [], 0
+    for m in meshes:
+        flags = FLAG_SINGLE | (FLAG_NORMALS if m.normals is not None else 0) | (FLAG_TEXCOORDS if m.uv is not None else 0) | (FLAG_FACE_NORMALS if m.face_normals else 0)
+        body = struct.pack("<I", flags) + m.name.encode("utf-8") + b"\0" + struct.pack("<QQ", len(m.positions), len(m.triangles))
+        body += m.positions.astype("<f4").tobytes()
+        if m.normals is not None:
+            body += m.normals.astype("<f4").tobytes()
+        if m.uv is not None:
+            body += m.uv.astype("<f4").tobytes()
+        body += m.triangles.astype("<u4").tobytes()
+        blob = struct.pack("<HH", FILEFORMAT_HEADER, VERSION_V4) + zlib.compress(body)
+        offsets.append(pos); blobs.append(blob); pos += len(blob)
+    with open(path, "wb") as f:
+        for b in blobs:
+            f.write(b)
+        f.write(struct.pack(f"<{len(offsets)}Q", *offsets))
+        f.write(struct.pack("<I", len(offsets)))
+
+
+# ---- cube ------------------------------------------------------------------------------------------------------------------------
+def make_cube(to_world=None, face_normals=False, flip_normals=False):
+    d = np.load(os.path.join(_DATA, "cube_mesh.npz"))
+    P, N, UV, T = d["positions"], d["normals"], d["uv"], d["triangles"]
+    if not _is_identity(to_world):
+        tw = np.asarray(to_world, F)
+        P = transform_points(tw, P)
+        N = _normalize_rows(transform_normals(_inverse(tw), N))
+    return [configure_mesh(Mesh("unnamed", P, T, N, UV), face_normals, flip_normals)]
+
+
+def save_obj(path, mesh, precision=9):
+    """Plain OBJ writer (positions, optional normals / uv sharing the position index)."""
+    with open(path, "w") as f:
+        for p in mesh.positions:
+            f.write("v %.*g %.*g %.*g\n" % (precision, p[0], precision, p[1], precision, p[2]))
+        if mesh.uv is not None:
+            for t in mesh.uv:
+                f.write("vt %.*g %.*g\n" % (precision, t[0], precision, t[1]))
+        if mesh.normals is not None:
+            for n in mesh.normals:
+                f.write("vn %.*g %.*g %.*g\n" % (precision, n[0], precision, n[1], precision, n[2]))
+        for t in mesh.triangles.astype(np.int64) + 1:
+            if mesh.uv is not None and mesh.normals is not None:
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (t[0], t[0], t[0], t[1], t[1], t[1], t[2], t[2], t[2]))
+            elif mesh.normals is not None:
+                f.write("f %d//%d %d//%d %d//%d\n" % (t[0], t[0], t[1], t[1], t[2], t[2]))
+            elif mesh.uv is not None:
+                f.write("f %d/%d %d/%d %d/%d\n" % (t[0], t[0], t[1], t[1], t[2], t[2]))
+            else:
+                f.write("f %d %d %d\n" % (t[0], t[1], t[2]))

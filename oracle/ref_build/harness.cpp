@@ -724,6 +724,55 @@ static void modeResponsive(Built &b, const FScene &fs, const std::string &plugin
     printf("responsive[%s]: rc %d, %.3f s, %zu progress calls%s%s\n", plugin.c_str(), rc, sec, in.calls.size(), st ? ", " : "", st ? st : "");
 }
 
+// mesh loaders (src/shapes/{obj,ply,serialized,cube}.cpp over TriMesh::configure): dump every mesh the plugin creates, after configure()
+static void modeMesh(int argc, char **argv) {
+    // mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [16 floats toWorld, row major]
+    Properties p(argv[2]);
+    if (std::string(argv[3]) != "-") p.setString("filename", argv[3]);
+    p.setBoolean("faceNormals", atoi(argv[5]) != 0);
+    p.setBoolean("flipNormals", atoi(argv[6]) != 0);
+    if (atof(argv[7]) >= 0) p.setFloat("maxSmoothAngle", (Float) atof(argv[7]));
+    if (atoi(argv[8]) >= 0) p.setInteger("shapeIndex", atoi(argv[8]));
+    if (std::string(argv[2]) == "obj") { p.setBoolean("flipTexCoords", atoi(argv[9]) != 0); p.setBoolean("loadMaterials", false); }
+    if (argc >= 26) {
+        Matrix4x4 m; for (int i = 0; i < 16; ++i) m.m[i / 4][i % 4] = (Float) atof(argv[10 + i]);
+        p.setTransform("toWorld", Transform(m));
+    }
+    ref<Shape> shape;
+    if (std::string(argv[2]) == "serialized") {
+        // the serialized PLUGIN needs pushSceneCleanupHandler from scenehandler.cpp (xerces, absent): the file format is read through the
+        // reader the plugin itself calls, TriMesh::loadCompressed (src/librender/trimesh.cpp:80-87, :176-253); toWorld / flags are ignored
+        ref<FileStream> in = new FileStream(fs::pathstr(argv[3]), FileStream::EReadOnly);
+        in->setByteOrder(Stream::ELittleEndian);
+        shape = new TriMesh(in, std::max(atoi(argv[8]), 0));
+    } else
+        shape = static_cast<Shape *>(create(MTS_CLASS(Shape), p));
+    shape->configure();
+    std::vector<ref<TriMesh> > meshes;
+    if (shape->isCompound()) {
+        for (int i = 0; ; ++i) { Shape *e = shape->getElement(i); if (!e) break; meshes.push_back(static_cast<TriMesh *>(e)); }
+    } else meshes.push_back(static_cast<TriMesh *>(shape.get()));
+    FILE *f = fopen(argv[4], "wb");
+    uint32_t n = (uint32_t) meshes.size(); fwrite(&n, 4, 1, f);
+    for (size_t k = 0; k < meshes.size(); ++k) {
+        TriMesh *m = meshes[k];
+        uint32_t hdr[4] = { (uint32_t) m->getVertexCount(), (uint32_t) m->getTriangleCount(),
+                            (uint32_t) ((m->hasVertexNormals() ? 1 : 0) | (m->hasVertexTexcoords() ? 2 : 0)), (uint32_t) m->getName().size() };
+        fwrite(hdr, 4, 4, f); fwrite(m->getName().data(), 1, hdr[3], f);
+        fwrite(m->getVertexPositions(), 12, hdr[0], f);
+        if (m->hasVertexNormals()) fwrite(m->getVertexNormals(), 12, hdr[0], f);
+        if (m->hasVertexTexcoords()) fwrite(m->getVertexTexcoords(), 8, hdr[0], f);
+        fwrite(m->getTriangles(), 12, hdr[1], f);
+    }
+    fclose(f);
+    {   // the first mesh again, through the reference's own writer (TriMesh::serialize, src/librender/trimesh.cpp:1131)
+        ref<FileStream> fsm = new FileStream(fs::pathstr(std::string(argv[4]) + ".serialized"), FileStream::ETruncReadWrite);
+        fsm->setByteOrder(Stream::ELittleEndian);
+        meshes[0]->serialize(fsm);
+        fsm->close();
+    }
+}
+
 int main(int argc, char **argv) {
     Class::staticInitialization();
     Object::staticInitialization();
@@ -738,7 +787,8 @@ int main(int argc, char **argv) {
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
     Thread::getThread()->getFileResolver()->appendPath(fs::pathstr(MI_REF_ROOT));   // data/microfacet/*.dat, data/ior/*.spd (roughplastic, named conductors)
     if (argc >= 8 && std::string(argv[1]) == "mipmap") { modeMipmap(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7]); fflush(NULL); _exit(0); }
-    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
+    if (argc >= 10 && std::string(argv[1]) == "mesh") { modeMesh(argc, argv); fflush(NULL); _exit(0); }
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
     FScene fs = loadScene(argv[1]);
