@@ -1,0 +1,970 @@
+"""Scene-description front end: reads a Mitsuba 0.5 / 0.6 XML scene file and produces the flattened scene the
+HIP path tracer uploads (the same `scenes.Scene` record the synthetic generators build), so that a scene written for the reference can
+be rendered without it.
+
+What is read (reference: src/librender/scenehandler.cpp:104-140 tag table, :300-800 property handlers): <scene>, <default> / $name
+substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <vector> <rgb> <srgb> <spectrum>, <transform> with
+<translate> <rotate> <scale> <matrix> <lookat>, and the plugin tags <integrator> <sensor> <sampler> <film> <rfilter> <shape> <bsdf>
+<texture> <emitter>.  Plugins understood = the ones the hot path implements:
+    integrator  path
+    sensor      perspective                                  (src/librender/sensor.cpp:225-305 fov / fovAxis / focalLength)
+    sampler     independent, sobol
+    film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
+    rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
+    shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
+    bsdf        diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, twosided
+    texture     checkerboard, gridtexture, bitmap (diffuse reflectance)
+    emitter     area, constant, envmap, point, spot, directional
+Anything else raises SceneError naming the plugin: there is no silent substitution.
+
+Emitter order follows Scene::addChild / Scene::configure (src/librender/scene.cpp:527-547, :589-623): scene-level emitters in document
+order first, then the area lights in shape order.  Parity status: the mesh readers are pinned against the reference's loaders
+(tests/test_meshio.py); the XML layer itself is "parity unpinned" -- the reference's scene loader needs xerces-c, absent from the image,
+so it is checked against the conventions read from scenehandler.cpp and against the synthetic generators (tests/test_xml_scene.py).
+"""
+import math
+import os
+import re
+import struct
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from . import meshio
+from . import scenes as S
+
+f32 = np.float32
+
+IOR_TABLE = {  # src/bsdfs/ior.h:38-66 (Hecht, Optics; ~589 nm)
+    "vacuum": 1.0, "helium": 1.000036, "hydrogen": 1.000132, "air": 1.000277, "carbon dioxide": 1.00045, "water": 1.3330, "acetone": 1.36,
+    "ethanol": 1.361, "carbon tetrachloride": 1.461, "glycerol": 1.4729, "benzene": 1.501, "silicone oil": 1.52045, "bromine": 1.661,
+    "water ice": 1.31, "fused quartz": 1.458, "pyrex": 1.470, "acrylic glass": 1.49, "polypropylene": 1.49, "bk7": 1.5046,
+    "sodium chloride": 1.544, "amber": 1.55, "pet": 1.5750, "diamond": 2.419,
+}
+PROPERTY_TAGS = {"integer", "float", "boolean", "string", "point", "vector", "rgb", "srgb", "spectrum", "blackbody", "transform", "animation"}
+PLUGIN_TAGS = {"scene", "shape", "sampler", "film", "integrator", "texture", "sensor", "emitter", "subsurface", "medium", "volume", "phase", "bsdf", "rfilter"}
+
+
+class SceneError(ValueError):
+    pass
+
+
+class Plugin:
+    """One plugin element: its tag, type, id, properties (name -> value) and children ((name, Plugin) in document order)."""
+
+    def __init__(self, tag, type_, id_):
+        self.tag, self.type, self.id = tag, type_, id_
+        self.props, self.children, self.queried = {}, [], set()
+
+    def get(self, name, default=None):
+        self.queried.add(name)
+        return self.props.get(name, default)
+
+    def has(self, name):
+        return name in self.props
+
+    def check_all_used(self):
+        """Properties::getUnqueried(): the reference refuses properties nobody asked for (src/libcore/plugin.cpp via scenehandler.cpp:857-870)."""
+        left = [k for k in self.props if k not in self.queried]
+        if left:
+            raise SceneError(f"<{self.tag} type=\"{self.type}\">: unused or unsupported propert{'y' if len(left) == 1 else 'ies'} {', '.join(sorted(left))}")
+
+    def child(self, tag, name=None):
+        for n, c in self.children:
+            if c.tag == tag and (name is None or n == name):
+                return c
+        return None
+
+    def children_of(self, tag):
+        return [(n, c) for n, c in self.children if c.tag == tag]
+
+
+# ---- values ----------------------------------------------------------------------------------------------------------------------
+def _tokens(s):
+    return [t for t in re.split(r"[,\s]+", s.strip()) if t]
+
+
+def _float(s, what):
+    try:
+        return float(f32(float(s)))
+    except (TypeError, ValueError):
+        raise SceneError(f"Invalid floating point value specified (in <{what}>)")
+
+
+def srgb_to_linear(v):
+    """Spectrum::fromSRGB (src/libcore/spectrum.cpp): the piecewise sRGB decoding curve per channel."""
+    v = f32(v)
+    return float(v / f32(12.92)) if v <= f32(0.04045) else float(f32(math.pow((float(v) + 0.055) / 1.055, 2.4)))
+
+
+_HAT_TABLE = None
+
+
+def spectrum_to_rgb(pairs):
+    """<spectrum value="wavelength:value, ..."> in an RGB build: InterpolatedSpectrum + zeroExtend + Spectrum::fromContinuousSpectrum
+    (src/libcore/spectrum.cpp:172-185, :630-650).  The conversion is linear in the spectrum, so it is applied through the reference's own response
+    to hat functions on a 10-nm grid over 360..830 nm (mitsuba-im_amd/data/spectrum_hat_response.npy, dumped by oracle/_ref/harness `tables`)."""
+    global _HAT_TABLE
+    if _HAT_TABLE is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "spectrum_hat_response.npy")
+        if not os.path.exists(path):
+            raise SceneError("wavelength:value spectra need mitsuba-im_amd/data/spectrum_hat_response.npy")
+        _HAT_TABLE = np.load(path).astype(np.float64)
+    wl = [float(f32(w)) for w, _ in pairs]; val = [float(f32(v)) for _, v in pairs]
+    if len(wl) < 2:
+        raise SceneError("InterpolatedSpectrum::zeroExtend() -- at least 2 entries are needed!")
+    spacing = float(np.mean(np.diff(wl)))
+    if val[0] != 0:
+        wl.insert(0, wl[0] - spacing); val.insert(0, 0.0)
+    if val[-1] != 0:
+        wl.append(wl[-1] + spacing); val.append(0.0)
+    step = 470.0 / (len(_HAT_TABLE) - 1)
+    grid = 360.0 + step * np.arange(len(_HAT_TABLE))
+    coarse = np.interp(grid, wl, val, left=0.0, right=0.0)            # the spectrum's interpolant on the table's knots: converted by the table
+    rgb = coarse @ _HAT_TABLE
+    # what the 10-nm interpolant misses (detail between its knots) is small and oscillating; it is integrated against an analytic fit of the CIE 1931
+    # observer (Wyman, Sloan, Shirley, "Simple Analytic Approximations to the CIE XYZ Color Matching Functions", JCGT 2013) and converted like fromXYZ
+    fine = np.linspace(360.0, 830.0, 470 * 8 + 1)
+    resid = np.interp(fine, wl, val, left=0.0, right=0.0) - np.interp(fine, grid, coarse)
+
+    def lobe(mu, s1, s2):
+        t = (fine - mu) / np.where(fine < mu, s1, s2)
+        return np.exp(-0.5 * t * t)
+    xb = 1.056 * lobe(599.8, 37.9, 31.0) + 0.362 * lobe(442.0, 16.0, 26.7) - 0.065 * lobe(501.1, 20.4, 26.2)
+    yb = 0.821 * lobe(568.8, 46.9, 40.5) + 0.286 * lobe(530.9, 16.3, 31.1)
+    zb = 1.217 * lobe(437.0, 11.8, 36.0) + 0.681 * lobe(459.0, 26.0, 13.8)
+    w = np.full(len(fine), 1.0); w[0] = w[-1] = 0.5
+    xyz = np.array([np.sum(w * resid * c) for c in (xb, yb, zb)]) / np.sum(w * yb)
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])   # spectrum.cpp:222-227
+    rgb = rgb + m @ xyz
+    return tuple(max(0.0, float(f32(c))) for c in rgb)       # clampNegative()
+
+
+# ---- transforms (scenehandler.cpp:432-525; src/libcore/transform.cpp) -----------------------------------------------------------------
+def _parse_transform(elem, subst):
+    m = np.eye(4)
+    for op in elem:
+        a = {k: subst(v) for k, v in op.attrib.items()}
+        tag = op.tag
+        if tag == "translate":
+            t = S.translate(_float(a.get("x", "0"), tag), _float(a.get("y", "0"), tag), _float(a.get("z", "0"), tag))
+        elif tag == "rotate":
+            if "angle" not in a:
+                raise SceneError("Missing floating point value (in <rotate>)")
+            axis = (_float(a.get("x", "0"), tag), _float(a.get("y", "0"), tag), _float(a.get("z", "0"), tag))
+            if axis == (0.0, 0.0, 0.0):
+                raise SceneError("<rotate>: the rotation axis is zero")
+            t = S.rotate(axis, _float(a["angle"], tag))
+        elif tag == "scale":
+            has_xyz = any(a.get(k, "") != "" for k in "xyz"); has_value = a.get("value", "") != ""
+            if has_xyz and has_value:
+                raise SceneError("<scale>: provided both xyz and value arguments!")
+            if has_xyz:
+                t = S.scale(_float(a.get("x") or "1", tag), _float(a.get("y") or "1", tag), _float(a.get("z") or "1", tag))
+            elif has_value:
+                t = S.scale(_float(a["value"], tag))
+            else:
+                raise SceneError("<scale>: provided neither xyz nor value arguments!")
+        elif tag == "matrix":
+            tok = _tokens(a.get("value", ""))
+            if len(tok) != 16:
+                raise SceneError("Invalid matrix specified")
+            t = np.array([_float(x, tag) for x in tok], np.float64).reshape(4, 4)
+        elif tag in ("lookat", "lookAt"):
+            o = _tokens(a.get("origin", "")); tg = _tokens(a.get("target", "")); up = _tokens(a.get("up", ""))
+            if len(o) != 3:
+                raise SceneError("<lookat>: invalid 'origin' argument")
+            if len(tg) != 3:
+                raise SceneError("<lookat>: invalid 'target' argument")
+            if len(up) not in (0, 3):
+                raise SceneError("<lookat>: invalid 'up' argument")
+            o = [_float(x, tag) for x in o]; tg = [_float(x, tag) for x in tg]
+            u = [_float(x, tag) for x in up] if up else [0.0, 0.0, 0.0]
+            if u == [0.0, 0.0, 0.0]:             # no 'up': an arbitrary axis perpendicular to the viewing direction
+                d = np.asarray(tg, f32) - np.asarray(o, f32); d = d / np.sqrt(np.dot(d, d))
+                u = S._coordinate_system(d)[0]
+            t = S.look_at(o, tg, u).astype(np.float64)
+        else:
+            raise SceneError(f"Unhandled tag \"{tag}\" encountered inside <transform>!")
+        m = t @ m
+    return m.astype(f32)
+
+
+# ---- XML -> Plugin tree ----------------------------------------------------------------------------------------------------------------
+class _Reader:
+    def __init__(self, path, params):
+        self.params = dict(params or {})
+        self.ids = {}
+        self.dirs = [os.path.dirname(os.path.abspath(path))]
+
+    def subst(self, value):
+        if "$" in value:
+            for k in sorted(self.params, key=len, reverse=True):
+                value = value.replace("$" + k, str(self.params[k]))
+            if "$" in value and "[" not in value:
+                raise SceneError(f"The scene referenced an undefined parameter: \"{value}\"")
+        return value
+
+    def resolve(self, filename):
+        if os.path.isabs(filename) and os.path.exists(filename):
+            return filename
+        for d in self.dirs:
+            p = os.path.join(d, filename)
+            if os.path.exists(p):
+                return p
+        raise SceneError(f"file \"{filename}\" could not be found (searched {', '.join(self.dirs)})")
+
+    def read_file(self, path):
+        try:
+            root = ET.parse(path).getroot()
+        except ET.ParseError as e:
+            raise SceneError(f"{os.path.basename(path)}: XML parse error: {e}")
+        return root
+
+    def plugin(self, elem, parent_tag=None):
+        a = {k: self.subst(v) for k, v in elem.attrib.items()}
+        if elem.tag != "scene" and "type" not in a:
+            raise SceneError(f"Missing plugin type in <{elem.tag}>")
+        p = Plugin(elem.tag, a.get("type", "scene"), a.get("id"))
+        for ch in elem:
+            tag = ch.tag
+            ca = {k: self.subst(v) for k, v in ch.attrib.items()}
+            if tag == "default":
+                self.params.setdefault(ca["name"], ca["value"])
+            elif tag == "include":
+                inc = self.read_file(self.resolve(ca["filename"]))
+                if inc.tag != "scene":
+                    p.children.append((ca.get("name", ""), self.plugin(inc)))
+                else:
+                    sub = self.plugin(inc)
+                    p.children.extend(sub.children)
+            elif tag == "alias":
+                if ca.get("id") not in self.ids:
+                    raise SceneError(f"Referenced object '{ca.get('id')}' not found!")
+                self.ids[ca["as"]] = self.ids[ca["id"]]
+            elif tag == "ref":
+                if ca.get("id") not in self.ids:
+                    raise SceneError(f"Referenced object '{ca.get('id')}' not found!")
+                p.children.append((ca.get("name", ""), self.ids[ca["id"]]))
+            elif tag == "null":
+                pass
+            elif tag in PROPERTY_TAGS:
+                if "name" not in ca:
+                    raise SceneError(f"<{tag}> without a name (in <{elem.tag}>)")
+                p.props[ca["name"]] = self.value(tag, ca, ch, elem.tag)
+            elif tag in PLUGIN_TAGS:
+                c = self.plugin(ch, elem.tag)
+                if c.id:
+                    self.ids[c.id] = c
+                p.children.append((ca.get("name", ""), c))
+            else:
+                raise SceneError(f"Unhandled tag \"{tag}\" encountered!")
+        return p
+
+    def value(self, tag, a, elem, parent_tag):
+        v = a.get("value", "")
+        if tag == "integer":
+            try:
+                return int(v)
+            except ValueError:
+                raise SceneError(f"Invalid integer value specified (in <{a['name']}>)")
+        if tag == "float":
+            return _float(v, a["name"])
+        if tag == "boolean":
+            if v.lower() not in ("true", "false"):
+                raise SceneError(f"Invalid boolean value specified (in <{a['name']}>)")       # scenehandler.cpp:410-424
+            return v.lower() == "true"
+        if tag == "string":
+            return v
+        if tag in ("point", "vector"):
+            return np.array([_float(a.get(k, ""), tag) for k in "xyz"], f32)
+        if tag == "transform":
+            return _parse_transform(elem, self.subst)
+        if tag == "animation":
+            raise SceneError("animated transforms are not supported (the path renders one shutter instant)")
+        if tag == "blackbody":
+            raise SceneError("<blackbody> spectra are not supported")
+        tok = _tokens(v)
+        if tag in ("rgb", "srgb"):
+            if len(tok) == 1 and len(tok[0]) == 7 and tok[0][0] == "#":
+                try:
+                    enc = int(tok[0][1:], 16)
+                except ValueError:
+                    raise SceneError(f"Invalid {tag} value specified (in <{a['name']}>)")
+                c = [float(f32((enc >> 16) & 255) / f32(255)), float(f32((enc >> 8) & 255) / f32(255)), float(f32(enc & 255) / f32(255))]
+            elif len(tok) == 1:
+                c = [_float(tok[0], tag)] * 3
+            elif len(tok) == 3:
+                c = [_float(t, tag) for t in tok]
+            else:
+                raise SceneError("Invalid RGB value specified" if tag == "rgb" else "Invalid sRGB value specified")
+            return tuple(c) if tag == "rgb" else tuple(srgb_to_linear(x) for x in c)       # RGB build: fromLinearRGB is the identity
+        if tag == "spectrum":
+            if ("value" in a) == ("filename" in a):
+                raise SceneError("<spectrum>: please provide one of 'value' or 'filename'")
+            if "filename" in a:
+                rows = [l.split() for l in open(self_resolve(self, a["filename"])) if l.strip() and not l.lstrip().startswith("#")]
+                return spectrum_to_rgb([(r[0], r[1]) for r in rows])
+            if len(tok) == 1 and ":" not in tok[0]:
+                x = _float(tok[0], tag)
+                return (x, x, x)                     # reflectance: Spectrum(x); illuminant: D65 * x, and D65 is white in an RGB build
+            if ":" in tok[0]:
+                pairs = []
+                for t in tok:
+                    parts = t.split(":")
+                    if len(parts) != 2:
+                        raise SceneError("Invalid spectrum->value mapping specified")
+                    pairs.append((_float(parts[0], tag), _float(parts[1], tag)))
+                return spectrum_to_rgb(pairs)
+            if len(tok) != 3:
+                raise SceneError("Invalid spectrum value specified (length does not match the current spectral discretization!)")
+            return tuple(_float(t, tag) for t in tok)
+        raise SceneError(f"Unhandled tag \"{tag}\" encountered!")
+
+
+def self_resolve(reader, filename):
+    return reader.resolve(filename)
+
+
+# ---- image files for environment maps ----------------------------------------------------------------------------------------------
+def load_image(path):
+    """RGB float image [h, w, 3] from .npy, .pfm or Radiance .hdr (OpenEXR needs a library the image does not have)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        a = np.load(path).astype(f32)
+    elif ext == ".pfm":
+        with open(path, "rb") as f:
+            kind = f.readline().strip(); w, h = map(int, f.readline().split()); sc = float(f.readline())
+            ch = 3 if kind == b"PF" else 1
+            a = np.frombuffer(f.read(w * h * ch * 4), "<f4" if sc < 0 else ">f4").reshape(h, w, ch)[::-1].astype(f32)
+    elif ext in (".hdr", ".rgbe", ".pic"):
+        a = _load_rgbe(path)
+    else:
+        raise SceneError(f"image format of \"{os.path.basename(path)}\" is not readable here (supported: .npy, .pfm, .hdr)")
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.shape[2] == 1:
+        a = np.repeat(a, 3, axis=2)
+    return np.ascontiguousarray(a[:, :, :3], f32)
+
+
+def _load_rgbe(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = data.index(b"\n\n") + 2
+    m = re.match(rb"-Y (\d+) \+X (\d+)\n", data[pos:pos + 64])
+    if not m:
+        raise SceneError(f"\"{path}\": unsupported Radiance HDR orientation")
+    h, w = int(m.group(1)), int(m.group(2)); pos += m.end()
+    out = np.zeros((h, w, 4), np.uint8)
+    for y in range(h):
+        if w < 8 or w > 0x7FFF or data[pos] != 2 or data[pos + 1] != 2 or (data[pos + 2] & 0x80):
+            out[y] = np.frombuffer(data, np.uint8, w * 4, pos).reshape(w, 4); pos += w * 4       # flat scanline
+            continue
+        pos += 4
+        for c in range(4):
+            x = 0
+            while x < w:
+                n = data[pos]; pos += 1
+                if n > 128:
+                    n -= 128; out[y, x:x + n, c] = data[pos]; pos += 1
+                else:
+                    out[y, x:x + n, c] = np.frombuffer(data, np.uint8, n, pos); pos += n
+                x += n
+    e = out[:, :, 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(1.0, e - 136), 0.0)
+    return (out[:, :, :3].astype(np.float64) * scale[:, :, None]).astype(f32)
+
+
+# ---- interpretation ------------------------------------------------------------------------------------------------------------------
+def _ior(p, name, default):
+    v = p.get(name, default)
+    if isinstance(v, str):
+        if v.lower() not in IOR_TABLE:
+            raise SceneError(f"unable to find an IOR value for \"{v}\"")
+        return IOR_TABLE[v.lower()]
+    return float(v)
+
+
+def _microfacet(p):
+    d = str(p.get("distribution", "beckmann")).lower()
+    if d not in ("beckmann", "ggx"):
+        raise SceneError(f"microfacet distribution \"{d}\" is not supported (beckmann, ggx)")
+    if p.has("alphaU") or p.has("alphaV"):
+        if p.get("alphaU") != p.get("alphaV"):
+            raise SceneError("anisotropic roughness (alphaU != alphaV) is not supported")
+        alpha = p.get("alphaU")
+    else:
+        alpha = p.get("alpha", 0.1)
+    if not isinstance(alpha, float):
+        raise SceneError("textured roughness is not supported")
+    return (S.DISTR_GGX if d == "ggx" else S.DISTR_BECKMANN), alpha, bool(p.get("sampleVisible", True))
+
+
+def _spectrum_or_texture(p, names, default):
+    """A spectrum-valued BSDF parameter: constant from the properties, or a nested <texture name=...>."""
+    for n in names:
+        for cn, c in p.children_of("texture"):
+            if cn == n:
+                return None, c
+    for n in names:
+        if p.has(n):
+            v = p.get(n)
+            return ((v, v, v) if isinstance(v, float) else tuple(v)), None
+    return default, None
+
+
+class _SceneBuilder:
+    def __init__(self, reader, root):
+        self.r, self.root = reader, root
+        self.bsdfs, self.bsdf_index, self.textures = [], {}, []
+        self.verts, self.normals, self.uvs, self.tris, self.shapes = [], [], [], [], []
+        self.any_normals = self.any_uv = False
+        self.analytic, self.instances, self.groups = [], [], {}
+        self.scene_emitters, self.area = [], []          # area: (document order, kind 'mesh' / 'analytic', index, radiance, weight)
+        self.envmap = None
+        self.order = 0
+
+    # -- materials
+    def texture(self, t):
+        if t.type in ("checkerboard", "gridtexture"):
+            kind = S.TEXTURE_CHECKERBOARD if t.type == "checkerboard" else S.TEXTURE_GRID
+            d0, d1 = ((0.4,) * 3, (0.2,) * 3) if kind == S.TEXTURE_CHECKERBOARD else ((0.2,) * 3, (0.4,) * 3)
+            c0, c1 = t.get("color0", d0), t.get("color1", d1)
+            c0 = (c0,) * 3 if isinstance(c0, float) else c0; c1 = (c1,) * 3 if isinstance(c1, float) else c1
+            if t.get("coordinates", "uv") != "uv":
+                raise SceneError("texture coordinates other than 'uv' are not supported")
+            uvs = t.get("uvscale", 1.0)
+            rec = S.make_texture(kind, c0, c1, t.get("lineWidth", 0.01) if kind == S.TEXTURE_GRID else 0.01, t.get("uoffset", 0.0), t.get("voffset", 0.0),
+                                 t.get("uscale", uvs), t.get("vscale", uvs))
+        elif t.type == "bitmap":
+            path = self.r.resolve(t.get("filename"))
+            if not path.endswith(".npz"):
+                raise SceneError("bitmap textures take a precomputed MIP pyramid (.npz with base / sizes / texels, see scenes.load_texture_pyramid): "
+                                 "the pyramid is input data of the path, the reference builds it at load time (include/mitsuba/render/mipmap.h)")
+            d = np.load(path); levels = []; off = 0
+            for w, h in d["sizes"]:
+                n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
+            wrap = {"repeat": S.WRAP_REPEAT, "clamp": S.WRAP_CLAMP, "mirror": S.WRAP_MIRROR, "zero": S.WRAP_ZERO, "one": S.WRAP_ONE}
+            filt = {"ewa": S.MIP_EWA, "trilinear": S.MIP_TRILINEAR, "bilinear": S.MIP_BILINEAR, "nearest": S.MIP_NEAREST}
+            wm = t.get("wrapMode", "repeat"); wu, wv = t.get("wrapModeU", wm), t.get("wrapModeV", wm); ft = str(t.get("filterType", "ewa")).lower()
+            if wu not in wrap or wv not in wrap or ft not in filt:
+                raise SceneError("bitmap: unknown wrapMode / filterType")
+            if t.get("channel", "") != "":
+                raise SceneError("bitmap: 'channel' selection is not supported")
+            t.get("gamma", 0.0); t.get("cache", True)
+            uvs = t.get("uvscale", 1.0)
+            rec = S.make_texture(S.TEXTURE_BITMAP, uoffset=t.get("uoffset", 0.0), voffset=t.get("voffset", 0.0), uscale=t.get("uscale", uvs), vscale=t.get("vscale", uvs),
+                                 pyramid=dict(levels=levels), wrap_u=wrap[wu], wrap_v=wrap[wv], filter_type=filt[ft], max_anisotropy=t.get("maxAnisotropy", 20.0))
+        else:
+            raise SceneError(f"texture plugin \"{t.type}\" is not supported")
+        t.check_all_used()
+        self.textures.append(rec)
+        return len(self.textures) - 1
+
+    def bsdf(self, p, twosided=False):
+        key = (id(p), twosided)
+        if key in self.bsdf_index:
+            return self.bsdf_index[key]
+        t = p.type
+        if t == "twosided":
+            inner = p.children_of("bsdf")
+            if len(inner) != 1:
+                raise SceneError("twosided: exactly one nested BSDF is supported (the same material on both sides)")
+            p.check_all_used()
+            i = self.bsdf(inner[0][1], True)
+            self.bsdf_index[key] = i
+            return i
+        tex = None
+        if t == "diffuse":
+            refl, tex = _spectrum_or_texture(p, ("reflectance", "diffuseReflectance"), (0.5, 0.5, 0.5))
+            rec = S.make_bsdf(S.BSDF_DIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), twosided=twosided)
+        elif t == "difftrans":
+            tr, tex = _spectrum_or_texture(p, ("transmittance", "diffuseTransmittance"), (0.5, 0.5, 0.5))
+            if tex is not None:
+                raise SceneError("difftrans: textured transmittance is not supported");
+            rec = S.make_bsdf(S.BSDF_DIFFTRANS, reflectance=tr)
+        elif t in ("conductor", "roughconductor"):
+            ext = _ior(p, "extEta", "air")
+            mat = p.get("material", "Cu")
+            if p.has("eta") or p.has("k"):
+                eta, k = p.get("eta", None), p.get("k", None)
+                if eta is None or k is None:
+                    if mat not in S.CONDUCTOR_IOR:
+                        raise SceneError(f"conductor: give both 'eta' and 'k' (material \"{mat}\" is not in the built-in table)")
+                    eta = S.CONDUCTOR_IOR[mat][0] if eta is None else eta; k = S.CONDUCTOR_IOR[mat][1] if k is None else k
+            elif mat == "none":
+                eta, k = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+            elif mat in S.CONDUCTOR_IOR:
+                eta, k = S.CONDUCTOR_IOR[mat]
+            else:
+                raise SceneError(f"conductor material \"{mat}\" needs the reference's data/ior database; built in: {', '.join(sorted(S.CONDUCTOR_IOR))} -- or give 'eta' and 'k'")
+            eta = tuple(float(f32(e) / f32(ext)) for e in ((eta,) * 3 if isinstance(eta, float) else eta))
+            k = tuple(float(f32(e) / f32(ext)) for e in ((k,) * 3 if isinstance(k, float) else k))
+            spec, stex = _spectrum_or_texture(p, ("specularReflectance",), (1.0, 1.0, 1.0))
+            if stex is not None:
+                raise SceneError(f"{t}: textured specularReflectance is not supported")
+            if t == "conductor":
+                rec = S.make_bsdf(S.BSDF_CONDUCTOR, eta=eta, k=k, specular=spec, twosided=twosided)
+            else:
+                distr, alpha, sv = _microfacet(p)
+                rec = S.make_bsdf(S.BSDF_ROUGHCONDUCTOR, eta=eta, k=k, specular=spec, alpha=alpha, distr=distr, sample_visible=sv, twosided=twosided)
+        elif t in ("dielectric", "roughdielectric", "plastic", "roughplastic"):
+            plastic = t.endswith("plastic")
+            ior = float(f32(_ior(p, "intIOR", "polypropylene" if plastic else "bk7")) / f32(_ior(p, "extIOR", "air")))
+            spec, stex = _spectrum_or_texture(p, ("specularReflectance",), (1.0, 1.0, 1.0))
+            second, ttex = _spectrum_or_texture(p, ("diffuseReflectance",) if plastic else ("specularTransmittance",), (0.5,) * 3 if plastic else (1.0,) * 3)
+            if stex is not None or ttex is not None:
+                raise SceneError(f"{t}: textured parameters are not supported")
+            kw = dict(ior=ior, specular=spec, reflectance=second)
+            if plastic:
+                kw["nonlinear"] = bool(p.get("nonlinear", False)); kw["twosided"] = twosided
+            elif twosided:
+                raise SceneError("twosided cannot wrap a transmissive BSDF")        # src/bsdfs/twosided.cpp:77-80
+            if t.startswith("rough"):
+                distr, alpha, sv = _microfacet(p)
+                kind = S.BSDF_ROUGHPLASTIC if plastic else S.BSDF_ROUGHDIELECTRIC
+                try:
+                    rec = S.make_bsdf(kind, alpha=alpha, distr=distr, sample_visible=sv, **kw)
+                except ValueError as e:
+                    raise SceneError(f"roughplastic: {e}")
+                if kind == S.BSDF_ROUGHPLASTIC:
+                    rec["sample_visible"] = (2 if kw["nonlinear"] else 0) | (1 if sv else 0)
+            else:
+                rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_DIELECTRIC, **kw)
+        else:
+            raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
+                             "roughdielectric, difftrans, roughplastic, twosided)")
+        if tex is not None:
+            rec["texture"] = self.texture(tex)
+        p.check_all_used()
+        self.bsdfs.append(rec)
+        self.bsdf_index[key] = len(self.bsdfs) - 1
+        return len(self.bsdfs) - 1
+
+    def default_bsdf(self):
+        key = ("default", False)
+        if key not in self.bsdf_index:       # Shape::configure(): a shape without a BSDF gets a diffuse one (src/librender/shape.cpp)
+            self.bsdfs.append(S.make_bsdf(S.BSDF_DIFFUSE)); self.bsdf_index[key] = len(self.bsdfs) - 1
+        return self.bsdf_index[key]
+
+    # -- shapes
+    def add_mesh(self, m, bsdf, group):
+        fv, ft = sum(len(v) for v in self.verts), sum(len(t) for t in self.tris)
+        self.verts.append(m.positions); self.tris.append(m.triangles.astype(np.int64) + fv)
+        self.normals.append(m.normals); self.uvs.append(m.uv)
+        self.any_normals |= m.normals is not None; self.any_uv |= m.uv is not None
+        self.shapes.append(dict(first_tri=ft, tri_count=len(m.triangles), first_vert=fv, vert_count=len(m.positions), bsdf=bsdf, emitter=-1,
+                                face_normals=int(m.normals is None), group=group, has_uv=int(m.uv is not None)))
+        return len(self.shapes) - 1
+
+    def shape(self, p, group=0):
+        t = p.type
+        tw = p.get("toWorld", None)
+        if t == "shapegroup":
+            if group:
+                raise SceneError("nested shape groups are not supported")
+            g = len(self.groups); self.groups[id(p)] = g
+            for _, c in p.children_of("shape"):
+                self.shape(c, group=g + 1)
+            p.check_all_used()
+            return
+        if t == "instance":
+            if group:
+                raise SceneError("instances inside a shape group are not supported")
+            ref = [c for _, c in p.children_of("shape")]
+            if len(ref) != 1 or ref[0].type != "shapegroup":
+                raise SceneError("instance: exactly one <ref> to a shapegroup is expected")
+            if id(ref[0]) not in self.groups:
+                self.shape(ref[0])
+            self.instances.append(S.make_instance(self.groups[id(ref[0])], np.eye(4, dtype=f32) if tw is None else tw))
+            p.check_all_used()
+            return
+        named = [(n, c) for n, c in p.children_of("bsdf")]
+        em = p.children_of("emitter")
+        if len(em) > 1 or (em and em[0][1].type != "area"):
+            raise SceneError("a shape takes at most one nested emitter, of type 'area'")
+        if p.children_of("medium") or p.children_of("subsurface") or p.children_of("sensor"):
+            raise SceneError("participating media, subsurface and shape-attached sensors are outside the surface path tracer")
+        radiance = None
+        if em:
+            e = em[0][1]
+            radiance = e.get("radiance", (1.0, 1.0, 1.0)); radiance = (radiance,) * 3 if isinstance(radiance, float) else radiance
+            weight = e.get("samplingWeight", 1.0)
+            e.check_all_used()
+            if group:
+                raise SceneError("Instancing of emitters is not supported")       # src/shapes/shapegroup.cpp
+        order = self.order; self.order += 1
+        if t in ("obj", "ply", "serialized", "cube"):
+            if p.has("maxSmoothAngle"):
+                raise SceneError("maxSmoothAngle (TriMesh::rebuildTopology) is not supported")
+            kw = dict(to_world=tw, face_normals=bool(p.get("faceNormals", False)), flip_normals=bool(p.get("flipNormals", False)))
+            try:
+                if t == "cube":
+                    meshes = meshio.make_cube(**kw)
+                else:
+                    path = self.r.resolve(p.get("filename"))
+                    if t == "obj":
+                        p.get("loadMaterials", True)
+                        meshes = meshio.load_obj(path, flip_tex_coords=bool(p.get("flipTexCoords", True)), collapse=bool(p.get("collapse", False)),
+                                                 shape_index=int(p.get("shapeIndex", -1)), **kw)
+                    elif t == "ply":
+                        p.get("srgb", True)
+                        meshes = meshio.load_ply(path, **kw)
+                    else:
+                        meshes = meshio.load_serialized(path, shape_index=int(p.get("shapeIndex", 0)), name=p.id, **kw)
+            except meshio.MeshError as e:
+                raise SceneError(str(e))
+            if not meshes:
+                raise SceneError(f"shape \"{t}\": no geometry found")
+            unnamed = [c for n, c in named if n == ""]
+            for m in meshes:
+                b = None
+                for n, c in named:                   # obj.cpp:734-760: a named BSDF goes to the meshes using that material, an unnamed one to all
+                    if n != "" and n == m.material:
+                        b = self.bsdf(c)
+                if b is None and unnamed:
+                    b = self.bsdf(unnamed[-1])
+                if b is None:
+                    b = self.default_bsdf()
+                si = self.add_mesh(m, b, group)
+                if radiance is not None:
+                    self.area.append((order, "mesh", si, radiance, weight))
+        elif t in ("rectangle", "disk", "sphere", "cylinder"):
+            if group:
+                raise SceneError("analytic shapes inside a shape group are not supported")
+            if len(named) > 1:
+                raise SceneError("a shape takes one BSDF")
+            b = self.bsdf(named[0][1]) if named else self.default_bsdf()
+            flip = bool(p.get("flipNormals", False))
+            m = np.eye(4) if tw is None else tw.astype(np.float64)
+            if t in ("rectangle", "disk"):
+                if flip:
+                    m = m @ S.scale(1.0, 1.0, -1.0)       # rectangle.cpp:82-83, disk.cpp:86-87
+                rec = S.make_analytic(S.SHAPE_RECTANGLE if t == "rectangle" else S.SHAPE_DISK, m, b)
+            elif t == "sphere":
+                c = p.get("center", np.zeros(3, f32)); radius = p.get("radius", 1.0)
+                o2w = S.translate(*map(float, c))
+                if tw is not None:                         # sphere.cpp:113-122: the scale moves from the transform into the radius
+                    s = float(np.linalg.norm(m[:3, 0]))
+                    o2w = m @ S.scale(1.0 / s) @ o2w; radius = float(f32(radius) * f32(s))
+                if radius <= 0:
+                    raise SceneError("Cannot create spheres of radius <= 0")
+                rec = S.make_analytic(S.SHAPE_SPHERE, o2w, b, flip=flip, radius=radius)
+            else:
+                p0 = p.get("p0", np.array([0, 0, 0], f32)); p1 = p.get("p1", np.array([0, 0, 1], f32)); radius = p.get("radius", 1.0)
+                base, length = S.cylinder_to_world(p0, p1)
+                o2w = base.astype(np.float64) @ S.scale(radius, radius, length)
+                if tw is not None:
+                    o2w = m @ o2w
+                r = float(np.linalg.norm(o2w[:3, 0])); l = float(np.linalg.norm(o2w[:3, 2]))      # cylinder.cpp:99-103
+                rec = S.make_analytic(S.SHAPE_CYLINDER, o2w @ S.scale(1.0 / r, 1.0 / r, 1.0 / l), b, flip=flip, radius=r, length=l)
+            self.analytic.append(rec)
+            if radiance is not None:
+                self.area.append((order, "analytic", len(self.analytic) - 1, radiance, weight))
+        else:
+            raise SceneError(f"shape plugin \"{t}\" is not supported (obj, ply, serialized, cube, rectangle, disk, sphere, cylinder, shapegroup, instance)")
+        p.check_all_used()
+
+    # -- scene-level emitters
+    def emitter(self, e):
+        t = e.type
+        w = e.get("samplingWeight", 1.0)
+        tw = e.get("toWorld", None)
+
+        def spec(name):
+            v = e.get(name, (1.0, 1.0, 1.0))
+            return (v,) * 3 if isinstance(v, float) else v
+        if t == "constant":
+            rec = S.constant_emitter(spec("radiance"), w)
+        elif t == "point":
+            if e.has("position"):
+                if tw is not None:
+                    raise SceneError("Only one of the parameters 'position' and 'toWorld' can be used!")       # point.cpp:62-65
+                tw = S.translate(*map(float, e.get("position"))).astype(f32)
+            rec = dict(type=S.EMITTER_POINT, shape=-1, radiance=tuple(map(float, spec("intensity"))), weight=float(w), to_world=np.eye(4, dtype=f32) if tw is None else tw)
+        elif t == "spot":
+            cutoff = e.get("cutoffAngle", 20.0)
+            if e.children_of("texture"):
+                raise SceneError("spot: projection textures are not supported")
+            rec = dict(type=S.EMITTER_SPOT, shape=-1, radiance=tuple(map(float, spec("intensity"))), weight=float(w), to_world=np.eye(4, dtype=f32) if tw is None else tw,
+                       cutoff=float(cutoff), beam=float(e.get("beamWidth", float(f32(cutoff) * f32(3.0) / f32(4.0)))))
+        elif t == "directional":
+            if e.has("direction"):
+                if tw is not None:
+                    raise SceneError("Only one of the parameters 'direction' and 'toWorld' can be used!")      # directional.cpp:59-62
+                rec = S.directional_emitter(e.get("direction"), spec("irradiance"), w)
+            else:
+                rec = dict(type=S.EMITTER_DIRECTIONAL, shape=-1, radiance=tuple(map(float, spec("irradiance"))), weight=float(w), to_world=np.eye(4, dtype=f32) if tw is None else tw)
+        elif t == "envmap":
+            if self.envmap is not None:
+                raise SceneError("The scene may only contain one environment emitter")          # scene.cpp:541-543
+            e.get("cache", True); e.get("gamma", 0.0)
+            img = load_image(self.r.resolve(e.get("filename")))
+            self.envmap = dict(rgb=img.astype(np.float16).astype(f32), to_world=np.eye(4, dtype=f32) if tw is None else tw, scale=float(e.get("scale", 1.0)))   # envmap.cpp:103: half-precision MIP map
+            rec = dict(type=S.EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=float(w))
+        elif t == "area":
+            raise SceneError("an area emitter must be nested in a shape")
+        else:
+            raise SceneError(f"emitter plugin \"{t}\" is not supported (area, constant, envmap, point, spot, directional)")
+        if t == "constant" and any(x["type"] in (S.EMITTER_CONSTANT, S.EMITTER_ENVMAP) for x in self.scene_emitters) or \
+           t == "envmap" and any(x["type"] == S.EMITTER_CONSTANT for x in self.scene_emitters):
+            raise SceneError("The scene may only contain one environment emitter")
+        e.check_all_used()
+        self.scene_emitters.append(rec)
+
+    # -- everything
+    def build(self, name):
+        root = self.root
+        integ = root.child("integrator")
+        if integ is None:
+            raise SceneError("the scene has no <integrator> (the reference would insert a direct-illumination integrator, which is not this path)")
+        if integ.type != "path":
+            raise SceneError(f"integrator \"{integ.type}\" is not supported: this framework implements the 'path' integrator (MIPathTracer)")
+        max_depth, rr_depth = int(integ.get("maxDepth", -1)), int(integ.get("rrDepth", 5))
+        strict, hide = bool(integ.get("strictNormals", False)), bool(integ.get("hideEmitters", False))
+        integ.check_all_used()
+        sensors = root.children_of("sensor")
+        if len(sensors) != 1:
+            raise SceneError("exactly one <sensor> is expected (the reference builds a default camera from the scene bounds; give one explicitly)")
+        sen = sensors[0][1]
+        if sen.type != "perspective":
+            raise SceneError(f"sensor \"{sen.type}\" is not supported (perspective)")
+        film = sen.child("film"); smp = sen.child("sampler")
+        width = int(film.get("width", 768)) if film is not None else 768
+        height = int(film.get("height", 576)) if film is not None else 576
+        filter_kind, f_radius, f_stddev = S.FILTER_GAUSSIAN, None, None       # Film: a gaussian filter unless the film names one (src/librender/film.cpp)
+        if film is not None:
+            if film.type not in ("hdrfilm", "ldrfilm", "mfilm", "tiledhdrfilm"):
+                raise SceneError(f"film \"{film.type}\" is not supported")
+            for k in ("cropOffsetX", "cropOffsetY", "cropWidth", "cropHeight"):
+                if film.has(k):
+                    raise SceneError("film crop windows are not supported")
+            for k in ("banner", "attachLog", "fileFormat", "pixelFormat", "channelNames", "componentFormat", "highQualityEdges", "gamma", "exposure", "tonemapMethod", "key", "burn"):
+                film.get(k)
+            rf = film.child("rfilter")
+            if rf is not None:
+                kinds = {"box": S.FILTER_BOX, "gaussian": S.FILTER_GAUSSIAN, "tent": S.FILTER_TENT, "mitchell": S.FILTER_MITCHELL, "catmullrom": S.FILTER_CATMULLROM, "lanczos": S.FILTER_LANCZOS}
+                if rf.type not in kinds:
+                    raise SceneError(f"reconstruction filter \"{rf.type}\" is not supported")
+                filter_kind = kinds[rf.type]
+                if rf.type == "box" and rf.has("radius"):
+                    f_radius = rf.get("radius")
+                if rf.type == "gaussian" and rf.has("stddev"):
+                    f_stddev = rf.get("stddev"); f_radius = 4.0 * f_stddev
+                if rf.type == "mitchell":
+                    f_radius, f_stddev = rf.get("B", 1.0 / 3.0), rf.get("C", 1.0 / 3.0)
+                if rf.type == "lanczos":
+                    f_radius = float(int(rf.get("lobes", 3)))
+                rf.check_all_used()
+            film.check_all_used()
+        sampler, spp, seed = S.SAMPLER_INDEPENDENT, 4, 0
+        if smp is not None:
+            if smp.type not in ("independent", "sobol"):
+                raise SceneError(f"sampler \"{smp.type}\" is not supported (independent, sobol)")
+            sampler = S.SAMPLER_SOBOL if smp.type == "sobol" else S.SAMPLER_INDEPENDENT
+            spp = int(smp.get("sampleCount", 4))
+            if smp.type == "sobol" and int(smp.get("scramble", 0)) != 0:
+                raise SceneError("sobol: only scramble = 0 is supported")
+            seed = int(smp.get("seed", 0)) if smp.type == "independent" else 0
+            smp.check_all_used()
+        aspect = width / height
+        if sen.has("fov") and sen.has("focalLength"):
+            raise SceneError("Please specify either a focal length ('focalLength') or a field of view ('fov')!")
+        def diag_to_x(d):
+            diagonal = 2.0 * math.tan(0.5 * math.radians(d)); w = diagonal / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+            return math.degrees(2.0 * math.atan(w * 0.5))
+        if sen.has("fov"):
+            fov = sen.get("fov"); axis = str(sen.get("fovAxis", "x")).lower()
+            if axis == "smaller":
+                axis = "y" if aspect > 1 else "x"
+            elif axis == "larger":
+                axis = "x" if aspect > 1 else "y"
+            if axis == "x":
+                xfov = fov
+            elif axis == "y":
+                xfov = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+            elif axis == "diagonal":
+                xfov = diag_to_x(fov)
+            else:
+                raise SceneError("The 'fovAxis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+        else:
+            fl = str(sen.get("focalLength", "50mm")); fl = fl[:-2] if fl.endswith("mm") else fl
+            try:
+                flv = float(fl)
+            except ValueError:
+                raise SceneError("Could not parse the focal length (must be of the form <x>mm, where <x> is a positive integer)!")
+            xfov = diag_to_x(2.0 * 180.0 / math.pi * math.atan(math.sqrt(36.0 * 36.0 + 24.0 * 24.0) / (2.0 * flv)))
+        xfov = float(f32(xfov))
+        if not (0 < xfov < 180):
+            raise SceneError("The horizontal field of view must be in the interval (0, 180)!")
+        near, far = sen.get("nearClip", 1e-2), sen.get("farClip", 1e4)
+        cam = sen.get("toWorld", np.eye(4, dtype=f32))
+        lin = cam[:3, :3].astype(np.float64)
+        if not np.allclose(lin.T @ lin, np.eye(3), atol=1e-3):
+            raise SceneError("Scale factors in the camera-to-world transformation are not allowed!")      # perspective.cpp:116-118
+        for k in ("shutterOpen", "shutterClose", "focusDistance"):
+            sen.get(k)
+        sen.check_all_used()
+
+        for _, c in root.children:       # scene-level BSDF definitions become materials in document order (the reference instantiates them as it parses)
+            if c.tag == "bsdf":
+                self.bsdf(c)
+        for _, c in root.children:
+            if c.tag == "shape":
+                self.shape(c)
+            elif c.tag == "emitter":
+                self.emitter(c)
+            elif c.tag in ("bsdf", "texture", "integrator", "sensor"):
+                pass                                    # definitions for later <ref>s; instantiated on use
+            elif c.tag in ("medium", "subsurface", "volume", "phase"):
+                raise SceneError(f"<{c.tag}>: participating media are outside the surface path tracer")
+            else:
+                raise SceneError(f"<{c.tag}> is not expected at scene level")
+        root.check_all_used()
+        if not self.shapes and not self.analytic and not self.instances:
+            raise SceneError("the scene contains no shapes")
+        emitters = list(self.scene_emitters)
+        for order, kind, idx, radiance, weight in sorted(self.area, key=lambda a: a[0]):
+            shape_index = idx if kind == "mesh" else len(self.shapes) + idx
+            emitters.append(dict(type=S.EMITTER_AREA, shape=shape_index, radiance=tuple(map(float, radiance)), weight=float(weight)))
+            (self.shapes[idx] if kind == "mesh" else self.analytic[idx])["emitter"] = len(emitters) - 1
+        if not emitters:
+            raise SceneError("the scene has no emitters (the reference would add a sun & sky environment, which this path does not implement)")
+        verts = np.concatenate(self.verts) if self.verts else np.zeros((0, 3), f32)
+        tris = np.concatenate(self.tris) if self.tris else np.zeros((0, 3), np.int64)
+        normals = uvs = None
+        if self.any_normals:
+            normals = np.concatenate([n if n is not None else np.zeros((len(v), 3), f32) for n, v in zip(self.normals, self.verts)])
+        if self.any_uv:
+            uvs = np.concatenate([u if u is not None else np.zeros((len(v), 2), f32) for u, v in zip(self.uvs, self.verts)])
+        sc = S.finish_scene(verts, tris, self.shapes, self.bsdfs, emitters, cam, xfov, near, far, width, height, spp, sampler, max_depth, rr_depth,
+                            filter_kind, seed, normals=normals, uvs=uvs, strict_normals=strict, hide_emitters=hide, envmap=self.envmap, name=name,
+                            analytic=self.analytic, instances=self.instances, textures=self.textures)
+        if f_radius is not None:
+            sc.filter_radius = float(f_radius)
+        if f_stddev is not None:
+            sc.filter_stddev = float(f_stddev)
+        return sc
+
+
+def load_scene(path, params=None):
+    """Read a scene XML file -> scenes.Scene.  `params`: values for $name placeholders (the reference's -D name=value)."""
+    if not os.path.exists(path):
+        raise SceneError(f"scene file \"{path}\" not found")
+    r = _Reader(path, params)
+    root_elem = r.read_file(path)
+    if root_elem.tag != "scene":
+        raise SceneError("the root element must be <scene>")
+    root = r.plugin(root_elem)
+    return _SceneBuilder(r, root).build(os.path.splitext(os.path.basename(path))[0])
+
+
+# ---- the other direction: a flattened scene written as XML + one .serialized file ---------------------------------------------------
+def export_scene(sc, directory, name=None, mesh_format="serialized"):
+    """Write `sc` (scenes.Scene) as <directory>/<name>.xml plus its meshes (one `.serialized` file with an offset dictionary, or one OBJ per
+    shape), in the reference's scene format: the BASELINE workloads can be handed to a full build of the reference this way, and
+    `load_scene` reads the result back.  Instances, bitmap textures and environment maps are not written."""
+    if sc.get("instances") or sc.get("envmap") is not None or any(t["type"] == S.TEXTURE_BITMAP for t in sc.get("textures") or []):
+        raise SceneError("export_scene: instances, environment maps and bitmap textures are not written")
+    name = name or sc.name
+    os.makedirs(directory, exist_ok=True)
+    fmt = lambda v: " ".join("%.9g" % float(x) for x in np.asarray(v, np.float64).reshape(-1))
+    rgb = lambda n, v: f'<rgb name="{n}" value="{fmt(v).replace(" ", ", ")}"/>'
+    mat = lambda n, m: f'<transform name="{n}"><matrix value="{fmt(m)}"/></transform>'
+    out = ['<?xml version="1.0" encoding="utf-8"?>', '<scene version="0.5.0">']
+    out.append(f'\t<integrator type="path"><integer name="maxDepth" value="{sc.max_depth}"/><integer name="rrDepth" value="{sc.rr_depth}"/>'
+               f'<boolean name="strictNormals" value="{str(bool(sc.strict_normals)).lower()}"/><boolean name="hideEmitters" value="{str(bool(sc.hide_emitters)).lower()}"/></integrator>')
+    filt = {S.FILTER_BOX: "box", S.FILTER_GAUSSIAN: "gaussian", S.FILTER_TENT: "tent", S.FILTER_MITCHELL: "mitchell", S.FILTER_CATMULLROM: "catmullrom", S.FILTER_LANCZOS: "lanczos"}[sc.filter]
+    fprops = {"box": f'<float name="radius" value="{fmt([sc.filter_radius])}"/>', "gaussian": f'<float name="stddev" value="{fmt([sc.filter_stddev])}"/>',
+              "mitchell": f'<float name="B" value="{fmt([sc.filter_radius])}"/><float name="C" value="{fmt([sc.filter_stddev])}"/>',
+              "lanczos": f'<integer name="lobes" value="{int(sc.filter_radius)}"/>'}.get(filt, "")
+    smp = "sobol" if sc.sampler == S.SAMPLER_SOBOL else "independent"
+    seed = f'<integer name="seed" value="{sc.seed}"/>' if smp == "independent" and sc.seed else ""
+    out.append(f'\t<sensor type="perspective"><float name="fov" value="{fmt([sc.xfov])}"/><string name="fovAxis" value="x"/>'
+               f'<float name="nearClip" value="{fmt([sc.near])}"/><float name="farClip" value="{fmt([sc.far])}"/>{mat("toWorld", sc.cam_to_world)}\n'
+               f'\t\t<sampler type="{smp}"><integer name="sampleCount" value="{sc.spp}"/>{seed}</sampler>\n'
+               f'\t\t<film type="hdrfilm"><integer name="width" value="{sc.width}"/><integer name="height" value="{sc.height}"/><boolean name="banner" value="false"/>'
+               f'<rfilter type="{filt}">{fprops}</rfilter></film>\n\t</sensor>')
+    distr = {S.DISTR_BECKMANN: "beckmann", S.DISTR_GGX: "ggx"}
+
+    def texture_xml(t, pname):
+        kind = "checkerboard" if t["type"] == S.TEXTURE_CHECKERBOARD else "gridtexture"
+        lw = f'<float name="lineWidth" value="{fmt([t["line_width"]])}"/>' if kind == "gridtexture" else ""
+        return (f'<texture type="{kind}" name="{pname}">{rgb("color0", t["color0"])}{rgb("color1", t["color1"])}{lw}<float name="uoffset" value="{fmt([t["uoffset"]])}"/>'
+                f'<float name="voffset" value="{fmt([t["voffset"]])}"/><float name="uscale" value="{fmt([t["uscale"]])}"/><float name="vscale" value="{fmt([t["vscale"]])}"/></texture>')
+    for i, b in enumerate(sc.bsdfs):
+        t = b["type"]; mf = f'<string name="distribution" value="{distr.get(b["distr"], "beckmann")}"/><float name="alpha" value="{fmt([b["alpha"]])}"/>'
+        sv = f'<boolean name="sampleVisible" value="{str(bool(b["sample_visible"] & 1)).lower()}"/>'
+        ior = f'<float name="intIOR" value="{fmt([b["eta"][0]])}"/><float name="extIOR" value="1"/>'
+        cond = f'{rgb("eta", b["eta"])}{rgb("k", b["k"])}<float name="extEta" value="1"/>{rgb("specularReflectance", b["specular"])}'
+        nl = f'<boolean name="nonlinear" value="{str(bool(b.get("nonlinear", 0))).lower()}"/>'
+        if t == S.BSDF_DIFFUSE:
+            inner = f'<bsdf type="diffuse">{texture_xml(sc.textures[b["texture"]], "reflectance") if b.get("texture", -1) >= 0 else rgb("reflectance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_ROUGHCONDUCTOR:
+            inner = f'<bsdf type="roughconductor">{mf}{sv}{cond}</bsdf>'
+        elif t == S.BSDF_CONDUCTOR:
+            inner = f'<bsdf type="conductor">{cond}</bsdf>'
+        elif t == S.BSDF_DIELECTRIC:
+            inner = f'<bsdf type="dielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_ROUGHDIELECTRIC:
+            inner = f'<bsdf type="roughdielectric">{mf}{sv}{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_PLASTIC:
+            inner = f'<bsdf type="plastic">{ior}{nl}{rgb("specularReflectance", b["specular"])}{rgb("diffuseReflectance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_ROUGHPLASTIC:
+            inner = f'<bsdf type="roughplastic">{mf}{sv}{ior}{nl}{rgb("specularReflectance", b["specular"])}{rgb("diffuseReflectance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_DIFFTRANS:
+            inner = f'<bsdf type="difftrans">{rgb("transmittance", b["reflectance"])}</bsdf>'
+        else:
+            raise SceneError(f"export_scene: material type {t}")
+        if b["twosided"]:
+            out.append(f'\t<bsdf type="twosided" id="bsdf{i}">{inner}</bsdf>')
+        else:
+            out.append("\t" + inner.replace(">", f' id="bsdf{i}">', 1))
+    area = {}
+    for e in sc.emitters:
+        w = f'<float name="samplingWeight" value="{fmt([e.get("weight", 1.0)])}"/>'
+        if e["type"] == S.EMITTER_AREA:
+            area[e["shape"]] = f'<emitter type="area">{rgb("radiance", e["radiance"])}{w}</emitter>'
+        elif e["type"] == S.EMITTER_CONSTANT:
+            out.append(f'\t<emitter type="constant">{rgb("radiance", e["radiance"])}{w}</emitter>')
+        elif e["type"] == S.EMITTER_POINT:
+            out.append(f'\t<emitter type="point">{rgb("intensity", e["radiance"])}{w}{mat("toWorld", e["to_world"])}</emitter>')
+        elif e["type"] == S.EMITTER_SPOT:
+            out.append(f'\t<emitter type="spot">{rgb("intensity", e["radiance"])}{w}<float name="cutoffAngle" value="{fmt([e["cutoff"]])}"/>'
+                       f'<float name="beamWidth" value="{fmt([e["beam"]])}"/>{mat("toWorld", e["to_world"])}</emitter>')
+        elif e["type"] == S.EMITTER_DIRECTIONAL:
+            out.append(f'\t<emitter type="directional">{rgb("irradiance", e["radiance"])}{w}{mat("toWorld", e["to_world"])}</emitter>')
+    meshes = []
+    for si, sh in enumerate(sc.shapes):
+        if sh.get("group", 0):
+            raise SceneError("export_scene: shape groups are not written")
+        v0, nv, t0, nt = sh["first_vert"], sh["vert_count"], sh["first_tri"], sh["tri_count"]
+        fn = bool(sh["face_normals"])
+        m = meshio.Mesh(f"shape{si}", sc.pos[v0:v0 + nv], sc.idx[t0:t0 + nt].astype(np.int64) - v0,
+                        None if (sc.nrm is None or fn) else sc.nrm[v0:v0 + nv], sc.uv[v0:v0 + nv] if (sc.uv is not None and sh.get("has_uv", 1)) else None, face_normals=fn)
+        meshes.append(m)
+        if mesh_format == "serialized":
+            src = f'<shape type="serialized"><string name="filename" value="{name}.serialized"/><integer name="shapeIndex" value="{si}"/>'
+        else:
+            meshio.save_obj(os.path.join(directory, f"{name}_shape{si}.obj"), m)
+            src = f'<shape type="obj"><string name="filename" value="{name}_shape{si}.obj"/><boolean name="flipTexCoords" value="false"/>'
+        out.append(f'\t{src}<boolean name="faceNormals" value="{str(fn).lower()}"/><ref id="bsdf{sh["bsdf"]}"/>{area.get(si, "")}</shape>')
+    if mesh_format == "serialized" and meshes:
+        meshio.save_serialized(os.path.join(directory, f"{name}.serialized"), meshes)
+    kinds = {S.SHAPE_RECTANGLE: "rectangle", S.SHAPE_DISK: "disk", S.SHAPE_SPHERE: "sphere", S.SHAPE_CYLINDER: "cylinder"}
+    for ai, a in enumerate(sc.get("analytic") or []):
+        k = kinds[a["type"]]; tw = a["to_world"].astype(np.float64)
+        extra = ""
+        if k == "sphere":
+            tw = tw @ S.scale(a["radius"])
+        elif k == "cylinder":
+            tw = tw @ S.scale(a["radius"], a["radius"], a["length"])
+        if k in ("sphere", "cylinder") and a["flags"] & 1:
+            extra = '<boolean name="flipNormals" value="true"/>'
+        out.append(f'\t<shape type="{k}">{mat("toWorld", tw)}{extra}<ref id="bsdf{a["bsdf"]}"/>{area.get(len(sc.shapes) + ai, "")}</shape>')
+    out.append("</scene>")
+    path = os.path.join(directory, f"{name}.xml")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    return path

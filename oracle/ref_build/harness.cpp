@@ -494,6 +494,20 @@ static void modeTables(const std::string &out) {
         for (size_t i = 0; i < 100; ++i) rt.push_back(ext->trans()[i]);
     }
     save(out + "/rough_transmittance_slices.npy", "<f4", {rt.size() / 104, 104}, rt);
+    {   // Spectrum::fromContinuousSpectrum (src/libcore/spectrum.cpp:172-185) applied to hat functions of half-width H nm centred every H nm over
+        // 360..830 nm: the linear map from a piecewise-linear spectrum (knots on that grid) to linear RGB that <spectrum value="wavelength:value, ...">
+        // goes through in an RGB build.  (Narrower hats are missed by the adaptive quadrature of ContinuousSpectrum::average, spectrum.cpp:546-568.)
+        const int H = getenv("MI_HAT") ? atoi(getenv("MI_HAT")) : 5;
+        std::vector<float> hat; size_t n = 0;
+        for (int c = 360; c <= 830; c += H, ++n) {
+            InterpolatedSpectrum sp(3);
+            sp.append((Float) (c - H), 0.0f); sp.append((Float) c, 1.0f); sp.append((Float) (c + H), 0.0f);
+            Spectrum rgbv; rgbv.fromContinuousSpectrum(sp);
+            Float r, g, b; rgbv.toLinearRGB(r, g, b);
+            hat.push_back(r); hat.push_back(g); hat.push_back(b);
+        }
+        save(out + "/spectrum_hat_response.npy", "<f4", {n, 3}, hat);
+    }
 }
 
 static uint64_t g_rays = 0, g_shadow = 0;
@@ -773,6 +787,16 @@ static void modeMesh(int argc, char **argv) {
     }
 }
 
+// <spectrum value="wl:value, ..."> as scenehandler.cpp:680-697 converts it (InterpolatedSpectrum, zeroExtend, fromContinuousSpectrum, clampNegative)
+static void modeSpectrum(int argc, char **argv) {
+    InterpolatedSpectrum sp((size_t) (argc - 2) / 2);
+    for (int i = 2; i + 1 < argc; i += 2) sp.append((Float) atof(argv[i]), (Float) atof(argv[i + 1]));
+    sp.zeroExtend();
+    Spectrum d; d.fromContinuousSpectrum(sp); d.clampNegative();
+    Float r, g, b; d.toLinearRGB(r, g, b);
+    printf("%.9g %.9g %.9g\n", r, g, b);
+}
+
 int main(int argc, char **argv) {
     Class::staticInitialization();
     Object::staticInitialization();
@@ -787,8 +811,9 @@ int main(int argc, char **argv) {
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
     Thread::getThread()->getFileResolver()->appendPath(fs::pathstr(MI_REF_ROOT));   // data/microfacet/*.dat, data/ior/*.spd (roughplastic, named conductors)
     if (argc >= 8 && std::string(argv[1]) == "mipmap") { modeMipmap(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7]); fflush(NULL); _exit(0); }
+    if (argc >= 6 && std::string(argv[1]) == "spectrum") { modeSpectrum(argc, argv); fflush(NULL); _exit(0); }
     if (argc >= 10 && std::string(argv[1]) == "mesh") { modeMesh(argc, argv); fflush(NULL); _exit(0); }
-    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | spectrum <wl value>... | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
     FScene fs = loadScene(argv[1]);

@@ -62,6 +62,9 @@ def golden_scenes():
         "textured_room": scenes.textured_room(width=96, height=64, spp=16),
         # bitmap textures: MIP pyramid (input data = the reference's own), EWA / trilinear / bilinear / nearest, wrap modes, ray differentials
         "bitmap_room": scenes.bitmap_room(width=96, height=64, spp=16),
+        # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
+        # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
+        "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
     }
 
 

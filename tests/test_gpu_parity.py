@@ -495,3 +495,43 @@ def test_full_size_other_configs(mi, config):
         r.run(tile=(0, k, sc.width, sc.height), s0=0, s1=spp, row_stride=2)
     inter = r.read_film(0)
     assert np.allclose(inter, full, rtol=1e-5, atol=1e-6)
+
+
+def test_scene_file_bunny(mi, oracle, golden_scenes, tmp_path):
+    """a scene FILE (tests/golden/meshes/bunny_box.xml: hand-written Mitsuba XML around the reference's own PLY test asset) read by
+    xml_scene / meshio and rendered by the HIP path: bit-exact against the oracle (diffuse + smooth dielectric, generated vertex normals on 69451
+    triangles -> BVH2 traversal), within float rounding of the reference's own render of the same flattened scene; then through the command line."""
+    import importlib
+    name = "bunny_box"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    rng = np.random.default_rng(5); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    assert (bits(got) == bits(ref)).all()
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
+    assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
+    assert np.allclose(film, ofilm, rtol=2e-6, atol=1e-7) and (st["rays"], st["shadow_rays"], st["path_length_sum"]) == tuple(int(c) for c in cnt)
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-3
+    # the command-line front end renders the same image (developed film = sums / weights)
+    render_cli = importlib.import_module("mitsuba-im_amd.render")
+    out = str(tmp_path / "bunny.npy")
+    assert render_cli.main([os.path.join(GOLDEN, "meshes", "bunny_box.xml"), "-o", out]) == 0
+    b = (film.shape[0] - sc.height) // 2
+    dev = film[b:b + sc.height, b:b + sc.width, :3] / film[b:b + sc.height, b:b + sc.width, 4:5]
+    np.testing.assert_allclose(np.load(out), dev, rtol=1e-6, atol=1e-7)
+    assert render_cli.main([str(tmp_path / "missing.xml")]) == 1
+
+
+def test_scene_file_round_trip_renders_identically(mi, tmp_path):
+    """export_scene -> load_scene: the HIP path renders the same film from the scene file as from the generator (Cornell box, serialized meshes)."""
+    import importlib
+    X = importlib.import_module("mitsuba-im_amd.xml_scene"); S = mi.scenes
+    sc = S.cornell_box(width=160, height=90, spp=8)
+    sc.xfov = float(np.float32(sc.xfov)); sc.sample_to_camera = S.sample_to_camera(sc.xfov, sc.near, sc.far, sc.width / sc.height)
+    sc2 = X.load_scene(X.export_scene(sc, str(tmp_path)))
+    films = []
+    for s in (sc, sc2):
+        r = mi.Render(mi.Scene(s)); r.run(); films.append(r.read_film(0))
+    assert (bits(films[0]) == bits(films[1])).all()

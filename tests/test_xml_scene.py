@@ -1,0 +1,209 @@
+"""Scene front end (mitsuba-im_amd/xml_scene.py): Mitsuba XML -> flattened scene.  The reference's own loader (src/librender/scenehandler.cpp)
+needs xerces-c and cannot be built here, so this layer is checked against (a) the conventions that file states, (b) the synthetic generators
+through export_scene -> load_scene round trips, with the oracle rendering both sides, (c) the reference's conversion of spectra
+(tests/golden/spectrum_rgb.npz, from oracle/_ref/harness `spectrum`)."""
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MESHES = os.path.join(HERE, "golden", "meshes")
+X = importlib.import_module("mitsuba-im_amd.xml_scene")
+S = importlib.import_module("mitsuba-im_amd.scenes")
+
+GENERATORS = ["cornell_box", "cbox_shapes", "cbox_materials", "cbox_lights", "open_constant", "cbox_translucent", "cbox_roughplastic", "textured_room",
+              "shape_lights", "veach_mis"]
+
+
+def assert_same_scene(a, b, exact_analytic=False):
+    np.testing.assert_array_equal(a.pos[a.idx.astype(np.int64)], b.pos[b.idx.astype(np.int64)])
+    if a.nrm is not None:
+        for sa, sb in zip(a.shapes, b.shapes):
+            if not sa["face_normals"]:
+                ia = a.idx[sa["first_tri"]:sa["first_tri"] + sa["tri_count"]].astype(np.int64); ib = b.idx[sb["first_tri"]:sb["first_tri"] + sb["tri_count"]].astype(np.int64)
+                np.testing.assert_allclose(a.nrm[ia], b.nrm[ib], rtol=0, atol=1.5e-7)       # the OBJ reader re-normalises (obj.cpp:658-660)
+    for k in ("width", "height", "spp", "sampler", "max_depth", "rr_depth", "strict_normals", "hide_emitters", "filter", "seed"):
+        assert a[k] == b[k], k
+    assert a.filter_radius == pytest.approx(b.filter_radius) and a.filter_stddev == pytest.approx(b.filter_stddev)
+    np.testing.assert_array_equal(a.cam_to_world, b.cam_to_world)
+    np.testing.assert_allclose(a.sample_to_camera, b.sample_to_camera, rtol=3e-7, atol=1e-9)      # the file holds the field of view as a float32 (like the reference's m_xfov)
+    assert len(a.shapes) == len(b.shapes) and len(a.bsdfs) == len(b.bsdfs) and len(a.emitters) == len(b.emitters)
+    for sa, sb in zip(a.shapes, b.shapes):
+        for k in ("first_tri", "tri_count", "bsdf", "emitter", "face_normals"):
+            assert sa[k] == sb[k], k
+    for ba, bb in zip(a.bsdfs, b.bsdfs):
+        for k in ("type", "twosided", "distr", "texture"):
+            assert ba[k] == bb[k], (k, ba, bb)
+        assert (ba["sample_visible"] & 1) == (bb["sample_visible"] & 1) or ba["type"] not in (S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHDIELECTRIC, S.BSDF_ROUGHPLASTIC)
+        for k in ("reflectance", "specular", "eta", "k"):
+            np.testing.assert_allclose(ba[k], bb[k], rtol=2e-7, atol=0, err_msg=k)
+        assert ba["alpha"] == pytest.approx(bb["alpha"], rel=1e-7)
+    for ea, eb in zip(a.emitters, b.emitters):
+        assert ea["type"] == eb["type"] and ea["shape"] == eb["shape"]
+        np.testing.assert_allclose(ea["radiance"], eb["radiance"], rtol=1e-7)
+        if "to_world" in ea:
+            np.testing.assert_allclose(ea["to_world"], eb["to_world"], rtol=0, atol=1e-6)
+    assert len(a.analytic) == len(b.analytic)
+    for xa, xb in zip(a.analytic, b.analytic):
+        assert xa["type"] == xb["type"] and xa["bsdf"] == xb["bsdf"] and xa["emitter"] == xb["emitter"] and xa["flags"] == xb["flags"]
+        np.testing.assert_allclose(xa["to_world"], xb["to_world"], rtol=0, atol=2e-5 * max(1.0, float(np.abs(xa["to_world"]).max())))
+        assert xa["radius"] == pytest.approx(xb["radius"], rel=1e-6) and xa["length"] == pytest.approx(xb["length"], rel=1e-6)
+    assert len(a.textures) == len(b.textures)
+    for ta, tb in zip(a.textures, b.textures):
+        for k in ("type", "color0", "color1", "uoffset", "voffset", "uscale", "vscale"):
+            assert ta[k] == pytest.approx(tb[k]), k
+
+
+@pytest.mark.parametrize("gen", GENERATORS)
+@pytest.mark.parametrize("fmt", ["serialized", "obj"])
+def test_export_load_round_trip(gen, fmt, tmp_path):
+    sc = getattr(S, gen)(width=48, height=32, spp=4)
+    path = X.export_scene(sc, str(tmp_path), mesh_format=fmt)
+    assert_same_scene(sc, X.load_scene(path))
+
+
+def test_round_trip_renders_identically_in_the_oracle(tmp_path):
+    """The loaded scene is not just field-equal: the oracle traces the same image from it (Cornell box: bit-identical film)."""
+    import oracle
+    oracle.build()
+    def f32_fov(sc):       # the generators keep the field of view in double; a scene file (and the reference's camera) holds a float32
+        sc.xfov = float(np.float32(sc.xfov)); sc.sample_to_camera = S.sample_to_camera(sc.xfov, sc.near, sc.far, sc.width / sc.height); return sc
+    sc = f32_fov(S.cornell_box(width=40, height=30, spp=4))
+    sc2 = X.load_scene(X.export_scene(sc, str(tmp_path)))
+    np.testing.assert_array_equal(sc.sample_to_camera, sc2.sample_to_camera)
+    a = oracle.Oracle(sc).render_image(threads=4)[0]; b = oracle.Oracle(sc2).render_image(threads=4)[0]
+    np.testing.assert_array_equal(a, b)
+    sc = f32_fov(S.cbox_materials(width=40, height=30, spp=4))
+    sc2 = X.load_scene(X.export_scene(sc, str(tmp_path), name="m"))
+    a = oracle.Oracle(sc).render_image(threads=4)[0]; b = oracle.Oracle(sc2).render_image(threads=4)[0]
+    assert np.linalg.norm(a - b) / np.linalg.norm(a) < 2e-2          # analytic transforms are re-derived (sphere scale split): paths may diverge at edges
+
+
+def test_spectrum_conversion_matches_reference():
+    g = np.load(os.path.join(HERE, "golden", "spectrum_rgb.npz"))
+    for i in range(int(g["n"])):
+        pairs = g[f"pairs{i}"]
+        mine = X.spectrum_to_rgb([(w, v) for w, v in pairs])
+        np.testing.assert_allclose(mine, g[f"rgb{i}"], rtol=float(g[f"tol{i}"]), atol=1e-5)
+    assert X.srgb_to_linear(0.0) == 0.0 and X.srgb_to_linear(1.0) == pytest.approx(1.0, rel=1e-6)
+    assert X.srgb_to_linear(0.5) == pytest.approx(0.21404114, rel=1e-5) and X.srgb_to_linear(0.03) == pytest.approx(0.03 / 12.92, rel=1e-6)
+
+
+def test_bunny_box_scene_file():
+    """Hand-written scene around the reference's own test asset: <default>/$name, lookat, fovAxis, spectra, refs, named IORs, PLY."""
+    sc = X.load_scene(os.path.join(MESHES, "bunny_box.xml"), params={"spp": 8})
+    assert (sc.width, sc.height, sc.spp, sc.max_depth, sc.rr_depth) == (128, 96, 8, 6, 4)
+    assert sc.sampler == S.SAMPLER_SOBOL and sc.filter == S.FILTER_BOX
+    # fovAxis "smaller" on a 4:3 film = the y axis (sensor.cpp:243-246): xfov = 2 atan(tan(19 deg) * 4/3)
+    assert sc.xfov == pytest.approx(math.degrees(2 * math.atan(math.tan(math.radians(19.0)) * 128 / 96)), rel=1e-6)
+    assert len(sc.idx) == 69451 and len(sc.pos) == 35947 and sc.nrm is not None and not sc.shapes[0]["face_normals"]
+    assert len(sc.analytic) == 7 and [a["type"] for a in sc.analytic] == [S.SHAPE_RECTANGLE] * 5 + [S.SHAPE_SPHERE, S.SHAPE_RECTANGLE]
+    assert sc.analytic[5]["radius"] == pytest.approx(0.03) and np.allclose(sc.analytic[5]["to_world"][:3, 3], [0.1, 0.063, 0.05])
+    assert len(sc.emitters) == 1 and sc.emitters[0]["shape"] == len(sc.shapes) + 6 and sc.analytic[6]["emitter"] == 0
+    glass = sc.bsdfs[sc.analytic[5]["bsdf"]]
+    assert glass["type"] == S.BSDF_DIELECTRIC and glass["eta"][0] == pytest.approx(1.5046 / 1.000277, rel=1e-6)
+    red = sc.bsdfs[sc.analytic[3]["bsdf"]]["reflectance"]
+    assert red == pytest.approx([X.srgb_to_linear(0xa8 / 255), X.srgb_to_linear(0x20 / 255), X.srgb_to_linear(0x18 / 255)], rel=1e-6)
+    # camera: lookat(origin, target, up) puts the origin in the last column and looks down +z
+    np.testing.assert_allclose(sc.cam_to_world[:3, 3], [0, 0.11, 0.42], atol=1e-7)
+    d = np.array([-0.015, 0.1, 0]) - np.array([0, 0.11, 0.42]); np.testing.assert_allclose(sc.cam_to_world[:3, 2], d / np.linalg.norm(d), atol=1e-6)
+    assert X.load_scene(os.path.join(MESHES, "bunny_box.xml")).spp == 16          # the <default>
+
+
+MINIMAL = """<scene version="0.5.0"><integrator type="path"/>
+<sensor type="perspective">{sensor}<film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="32"/>{film}</film></sensor>
+{body}
+<shape type="rectangle"><emitter type="area"><spectrum name="radiance" value="3"/></emitter></shape></scene>"""
+
+
+def load_text(tmp_path, text, **kw):
+    p = tmp_path / "s.xml"; p.write_text(text)
+    return X.load_scene(str(p), **kw)
+
+
+def test_defaults_and_conventions(tmp_path):
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=""))
+    # plugin defaults: integrator.cpp:193-219, sensor.cpp:157-159, sampler plugins (4 samples), film.cpp:89-92 (gaussian filter), shape.cpp (diffuse 0.5)
+    assert (sc.max_depth, sc.rr_depth, sc.strict_normals, sc.hide_emitters) == (-1, 5, 0, 0)
+    assert (sc.near, sc.far, sc.spp, sc.sampler, sc.filter) == (pytest.approx(1e-2), pytest.approx(1e4), 4, S.SAMPLER_INDEPENDENT, S.FILTER_GAUSSIAN)
+    assert sc.bsdfs[0]["type"] == S.BSDF_DIFFUSE and sc.bsdfs[0]["reflectance"] == (0.5, 0.5, 0.5)
+    assert sc.emitters[0]["radiance"] == (3.0, 3.0, 3.0)
+    # default focal length 50mm on a 36x24 sensor diagonal (sensor.cpp:264-277), aspect 2
+    diag = 2 * math.atan(math.sqrt(36 ** 2 + 24 ** 2) / 100.0); w = 2 * math.tan(diag / 2) / math.sqrt(1 + 1 / 4.0)
+    assert sc.xfov == pytest.approx(math.degrees(2 * math.atan(w / 2)), rel=1e-6)
+    sc = load_text(tmp_path, MINIMAL.format(sensor='<float name="fov" value="40"/><string name="fovAxis" value="diagonal"/>', film='<rfilter type="mitchell"><float name="B" value="0.2"/></rfilter>', body=""))
+    w = 2 * math.tan(math.radians(20)) / math.sqrt(1 + 1 / 4.0)
+    assert sc.xfov == pytest.approx(math.degrees(2 * math.atan(w / 2)), rel=1e-6)
+    assert sc.filter == S.FILTER_MITCHELL and sc.filter_radius == pytest.approx(0.2) and sc.filter_stddev == pytest.approx(1 / 3)
+    # transforms compose left to right in document order, each multiplying from the left (scenehandler.cpp:432-447)
+    body = '<shape type="sphere"><transform name="toWorld"><scale value="2"/><translate x="1"/><rotate z="1" angle="90"/></transform><float name="radius" value="0.5"/></shape>'
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
+    sph = sc.analytic[0]
+    assert sph["radius"] == pytest.approx(1.0) and np.allclose(sph["to_world"][:3, 3], [0, 1, 0], atol=1e-6)      # scale moved into the radius (sphere.cpp:113-122)
+    # emitter order: scene-level emitters first in document order, then area lights in shape order (scene.cpp:527-547, :589-623)
+    body = ('<shape type="disk"><emitter type="area"><rgb name="radiance" value="1,2,3"/></emitter></shape><emitter type="point"><point name="position" x="1" y="2" z="3"/></emitter>'
+            '<emitter type="constant"><spectrum name="radiance" value="0.5"/></emitter>')
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
+    assert [e["type"] for e in sc.emitters] == [S.EMITTER_POINT, S.EMITTER_CONSTANT, S.EMITTER_AREA, S.EMITTER_AREA]
+    assert sc.emitters[2]["radiance"] == (1.0, 2.0, 3.0) and sc.analytic[0]["emitter"] == 2 and sc.analytic[1]["emitter"] == 3
+    np.testing.assert_array_equal(sc.emitters[0]["to_world"][:3, 3], [1, 2, 3])
+
+
+def test_obj_materials_groups_and_instances(tmp_path):
+    (tmp_path / "two.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nusemtl a\nf 1 2 3\nusemtl b\nf 1 2 4\n")
+    body = ('<bsdf type="diffuse" id="A"><rgb name="reflectance" value="0.1"/></bsdf>'
+            '<shape type="obj"><string name="filename" value="two.obj"/><ref name="a" id="A"/><bsdf name="b" type="conductor"><string name="material" value="Au"/></bsdf></shape>'
+            '<shape type="shapegroup" id="grp"><shape type="cube"><ref id="A"/></shape></shape>'
+            '<shape type="instance"><ref id="grp"/><transform name="toWorld"><translate x="5"/></transform></shape>'
+            '<shape type="instance"><ref id="grp"/></shape>')
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
+    assert [sh["group"] for sh in sc.shapes] == [0, 0, 1] and [sh["tri_count"] for sh in sc.shapes] == [1, 1, 12]
+    assert sc.bsdfs[sc.shapes[0]["bsdf"]]["reflectance"] == pytest.approx((0.1, 0.1, 0.1)) and sc.bsdfs[sc.shapes[1]["bsdf"]]["type"] == S.BSDF_CONDUCTOR
+    eta, k = S.CONDUCTOR_IOR["Au"]
+    np.testing.assert_allclose(sc.bsdfs[sc.shapes[1]["bsdf"]]["eta"], np.float32(eta) / np.float32(1.000277), rtol=1e-6)       # conductor.cpp:176: divided by extEta (air)
+    assert sc.shapes[2]["bsdf"] == sc.shapes[0]["bsdf"]                        # one <ref>erenced BSDF = one material
+    assert len(sc.instances) == 2 and sc.instances[0]["to_world"][0, 3] == 5 and sc.instances[0]["group"] == 0
+
+
+@pytest.mark.parametrize("text,msg", [
+    (MINIMAL.format(sensor="", film="", body='<shape type="hair"><string name="filename" value="x"/></shape>'), 'shape plugin "hair" is not supported'),
+    (MINIMAL.format(sensor="", film="", body='<shape type="sphere"><bsdf type="phong"/></shape>'), 'BSDF plugin "phong" is not supported'),
+    (MINIMAL.format(sensor="", film="", body='<shape type="sphere"><float name="radus" value="1"/></shape>'), "unused or unsupported property radus"),
+    (MINIMAL.format(sensor="", film="", body='<shape type="sphere"><float name="radius" value="$r"/></shape>'), "undefined parameter"),
+    (MINIMAL.format(sensor="", film="", body='<shape type="sphere"><ref id="nope"/></shape>'), "Referenced object 'nope' not found"),
+    (MINIMAL.format(sensor="", film="", body='<shape type="obj"><string name="filename" value="missing.obj"/></shape>'), "could not be found"),
+    (MINIMAL.format(sensor="", film="", body='<foo/>'), 'Unhandled tag "foo"'),
+    (MINIMAL.format(sensor='<float name="fov" value="30"/><string name="focalLength" value="35mm"/>', film="", body=""), "either a focal length"),
+    (MINIMAL.format(sensor='<transform name="toWorld"><scale value="2"/></transform>', film="", body=""), "Scale factors in the camera-to-world"),
+    (MINIMAL.format(sensor="", film="", body='<emitter type="sunsky"/>'), 'emitter plugin "sunsky" is not supported'),
+    (MINIMAL.format(sensor="", film="", body='<medium type="homogeneous" id="m"/>'), "participating media"),
+    (MINIMAL.replace('type="path"', 'type="bdpt"').format(sensor="", film="", body=""), 'integrator "bdpt" is not supported'),
+    (MINIMAL.format(sensor="", film="", body='<shape type="sphere"><transform name="toWorld"><scale x="1" value="2"/></transform></shape>'), "both xyz and value"),
+    ("<scene version='0.5.0'><integrator type='path'/><sensor type='perspective'/><shape type='sphere'/></scene>", "no emitters"),
+    ("<scene", "XML parse error"),
+])
+def test_errors_name_the_problem(tmp_path, text, msg):
+    with pytest.raises(X.SceneError, match=msg):
+        load_text(tmp_path, text)
+
+
+def test_images_for_environment_maps(tmp_path):
+    img = (np.arange(4 * 8 * 3, dtype=np.float32).reshape(4, 8, 3) / 7.0)
+    np.save(tmp_path / "e.npy", img)
+    with open(tmp_path / "e.pfm", "wb") as f:
+        f.write(b"PF\n8 4\n-1.0\n"); f.write(img[::-1].astype("<f4").tobytes())
+    np.testing.assert_array_equal(X.load_image(str(tmp_path / "e.npy")), img)
+    np.testing.assert_array_equal(X.load_image(str(tmp_path / "e.pfm")), img)
+    # Radiance RGBE, flat scanlines: (128, 64, 32, 129) = (1.0, 0.5, 0.25)
+    with open(tmp_path / "e.hdr", "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 2\n"); f.write(bytes([128, 64, 32, 129] * 4))
+    np.testing.assert_allclose(X.load_image(str(tmp_path / "e.hdr")), np.tile([1.0, 0.5, 0.25], (2, 2, 1)), rtol=1e-6)
+    with pytest.raises(X.SceneError, match="not readable"):
+        X.load_image(str(tmp_path / "e.exr"))
+    body = '<emitter type="envmap"><string name="filename" value="e.pfm"/><float name="scale" value="2"/></emitter>'
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
+    assert sc.envmap["scale"] == 2.0 and sc.envmap["rgb"].shape == (4, 8, 3) and sc.emitters[0]["type"] == S.EMITTER_ENVMAP
+    np.testing.assert_array_equal(sc.envmap["rgb"], img.astype(np.float16).astype(np.float32))
