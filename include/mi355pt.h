@@ -151,6 +151,10 @@ int mi_scene_set_texture_data(mi_scene *s, const uint32_t *levels, uint32_t n_le
 int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n);   /* float tables the materials refer to by offset (roughplastic) */
 int mi_scene_set_emitters(mi_scene *s, const mi_emitter *emitters, uint32_t n);    /* Scene::getEmitters order; samplingWeight in .weight */
 int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, const float *to_world16, float scale);
+/* MIP pyramid of the environment map = record `texture` of mi_scene_set_textures (type bitmap, u repeats, v clamps, EWA, anisotropy 10: the settings of
+ * src/emitters/envmap.cpp:144-145, 182-185; level 0 = the map itself): camera rays that leave the scene then get the filtered lookup of
+ * EnvironmentMap::evalEnvironment (envmap.cpp:398-411).  -1 (default): level-0 bilinear lookups for them as for every other ray */
+int mi_scene_set_envmap_filter(mi_scene *s, int32_t texture);
 /* PerspectiveCameraImpl: m_sampleToCamera, world transform, clip planes (src/sensors/perspective.cpp:126-178) */
 int mi_scene_set_camera(mi_scene *s, const float *sample_to_camera16, const float *to_world16, float near_clip, float far_clip);
 /* Film crop size + reconstruction filter (src/librender/film.cpp:92; src/rfilters/*.cpp): kind 0 box(radius), 1 gaussian(stddev), 2 tent,

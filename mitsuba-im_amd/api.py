@@ -63,7 +63,7 @@ class MiStats(C.Structure):
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
-           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_envmap_filter", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays"]
@@ -97,6 +97,7 @@ class Lib:
         L.mi_scene_set_materials.argtypes = [vp, vp, u32]
         L.mi_scene_set_emitters.argtypes = [vp, vp, u32]
         L.mi_scene_set_envmap.argtypes = [vp, vp, u32, u32, vp, f32]
+        L.mi_scene_set_envmap_filter.argtypes = [vp, C.c_int32]
         L.mi_scene_set_camera.argtypes = [vp, vp, vp, f32, f32]
         L.mi_scene_set_film.argtypes = [vp, u32, u32, u32, f32, f32]
         L.mi_scene_commit.argtypes = [vp, u32]
@@ -201,6 +202,8 @@ class Scene:
         if sc.envmap is not None:
             rgb = np.ascontiguousarray(sc.envmap["rgb"], np.float32); tw = np.ascontiguousarray(sc.envmap["to_world"], np.float32)
             L.check(L.L.mi_scene_set_envmap(h, _p(rgb), rgb.shape[1], rgb.shape[0], _p(tw), float(sc.envmap["scale"])))
+            if sc.get("env_texture", 0):
+                L.check(L.L.mi_scene_set_envmap_filter(h, int(sc.env_texture) - 1))
         s2c = np.ascontiguousarray(sc.sample_to_camera, np.float32); c2w = np.ascontiguousarray(sc.cam_to_world, np.float32)
         L.check(L.L.mi_scene_set_camera(h, _p(s2c), _p(c2w), sc.near, sc.far))
         L.check(L.L.mi_scene_set_film(h, sc.width, sc.height, sc.filter, sc.filter_radius, sc.filter_stddev))

@@ -35,7 +35,7 @@ MTS_NAMESPACE_BEGIN
 namespace {
 
 struct FlatScene {
-    std::vector<float> uv; bool anyUV = false; std::vector<mi_texture> textures; std::vector<uint32_t> texLevels; std::vector<float> texTexels;
+    std::vector<float> uv; bool anyUV = false; std::vector<mi_texture> textures; std::vector<uint32_t> texLevels; std::vector<float> texTexels; int32_t envTexture = -1;
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
     std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances; std::vector<float> materialTables;
     bool anyNormals = false;
@@ -366,6 +366,24 @@ static void flatten(const Scene *scene, FlatScene &fs) {
             else SLog(EError, "path_hip: unexpected environment bitmap component format");
             Matrix4x4 tw = em->getWorldTransform()->eval(0.0f).getMatrix(); for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) fs.envToWorld[i * 4 + j] = tw(i, j);
             fs.envScale = em->getProperties().getFloat("scale", 1.0f);
+            {   // MIP pyramid for the filtered camera-ray lookups (envmap.cpp:398-411), built by the reference's own TMIPMap with the settings of envmap.cpp:144-145,
+                // 182-185 from level 0 (the map's own pyramid is a private member; its level 0 is what getBitmap returns, already rounded to half precision)
+                ref<Bitmap> f32bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i((int) fs.envW, (int) fs.envH));
+                memcpy(f32bmp->getFloat32Data(), fs.envRGB.data(), n * sizeof(float));
+                Properties rp("lanczos"); rp.setInteger("lobes", 2);
+                ref<ReconstructionFilter> rf = static_cast<ReconstructionFilter *>(PluginManager::getInstance()->createObject(MTS_CLASS(ReconstructionFilter), rp)); rf->configure();
+                typedef TSpectrum<Float, 3> Color3; typedef TSpectrum<half, 3> Color3h;
+                ref<TMIPMap<Color3, Color3h> > mip = new TMIPMap<Color3, Color3h>(f32bmp, Bitmap::ERGB, Bitmap::EFloat, rf, ReconstructionFilter::ERepeat, ReconstructionFilter::EClamp,
+                                                                                 EEWA, 10.0f, fs::pathstr(), 0, std::numeric_limits<Float>::infinity(), Spectrum::EIlluminant);
+                mi_texture t; memset(&t, 0, sizeof(t)); t.type = MI_TEXTURE_BITMAP; t.uscale = t.vscale = 1.0f; t.wrap_u = 1; t.wrap_v = 0; t.filter = 3; t.max_anisotropy = 10.0f;
+                t.first_level = (uint32_t) (fs.texLevels.size() / 3); t.n_levels = (uint32_t) mip->getLevels();
+                for (int l = 0; l < mip->getLevels(); ++l) {
+                    ref<Bitmap> lb = mip->toBitmap(l); const half *hp = lb->getFloat16Data(); const size_t ln = (size_t) lb->getWidth() * lb->getHeight() * 3;
+                    fs.texLevels.push_back((uint32_t) lb->getWidth()); fs.texLevels.push_back((uint32_t) lb->getHeight()); fs.texLevels.push_back((uint32_t) fs.texTexels.size());
+                    for (size_t i = 0; i < ln; ++i) fs.texTexels.push_back((float) hp[i]);
+                }
+                fs.envTexture = (int32_t) fs.textures.size(); fs.textures.push_back(t);
+            }
             mi_emitter me; memset(&me, 0, sizeof(me)); me.type = MI_EMITTER_ENVMAP; me.shape = -1; me.weight = em->getSamplingWeight();
             fs.emitters.push_back(me); continue;
         }
@@ -422,6 +440,7 @@ struct GpuScene {
         if (!fs.materialTables.empty()) MI_CHECK(mi_scene_set_material_tables(scene, fs.materialTables.data(), (uint32_t) fs.materialTables.size()));
         MI_CHECK(mi_scene_set_emitters(scene, fs.emitters.data(), (uint32_t) fs.emitters.size()));
         if (fs.envW) MI_CHECK(mi_scene_set_envmap(scene, fs.envRGB.data(), fs.envW, fs.envH, fs.envToWorld, fs.envScale));
+        if (fs.envTexture >= 0) MI_CHECK(mi_scene_set_envmap_filter(scene, fs.envTexture));
         // camera: rebuild m_sampleToCamera exactly as PerspectiveCameraImpl::configure does (perspective.cpp:150-157); it is a protected member
         if (!sensor->getClass()->derivesFrom(MTS_CLASS(PerspectiveCamera))) SLog(EError, "path_hip: only the perspective camera is implemented");
         const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);

@@ -18,6 +18,7 @@ void mi_upload_packet(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, 
 void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
+void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_film_layout(const float *, const float *, float *, int, int, int, int, hipStream_t);
 void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float *, hipStream_t);
 void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, int *, hipStream_t);
@@ -30,6 +31,7 @@ void mi_upload_packet_fast(const TriAccelD *, uint32_t, const AnalyticD *, uint3
 void mi_launch_shade_fast(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow_fast(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film_fast(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
+void mi_launch_env_primary_fast(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 }
 struct LaunchSet {
     void (*generate)(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
@@ -38,9 +40,10 @@ struct LaunchSet {
     void (*shade)(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
     void (*shadow)(const DScene &, const Queues &, uint32_t, hipStream_t);
     void (*film)(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
+    void (*envPrimary)(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 };
-static const LaunchSet kPrecise = {mi_launch_generate, mi_launch_extend, mi_upload_packet, mi_launch_shade, mi_launch_shadow, mi_launch_film};
-static const LaunchSet kFast = {mi_launch_generate_fast, mi_launch_extend_fast, mi_upload_packet_fast, mi_launch_shade_fast, mi_launch_shadow_fast, mi_launch_film_fast};
+static const LaunchSet kPrecise = {mi_launch_generate, mi_launch_extend, mi_upload_packet, mi_launch_shade, mi_launch_shadow, mi_launch_film, mi_launch_env_primary};
+static const LaunchSet kFast = {mi_launch_generate_fast, mi_launch_extend_fast, mi_upload_packet_fast, mi_launch_shade_fast, mi_launch_shadow_fast, mi_launch_film_fast, mi_launch_env_primary_fast};
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -147,6 +150,11 @@ int mi_scene_set_texture_data(mi_scene *s, const uint32_t *levels, uint32_t nLev
         if (!levels[i * 3] || !levels[i * 3 + 1] || (uint64_t) levels[i * 3 + 2] + (uint64_t) levels[i * 3] * levels[i * 3 + 1] * 3 > nTexels) return fail(MI_ERR_INVALID, "mi_scene_set_texture_data: MIP level outside the texel buffer");
     s->h.texLevels.assign(levels, levels + (size_t) nLevels * 3); s->h.texTexels.assign(texels, texels + nTexels); s->h.committed = false; return MI_OK;
 }
+int mi_scene_set_envmap_filter(mi_scene *s, int32_t texture) {
+    if (!s) return fail(MI_ERR_INVALID, "mi_scene_set_envmap_filter: null argument");
+    if (texture < -1) return fail(MI_ERR_INVALID, "mi_scene_set_envmap_filter: texture index must be >= -1");
+    s->h.envTexture = texture; s->h.committed = false; return MI_OK;
+}
 int mi_scene_set_material_tables(mi_scene *s, const float *data, uint32_t n) {
     if (!s || (n && !data)) return fail(MI_ERR_INVALID, "mi_scene_set_material_tables: null argument");
     s->h.materialTables.assign(data, data + n); s->h.committed = false; return MI_OK;
@@ -247,9 +255,11 @@ int SceneHost::upload(int dev) {
         float p0[3], px[3], py[3]; pt(0.0f, 0.0f, p0); pt(irx, 0.0f, px); pt(0.0f, iry, py);
         for (int i = 0; i < 3; ++i) { d.cam_dx[i] = px[i] - p0[i]; d.cam_dy[i] = py[i] - p0[i]; }
     }
-    d.material_tables = (const float *) dMaterialTables; d.triuv = (const TriUV *) dTriUV; d.textures = (const TextureD *) dTextures; d.n_textures = (uint32_t) textures.size();
+    d.material_tables = (const float *) dMaterialTables; d.triuv = (const TriUV *) dTriUV; d.textures = (const TextureD *) dTextures;
+    bool matTextures = false; for (const auto &m : mats) if ((m.flags >> 8) & 0xFFFFu) matTextures = true;
+    d.n_textures = matTextures ? (uint32_t) textures.size() : 0u; d.env_texture = envTexture >= 0 ? (uint32_t) envTexture + 1u : 0u;
     d.instances = (const InstanceD *) dInstances; d.n_instances = (uint32_t) instancesD.size();
-    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters || anyUV || !textures.empty()) ? 1u : 0u;
+    d.emitter_x = (const float *) dEmitterX; d.env_constant = envConstant ? 1u : 0u; d.ext = (!analyticD.empty() || !instancesD.empty() || hasDeltaEmitters || anyUV || matTextures) ? 1u : 0u;
     memcpy(d.dir_bs_center, dirBsCenter, 12); d.dir_bs_radius = dirBsRadius;
     d.n_tris = nTris; d.n_nodes = (uint32_t) nodes.size(); d.n_emitters = (uint32_t) emittersD.size(); d.n_materials = (uint32_t) mats.size();
     d.emitter_norm = emitterNorm;
@@ -296,6 +306,13 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
             (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
         if (tex && (tex > s->h.textures.size() || m.type != MI_BSDF_DIFFUSE)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to the reflectance of `diffuse` BSDFs only (and must exist)");
+    }
+    if (s->h.envTexture >= 0) {       // MIP pyramid of the environment map (camera-ray lookups, envmap.cpp:398-411)
+        if (!s->h.envW) return fail(MI_ERR_INVALID, "mi_scene_commit: mi_scene_set_envmap_filter without an environment map");
+        if ((size_t) s->h.envTexture >= s->h.textures.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: mi_scene_set_envmap_filter refers to a missing texture record");
+        const mi_texture &t = s->h.textures[s->h.envTexture];
+        if (t.type != MI_TEXTURE_BITMAP || (size_t) t.first_level + t.n_levels > s->h.texLevels.size() / 3 || s->h.texLevels[(size_t) t.first_level * 3] != s->h.envW || s->h.texLevels[(size_t) t.first_level * 3 + 1] != s->h.envH)
+            return fail(MI_ERR_INVALID, "mi_scene_commit: the environment map's pyramid must be a bitmap texture record whose level 0 has the map's size");
     }
     for (const mi_analytic &a : s->h.analytic) if (a.bsdf >= 0 && (size_t) a.bsdf < s->h.materials.size() && ((s->h.materials[a.bsdf].flags >> 8) & 0xFFFFu))
         return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textured materials on analytic shapes are not implemented");
@@ -457,6 +474,7 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
         mark(r, 1, evUsed, st); r->k->extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
+        if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) r->k->envPrimary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
         mark(r, 2, evUsed, st); r->k->shade(sc, r->rc, Q, buf, r->gridShade, st);
         if (depth < maxDepth) { mark(r, 3, evUsed, st); r->k->shadow(sc, Q, r->gridShadow, st); }
         buf ^= 1;

@@ -261,6 +261,28 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
     if (tid == 0 && rays) atomicAdd(&q.counters[0], rays);
 }
 
+// Camera rays that leave the scene: EnvironmentMap::evalEnvironment WITH ray differentials (src/emitters/envmap.cpp:384-416) -- texture-space partials
+// of the sensor ray's rx / ry directions, then TMIPMap::eval (EWA, anisotropy <= 10; u repeats, v clamps) over the map's MIP pyramid (input data).
+// Runs once per batch between the first extend and the first shade; throughput is 1 at depth 1.
+__global__ __launch_bounds__(WG) void k_env_primary(DScene sc, RenderConst rc, Queues q, int buf) {
+    const TextureD tx = sc.textures[sc.env_texture - 1u];
+    for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
+        const uint32_t n = q.count[buf][seg]; const uint64_t segBase = (uint64_t) seg * q.cap;
+        for (uint32_t i = threadIdx.x; i < n; i += WG) {
+            if (__float_as_uint(q.hit[segBase + i].w) != 0xFFFFFFFFu) continue;
+            const float4 rd = q.rayD[buf][segBase + i]; const uint32_t pid = q.st0[buf][segBase + i].x;
+            const v3 d = V(rd.x, rd.y, rd.z); const float2 sp = q.pos[pid];
+            v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
+            const v3 v = mat3(sc.env_to_local, d);
+            const float uvx = atan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
+            const v3 dvdx = mat3(sc.env_to_local, rxd) - v, dvdy = mat3(sc.env_to_local, ryd) - v;
+            const float t1 = MI_INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -MI_INV_PI / maxf(sqrtf(maxf(0.0f, 1.0f - v.y * v.y)), MI_EPSILON);
+            const v3 value = mipEval(sc, tx, uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y) * sc.env_scale;
+            float4 a = q.acc[pid]; a.x += value.x; a.y += value.y; a.z += value.z; q.acc[pid] = a;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- shade
 // One bounce of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for every live path of the segment:
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
@@ -351,7 +373,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
                     if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
                     if (ENV) {
-                        if (depth == 1) { if (!rc.hide_emitters) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141 (level-0 lookup)
+                        if (depth == 1) { if (!rc.hide_emitters && !sc.env_texture) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141; with a MIP pyramid k_env_primary has added the filtered lookup
                         else {
                             // BSDF ray left the scene: env->evalEnvironment + fillDirectSamplingRecord (envmap.cpp:362-378), MIS term path.cpp:257-264
                             float4 ro = q.rayO[buf][slot]; float nearT, farT;
@@ -641,6 +663,7 @@ void MI_FN(mi_launch_shadow)(const DScene &sc, const Queues &q, uint32_t grid, h
     if (sc.n_analytic || sc.n_instances) MI_BY_STACK(k_shadow, true, sc, q); else MI_BY_STACK(k_shadow, false, sc, q);
 }
 #undef MI_BY_STACK
+void MI_FN(mi_launch_env_primary)(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_env_primary, dim3(grid), dim3(WG), 0, st, sc, rc, q, buf); }
 void MI_FN(mi_launch_film)(const DScene &sc, const Queues &q, const BatchDesc &bd, float *film, float *spill, hipStream_t st) { hipLaunchKernelGGL(k_film, dim3((bd.n_pix + WG - 1) / WG), dim3(WG), 0, st, sc, q, bd, film, spill); }
 #ifndef MI_FAST_MATH
 void mi_launch_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout, hipStream_t st) {

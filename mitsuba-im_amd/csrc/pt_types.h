@@ -94,7 +94,7 @@ struct DScene {
     uint32_t ext;                         // analytic shapes or delta emitters present: selects the k_shade<..., EXT> variants
     // scene-level emitters beyond envmap (src/emitters/constant.cpp, point.cpp, spot.cpp, directional.cpp): per emitter 16 floats
     //   [0..2] position (point, spot) / travel direction (directional); spot: [3] cos(cutoff), [4..12] world->local 3x3, [13] cos(beam), [14] cutoff, [15] 1/(cutoff-beam)
-    const TriUV *triuv; const TextureD *textures; uint32_t n_textures, tex_pad;
+    const TriUV *triuv; const TextureD *textures; uint32_t n_textures, env_texture;   // n_textures: bound to materials (kernel variant); env_texture: index + 1 of the environment map's MIP pyramid record, 0 = none
     const uint32_t *tex_levels; const float *tex_texels; const float *mip_lut;   // MIP pyramids (input data); EWA weight table (mipmap.h:297-302)
     float cam_dx[3], cam_dy[3];           // PerspectiveCameraImpl::m_dx / m_dy (perspective.cpp:159-163)
     const float *material_tables;                    // float tables referenced by materials (roughplastic: k[1] = offset, k[2] = length)

@@ -164,6 +164,12 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     sc.strict_normals = int(strict_normals); sc.hide_emitters = int(hide_emitters)
     sc.sampler = sampler; sc.spp = int(spp); sc.seed = int(seed)
     sc.envmap = envmap          # None or dict(rgb[h,w,3] f32, to_world[4,4], scale)
+    textures = list(textures or [])
+    sc.env_texture = 0                              # index + 1 of the texture record holding the environment map's MIP pyramid (camera-ray lookups, envmap.cpp:398-411)
+    if envmap is not None and envmap.get("filtered", True):
+        levels = envmap.get("levels") or build_mip_pyramid(envmap["rgb"], WRAP_REPEAT, WRAP_CLAMP, float("inf"))
+        textures.append(make_texture(TEXTURE_BITMAP, pyramid=dict(levels=levels), wrap_u=WRAP_REPEAT, wrap_v=WRAP_CLAMP, filter_type=MIP_EWA, max_anisotropy=10.0))
+        sc.env_texture = len(textures)
     lv = []; tx = []                                # MIP pyramids of the bitmap textures, concatenated: texture_levels[n][3] = (w, h, offset), texture_texels
     for t in (textures or []):
         if t.get("pyramid") is not None:
@@ -813,6 +819,39 @@ def open_constant(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=
     return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
 
 
+def detailed_sky(w=256, h=128):
+    """Lat-long environment with texel-scale detail (tiles, thin bands, a small sun): seen by the camera on a small film it is minified, so the
+    filtered lookup of EnvironmentMap::evalEnvironment (EWA over the MIP pyramid) differs visibly from a level-0 lookup."""
+    y, x = np.mgrid[0:h, 0:w]
+    tiles = ((x // 3 + y // 2) % 2).astype(np.float64)
+    bands = ((y % 7) < 2).astype(np.float64)
+    rgb = np.stack([0.15 + 0.8 * tiles, 0.25 + 0.5 * bands, 0.9 - 0.6 * tiles * bands], -1)
+    rgb[y > h * 0.55] *= 0.25                                # darker below the horizon
+    sun = np.exp(-(((x - w * 0.62) / 2.5) ** 2 + ((y - h * 0.3) / 2.0) ** 2))
+    rgb = rgb + (40.0 * sun)[..., None] * np.array([1.0, 0.9, 0.7])
+    return rgb.astype(np.float16).astype(f32)
+
+
+def sky_view(width=64, height=48, spp=16, sampler=SAMPLER_SOBOL, max_depth=5, rr_depth=4, seed=0, env_size=(256, 128), hide_emitters=False):
+    """Camera looking at the horizon under a detailed environment map: most camera rays leave the scene directly, each pixel covers several texels
+    (EWA-filtered environment lookups with the sensor ray's differentials, envmap.cpp:398-411); a floor and a block keep the bounce loop busy."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.5, 0.5, 0.5)); red = b.bsdf(reflectance=(0.65, 0.2, 0.15))
+    b.begin(); b.quad([(8, 0, -8), (-8, 0, -8), (-8, 0, 8), (8, 0, 8)]); b.end(grey)
+    b.begin()
+    x0, z0, x1, z1, hh = -1.2, 0.8, 0.2, 2.0, 1.4
+    b.quad([(x0, hh, z0), (x0, hh, z1), (x1, hh, z1), (x1, hh, z0)])
+    b.quad([(x0, 0, z0), (x0, hh, z0), (x1, hh, z0), (x1, 0, z0)]); b.quad([(x1, 0, z0), (x1, hh, z0), (x1, hh, z1), (x1, 0, z1)])
+    b.quad([(x1, 0, z1), (x1, hh, z1), (x0, hh, z1), (x0, 0, z1)]); b.quad([(x0, 0, z1), (x0, hh, z1), (x0, hh, z0), (x0, 0, z0)])
+    b.end(red)
+    cam = look_at((0.8, 1.1, -4.5), (-0.2, 1.9, 1.0), (0.05, 1, 0))
+    env = dict(rgb=detailed_sky(*env_size), to_world=(rotate((0, 1, 0), 25.0) @ rotate((1, 0, 0), 8.0)).astype(f32), scale=0.8)
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 55.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                      seed=seed, hide_emitters=hide_emitters, envmap=env, name="sky_view")
+    sc.emitters.insert(0, dict(type=EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=1.0))
+    return sc
+
+
 # ---------------------------------------------------------------------------------------------
 # binary container for the oracle-side harness
 # ---------------------------------------------------------------------------------------------
@@ -854,9 +893,10 @@ def save_scene(sc, path):
                 f.write(struct.pack("<I2iI", a["type"], a["bsdf"], a["emitter"], a["flags"]))
                 f.write(a["to_world"].tobytes()); f.write(a["to_object"].tobytes())
                 f.write(struct.pack("<2f", a["radius"], a["length"]))
-        if sc.get("textures"):
-            f.write(b"TEXR"); f.write(struct.pack("<I", len(sc.textures)))
-            for t in sc.textures:
+        mat_textures = [t for i, t in enumerate(sc.get("textures") or []) if i + 1 != sc.get("env_texture", 0)]     # the environment map's pyramid record is ours; the reference builds its own
+        if mat_textures:
+            f.write(b"TEXR"); f.write(struct.pack("<I", len(mat_textures)))
+            for t in mat_textures:
                 f.write(struct.pack("<I11f", t["type"], *t["color0"], *t["color1"], t["line_width"], t["uoffset"], t["voffset"], t["uscale"], t["vscale"]))
                 f.write(struct.pack("<3If2I", t["wrap_u"], t["wrap_v"], t["filter"], t["max_anisotropy"], 0, 0))
                 if t["type"] == TEXTURE_BITMAP:              # the harness builds the reference's own BitmapTexture (and MIP pyramid) from the base image
@@ -866,3 +906,67 @@ def save_scene(sc, path):
             f.write(b"INST"); f.write(struct.pack("<I", len(sc.instances)))
             for a in sc.instances:
                 f.write(struct.pack("<4I", a["group"], 0, 0, 0)); f.write(a["to_world"].tobytes()); f.write(a["to_object"].tobytes())
+
+
+# ---------------------------------------------------------------------------------------------
+# MIP pyramid construction: TMIPMap's constructor (include/mitsuba/render/mipmap.h:176-271) over Bitmap::resample
+# (src/libcore/bitmap.cpp:2231-2330) and Resampler (include/mitsuba/core/rfilter.h:123-198, :232-330, :437-457) with the 2-lobed
+# Lanczos filter (src/rfilters/lanczos.cpp).  Host-side data preparation: the pyramid is INPUT of the path.
+# ---------------------------------------------------------------------------------------------
+def _lanczos2(x):
+    x = np.abs(x.astype(f32))
+    x1 = (f32(math.pi) * x).astype(f32); x2 = (x1 / f32(2.0)).astype(f32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        v = ((np.sin(x1) * np.sin(x2)) / (x1 * x2)).astype(f32)
+    return np.where(x < f32(1e-4), f32(1.0), np.where(x > f32(2.0), f32(0.0), v)).astype(f32)
+
+
+def _resample_axis(src, target, bc, lo, hi):
+    """Resampler::resampleAndClamp along axis 0 of src[n, ...]: every output sample is sum_j source[start + j] * weight[j] accumulated in tap order."""
+    n = src.shape[0]
+    scale = f32(n) / f32(target); inv = f32(1.0) / scale; radius = f32(2.0) * scale
+    taps = int(math.ceil(float(radius) * 2.0))
+    i = np.arange(target)
+    center = ((i.astype(f32) + f32(0.5)) / f32(target) * f32(n)).astype(f32)
+    start = np.floor(center - radius + f32(0.5)).astype(np.int64)
+    pos = (start[:, None] + np.arange(taps)[None, :]).astype(f32) + f32(0.5) - center[:, None]
+    w = _lanczos2((pos * inv).astype(f32))
+    total = np.zeros(target, f32)
+    for j in range(taps):
+        total = (total + w[:, j]).astype(f32)
+    w = (w * (f32(1.0) / total)[:, None]).astype(f32)
+    out = np.zeros((target,) + src.shape[1:], f32)
+    for j in range(taps):
+        p = start + j
+        outside = (p < 0) | (p >= n)
+        if bc == WRAP_CLAMP:
+            q = np.clip(p, 0, n - 1)
+        elif bc == WRAP_REPEAT:
+            q = np.mod(p, n)
+        elif bc == WRAP_MIRROR:
+            q = np.mod(p, 2 * n); q = np.where(q >= n, 2 * n - q - 1, q)
+        else:
+            q = np.clip(p, 0, n - 1)
+        v = src[q]
+        if bc in (WRAP_ZERO, WRAP_ONE):
+            v = np.where(outside.reshape((-1,) + (1,) * (src.ndim - 1)), f32(0.0 if bc == WRAP_ZERO else 1.0), v)
+        out = (out + v * w[:, j].reshape((-1,) + (1,) * (src.ndim - 1))).astype(f32)
+    return np.minimum(f32(hi), np.maximum(f32(lo), out)).astype(f32)
+
+
+def build_mip_pyramid(rgb, wrap_u=WRAP_REPEAT, wrap_v=WRAP_REPEAT, max_value=1.0):
+    """levels [(w, h, texels[h*w*3])] of `rgb[h, w, 3]` as TMIPMap<Color3, Color3h> holds them: each level is resampled from the previous one in
+    float (x first, then y; results clamped to [0, max_value]) and stored rounded to half.  Bitmap textures use max_value = 1, the environment
+    map infinity (src/emitters/envmap.cpp:182-185)."""
+    cur = np.maximum(np.asarray(rgb, f32), f32(0.0))          # negative texels are clamped (mipmap.h:236-243)
+    levels = [(cur.shape[1], cur.shape[0], np.ascontiguousarray(cur.astype(np.float16).astype(f32).reshape(-1)))]
+    h, w = cur.shape[:2]
+    while w > 1 or h > 1:
+        nw, nh = max(1, (w + 1) // 2), max(1, (h + 1) // 2)
+        if nw != w:
+            cur = np.ascontiguousarray(np.swapaxes(_resample_axis(np.ascontiguousarray(np.swapaxes(cur, 0, 1)), nw, wrap_u, 0.0, max_value), 0, 1))
+        if nh != h:
+            cur = _resample_axis(cur, nh, wrap_v, 0.0, max_value)
+        w, h = nw, nh
+        levels.append((w, h, np.ascontiguousarray(cur.astype(np.float16).astype(f32).reshape(-1))))
+    return levels

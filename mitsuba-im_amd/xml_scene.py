@@ -13,7 +13,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
     bsdf        diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, twosided
-    texture     checkerboard, gridtexture, bitmap (diffuse reflectance)
+    texture     checkerboard, gridtexture, bitmap (diffuse reflectance; images .npy / .pfm / .hdr or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
 
@@ -439,17 +439,17 @@ class _SceneBuilder:
                                  t.get("uscale", uvs), t.get("vscale", uvs))
         elif t.type == "bitmap":
             path = self.r.resolve(t.get("filename"))
-            if not path.endswith(".npz"):
-                raise SceneError("bitmap textures take a precomputed MIP pyramid (.npz with base / sizes / texels, see scenes.load_texture_pyramid): "
-                                 "the pyramid is input data of the path, the reference builds it at load time (include/mitsuba/render/mipmap.h)")
-            d = np.load(path); levels = []; off = 0
-            for w, h in d["sizes"]:
-                n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
             wrap = {"repeat": S.WRAP_REPEAT, "clamp": S.WRAP_CLAMP, "mirror": S.WRAP_MIRROR, "zero": S.WRAP_ZERO, "one": S.WRAP_ONE}
             filt = {"ewa": S.MIP_EWA, "trilinear": S.MIP_TRILINEAR, "bilinear": S.MIP_BILINEAR, "nearest": S.MIP_NEAREST}
             wm = t.get("wrapMode", "repeat"); wu, wv = t.get("wrapModeU", wm), t.get("wrapModeV", wm); ft = str(t.get("filterType", "ewa")).lower()
             if wu not in wrap or wv not in wrap or ft not in filt:
                 raise SceneError("bitmap: unknown wrapMode / filterType")
+            if path.endswith(".npz"):                    # a precomputed pyramid (base / sizes / texels, see scenes.load_texture_pyramid)
+                d = np.load(path); levels = []; off = 0
+                for w, h in d["sizes"]:
+                    n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
+            else:                                        # an image: the pyramid as TMIPMap builds it (bitmap.cpp:363-401: 2-lobed Lanczos, values clamped to [0, 1])
+                levels = S.build_mip_pyramid(load_image(path), wrap[wu], wrap[wv], 1.0)
             if t.get("channel", "") != "":
                 raise SceneError("bitmap: 'channel' selection is not supported")
             t.get("gamma", 0.0); t.get("cache", True)

@@ -50,7 +50,7 @@ class OrcSceneDesc(C.Structure):
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
-                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_texture_levels", C.c_uint32), ("texture_levels", C.c_void_p), ("n_texture_texels", C.c_uint32), ("texture_texels", C.c_void_p)]
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_texture_levels", C.c_uint32), ("texture_levels", C.c_void_p), ("n_texture_texels", C.c_uint32), ("texture_texels", C.c_void_p), ("env_texture", C.c_uint32)]
 
 
 def build():
@@ -191,6 +191,7 @@ class Oracle:
             if sc.get("texture_levels") is not None:
                 self._keep += [sc.texture_levels, sc.texture_texels]
                 d.n_texture_levels, d.texture_levels, d.n_texture_texels, d.texture_texels = len(sc.texture_levels), _ptr(sc.texture_levels), len(sc.texture_texels), _ptr(sc.texture_texels)
+        d.env_texture = int(sc.get("env_texture", 0) or 0)
         mt = sc.get("material_tables")
         if mt is not None:
             self._keep.append(mt); d.n_material_tables, d.material_tables = len(mt), _ptr(mt)

@@ -1612,6 +1612,17 @@ static v3 texture_eval(const orc_scene *s, const orc_texture *t, float u, float 
     }
     return first ? V(t->color0[0], t->color0[1], t->color0[2]) : V(t->color1[0], t->color1[1], t->color1[2]);
 }
+/* envmap.cpp:384-416 evalEnvironment WITH ray differentials (the sensor ray, path.cpp:139-141): texture-space partials, then TMIPMap::eval over the
+ * map's pyramid (input data; record s->d.env_texture - 1 of the texture table) */
+static v3 env_eval_filtered(const orc_scene *s, v3 d, v3 rxd, v3 ryd) {
+    v3 v = mat3(s->env_to_local, d);
+    float uvx = atan2f(v.x, -v.z) * INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * INV_PI;
+    v3 dvdx = sub(mat3(s->env_to_local, rxd), v), dvdy = sub(mat3(s->env_to_local, ryd), v);
+    float t1 = INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -INV_PI / maxf(sqrtf(maxf(0.0f, 1.0f - v.y * v.y)), EPSILON);
+    v3 value = mip_eval(s, &s->textures[s->d.env_texture - 1], uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y);
+    return scale(value, s->env_scale);
+}
+
 /* ------------------------------------------------------------------------------------------------ the Li loop */
 static inline float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   /* path.cpp:296-300 */
 
@@ -1627,8 +1638,8 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
     v3 throughput = V(1, 1, 1); float eta = 1.0f;
     while (depth <= maxDepth || maxDepth < 0) {
         if (!its.valid) {                                /* path.cpp:136-143 (reached by camera rays only; BSDF-ray misses are handled below) */
-            /* NB the reference filters this lookup with the camera ray's differentials (EWA, envmap.cpp:398-411); level-0 bilinear here */
-            if (s->env_index >= 0 && emitted_radiance && (!hide || scattered)) Li = add(Li, mul(throughput, env_eval(s, d)));
+            if (s->env_index >= 0 && emitted_radiance && (!hide || scattered))
+                Li = add(Li, mul(throughput, (s->d.env_texture && !s->env_constant && depth == 1 && !scattered) ? env_eval_filtered(s, d, *rxd, *ryd) : env_eval(s, d)));
             break;
         }
         mat_t bsdf_local = s->materials[its.material];        /* textured reflectance: evaluated at the hit's uv (diffuse.cpp:112-121: m_reflectance->eval(bRec.its)) */

@@ -419,13 +419,13 @@ static Built buildScene(const FScene &fs) {
 // BitmapTexture builds TMIPMap<Color3, Color3h> with a 2-lobed Lanczos filter (src/textures/bitmap.cpp:193-214).  This mode builds the very same
 // pyramid from raw RGB floats and dumps every level (half-precision texels widened to float): texture input data for the build's scenes.
 #include <mitsuba/render/mipmap.h>
-static void modeMipmap(const std::string &in, int w, int h, int bcu, int bcv, const std::string &out) {
+static void modeMipmap(const std::string &in, int w, int h, int bcu, int bcv, const std::string &out, Float maxValue = 1.0f) {
     typedef TSpectrum<Float, 3> Color3; typedef TSpectrum<half, 3> Color3h; typedef TMIPMap<Color3, Color3h> MIPMap3;
     ref<Bitmap> bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(w, h));
     FILE *f = fopen(in.c_str(), "rb"); if (!f || fread(bmp->getFloat32Data(), 4, (size_t) w * h * 3, f) != (size_t) w * h * 3) { fprintf(stderr, "cannot read %s\n", in.c_str()); _exit(2); } fclose(f);
     Properties rp("lanczos"); rp.setInteger("lobes", 2);
     ref<ReconstructionFilter> rf = static_cast<ReconstructionFilter *>(create(MTS_CLASS(ReconstructionFilter), rp)); rf->configure();
-    ref<MIPMap3> mip = new MIPMap3(bmp, Bitmap::ERGB, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) bcu, (ReconstructionFilter::EBoundaryCondition) bcv, EEWA, 20.0f);
+    ref<MIPMap3> mip = new MIPMap3(bmp, Bitmap::ERGB, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) bcu, (ReconstructionFilter::EBoundaryCondition) bcv, EEWA, 20.0f, fs::pathstr(), 0, maxValue);
     std::vector<float> texels; std::vector<int32_t> sizes;
     for (int l = 0; l < mip->getLevels(); ++l) {
         ref<Bitmap> lb = mip->toBitmap(l); const half *hp = lb->getFloat16Data(); const size_t n = (size_t) lb->getWidth() * lb->getHeight() * 3;
@@ -810,10 +810,10 @@ int main(int argc, char **argv) {
     Scheduler::staticInitialization();
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
     Thread::getThread()->getFileResolver()->appendPath(fs::pathstr(MI_REF_ROOT));   // data/microfacet/*.dat, data/ior/*.spd (roughplastic, named conductors)
-    if (argc >= 8 && std::string(argv[1]) == "mipmap") { modeMipmap(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7]); fflush(NULL); _exit(0); }
+    if (argc >= 8 && std::string(argv[1]) == "mipmap") { modeMipmap(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7], argc >= 9 ? (std::string(argv[8]) == "inf" ? std::numeric_limits<Float>::infinity() : (Float) atof(argv[8])) : 1.0f); fflush(NULL); _exit(0); }
     if (argc >= 6 && std::string(argv[1]) == "spectrum") { modeSpectrum(argc, argv); fflush(NULL); _exit(0); }
     if (argc >= 10 && std::string(argv[1]) == "mesh") { modeMesh(argc, argv); fflush(NULL); _exit(0); }
-    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | spectrum <wl value>... | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | spectrum <wl value>... | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> [maxValue|inf] | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
     FScene fs = loadScene(argv[1]);

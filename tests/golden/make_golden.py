@@ -62,6 +62,10 @@ def golden_scenes():
         "textured_room": scenes.textured_room(width=96, height=64, spp=16),
         # bitmap textures: MIP pyramid (input data = the reference's own), EWA / trilinear / bilinear / nearest, wrap modes, ray differentials
         "bitmap_room": scenes.bitmap_room(width=96, height=64, spp=16),
+        # camera rays straight into a detailed environment map: EWA-filtered lookups with the sensor ray's differentials
+        # (footprints shrink with 1 / sqrt(spp), integrator.cpp:145-146: 1-2 spp on a small film under a 1024 x 512 map gives minification)
+        "sky_view": scenes.sky_view(width=60, height=44, spp=1, env_size=(1024, 512)),      # not a power of two: the reference's responsive driver walks (W+2b) x (H+2b) pixels (integrator.cpp:338-339) and Sobol pixel 64 would alias pixel 0
+        "sky_view_indep": scenes.sky_view(width=60, height=44, spp=2, env_size=(1024, 512), sampler=scenes.SAMPLER_INDEPENDENT, seed=2),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
@@ -100,7 +104,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room"):
+        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", "path", -1, base + "_resp")

@@ -535,3 +535,31 @@ def test_scene_file_round_trip_renders_identically(mi, tmp_path):
     for s in (sc, sc2):
         r = mi.Render(mi.Scene(s)); r.run(); films.append(r.read_film(0))
     assert (bits(films[0]) == bits(films[1])).all()
+
+
+@pytest.mark.parametrize("name", ["sky_view", "sky_view_indep"])
+def test_filtered_environment_lookups(mi, oracle, golden_scenes, name):
+    """SURVEY.md §8 a10, camera rays: EnvironmentMap::evalEnvironment with the sensor ray's differentials (texture-space partials -> TMIPMap::eval, EWA with
+    anisotropy <= 10 over the map's MIP pyramid; `k_env_primary` between the first extend and the first shade).  The pyramid is built by
+    scenes.build_mip_pyramid (pinned against the reference's Bitmap::resample).  log / atan / sin / cos of the level and ellipse selection come from the
+    device math library -> tolerance-pinned against the oracle; the reference's own samples and film next to it."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    ref = orc.render_samples(gd["pairs"])["li"]; got = r.samples(gd["pairs"])
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-5).mean() > 0.95 and (err < 1e-3).mean() > 0.995 and err.max() < 5e-3, ((err < 1e-5).mean(), err.max())     # a last-bit change of the ellipse coefficients moves a texel in or out of the EWA footprint
+    err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)                    # the reference's own Li
+    assert (err < 1e-4).mean() > 0.98 and err.max() < 5e-3 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-4
+    assert (st["rays"], st["shadow_rays"]) == (int(cnt[0]), int(cnt[1]))
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-4
+    # without the pyramid (mi_scene_set_envmap_filter not called) the camera-ray samples are the level-0 lookups: far from the reference here
+    sc0 = type(sc)(sc); sc0["env_texture"] = 0
+    r0 = mi.Render(mi.Scene(sc0)); r0.run(); f0 = r0.read_film(0)
+    assert np.linalg.norm(f0[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) > 5e-2
+    # hideEmitters: camera rays do not see the map at all (path.cpp:139), with or without the pyramid
+    rh = mi.Render(gs, hide_emitters=True); rh.run(); fh = rh.read_film(0)
+    oh = type(sc)(sc); oh["hide_emitters"] = 1; ofh, _ = oracle.Oracle(oh).render_image(threads=4)
+    assert np.linalg.norm(fh[..., :3] - ofh[..., :3]) / max(np.linalg.norm(ofh[..., :3]), 1e-9) < 1e-4

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -56,6 +56,13 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     if name.startswith("atrium"):
         # coarse smooth-shaded columns (6 segments): the interpolated normal amplifies last-bit differences of (u, v) at grazing angles
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6
+    elif name.startswith("sky_view"):
+        # camera rays into a detailed 1024 x 512 environment map at 1-2 spp: EWA-filtered lookups (envmap.cpp:398-411) over OUR pyramid builder's
+        # output (scenes.build_mip_pyramid) vs the pyramid the reference built for itself; level selection goes through log / atan
+        assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.99 and err.max() < 2e-3 and np.median(err) < 1e-6
+        sc0 = type(sc)(sc); sc0["env_texture"] = 0                 # without the filtered lookup the camera-ray samples are far off: the row is needed
+        e0 = np.abs(oracle.Oracle(sc0).render_samples(gd["pairs"])["li"] - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
+        assert (e0 < 1e-4).mean() < 0.5
     elif name == "bunny_box":
         # scene file (XML + PLY, tests/golden/meshes/bunny_box.xml) read by xml_scene / meshio: 69451 smooth-shaded triangles + a glass sphere
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
@@ -172,7 +179,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box",
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep",
                                   "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
@@ -214,3 +221,20 @@ def test_oracle_edge_cases(oracle, mi):
     ok, _ = orc.intersect(np.array([278, 273, -800, 1e-4, 0, 0, -1, np.inf], np.float32)); assert not ok
     assert not orc.occluded(np.array([278, 273, -800, 1e-4, 0, 0, -1, 100.0], np.float32))
     assert orc.occluded(np.array([278, 273, 100, 1e-4, 0, 1, 0, 1000.0], np.float32))   # towards the ceiling
+
+
+def test_mip_pyramid_builder_vs_reference(mi):
+    """scenes.build_mip_pyramid (TMIPMap constructor over Bitmap::resample / Resampler with the 2-lobed Lanczos filter) against pyramids the reference
+    built: the 48x40 texture (repeat / repeat, clamped to [0, 1]) and an HDR 50x23 map with the environment map's settings (repeat / clamp, unbounded)."""
+    S = mi.scenes
+    pyr = S.load_texture_pyramid()
+    mine = S.build_mip_pyramid(pyr["base"], S.WRAP_REPEAT, S.WRAP_REPEAT, 1.0)
+    assert [(w, h) for w, h, _ in mine] == [(w, h) for w, h, _ in pyr["levels"]]
+    for (_, _, a), (_, _, b) in zip(mine, pyr["levels"]):
+        np.testing.assert_array_equal(a, b)
+    gd = g("env_pyramid_50x23.npz")
+    mine = S.build_mip_pyramid(gd["base"], S.WRAP_REPEAT, S.WRAP_CLAMP, float("inf"))
+    assert [[w, h] for w, h, _ in mine] == gd["sizes"].tolist()
+    ref = gd["texels"]; got = np.concatenate([t for _, _, t in mine])
+    # half-precision storage: a value a float ulp away from a rounding boundary may land on the neighbouring half (3 of 4680 texels here)
+    assert (got != ref).sum() <= 4 and np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()

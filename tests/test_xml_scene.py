@@ -207,3 +207,20 @@ def test_images_for_environment_maps(tmp_path):
     sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
     assert sc.envmap["scale"] == 2.0 and sc.envmap["rgb"].shape == (4, 8, 3) and sc.emitters[0]["type"] == S.EMITTER_ENVMAP
     np.testing.assert_array_equal(sc.envmap["rgb"], img.astype(np.float16).astype(np.float32))
+
+
+def test_bitmap_texture_from_an_image_file(tmp_path):
+    """<texture type="bitmap"> from an image: the MIP pyramid is built at load time like BitmapTexture does (scenes.build_mip_pyramid, pinned against the
+    reference's pyramids in tests/test_oracle_golden.py) -- here from the base image of the reference-built 48x40 pyramid, so the result must equal it."""
+    pyr = S.load_texture_pyramid()
+    np.save(tmp_path / "tex.npy", pyr["base"])
+    body = ('<shape type="cube"><bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="tex.npy"/>'
+            '<string name="wrapModeV" value="repeat"/><float name="uvscale" value="2"/><string name="filterType" value="trilinear"/></texture></bsdf></shape>')
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
+    t = sc.textures[0]
+    assert t["type"] == S.TEXTURE_BITMAP and t["filter"] == S.MIP_TRILINEAR and (t["uscale"], t["vscale"]) == (2.0, 2.0) and t["n_levels"] == len(pyr["levels"])
+    off = 0
+    for (w, h, ref), lv in zip(pyr["levels"], sc.texture_levels):
+        assert (int(lv[0]), int(lv[1]), int(lv[2])) == (w, h, off)
+        np.testing.assert_array_equal(sc.texture_texels[off:off + w * h * 3], ref); off += w * h * 3
+    assert sc.bsdfs[0]["texture"] == 0 and sc.uv is not None
