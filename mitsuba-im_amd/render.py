@@ -1,6 +1,6 @@
 """Command-line front end: render a Mitsuba XML scene on the MI355X path tracer (what `mitsuba scene.xml` does for the `path` integrator).
 
-    python -m mitsuba-im_amd.render scene.xml [-o out.pfm|out.npy] [-D name=value ...] [--spp N] [--fast-math] [--device K]
+    python -m mitsuba-im_amd.render scene.xml [-o out.pfm|out.npy] [-D name=value ...] [--spp N] [--sampler sobol|independent] [--fast-math] [--device K]
 
 The image written is the developed film (sum / weight, linear RGB, as HDRFilm::develop would hand to its writer); `.pfm` and `.npy` are the
 formats available without an image library.  There is no CPU fallback: without the HIP library / a GPU this exits with an error.
@@ -32,6 +32,7 @@ def main(argv=None):
     ap.add_argument("-o", "--output", default=None)
     ap.add_argument("-D", dest="defines", action="append", default=[], metavar="name=value")
     ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--sampler", choices=["sobol", "independent"], default=None, help="replace the scene's sampler plugin (keeps its sampleCount)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--fast-math", action="store_true")
     a = ap.parse_args(argv)
@@ -42,7 +43,7 @@ def main(argv=None):
         k, v = d.split("=", 1); params[k] = v
     try:
         t0 = time.perf_counter()
-        sc = xml_scene.load_scene(a.scene, params)
+        sc = xml_scene.load_scene(a.scene, params, sampler=a.sampler)
         if a.spp is not None:
             sc.spp = a.spp
         t1 = time.perf_counter()

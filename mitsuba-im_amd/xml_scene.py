@@ -415,8 +415,8 @@ def _spectrum_or_texture(p, names, default):
 
 
 class _SceneBuilder:
-    def __init__(self, reader, root):
-        self.r, self.root = reader, root
+    def __init__(self, reader, root, sampler_override=None):
+        self.r, self.root, self.sampler_override = reader, root, sampler_override
         self.bsdfs, self.bsdf_index, self.textures = [], {}, []
         self.verts, self.normals, self.uvs, self.tris, self.shapes = [], [], [], [], []
         self.any_normals = self.any_uv = False
@@ -760,14 +760,19 @@ class _SceneBuilder:
             film.check_all_used()
         sampler, spp, seed = S.SAMPLER_INDEPENDENT, 4, 0
         if smp is not None:
-            if smp.type not in ("independent", "sobol"):
-                raise SceneError(f"sampler \"{smp.type}\" is not supported (independent, sobol)")
-            sampler = S.SAMPLER_SOBOL if smp.type == "sobol" else S.SAMPLER_INDEPENDENT
+            stype = self.sampler_override or smp.type
+            if stype not in ("independent", "sobol"):
+                raise SceneError(f"sampler \"{stype}\" is not supported (independent, sobol); load_scene(..., sampler=\"sobol\") / --sampler sobol keeps the file's sample count")
+            sampler = S.SAMPLER_SOBOL if stype == "sobol" else S.SAMPLER_INDEPENDENT
             spp = int(smp.get("sampleCount", 4))
-            if smp.type == "sobol" and int(smp.get("scramble", 0)) != 0:
+            if stype == "sobol" and int(smp.get("scramble", 0)) != 0:
                 raise SceneError("sobol: only scramble = 0 is supported")
-            seed = int(smp.get("seed", 0)) if smp.type == "independent" else 0
+            seed = int(smp.get("seed", 0)) if stype == "independent" else 0
+            if self.sampler_override:
+                smp.queried.update(smp.props)           # another sampler's own parameters do not apply
             smp.check_all_used()
+        elif self.sampler_override:
+            sampler = S.SAMPLER_SOBOL if self.sampler_override == "sobol" else S.SAMPLER_INDEPENDENT
         aspect = width / height
         if sen.has("fov") and sen.has("focalLength"):
             raise SceneError("Please specify either a focal length ('focalLength') or a field of view ('fov')!")
@@ -848,8 +853,11 @@ class _SceneBuilder:
         return sc
 
 
-def load_scene(path, params=None):
-    """Read a scene XML file -> scenes.Scene.  `params`: values for $name placeholders (the reference's -D name=value)."""
+def load_scene(path, params=None, sampler=None):
+    """Read a scene XML file -> scenes.Scene.  `params`: values for $name placeholders (the reference's -D name=value); `sampler`: "sobol" /
+    "independent" replaces the file's sampler plugin (e.g. `ldsampler`, which the path does not implement), keeping its sampleCount."""
+    if sampler not in (None, "sobol", "independent"):
+        raise SceneError("sampler override must be 'sobol' or 'independent'")
     if not os.path.exists(path):
         raise SceneError(f"scene file \"{path}\" not found")
     r = _Reader(path, params)
@@ -857,7 +865,7 @@ def load_scene(path, params=None):
     if root_elem.tag != "scene":
         raise SceneError("the root element must be <scene>")
     root = r.plugin(root_elem)
-    return _SceneBuilder(r, root).build(os.path.splitext(os.path.basename(path))[0])
+    return _SceneBuilder(r, root, sampler).build(os.path.splitext(os.path.basename(path))[0])
 
 
 # ---- the other direction: a flattened scene written as XML + one .serialized file ---------------------------------------------------

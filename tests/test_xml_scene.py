@@ -224,3 +224,13 @@ def test_bitmap_texture_from_an_image_file(tmp_path):
         assert (int(lv[0]), int(lv[1]), int(lv[2])) == (w, h, off)
         np.testing.assert_array_equal(sc.texture_texels[off:off + w * h * 3], ref); off += w * h * 3
     assert sc.bsdfs[0]["texture"] == 0 and sc.uv is not None
+
+
+def test_sampler_override(tmp_path):
+    text = MINIMAL.format(sensor='<sampler type="ldsampler"><integer name="sampleCount" value="64"/><integer name="dimension" value="8"/></sampler>', film="", body="")
+    with pytest.raises(X.SceneError, match='sampler "ldsampler" is not supported'):
+        load_text(tmp_path, text)
+    sc = load_text(tmp_path, text, sampler="sobol")
+    assert sc.sampler == S.SAMPLER_SOBOL and sc.spp == 64
+    with pytest.raises(X.SceneError, match="override"):
+        load_text(tmp_path, text, sampler="halton")
