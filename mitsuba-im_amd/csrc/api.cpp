@@ -392,7 +392,6 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
     if (p->sampler == MI_SAMPLER_SOBOL) {
         if (!s->h.d.sobol_m32) return fail(MI_ERR_INVALID, "mi_render_create: Sobol tables not loaded before mi_scene_commit (mi_set_sobol_tables)");
-        if (p->seed != 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: Sobol scramble != 0 not implemented");
         // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR) + the dim-4 skip (sobol.cpp:218-251 aborts beyond the table)
         int depth = p->max_depth < 0 ? 250 : p->max_depth;
         if (p->max_depth > 0 && (uint32_t) (3 + 5 * depth) > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "Lookup dimension exceeds the direction number table size! You may have to reduce the 'maxDepth' parameter of your integrator.");
@@ -401,6 +400,16 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
+    r->rc.sobol_scramble = 0;
+    if (p->sampler == MI_SAMPLER_SOBOL && p->seed) {          // SobolSampler: a nonzero `scramble` goes through sampleTEA (sobol.cpp:96-102; qmc.h:146-156, 4 rounds)
+        uint32_t v0 = (uint32_t) p->seed, v1 = (uint32_t) (p->seed >> 32), sum = 0;
+        for (int i = 0; i < 4; ++i) {
+            sum += 0x9e3779b9u;
+            v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xC8013EA4u);
+            v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7E95761Eu);
+        }
+        r->rc.sobol_scramble = v0;                           // single precision build: the low 32 bits of (v1 << 32) + v0 (sobolseq.h:87-96)
+    }
     r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u)); r->k = p->fast_math ? &kFast : &kPrecise;
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch

@@ -208,16 +208,16 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
         if (bd.list) { px = bd.list[pid * 3]; py = bd.list[pid * 3 + 1]; sidx = bd.list[pid * 3 + 2]; }
         SamplerState ss; float jx, jy;
         if (rc.sampler == 1) {
-            uint64_t idx = sc.log_res > 1 ? sobolLookUp(sc.sobol_vdc, sc.sobol_vdc_inv, sc.log_res, sidx, px, py) : (uint64_t) sidx;
+            uint64_t idx = sc.log_res > 1 ? sobolLookUp(sc.sobol_vdc, sc.sobol_vdc_inv, sc.log_res, sidx, px, py, rc.sobol_scramble) : (uint64_t) sidx;
             ss.a = (uint32_t) idx; ss.b = (uint32_t) (idx >> 32); ss.dim = 0;
-            const SobolTab gt{rc.sobol_nib, rc.nib_count};
+            const SobolTab gt{rc.sobol_nib, rc.nib_count, rc.sobol_scramble};
             jx = sobolSampleNib(gt, ss.a, ss.b, 0); jy = sobolSampleNib(gt, ss.a, ss.b, 1); ss.dim = 2;
             if (idx != (uint64_t) sidx) {      // sobol.cpp:239-245: rescale the first two dimensions to a pixel-relative offset
                 jx = jx * sc.resolution - (float) (int) px; jy = jy * sc.resolution - (float) (int) py;
             }
         } else {
             ss.a = (py * sc.width + px) ^ rc.seed_mix; ss.b = sidx; ss.dim = 0;
-            next2D(ss, 0, SobolTab{nullptr, 0}, jx, jy);
+            next2D(ss, 0, SobolTab{nullptr, 0, 0}, jx, jy);
         }
         float sx = (float) (int) px + jx, sy = (float) (int) py + jy;
         v3 o, d; float mint, maxt; cameraRay(sc, sx, sy, o, d, mint, maxt);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     uint32_t *s_nib = s_dyn;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = buf ^ 1;
-    const SobolTabLds m32{(lds_u32_ptr) s_nib, rc.nib_count};   // always the LDS copy (ds_read lookups); unused by the independent stream
+    const SobolTabLds m32{(lds_u32_ptr) s_nib, rc.nib_count, rc.sobol_scramble};   // always the LDS copy (ds_read lookups); unused by the independent stream
     const uint32_t nibWords = rc.sampler == 1 ? rc.nib_dims * rc.nib_count * 16u : 4u;
     if (rc.sampler == 1) {   // stage the Sobol' nibble tables in LDS (nib_dims x nib_count x 16 words)
         for (uint32_t i = tid; i < nibWords; i += WG) s_nib[i] = rc.sobol_nib[i];

@@ -39,9 +39,9 @@ DEV uint64_t sampleTEA(uint32_t v0, uint32_t v1) {
 // src/libcore/random.cpp:626-634
 DEV float bitsToFloat(uint32_t b) { return __uint_as_float((b >> 9) | 0x3f800000u) - 1.0f; }
 
-// src/samplers/sobolseq.h:43-58 sampleSingle, scramble 0.  `m32` may point to LDS or global memory.
-DEV float sobolSample(const uint32_t *m32, uint64_t index, uint32_t dim) {
-    uint32_t result = 0;
+// src/samplers/sobolseq.h:43-58 sampleSingle (the XOR sum starts from the scramble value).  `m32` may point to LDS or global memory.
+DEV float sobolSample(const uint32_t *m32, uint64_t index, uint32_t dim, uint32_t scramble = 0u) {
+    uint32_t result = scramble;
     for (uint32_t i = dim * MI_SOBOL_SIZE; index; index >>= 1, ++i)
         if (index & 1) result ^= m32[i];
     return minf((float) result * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
@@ -49,13 +49,13 @@ DEV float sobolSample(const uint32_t *m32, uint64_t index, uint32_t dim) {
 // The same XOR sum, four index bits per table lookup (tables built on the host from the same matrices: api.cpp buildNibbleTables).
 // XOR is associative, so the result is bit-identical to sampleSingle.  `tab` may point to LDS or global memory.
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;   // explicit LDS pointer: lookups compile to ds_read, not flat loads
-template <typename P> struct SobolTabT { P tab; uint32_t nibs; };
+template <typename P> struct SobolTabT { P tab; uint32_t nibs; uint32_t scramble; };
 typedef SobolTabT<const uint32_t *> SobolTab;       // global memory
 typedef SobolTabT<lds_u32_ptr> SobolTabLds;         // LDS copy
 template <typename P>
 DEV float sobolSampleNib(SobolTabT<P> st, uint32_t lo, uint32_t hi, uint32_t dim) {
     P T = st.tab + dim * st.nibs * 16u;
-    uint32_t result = 0;
+    uint32_t result = st.scramble;
     const uint32_t nlo = st.nibs < 8u ? st.nibs : 8u;
     for (uint32_t n = 0; n < nlo; ++n) result ^= T[n * 16u + ((lo >> (4u * n)) & 15u)];
     for (uint32_t n = 8; n < st.nibs; ++n) result ^= T[n * 16u + ((hi >> (4u * (n - 8u))) & 15u)];
@@ -86,8 +86,9 @@ template <bool L> DEV EmitterD loadEmitter(const Tabs<L> &t, int id) {
     e.type = __float_as_uint(c.x); e.shape = __float_as_int(c.y); e.analytic = __float_as_int(c.z);
     return e;
 }
-// src/samplers/sobolseq.h:99-131 look_up, scramble 0; vdc / vdcInv = row (m-1) of the tables
-DEV uint64_t sobolLookUp(const uint64_t *vdc, const uint64_t *vdcInv, uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
+// src/samplers/sobolseq.h:99-131 look_up (pixel coordinates flipped by the scramble value's top m bits); vdc / vdcInv = row (m-1) of the tables
+DEV uint64_t sobolLookUp(const uint64_t *vdc, const uint64_t *vdcInv, uint32_t m, uint32_t frame, uint32_t px, uint32_t py, uint32_t scramble = 0u) {
+    const uint32_t scr = scramble >> (32u - m); px ^= scr; py ^= scr;
     uint64_t index = (uint64_t) frame << (m << 1);
     uint64_t delta = 0;
     for (uint32_t c = 0; frame; frame >>= 1, ++c)

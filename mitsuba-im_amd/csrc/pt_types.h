@@ -129,6 +129,7 @@ struct DScene {
 struct RenderConst {
     int32_t max_depth, rr_depth; uint32_t strict_normals, hide_emitters, opacity;
     uint32_t sampler; uint32_t seed_mix;  // independent: seed * 0x9E3779B9
+    uint32_t sobol_scramble;              // Sobol: low 32 bits of sampleTEA(scramble) (src/samplers/sobol.cpp:92-102), 0 = unscrambled
     // Sobol' direction matrices folded into 4-bit lookup tables: nib[dim][n][v] = XOR of matrices32[dim*52 + 4n + b] over the bits b of v
     const uint32_t *sobol_nib; uint32_t nib_count, nib_dims;
     float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)

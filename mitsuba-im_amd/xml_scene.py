@@ -765,9 +765,7 @@ class _SceneBuilder:
                 raise SceneError(f"sampler \"{stype}\" is not supported (independent, sobol); load_scene(..., sampler=\"sobol\") / --sampler sobol keeps the file's sample count")
             sampler = S.SAMPLER_SOBOL if stype == "sobol" else S.SAMPLER_INDEPENDENT
             spp = int(smp.get("sampleCount", 4))
-            if stype == "sobol" and int(smp.get("scramble", 0)) != 0:
-                raise SceneError("sobol: only scramble = 0 is supported")
-            seed = int(smp.get("seed", 0)) if stype == "independent" else 0
+            seed = int(smp.get("seed", 0)) if stype == "independent" else int(smp.get("scramble", 0)) if smp.type == "sobol" else 0
             if self.sampler_override:
                 smp.queried.update(smp.props)           # another sampler's own parameters do not apply
             smp.check_all_used()
@@ -888,7 +886,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
               "mitchell": f'<float name="B" value="{fmt([sc.filter_radius])}"/><float name="C" value="{fmt([sc.filter_stddev])}"/>',
               "lanczos": f'<integer name="lobes" value="{int(sc.filter_radius)}"/>'}.get(filt, "")
     smp = "sobol" if sc.sampler == S.SAMPLER_SOBOL else "independent"
-    seed = f'<integer name="seed" value="{sc.seed}"/>' if smp == "independent" and sc.seed else ""
+    seed = f'<integer name="{"seed" if smp == "independent" else "scramble"}" value="{sc.seed}"/>' if sc.seed else ""
     out.append(f'\t<sensor type="perspective"><float name="fov" value="{fmt([sc.xfov])}"/><string name="fovAxis" value="x"/>'
                f'<float name="nearClip" value="{fmt([sc.near])}"/><float name="farClip" value="{fmt([sc.far])}"/>{mat("toWorld", sc.cam_to_world)}\n'
                f'\t\t<sampler type="{smp}"><integer name="sampleCount" value="{sc.spp}"/>{seed}</sampler>\n'

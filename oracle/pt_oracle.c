@@ -97,21 +97,27 @@ uint64_t orc_tea(uint32_t v0, uint32_t v1, int rounds) {
 /* src/libcore/random.cpp:626-634 nextFloat bit trick */
 static inline float bits_to_float(uint32_t b) { union { uint32_t u; float f; } x; x.u = (b >> 9) | 0x3f800000u; return x.f - 1.0f; }
 
-/* src/samplers/sobolseq.h:43-58 sampleSingle (scramble 0) */
+/* SobolSampler's scramble value (src/samplers/sobol.cpp:92-102): 0 stays 0, a frame number goes through sampleTEA (4 rounds) */
+static inline uint64_t sobol_scramble(const orc_scene *s) {
+    const uint64_t v = s->d.seed;
+    return (s->d.sampler == 1 && v) ? orc_tea((uint32_t) v, (uint32_t) (v >> 32), 4) : 0;
+}
+/* src/samplers/sobolseq.h:43-58 sampleSingle: the XOR sum starts from the (low 32 bits of the) scramble value */
 float orc_sobol_sample(const orc_scene *s, uint64_t index, uint32_t dim) {
-    uint32_t result = 0;
+    uint32_t result = (uint32_t) sobol_scramble(s);
     for (uint32_t i = dim * 52; index; index >>= 1, ++i)
         if (index & 1) result ^= s->d.sobol_matrices32[i];
     return minf((float) result * (1.0f / 4294967296.0f), ONE_MINUS_EPS);
 }
-/* src/samplers/sobolseq.h:99-131 look_up (scramble 0) */
+/* src/samplers/sobolseq.h:99-131 look_up; the pixel coordinates are flipped by the scramble value's top m bits (:117-124) */
 uint64_t orc_sobol_look_up(const orc_scene *s, uint32_t m, uint32_t frame, uint32_t px, uint32_t py) {
     const uint32_t m2 = m << 1;
     uint64_t index = (uint64_t) frame << m2;
     uint64_t delta = 0;
     for (uint32_t c = 0; frame; frame >>= 1, ++c)
         if (frame & 1) delta ^= s->d.sobol_vdc[(m - 1) * 52 + c];
-    uint64_t b = (((uint64_t) px << m) | py) ^ delta;
+    const uint64_t scr = (sobol_scramble(s) & 0xFFFFFFFFull) >> (32 - m);
+    uint64_t b = (((uint64_t) (px ^ scr) << m) | (py ^ scr)) ^ delta;
     for (uint32_t c = 0; b; b >>= 1, ++c)
         if (b & 1) index ^= s->d.sobol_vdc_inv[(m - 1) * 52 + c];
     return index;

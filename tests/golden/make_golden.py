@@ -66,6 +66,8 @@ def golden_scenes():
         # (footprints shrink with 1 / sqrt(spp), integrator.cpp:145-146: 1-2 spp on a small film under a 1024 x 512 map gives minification)
         "sky_view": scenes.sky_view(width=60, height=44, spp=1, env_size=(1024, 512)),      # not a power of two: the reference's responsive driver walks (W+2b) x (H+2b) pixels (integrator.cpp:338-339) and Sobol pixel 64 would alias pixel 0
         "sky_view_indep": scenes.sky_view(width=60, height=44, spp=2, env_size=(1024, 512), sampler=scenes.SAMPLER_INDEPENDENT, seed=2),
+        # Sobol sampler with a scramble value (sobol.cpp:92-102: frame number -> sampleTEA; XORed into every sample, flips the pixel bits of look_up)
+        "cornell_scramble": scenes.cornell_box(width=96, height=54, spp=8, sampler=scenes.SAMPLER_SOBOL, seed=7),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -63,6 +63,9 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         sc0 = type(sc)(sc); sc0["env_texture"] = 0                 # without the filtered lookup the camera-ray samples are far off: the row is needed
         e0 = np.abs(oracle.Oracle(sc0).render_samples(gd["pairs"])["li"] - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
         assert (e0 < 1e-4).mean() < 0.5
+    elif name == "cornell_scramble":
+        # SobolSampler with scramble = 7: film positions and every sampler value bit-identical (look_up pixel flip + XOR into the samples)
+        assert same_path.all() and same_vals.all() and (err < 2e-4).mean() > 0.998 and err.max() < 5e-3 and np.median(err) < 1e-6
     elif name == "bunny_box":
         # scene file (XML + PLY, tests/golden/meshes/bunny_box.xml) read by xml_scene / meshio: 69451 smooth-shaded triangles + a glass sphere
         assert same_path.mean() > 0.998 and same_vals.mean() > 0.995 and (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
@@ -179,7 +182,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep",
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble",
                                   "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
