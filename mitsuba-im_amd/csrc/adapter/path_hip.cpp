@@ -89,8 +89,10 @@ static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
     if (cls == "RoughConductor") {
         uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
         std::vector<float> au = rd.texture(), av = rd.texture(), spec = rd.texture();
-        if (distr > 1 || !sampleVisible || au[0] != av[0]) SLog(EError, "path_hip: roughconductor is implemented for isotropic beckmann / ggx with sampleVisible = true");
-        m.type = MI_BSDF_ROUGHCONDUCTOR; m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = au[0];
+        // MicrofacetDistribution::EType: EBeckmann 0, EGGX 1, EPhong 2 (microfacet.h:46-52); sampleVisible as stored (Phong clears it in the constructor, :141-145)
+        if (distr > 2) SLog(EError, "path_hip: unknown microfacet distribution");
+        m.type = MI_BSDF_ROUGHCONDUCTOR; m.distr = distr; m.alpha = au[0]; if (sampleVisible) m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE;
+        if (au[0] != av[0]) { m.flags |= MI_BSDF_FLAG_ANISOTROPIC; m.reflectance[0] = av[0]; }
         memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
     } else if (cls == "SmoothConductor") {
         std::vector<float> spec = rd.texture(); m.type = MI_BSDF_CONDUCTOR; memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
@@ -173,9 +175,15 @@ static mi_material convertBSDF(const BSDF *bsdf) {
         }
         Float extEta = lookupIOR(props, "extEta", "air");
         Spectrum eta = props.getSpectrum("eta", intEta) / extEta, k = props.getSpectrum("k", intK) / extEta, spec = props.getSpectrum("specularReflectance", Spectrum(1.0f));
-        if (props.hasProperty("alphaU") || props.hasProperty("alphaV") || (distr != "beckmann" && distr != "ggx") || !props.getBoolean("sampleVisible", true))
-            SLog(EError, "path_hip: roughconductor is implemented for isotropic beckmann / ggx with sampleVisible = true");
-        m.type = MI_BSDF_ROUGHCONDUCTOR; m.flags = MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr == "ggx" ? 1u : 0u; m.alpha = props.getFloat("alpha", 0.1f);
+        // MicrofacetDistribution(props) (microfacet.h:98-146): distribution, alpha | alphaU + alphaV, sampleVisible (never for phong / as)
+        if (distr != "beckmann" && distr != "ggx" && distr != "phong" && distr != "as") SLog(EError, "Specified an invalid distribution \"%s\", must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!", distr.c_str());
+        m.type = MI_BSDF_ROUGHCONDUCTOR; m.distr = distr == "ggx" ? 1u : distr == "beckmann" ? 0u : 2u;
+        m.flags = (props.getBoolean("sampleVisible", true) && m.distr != 2u) ? MI_BSDF_FLAG_SAMPLE_VISIBLE : 0u;
+        if (props.hasProperty("alphaU") || props.hasProperty("alphaV")) {
+            if (!props.hasProperty("alphaU") || !props.hasProperty("alphaV")) SLog(EError, "Microfacet model: both 'alphaU' and 'alphaV' must be specified.");
+            m.alpha = props.getFloat("alphaU"); const Float av = props.getFloat("alphaV");
+            if (av != m.alpha) { m.flags |= MI_BSDF_FLAG_ANISOTROPIC; m.reflectance[0] = av; }
+        } else m.alpha = props.getFloat("alpha", 0.1f);
         Float r, g, b;
         eta.toLinearRGB(r, g, b); m.eta[0] = r; m.eta[1] = g; m.eta[2] = b;
         k.toLinearRGB(r, g, b); m.k[0] = r; m.k[1] = g; m.k[2] = b;

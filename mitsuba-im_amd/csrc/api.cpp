@@ -171,8 +171,10 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
         if (m[i].type > MI_BSDF_ROUGHPLASTIC) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic (those without transmission optionally twosided)");
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_DIFFTRANS) && (m[i].flags & MI_BSDF_FLAG_TWOSIDED)) return fail(MI_ERR_INVALID, "Only BSDFs without a transmission component can be nested!");   // twosided.cpp:86-88
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
-        if ((m[i].type == MI_BSDF_ROUGHCONDUCTOR || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC) && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE)))
-            return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: roughconductor / roughdielectric support beckmann / ggx with sampleVisible = true");
+        if ((m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC) && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE) || (m[i].flags & MI_BSDF_FLAG_ANISOTROPIC)))
+            return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: roughdielectric / roughplastic support isotropic beckmann / ggx with sampleVisible = true");
+        if (m[i].type == MI_BSDF_ROUGHCONDUCTOR && m[i].distr > 2) return fail(MI_ERR_INVALID, "Specified an invalid distribution, must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!");   // microfacet.h:113-115
+        if ((m[i].flags & MI_BSDF_FLAG_ANISOTROPIC) && m[i].type != MI_BSDF_ROUGHCONDUCTOR) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: anisotropic roughness is implemented for roughconductor");
     }
     s->h.materials.assign(m, m + n); s->h.committed = false; return MI_OK;
 }
@@ -314,6 +316,9 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         if (t.type != MI_TEXTURE_BITMAP || (size_t) t.first_level + t.n_levels > s->h.texLevels.size() / 3 || s->h.texLevels[(size_t) t.first_level * 3] != s->h.envW || s->h.texLevels[(size_t) t.first_level * 3 + 1] != s->h.envH)
             return fail(MI_ERR_INVALID, "mi_scene_commit: the environment map's pyramid must be a bitmap texture record whose level 0 has the map's size");
     }
+    for (const mi_shape &sh : s->h.shapes)         // TriMesh::computeUVTangents (trimesh.cpp:683-692): an anisotropic BSDF takes its tangent from the texture coordinates
+        if (sh.bsdf >= 0 && (size_t) sh.bsdf < s->h.materials.size() && (s->h.materials[sh.bsdf].flags & MI_BSDF_FLAG_ANISOTROPIC) && !((sh.flags & 2u) && !s->h.uv.empty()))
+            return fail(MI_ERR_INVALID, "computeUVTangents(): texture coordinates are required to generate tangent vectors. If you want to render with an anisotropic material, please make sure that all associated shapes have valid texture coordinates.");
     for (const mi_analytic &a : s->h.analytic) if (a.bsdf >= 0 && (size_t) a.bsdf < s->h.materials.size() && ((s->h.materials[a.bsdf].flags >> 8) & 0xFFFFu))
         return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textured materials on analytic shapes are not implemented");
     for (const mi_material &m : s->h.materials)

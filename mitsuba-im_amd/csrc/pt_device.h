@@ -641,8 +641,26 @@ DEV float miErf(float x) {
     float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * fastexpf_(-x * x);
     return sign * y;
 }
-// microfacet.h:190-237
-DEV float mfEval(uint32_t distr, float alpha, v3 m) {
+// microfacet.h:190-237: distr 0 Beckmann, 1 GGX, 2 Phong (isotropic) / Ashikhmin-Shirley (anisotropic); exponents :717-720, interpolation :559-570
+DEV float mfPhongExponent(float alpha) { return maxf(2.0f / (alpha * alpha) - 2.0f, 0.0f); }
+DEV float mfInterpExponent(float au, float av, v3 v) {
+    const float eu = mfPhongExponent(au), ev = mfPhongExponent(av), sinTheta2 = 1.0f - v.z * v.z;
+    if (au == av || sinTheta2 <= 0x1p-128f) return eu;
+    float invSinTheta2 = 1 / sinTheta2, cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+    return eu * cosPhi2 + ev * sinPhi2;
+}
+DEV float mfEval2(uint32_t distr, float au, float av, v3 m) {
+    if (m.z <= 0) return 0.0f;
+    float cosTheta2 = m.z * m.z;
+    float beckmannExponent = ((m.x * m.x) / (au * au) + (m.y * m.y) / (av * av)) / cosTheta2;
+    float result;
+    if (distr == 0) result = fastexpf_(-beckmannExponent) / (MI_PI * au * av * cosTheta2 * cosTheta2);
+    else if (distr == 1) { float root = (1.0f + beckmannExponent) * cosTheta2; result = 1.0f / (MI_PI * au * av * root * root); }
+    else result = sqrtf((mfPhongExponent(au) + 2) * (mfPhongExponent(av) + 2)) * MI_INV_TWOPI * powf(m.z, mfInterpExponent(au, av, m));
+    if (result * m.z < 1e-20f) result = 0;
+    return result;
+}
+DEV float mfEval(uint32_t distr, float alpha, v3 m) {            // isotropic Beckmann / GGX (roughdielectric, roughplastic)
     if (m.z <= 0) return 0.0f;
     float cosTheta2 = m.z * m.z;
     float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
@@ -658,7 +676,7 @@ DEV float mfSmithG1(uint32_t distr, float alpha, v3 v, v3 m) {
     float temp = 1 - v.z * v.z;
     float tanTheta = temp <= 0.0f ? 0.0f : fabsf(sqrtf(temp) / v.z);
     if (tanTheta == 0.0f) return 1.0f;
-    if (distr == 0) {
+    if (distr != 1u) {                                           // Beckmann, and Phong through the same fit (microfacet.h:489-491)
         float a = 1.0f / (alpha * tanTheta);
         if (a >= 1.6f) return 1.0f;
         float aSqr = a * a;
@@ -743,35 +761,110 @@ DEV v3 fresnelConductorExact(float cosThetaI, const float *eta, const float *k) 
     }
     return V(out[0], out[1], out[2]);
 }
+// microfacet.h:420-473 with separate roughness along the tangent / bitangent; :545-556 projectRoughness
+DEV v3 mfSampleVisible2(uint32_t distr, float au, float av, v3 wi_, float sx, float sy) {
+    v3 wi = normalize(V(au * wi_.x, av * wi_.y, wi_.z));
+    float theta = 0, phi = 0;
+    if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    float slx, sly; mfSampleVisible11(distr, theta, sx, sy, slx, sly);
+    float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+    rx *= au; ry *= av;
+    float normalization = 1.0f / sqrtf(rx * rx + ry * ry + 1.0f);
+    return V(-rx * normalization, -ry * normalization, normalization);
+}
+DEV float mfProjectRoughness(float au, float av, v3 v) {
+    float invSinTheta2 = 1 / (1.0f - v.z * v.z);
+    if (au == av || invSinTheta2 <= 0) return au;
+    float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+    return sqrtf(cosPhi2 * au * au + sinPhi2 * av * av);
+}
+DEV float mfSmithG1_2(uint32_t distr, float au, float av, v3 v, v3 m) { return mfSmithG1(distr, mfProjectRoughness(au, av, v), v, m); }
+// microfacet.h:722-731 sampleFirstQuadrant (Ashikhmin-Shirley); :286-392 sampleAll (all normals, density D(m) cos(theta_m))
+DEV void mfSampleFirstQuadrant(float eu, float ev, float u1, float &phi, float &exponent) {
+    phi = atanf(sqrtf((eu + 2.0f) / (ev + 2.0f)) * tanf(MI_PI * u1 * 0.5f));
+    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    exponent = eu * cosPhi * cosPhi + ev * sinPhi * sinPhi;
+}
+DEV v3 mfSampleAll(uint32_t distr, float au, float av, float sx, float sy, float &pdf) {
+    float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
+    if (distr <= 1u) {
+        if (au == av) { float ph = (2.0f * MI_PI) * sy; sinPhiM = sinf(ph); cosPhiM = cosf(ph); alphaSqr = au * au; }
+        else {
+            float phiM = atanf(av / au * tanf(MI_PI + 2 * MI_PI * sy)) + MI_PI * floorf(2 * sy + 0.5f);
+            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+            float cosSc = cosPhiM / au, sinSc = sinPhiM / av; alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+        }
+        if (distr == 0u) {
+            float tanThetaMSqr = alphaSqr * -fastlogf_(1.0f - sx);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            pdf = (1.0f - sx) / (MI_PI * au * av * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            float tanThetaMSqr = alphaSqr * sx / (1.0f - sx);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            float temp = 1 + tanThetaMSqr / alphaSqr;
+            pdf = MI_INV_PI / (au * av * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+    } else {
+        const float eu = mfPhongExponent(au), ev = mfPhongExponent(av);
+        float phiM, exponent;
+        if (au == av) { phiM = (2.0f * MI_PI) * sy; exponent = eu; }
+        else if (sy < 0.25f) mfSampleFirstQuadrant(eu, ev, 4 * sy, phiM, exponent);
+        else if (sy < 0.5f) { mfSampleFirstQuadrant(eu, ev, 4 * (0.5f - sy), phiM, exponent); phiM = MI_PI - phiM; }
+        else if (sy < 0.75f) { mfSampleFirstQuadrant(eu, ev, 4 * (sy - 0.5f), phiM, exponent); phiM += MI_PI; }
+        else { mfSampleFirstQuadrant(eu, ev, 4 * (1 - sy), phiM, exponent); phiM = 2 * MI_PI - phiM; }
+        sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+        cosThetaM = powf(sx, 1.0f / (exponent + 2.0f));
+        pdf = sqrtf((eu + 2.0f) * (ev + 2.0f)) * MI_INV_TWOPI * powf(cosThetaM, exponent + 1.0f);
+    }
+    if (pdf < 1e-20f) pdf = 0;
+    float sinThetaM = sqrtf(maxf(0.0f, 1 - cosThetaM * cosThetaM));
+    return V(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+}
+// The roughconductor's MicrofacetDistribution: flags bit1 sampleVisible, bit3 anisotropic (alphaV in reflectance[0]); Phong samples all normals (:141-145)
+struct MfD { uint32_t distr; float au, av; bool visible; };
+DEV MfD mfOfRoughConductor(const MaterialD &m) {
+    MfD d; d.distr = m.distr; d.au = maxf(m.alpha, 1e-4f); d.av = (m.flags & 8u) ? maxf(m.reflectance[0], 1e-4f) : d.au;
+    d.visible = (m.flags & 2u) != 0 && m.distr != 2u; return d;
+}
+DEV float mfdPdf(const MfD &d, v3 wi, v3 m) {                    // microfacet.h:269-274
+    if (d.visible) { if (wi.z == 0) return 0.0f; return mfSmithG1_2(d.distr, d.au, d.av, wi, m) * fabsf(dot(wi, m)) * mfEval2(d.distr, d.au, d.av, m) / fabsf(wi.z); }
+    return mfEval2(d.distr, d.au, d.av, m) * m.z;
+}
+// src/bsdfs/roughconductor.cpp:260-297, :299-324, :373-425
 DEV v3 rcEval(const MaterialD &m, v3 wi, v3 wo) {
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
-    float alpha = maxf(m.alpha, 1e-4f);
+    const MfD d = mfOfRoughConductor(m);
     v3 H = normalize(wo + wi);
-    float D = mfEval(m.distr, alpha, H);
+    float D = mfEval2(d.distr, d.au, d.av, H);
     if (D == 0) return V(0, 0, 0);
     v3 F = fresnelConductorExact(dot(wi, H), m.eta, m.k) * ld3(m.specular);
-    float G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H);
+    float G = mfSmithG1_2(d.distr, d.au, d.av, wi, H) * mfSmithG1_2(d.distr, d.au, d.av, wo, H);
     float model = D * G / (4.0f * wi.z);
     return F * model;
 }
 DEV float rcPdf(const MaterialD &m, v3 wi, v3 wo) {
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
-    float alpha = maxf(m.alpha, 1e-4f);
+    const MfD d = mfOfRoughConductor(m);
     v3 H = normalize(wo + wi);
-    return mfEval(m.distr, alpha, H) * mfSmithG1(m.distr, alpha, wi, H) / (4.0f * wi.z);
+    if (d.visible) return mfEval2(d.distr, d.au, d.av, H) * mfSmithG1_2(d.distr, d.au, d.av, wi, H) / (4.0f * wi.z);
+    return mfdPdf(d, wi, H) / (4 * fabsf(dot(wo, H)));
 }
 DEV v3 rcSample(const MaterialD &mt, v3 wi, float u, float v, v3 &wo, float &pdf, float &eta) {
     if (wi.z < 0) return V(0, 0, 0);
-    float alpha = maxf(mt.alpha, 1e-4f);
-    v3 m = mfSampleVisible(mt.distr, alpha, wi, u, v);
-    pdf = mfPdfVisible(mt.distr, alpha, wi, m);
+    const MfD d = mfOfRoughConductor(mt);
+    v3 m;
+    if (d.visible) { m = mfSampleVisible2(d.distr, d.au, d.av, wi, u, v); pdf = mfdPdf(d, wi, m); }
+    else m = mfSampleAll(d.distr, d.au, d.av, u, v, pdf);
     if (pdf == 0) return V(0, 0, 0);
     float c = 2 * dot(wi, m);
     wo = m * c - wi;
     eta = 1.0f;
     if (wo.z <= 0) return V(0, 0, 0);
     v3 F = fresnelConductorExact(dot(wi, m), mt.eta, mt.k) * ld3(mt.specular);
-    float weight = mfSmithG1(mt.distr, alpha, wo, m);
+    float weight;
+    if (d.visible) weight = mfSmithG1_2(d.distr, d.au, d.av, wo, m);
+    else weight = mfEval2(d.distr, d.au, d.av, m) * (mfSmithG1_2(d.distr, d.au, d.av, wi, m) * mfSmithG1_2(d.distr, d.au, d.av, wo, m)) * dot(wi, m) / (pdf * wi.z);
     pdf /= 4.0f * dot(wo, m);
     return F * weight;
 }
@@ -1045,7 +1138,6 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
 // ---------------------------------------------------------------------------------------------- environment emitter
 // src/emitters/envmap.cpp (level-0 bilinear lookups only; the reference EWA-filters camera rays that see the sky directly, :398-411).
 // atan2/acos/sin/cos come from the device math library: tolerance-pinned like the rough conductor.
-#define MI_INV_TWOPI 0.15915494309189533577f
 DEV v3 mat3(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z); }
 DEV float luminance(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
 // include/mitsuba/render/mipmap.h:504-560 evalTexel (u: ERepeat, v: EClamp)

@@ -5,6 +5,7 @@
 #define MI_EPSILON 1e-4f                    // reference include/mitsuba/core/constants.h:28
 #define MI_SHADOW_EPSILON 1e-3f             // constants.h:29
 #define MI_INV_PI 0.31830988618379067154f   // constants.h:64
+#define MI_INV_TWOPI 0.15915494309189533577f
 #define MI_ONE_MINUS_EPS 0.999999940395355225f
 #define MI_PI 3.14159265358979323846f
 #define MI_FILTER_RES 31                    // include/mitsuba/core/rfilter.h:28

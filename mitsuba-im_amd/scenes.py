@@ -36,6 +36,7 @@ SAMPLER_INDEPENDENT = 0
 SAMPLER_SOBOL = 1
 DISTR_BECKMANN = 0
 DISTR_GGX = 1
+DISTR_PHONG = 2            # isotropic: Phong; anisotropic: Ashikhmin-Shirley (src/bsdfs/microfacet.h:214-221); roughconductor only
 SHAPE_RECTANGLE = 0
 SHAPE_DISK = 1
 SHAPE_SPHERE = 2
@@ -96,7 +97,7 @@ def rough_transmittance_slice(distr, ior, alpha):
 
 def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
               distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
-              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False):
+              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False, alpha_v=None):
     if kind == BSDF_ROUGHDIELECTRIC:
         eta = (float(f32(ior)), 0.0, 0.0)
     table = None
@@ -107,7 +108,13 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         k = (float(f32(fresnel_diffuse_reflectance(1.0 / float(f32(ior))))), 0.0, 0.0) if kind == BSDF_PLASTIC else (0.0, 0.0, 0.0)
     if kind == BSDF_ROUGHPLASTIC:
         sample_visible = 2 if nonlinear else 1          # container field: the harness reads the nonlinear flag of roughplastic from here
-    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible), nonlinear=int(nonlinear), table=table, texture=-1,
+    aniso = 0
+    if kind == BSDF_ROUGHCONDUCTOR:
+        if distr == DISTR_PHONG:
+            sample_visible = False                     # microfacet.h:141-145: the Phong / Ashikhmin-Shirley distribution samples all normals
+        if alpha_v is not None and float(f32(alpha_v)) != float(f32(alpha)):
+            aniso = 1; reflectance = (float(f32(alpha_v)), 0.0, 0.0)      # roughconductor: anisotropic roughness, alphaV travels in reflectance[0] (flags bit3)
+    return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible), nonlinear=int(nonlinear), table=table, texture=-1, aniso=aniso,
                 reflectance=tuple(map(float, reflectance)), alpha=float(alpha),
                 eta=tuple(map(float, eta)), k=tuple(map(float, k)),
                 specular=tuple(map(float, specular)))
@@ -637,7 +644,7 @@ def _disc(b, center, normal, radius, n=32):
         b.tris.append((base, base + 1 + i, base + 1 + (i + 1) % n))
 
 
-def veach_mis(width=1920, height=1080, spp=512, sampler=SAMPLER_SOBOL, max_depth=12, rr_depth=5, filter_kind=FILTER_BOX):
+def veach_mis(width=1920, height=1080, spp=512, sampler=SAMPLER_SOBOL, max_depth=12, rr_depth=5, filter_kind=FILTER_BOX, microfacets=None, seed=0):
     """S2: Veach's multiple-importance-sampling test -- four tilted plates of increasing roughness
     (`twosided(roughconductor)`, Beckmann alpha 0.005 / 0.02 / 0.05 and GGX 0.1) reflecting four disc lights of radii
     0.03 / 0.1 / 0.3 / 0.9 with power-equalised radiance, over a diffuse floor and back wall; 140 triangles."""
@@ -652,17 +659,30 @@ def veach_mis(width=1920, height=1080, spp=512, sampler=SAMPLER_SOBOL, max_depth
     ]
     b.begin(); b.quad([(-10, -4.14615, -10), (-10, -4.14615, 10), (10, -4.14615, 10), (10, -4.14615, -10)]); b.end(grey)     # floor (+y)
     b.begin(); b.quad([(-10, -10, -2), (10, -10, -2), (10, 10, -2), (-10, 10, -2)]); b.end(grey)                           # back wall (+z)
-    for pts, alpha, distr, (eta, k) in plates:
-        m = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, twosided=True, alpha=alpha, distr=distr, eta=eta, k=k)
+    plate_shapes = []
+    for pi, (pts, alpha, distr, (eta, k)) in enumerate(plates):
+        kw = dict(alpha=alpha, distr=distr)
+        if microfacets is not None:                  # per-plate overrides: alpha, alpha_v, distr, sample_visible (the full MicrofacetDistribution of src/bsdfs/microfacet.h)
+            kw.update(microfacets[pi])
+        m = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, twosided=True, eta=eta, k=k, **kw)
         b.begin(); b.quad(pts); b.end(m)
+        plate_shapes.append(len(b.shapes) - 1)
     lightm = b.bsdf(reflectance=(0.0, 0.0, 0.0))
     for x, r, tint in [(-3.75, 0.03, (1.0, 0.6, 0.6)), (-1.25, 0.1, (1.0, 1.0, 0.6)), (1.25, 0.3, (0.6, 1.0, 0.6)), (3.75, 0.9, (0.6, 0.6, 1.0))]:
         rad = 8.0 / (math.pi * r * r)
         b.begin(); _disc(b, (x, 0.0, 0.0), (0.0, -0.8, 0.6), r); b.end(lightm, radiance=tuple(rad * t for t in tint))
     b.begin(); b.quad([(-3, 8, 0), (3, 8, 0), (3, 8, 6), (-3, 8, 6)]); b.end(lightm, radiance=(1.5, 1.5, 1.5))             # dim fill light (-y)
     cam = look_at((0, 2, 15), (0, -2, 2.5), (0, 1, 0))
+    uvs = None
+    if microfacets is not None:                      # anisotropic BSDFs need texture coordinates: the tangent is dp/du (TriMesh::configure, trimesh.cpp:380-382)
+        uvs = np.zeros((len(b.verts), 2), f32)
+        for sh in b.shapes: sh["has_uv"] = 0
+        for k_, si in enumerate(plate_shapes):
+            sh = b.shapes[si]; sh["has_uv"] = 1
+            quad = [(0, 0), (0, 1), (1, 1), (1, 0)] if k_ % 2 == 0 else [(0.2, 0), (0, 0.8), (0.9, 1), (1, 0.1)]       # every other plate: sheared uv, tangent off the plate's edge
+            uvs[sh["first_vert"]:sh["first_vert"] + 4] = quad
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 28.0, 0.1, 100.0,
-                        width, height, spp, sampler, max_depth, rr_depth, filter_kind, name="veach_mis")
+                        width, height, spp, sampler, max_depth, rr_depth, filter_kind, seed=seed, uvs=uvs, name="veach_mis")
 
 
 def procedural_sky(w=1024, h=512):
@@ -852,6 +872,20 @@ def sky_view(width=64, height=48, spp=16, sampler=SAMPLER_SOBOL, max_depth=5, rr
     return sc
 
 
+VEACH_MICROFACETS = [   # the plates of veach_mis with the rest of MicrofacetDistribution: anisotropy, all-normal sampling, Phong / Ashikhmin-Shirley
+    dict(alpha=0.02, alpha_v=0.1, distr=DISTR_BECKMANN, sample_visible=True),
+    dict(alpha=0.15, alpha_v=0.03, distr=DISTR_GGX, sample_visible=False),
+    dict(alpha=0.05, distr=DISTR_PHONG),
+    dict(alpha=0.04, alpha_v=0.2, distr=DISTR_PHONG),
+]
+VEACH_MICROFACETS_2 = [
+    dict(alpha=0.03, distr=DISTR_BECKMANN, sample_visible=False),
+    dict(alpha=0.05, alpha_v=0.25, distr=DISTR_BECKMANN, sample_visible=False),
+    dict(alpha=0.2, alpha_v=0.04, distr=DISTR_GGX, sample_visible=True),
+    dict(alpha=0.1, distr=DISTR_GGX, sample_visible=False),
+]
+
+
 # ---------------------------------------------------------------------------------------------
 # binary container for the oracle-side harness
 # ---------------------------------------------------------------------------------------------
@@ -870,7 +904,7 @@ def save_scene(sc, path):
             f.write(struct.pack("<4I2i2I", s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"],
                                 s["bsdf"], s["emitter"], (s["face_normals"] & 1) | ((s.get("has_uv", 0) & 1) << 1), s.get("group", 0)))
         for b in sc.bsdfs:
-            f.write(struct.pack("<4I", b["type"], b["twosided"], b["distr"], b["sample_visible"]))
+            f.write(struct.pack("<4I", b["type"], b["twosided"], b["distr"], b["sample_visible"] | (b.get("aniso", 0) << 2)))
             f.write(struct.pack("<13f", *b["reflectance"], b["alpha"], *b["eta"], *b["k"], *b["specular"]))
         for e in sc.emitters:
             f.write(struct.pack("<Ii4f", e["type"], e["shape"], *e["radiance"], e["weight"]))

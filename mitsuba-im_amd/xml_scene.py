@@ -386,19 +386,31 @@ def _ior(p, name, default):
     return float(v)
 
 
-def _microfacet(p):
+def _microfacet(p, full=False):
+    """MicrofacetDistribution(props) (src/bsdfs/microfacet.h:98-146).  full (roughconductor): phong / as, alphaU != alphaV, sampleVisible = false."""
     d = str(p.get("distribution", "beckmann")).lower()
-    if d not in ("beckmann", "ggx"):
-        raise SceneError(f"microfacet distribution \"{d}\" is not supported (beckmann, ggx)")
-    if p.has("alphaU") or p.has("alphaV"):
-        if p.get("alphaU") != p.get("alphaV"):
-            raise SceneError("anisotropic roughness (alphaU != alphaV) is not supported")
-        alpha = p.get("alphaU")
+    kinds = {"beckmann": S.DISTR_BECKMANN, "ggx": S.DISTR_GGX, "phong": S.DISTR_PHONG, "as": S.DISTR_PHONG}
+    if d not in kinds:
+        raise SceneError(f"Specified an invalid distribution \"{d}\", must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!")
+    alpha_v = None
+    if p.has("alpha"):
+        if p.has("alphaU") or p.has("alphaV"):
+            raise SceneError("Microfacet model: please specify either 'alpha' or 'alphaU'/'alphaV'.")
+        alpha = p.get("alpha")
+    elif p.has("alphaU") or p.has("alphaV"):
+        if not (p.has("alphaU") and p.has("alphaV")):
+            raise SceneError("Microfacet model: both 'alphaU' and 'alphaV' must be specified.")
+        alpha, alpha_v = p.get("alphaU"), p.get("alphaV")
     else:
-        alpha = p.get("alpha", 0.1)
-    if not isinstance(alpha, float):
+        alpha = 0.1
+    if not isinstance(alpha, float) or (alpha_v is not None and not isinstance(alpha_v, float)):
         raise SceneError("textured roughness is not supported")
-    return (S.DISTR_GGX if d == "ggx" else S.DISTR_BECKMANN), alpha, bool(p.get("sampleVisible", True))
+    sv = bool(p.get("sampleVisible", True))
+    if not full:
+        if kinds[d] == S.DISTR_PHONG or (alpha_v is not None and alpha_v != alpha) or not sv:
+            raise SceneError(f"{p.type}: implemented for isotropic beckmann / ggx with sampleVisible = true (the full distribution: roughconductor)")
+        return kinds[d], alpha, sv
+    return kinds[d], alpha, sv, alpha_v
 
 
 def _spectrum_or_texture(p, names, default):
@@ -507,8 +519,8 @@ class _SceneBuilder:
             if t == "conductor":
                 rec = S.make_bsdf(S.BSDF_CONDUCTOR, eta=eta, k=k, specular=spec, twosided=twosided)
             else:
-                distr, alpha, sv = _microfacet(p)
-                rec = S.make_bsdf(S.BSDF_ROUGHCONDUCTOR, eta=eta, k=k, specular=spec, alpha=alpha, distr=distr, sample_visible=sv, twosided=twosided)
+                distr, alpha, sv, alpha_v = _microfacet(p, full=True)
+                rec = S.make_bsdf(S.BSDF_ROUGHCONDUCTOR, eta=eta, k=k, specular=spec, alpha=alpha, alpha_v=alpha_v, distr=distr, sample_visible=sv, twosided=twosided)
         elif t in ("dielectric", "roughdielectric", "plastic", "roughplastic"):
             plastic = t.endswith("plastic")
             ior = float(f32(_ior(p, "intIOR", "polypropylene" if plastic else "bk7")) / f32(_ior(p, "extIOR", "air")))
@@ -528,8 +540,6 @@ class _SceneBuilder:
                     rec = S.make_bsdf(kind, alpha=alpha, distr=distr, sample_visible=sv, **kw)
                 except ValueError as e:
                     raise SceneError(f"roughplastic: {e}")
-                if kind == S.BSDF_ROUGHPLASTIC:
-                    rec["sample_visible"] = (2 if kw["nonlinear"] else 0) | (1 if sv else 0)
             else:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_DIELECTRIC, **kw)
         else:
@@ -892,7 +902,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
                f'\t\t<sampler type="{smp}"><integer name="sampleCount" value="{sc.spp}"/>{seed}</sampler>\n'
                f'\t\t<film type="hdrfilm"><integer name="width" value="{sc.width}"/><integer name="height" value="{sc.height}"/><boolean name="banner" value="false"/>'
                f'<rfilter type="{filt}">{fprops}</rfilter></film>\n\t</sensor>')
-    distr = {S.DISTR_BECKMANN: "beckmann", S.DISTR_GGX: "ggx"}
+    distr = {S.DISTR_BECKMANN: "beckmann", S.DISTR_GGX: "ggx", S.DISTR_PHONG: "phong"}
 
     def texture_xml(t, pname):
         kind = "checkerboard" if t["type"] == S.TEXTURE_CHECKERBOARD else "gridtexture"
@@ -900,8 +910,10 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
         return (f'<texture type="{kind}" name="{pname}">{rgb("color0", t["color0"])}{rgb("color1", t["color1"])}{lw}<float name="uoffset" value="{fmt([t["uoffset"]])}"/>'
                 f'<float name="voffset" value="{fmt([t["voffset"]])}"/><float name="uscale" value="{fmt([t["uscale"]])}"/><float name="vscale" value="{fmt([t["vscale"]])}"/></texture>')
     for i, b in enumerate(sc.bsdfs):
-        t = b["type"]; mf = f'<string name="distribution" value="{distr.get(b["distr"], "beckmann")}"/><float name="alpha" value="{fmt([b["alpha"]])}"/>'
-        sv = f'<boolean name="sampleVisible" value="{str(bool(b["sample_visible"] & 1)).lower()}"/>'
+        t = b["type"]; mf = f'<string name="distribution" value="{distr.get(b["distr"], "beckmann")}"/>' + (
+            f'<float name="alphaU" value="{fmt([b["alpha"]])}"/><float name="alphaV" value="{fmt([b["reflectance"][0]])}"/>' if b.get("aniso") else f'<float name="alpha" value="{fmt([b["alpha"]])}"/>')
+        vis = True if t == S.BSDF_ROUGHPLASTIC else bool(b["sample_visible"] & 1)      # roughplastic: the field doubles as the container's nonlinear flag (scenes.make_bsdf)
+        sv = f'<boolean name="sampleVisible" value="{str(vis).lower()}"/>'
         ior = f'<float name="intIOR" value="{fmt([b["eta"][0]])}"/><float name="extIOR" value="1"/>'
         cond = f'{rgb("eta", b["eta"])}{rgb("k", b["k"])}<float name="extEta" value="1"/>{rgb("specularReflectance", b["specular"])}'
         nl = f'<boolean name="nonlinear" value="{str(bool(b.get("nonlinear", 0))).lower()}"/>'

@@ -824,24 +824,37 @@ static float mi_erf(float x) {
     float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * fastexpf_(-x * x);
     return sign * y;
 }
-/* microfacet.h:190-237 eval (isotropic) */
-static float mf_eval(uint32_t distr, float alpha, v3 m) {
+#ifndef INV_TWOPI
+#define INV_TWOPI 0.15915494309189533577f
+#endif
+#define RCPOVERFLOW 0x1p-128f
+/* microfacet.h:190-237 eval: distr 0 Beckmann, 1 GGX, 2 Phong (isotropic) / Ashikhmin-Shirley (anisotropic); exponents :717-720, :559-570 */
+static inline float mf_phong_exponent(float alpha) { return maxf(2.0f / (alpha * alpha) - 2.0f, 0.0f); }
+static float mf_interp_exponent(float au, float av, v3 v) {
+    const float eu = mf_phong_exponent(au), ev = mf_phong_exponent(av), sinTheta2 = 1.0f - v.z * v.z;
+    if (au == av || sinTheta2 <= RCPOVERFLOW) return eu;
+    float invSinTheta2 = 1 / sinTheta2, cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+    return eu * cosPhi2 + ev * sinPhi2;
+}
+static float mf_eval2(uint32_t distr, float au, float av, v3 m) {
     if (m.z <= 0) return 0.0f;
     float cosTheta2 = m.z * m.z;
-    float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
+    float beckmannExponent = ((m.x * m.x) / (au * au) + (m.y * m.y) / (av * av)) / cosTheta2;
     float result;
-    if (distr == 0) result = fastexpf_(-beckmannExponent) / (M_PI_F * alpha * alpha * cosTheta2 * cosTheta2);
-    else { float root = (1.0f + beckmannExponent) * cosTheta2; result = 1.0f / (M_PI_F * alpha * alpha * root * root); }
+    if (distr == 0) result = fastexpf_(-beckmannExponent) / (M_PI_F * au * av * cosTheta2 * cosTheta2);
+    else if (distr == 1) { float root = (1.0f + beckmannExponent) * cosTheta2; result = 1.0f / (M_PI_F * au * av * root * root); }
+    else result = sqrtf((mf_phong_exponent(au) + 2) * (mf_phong_exponent(av) + 2)) * INV_TWOPI * powf(m.z, mf_interp_exponent(au, av, m));
     if (result * m.z < 1e-20f) result = 0;
     return result;
 }
-/* microfacet.h:476-517 smithG1 (isotropic: projectRoughness = alpha) */
+static float mf_eval(uint32_t distr, float alpha, v3 m) { return mf_eval2(distr, alpha, alpha, m); }
+/* microfacet.h:476-517 smithG1 with the roughness projected on v (projectRoughness :545-556); Phong uses the Beckmann fit */
 static float mf_smith_g1(uint32_t distr, float alpha, v3 v, v3 m) {
     if (dot(v, m) * v.z <= 0) return 0.0f;
     float temp = 1 - v.z * v.z;
     float tanTheta = temp <= 0.0f ? 0.0f : fabsf(sqrtf(temp) / v.z);       /* frame.h:122-127 */
     if (tanTheta == 0.0f) return 1.0f;
-    if (distr == 0) {
+    if (distr != 1) {
         float a = 1.0f / (alpha * tanTheta);
         if (a >= 1.6f) return 1.0f;
         float aSqr = a * a;
@@ -919,6 +932,82 @@ static float mf_pdf_visible(uint32_t distr, float alpha, v3 wi, v3 m) {
     if (wi.z == 0) return 0.0f;
     return mf_smith_g1(distr, alpha, wi, m) * fabsf(dot(wi, m)) * mf_eval(distr, alpha, m) / fabsf(wi.z);
 }
+/* microfacet.h:420-473 sampleVisible / pdfVisible with separate roughness along the tangent and bitangent */
+static v3 mf_sample_visible2(uint32_t distr, float au, float av, v3 wi_, float sx, float sy) {
+    v3 wi = normalize(V(au * wi_.x, av * wi_.y, wi_.z));
+    float theta = 0, phi = 0;
+    if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    float slx, sly; mf_sample_visible11(distr, theta, sx, sy, &slx, &sly);
+    float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+    rx *= au; ry *= av;
+    float normalization = 1.0f / sqrtf(rx * rx + ry * ry + 1.0f);
+    return V(-rx * normalization, -ry * normalization, normalization);
+}
+/* microfacet.h:545-556 projectRoughness */
+static float mf_project_roughness(float au, float av, v3 v) {
+    float invSinTheta2 = 1 / (1.0f - v.z * v.z);
+    if (au == av || invSinTheta2 <= 0) return au;
+    float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+    return sqrtf(cosPhi2 * au * au + sinPhi2 * av * av);
+}
+static float mf_smith_g1_2(uint32_t distr, float au, float av, v3 v, v3 m) { return mf_smith_g1(distr, mf_project_roughness(au, av, v), v, m); }
+/* microfacet.h:722-731 sampleFirstQuadrant (Ashikhmin-Shirley) */
+static void mf_sample_first_quadrant(float eu, float ev, float u1, float *phi, float *exponent) {
+    *phi = atanf(sqrtf((eu + 2.0f) / (ev + 2.0f)) * tanf(M_PI_F * u1 * 0.5f));
+    float sinPhi = sinf(*phi), cosPhi = cosf(*phi);
+    *exponent = eu * cosPhi * cosPhi + ev * sinPhi * sinPhi;
+}
+/* microfacet.h:286-392 sampleAll: all normals, density D(m) cos(theta_m) */
+static v3 mf_sample_all(uint32_t distr, float au, float av, float sx, float sy, float *pdf) {
+    float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
+    if (distr == 0 || distr == 1) {
+        if (au == av) { float ph = (2.0f * M_PI_F) * sy; sinPhiM = sinf(ph); cosPhiM = cosf(ph); alphaSqr = au * au; }
+        else {
+            float phiM = atanf(av / au * tanf(M_PI_F + 2 * M_PI_F * sy)) + M_PI_F * floorf(2 * sy + 0.5f);
+            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+            float cosSc = cosPhiM / au, sinSc = sinPhiM / av; alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+        }
+        if (distr == 0) {
+            float tanThetaMSqr = alphaSqr * -fastlogf_(1.0f - sx);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            *pdf = (1.0f - sx) / (M_PI_F * au * av * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            float tanThetaMSqr = alphaSqr * sx / (1.0f - sx);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            float temp = 1 + tanThetaMSqr / alphaSqr;
+            *pdf = INV_PI / (au * av * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+    } else {
+        const float eu = mf_phong_exponent(au), ev = mf_phong_exponent(av);
+        float phiM, exponent;
+        if (au == av) { phiM = (2.0f * M_PI_F) * sy; exponent = eu; }
+        else if (sy < 0.25f) mf_sample_first_quadrant(eu, ev, 4 * sy, &phiM, &exponent);
+        else if (sy < 0.5f) { mf_sample_first_quadrant(eu, ev, 4 * (0.5f - sy), &phiM, &exponent); phiM = M_PI_F - phiM; }
+        else if (sy < 0.75f) { mf_sample_first_quadrant(eu, ev, 4 * (sy - 0.5f), &phiM, &exponent); phiM += M_PI_F; }
+        else { mf_sample_first_quadrant(eu, ev, 4 * (1 - sy), &phiM, &exponent); phiM = 2 * M_PI_F - phiM; }
+        sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+        cosThetaM = powf(sx, 1.0f / (exponent + 2.0f));
+        *pdf = sqrtf((eu + 2.0f) * (ev + 2.0f)) * INV_TWOPI * powf(cosThetaM, exponent + 1.0f);
+    }
+    if (*pdf < 1e-20f) *pdf = 0;
+    float sinThetaM = sqrtf(maxf(0.0f, 1 - cosThetaM * cosThetaM));
+    return V(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+}
+/* microfacet.h:239-274 sample / pdf: visible normals or all normals; Phong never samples visible normals (:141-145) */
+typedef struct { uint32_t distr; float au, av; int visible; } mfd_t;
+static mfd_t mfd_of_roughconductor(const orc_material *m) {      /* flags bit1 sampleVisible, bit3 anisotropic: alphaV in reflectance[0] */
+    mfd_t d; d.distr = m->distr; d.au = maxf(m->alpha, 1e-4f); d.av = (m->flags & 8u) ? maxf(m->reflectance[0], 1e-4f) : d.au;
+    d.visible = (m->flags & 2u) != 0 && m->distr != 2; return d;
+}
+static float mfd_pdf(const mfd_t *d, v3 wi, v3 m) {
+    if (d->visible) { if (wi.z == 0) return 0.0f; return mf_smith_g1_2(d->distr, d->au, d->av, wi, m) * fabsf(dot(wi, m)) * mf_eval2(d->distr, d->au, d->av, m) / fabsf(wi.z); }
+    return mf_eval2(d->distr, d->au, d->av, m) * m.z;
+}
+static v3 mfd_sample(const mfd_t *d, v3 wi, float sx, float sy, float *pdf) {
+    if (d->visible) { v3 m = mf_sample_visible2(d->distr, d->au, d->av, wi, sx, sy); *pdf = mfd_pdf(d, wi, m); return m; }
+    return mf_sample_all(d->distr, d->au, d->av, sx, sy, pdf);
+}
 /* src/libcore/util.cpp:741-763 fresnelConductorExact, per RGB channel */
 static v3 fresnel_conductor_exact(float cosThetaI, const float *eta, const float *k) {
     float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
@@ -935,35 +1024,37 @@ static v3 fresnel_conductor_exact(float cosThetaI, const float *eta, const float
     }
     return V(out[0], out[1], out[2]);
 }
-static v3 rc_eval(const orc_material *m, v3 wi, v3 wo) {
+static v3 rc_eval(const orc_material *m, v3 wi, v3 wo) {                /* roughconductor.cpp:260-297 */
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
-    float alpha = maxf(m->alpha, 1e-4f);
+    const mfd_t d = mfd_of_roughconductor(m);
     v3 H = normalize(add(wo, wi));
-    float D = mf_eval(m->distr, alpha, H);
+    float D = mf_eval2(d.distr, d.au, d.av, H);
     if (D == 0) return V(0, 0, 0);
     v3 F = mul(fresnel_conductor_exact(dot(wi, H), m->eta, m->k), V(m->specular[0], m->specular[1], m->specular[2]));
-    float G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H);
+    float G = mf_smith_g1_2(d.distr, d.au, d.av, wi, H) * mf_smith_g1_2(d.distr, d.au, d.av, wo, H);
     float model = D * G / (4.0f * wi.z);
     return scale(F, model);
 }
-static float rc_pdf(const orc_material *m, v3 wi, v3 wo) {
+static float rc_pdf(const orc_material *m, v3 wi, v3 wo) {              /* roughconductor.cpp:299-324 */
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
-    float alpha = maxf(m->alpha, 1e-4f);
+    const mfd_t d = mfd_of_roughconductor(m);
     v3 H = normalize(add(wo, wi));
-    return mf_eval(m->distr, alpha, H) * mf_smith_g1(m->distr, alpha, wi, H) / (4.0f * wi.z);
+    if (d.visible) return mf_eval2(d.distr, d.au, d.av, H) * mf_smith_g1_2(d.distr, d.au, d.av, wi, H) / (4.0f * wi.z);
+    return mfd_pdf(&d, wi, H) / (4 * fabsf(dot(wo, H)));
 }
-static v3 rc_sample(const orc_material *mt, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {
+static v3 rc_sample(const orc_material *mt, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta) {   /* roughconductor.cpp:373-425 */
     if (wi.z < 0) return V(0, 0, 0);
-    float alpha = maxf(mt->alpha, 1e-4f);
-    v3 m = mf_sample_visible(mt->distr, alpha, wi, u, v);
-    *pdf = mf_pdf_visible(mt->distr, alpha, wi, m);
+    const mfd_t d = mfd_of_roughconductor(mt);
+    v3 m = mfd_sample(&d, wi, u, v, pdf);
     if (*pdf == 0) return V(0, 0, 0);
     float c = 2 * dot(wi, m);
     *wo = sub(scale(m, c), wi);                                  /* reflect(wi, m) = 2 dot(wi,m) m - wi */
     *eta = 1.0f;
     if (wo->z <= 0) return V(0, 0, 0);
     v3 F = mul(fresnel_conductor_exact(dot(wi, m), mt->eta, mt->k), V(mt->specular[0], mt->specular[1], mt->specular[2]));
-    float weight = mf_smith_g1(mt->distr, alpha, *wo, m);
+    float weight;
+    if (d.visible) weight = mf_smith_g1_2(d.distr, d.au, d.av, *wo, m);
+    else weight = mf_eval2(d.distr, d.au, d.av, m) * (mf_smith_g1_2(d.distr, d.au, d.av, wi, m) * mf_smith_g1_2(d.distr, d.au, d.av, *wo, m)) * dot(wi, m) / (*pdf * wi.z);
     *pdf /= 4.0f * dot(*wo, m);
     return scale(F, weight);
 }
@@ -1228,7 +1319,9 @@ void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float
 }
 
 /* ------------------------------------------------------------------------------------------------ environment emitter */
+#ifndef INV_TWOPI
 #define INV_TWOPI 0.15915494309189533577f
+#endif
 static inline v3 mat3(const float *m, v3 v) { return V(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z); }
 /* include/mitsuba/render/mipmap.h:504-560 evalTexel, level 0, u: ERepeat, v: EClamp (envmap.cpp:181-183) */
 static v3 env_texel(const orc_scene *s, int x, int y) {

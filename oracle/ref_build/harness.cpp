@@ -241,11 +241,12 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else {
             Properties p("roughconductor");
-            p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx");
-            p.setFloat("alpha", fb.alpha);
+            p.setString("distribution", fb.distr == 0 ? "beckmann" : fb.distr == 1 ? "ggx" : "phong");
+            if (fb.sampleVisible & 4u) { p.setFloat("alphaU", fb.alpha); p.setFloat("alphaV", fb.refl[0]); }     // anisotropic: alphaV travels in refl[0]
+            else p.setFloat("alpha", fb.alpha);
             p.setSpectrum("eta", rgb(fb.eta)); p.setSpectrum("k", rgb(fb.k));
             p.setSpectrum("specularReflectance", rgb(fb.spec));
-            p.setBoolean("sampleVisible", fb.sampleVisible != 0);
+            p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setString("material", "none"); p.setFloat("extEta", 1.0f);   // eta / k are given as RGB, already relative to the exterior
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         }

@@ -581,3 +581,30 @@ def test_sobol_scramble(mi, oracle, golden_scenes):
     assert not np.array_equal(r0.read_film(0), film)                 # a different scramble is a different sequence ...
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-4       # ... and this one is the reference's
+
+
+@pytest.mark.parametrize("name", ["veach_microfacets", "veach_microfacets_2"])
+def test_full_microfacet_distribution(mi, oracle, golden_scenes, name):
+    """SURVEY.md §8 a12, the rest of MicrofacetDistribution under roughconductor (src/bsdfs/microfacet.h): anisotropic Beckmann / GGX (alphaU != alphaV, the
+    tangent comes from the plates' texture coordinates), sampleVisible = false (sampleAll / pdfAll and the D G (wi.m) / (pdf cos) weight), Phong and
+    Ashikhmin-Shirley.  exp / log / pow / atan / tan come from the device math library -> tolerance-pinned against the oracle, the reference's own samples
+    and film next to it."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(21); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-4).mean() > 0.99 and (err < 1e-2).mean() > 0.999 and np.median(err) < 1e-6, ((err < 1e-4).mean(), (err < 1e-2).mean(), np.median(err))
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 1e-3).mean() > 0.99 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
+    # an anisotropic material on a mesh without texture coordinates is refused like TriMesh::computeUVTangents does
+    bad = type(sc)(sc); bad["shapes"] = [dict(s, has_uv=0) for s in sc.shapes]
+    if any(b.get("aniso") for b in sc.bsdfs):
+        with pytest.raises(mi.MiError, match="texture coordinates are required"):
+            mi.Scene(bad)

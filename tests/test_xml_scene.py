@@ -15,7 +15,7 @@ X = importlib.import_module("mitsuba-im_amd.xml_scene")
 S = importlib.import_module("mitsuba-im_amd.scenes")
 
 GENERATORS = ["cornell_box", "cbox_shapes", "cbox_materials", "cbox_lights", "open_constant", "cbox_translucent", "cbox_roughplastic", "textured_room",
-              "shape_lights", "veach_mis"]
+              "shape_lights", "veach_mis", "veach_microfacets"]
 
 
 def assert_same_scene(a, b, exact_analytic=False):
@@ -35,9 +35,10 @@ def assert_same_scene(a, b, exact_analytic=False):
         for k in ("first_tri", "tri_count", "bsdf", "emitter", "face_normals"):
             assert sa[k] == sb[k], k
     for ba, bb in zip(a.bsdfs, b.bsdfs):
+        assert ba.get("aniso", 0) == bb.get("aniso", 0) and ba.get("nonlinear", 0) == bb.get("nonlinear", 0)
         for k in ("type", "twosided", "distr", "texture"):
             assert ba[k] == bb[k], (k, ba, bb)
-        assert (ba["sample_visible"] & 1) == (bb["sample_visible"] & 1) or ba["type"] not in (S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHDIELECTRIC, S.BSDF_ROUGHPLASTIC)
+        assert (ba["sample_visible"] & 1) == (bb["sample_visible"] & 1) or ba["type"] not in (S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHDIELECTRIC)
         for k in ("reflectance", "specular", "eta", "k"):
             np.testing.assert_allclose(ba[k], bb[k], rtol=2e-7, atol=0, err_msg=k)
         assert ba["alpha"] == pytest.approx(bb["alpha"], rel=1e-7)
@@ -60,7 +61,7 @@ def assert_same_scene(a, b, exact_analytic=False):
 @pytest.mark.parametrize("gen", GENERATORS)
 @pytest.mark.parametrize("fmt", ["serialized", "obj"])
 def test_export_load_round_trip(gen, fmt, tmp_path):
-    sc = getattr(S, gen)(width=48, height=32, spp=4)
+    sc = S.veach_mis(width=48, height=32, spp=4, microfacets=S.VEACH_MICROFACETS) if gen == "veach_microfacets" else getattr(S, gen)(width=48, height=32, spp=4)
     path = X.export_scene(sc, str(tmp_path), mesh_format=fmt)
     assert_same_scene(sc, X.load_scene(path))
 
