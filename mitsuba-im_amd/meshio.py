@@ -15,6 +15,7 @@ Reference behaviour followed (file:line, reference = /root/reference):
 Checked against the compiled reference plugins by tests/test_oracle_golden.py (fixtures: tests/golden/mesh_*.npz).  The reference's
 PLY plugin cannot be built here (its parser needs boost::mpl): the PLY reader is pinned through the same mesh written as OBJ.
 """
+import math
 import os
 import struct
 import zlib
@@ -118,6 +119,59 @@ def generate_vertex_normals(positions, triangles, flip=False):
     return out
 
 
+def rebuild_topology(mesh, max_angle):
+    """TriMesh::rebuildTopology (trimesh.cpp:468-606, the `maxSmoothAngle` parameter): vertices are split wherever the adjacent faces' normals differ by
+    more than `max_angle` degrees (greedy clustering per vertex in the reference's order: vertex keys (p, uv) sorted lexicographically, faces in
+    mesh order, each cluster seeded by its first face), existing normals are dropped; the caller regenerates them (configure_mesh)."""
+    P = mesh.positions; T = mesh.triangles.astype(np.int64); UV = mesh.uv
+    thresh = F(math.cos(math.radians(float(F(max_angle)))))
+    v0, v1, v2 = P[T[:, 0]], P[T[:, 1]], P[T[:, 2]]
+    n = np.cross((v1 - v0).astype(F), (v2 - v0).astype(F)).astype(F)
+    l = np.sqrt((n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1]) + n[:, 2] * n[:, 2]).astype(F)
+    ok = l > F(2.93873587705571876e-39)
+    fn = np.where(ok[:, None], n / np.where(ok, l, F(1))[:, None], F(0)).astype(F)
+    corners = T.reshape(-1)                                            # entry e = corner e % 3 of triangle e // 3, in insertion order
+    key = P[corners] + F(0)
+    if UV is not None:
+        key = np.concatenate([key, UV[corners] + F(0)], axis=1)
+    order = np.lexsort(tuple(key[:, c] for c in range(key.shape[1] - 1, -1, -1)))      # stable: equal keys keep insertion order (std::multimap)
+    sk = key[order]
+    boundary = np.ones(len(order), bool); boundary[1:] = np.any(sk[1:] != sk[:-1], axis=1)
+    starts = np.flatnonzero(boundary); ends = np.append(starts[1:], len(order))
+    new_T = np.full_like(T, -1); new_P = []; new_UV = []
+    fnl = fn.tolist(); thr = float(thresh)
+    for a, b in zip(starts.tolist(), ends.tolist()):
+        entries = order[a:b].tolist(); tris = [e // 3 for e in entries]
+        vp = P[corners[entries[0]]]
+        clustered = [False] * len(entries)
+        for i in range(len(entries)):
+            if clustered[i]:
+                continue
+            vid = len(new_P); new_P.append(vp)
+            if UV is not None:
+                new_UV.append(UV[corners[entries[0]]])
+            n1 = fnl[tris[i]]
+            for j in range(i, len(entries)):
+                if clustered[j]:
+                    continue
+                n2 = fnl[tris[j]]
+                d = float(F(F(F(n1[0]) * F(n2[0]) + F(n1[1]) * F(n2[1])) + F(n1[2]) * F(n2[2])))
+                if n1 == n2 or d > thr:
+                    t = tris[j]
+                    for c in range(3):
+                        q = P[T[t, c]]
+                        if q[0] == vp[0] and q[1] == vp[1] and q[2] == vp[2]:
+                            new_T[t, c] = vid
+                    clustered[j] = True
+    if (new_T < 0).any():
+        raise MeshError("rebuildTopology: internal error (unassigned triangle corner)")
+    mesh.positions = np.ascontiguousarray(np.asarray(new_P, F).reshape(-1, 3))
+    mesh.uv = None if UV is None else np.ascontiguousarray(np.asarray(new_UV, F).reshape(-1, 2))
+    mesh.triangles = new_T.astype(np.uint32)
+    mesh.normals = None
+    return mesh
+
+
 def configure_mesh(mesh, face_normals=False, flip_normals=False):
     """TriMesh::configure() -> computeNormals() (trimesh.cpp:608-683)."""
     if face_normals:
@@ -131,6 +185,14 @@ def configure_mesh(mesh, face_normals=False, flip_normals=False):
     else:
         mesh.normals = generate_vertex_normals(mesh.positions, mesh.triangles, flip_normals)
     return mesh
+
+
+def _finish(mesh, face_normals, flip_normals, max_smooth_angle):
+    if max_smooth_angle is not None:
+        if face_normals:
+            raise MeshError("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!")
+        rebuild_topology(mesh, max_smooth_angle)
+    return configure_mesh(mesh, face_normals, flip_normals)
 
 
 # ---- Wavefront OBJ ---------------------------------------------------------------------------------------------------------------
@@ -210,7 +272,7 @@ def _obj_create_mesh(name, material, vertices, normals, texcoords, corners, to_w
     return Mesh(name, verts[:, 0:3], idx, verts[:, 3:6] if has_n else None, verts[:, 6:8] if has_uv else None, material=material)
 
 
-def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_tex_coords=True, collapse=False, shape_index=-1):
+def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_tex_coords=True, collapse=False, shape_index=-1, max_smooth_angle=None):
     """All meshes of a Wavefront OBJ file (one per `g` / `usemtl` run unless `collapse`), configured."""
     if not os.path.exists(path):
         raise MeshError(f"Wavefront OBJ file '{path}' not found!")
@@ -279,7 +341,7 @@ def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_t
         m = _obj_create_mesh(name, material, vertices, normals, texcoords, corners, tw, twi)
         if m is not None:
             meshes.append(m)
-    return [configure_mesh(m, face_normals, flip_normals) for m in meshes]
+    return [_finish(m, face_normals, flip_normals, max_smooth_angle) for m in meshes]
 
 
 # ---- Stanford PLY ----------------------------------------------------------------------------------------------------------------
@@ -287,7 +349,7 @@ _PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short":
               "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
 
 
-def load_ply(path, to_world=None, face_normals=False, flip_normals=False):
+def load_ply(path, to_world=None, face_normals=False, flip_normals=False, max_smooth_angle=None):
     if not os.path.exists(path):
         raise MeshError(f"PLY file \"{path}\" could not be found!")
     with open(path, "rb") as f:
@@ -400,7 +462,7 @@ def load_ply(path, to_world=None, face_normals=False, flip_normals=False):
     if N is not None:
         N = _normalize_rows(N)
     m = Mesh(os.path.splitext(os.path.basename(path))[0], P, tris, N, UV)
-    return [configure_mesh(m, face_normals, flip_normals)]
+    return [_finish(m, face_normals, flip_normals, max_smooth_angle)]
 
 
 # ---- Mitsuba .serialized ---------------------------------------------------------------------------------------------------------
@@ -417,7 +479,7 @@ def _serialized_offsets(data, version):
     return list(struct.unpack_from(f"<{count}I", data, len(data) - 4 * (count + 1)))
 
 
-def load_serialized(path, shape_index=0, to_world=None, face_normals=False, flip_normals=False, name=None):
+def load_serialized(path, shape_index=0, to_world=None, face_normals=False, flip_normals=False, name=None, max_smooth_angle=None):
     if shape_index < 0:
         raise MeshError("Shape index must be nonnegative!")
     with open(path, "rb") as f:
@@ -467,7 +529,7 @@ def load_serialized(path, shape_index=0, to_world=None, face_normals=False, flip
             T = np.ascontiguousarray(T[:, [1, 0, 2]])
     base = os.path.splitext(os.path.basename(path))[0]
     m = Mesh(mesh_name or name or f"{base}@{shape_index}", P, T, N, UV)
-    return [configure_mesh(m, face_normals, flip_normals)]
+    return [_finish(m, face_normals, flip_normals, max_smooth_angle)]
 
 
 def save_serialized(path, meshes):

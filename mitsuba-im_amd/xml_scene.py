@@ -606,9 +606,9 @@ class _SceneBuilder:
                 raise SceneError("Instancing of emitters is not supported")       # src/shapes/shapegroup.cpp
         order = self.order; self.order += 1
         if t in ("obj", "ply", "serialized", "cube"):
-            if p.has("maxSmoothAngle"):
-                raise SceneError("maxSmoothAngle (TriMesh::rebuildTopology) is not supported")
             kw = dict(to_world=tw, face_normals=bool(p.get("faceNormals", False)), flip_normals=bool(p.get("flipNormals", False)))
+            if t != "cube" and p.has("maxSmoothAngle"):
+                kw["max_smooth_angle"] = p.get("maxSmoothAngle")
             try:
                 if t == "cube":
                     meshes = meshio.make_cube(**kw)

@@ -137,6 +137,13 @@ def main():
                         positions_sel=ref["positions"][sel], normals_sel=ref["normals"][sel], triangles_sel=ref["triangles"][::16],
                         positions_sum=ref["positions"].astype(np.float64).sum(0), normals_sum=ref["normals"].astype(np.float64).sum(0),
                         triangles_sum=ref["triangles"].astype(np.int64).sum(0))
+    # -- maxSmoothAngle (TriMesh::rebuildTopology): the OBJ statements file (with uv) at 40 degrees, the bunny at 25 degrees
+    np.savez_compressed(os.path.join(HERE, "mesh_obj_smooth40.npz"), **pack(run_mesh("obj", obj, max_smooth=40)))
+    with tempfile.TemporaryDirectory() as tmp:
+        p = os.path.join(tmp, "bunny.obj"); meshio.save_obj(p, m)
+        r = run_mesh("obj", p, max_smooth=25)[0]
+    np.savez_compressed(os.path.join(HERE, "mesh_bunny_smooth25.npz"), n_verts=np.array(len(r["positions"])), triangles_sum=r["triangles"].astype(np.int64).sum(0),
+                        triangles_sel=r["triangles"][::16], sel=np.arange(0, len(r["positions"]), 16), positions_sel=r["positions"][::16], normals_sel=r["normals"][::16])
     print("mesh fixtures written")
 
 

@@ -147,3 +147,22 @@ def test_ply_ascii_quads_and_properties(tmp_path):
                                         "0 0 0\n1 0 0\n1 1 0\n0 1 0\n0 0 1\n5 0 1 2 3 4\n")
     with pytest.raises(meshio.MeshError, match="Only triangle and quad"):
         meshio.load_ply(str(tmp_path / "penta.ply"))
+
+
+def test_max_smooth_angle_matches_reference(tmp_path):
+    """`maxSmoothAngle` = TriMesh::rebuildTopology (trimesh.cpp:468-606): vertex splitting at creases, then regenerated normals -- vertex numbering,
+    triangles and positions identical to the reference's, on the OBJ statements file (with texture coordinates) and on the bunny (35947 -> 37862 vertices)."""
+    g = np.load(os.path.join(GOLD, "mesh_obj_smooth40.npz"))
+    check(meshio.load_obj(os.path.join(MESHES, "statements.obj"), max_smooth_angle=40.0), g)
+    raw = meshio.load_ply(os.path.join(MESHES, "bunny.ply"))[0]; raw.normals = None
+    meshio.save_obj(str(tmp_path / "bunny.obj"), raw)
+    m = meshio.load_obj(str(tmp_path / "bunny.obj"), max_smooth_angle=25.0)[0]
+    g = np.load(os.path.join(GOLD, "mesh_bunny_smooth25.npz"))
+    assert len(m.positions) == int(g["n_verts"]) == 37862
+    np.testing.assert_array_equal(m.triangles[::16], g["triangles_sel"]); np.testing.assert_array_equal(m.triangles.astype(np.int64).sum(0), g["triangles_sum"])
+    np.testing.assert_array_equal(m.positions[::16], g["positions_sel"]); np.testing.assert_allclose(m.normals[::16], g["normals_sel"], rtol=0, atol=2e-6)
+    # the PLY loader takes the same parameter (same surface: the PLY holds duplicate positions the OBJ path merges first, so only the corner normals are compared)
+    mp = meshio.load_ply(os.path.join(MESHES, "bunny.ply"), max_smooth_angle=25.0)[0]
+    np.testing.assert_array_equal(mp.positions[mp.triangles.reshape(-1)], m.positions[m.triangles.reshape(-1)])
+    with pytest.raises(meshio.MeshError, match="can't be specified at the same time"):
+        meshio.load_obj(os.path.join(MESHES, "statements.obj"), max_smooth_angle=40.0, face_normals=True)
