@@ -53,7 +53,7 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
-#define MI_BSDF_FLAG_ANISOTROPIC 8u /* roughconductor: alphaU = alpha, alphaV = reflectance[0] (src/bsdfs/microfacet.h:116-127); its shapes need texture coordinates */
+#define MI_BSDF_FLAG_ANISOTROPIC 8u /* alphaU = alpha, alphaV = reflectance[0] (roughconductor) / k[0] (roughdielectric) (src/bsdfs/microfacet.h:116-127); mesh shapes need texture coordinates */
 #define MI_BSDF_TEXTURE(i) (((uint32_t) (i) + 1u) << 8)   /* flags bits 8..23: texture i (mi_scene_set_textures) bound to `reflectance`; diffuse only */
 
 /* 2-D procedural textures over Texture2D (src/librender/texture.cpp:81-121: uv * scale + offset): src/textures/checkerboard.cpp, gridtexture.cpp */
@@ -67,7 +67,7 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 typedef struct { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale;
                  uint32_t wrap_u, wrap_v, filter; float max_anisotropy; uint32_t first_level, n_levels; } mi_texture;
 typedef struct {
-    uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx, 2 phong / Ashikhmin-Shirley (roughconductor only; samples all normals, microfacet.h:141-145) */
+    uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx, 2 phong / Ashikhmin-Shirley (roughconductor, roughdielectric; samples all normals, microfacet.h:141-145) */
     float alpha;
     float reflectance[3], eta[3], k[3], specular[3];
 } mi_material;

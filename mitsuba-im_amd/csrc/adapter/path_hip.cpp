@@ -214,9 +214,15 @@ static mi_material convertBSDF(const BSDF *bsdf) {
         }
         if (cls == "RoughDielectric") {
             std::string distr = props.getString("distribution", "beckmann"); std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
-            if (props.hasProperty("alphaU") || props.hasProperty("alphaV") || (distr != "beckmann" && distr != "ggx") || !props.getBoolean("sampleVisible", true))
-                SLog(EError, "path_hip: roughdielectric is implemented for isotropic beckmann / ggx with sampleVisible = true");
-            m.type = MI_BSDF_ROUGHDIELECTRIC; m.flags = MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr == "ggx" ? 1u : 0u; m.alpha = props.getFloat("alpha", 0.1f);
+            // MicrofacetDistribution(props) (microfacet.h:98-146), as for the rough conductor; alphaV travels in k[0]
+            if (distr != "beckmann" && distr != "ggx" && distr != "phong" && distr != "as") SLog(EError, "Specified an invalid distribution \"%s\", must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!", distr.c_str());
+            m.type = MI_BSDF_ROUGHDIELECTRIC; m.distr = distr == "ggx" ? 1u : distr == "beckmann" ? 0u : 2u;
+            m.flags = (props.getBoolean("sampleVisible", true) && m.distr != 2u) ? MI_BSDF_FLAG_SAMPLE_VISIBLE : 0u;
+            if (props.hasProperty("alphaU") || props.hasProperty("alphaV")) {
+                if (!props.hasProperty("alphaU") || !props.hasProperty("alphaV")) SLog(EError, "Microfacet model: both 'alphaU' and 'alphaV' must be specified.");
+                m.alpha = props.getFloat("alphaU"); const Float av = props.getFloat("alphaV");
+                if (av != m.alpha) { m.flags |= MI_BSDF_FLAG_ANISOTROPIC; m.k[0] = av; }
+            } else m.alpha = props.getFloat("alpha", 0.1f);
             m.eta[0] = lookupIOR(props, "intIOR", "bk7") / lookupIOR(props, "extIOR", "air");
             rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.reflectance);
             return m;

@@ -831,6 +831,20 @@ DEV float mfdPdf(const MfD &d, v3 wi, v3 m) {                    // microfacet.h
     if (d.visible) { if (wi.z == 0) return 0.0f; return mfSmithG1_2(d.distr, d.au, d.av, wi, m) * fabsf(dot(wi, m)) * mfEval2(d.distr, d.au, d.av, m) / fabsf(wi.z); }
     return mfEval2(d.distr, d.au, d.av, m) * m.z;
 }
+DEV MfD mfOfRoughDielectric(const MaterialD &m) {               // alphaV in k[0] when flags bit3 is set
+    MfD d; d.distr = m.distr; d.au = maxf(m.alpha, 1e-4f); d.av = (m.flags & 8u) ? maxf(m.k[0], 1e-4f) : d.au;
+    d.visible = (m.flags & 2u) != 0 && m.distr != 2u; return d;
+}
+// roughdielectric.cpp:409-414: Walter et al.'s widened sampling distribution unless visible normals are sampled (scaleAlpha, microfacet.h:180-185)
+DEV MfD mfSampling(const MfD &d, float cosThetaI) {
+    MfD s = d;
+    if (!d.visible) { float f = 1.2f - 0.2f * sqrtf(fabsf(cosThetaI)); s.au *= f; s.av *= f; }
+    return s;
+}
+DEV v3 mfdSample(const MfD &d, v3 wi, float sx, float sy, float &pdf) {      // microfacet.h:239-248
+    if (d.visible) { v3 m = mfSampleVisible2(d.distr, d.au, d.av, wi, sx, sy); pdf = mfdPdf(d, wi, m); return m; }
+    return mfSampleAll(d.distr, d.au, d.av, sx, sy, pdf);
+}
 // src/bsdfs/roughconductor.cpp:260-297, :299-324, :373-425
 DEV v3 rcEval(const MaterialD &m, v3 wi, v3 wo) {
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
@@ -951,13 +965,13 @@ DEV v3 plasticSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, floa
 DEV float signum_(float v) { return copysignf(1.0f, v); }
 DEV v3 rdEval(const MaterialD &m, v3 wi, v3 wo) {
     if (wi.z == 0) return V(0, 0, 0);
-    const float etaM = m.eta[0], invEta = 1 / etaM, alpha = maxf(m.alpha, 1e-4f); const bool reflect = wi.z * wo.z > 0; v3 H;
+    const float etaM = m.eta[0], invEta = 1 / etaM; const MfD d = mfOfRoughDielectric(m); const bool reflect = wi.z * wo.z > 0; v3 H;
     if (reflect) H = normalize(wo + wi);
     else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(wi + wo * eta); }
     H = H * signum_(H.z);
-    float D = mfEval(m.distr, alpha, H); if (D == 0) return V(0, 0, 0);
+    float D = mfEval2(d.distr, d.au, d.av, H); if (D == 0) return V(0, 0, 0);
     float ct, F = fresnelDielectricExt(dot(wi, H), ct, etaM);
-    float G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H);
+    float G = mfSmithG1_2(d.distr, d.au, d.av, wi, H) * mfSmithG1_2(d.distr, d.au, d.av, wo, H);
     if (reflect) { float value = F * D * G / (4.0f * fabsf(wi.z)); return ld3(m.specular) * value; }
     float eta = wi.z > 0.0f ? etaM : invEta;
     float sqrtDenom = dot(wi, H) + eta * dot(wo, H);
@@ -966,20 +980,19 @@ DEV v3 rdEval(const MaterialD &m, v3 wi, v3 wo) {
     return ld3(m.reflectance) * fabsf(value * factor * factor);
 }
 DEV float rdPdf(const MaterialD &m, v3 wi, v3 wo) {
-    const float etaM = m.eta[0], invEta = 1 / etaM, alpha = maxf(m.alpha, 1e-4f); const bool reflect = wi.z * wo.z > 0; v3 H; float dwh_dwo;
+    const float etaM = m.eta[0], invEta = 1 / etaM; const MfD d = mfSampling(mfOfRoughDielectric(m), wi.z); const bool reflect = wi.z * wo.z > 0; v3 H; float dwh_dwo;
     if (reflect) { H = normalize(wo + wi); dwh_dwo = 1.0f / (4.0f * dot(wo, H)); }
     else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(wi + wo * eta); float sqrtDenom = dot(wi, H) + eta * dot(wo, H); dwh_dwo = (eta * eta * dot(wo, H)) / (sqrtDenom * sqrtDenom); }
     H = H * signum_(H.z);
-    float prob = mfPdfVisible(m.distr, alpha, wi * signum_(wi.z), H);
+    float prob = mfdPdf(d, wi * signum_(wi.z), H);
     float ct, F = fresnelDielectricExt(dot(wi, H), ct, etaM);
     prob *= reflect ? F : (1 - F);
     return fabsf(prob * dwh_dwo);
 }
 DEV v3 rdSample(const MaterialD &mt, v3 wi, float sx, float sy, float extra, v3 &wo, float &pdf, float &etaOut) {
-    const float etaM = mt.eta[0], invEta = 1 / etaM, alpha = maxf(mt.alpha, 1e-4f);
+    const float etaM = mt.eta[0], invEta = 1 / etaM; const MfD d = mfOfRoughDielectric(mt);
     v3 wiS = wi * signum_(wi.z);
-    v3 m = mfSampleVisible(mt.distr, alpha, wiS, sx, sy);
-    float microfacetPDF = mfPdfVisible(mt.distr, alpha, wiS, m);
+    float microfacetPDF; v3 m = mfdSample(mfSampling(d, wi.z), wiS, sx, sy, microfacetPDF);
     if (microfacetPDF == 0) return V(0, 0, 0);
     pdf = microfacetPDF;
     float cosThetaT, F = fresnelDielectricExt(dot(wi, m), cosThetaT, etaM);
@@ -1001,7 +1014,8 @@ DEV v3 rdSample(const MaterialD &mt, v3 wi, float sx, float sy, float extra, v3 
         float sqrtDenom = dot(wi, m) + etaOut * dot(wo, m);
         dwh_dwo = (etaOut * etaOut * dot(wo, m)) / (sqrtDenom * sqrtDenom);
     }
-    weight = weight * mfSmithG1(mt.distr, alpha, wo, m);
+    if (d.visible) weight = weight * mfSmithG1_2(d.distr, d.au, d.av, wo, m);           // roughdielectric.cpp:607-612
+    else weight = weight * fabsf(mfEval2(d.distr, d.au, d.av, m) * (mfSmithG1_2(d.distr, d.au, d.av, wi, m) * mfSmithG1_2(d.distr, d.au, d.av, wo, m)) * dot(wi, m) / (microfacetPDF * wi.z));
     pdf *= fabsf(dwh_dwo);
     return weight;
 }

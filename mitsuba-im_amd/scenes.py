@@ -109,11 +109,13 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
     if kind == BSDF_ROUGHPLASTIC:
         sample_visible = 2 if nonlinear else 1          # container field: the harness reads the nonlinear flag of roughplastic from here
     aniso = 0
-    if kind == BSDF_ROUGHCONDUCTOR:
+    if kind in (BSDF_ROUGHCONDUCTOR, BSDF_ROUGHDIELECTRIC):
         if distr == DISTR_PHONG:
             sample_visible = False                     # microfacet.h:141-145: the Phong / Ashikhmin-Shirley distribution samples all normals
         if alpha_v is not None and float(f32(alpha_v)) != float(f32(alpha)):
-            aniso = 1; reflectance = (float(f32(alpha_v)), 0.0, 0.0)      # roughconductor: anisotropic roughness, alphaV travels in reflectance[0] (flags bit3)
+            aniso = 1                                  # anisotropic roughness (flags bit3): alphaV travels in reflectance[0] (roughconductor) / k[0] (roughdielectric)
+            if kind == BSDF_ROUGHCONDUCTOR: reflectance = (float(f32(alpha_v)), 0.0, 0.0)
+            else: k = (float(f32(alpha_v)), 0.0, 0.0)
     return dict(type=kind, twosided=int(twosided), distr=distr, sample_visible=int(sample_visible), nonlinear=int(nonlinear), table=table, texture=-1, aniso=aniso,
                 reflectance=tuple(map(float, reflectance)), alpha=float(alpha),
                 eta=tuple(map(float, eta)), k=tuple(map(float, k)),
@@ -482,14 +484,14 @@ def instanced_garden(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_dep
     return add_scene_emitters(sc, [constant_emitter((0.25, 0.3, 0.4))])
 
 
-def cbox_translucent(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=10, rr_depth=5, seed=0, strict_normals=False, hide_emitters=False):
+def cbox_translucent(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=10, rr_depth=5, seed=0, strict_normals=False, hide_emitters=False, frost_kw=None, slab_kw=None):
     """Cornell room with `roughdielectric` (frosted Beckmann sphere, GGX slab -- microfacet refraction, draws one extra sampler dimension per
     bounce) and a `difftrans` sheet in front of the back wall."""
     b = _Builder()
     white = b.bsdf(reflectance=(0.725, 0.71, 0.68)); red = b.bsdf(reflectance=(0.63, 0.065, 0.05)); green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
     lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78))
-    frost = b.bsdf(kind=BSDF_ROUGHDIELECTRIC, alpha=0.15, distr=DISTR_BECKMANN, ior=1.5046, reflectance=(0.97, 1.0, 0.95), specular=(1.0, 1.0, 1.0))
-    slab = b.bsdf(kind=BSDF_ROUGHDIELECTRIC, alpha=0.3, distr=DISTR_GGX, ior=1.33, reflectance=(0.8, 0.9, 1.0), specular=(0.9, 0.9, 0.9))
+    frost = b.bsdf(kind=BSDF_ROUGHDIELECTRIC, ior=1.5046, reflectance=(0.97, 1.0, 0.95), specular=(1.0, 1.0, 1.0), **(frost_kw or dict(alpha=0.15, distr=DISTR_BECKMANN)))
+    slab = b.bsdf(kind=BSDF_ROUGHDIELECTRIC, ior=1.33, reflectance=(0.8, 0.9, 1.0), specular=(0.9, 0.9, 0.9), **(slab_kw or dict(alpha=0.3, distr=DISTR_GGX)))   # the slab mesh has no uv: isotropic only
     shade = b.bsdf(kind=BSDF_DIFFTRANS, reflectance=(0.7, 0.55, 0.3))
     b.begin(); b.quad([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]); b.end(white)
     b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)

@@ -408,7 +408,7 @@ def _microfacet(p, full=False):
     sv = bool(p.get("sampleVisible", True))
     if not full:
         if kinds[d] == S.DISTR_PHONG or (alpha_v is not None and alpha_v != alpha) or not sv:
-            raise SceneError(f"{p.type}: implemented for isotropic beckmann / ggx with sampleVisible = true (the full distribution: roughconductor)")
+            raise SceneError(f"{p.type}: implemented for isotropic beckmann / ggx with sampleVisible = true (the full distribution: roughconductor, roughdielectric)")
         return kinds[d], alpha, sv
     return kinds[d], alpha, sv, alpha_v
 
@@ -534,8 +534,11 @@ class _SceneBuilder:
             elif twosided:
                 raise SceneError("twosided cannot wrap a transmissive BSDF")        # src/bsdfs/twosided.cpp:77-80
             if t.startswith("rough"):
-                distr, alpha, sv = _microfacet(p)
                 kind = S.BSDF_ROUGHPLASTIC if plastic else S.BSDF_ROUGHDIELECTRIC
+                if plastic:
+                    distr, alpha, sv = _microfacet(p)
+                else:
+                    distr, alpha, sv, kw["alpha_v"] = _microfacet(p, full=True)
                 try:
                     rec = S.make_bsdf(kind, alpha=alpha, distr=distr, sample_visible=sv, **kw)
                 except ValueError as e:
@@ -911,7 +914,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
                 f'<float name="voffset" value="{fmt([t["voffset"]])}"/><float name="uscale" value="{fmt([t["uscale"]])}"/><float name="vscale" value="{fmt([t["vscale"]])}"/></texture>')
     for i, b in enumerate(sc.bsdfs):
         t = b["type"]; mf = f'<string name="distribution" value="{distr.get(b["distr"], "beckmann")}"/>' + (
-            f'<float name="alphaU" value="{fmt([b["alpha"]])}"/><float name="alphaV" value="{fmt([b["reflectance"][0]])}"/>' if b.get("aniso") else f'<float name="alpha" value="{fmt([b["alpha"]])}"/>')
+            f'<float name="alphaU" value="{fmt([b["alpha"]])}"/><float name="alphaV" value="{fmt([b["reflectance"][0] if b["type"] == S.BSDF_ROUGHCONDUCTOR else b["k"][0]])}"/>' if b.get("aniso") else f'<float name="alpha" value="{fmt([b["alpha"]])}"/>')
         vis = True if t == S.BSDF_ROUGHPLASTIC else bool(b["sample_visible"] & 1)      # roughplastic: the field doubles as the container's nonlinear flag (scenes.make_bsdf)
         sv = f'<boolean name="sampleVisible" value="{str(vis).lower()}"/>'
         ior = f'<float name="intIOR" value="{fmt([b["eta"][0]])}"/><float name="extIOR" value="1"/>'

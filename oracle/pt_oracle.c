@@ -1000,6 +1000,16 @@ static mfd_t mfd_of_roughconductor(const orc_material *m) {      /* flags bit1 s
     mfd_t d; d.distr = m->distr; d.au = maxf(m->alpha, 1e-4f); d.av = (m->flags & 8u) ? maxf(m->reflectance[0], 1e-4f) : d.au;
     d.visible = (m->flags & 2u) != 0 && m->distr != 2; return d;
 }
+static mfd_t mfd_of_roughdielectric(const orc_material *m) {     /* alphaV in k[0] when flags bit3 is set */
+    mfd_t d; d.distr = m->distr; d.au = maxf(m->alpha, 1e-4f); d.av = (m->flags & 8u) ? maxf(m->k[0], 1e-4f) : d.au;
+    d.visible = (m->flags & 2u) != 0 && m->distr != 2; return d;
+}
+/* roughdielectric.cpp:409-414: Walter et al.'s trick -- sample from a slightly wider distribution unless visible normals are sampled (scaleAlpha, microfacet.h:180-185) */
+static mfd_t mfd_sampling(const mfd_t *d, float cosThetaI) {
+    mfd_t s = *d;
+    if (!d->visible) { float f = 1.2f - 0.2f * sqrtf(fabsf(cosThetaI)); s.au *= f; s.av *= f; }
+    return s;
+}
 static float mfd_pdf(const mfd_t *d, v3 wi, v3 m) {
     if (d->visible) { if (wi.z == 0) return 0.0f; return mf_smith_g1_2(d->distr, d->au, d->av, wi, m) * fabsf(dot(wi, m)) * mf_eval2(d->distr, d->au, d->av, m) / fabsf(wi.z); }
     return mf_eval2(d->distr, d->au, d->av, m) * m.z;
@@ -1130,19 +1140,19 @@ static v3 plastic_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *w
     return scale(plastic_diffuse(m), invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
 }
 
-/* ---- rough dielectric: src/bsdfs/roughdielectric.cpp:274-617 over microfacet.h (isotropic alpha, Beckmann / GGX, sampleVisible = true).
+/* ---- rough dielectric: src/bsdfs/roughdielectric.cpp:274-617 over the whole MicrofacetDistribution (flags bit1 sampleVisible, bit3 anisotropic with alphaV in k[0]).
  * Fields: alpha, distr, eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance.  sample() draws one more
  * number from the path's sampler to choose reflection / refraction (EUsesSampler, roughdielectric.cpp:480-481). */
 static inline float signum_(float v) { return copysignf(1.0f, v); }
 static v3 rd_eval(const orc_material *m, v3 wi, v3 wo) {
     if (wi.z == 0) return V(0, 0, 0);
-    const float etaM = m->eta[0], invEta = 1 / etaM, alpha = maxf(m->alpha, 1e-4f); const int reflect = wi.z * wo.z > 0; v3 H;
+    const float etaM = m->eta[0], invEta = 1 / etaM; const mfd_t d = mfd_of_roughdielectric(m); const int reflect = wi.z * wo.z > 0; v3 H;
     if (reflect) H = normalize(add(wo, wi));
     else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(add(wi, scale(wo, eta))); }
     H = scale(H, signum_(H.z));
-    float D = mf_eval(m->distr, alpha, H); if (D == 0) return V(0, 0, 0);
+    float D = mf_eval2(d.distr, d.au, d.av, H); if (D == 0) return V(0, 0, 0);
     float ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, etaM);
-    float G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H);
+    float G = mf_smith_g1_2(d.distr, d.au, d.av, wi, H) * mf_smith_g1_2(d.distr, d.au, d.av, wo, H);
     if (reflect) { float value = F * D * G / (4.0f * fabsf(wi.z)); return scale(V(m->specular[0], m->specular[1], m->specular[2]), value); }
     float eta = wi.z > 0.0f ? etaM : invEta;
     float sqrtDenom = dot(wi, H) + eta * dot(wo, H);
@@ -1151,20 +1161,19 @@ static v3 rd_eval(const orc_material *m, v3 wi, v3 wo) {
     return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), fabsf(value * factor * factor));
 }
 static float rd_pdf(const orc_material *m, v3 wi, v3 wo) {
-    const float etaM = m->eta[0], invEta = 1 / etaM, alpha = maxf(m->alpha, 1e-4f); const int reflect = wi.z * wo.z > 0; v3 H; float dwh_dwo;
+    const float etaM = m->eta[0], invEta = 1 / etaM; const mfd_t d0 = mfd_of_roughdielectric(m), d = mfd_sampling(&d0, wi.z); const int reflect = wi.z * wo.z > 0; v3 H; float dwh_dwo;
     if (reflect) { H = normalize(add(wo, wi)); dwh_dwo = 1.0f / (4.0f * dot(wo, H)); }
     else { float eta = wi.z > 0 ? etaM : invEta; H = normalize(add(wi, scale(wo, eta))); float sqrtDenom = dot(wi, H) + eta * dot(wo, H); dwh_dwo = (eta * eta * dot(wo, H)) / (sqrtDenom * sqrtDenom); }
     H = scale(H, signum_(H.z));
-    float prob = mf_pdf_visible(m->distr, alpha, scale(wi, signum_(wi.z)), H);
+    float prob = mfd_pdf(&d, scale(wi, signum_(wi.z)), H);
     float ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, etaM);
     prob *= reflect ? F : (1 - F);
     return fabsf(prob * dwh_dwo);
 }
 static v3 rd_sample(const orc_material *mt, v3 wi, float sx, float sy, float extra, v3 *wo, float *pdf, float *etaOut) {
-    const float etaM = mt->eta[0], invEta = 1 / etaM, alpha = maxf(mt->alpha, 1e-4f);
+    const float etaM = mt->eta[0], invEta = 1 / etaM; const mfd_t d = mfd_of_roughdielectric(mt), sd = mfd_sampling(&d, wi.z);
     v3 wiS = scale(wi, signum_(wi.z));
-    v3 m = mf_sample_visible(mt->distr, alpha, wiS, sx, sy);
-    float microfacetPDF = mf_pdf_visible(mt->distr, alpha, wiS, m);
+    float microfacetPDF; v3 m = mfd_sample(&sd, wiS, sx, sy, &microfacetPDF);
     if (microfacetPDF == 0) return V(0, 0, 0);
     *pdf = microfacetPDF;
     float cosThetaT, F = fresnel_dielectric_ext(dot(wi, m), &cosThetaT, etaM);
@@ -1186,7 +1195,8 @@ static v3 rd_sample(const orc_material *mt, v3 wi, float sx, float sy, float ext
         float sqrtDenom = dot(wi, m) + *etaOut * dot(*wo, m);
         dwh_dwo = (*etaOut * *etaOut * dot(*wo, m)) / (sqrtDenom * sqrtDenom);
     }
-    weight = scale(weight, mf_smith_g1(mt->distr, alpha, *wo, m));
+    if (d.visible) weight = scale(weight, mf_smith_g1_2(d.distr, d.au, d.av, *wo, m));          /* roughdielectric.cpp:607-612 */
+    else weight = scale(weight, fabsf(mf_eval2(d.distr, d.au, d.av, m) * (mf_smith_g1_2(d.distr, d.au, d.av, wi, m) * mf_smith_g1_2(d.distr, d.au, d.av, *wo, m)) * dot(wi, m) / (microfacetPDF * wi.z)));
     *pdf *= fabsf(dwh_dwo);
     return weight;
 }

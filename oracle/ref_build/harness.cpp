@@ -226,8 +226,9 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 5) {
             Properties p("roughdielectric");
-            p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx"); p.setFloat("alpha", fb.alpha);
-            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", fb.sampleVisible != 0);
+            p.setString("distribution", fb.distr == 0 ? "beckmann" : fb.distr == 1 ? "ggx" : "phong");
+            if (fb.sampleVisible & 4u) { p.setFloat("alphaU", fb.alpha); p.setFloat("alphaV", fb.k[0]); } else p.setFloat("alpha", fb.alpha);     // anisotropic: alphaV travels in k[0]
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 6) {

@@ -71,6 +71,12 @@ def golden_scenes():
         # the rest of MicrofacetDistribution on the Veach plates: anisotropic Beckmann / GGX, sampleVisible = false, Phong and Ashikhmin-Shirley
         "veach_microfacets": scenes.veach_mis(width=96, height=54, spp=16, microfacets=scenes.VEACH_MICROFACETS),
         "veach_microfacets_2": scenes.veach_mis(width=96, height=54, spp=8, microfacets=scenes.VEACH_MICROFACETS_2, sampler=scenes.SAMPLER_INDEPENDENT, seed=3),
+        # roughdielectric over the rest of MicrofacetDistribution: anisotropic sphere (tangent from its own parameterisation), all-normal sampling with
+        # Walter's widened sampling distribution (roughdielectric.cpp:409-414), Phong
+        "cbox_translucent_mf": scenes.cbox_translucent(width=96, height=96, spp=16, frost_kw=dict(alpha=0.08, alpha_v=0.3, distr=scenes.DISTR_GGX, sample_visible=False),
+                                                      slab_kw=dict(alpha=0.2, distr=scenes.DISTR_BECKMANN, sample_visible=False)),
+        "cbox_translucent_mf2": scenes.cbox_translucent(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=5, frost_kw=dict(alpha=0.25, alpha_v=0.1, distr=scenes.DISTR_BECKMANN, sample_visible=True),
+                                                       slab_kw=dict(alpha=0.3, distr=scenes.DISTR_PHONG)),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
@@ -101,7 +107,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)

@@ -583,11 +583,12 @@ def test_sobol_scramble(mi, oracle, golden_scenes):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-4       # ... and this one is the reference's
 
 
-@pytest.mark.parametrize("name", ["veach_microfacets", "veach_microfacets_2"])
+@pytest.mark.parametrize("name", ["veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2"])
 def test_full_microfacet_distribution(mi, oracle, golden_scenes, name):
     """SURVEY.md §8 a12, the rest of MicrofacetDistribution under roughconductor (src/bsdfs/microfacet.h): anisotropic Beckmann / GGX (alphaU != alphaV, the
     tangent comes from the plates' texture coordinates), sampleVisible = false (sampleAll / pdfAll and the D G (wi.m) / (pdf cos) weight), Phong and
-    Ashikhmin-Shirley.  exp / log / pow / atan / tan come from the device math library -> tolerance-pinned against the oracle, the reference's own samples
+    Ashikhmin-Shirley; and under roughdielectric (cbox_translucent_mf*: anisotropic sphere, Walter's widened sampling distribution for all-normal sampling,
+    Phong slab; roughdielectric.cpp:409-414, 607-612).  exp / log / pow / atan / tan come from the device math library -> tolerance-pinned against the oracle, the reference's own samples
     and film next to it."""
     sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
     gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
@@ -605,6 +606,6 @@ def test_full_microfacet_distribution(mi, oracle, golden_scenes, name):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
     # an anisotropic material on a mesh without texture coordinates is refused like TriMesh::computeUVTangents does
     bad = type(sc)(sc); bad["shapes"] = [dict(s, has_uv=0) for s in sc.shapes]
-    if any(b.get("aniso") for b in sc.bsdfs):
+    if any(sc.bsdfs[s["bsdf"]].get("aniso") for s in sc.shapes):      # (analytic shapes carry their own parameterisation)
         with pytest.raises(mi.MiError, match="texture coordinates are required"):
             mi.Scene(bad)
