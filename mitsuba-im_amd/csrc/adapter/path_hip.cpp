@@ -60,71 +60,41 @@ static void roughPlasticTables(mi_material &m) {
     g_tables->insert(g_tables->end(), ext->trans(), ext->trans() + ext->thetaSamples());
 }
 
-/// `twosided` keeps its nested BSDF private (src/bsdfs/twosided.cpp:197-198) and the nested object's Properties are gone once it is configured
-/// from a parent, so the wrapper is read through the one public door that shows its content: serialisation.  TwoSidedBRDF::serialize
-/// (twosided.cpp:79-84) writes the nested objects through the InstanceManager (src/libcore/serialization.cpp:76-91: id, class name, then the
-/// object's own serialize()); the layouts parsed here are RoughConductor::serialize (roughconductor.cpp:219-229), SmoothConductor::serialize
-/// (conductor.cpp:204-209), SmoothPlastic::serialize (plastic.cpp:169-176), constant textures (src/librender/basictexture.cpp:29-49).
+/// `twosided` keeps its nested BSDF private (src/bsdfs/twosided.cpp:197-198), the nested object's Properties are gone once it is configured from a
+/// parent, and every BSDF keeps its textures private, so wrappers and spatially varying BSDFs are read through the one public door that shows their
+/// content: serialisation.  InstanceManager::serialize (src/libcore/serialization.cpp:76-91) writes id, class name, then the object's own serialize();
+/// the layouts parsed here are TwoSidedBRDF (twosided.cpp:79-84), RoughConductor (roughconductor.cpp:219-229), SmoothConductor (conductor.cpp:204-209),
+/// SmoothPlastic (plastic.cpp:180-187), RoughPlastic (roughplastic.cpp:247-257), SmoothDiffuse (diffuse.cpp:163-167), DiffuseTransmitter
+/// (difftrans.cpp:66-70), constant textures (src/librender/basictexture.cpp:29-49), Texture2D (src/librender/texture.cpp:106-110) with Checkerboard /
+/// GridTexture / BitmapTexture (bitmap.cpp:404-432).
+static std::vector<mi_texture> *g_textures = NULL; static std::vector<uint32_t> *g_texLevels = NULL; static std::vector<float> *g_texTexels = NULL;
 struct NestedReader {
-    ref<MemoryStream> ms; std::map<uint32_t, std::vector<float> > seen;
-    /// a ConstantSpectrumTexture / ConstantFloatTexture reference -> its value(s); back-references resolve through `seen`
+    ref<MemoryStream> ms; std::map<uint32_t, std::vector<float> > seen; std::map<uint32_t, int> seenTexture;
+    int lastTexture = -1;                 ///< index into g_textures when the last texture() call met a spatially varying texture, else -1
+    int spatialTexture(const std::string &tcls);
+    /// a texture reference -> its constant value(s), or (checkerboard / gridtexture / bitmap) a texture record (`lastTexture`); back-references resolve through `seen`
     std::vector<float> texture() {
-        uint32_t id = ms->readUInt(); if (id == 0) SLog(EError, "path_hip: missing texture inside a twosided BSDF");
-        if (seen.count(id)) return seen[id];
+        lastTexture = -1;
+        uint32_t id = ms->readUInt(); if (id == 0) SLog(EError, "path_hip: missing texture inside a BSDF");
+        if (seen.count(id)) { lastTexture = seenTexture[id]; return seen[id]; }
         std::string cls = ms->readString(); std::vector<float> v;
         if (cls == "ConstantSpectrumTexture") { Spectrum sp(ms.get()); Float r, g, b; sp.toLinearRGB(r, g, b); v = {(float) r, (float) g, (float) b}; }
         else if (cls == "ConstantFloatTexture") v = {(float) ms->readFloat()};
-        else SLog(EError, "path_hip: texture \"%s\" inside a twosided BSDF is not implemented (constant values only)", cls.c_str());
-        seen[id] = v; return v;
+        else if (cls == "Checkerboard" || cls == "GridTexture" || cls == "BitmapTexture") { lastTexture = spatialTexture(cls); v = {0.5f, 0.5f, 0.5f}; }
+        else SLog(EError, "path_hip: texture \"%s\" is not implemented (constant values, checkerboard, gridtexture, bitmap)", cls.c_str());
+        seen[id] = v; seenTexture[id] = lastTexture; return v;
+    }
+    /// a parameter the path only takes as a constant
+    std::vector<float> constant(const char *what) {
+        std::vector<float> v = texture();
+        if (lastTexture >= 0) SLog(EError, "path_hip: a texture on \"%s\" is not implemented (textures drive diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance)", what);
+        return v;
     }
     void rgb(float *dst) { Spectrum sp(ms.get()); Float r, g, b; sp.toLinearRGB(r, g, b); dst[0] = r; dst[1] = g; dst[2] = b; }
 };
-static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
-    NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
-    mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
-    rd.ms->readUInt(); if (rd.ms->readString() != "TwoSidedBRDF") return false;
-    rd.ms->readBool();                                                  // BSDF::serialize: m_ensureEnergyConservation (bsdf.cpp:43-46)
-    uint32_t id0 = rd.ms->readUInt(); std::string cls = rd.ms->readString(); rd.ms->readBool();
-    memset(&m, 0, sizeof(m)); m.flags = MI_BSDF_FLAG_TWOSIDED;
-    if (cls == "RoughConductor") {
-        uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
-        std::vector<float> au = rd.texture(), av = rd.texture(), spec = rd.texture();
-        // MicrofacetDistribution::EType: EBeckmann 0, EGGX 1, EPhong 2 (microfacet.h:46-52); sampleVisible as stored (Phong clears it in the constructor, :141-145)
-        if (distr > 2) SLog(EError, "path_hip: unknown microfacet distribution");
-        m.type = MI_BSDF_ROUGHCONDUCTOR; m.distr = distr; m.alpha = au[0]; if (sampleVisible) m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE;
-        if (au[0] != av[0]) { m.flags |= MI_BSDF_FLAG_ANISOTROPIC; m.reflectance[0] = av[0]; }
-        memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
-    } else if (cls == "SmoothConductor") {
-        std::vector<float> spec = rd.texture(); m.type = MI_BSDF_CONDUCTOR; memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
-    } else if (cls == "RoughPlastic") {                                 // roughplastic.cpp:247-257
-        uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
-        std::vector<float> spec = rd.texture(), diff = rd.texture(), alpha = rd.texture();
-        if (distr > 1 || !sampleVisible) SLog(EError, "path_hip: roughplastic is implemented for beckmann / ggx with sampleVisible = true");
-        m.type = MI_BSDF_ROUGHPLASTIC; m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = alpha[0];
-        memcpy(m.specular, spec.data(), 12); memcpy(m.reflectance, diff.data(), 12);
-        m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
-        roughPlasticTables(m);
-    } else if (cls == "SmoothPlastic") {
-        m.type = MI_BSDF_PLASTIC; m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
-        std::vector<float> spec = rd.texture(), diff = rd.texture(); memcpy(m.specular, spec.data(), 12); memcpy(m.reflectance, diff.data(), 12);
-        m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
-    } else return false;                                                // twosided(diffuse) and anything else: the generic component check below
-    if (rd.ms->readUInt() != id0) SLog(EError, "path_hip: twosided with two different nested BSDFs is not implemented");
-    return true;
-}
-
-/// A spatially varying `diffuse` (optionally inside `twosided`): its reflectance texture is private as well, so it is read from the serialised form
-/// (SmoothDiffuse::serialize, diffuse.cpp:163-167; Texture2D::serialize, src/librender/texture.cpp:106-110; Checkerboard / GridTexture::serialize)
-static std::vector<mi_texture> *g_textures = NULL; static std::vector<uint32_t> *g_texLevels = NULL; static std::vector<float> *g_texTexels = NULL;
-static bool convertTexturedDiffuse(const BSDF *bsdf, mi_material &m) {
-    NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
-    mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
-    rd.ms->readUInt(); std::string cls = rd.ms->readString(); rd.ms->readBool();
-    memset(&m, 0, sizeof(m)); m.type = MI_BSDF_DIFFUSE;
-    if (cls == "TwoSidedBRDF") { m.flags |= MI_BSDF_FLAG_TWOSIDED; rd.ms->readUInt(); cls = rd.ms->readString(); rd.ms->readBool(); }
-    if (cls != "SmoothDiffuse") return false;
-    rd.ms->readUInt(); std::string tcls = rd.ms->readString();
-    if (tcls != "Checkerboard" && tcls != "GridTexture" && tcls != "BitmapTexture") SLog(EError, "path_hip: texture \"%s\" is not implemented (checkerboard, gridtexture, bitmap)", tcls.c_str());
+/// Texture2D::serialize + the texture's own fields -> a mi_texture record (bitmaps: the MIP pyramid rebuilt with the reference's own TMIPMap, average in color0)
+int NestedReader::spatialTexture(const std::string &tcls) {
+    NestedReader &rd = *this;
     mi_texture t; memset(&t, 0, sizeof(t)); t.type = tcls == "GridTexture" ? MI_TEXTURE_GRID : tcls == "BitmapTexture" ? MI_TEXTURE_BITMAP : MI_TEXTURE_CHECKERBOARD;
     t.uoffset = rd.ms->readFloat(); t.voffset = rd.ms->readFloat(); t.uscale = rd.ms->readFloat(); t.vscale = rd.ms->readFloat();
     if (t.type == MI_TEXTURE_BITMAP) {
@@ -147,19 +117,78 @@ static bool convertTexturedDiffuse(const BSDF *bsdf, mi_material &m) {
             for (size_t i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) g_texTexels->push_back((float) hp[i * ch + (ch == 3 ? c : 0)]);
         };
         if (lum) { ref<TMIPMap<Color1, Color1h> > mip = new TMIPMap<Color1, Color1h>(bitmap, Bitmap::ELuminance, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) t.wrap_u, (ReconstructionFilter::EBoundaryCondition) t.wrap_v, (EMIPFilterType) t.filter, t.max_anisotropy);
-                   t.n_levels = (uint32_t) mip->getLevels(); for (int l = 0; l < mip->getLevels(); ++l) pushLevel(mip->toBitmap(l), 1); }
+                   t.n_levels = (uint32_t) mip->getLevels(); for (int l = 0; l < mip->getLevels(); ++l) pushLevel(mip->toBitmap(l), 1);
+                   t.color0[0] = t.color0[1] = t.color0[2] = mip->getAverage()[0]; }                    // BitmapTexture::getAverage (bitmap.cpp:504-514)
         else { ref<TMIPMap<Color3, Color3h> > mip = new TMIPMap<Color3, Color3h>(bitmap, Bitmap::ERGB, Bitmap::EFloat, rf, (ReconstructionFilter::EBoundaryCondition) t.wrap_u, (ReconstructionFilter::EBoundaryCondition) t.wrap_v, (EMIPFilterType) t.filter, t.max_anisotropy);
-               t.n_levels = (uint32_t) mip->getLevels(); for (int l = 0; l < mip->getLevels(); ++l) pushLevel(mip->toBitmap(l), 3); }
+               t.n_levels = (uint32_t) mip->getLevels(); for (int l = 0; l < mip->getLevels(); ++l) pushLevel(mip->toBitmap(l), 3);
+               Color3 avg = mip->getAverage(); for (int c = 0; c < 3; ++c) t.color0[c] = avg[c]; }
     } else { rd.rgb(t.color0); rd.rgb(t.color1); if (t.type == MI_TEXTURE_GRID) t.line_width = rd.ms->readFloat(); }
-    m.flags |= MI_BSDF_TEXTURE(g_textures->size()); m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;
     g_textures->push_back(t);
+    return (int) g_textures->size() - 1;
+}
+/// one nested / serialised BSDF of class `cls` (its BSDF::serialize bool already consumed) -> material; false: leave it to the generic path
+static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_material &m) {
+    auto bind = [&](const std::vector<float> &v) { if (rd.lastTexture >= 0) m.flags |= MI_BSDF_TEXTURE(rd.lastTexture); memcpy(m.reflectance, v.data(), 12); };
+    if (cls == "RoughConductor") {
+        uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
+        std::vector<float> au = rd.constant("alphaU"), av = rd.constant("alphaV"), spec = rd.constant("specularReflectance");
+        // MicrofacetDistribution::EType: EBeckmann 0, EGGX 1, EPhong 2 (microfacet.h:46-52); sampleVisible as stored (Phong clears it in the constructor, :141-145)
+        if (distr > 2) SLog(EError, "path_hip: unknown microfacet distribution");
+        m.type = MI_BSDF_ROUGHCONDUCTOR; m.distr = distr; m.alpha = au[0]; if (sampleVisible) m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE;
+        if (au[0] != av[0]) { m.flags |= MI_BSDF_FLAG_ANISOTROPIC; m.reflectance[0] = av[0]; }
+        memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
+    } else if (cls == "SmoothConductor") {
+        std::vector<float> spec = rd.constant("specularReflectance"); m.type = MI_BSDF_CONDUCTOR; memcpy(m.specular, spec.data(), 12); rd.rgb(m.eta); rd.rgb(m.k);
+    } else if (cls == "RoughPlastic") {                                 // roughplastic.cpp:247-257
+        uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
+        std::vector<float> spec = rd.constant("specularReflectance"), diff = rd.texture(); bind(diff);
+        std::vector<float> alpha = rd.constant("alpha");
+        if (distr > 1 || !sampleVisible) SLog(EError, "path_hip: roughplastic is implemented for beckmann / ggx with sampleVisible = true");
+        m.type = MI_BSDF_ROUGHPLASTIC; m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = alpha[0];
+        memcpy(m.specular, spec.data(), 12);
+        m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
+        roughPlasticTables(m);
+    } else if (cls == "SmoothPlastic") {
+        m.type = MI_BSDF_PLASTIC; m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
+        std::vector<float> spec = rd.constant("specularReflectance"), diff = rd.texture(); bind(diff); memcpy(m.specular, spec.data(), 12);
+        m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
+    } else if (cls == "SmoothDiffuse") {
+        std::vector<float> refl = rd.texture(); if (rd.lastTexture < 0) return false;      // constant reflectance: the generic path reads it through the public interface
+        m.type = MI_BSDF_DIFFUSE; bind(refl);
+    } else if (cls == "DiffuseTransmitter") {
+        std::vector<float> tr = rd.texture(); m.type = MI_BSDF_DIFFTRANS; bind(tr);
+    } else return false;
     return true;
+}
+static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
+    NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
+    mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
+    rd.ms->readUInt(); if (rd.ms->readString() != "TwoSidedBRDF") return false;
+    rd.ms->readBool();                                                  // BSDF::serialize: m_ensureEnergyConservation (bsdf.cpp:43-46)
+    uint32_t id0 = rd.ms->readUInt(); std::string cls = rd.ms->readString(); rd.ms->readBool();
+    memset(&m, 0, sizeof(m)); m.flags = MI_BSDF_FLAG_TWOSIDED;
+    const size_t nTex = g_textures->size(), nLev = g_texLevels->size(), nTxl = g_texTexels->size();
+    if (!readSerializedBSDF(rd, cls, m)) { g_textures->resize(nTex); g_texLevels->resize(nLev); g_texTexels->resize(nTxl); return false; }   // twosided(diffuse) and anything else: the generic component check
+    if (rd.ms->readUInt() != id0) SLog(EError, "path_hip: twosided with two different nested BSDFs is not implemented");
+    return true;
+}
+/// A spatially varying BSDF outside `twosided`: read from its serialised form like the nested ones
+static bool convertSpatiallyVarying(const BSDF *bsdf, mi_material &m) {
+    NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
+    mgr->serialize(rd.ms, bsdf); rd.ms->seek(0);
+    rd.ms->readUInt(); std::string cls = rd.ms->readString(); rd.ms->readBool();
+    memset(&m, 0, sizeof(m));
+    return readSerializedBSDF(rd, cls, m);
 }
 
 /// BSDF -> mi_material.  Only what the hot path implements; anything else is reported, never silently approximated.
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
     if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
+    if ((bsdf->getType() & BSDF::ESpatiallyVarying) && bsdf->getClass()->getName() != "TwoSidedBRDF") {      // textures are private members: never fall through to the Properties (constants only)
+        if (convertSpatiallyVarying(bsdf, m)) return m;
+        SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on diffuse.reflectance, plastic / roughplastic.diffuseReflectance and difftrans.transmittance", bsdf->getClass()->getName().c_str());
+    }
     if (bsdf->getClass()->getName() == "RoughConductor") {
         // same derivation as RoughConductor's constructor (src/bsdfs/roughconductor.cpp:170-207): eta / k from the properties or from
         // data/ior/<material>.{eta,k}.spd, divided by the exterior IOR; isotropic alpha; Beckmann / GGX with visible-normal sampling
@@ -249,10 +278,8 @@ static mi_material convertBSDF(const BSDF *bsdf) {
             return m;
         }
     }
-    if (bsdf->getType() & BSDF::ESpatiallyVarying) {
-        if (convertTexturedDiffuse(bsdf, m)) return m;
-        SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on the reflectance of `diffuse` only", bsdf->getClass()->getName().c_str());
-    }
+    if (bsdf->getType() & BSDF::ESpatiallyVarying)
+        SLog(EError, "path_hip: spatially varying BSDF \"%s\" inside twosided: textures are implemented on diffuse.reflectance and plastic / roughplastic.diffuseReflectance", bsdf->getClass()->getName().c_str());
     bool backSide = false;
     for (int i = 0; i < bsdf->getComponentCount(); ++i) {
         unsigned int type = bsdf->getType(i);

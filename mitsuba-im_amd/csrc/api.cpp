@@ -228,6 +228,20 @@ int SceneHost::upload(int dev) {
     if (hipSetDevice(dev) != hipSuccess) return 1;
     std::vector<MaterialD> mats(materials.size());
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
+    for (MaterialD &m : mats) {          // plastic / roughplastic: m_specularSamplingWeight = sAvg / (dAvg + sAvg) over Texture::getAverage() (plastic.cpp:204-207, roughplastic.cpp:244-246) -> eta[1]
+        if (m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC) continue;
+        float d[3] = {m.reflectance[0], m.reflectance[1], m.reflectance[2]}; const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
+        if (tex && tex <= textures.size()) {     // checkerboard.cpp:102-104, gridtexture.cpp:116-121; a bitmap's average is input (color0, from TMIPMap::getAverage)
+            const mi_texture &t = textures[tex - 1];
+            for (int c = 0; c < 3; ++c) {
+                if (t.type == MI_TEXTURE_CHECKERBOARD) d[c] = (t.color0[c] + t.color1[c]) * 0.5f;
+                else if (t.type == MI_TEXTURE_GRID) { const float iw = std::max(0.0f, 1 - 2 * t.line_width), ia = iw * iw, la = 1 - ia; d[c] = t.color1[c] * la + t.color0[c] * ia; }
+                else d[c] = t.color0[c];
+            }
+        }
+        const float dl = d[0] * 0.212671f + d[1] * 0.715160f + d[2] * 0.072169f, sl = m.specular[0] * 0.212671f + m.specular[1] * 0.715160f + m.specular[2] * 0.072169f;
+        m.eta[1] = sl / (dl + sl);
+    }
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
     int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
               up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dMaterialTables, materialTables) | up(&dTriUV, triuv) | up(&dTextures, textures) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
@@ -307,7 +321,8 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
         if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
             (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
-        if (tex && (tex > s->h.textures.size() || m.type != MI_BSDF_DIFFUSE)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to the reflectance of `diffuse` BSDFs only (and must exist)");
+        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS)))
+            return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance or difftrans.transmittance (and must exist)");
     }
     if (s->h.envTexture >= 0) {       // MIP pyramid of the environment map (camera-ray lookups, envmap.cpp:398-411)
         if (!s->h.envW) return fail(MI_ERR_INVALID, "mi_scene_commit: mi_scene_set_envmap_filter without an environment map");

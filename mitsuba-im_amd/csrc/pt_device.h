@@ -920,8 +920,8 @@ DEV v3 dielectricSample(const MaterialD &m, v3 wi, float sx, v3 &wo, float &pdf,
     return ld3(m.reflectance) * (factor * factor);
 }
 DEV float luminance3(v3 c) { return c.x * 0.212671f + c.y * 0.715160f + c.z * 0.072169f; }
-DEV float plasticProbSpecular(const MaterialD &m, float Fi) {       // plastic.cpp:204-207 + :301-304
-    float dAvg = luminance3(ld3(m.reflectance)), sAvg = luminance3(ld3(m.specular)), w = sAvg / (dAvg + sAvg);
+DEV float plasticProbSpecular(const MaterialD &m, float Fi) {       // plastic.cpp:301-304; w = m_specularSamplingWeight (:204-207), derived on the host into eta[1] from the textures' averages
+    const float w = m.eta[1];
     return (Fi * w) / (Fi * w + (1 - Fi) * (1 - w));
 }
 DEV v3 plasticDiffuse(const MaterialD &m) {
@@ -1051,7 +1051,7 @@ DEV float rpTransmittance(const DScene &sc, const MaterialD &m, float cosTheta) 
 }
 DEV float rpProbSpecular(const DScene &sc, const MaterialD &m, float cosThetaI) {
     float probSpecular = 1 - rpTransmittance(sc, m, cosThetaI);
-    float dAvg = luminance3(ld3(m.reflectance)), sAvg = luminance3(ld3(m.specular)), w = sAvg / (dAvg + sAvg);
+    const float w = m.eta[1];                                        // m_specularSamplingWeight (roughplastic.cpp:244-246), host-derived like the plastic's
     return (probSpecular * w) / (probSpecular * w + (1 - probSpecular) * (1 - w));
 }
 DEV v3 rpEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {

@@ -251,6 +251,17 @@ def load_texture_pyramid(name="texture_pyramid_48x40.npz"):
 
 def make_texture(kind, color0=(0, 0, 0), color1=(0, 0, 0), line_width=0.01, uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0,
                  pyramid=None, wrap_u=WRAP_REPEAT, wrap_v=WRAP_REPEAT, filter_type=MIP_EWA, max_anisotropy=20.0):
+    if kind == TEXTURE_BITMAP and pyramid is not None:
+        # a bitmap's average (TMIPMap::getAverage: the float sum of the base image in row-major order / pixel count, barray.h:309-332) travels in color0:
+        # plastic / roughplastic derive their lobe-selection weight from it (plastic.cpp:204-207)
+        base = pyramid.get("base")
+        if base is None:
+            w0, h0, t0 = pyramid["levels"][0]; base = np.asarray(t0, f32).reshape(h0, w0, 3)
+        elif (wrap_u, wrap_v) != (WRAP_REPEAT, WRAP_REPEAT) and not pyramid.get("wrapped"):
+            # the reference resamples with the texture's own boundary conditions (bitmap.cpp:363-401): rebuild the levels for this wrap mode
+            pyramid = dict(base=base, levels=build_mip_pyramid(base, wrap_u, wrap_v, 1.0), wrapped=True)
+        flat = np.maximum(np.asarray(base, f32), f32(0)).reshape(-1, 3)
+        color0 = tuple(float(np.cumsum(flat[:, c], dtype=f32)[-1] / f32(len(flat))) for c in range(3))
     return dict(type=int(kind), color0=tuple(map(float, color0)), color1=tuple(map(float, color1)), line_width=float(line_width),
                 uoffset=float(uoffset), voffset=float(voffset), uscale=float(uscale), vscale=float(vscale), pyramid=pyramid,
                 wrap_u=int(wrap_u), wrap_v=int(wrap_v), filter=int(filter_type), max_anisotropy=float(max_anisotropy if filter_type == MIP_EWA else 1.0),
@@ -580,6 +591,32 @@ def bitmap_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6,
     out = finish_scene(sc.pos, sc.idx, sc.shapes, sc.bsdfs, sc.emitters, sc.cam_to_world, sc.xfov, sc.near, sc.far, width, height, spp, sampler, max_depth, rr_depth,
                        seed=seed, normals=sc.nrm, uvs=sc.uv, name="bitmap_room", textures=tex)
     return out
+
+
+def textured_plastics(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, rough=True):
+    """The textured room with textures on the OTHER diffuse-like parameters: `plastic` floor (checkerboard diffuseReflectance, nonlinear), `roughplastic` wall
+    (bitmap diffuseReflectance, trilinear), `difftrans` mound (grid transmittance), `roughplastic` panel (grid texture).  plastic / roughplastic pick their lobe
+    with a weight derived from the texture's AVERAGE (plastic.cpp:204-207), evaluate with its local value."""
+    sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed)
+    pyr = load_texture_pyramid()
+    tex = [make_texture(TEXTURE_CHECKERBOARD, (0.8, 0.75, 0.6), (0.15, 0.2, 0.3), uscale=6.0, vscale=4.0, uoffset=0.13, voffset=-0.2),
+           make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=1.7, vscale=1.3, wrap_u=WRAP_MIRROR, wrap_v=WRAP_CLAMP, filter_type=MIP_TRILINEAR),
+           make_texture(TEXTURE_GRID, (0.2, 0.6, 0.25), (0.9, 0.9, 0.2), line_width=0.08, uscale=3.0, vscale=3.0),
+           make_texture(TEXTURE_GRID, (0.7, 0.3, 0.25), (0.05, 0.05, 0.05), line_width=0.06, uscale=2.0, vscale=2.0)]
+    bs = [make_bsdf(kind=BSDF_PLASTIC, ior=1.49, specular=(0.9, 0.9, 0.9), nonlinear=True),
+          make_bsdf(kind=BSDF_ROUGHPLASTIC, alpha=0.1, distr=DISTR_GGX, ior=1.5046, specular=(0.9, 0.9, 0.9), twosided=True),
+          make_bsdf(kind=BSDF_DIFFTRANS),
+          make_bsdf(kind=BSDF_ROUGHPLASTIC, alpha=0.3, distr=DISTR_BECKMANN, ior=1.49, nonlinear=True)]
+    if not rough:      # smooth plastics and procedural textures only: the reference's roughplastic needs its data/microfacet tables at run time, and its
+        # BitmapTexture can only be serialised (= read by the adapter) in a build with OpenEXR
+        tex[1] = make_texture(TEXTURE_CHECKERBOARD, (0.3, 0.5, 0.8), (0.85, 0.8, 0.7), uscale=5.0, vscale=3.0, uoffset=0.2)
+        bs[1] = make_bsdf(kind=BSDF_PLASTIC, ior=1.5046, specular=(0.9, 0.9, 0.9), twosided=True); bs[3] = make_bsdf(kind=BSDF_PLASTIC, ior=1.9)
+    for i, b in enumerate(bs):
+        b["texture"] = i; sc.bsdfs[i] = b
+    sc.shapes[3]["has_uv"] = 1
+    sc.uv[sc.shapes[3]["first_vert"]:sc.shapes[3]["first_vert"] + 4] = np.array([(-0.3, -0.2), (-0.3, 1.4), (1.6, 1.4), (1.6, -0.2)], f32)
+    return finish_scene(sc.pos, sc.idx, sc.shapes, sc.bsdfs, sc.emitters, sc.cam_to_world, sc.xfov, sc.near, sc.far, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, normals=sc.nrm, uvs=sc.uv, name="textured_plastics", textures=tex)
 
 
 def shape_lights(width=192, height=128, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):

@@ -13,7 +13,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
     bsdf        diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, twosided
-    texture     checkerboard, gridtexture, bitmap (diffuse reflectance; images .npy / .pfm / .hdr or a precomputed pyramid .npz)
+    texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .npy / .pfm / .hdr or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
 
@@ -456,18 +456,19 @@ class _SceneBuilder:
             wm = t.get("wrapMode", "repeat"); wu, wv = t.get("wrapModeU", wm), t.get("wrapModeV", wm); ft = str(t.get("filterType", "ewa")).lower()
             if wu not in wrap or wv not in wrap or ft not in filt:
                 raise SceneError("bitmap: unknown wrapMode / filterType")
+            base = None
             if path.endswith(".npz"):                    # a precomputed pyramid (base / sizes / texels, see scenes.load_texture_pyramid)
-                d = np.load(path); levels = []; off = 0
+                d = np.load(path); levels = []; off = 0; base = d["base"] if "base" in d.files else None
                 for w, h in d["sizes"]:
                     n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
             else:                                        # an image: the pyramid as TMIPMap builds it (bitmap.cpp:363-401: 2-lobed Lanczos, values clamped to [0, 1])
-                levels = S.build_mip_pyramid(load_image(path), wrap[wu], wrap[wv], 1.0)
+                base = load_image(path); levels = S.build_mip_pyramid(base, wrap[wu], wrap[wv], 1.0)
             if t.get("channel", "") != "":
                 raise SceneError("bitmap: 'channel' selection is not supported")
             t.get("gamma", 0.0); t.get("cache", True)
             uvs = t.get("uvscale", 1.0)
             rec = S.make_texture(S.TEXTURE_BITMAP, uoffset=t.get("uoffset", 0.0), voffset=t.get("voffset", 0.0), uscale=t.get("uscale", uvs), vscale=t.get("vscale", uvs),
-                                 pyramid=dict(levels=levels), wrap_u=wrap[wu], wrap_v=wrap[wv], filter_type=filt[ft], max_anisotropy=t.get("maxAnisotropy", 20.0))
+                                 pyramid=dict(levels=levels, **({} if base is None else {"base": base})), wrap_u=wrap[wu], wrap_v=wrap[wv], filter_type=filt[ft], max_anisotropy=t.get("maxAnisotropy", 20.0))
         else:
             raise SceneError(f"texture plugin \"{t.type}\" is not supported")
         t.check_all_used()
@@ -493,9 +494,7 @@ class _SceneBuilder:
             rec = S.make_bsdf(S.BSDF_DIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), twosided=twosided)
         elif t == "difftrans":
             tr, tex = _spectrum_or_texture(p, ("transmittance", "diffuseTransmittance"), (0.5, 0.5, 0.5))
-            if tex is not None:
-                raise SceneError("difftrans: textured transmittance is not supported");
-            rec = S.make_bsdf(S.BSDF_DIFFTRANS, reflectance=tr)
+            rec = S.make_bsdf(S.BSDF_DIFFTRANS, reflectance=tr or (0.5, 0.5, 0.5))
         elif t in ("conductor", "roughconductor"):
             ext = _ior(p, "extEta", "air")
             mat = p.get("material", "Cu")
@@ -526,9 +525,10 @@ class _SceneBuilder:
             ior = float(f32(_ior(p, "intIOR", "polypropylene" if plastic else "bk7")) / f32(_ior(p, "extIOR", "air")))
             spec, stex = _spectrum_or_texture(p, ("specularReflectance",), (1.0, 1.0, 1.0))
             second, ttex = _spectrum_or_texture(p, ("diffuseReflectance",) if plastic else ("specularTransmittance",), (0.5,) * 3 if plastic else (1.0,) * 3)
-            if stex is not None or ttex is not None:
-                raise SceneError(f"{t}: textured parameters are not supported")
-            kw = dict(ior=ior, specular=spec, reflectance=second)
+            if stex is not None or (ttex is not None and not plastic):
+                raise SceneError(f"{t}: textures are supported on diffuseReflectance (plastic, roughplastic) only")
+            tex = ttex
+            kw = dict(ior=ior, specular=spec, reflectance=second or (0.5, 0.5, 0.5))
             if plastic:
                 kw["nonlinear"] = bool(p.get("nonlinear", False)); kw["twosided"] = twosided
             elif twosided:
@@ -883,9 +883,9 @@ def load_scene(path, params=None, sampler=None):
 def export_scene(sc, directory, name=None, mesh_format="serialized"):
     """Write `sc` (scenes.Scene) as <directory>/<name>.xml plus its meshes (one `.serialized` file with an offset dictionary, or one OBJ per
     shape), in the reference's scene format: the BASELINE workloads can be handed to a full build of the reference this way, and
-    `load_scene` reads the result back.  Instances, bitmap textures and environment maps are not written."""
-    if sc.get("instances") or sc.get("envmap") is not None or any(t["type"] == S.TEXTURE_BITMAP for t in sc.get("textures") or []):
-        raise SceneError("export_scene: instances, environment maps and bitmap textures are not written")
+    `load_scene` reads the result back (bitmap textures: the base image as `.npy`, the pyramid is rebuilt on load).  Instances and environment maps are not written."""
+    if sc.get("instances") or sc.get("envmap") is not None:
+        raise SceneError("export_scene: instances and environment maps are not written")
     name = name or sc.name
     os.makedirs(directory, exist_ok=True)
     fmt = lambda v: " ".join("%.9g" % float(x) for x in np.asarray(v, np.float64).reshape(-1))
@@ -907,7 +907,21 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
                f'<rfilter type="{filt}">{fprops}</rfilter></film>\n\t</sensor>')
     distr = {S.DISTR_BECKMANN: "beckmann", S.DISTR_GGX: "ggx", S.DISTR_PHONG: "phong"}
 
+    wrap_names = {S.WRAP_REPEAT: "repeat", S.WRAP_CLAMP: "clamp", S.WRAP_MIRROR: "mirror", S.WRAP_ZERO: "zero", S.WRAP_ONE: "one"}
+    filter_names = {S.MIP_EWA: "ewa", S.MIP_TRILINEAR: "trilinear", S.MIP_BILINEAR: "bilinear", S.MIP_NEAREST: "nearest"}
+
     def texture_xml(t, pname):
+        if t["type"] == S.TEXTURE_BITMAP:
+            ti = [id(x) for x in sc.textures].index(id(t)); fn = f"{name}_tex{ti}.npy"
+            base = t["pyramid"].get("base")
+            if base is None:
+                w0, h0, t0 = t["pyramid"]["levels"][0]; base = np.asarray(t0, f32).reshape(h0, w0, 3)
+            np.save(os.path.join(directory, fn), np.asarray(base, f32))
+            return (f'<texture type="bitmap" name="{pname}"><string name="filename" value="{fn}"/><string name="wrapModeU" value="{wrap_names[t["wrap_u"]]}"/>'
+                    f'<string name="wrapModeV" value="{wrap_names[t["wrap_v"]]}"/><string name="filterType" value="{filter_names[t["filter"]]}"/>'
+                    + (f'<float name="maxAnisotropy" value="{fmt([t["max_anisotropy"]])}"/>' if t["filter"] == S.MIP_EWA else "") +
+                    f'<float name="uoffset" value="{fmt([t["uoffset"]])}"/><float name="voffset" value="{fmt([t["voffset"]])}"/>'
+                    f'<float name="uscale" value="{fmt([t["uscale"]])}"/><float name="vscale" value="{fmt([t["vscale"]])}"/></texture>')
         kind = "checkerboard" if t["type"] == S.TEXTURE_CHECKERBOARD else "gridtexture"
         lw = f'<float name="lineWidth" value="{fmt([t["line_width"]])}"/>' if kind == "gridtexture" else ""
         return (f'<texture type="{kind}" name="{pname}">{rgb("color0", t["color0"])}{rgb("color1", t["color1"])}{lw}<float name="uoffset" value="{fmt([t["uoffset"]])}"/>'
@@ -920,8 +934,9 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
         ior = f'<float name="intIOR" value="{fmt([b["eta"][0]])}"/><float name="extIOR" value="1"/>'
         cond = f'{rgb("eta", b["eta"])}{rgb("k", b["k"])}<float name="extEta" value="1"/>{rgb("specularReflectance", b["specular"])}'
         nl = f'<boolean name="nonlinear" value="{str(bool(b.get("nonlinear", 0))).lower()}"/>'
+        diffuse_param = lambda pname: texture_xml(sc.textures[b["texture"]], pname) if b.get("texture", -1) >= 0 else rgb(pname, b["reflectance"])
         if t == S.BSDF_DIFFUSE:
-            inner = f'<bsdf type="diffuse">{texture_xml(sc.textures[b["texture"]], "reflectance") if b.get("texture", -1) >= 0 else rgb("reflectance", b["reflectance"])}</bsdf>'
+            inner = f'<bsdf type="diffuse">{diffuse_param("reflectance")}</bsdf>'
         elif t == S.BSDF_ROUGHCONDUCTOR:
             inner = f'<bsdf type="roughconductor">{mf}{sv}{cond}</bsdf>'
         elif t == S.BSDF_CONDUCTOR:
@@ -931,11 +946,11 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
         elif t == S.BSDF_ROUGHDIELECTRIC:
             inner = f'<bsdf type="roughdielectric">{mf}{sv}{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
         elif t == S.BSDF_PLASTIC:
-            inner = f'<bsdf type="plastic">{ior}{nl}{rgb("specularReflectance", b["specular"])}{rgb("diffuseReflectance", b["reflectance"])}</bsdf>'
+            inner = f'<bsdf type="plastic">{ior}{nl}{rgb("specularReflectance", b["specular"])}{diffuse_param("diffuseReflectance")}</bsdf>'
         elif t == S.BSDF_ROUGHPLASTIC:
-            inner = f'<bsdf type="roughplastic">{mf}{sv}{ior}{nl}{rgb("specularReflectance", b["specular"])}{rgb("diffuseReflectance", b["reflectance"])}</bsdf>'
+            inner = f'<bsdf type="roughplastic">{mf}{sv}{ior}{nl}{rgb("specularReflectance", b["specular"])}{diffuse_param("diffuseReflectance")}</bsdf>'
         elif t == S.BSDF_DIFFTRANS:
-            inner = f'<bsdf type="difftrans">{rgb("transmittance", b["reflectance"])}</bsdf>'
+            inner = f'<bsdf type="difftrans">{diffuse_param("transmittance")}</bsdf>'
         else:
             raise SceneError(f"export_scene: material type {t}")
         if b["twosided"]:

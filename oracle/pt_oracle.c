@@ -1103,10 +1103,9 @@ static v3 dielectric_sample(const orc_material *m, v3 wi, float sx, v3 *wo, floa
     float factor = cosThetaT < 0 ? invEta : eta;
     return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), factor * factor);
 }
-static float plastic_spec_weight(const orc_material *m) {      /* plastic.cpp:204-207, Spectrum::getLuminance of the constant textures */
-    float dAvg = luminance(V(m->reflectance[0], m->reflectance[1], m->reflectance[2])), sAvg = luminance(V(m->specular[0], m->specular[1], m->specular[2]));
-    return sAvg / (dAvg + sAvg);
-}
+/* plastic.cpp:204-207 / roughplastic.cpp:244-246 m_specularSamplingWeight = sAvg / (dAvg + sAvg) from the textures' getAverage(): derived once at scene creation
+ * (orc_scene_create) into the otherwise unused eta[1] of the material copy, because a textured diffuse reflectance contributes its AVERAGE here, not its local value */
+static float plastic_spec_weight(const orc_material *m) { return m->eta[1]; }
 static v3 plastic_diffuse(const orc_material *m) {              /* diff /= 1 - fdrInt  (or the nonlinear form) */
     v3 diff = V(m->reflectance[0], m->reflectance[1], m->reflectance[2]); const float fdrInt = m->k[0];
     if (m->flags & BSDF_FLAG_NONLINEAR) return V(diff.x / (1.0f - diff.x * fdrInt), diff.y / (1.0f - diff.y * fdrInt), diff.z / (1.0f - diff.z * fdrInt));
@@ -1954,6 +1953,18 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
     s->uv = (float *) dup(d->uv, (size_t) d->n_verts * 8);
     s->textures = (orc_texture *) dup(d->textures, (size_t) (d->textures ? d->n_textures : 0) * sizeof(orc_texture)); s->d.textures = NULL;
+    for (uint32_t i = 0; i < d->n_materials; ++i) {       /* Texture::getAverage(): checkerboard.cpp:102-104, gridtexture.cpp:116-121, bitmap.cpp:504-514 (the bitmap's average is input: color0) */
+        orc_material *m = &s->materials[i].m; if (m->type != BSDF_PLASTIC && m->type != BSDF_ROUGHPLASTIC) continue;
+        v3 dAvg = V(m->reflectance[0], m->reflectance[1], m->reflectance[2]); const uint32_t tex = (m->flags >> 8) & 0xFFFFu;
+        if (tex && tex <= d->n_textures) {
+            const orc_texture *t = &s->textures[tex - 1]; v3 c0 = V(t->color0[0], t->color0[1], t->color0[2]), c1 = V(t->color1[0], t->color1[1], t->color1[2]);
+            if (t->type == 0) dAvg = scale(add(c0, c1), 0.5f);
+            else if (t->type == 1) { float iw = maxf(0.0f, 1 - 2 * t->line_width), ia = iw * iw, la = 1 - ia; dAvg = add(scale(c1, la), scale(c0, ia)); }
+            else dAvg = c0;
+        }
+        float dl = luminance(dAvg), sl = luminance(V(m->specular[0], m->specular[1], m->specular[2]));
+        m->eta[1] = sl / (dl + sl);
+    }
     s->tex_levels = (uint32_t *) dup(d->texture_levels, (size_t) (d->texture_levels ? d->n_texture_levels : 0) * 12);
     s->tex_texels = (float *) dup(d->texture_texels, (size_t) (d->texture_texels ? d->n_texture_texels : 0) * 4);
     s->d.texture_levels = NULL; s->d.texture_texels = NULL;

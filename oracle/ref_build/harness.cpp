@@ -266,7 +266,8 @@ static Built buildScene(const FScene &fs) {
               if (ft.type == 1) tp.setFloat("lineWidth", ft.lineWidth);
               tp.setFloat("uoffset", ft.uoffset); tp.setFloat("voffset", ft.voffset); tp.setFloat("uscale", ft.uscale); tp.setFloat("vscale", ft.vscale);
               ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp)); tex->configure();
-              bsdf->addChild("reflectance", tex); tex->setParent(bsdf);
+              // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance or difftrans.transmittance (the material record's `reflectance`)
+              bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : "reflectance", tex); tex->setParent(bsdf);
           } }
         bsdf->configure();
         if (fb.twosided) {

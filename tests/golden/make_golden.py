@@ -77,6 +77,9 @@ def golden_scenes():
                                                       slab_kw=dict(alpha=0.2, distr=scenes.DISTR_BECKMANN, sample_visible=False)),
         "cbox_translucent_mf2": scenes.cbox_translucent(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=5, frost_kw=dict(alpha=0.25, alpha_v=0.1, distr=scenes.DISTR_BECKMANN, sample_visible=True),
                                                        slab_kw=dict(alpha=0.3, distr=scenes.DISTR_PHONG)),
+        # textures on plastic.diffuseReflectance / roughplastic.diffuseReflectance / difftrans.transmittance (lobe weights from the texture's average)
+        "textured_plastics": scenes.textured_plastics(width=96, height=64, spp=16),
+        "textured_plastics_smooth": scenes.textured_plastics(width=96, height=64, spp=8, rough=False, sampler=scenes.SAMPLER_INDEPENDENT, seed=6),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
@@ -115,7 +118,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets"):
+        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", "path", -1, base + "_resp")

@@ -609,3 +609,28 @@ def test_full_microfacet_distribution(mi, oracle, golden_scenes, name):
     if any(sc.bsdfs[s["bsdf"]].get("aniso") for s in sc.shapes):      # (analytic shapes carry their own parameterisation)
         with pytest.raises(mi.MiError, match="texture coordinates are required"):
             mi.Scene(bad)
+
+
+def test_textures_on_plastic_and_difftrans(mi, oracle, golden_scenes):
+    """textures on plastic.diffuseReflectance (checkerboard, nonlinear), roughplastic.diffuseReflectance (bitmap, trilinear; grid) and
+    difftrans.transmittance (grid).  The lobe-selection weight comes from the texture's AVERAGE (plastic.cpp:204-207; derived on the host at commit), the
+    lobes use the local value.  Procedural textures and the smooth plastic are libm-free -> most samples bit-exact; roughplastic / bitmap level selection
+    are tolerance-pinned."""
+    name = "textured_plastics"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(77); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-5).mean() > 0.99 and (err < 1e-2).mean() > 0.999 and np.median(err) < 1e-6, ((err < 1e-5).mean(), err.max())
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-3
+    # a texture on a parameter the path takes as a constant only is refused
+    bad = type(sc)(sc); bad["bsdfs"] = [dict(b) for b in sc.bsdfs]; bad["bsdfs"][4] = dict(mi.scenes.make_bsdf(kind=mi.scenes.BSDF_CONDUCTOR), texture=0)
+    with pytest.raises(mi.MiError, match="textures bind to"):
+        mi.Scene(bad)

@@ -15,7 +15,7 @@ X = importlib.import_module("mitsuba-im_amd.xml_scene")
 S = importlib.import_module("mitsuba-im_amd.scenes")
 
 GENERATORS = ["cornell_box", "cbox_shapes", "cbox_materials", "cbox_lights", "open_constant", "cbox_translucent", "cbox_roughplastic", "textured_room",
-              "shape_lights", "veach_mis", "veach_microfacets"]
+              "shape_lights", "veach_mis", "veach_microfacets", "textured_plastics", "bitmap_room"]
 
 
 def assert_same_scene(a, b, exact_analytic=False):
@@ -40,6 +40,7 @@ def assert_same_scene(a, b, exact_analytic=False):
             assert ba[k] == bb[k], (k, ba, bb)
         assert (ba["sample_visible"] & 1) == (bb["sample_visible"] & 1) or ba["type"] not in (S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHDIELECTRIC)
         for k in ("reflectance", "specular", "eta", "k"):
+            if k == "reflectance" and ba.get("texture", -1) >= 0: continue          # the texture replaces it
             np.testing.assert_allclose(ba[k], bb[k], rtol=2e-7, atol=0, err_msg=k)
         assert ba["alpha"] == pytest.approx(bb["alpha"], rel=1e-7)
     for ea, eb in zip(a.emitters, b.emitters):
@@ -54,8 +55,10 @@ def assert_same_scene(a, b, exact_analytic=False):
         assert xa["radius"] == pytest.approx(xb["radius"], rel=1e-6) and xa["length"] == pytest.approx(xb["length"], rel=1e-6)
     assert len(a.textures) == len(b.textures)
     for ta, tb in zip(a.textures, b.textures):
-        for k in ("type", "color0", "color1", "uoffset", "voffset", "uscale", "vscale"):
+        for k in ("type", "color0", "color1", "uoffset", "voffset", "uscale", "vscale", "wrap_u", "wrap_v", "filter", "n_levels"):
             assert ta[k] == pytest.approx(tb[k]), k
+    if a.texture_texels is not None:
+        np.testing.assert_array_equal(a.texture_levels, b.texture_levels); np.testing.assert_array_equal(a.texture_texels, b.texture_texels)
 
 
 @pytest.mark.parametrize("gen", GENERATORS)
