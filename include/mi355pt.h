@@ -50,6 +50,7 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
                                      transmittance (m_internalRoughTransmittance->evalDiffuse(alpha), roughplastic.cpp:372), k[1] / k[2] = offset / length of the
                                      external rough-transmittance slice (RoughTransmittance after setEta + setAlpha, src/bsdfs/rtrans.h:292-388) in the table
                                      buffer of mi_scene_set_material_tables */
+#define MI_BSDF_THINDIELECTRIC 8  /* src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance (ENull transmission) */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

@@ -236,6 +236,11 @@ static mi_material convertBSDF(const BSDF *bsdf) {
             rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular);
             return m;
         }
+        if (cls == "ThinDielectric") {           // thindielectric.cpp:70-86
+            m.type = MI_BSDF_THINDIELECTRIC; m.eta[0] = lookupIOR(props, "intIOR", "bk7") / lookupIOR(props, "extIOR", "air");
+            rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.reflectance);
+            return m;
+        }
         if (cls == "SmoothDielectric") {
             m.type = MI_BSDF_DIELECTRIC; m.eta[0] = lookupIOR(props, "intIOR", "bk7") / lookupIOR(props, "extIOR", "air");
             rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.reflectance);

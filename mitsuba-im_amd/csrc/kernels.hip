@@ -357,7 +357,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         //   B: BSDF sampling                                                     -> next ray / state
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
-        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0;
+        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false;
         if (i < n) {
             const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
             float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
@@ -365,6 +365,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
             depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
             const bool prevDelta = RC && ((s0.w >> 17) & 1u) != 0;      // the BSDF sample that spawned this ray was a delta component -> lumPdf = 0 (path.cpp:259-260)
+            unscattered = RC && ((s0.w >> 18) & 1u) != 0;    // every component sampled so far was ENull (thin dielectric panes): `scattered` is still false (path.cpp:213)
             v3 d = V(rd.x, rd.y, rd.z); T = V(s1.x, s1.y, s1.z); eta = s1.w;
             const uint32_t prim = __float_as_uint(hr.w);
             v3 add = V(0, 0, 0); bool haveAdd = false;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                         else {
                             // BSDF ray left the scene: env->evalEnvironment + fillDirectSamplingRecord (envmap.cpp:362-378), MIS term path.cpp:257-264
                             float4 ro = q.rayO[buf][slot]; float nearT, farT;
-                            if (bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {
+                            if (!(rc.hide_emitters && unscattered) && bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {   // path.cpp:238-239: hideEmitters && !scattered
                                 v3 value = envEval(sc, d);
                                 float pdfSA;
                                 if (sc.env_constant) {      // ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233): needs the reference normal of the previous vertex
@@ -470,9 +471,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             // BSDF sampling (path.cpp:207-226)
             float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
             float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-            bool sampledDelta; float extra = 0.0f;
+            bool sampledDelta, sampledNull; float extra = 0.0f;
             if (RC && bsdfUsesSampler(bsdf)) extra = next1D(ss, rc.sampler, m32);      // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler)
-            v3 bw = bsdfSample<RC>(sc, bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta);
+            v3 bw = bsdfSample<RC>(sc, bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta, sampledNull);
             v3 wo = toWorld(h, woL);
             if (isZero(bw) || (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0)) pathLen += (unsigned) depth;
             else {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 const float cosRef = dot(wo, refN);
                 uint32_t fl = cosRef >= 0 ? 1u : 0u;
                 nS3 = (h.flags & 2u) ? 2.0f : cosRef;
-                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16) | ((RC && sampledDelta) ? (1u << 17) : 0u));
+                nS0 = make_uint4(pid, ss.a, ss.b, (ss.dim & 0xFFu) | ((uint32_t) (depth + 1) << 8) | (fl << 16) | ((RC && sampledDelta) ? (1u << 17) : 0u) | ((RC && sampledNull && (depth == 1 || unscattered)) ? (1u << 18) : 0u));
                 nS1 = make_float4(T.x, T.y, T.z, eta); nS2 = bPdf;
             }
         }

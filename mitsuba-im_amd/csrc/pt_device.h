@@ -891,6 +891,7 @@ DEV v3 rcSample(const MaterialD &mt, v3 wi, float u, float v, v3 &wo, float &pdf
 #define MI_BSDF_T_ROUGHCONDUCTOR 1u
 #define MI_BSDF_T_CONDUCTOR 2u
 #define MI_BSDF_T_DIELECTRIC 3u
+#define MI_BSDF_T_THINDIELECTRIC 8u
 #define MI_BSDF_T_PLASTIC 4u
 // src/libcore/util.cpp:653-683 fresnelDielectricExt
 DEV float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {
@@ -1098,6 +1099,14 @@ DEV v3 rpSample(const DScene &sc, const MaterialD &mt, v3 wi, float sx, float sy
 // ---------------------------------------------------------------------------------------------- BSDFs
 // src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side).  RC = the scene holds non-diffuse materials
 // (rough conductor, conductor, dielectric, plastic): the diffuse-only kernel variants carry none of that code.
+// src/bsdfs/thindielectric.cpp:206-258: delta reflection or straight-through transmission (an ENull component: `nullComp`), internal bounces summed
+DEV v3 thinDielectricSample(const MaterialD &m, v3 wi, float sx, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
+    float ct, R = fresnelDielectricExt(fabsf(wi.z), ct, m.eta[0]), T = 1 - R;
+    if (R < 1) R += T * T * R / (1 - R * R);
+    etaOut = 1.0f; delta = true;
+    if (sx <= R) { wo = V(-wi.x, -wi.y, wi.z); pdf = R; return ld3(m.specular); }
+    nullComp = true; wo = V(-wi.x, -wi.y, -wi.z); pdf = 1 - R; return ld3(m.reflectance);
+}
 template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     if (RC && m.type != 0) {
@@ -1128,8 +1137,8 @@ template <bool RC> DEV float bsdfPdf(const DScene &sc, const MaterialD &m, v3 wi
 // delta = the sampled component is a Dirac delta (bRec.sampledType & BSDF::EDelta, path.cpp:259-260)
 // `extra`: one more value from the path's sampler, drawn by the caller iff bsdfUsesSampler(m) (BSDF::EUsesSampler)
 DEV bool bsdfUsesSampler(const MaterialD &m) { return m.type == MI_BSDF_T_ROUGHDIELECTRIC; }
-template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi, float u, float v, float extra, v3 &wo, float &pdf, float &eta, bool &delta) {
-    bool flipped = false; delta = false;
+template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi, float u, float v, float extra, v3 &wo, float &pdf, float &eta, bool &delta, bool &nullComp) {
+    bool flipped = false; delta = false; nullComp = false;
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; flipped = true; }
     if (RC && m.type != 0) {
         v3 w;
@@ -1139,6 +1148,7 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
         else if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) w = rdSample(m, wi, u, v, extra, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_DIFFTRANS) w = dtSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_ROUGHPLASTIC) w = rpSample(sc, m, wi, u, v, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_THINDIELECTRIC) w = thinDielectricSample(m, wi, u, wo, pdf, eta, delta, nullComp);
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);
         if (flipped && !isZero(w) && pdf != 0) wo.z = -wo.z;      // twosided.cpp:176-180
         return w;

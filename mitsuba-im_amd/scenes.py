@@ -19,6 +19,7 @@ BSDF_DIELECTRIC = 3       # src/bsdfs/dielectric.cpp: eta[0] = intIOR / extIOR, 
 BSDF_ROUGHDIELECTRIC = 5  # src/bsdfs/roughdielectric.cpp: alpha, distr, eta[0], specular = specularReflectance, reflectance = specularTransmittance
 BSDF_DIFFTRANS = 6        # src/bsdfs/difftrans.cpp: reflectance = transmittance
 BSDF_ROUGHPLASTIC = 7     # src/bsdfs/roughplastic.cpp: alpha, distr, eta[0], specular, reflectance = diffuseReflectance, k = (Tdiff_int, table offset, table length)
+BSDF_THINDIELECTRIC = 8   # src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
 EMITTER_ENVMAP = 1
@@ -103,6 +104,8 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
     table = None
     if kind == BSDF_ROUGHPLASTIC:
         eta = (float(f32(ior)), 0.0, 0.0); tdiff, table = rough_transmittance_slice(distr, ior, alpha); k = (tdiff, 0.0, float(len(table)))
+    if kind == BSDF_THINDIELECTRIC:
+        eta = (float(f32(ior)), 0.0, 0.0)
     if kind in (BSDF_DIELECTRIC, BSDF_PLASTIC):      # scalar relative index; plastic: k[0] = m_fdrInt = fresnelDiffuseReflectance(1 / eta) (plastic.cpp:200)
         eta = (float(f32(ior)), 0.0, 0.0); distr = int(nonlinear)
         k = (float(f32(fresnel_diffuse_reflectance(1.0 / float(f32(ior))))), 0.0, 0.0) if kind == BSDF_PLASTIC else (0.0, 0.0, 0.0)
@@ -875,6 +878,32 @@ def open_constant(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=
     cam = look_at((0.5, 2.2, -5.0), (0.0, 0.6, 0.8), (0, 1, 0))
     sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
                       seed=seed, hide_emitters=hide_emitters, name="open_constant", analytic=b.resolve_analytic())
+    return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
+
+
+def glass_pane(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, hide_emitters=False):
+    """The open scene of `open_constant` seen partly through a `thindielectric` pane (delta reflection + straight-through ENull transmission with the
+    internal bounces summed), a second tinted pane deeper in the scene, and a small area light behind the first pane.  A path that has only crossed panes
+    counts as unscattered: with hideEmitters the sky stays hidden through the glass (path.cpp:213, 238-239) while the area light does not (:226-231)."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.55, 0.5, 0.45)); red = b.bsdf(reflectance=(0.6, 0.15, 0.1)); lightm = b.bsdf(reflectance=(0.3, 0.3, 0.3))
+    pane = b.bsdf(kind=BSDF_THINDIELECTRIC, ior=1.5046, specular=(1.0, 1.0, 1.0), reflectance=(0.92, 0.97, 1.0))
+    tinted = b.bsdf(kind=BSDF_THINDIELECTRIC, ior=1.33, specular=(0.9, 0.8, 0.7), reflectance=(0.5, 0.8, 0.6))
+    eta, k = CONDUCTOR_IOR["Au"]; gold = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.2, distr=DISTR_BECKMANN, eta=eta, k=k)
+    b.begin(); b.quad([(6, 0, -6), (-6, 0, -6), (-6, 0, 6), (6, 0, 6)]); b.end(grey)
+    b.begin()
+    x0, z0, x1, z1, h = -2.0, 0.5, -0.8, 1.7, 1.2
+    b.quad([(x0, h, z0), (x0, h, z1), (x1, h, z1), (x1, h, z0)])
+    b.quad([(x0, 0, z0), (x0, h, z0), (x1, h, z0), (x1, 0, z0)]); b.quad([(x1, 0, z0), (x1, h, z0), (x1, h, z1), (x1, 0, z1)])
+    b.quad([(x1, 0, z1), (x1, h, z1), (x0, h, z1), (x0, 0, z1)]); b.quad([(x0, 0, z1), (x0, h, z1), (x0, h, z0), (x0, 0, z0)])
+    b.end(red)
+    b.begin(); b.quad([(-3.0, 0.0, -2.5), (0.6, 0.0, -2.9), (0.6, 3.2, -2.9), (-3.0, 3.2, -2.5)]); b.end(pane)            # in front of the camera, left part of the view
+    b.begin(); b.quad([(0.2, 0.0, 2.6), (2.4, 0.0, 1.8), (2.4, 1.8, 1.8), (0.2, 1.8, 2.6)]); b.end(tinted)
+    b.begin(); b.quad([(-1.6, 2.2, 0.4), (-1.6, 2.2, 1.0), (-1.0, 2.2, 1.0), (-1.0, 2.2, 0.4)]); b.end(lightm, radiance=(9.0, 8.0, 6.0))   # faces down, seen through the pane
+    b.add_analytic(SHAPE_SPHERE, translate(0.9, 0.6, 0.2), gold, radius=0.6)
+    cam = look_at((0.5, 2.2, -5.0), (0.0, 0.9, 0.8), (0, 1, 0))
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                      seed=seed, hide_emitters=hide_emitters, name="glass_pane", analytic=b.resolve_analytic())
     return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
 
 

@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, twosided
+    bsdf        diffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .npy / .pfm / .hdr or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -520,7 +520,7 @@ class _SceneBuilder:
             else:
                 distr, alpha, sv, alpha_v = _microfacet(p, full=True)
                 rec = S.make_bsdf(S.BSDF_ROUGHCONDUCTOR, eta=eta, k=k, specular=spec, alpha=alpha, alpha_v=alpha_v, distr=distr, sample_visible=sv, twosided=twosided)
-        elif t in ("dielectric", "roughdielectric", "plastic", "roughplastic"):
+        elif t in ("dielectric", "thindielectric", "roughdielectric", "plastic", "roughplastic"):
             plastic = t.endswith("plastic")
             ior = float(f32(_ior(p, "intIOR", "polypropylene" if plastic else "bk7")) / f32(_ior(p, "extIOR", "air")))
             spec, stex = _spectrum_or_texture(p, ("specularReflectance",), (1.0, 1.0, 1.0))
@@ -544,10 +544,10 @@ class _SceneBuilder:
                 except ValueError as e:
                     raise SceneError(f"roughplastic: {e}")
             else:
-                rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_DIELECTRIC, **kw)
+                rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, twosided)")
+                             "roughdielectric, difftrans, roughplastic, thindielectric, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -943,6 +943,8 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="conductor">{cond}</bsdf>'
         elif t == S.BSDF_DIELECTRIC:
             inner = f'<bsdf type="dielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_THINDIELECTRIC:
+            inner = f'<bsdf type="thindielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
         elif t == S.BSDF_ROUGHDIELECTRIC:
             inner = f'<bsdf type="roughdielectric">{mf}{sv}{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
         elif t == S.BSDF_PLASTIC:

@@ -775,15 +775,15 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
-static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS; }
+static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC; }
 /* BSDF::ESmooth: a `diffuse` whose reflectance is identically zero registers NO component (src/bsdfs/diffuse.cpp:99-102), so its type
  * is 0 and MIPathTracer::Li skips emitter sampling -- and the sampler request that goes with it (path.cpp:174-176) */
 static int material_is_smooth(const orc_material *m) {
     if (m->type == BSDF_DIFFUSE) return ((m->flags >> 8) & 0xFFFFu) != 0 || maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;   /* a textured reflectance always registers the component */
-    if (m->type == BSDF_CONDUCTOR || m->type == BSDF_DIELECTRIC) return 0;     /* delta components only (conductor.cpp:201-202, dielectric.cpp:199-202) */
+    if (m->type == BSDF_CONDUCTOR || m->type == BSDF_DIELECTRIC || m->type == BSDF_THINDIELECTRIC) return 0;     /* delta components only (conductor.cpp:201-202, dielectric.cpp:199-202, thindielectric.cpp:117-120) */
     return 1;
 }
 
@@ -1092,6 +1092,15 @@ static v3 conductor_sample(const orc_material *m, v3 wi, v3 *wo, float *pdf, flo
     *wo = V(-wi.x, -wi.y, wi.z); *eta = 1.0f; *pdf = 1; *delta = 1;
     return mul(V(m->specular[0], m->specular[1], m->specular[2]), fresnel_conductor_exact(wi.z, m->eta, m->k));
 }
+/* src/bsdfs/thindielectric.cpp:206-258: a thin slab -- delta reflection or straight-through transmission (an ENull component: the path counts as unscattered,
+ * *delta = 2), reflectance with the internal bounces summed (R' = R + TRT + TR^3T + ...).  Fields: eta[0], specular = specularReflectance, reflectance = specularTransmittance */
+static v3 thindielectric_sample(const orc_material *m, v3 wi, float sx, v3 *wo, float *pdf, float *etaOut, int *delta) {
+    float ct, R = fresnel_dielectric_ext(fabsf(wi.z), &ct, m->eta[0]), T = 1 - R;
+    if (R < 1) R += T * T * R / (1 - R * R);
+    *etaOut = 1.0f;
+    if (sx <= R) { *delta = 1; *wo = V(-wi.x, -wi.y, wi.z); *pdf = R; return V(m->specular[0], m->specular[1], m->specular[2]); }
+    *delta = 2; *wo = neg(wi); *pdf = 1 - R; return V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
+}
 static v3 dielectric_sample(const orc_material *m, v3 wi, float sx, v3 *wo, float *pdf, float *etaOut, int *delta) {
     const float eta = m->eta[0], invEta = 1 / eta; float cosThetaT;
     float F = fresnel_dielectric_ext(wi.z, &cosThetaT, eta);
@@ -1278,7 +1287,7 @@ static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
         case BSDF_ROUGHCONDUCTOR: return rc_eval(m, wi, wo);
-        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: return V(0, 0, 0);
+        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: case BSDF_THINDIELECTRIC: return V(0, 0, 0);
         case BSDF_PLASTIC: return plastic_eval(m, wi, wo);
         case BSDF_ROUGHDIELECTRIC: return rd_eval(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_eval(m, wi, wo);
@@ -1290,7 +1299,7 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
         case BSDF_ROUGHCONDUCTOR: return rc_pdf(m, wi, wo);
-        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: return 0.0f;
+        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: case BSDF_THINDIELECTRIC: return 0.0f;
         case BSDF_PLASTIC: return plastic_pdf(m, wi, wo);
         case BSDF_ROUGHDIELECTRIC: return rd_pdf(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_pdf(wi, wo);
@@ -1313,6 +1322,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_ROUGHDIELECTRIC: w = rd_sample(m, wi, u, v, sp ? next1D(sp) : g_extra_unit, wo, pdf, eta); break;
         case BSDF_DIFFTRANS: w = dt_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_ROUGHPLASTIC: w = rp_sample(m, wi, u, v, wo, pdf, eta); break;
+        case BSDF_THINDIELECTRIC: w = thindielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;
     }
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
@@ -1782,7 +1792,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
         int sampledDelta = 0;
         v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta, sp);
         if (is_zero(bsdfWeight)) break;
-        scattered = 1;
+        scattered |= sampledDelta != 2;                  /* path.cpp:213: scattered |= bRec.sampledType != BSDF::ENull */
         v3 wo = to_world(&its, woL);
         float woDotGeoN = dot(its.ng, wo);
         if (strict && woDotGeoN * woL.z <= 0) break;

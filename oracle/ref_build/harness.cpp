@@ -231,6 +231,11 @@ static Built buildScene(const FScene &fs) {
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 8) {
+            Properties p("thindielectric");
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
+            p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 6) {
             Properties p("difftrans"); p.setSpectrum("transmittance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));

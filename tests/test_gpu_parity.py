@@ -634,3 +634,27 @@ def test_textures_on_plastic_and_difftrans(mi, oracle, golden_scenes):
     bad = type(sc)(sc); bad["bsdfs"] = [dict(b) for b in sc.bsdfs]; bad["bsdfs"][4] = dict(mi.scenes.make_bsdf(kind=mi.scenes.BSDF_CONDUCTOR), texture=0)
     with pytest.raises(mi.MiError, match="textures bind to"):
         mi.Scene(bad)
+
+
+@pytest.mark.parametrize("name", ["glass_pane", "glass_pane_hide_indep"])
+def test_thin_dielectric(mi, oracle, golden_scenes, name):
+    """`thindielectric` (src/bsdfs/thindielectric.cpp) -- delta reflection or straight-through transmission with the pane's internal bounces
+    summed.  The transmission is an ENull component: a path that has only crossed panes is still "unscattered" (path.cpp:213), which with hideEmitters keeps
+    the sky hidden through the glass (:238-239) but not the area light (:226-231); carried as one state bit.  No math library calls -> bit-exact."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(4); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)          # the gold sphere's rough conductor goes through the device math library
+    assert (bits(got) == bits(ref)).all(1).mean() > 0.9 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-4
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-4
+    # hideEmitters changes what is seen THROUGH the pane: the sky disappears there too
+    other = mi.Render(gs, hide_emitters=not sc.hide_emitters); other.run()
+    assert np.linalg.norm(other.read_film(0)[..., :3] - film[..., :3]) / np.linalg.norm(film[..., :3]) > 0.05
