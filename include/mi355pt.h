@@ -51,11 +51,12 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
                                      external rough-transmittance slice (RoughTransmittance after setEta + setAlpha, src/bsdfs/rtrans.h:292-388) in the table
                                      buffer of mi_scene_set_material_tables */
 #define MI_BSDF_THINDIELECTRIC 8  /* src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance (ENull transmission) */
+#define MI_BSDF_MASK 9            /* src/bsdfs/mask.cpp: reflectance = opacity (constant or a bound texture), distr = index of the nested material record; ENull pass-through lobe */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
 #define MI_BSDF_FLAG_ANISOTROPIC 8u /* alphaU = alpha, alphaV = reflectance[0] (roughconductor) / k[0] (roughdielectric) (src/bsdfs/microfacet.h:116-127); mesh shapes need texture coordinates */
-#define MI_BSDF_TEXTURE(i) (((uint32_t) (i) + 1u) << 8)   /* flags bits 8..23: texture i (mi_scene_set_textures) bound to `reflectance`: diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; a bitmap texture record carries its average in color0 (plastic lobe weights, plastic.cpp:204-207) */
+#define MI_BSDF_TEXTURE(i) (((uint32_t) (i) + 1u) << 8)   /* flags bits 8..23: texture i (mi_scene_set_textures) bound to `reflectance`: diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance, mask.opacity; a bitmap texture record carries its average in color0 (plastic lobe weights, plastic.cpp:204-207) */
 
 /* 2-D procedural textures over Texture2D (src/librender/texture.cpp:81-121: uv * scale + offset): src/textures/checkerboard.cpp, gridtexture.cpp */
 #define MI_TEXTURE_CHECKERBOARD 0

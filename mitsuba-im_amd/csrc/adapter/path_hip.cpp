@@ -68,6 +68,7 @@ static void roughPlasticTables(mi_material &m) {
 /// (difftrans.cpp:66-70), constant textures (src/librender/basictexture.cpp:29-49), Texture2D (src/librender/texture.cpp:106-110) with Checkerboard /
 /// GridTexture / BitmapTexture (bitmap.cpp:404-432).
 static std::vector<mi_texture> *g_textures = NULL; static std::vector<uint32_t> *g_texLevels = NULL; static std::vector<float> *g_texTexels = NULL;
+static std::vector<mi_material> *g_materials = NULL;       // FlatScene::materials of the flatten() in progress: a `mask` appends its nested BSDF's record
 struct NestedReader {
     ref<MemoryStream> ms; std::map<uint32_t, std::vector<float> > seen; std::map<uint32_t, int> seenTexture;
     int lastTexture = -1;                 ///< index into g_textures when the last texture() call met a spatially varying texture, else -1
@@ -127,7 +128,8 @@ int NestedReader::spatialTexture(const std::string &tcls) {
     return (int) g_textures->size() - 1;
 }
 /// one nested / serialised BSDF of class `cls` (its BSDF::serialize bool already consumed) -> material; false: leave it to the generic path
-static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_material &m) {
+static bool readNestedInstance(NestedReader &rd, mi_material &m);
+static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_material &m, bool acceptConstantDiffuse = false) {
     auto bind = [&](const std::vector<float> &v) { if (rd.lastTexture >= 0) m.flags |= MI_BSDF_TEXTURE(rd.lastTexture); memcpy(m.reflectance, v.data(), 12); };
     if (cls == "RoughConductor") {
         uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
@@ -153,12 +155,33 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         std::vector<float> spec = rd.constant("specularReflectance"), diff = rd.texture(); bind(diff); memcpy(m.specular, spec.data(), 12);
         m.k[0] = fresnelDiffuseReflectance(1 / m.eta[0], false);
     } else if (cls == "SmoothDiffuse") {
-        std::vector<float> refl = rd.texture(); if (rd.lastTexture < 0) return false;      // constant reflectance: the generic path reads it through the public interface
+        std::vector<float> refl = rd.texture(); if (rd.lastTexture < 0 && !acceptConstantDiffuse) return false;      // constant reflectance: the generic path reads it through the public interface
         m.type = MI_BSDF_DIFFUSE; bind(refl);
+    } else if (cls == "Mask") {                                         // mask.cpp:92-96: opacity texture, then the nested BSDF
+        std::vector<float> op = rd.texture(); const int opTex = rd.lastTexture;
+        mi_material nested; memset(&nested, 0, sizeof(nested));
+        if (!readNestedInstance(rd, nested)) SLog(EError, "path_hip: the BSDF nested in `mask` is not implemented");
+        if (nested.type == MI_BSDF_MASK) SLog(EError, "path_hip: a mask nested in a mask is not implemented");
+        const uint32_t keepFlags = m.flags;
+        memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MASK; m.flags = keepFlags; m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
+        memcpy(m.reflectance, op.data(), 12); if (opTex >= 0) m.flags |= MI_BSDF_TEXTURE(opTex);
     } else if (cls == "DiffuseTransmitter") {
         std::vector<float> tr = rd.texture(); m.type = MI_BSDF_DIFFTRANS; bind(tr);
     } else return false;
     return true;
+}
+/// an instance reference inside a serialised BSDF (id, class name, BSDF::serialize bool, content), `twosided` unwrapped
+static bool readNestedInstance(NestedReader &rd, mi_material &m) {
+    uint32_t id = rd.ms->readUInt(); if (id == 0) return false;
+    std::string cls = rd.ms->readString(); rd.ms->readBool();
+    if (cls == "TwoSidedBRDF") {
+        uint32_t id0 = rd.ms->readUInt(); std::string inner = rd.ms->readString(); rd.ms->readBool();
+        m.flags |= MI_BSDF_FLAG_TWOSIDED;
+        if (!readSerializedBSDF(rd, inner, m, true)) return false;
+        if (rd.ms->readUInt() != id0) SLog(EError, "path_hip: twosided with two different nested BSDFs is not implemented");
+        return true;
+    }
+    return readSerializedBSDF(rd, cls, m, true);
 }
 static bool convertTwoSided(const BSDF *bsdf, mi_material &m) {
     NestedReader rd; rd.ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager();
@@ -185,6 +208,10 @@ static bool convertSpatiallyVarying(const BSDF *bsdf, mi_material &m) {
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
     if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
+    if (bsdf->getClass()->getName() == "Mask") {                       // nested BSDF and opacity are private: serialised form
+        if (convertSpatiallyVarying(bsdf, m)) return m;
+        SLog(EError, "path_hip: this `mask` is not implemented");
+    }
     if ((bsdf->getType() & BSDF::ESpatiallyVarying) && bsdf->getClass()->getName() != "TwoSidedBRDF") {      // textures are private members: never fall through to the Properties (constants only)
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on diffuse.reflectance, plastic / roughplastic.diffuseReflectance and difftrans.transmittance", bsdf->getClass()->getName().c_str());
@@ -341,7 +368,7 @@ static bool convertAnalytic(const Shape *shape, mi_analytic &a) {
 }
 
 static void flatten(const Scene *scene, FlatScene &fs) {
-    g_tables = &fs.materialTables; g_textures = &fs.textures; g_texLevels = &fs.texLevels; g_texTexels = &fs.texTexels;
+    g_tables = &fs.materialTables; g_materials = &fs.materials; g_textures = &fs.textures; g_texLevels = &fs.texLevels; g_texTexels = &fs.texTexels;
     const std::vector<TriMesh *> &meshes = scene->getMeshes();
     std::map<const BSDF *, int> bsdfIndex; std::vector<const Instance *> insts;
     // non-mesh shapes: rectangle / disk / sphere / cylinder become analytic records (numbered after the meshes); anything else is refused
@@ -388,14 +415,14 @@ static void flatten(const Scene *scene, FlatScene &fs) {
         for (size_t k = 0; k < mesh->getTriangleCount(); ++k) for (int c = 0; c < 3; ++c) fs.idx.push_back(sh.first_vert + t[k].idx[c]);
         sh.flags = (n ? 0u : 1u) | (mesh->getVertexTexcoords() ? 2u : 0u);
         const BSDF *bsdf = mesh->getBSDF();
-        if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
+        if (!bsdfIndex.count(bsdf)) { const mi_material cm = convertBSDF(bsdf); bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(cm); }   // (a mask appends its nested record first)
         sh.bsdf = bsdfIndex[bsdf]; sh.emitter = -1; sh.group = meshGroup[mi];
         fs.shapes.push_back(sh);
     }
     for (size_t ai = 0; ai < fs.analytic.size(); ++ai) {
         const BSDF *bsdf = fs.analyticShapes[ai]->getBSDF();
         if (!bsdf) SLog(EError, "path_hip: analytic shape without a BSDF");
-        if (!bsdfIndex.count(bsdf)) { bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(convertBSDF(bsdf)); }
+        if (!bsdfIndex.count(bsdf)) { const mi_material cm = convertBSDF(bsdf); bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(cm); }   // (a mask appends its nested record first)
         fs.analytic[ai].bsdf = bsdfIndex[bsdf];
     }
     // emitters in Scene::getEmitters() order (the order the emitter PDF is built in, scene.cpp:383-388)

@@ -168,7 +168,8 @@ int mi_scene_set_instances(mi_scene *s, const mi_instance *a, uint32_t n) {
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_THINDIELECTRIC) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_MASK) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask (those without transmission optionally twosided)");
+        if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_DIFFTRANS || m[i].type == MI_BSDF_THINDIELECTRIC) && (m[i].flags & MI_BSDF_FLAG_TWOSIDED)) return fail(MI_ERR_INVALID, "Only BSDFs without a transmission component can be nested!");   // twosided.cpp:86-88
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC || m[i].type == MI_BSDF_THINDIELECTRIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
         if (m[i].type == MI_BSDF_ROUGHPLASTIC && (m[i].distr > 1 || !(m[i].flags & MI_BSDF_FLAG_SAMPLE_VISIBLE) || (m[i].flags & MI_BSDF_FLAG_ANISOTROPIC)))
@@ -321,8 +322,8 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
         if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
             (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
-        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS)))
-            return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance or difftrans.transmittance (and must exist)");
+        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK)))
+            return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance or mask.opacity (and must exist)");
     }
     if (s->h.envTexture >= 0) {       // MIP pyramid of the environment map (camera-ray lookups, envmap.cpp:398-411)
         if (!s->h.envW) return fail(MI_ERR_INVALID, "mi_scene_commit: mi_scene_set_envmap_filter without an environment map");

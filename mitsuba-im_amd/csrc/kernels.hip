@@ -357,7 +357,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         //   B: BSDF sampling                                                     -> next ray / state
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
-        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false;
+        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false;   // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
         if (i < n) {
             const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
             float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
@@ -412,8 +412,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
                 bsdf = loadMaterial(tb, h.material);
-                if (TEX) {                                                   // textured diffuse reflectance: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121)
-                    const uint32_t tex = (bsdf.flags >> 8) & 0xFFFFu;
+                auto applyTexture = [&](MaterialD &mm) {
+                if (TEX) {                                                   // a textured parameter: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121) and its siblings
+                    const uint32_t tex = (mm.flags >> 8) & 0xFFFFu;
                     if (tex) {
                         const TextureD &tx = sc.textures[tex - 1]; v3 c;
                         if (tx.type == 2u) {                                 // BitmapTexture::eval (src/textures/bitmap.cpp:434-502) under Texture2D::eval (texture.cpp:112-121)
@@ -428,8 +429,13 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                                 c = mipEval(sc, tx, uvx, uvy, pa[0] * tx.uscale, pa[1] * tx.vscale, pa[2] * tx.uscale, pa[3] * tx.vscale);
                             } else c = tx.filter != 0u ? mipBilinear(sc, tx, 0, uvx, uvy) : mipBox(sc, tx, 0, uvx, uvy);
                         } else c = textureEval(tx, h.uvx, h.uvy);
-                        bsdf.reflectance[0] = c.x; bsdf.reflectance[1] = c.y; bsdf.reflectance[2] = c.z;
+                        mm.reflectance[0] = c.x; mm.reflectance[1] = c.y; mm.reflectance[2] = c.z;
                     }
+                }
+                };
+                applyTexture(bsdf);
+                if (RC && bsdf.type == MI_BSDF_T_MASK) {                     // mask.cpp: this record's (textured) `reflectance` is the opacity in front of the nested record `distr`
+                    opac = ld3(bsdf.reflectance); masked = true; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
                 }
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
@@ -444,8 +450,10 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
                         v3 bsdfVal = bsdfEval<RC>(sc, bsdf, h.wi, wo);
+                        if (RC && masked) bsdfVal = bsdfVal * opac;                          // mask.cpp:124-127
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
                             float bp = dr.delta ? 0.0f : bsdfPdf<RC>(sc, bsdf, h.wi, wo);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
+                            if (RC && masked) bp *= luminance3(opac);                          // mask.cpp:141-146
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
                             wantShadow = true;
@@ -471,9 +479,18 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             // BSDF sampling (path.cpp:207-226)
             float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
             float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-            bool sampledDelta, sampledNull; float extra = 0.0f;
-            if (RC && bsdfUsesSampler(bsdf)) extra = next1D(ss, rc.sampler, m32);      // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler)
-            v3 bw = bsdfSample<RC>(sc, bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta, sampledNull);
+            bool sampledDelta, sampledNull; float extra = 0.0f; v3 bw;
+            bool passThrough = false;                                                   // mask.cpp:196-208: the nested BSDF with probability luminance(opacity), else straight through
+            if (RC && masked) { const float prob = luminance3(opac); if (sx < prob) sx /= prob; else passThrough = true; }
+            if (RC && passThrough) {
+                const float p = 1 - luminance3(opac);
+                woL = V(-h.wi.x, -h.wi.y, -h.wi.z); bEta = 1.0f; bPdf = p; sampledDelta = true; sampledNull = true;
+                bw = V((1.0f - opac.x) / p, (1.0f - opac.y) / p, (1.0f - opac.z) / p);
+            } else {
+                if (RC && bsdfUsesSampler(bsdf)) extra = next1D(ss, rc.sampler, m32);  // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler)
+                bw = bsdfSample<RC>(sc, bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                if (RC && masked) { const float prob = luminance3(opac); bw = V(bw.x * opac.x / prob, bw.y * opac.y / prob, bw.z * opac.z / prob); bPdf *= prob; }
+            }
             v3 wo = toWorld(h, woL);
             if (isZero(bw) || (rc.strict_normals && dot(h.ng, wo) * woL.z <= 0)) pathLen += (unsigned) depth;
             else {

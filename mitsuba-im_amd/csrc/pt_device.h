@@ -892,6 +892,7 @@ DEV v3 rcSample(const MaterialD &mt, v3 wi, float u, float v, v3 &wo, float &pdf
 #define MI_BSDF_T_CONDUCTOR 2u
 #define MI_BSDF_T_DIELECTRIC 3u
 #define MI_BSDF_T_THINDIELECTRIC 8u
+#define MI_BSDF_T_MASK 9u
 #define MI_BSDF_T_PLASTIC 4u
 // src/libcore/util.cpp:653-683 fresnelDielectricExt
 DEV float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {

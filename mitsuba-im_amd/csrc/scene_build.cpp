@@ -170,14 +170,15 @@ void SceneHost::commitHost() {
     triuv.assign(uv.empty() ? 0 : nt, TriUV{}); anyUV = false;
     std::vector<V3> tlo(np), thi(np), cen(np);
     auto materialFlags = [&](int bsdf) {
-        const mi_material &mat = materials[bsdf];
+        const bool masked = materials[bsdf].type == MI_BSDF_MASK;                  // mask.cpp:104-121: the nested BSDF's components + an ENull | EFrontSide | EBackSide one
+        const mi_material &mat = masked ? materials[materials[bsdf].distr] : materials[bsdf];
         // dRec.refN = 0 when the BSDF has ETransmission or EBackSide (records.inl:160-164): twosided wrapper, dielectric
         bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS || mat.type == MI_BSDF_THINDIELECTRIC;
         // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
         // conductor / dielectric register delta components only
         bool smooth = mat.type == MI_BSDF_DIFFUSE ? (((mat.flags >> 8) & 0xFFFFu) != 0 || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0)
                                                   : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC && mat.type != MI_BSDF_THINDIELECTRIC);
-        return (backside ? 2u : 0u) | (smooth ? 0u : 4u) | (mat.type != MI_BSDF_DIFFUSE ? 8u : 0u);
+        return ((backside || masked) ? 2u : 0u) | (smooth ? 0u : 4u) | ((mat.type != MI_BSDF_DIFFUSE || masked) ? 8u : 0u);
     };
     for (uint32_t t = 0; t < nt; ++t) {
         uint32_t a = idx[t * 3], b = idx[t * 3 + 1], c = idx[t * 3 + 2];

@@ -20,6 +20,7 @@ BSDF_ROUGHDIELECTRIC = 5  # src/bsdfs/roughdielectric.cpp: alpha, distr, eta[0],
 BSDF_DIFFTRANS = 6        # src/bsdfs/difftrans.cpp: reflectance = transmittance
 BSDF_ROUGHPLASTIC = 7     # src/bsdfs/roughplastic.cpp: alpha, distr, eta[0], specular, reflectance = diffuseReflectance, k = (Tdiff_int, table offset, table length)
 BSDF_THINDIELECTRIC = 8   # src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance
+BSDF_MASK = 9             # src/bsdfs/mask.cpp: reflectance = opacity (constant or textured), distr = index of the nested material record (an earlier one)
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
 EMITTER_ENVMAP = 1
@@ -98,7 +99,9 @@ def rough_transmittance_slice(distr, ior, alpha):
 
 def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
               distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
-              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False, alpha_v=None):
+              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False, alpha_v=None, nested=None):
+    if kind == BSDF_MASK:
+        distr = int(nested)                           # reflectance = opacity
     if kind == BSDF_ROUGHDIELECTRIC:
         eta = (float(f32(ior)), 0.0, 0.0)
     table = None
@@ -904,6 +907,41 @@ def glass_pane(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, 
     cam = look_at((0.5, 2.2, -5.0), (0.0, 0.9, 0.8), (0, 1, 0))
     sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
                       seed=seed, hide_emitters=hide_emitters, name="glass_pane", analytic=b.resolve_analytic())
+    return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
+
+
+def masked_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, hide_emitters=False):
+    """`mask` BSDFs (src/bsdfs/mask.cpp) in the open scene: a cut-out screen in front of the camera (checkerboard opacity 1 / 0 over a twosided diffuse), a
+    tinted half-transparent sheet over `plastic` (coloured opacity: the pass-through lobe carries 1 - opacity), and a grid-masked rough conductor panel.
+    Passing through is an ENull event: with hideEmitters the sky stays hidden through the holes."""
+    b = _Builder(); uvs = []
+    def quad_uv(pts, uv=((0, 0), (1, 0), (1, 1), (0, 1))):
+        b.quad(pts); uvs.extend(uv)
+    grey = b.bsdf(reflectance=(0.55, 0.5, 0.45)); red = b.bsdf(reflectance=(0.6, 0.15, 0.1)); lightm = b.bsdf(reflectance=(0.3, 0.3, 0.3))
+    green2 = b.bsdf(reflectance=(0.2, 0.6, 0.25), twosided=True)
+    plast = b.bsdf(kind=BSDF_PLASTIC, reflectance=(0.7, 0.4, 0.2), ior=1.49, twosided=True)
+    eta, k = CONDUCTOR_IOR["Au"]; gold = b.bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.15, distr=DISTR_GGX, eta=eta, k=k, twosided=True)
+    screen = b.bsdf(kind=BSDF_MASK, nested=green2); b.bsdfs[screen]["texture"] = 0
+    sheet = b.bsdf(kind=BSDF_MASK, nested=plast, reflectance=(0.3, 0.5, 0.7))
+    grille = b.bsdf(kind=BSDF_MASK, nested=gold); b.bsdfs[grille]["texture"] = 1
+    tex = [make_texture(TEXTURE_CHECKERBOARD, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), uscale=7.0, vscale=5.0, uoffset=0.1),
+           make_texture(TEXTURE_GRID, (0.0, 0.0, 0.0), (1.0, 0.9, 0.8), line_width=0.12, uscale=6.0, vscale=6.0)]
+    b.begin(); quad_uv([(6, 0, -6), (-6, 0, -6), (-6, 0, 6), (6, 0, 6)]); b.end(grey)
+    b.begin()
+    x0, z0, x1, z1, h = -2.0, 0.5, -0.8, 1.7, 1.2
+    quad_uv([(x0, h, z0), (x0, h, z1), (x1, h, z1), (x1, h, z0)])
+    quad_uv([(x0, 0, z0), (x0, h, z0), (x1, h, z0), (x1, 0, z0)]); quad_uv([(x1, 0, z0), (x1, h, z0), (x1, h, z1), (x1, 0, z1)])
+    quad_uv([(x1, 0, z1), (x1, h, z1), (x0, h, z1), (x0, 0, z1)]); quad_uv([(x0, 0, z1), (x0, h, z1), (x0, h, z0), (x0, 0, z0)])
+    b.end(red)
+    b.begin(); quad_uv([(-3.0, 0.0, -2.5), (0.4, 0.0, -2.9), (0.4, 3.0, -2.9), (-3.0, 3.0, -2.5)]); b.end(screen)         # in front of the camera, left part of the view
+    b.begin(); quad_uv([(0.2, 0.0, 2.6), (2.4, 0.0, 1.8), (2.4, 1.8, 1.8), (0.2, 1.8, 2.6)]); b.end(sheet)
+    b.begin(); quad_uv([(0.8, 0.0, -1.6), (2.6, 0.0, -1.2), (2.6, 1.5, -1.2), (0.8, 1.5, -1.6)]); b.end(grille)
+    b.begin(); quad_uv([(-1.6, 2.2, 0.4), (-1.6, 2.2, 1.0), (-1.0, 2.2, 1.0), (-1.0, 2.2, 0.4)]); b.end(lightm, radiance=(9.0, 8.0, 6.0))
+    for sh in b.shapes: sh["has_uv"] = 0
+    for si in (2, 4): b.shapes[si]["has_uv"] = 1
+    cam = look_at((0.5, 2.2, -5.0), (0.0, 0.9, 0.8), (0, 1, 0))
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                      seed=seed, hide_emitters=hide_emitters, uvs=uvs, name="masked_room", textures=tex)
     return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
 
 

@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, twosided
+    bsdf        diffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .npy / .pfm / .hdr or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -489,7 +489,18 @@ class _SceneBuilder:
             self.bsdf_index[key] = i
             return i
         tex = None
-        if t == "diffuse":
+        if t == "mask":                                   # src/bsdfs/mask.cpp: opacity (spectrum or texture, default 0.5) in front of one nested BSDF
+            inner = p.children_of("bsdf")
+            if len(inner) != 1:
+                raise SceneError("mask: exactly one nested BSDF is expected")
+            if twosided:
+                raise SceneError("twosided cannot wrap a transmissive BSDF")
+            op, tex = _spectrum_or_texture(p, ("opacity",), (0.5, 0.5, 0.5))
+            ni = self.bsdf(inner[0][1])
+            if self.bsdfs[ni]["type"] == S.BSDF_MASK:
+                raise SceneError("mask: a mask nested in a mask is not supported")
+            rec = S.make_bsdf(S.BSDF_MASK, reflectance=op or (0.5, 0.5, 0.5), nested=ni)
+        elif t == "diffuse":
             refl, tex = _spectrum_or_texture(p, ("reflectance", "diffuseReflectance"), (0.5, 0.5, 0.5))
             rec = S.make_bsdf(S.BSDF_DIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), twosided=twosided)
         elif t == "difftrans":
@@ -547,7 +558,7 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, thindielectric, twosided)")
+                             "roughdielectric, difftrans, roughplastic, thindielectric, mask, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -943,6 +954,8 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="conductor">{cond}</bsdf>'
         elif t == S.BSDF_DIELECTRIC:
             inner = f'<bsdf type="dielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_MASK:
+            inner = f'<bsdf type="mask">{diffuse_param("opacity")}<ref id="bsdf{b["distr"]}"/></bsdf>'
         elif t == S.BSDF_THINDIELECTRIC:
             inner = f'<bsdf type="thindielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
         elif t == S.BSDF_ROUGHDIELECTRIC:

@@ -775,7 +775,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC; }
@@ -1328,13 +1328,19 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
     return w;
 }
+typedef struct { mat_t inner; int masked; v3 opacity; float prob; } smat_t;       /* a hit's material with its textures evaluated and a `mask` wrapper resolved (below) */
+static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
+static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo);
+static float sm_pdf(const smat_t *sm, v3 wi, v3 wo);
+static v3 sm_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp);
 void orc_bsdf_sample(const orc_scene *s, uint32_t mi, const float *wi, float u, float v, float *o) {
-    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; v3 w = bsdf_sample(&s->materials[mi].m, V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta, NULL);
+    v3 wo = V(0, 0, 0); float pdf = 0, eta = 0; int delta; const smat_t sm = resolve_material(s, mi, NULL, 0, V(0, 0, 0), NULL, NULL); v3 w = sm_sample(&sm, V(wi[0], wi[1], wi[2]), u, v, &wo, &pdf, &eta, &delta, NULL);
     o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = pdf; o[4] = wo.x; o[5] = wo.y; o[6] = wo.z; o[7] = eta;
 }
 void orc_bsdf_eval(const orc_scene *s, uint32_t mi, const float *wi, const float *wo, float *o) {
-    v3 e = bsdf_eval(&s->materials[mi].m, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
-    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = bsdf_pdf(&s->materials[mi].m, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
+    const smat_t sm = resolve_material(s, mi, NULL, 0, V(0, 0, 0), NULL, NULL);
+    v3 e = sm_eval(&sm, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
+    o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = sm_pdf(&sm, V(wi[0], wi[1], wi[2]), V(wo[0], wo[1], wo[2]));
 }
 
 /* ------------------------------------------------------------------------------------------------ environment emitter */
@@ -1730,6 +1736,41 @@ static v3 texture_eval(const orc_scene *s, const orc_texture *t, float u, float 
     }
     return first ? V(t->color0[0], t->color0[1], t->color0[2]) : V(t->color1[0], t->color1[1], t->color1[2]);
 }
+/* ---- mask: src/bsdfs/mask.cpp:104-229.  A material record of type 9 puts an opacity (its `reflectance`, constant or textured) in front of the nested material
+ * record `distr`: eval = nested * opacity, pdf = nested * luminance(opacity); sample picks the nested BSDF with probability prob = luminance(opacity) (sample.x
+ * rescaled) or passes straight through (wo = -wi, an ENull component: the path stays "unscattered").  Its component list holds EBackSide -> refN = 0. */
+static void apply_texture(const orc_scene *s, mat_t *m, const hit_t *its, const float *partials_or_null, int want_partials, v3 o, const v3 *rxd, const v3 *ryd) {
+    uint32_t tex = (m->m.flags >> 8) & 0xFFFFu; if (!tex) return;
+    float pa[4]; const float *partials = partials_or_null;
+    if (want_partials && s->textures[tex - 1].type == 2) { compute_partials(its, o, *rxd, *ryd, &pa[0], &pa[1], &pa[2], &pa[3]); partials = pa; }
+    v3 c = texture_eval(s, &s->textures[tex - 1], its->uvx, its->uvy, partials); m->m.reflectance[0] = c.x; m->m.reflectance[1] = c.y; m->m.reflectance[2] = c.z;
+}
+static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd) {
+    smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.opacity = V(1, 1, 1); sm.prob = 1.0f;
+    if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    if (sm.inner.m.type == BSDF_MASK) {
+        sm.masked = 1; sm.opacity = V(sm.inner.m.reflectance[0], sm.inner.m.reflectance[1], sm.inner.m.reflectance[2]); sm.prob = luminance(sm.opacity);
+        sm.inner = s->materials[sm.inner.m.distr];
+        if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    }
+    return sm;
+}
+static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo) { v3 e = bsdf_eval(&sm->inner.m, wi, wo); return sm->masked ? mul(e, sm->opacity) : e; }
+static float sm_pdf(const smat_t *sm, v3 wi, v3 wo) { float p = bsdf_pdf(&sm->inner.m, wi, wo); return sm->masked ? p * sm->prob : p; }
+static v3 sm_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
+    if (!sm->masked) return bsdf_sample(&sm->inner.m, wi, u, v, wo, pdf, eta, delta, sp);
+    if (u < sm->prob) {                                                  /* mask.cpp:196-201 */
+        u /= sm->prob;
+        v3 w = bsdf_sample(&sm->inner.m, wi, u, v, wo, pdf, eta, delta, sp);
+        v3 r = V(w.x * sm->opacity.x / sm->prob, w.y * sm->opacity.y / sm->prob, w.z * sm->opacity.z / sm->prob);
+        *pdf *= sm->prob; return r;
+    }
+    *wo = neg(wi); *eta = 1.0f; *delta = 2; *pdf = 1 - sm->prob;       /* :202-208 */
+    return V((1.0f - sm->opacity.x) / *pdf, (1.0f - sm->opacity.y) / *pdf, (1.0f - sm->opacity.z) / *pdf);
+}
+static int sm_is_smooth(const smat_t *sm) { return material_is_smooth(&sm->inner.m); }
+static int sm_has_backside(const smat_t *sm) { return sm->masked || material_has_backside(&sm->inner.m); }
+
 /* envmap.cpp:384-416 evalEnvironment WITH ray differentials (the sensor ray, path.cpp:139-141): texture-space partials, then TMIPMap::eval over the
  * map's pyramid (input data; record s->d.env_texture - 1 of the texture table) */
 static v3 env_eval_filtered(const orc_scene *s, v3 d, v3 rxd, v3 ryd) {
@@ -1760,27 +1801,23 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
                 Li = add(Li, mul(throughput, (s->d.env_texture && !s->env_constant && depth == 1 && !scattered) ? env_eval_filtered(s, d, *rxd, *ryd) : env_eval(s, d)));
             break;
         }
-        mat_t bsdf_local = s->materials[its.material];        /* textured reflectance: evaluated at the hit's uv (diffuse.cpp:112-121: m_reflectance->eval(bRec.its)) */
-        { uint32_t tex = (bsdf_local.m.flags >> 8) & 0xFFFFu;
-          float pa[4]; const float *partials = NULL;            /* its.getBSDF(ray) -> computePartials: only the camera ray carries differentials (records.inl:68-75) */
-          if (tex && depth == 1 && !scattered && s->textures[tex - 1].type == 2) { compute_partials(&its, o, *rxd, *ryd, &pa[0], &pa[1], &pa[2], &pa[3]); partials = pa; }
-          if (tex) { v3 c = texture_eval(s, &s->textures[tex - 1], its.uvx, its.uvy, partials); bsdf_local.m.reflectance[0] = c.x; bsdf_local.m.reflectance[1] = c.y; bsdf_local.m.reflectance[2] = c.z; } }
-        const orc_material *bsdf = &bsdf_local.m;
+        /* its.getBSDF(ray) -> computePartials: only the camera ray carries differentials (records.inl:68-75); textured parameters are evaluated at the hit's uv */
+        const smat_t smat = resolve_material(s, its.material, &its, depth == 1 && !scattered, o, rxd, ryd); const smat_t *bsdf = &smat;
         if (its.emitter >= 0 && emitted_radiance && (!hide || scattered))
             Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
         if ((depth >= maxDepth && maxDepth > 0) || (strict && dot(d, its.ng) * its.wi.z >= 0)) break;
 
         /* direct illumination sampling (path.cpp:172-200), only for BSDFs with a smooth component */
-        v3 refN = material_has_backside(bsdf) ? V(0, 0, 0) : its.ns;      /* records.inl:160-164 */
+        v3 refN = sm_has_backside(bsdf) ? V(0, 0, 0) : its.ns;      /* records.inl:160-164 */
         direct_t dRec; memset(&dRec, 0, sizeof(dRec)); dRec.ref = its.p;
-        if (material_is_smooth(bsdf)) {
+        if (sm_is_smooth(bsdf)) {
             float sx, sy; next2D(sp, &sx, &sy);
             v3 value = sample_emitter_direct(s, its.p, refN, sx, sy, &dRec, 1, &counters[1]);
             if (!is_zero(value)) {
                 v3 wo = to_local(&its, dRec.d);
-                v3 bsdfVal = bsdf_eval(bsdf, its.wi, wo);
+                v3 bsdfVal = sm_eval(bsdf, its.wi, wo);
                 if (!is_zero(bsdfVal) && (!strict || dot(its.ng, dRec.d) * wo.z > 0)) {
-                    float bsdfPdf = dRec.delta ? 0.0f : bsdf_pdf(bsdf, its.wi, wo);   /* emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192) */
+                    float bsdfPdf = dRec.delta ? 0.0f : sm_pdf(bsdf, its.wi, wo);   /* emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192) */
                     float weight = mi_weight(dRec.pdf, bsdfPdf);
                     Li = add(Li, scale(mul(mul(throughput, value), bsdfVal), weight));
                 }
@@ -1790,7 +1827,7 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
         float bsdfPdf = 0, bEta = 1; v3 woL = V(0, 0, 0);
         float sx, sy; next2D(sp, &sx, &sy);
         int sampledDelta = 0;
-        v3 bsdfWeight = bsdf_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta, sp);
+        v3 bsdfWeight = sm_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta, sp);
         if (is_zero(bsdfWeight)) break;
         scattered |= sampledDelta != 2;                  /* path.cpp:213: scattered |= bRec.sampledType != BSDF::ENull */
         v3 wo = to_world(&its, woL);

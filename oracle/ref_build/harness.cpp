@@ -231,6 +231,11 @@ static Built buildScene(const FScene &fs) {
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 9) {           // mask: opacity in refl (or the bound texture), nested BSDF = an EARLIER record (index in distr)
+            Properties p("mask"); p.setSpectrum("opacity", rgb(fb.refl));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+            if (fb.distr >= bsdfs.size()) { fprintf(stderr, "mask: the nested material must precede it\n"); _exit(2); }
+            bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
         } else if (fb.type == 8) {
             Properties p("thindielectric");
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
@@ -272,7 +277,7 @@ static Built buildScene(const FScene &fs) {
               tp.setFloat("uoffset", ft.uoffset); tp.setFloat("voffset", ft.voffset); tp.setFloat("uscale", ft.uscale); tp.setFloat("vscale", ft.vscale);
               ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp)); tex->configure();
               // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance or difftrans.transmittance (the material record's `reflectance`)
-              bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : "reflectance", tex); tex->setParent(bsdf);
+              bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : fb.type == 9 ? "opacity" : "reflectance", tex); tex->setParent(bsdf);
           } }
         bsdf->configure();
         if (fb.twosided) {

@@ -678,3 +678,31 @@ def test_thin_dielectric(mi, oracle, golden_scenes, name):
     # hideEmitters changes what is seen THROUGH the pane: the sky disappears there too
     other = mi.Render(gs, hide_emitters=not sc.hide_emitters); other.run()
     assert np.linalg.norm(other.read_film(0)[..., :3] - film[..., :3]) / np.linalg.norm(film[..., :3]) > 0.05
+
+
+@pytest.mark.parametrize("name", ["masked_room", "masked_room_hide_indep"])
+def test_mask(mi, oracle, golden_scenes, name):
+    """`mask` (src/bsdfs/mask.cpp) -- an opacity (checkerboard / grid texture, coloured constant) in front of a nested material record: eval and
+    pdf scaled by opacity / its luminance, the nested BSDF or a straight pass-through (ENull: the path stays unscattered, hideEmitters keeps hiding the sky
+    through the holes) chosen by sample.x, which is rescaled for the nested sampler.  Diffuse / plastic nested BSDFs are libm-free -> bit-exact; the grille's
+    rough conductor is tolerance-pinned."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(14); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (bits(got) == bits(ref)).all(1).mean() > 0.9 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0, ((bits(got) == bits(ref)).all(1).mean(), (err < 1e-4).mean())
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-4
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-4
+    # validation: a mask must point at an existing non-mask record
+    bad = type(sc)(sc); bad["bsdfs"] = [dict(b) for b in sc.bsdfs]
+    mi_ = [i for i, b in enumerate(sc.bsdfs) if b["type"] == mi.scenes.BSDF_MASK]
+    bad["bsdfs"][mi_[0]]["distr"] = mi_[1]
+    with pytest.raises(mi.MiError, match="nested material record"):
+        mi.Scene(bad)
