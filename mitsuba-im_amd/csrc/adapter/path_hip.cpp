@@ -103,9 +103,15 @@ int NestedReader::spatialTexture(const std::string &tcls) {
         // own code exactly as BitmapTexture's constructors do (2-lobed Lanczos, TMIPMap<Color3, Color3h>; :193-214, :363-401)
         rd.ms->readString(); t.filter = rd.ms->readUInt(); t.wrap_u = rd.ms->readUInt(); t.wrap_v = rd.ms->readUInt();
         Float gamma = rd.ms->readFloat(); t.max_anisotropy = rd.ms->readFloat(); std::string channel = rd.ms->readString();
-        if (!channel.empty()) SLog(EError, "path_hip: bitmap textures restricted to one channel are not implemented");
         size_t size = rd.ms->readSize(); ref<MemoryStream> img = new MemoryStream(size); rd.ms->copyTo(img, size); img->seek(0);
         ref<Bitmap> bitmap = new Bitmap(Bitmap::EAuto, img); if (gamma != 0) bitmap->setGamma(gamma);
+        if (!channel.empty()) {              // a texture from one channel of the image (bitmap.cpp:261-266, findChannel :303-321): a luminance pyramid
+            int found = -1;
+            for (int i = 0; i < bitmap->getChannelCount(); ++i) { std::string nm = bitmap->getChannelName(i); std::transform(nm.begin(), nm.end(), nm.begin(), ::tolower); if (nm == channel) found = i; }
+            if (found < 0) SLog(EError, "Channel \"%s\" not found!", channel.c_str());
+            bitmap = bitmap->extractChannel(found);
+            if (channel == "a") bitmap->setGamma(1.0f);
+        }
         Properties rp("lanczos"); rp.setInteger("lobes", 2);
         ref<ReconstructionFilter> rf = static_cast<ReconstructionFilter *>(PluginManager::getInstance()->createObject(MTS_CLASS(ReconstructionFilter), rp)); rf->configure();
         typedef TSpectrum<Float, 3> Color3; typedef TSpectrum<half, 3> Color3h; typedef TSpectrum<Float, 1> Color1; typedef TSpectrum<half, 1> Color1h;

@@ -327,8 +327,9 @@ def self_resolve(reader, filename):
 
 
 # ---- image files for environment maps ----------------------------------------------------------------------------------------------
-def load_image(path):
-    """RGB float image [h, w, 3] from .npy, .pfm or Radiance .hdr (OpenEXR needs a library the image does not have)."""
+def load_image(path, channel=""):
+    """RGB float image [h, w, 3] from .npy, .pfm or Radiance .hdr (OpenEXR needs a library the image does not have).  `channel` ("r", "g", "b", "a" / "y"):
+    that channel alone, as a grey image (BitmapTexture's `channel` parameter, src/textures/bitmap.cpp:261-266; .npy files may hold 2 or 4 channels)."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".npy":
         a = np.load(path).astype(f32)
@@ -343,8 +344,13 @@ def load_image(path):
         raise SceneError(f"image format of \"{os.path.basename(path)}\" is not readable here (supported: .npy, .pfm, .hdr)")
     if a.ndim == 2:
         a = a[:, :, None]
-    if a.shape[2] == 1:
-        a = np.repeat(a, 3, axis=2)
+    if channel:
+        names = {1: "y", 2: "ya", 3: "rgb", 4: "rgba"}.get(a.shape[2], "")
+        if channel not in names:
+            raise SceneError(f"Channel \"{channel}\" not found! Must be one of: [{', '.join(names)}]")
+        a = a[:, :, names.index(channel):names.index(channel) + 1]
+    if a.shape[2] in (1, 2):
+        a = np.repeat(a[:, :, :1], 3, axis=2)
     return np.ascontiguousarray(a[:, :, :3], f32)
 
 
@@ -457,14 +463,14 @@ class _SceneBuilder:
             if wu not in wrap or wv not in wrap or ft not in filt:
                 raise SceneError("bitmap: unknown wrapMode / filterType")
             base = None
+            if path.endswith(".npz") and t.get("channel", "") != "":
+                raise SceneError("bitmap: 'channel' needs the image, not a precomputed pyramid")
             if path.endswith(".npz"):                    # a precomputed pyramid (base / sizes / texels, see scenes.load_texture_pyramid)
                 d = np.load(path); levels = []; off = 0; base = d["base"] if "base" in d.files else None
                 for w, h in d["sizes"]:
                     n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
             else:                                        # an image: the pyramid as TMIPMap builds it (bitmap.cpp:363-401: 2-lobed Lanczos, values clamped to [0, 1])
-                base = load_image(path); levels = S.build_mip_pyramid(base, wrap[wu], wrap[wv], 1.0)
-            if t.get("channel", "") != "":
-                raise SceneError("bitmap: 'channel' selection is not supported")
+                base = load_image(path, channel=str(t.get("channel", "")).lower()); levels = S.build_mip_pyramid(base, wrap[wu], wrap[wv], 1.0)
             t.get("gamma", 0.0); t.get("cache", True)
             uvs = t.get("uvscale", 1.0)
             rec = S.make_texture(S.TEXTURE_BITMAP, uoffset=t.get("uoffset", 0.0), voffset=t.get("voffset", 0.0), uscale=t.get("uscale", uvs), vscale=t.get("vscale", uvs),

@@ -238,3 +238,23 @@ def test_sampler_override(tmp_path):
     assert sc.sampler == S.SAMPLER_SOBOL and sc.spp == 64
     with pytest.raises(X.SceneError, match="override"):
         load_text(tmp_path, text, sampler="halton")
+
+
+def test_mask_with_alpha_channel_texture(tmp_path):
+    """The classic leaf card: <bsdf type="mask"> whose opacity is the alpha channel of an image (BitmapTexture `channel`, bitmap.cpp:261-266) over a twosided diffuse."""
+    rgba = np.zeros((8, 8, 4), np.float32); rgba[..., :3] = (0.2, 0.6, 0.1); rgba[2:6, 2:6, 3] = 1.0
+    np.save(tmp_path / "leaf.npy", rgba)
+    body = ('<shape type="rectangle"><bsdf type="mask"><texture type="bitmap" name="opacity"><string name="filename" value="leaf.npy"/><string name="channel" value="a"/>'
+            '<string name="filterType" value="nearest"/><string name="wrapMode" value="clamp"/></texture>'
+            '<bsdf type="twosided"><bsdf type="diffuse"><rgb name="reflectance" value="0.2, 0.6, 0.1"/></bsdf></bsdf></bsdf></shape>')
+    body = body.replace('<shape type="rectangle">', '<shape type="cube">')       # (textured materials go on meshes: analytic shapes take constants)
+    sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
+    mask = sc.bsdfs[sc.shapes[0]["bsdf"]]
+    assert mask["type"] == S.BSDF_MASK and mask["texture"] == 0 and sc.bsdfs[mask["distr"]]["type"] == S.BSDF_DIFFUSE and sc.bsdfs[mask["distr"]]["twosided"] == 1
+    t = sc.textures[0]
+    assert t["type"] == S.TEXTURE_BITMAP and t["filter"] == S.MIP_NEAREST and t["wrap_u"] == S.WRAP_CLAMP and t["n_levels"] == 1
+    lvl0 = sc.texture_texels[:8 * 8 * 3].reshape(8, 8, 3)
+    np.testing.assert_array_equal(lvl0[..., 0], rgba[..., 3]); np.testing.assert_array_equal(lvl0[..., 1], rgba[..., 3])
+    assert t["color0"] == pytest.approx((0.25, 0.25, 0.25))                  # the average opacity (16 of 64 texels)
+    with pytest.raises(X.SceneError, match='Channel "q" not found'):
+        load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body.replace('value="a"', 'value="q"')))
