@@ -357,6 +357,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     ensureSobolTables();
     s->h.commitHost();
     if (s->h.bvhDepth > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
+    if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "[mi355pt] %zu triangles, %zu analytic shapes, %zu instances, %zu BVH nodes, depth %d\n", s->h.idx.size() / 3, s->h.analytic.size(), s->h.instances.size(), s->h.nodes.size(), s->h.bvhDepth);
     int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
     if ((int) device >= devCount) return fail(MI_ERR_DEVICE, "mi_scene_commit: no such HIP device");
     if (s->h.upload((int) device)) return fail(MI_ERR_DEVICE, std::string("mi_scene_commit: upload failed: ") + hipGetErrorString(hipGetLastError()));

@@ -9,6 +9,7 @@
 // one LDS exchange per 256-path chunk, no global atomics, fully coalesced queue reads/writes, and a workgroup re-reads what
 // it (= the same XCD's L2 under round-robin dispatch) wrote in the previous stage.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pt_device.h"
 #include "queues.h"
 
@@ -659,7 +660,11 @@ void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, const AnalyticD 
 #define MI_BY_STACK(KERNEL, AN, ...) do { \
     if (sc.packet_n) hipLaunchKernelGGL((KERNEL<0, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 8) hipLaunchKernelGGL((KERNEL<8, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 12) hipLaunchKernelGGL((KERNEL<12, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((KERNEL<16, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 20 && !getenv("MI355PT_STACK24")) hipLaunchKernelGGL((KERNEL<20, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 24) hipLaunchKernelGGL((KERNEL<24, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 28) hipLaunchKernelGGL((KERNEL<28, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
 void MI_FN(mi_launch_extend)(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     if (sc.n_analytic || sc.n_instances) MI_BY_STACK(k_extend, true, sc, q, buf); else MI_BY_STACK(k_extend, false, sc, q, buf);
