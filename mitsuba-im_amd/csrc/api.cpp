@@ -335,8 +335,6 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     for (const mi_shape &sh : s->h.shapes)         // TriMesh::computeUVTangents (trimesh.cpp:683-692): an anisotropic BSDF takes its tangent from the texture coordinates
         if (sh.bsdf >= 0 && (size_t) sh.bsdf < s->h.materials.size() && (s->h.materials[sh.bsdf].flags & MI_BSDF_FLAG_ANISOTROPIC) && !((sh.flags & 2u) && !s->h.uv.empty()))
             return fail(MI_ERR_INVALID, "computeUVTangents(): texture coordinates are required to generate tangent vectors. If you want to render with an anisotropic material, please make sure that all associated shapes have valid texture coordinates.");
-    for (const mi_analytic &a : s->h.analytic) if (a.bsdf >= 0 && (size_t) a.bsdf < s->h.materials.size() && ((s->h.materials[a.bsdf].flags >> 8) & 0xFFFFu))
-        return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textured materials on analytic shapes are not implemented");
     for (const mi_material &m : s->h.materials)
         if (m.type == MI_BSDF_ROUGHPLASTIC && (m.k[2] < 2 || m.k[1] < 0 || (size_t) m.k[1] + (size_t) m.k[2] > s->h.materialTables.size()))
             return fail(MI_ERR_INVALID, "mi_scene_commit: roughplastic material without its rough-transmittance slice (mi_scene_set_material_tables)");

@@ -418,18 +418,22 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     const uint32_t tex = (mm.flags >> 8) & 0xFFFFu;
                     if (tex) {
                         const TextureD &tx = sc.textures[tex - 1]; v3 c;
+                        float huvx = h.uvx, huvy = h.uvy;
+                        const bool onAnalytic = AN && inst < 0 && prim >= sc.n_tris;         // an analytic shape: its own parameterisation, evaluated on demand
+                        if (onAnalytic) { v3 du, dv; analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, ro3 + d * hr.x, huvx, huvy, du, dv); }   // (tangents: recomputed below where a filtered lookup needs them)
                         if (tx.type == 2u) {                                 // BitmapTexture::eval (src/textures/bitmap.cpp:434-502) under Texture2D::eval (texture.cpp:112-121)
-                            const float uvx = h.uvx * tx.uscale + tx.uoffset, uvy = h.uvy * tx.vscale + tx.voffset;
+                            const float uvx = huvx * tx.uscale + tx.uoffset, uvy = huvy * tx.vscale + tx.voffset;
                             if (depth == 1) {                                // its.getBSDF(ray) -> computePartials: only the camera ray carries differentials (records.inl:68-75)
                                 v3 dpdu, dpdv;
-                                if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
+                                if (onAnalytic) { float tu_, tv_; analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, ro3 + d * hr.x, tu_, tv_, dpdu, dpdv); }
+                                else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
                                 else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                                 if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
                                 const float2 sp = q.pos[pid]; v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
                                 float pa[4]; computePartials(h.p, h.ng, dpdu, dpdv, ro3, rxd, ryd, pa);
                                 c = mipEval(sc, tx, uvx, uvy, pa[0] * tx.uscale, pa[1] * tx.vscale, pa[2] * tx.uscale, pa[3] * tx.vscale);
                             } else c = tx.filter != 0u ? mipBilinear(sc, tx, 0, uvx, uvy) : mipBox(sc, tx, 0, uvx, uvy);
-                        } else c = textureEval(tx, h.uvx, h.uvy);
+                        } else c = textureEval(tx, huvx, huvy);
                         mm.reflectance[0] = c.x; mm.reflectance[1] = c.y; mm.reflectance[2] = c.z;
                     }
                 }

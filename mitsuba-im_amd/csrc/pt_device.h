@@ -509,6 +509,34 @@ DEV bool analyticIntersect(const AnalyticD &sh, v3 o, v3 d, float mint, float ma
     else return false;
     u = 0; v = 0; return true;
 }
+// its.uv / its.dpdu / its.dpdv of an analytic hit (rectangle.cpp:161-163, disk.cpp:173-193, sphere.cpp:218-245, cylinder.cpp:204-216): textures need them, so they
+// are evaluated on demand in the texture block of k_shade.  (lx, ly): the hit's local coordinates as stored by the intersection routine; pRay = ray(t)
+DEV void analyticUV(const AnalyticD &sh, float lx, float ly, v3 pRay, float &uvx, float &uvy, v3 &dpdu, v3 &dpdv) {
+    const uint32_t type = sh.type;
+    if (type == MI_SHAPE_RECTANGLE) { uvx = 0.5f * (lx + 1); uvy = 0.5f * (ly + 1); dpdu = ld3(sh.dpdu); dpdv = xfVector(sh.to_world, V(0, 2, 0)); }
+    else if (type == MI_SHAPE_DISK) {
+        float r = sqrtf(lx * lx + ly * ly), invR = (r == 0) ? 0.0f : (1.0f / r);
+        float phi = atan2f(ly, lx); if (phi < 0) phi += 2 * MI_PI;
+        float cosPhi = lx * invR, sinPhi = ly * invR;
+        if (r != 0) { dpdu = xfVector(sh.to_world, V(cosPhi, sinPhi, 0)); dpdv = xfVector(sh.to_world, V(-sinPhi, cosPhi, 0)); }
+        else { dpdu = xfVector(sh.to_world, V(1, 0, 0)); dpdv = xfVector(sh.to_world, V(0, 1, 0)); }
+        uvx = r; uvy = phi * MI_INV_TWOPI;
+    } else if (type == MI_SHAPE_SPHERE) {
+        const v3 c = ld3(sh.center); v3 p = c + normalize(pRay - c) * sh.radius;
+        v3 local = xfVector(sh.to_object, p - c);
+        float theta = acosf(minf(1.0f, maxf(-1.0f, local.z / sh.radius))), phi = atan2f(local.y, local.x); if (phi < 0) phi += 2 * MI_PI;
+        uvx = phi * (0.5f * MI_INV_PI); uvy = theta * MI_INV_PI;
+        dpdu = xfVector(sh.to_world, V(-local.y, local.x, 0) * (2 * MI_PI));
+        float zrad = sqrtf(local.x * local.x + local.y * local.y), cosPhi = 0, sinPhi = 1;
+        if (zrad > 0) { float inv = 1.0f / zrad; cosPhi = local.x * inv; sinPhi = local.y * inv; }
+        dpdv = xfVector(sh.to_world, V(local.z * cosPhi, local.z * sinPhi, -sinf(theta) * sh.radius) * MI_PI);
+    } else {
+        v3 local = xfPoint(sh.to_object, pRay);
+        float phi = atan2f(local.y, local.x); if (phi < 0) phi += 2 * MI_PI;
+        uvx = phi / (2 * MI_PI); uvy = local.z / sh.length;
+        dpdu = xfVector(sh.to_world, V(-local.y, local.x, 0) * (2 * MI_PI)); dpdv = xfVector(sh.to_world, V(0, 0, sh.length));
+    }
+}
 // Shape::fillIntersectionRecord (rectangle.cpp:155-168, disk.cpp:172-200, sphere.cpp:196-245, cylinder.cpp:203-233) + computeShadingFrame
 // + wi (skdtree.h:421-427).  Disk: the reference leaves geoFrame unset; defined as the shading normal.
 DEV void fillHitAnalytic(const AnalyticD &sh, v3 o, v3 d, float t, float lx, float ly, Hit &h) {

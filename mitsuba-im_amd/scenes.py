@@ -409,6 +409,41 @@ def cbox_shapes(width=256, height=256, spp=16, sampler=SAMPLER_SOBOL, max_depth=
                         filter_kind, seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_shapes", analytic=b.resolve_analytic())
 
 
+def textured_shapes(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0):
+    """Textures on ANALYTIC shapes through their own parameterisations (rectangle.cpp:163, disk.cpp:193, sphere.cpp:225-226, cylinder.cpp:209-210): a
+    checkerboard `rectangle` floor, a grid-textured `plastic` sphere, a bitmap-textured (EWA) cylinder with a checkerboard `disk` lid, a `mask`ed
+    rectangle screen; mesh walls and the rectangle light of `cbox_shapes`."""
+    b = _Builder()
+    white = b.bsdf(reflectance=(0.725, 0.71, 0.68)); red = b.bsdf(reflectance=(0.63, 0.065, 0.05)); green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
+    lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78))
+    pyr = load_texture_pyramid()
+    tex = [make_texture(TEXTURE_CHECKERBOARD, (0.8, 0.75, 0.6), (0.15, 0.2, 0.3), uscale=8.0, vscale=8.0),
+           make_texture(TEXTURE_GRID, (0.2, 0.55, 0.7), (0.95, 0.9, 0.2), line_width=0.07, uscale=10.0, vscale=5.0),
+           make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=4.0, vscale=2.0, filter_type=MIP_EWA),
+           make_texture(TEXTURE_CHECKERBOARD, (0.9, 0.3, 0.2), (0.1, 0.1, 0.1), uscale=3.0, vscale=6.0, uoffset=0.2),
+           make_texture(TEXTURE_CHECKERBOARD, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), uscale=6.0, vscale=6.0)]
+    floor = b.bsdf(reflectance=(0.5, 0.5, 0.5)); b.bsdfs[floor]["texture"] = 0
+    ball = b.bsdf(kind=BSDF_PLASTIC, ior=1.49, specular=(0.9, 0.9, 0.9)); b.bsdfs[ball]["texture"] = 1
+    tube = b.bsdf(reflectance=(0.5, 0.5, 0.5), twosided=True); b.bsdfs[tube]["texture"] = 2
+    lid = b.bsdf(reflectance=(0.5, 0.5, 0.5), twosided=True); b.bsdfs[lid]["texture"] = 3
+    blue2 = b.bsdf(reflectance=(0.15, 0.25, 0.7), twosided=True)
+    screen = b.bsdf(kind=BSDF_MASK, nested=blue2); b.bsdfs[screen]["texture"] = 4
+    b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)
+    b.begin(); b.quad([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]); b.end(white)
+    b.begin(); b.quad([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]); b.end(green)
+    b.begin(); b.quad([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]); b.end(red)
+    b.add_analytic(SHAPE_RECTANGLE, translate(278, 548.3, 279.5) @ rotate((1, 0, 0), 90) @ scale(65, 52.5, 1), lightm, radiance=(17.0, 12.0, 4.0))
+    b.add_analytic(SHAPE_RECTANGLE, translate(278, 0, 279.6) @ rotate((1, 0, 0), -90) @ scale(278, 279.6, 1), floor)                 # the floor: +y
+    b.add_analytic(SHAPE_SPHERE, translate(150, 90, 170) @ rotate((0.3, 1, 0.2), 35), ball, radius=90.0)
+    m, length = cylinder_to_world((370, 0, 380), (370, 260, 380))
+    b.add_analytic(SHAPE_CYLINDER, m, tube, radius=80.0, length=length)
+    b.add_analytic(SHAPE_DISK, translate(370, 260, 380) @ rotate((1, 0, 0), -90) @ scale(80), lid)
+    b.add_analytic(SHAPE_RECTANGLE, translate(300, 150, 60) @ rotate((0, 1, 0), 20) @ scale(120, 110, 1), screen)
+    cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, name="textured_shapes", analytic=b.resolve_analytic(), textures=tex)
+
+
 def cbox_materials(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=10, rr_depth=5, seed=0, strict_normals=False, hide_emitters=False):
     """Cornell room with the smooth BSDF family: glass `dielectric` sphere, gold smooth `conductor` sphere, `plastic` tall
     block, nonlinear `plastic` floor, a `twosided(conductor)` mirror sheet; the usual ceiling quad light."""

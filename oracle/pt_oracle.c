@@ -421,6 +421,42 @@ static void analytic_fill(const analytic_t *sh, v3 o, v3 d, float t, float lx, f
     }
     }
 }
+#ifndef INV_TWOPI
+#define INV_TWOPI 0.15915494309189533577f
+#endif
+/* its.uv / its.dpdu / its.dpdv of an analytic hit (rectangle.cpp:161-163, disk.cpp:173-193, sphere.cpp:218-245, cylinder.cpp:204-216): needed by textures
+ * only, so evaluated on demand.  (lx, ly) = the hit's local coordinates as the intersection routine stored them (rectangle, disk); p_ray = ray(t) */
+static void analytic_uv(const analytic_t *sh, float lx, float ly, v3 p_ray, float *uvx, float *uvy, v3 *dpdu, v3 *dpdv) {
+    switch (sh->a.type) {
+    case SH_RECTANGLE: *uvx = 0.5f * (lx + 1); *uvy = 0.5f * (ly + 1); *dpdu = sh->dpdu; *dpdv = xf_vector(sh->a.to_world, V(0, 2, 0)); break;
+    case SH_DISK: {
+        float r = sqrtf(lx * lx + ly * ly), invR = (r == 0) ? 0.0f : (1.0f / r);
+        float phi = atan2f(ly, lx); if (phi < 0) phi += 2 * M_PI_F;
+        float cosPhi = lx * invR, sinPhi = ly * invR;
+        if (r != 0) { *dpdu = xf_vector(sh->a.to_world, V(cosPhi, sinPhi, 0)); *dpdv = xf_vector(sh->a.to_world, V(-sinPhi, cosPhi, 0)); }
+        else { *dpdu = xf_vector(sh->a.to_world, V(1, 0, 0)); *dpdv = xf_vector(sh->a.to_world, V(0, 1, 0)); }
+        *uvx = r; *uvy = phi * INV_TWOPI; break;
+    }
+    case SH_SPHERE: {
+        v3 p = add(sh->center, scale(normalize(sub(p_ray, sh->center)), sh->a.radius));
+        v3 local = xf_vector(sh->a.to_object, sub(p, sh->center));
+        float theta = acosf(minf(1.0f, maxf(-1.0f, local.z / sh->a.radius))), phi = atan2f(local.y, local.x); if (phi < 0) phi += 2 * M_PI_F;
+        *uvx = phi * (0.5f * INV_PI); *uvy = theta * INV_PI;
+        *dpdu = xf_vector(sh->a.to_world, scale(V(-local.y, local.x, 0), 2 * M_PI_F));
+        float zrad = sqrtf(local.x * local.x + local.y * local.y), cosPhi = 0, sinPhi = 1;
+        if (zrad > 0) { float inv = 1.0f / zrad; cosPhi = local.x * inv; sinPhi = local.y * inv; }
+        *dpdv = xf_vector(sh->a.to_world, scale(V(local.z * cosPhi, local.z * sinPhi, -sinf(theta) * sh->a.radius), M_PI_F));
+        break;
+    }
+    default: {
+        v3 local = xf_point(sh->a.to_object, p_ray);
+        float phi = atan2f(local.y, local.x); if (phi < 0) phi += 2 * M_PI_F;
+        *uvx = phi / (2 * M_PI_F); *uvy = local.z / sh->a.length;
+        *dpdu = xf_vector(sh->a.to_world, scale(V(-local.y, local.x, 0), 2 * M_PI_F)); *dpdv = xf_vector(sh->a.to_world, V(0, 0, sh->a.length));
+        break;
+    }
+    }
+}
 /* Shape::samplePosition: rectangle.cpp:215-221, disk.cpp:252-260, cylinder.cpp:235-250 (sphere: see analytic_sample_direct) */
 static void analytic_sample_position(const analytic_t *sh, float sx, float sy, v3 *p, v3 *n) {
     switch (sh->a.type) {
@@ -655,8 +691,9 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     h->instance = inst;
     if (prim >= s->d.n_tris) {                       /* skdtree.h:421-427: shape->fillIntersectionRecord, computeShadingFrame, wi */
         const analytic_t *sh = &s->analytic[prim - s->d.n_tris]; v3 dpdu;
-        h->valid = 1; h->t = t; h->u = u; h->v = v; h->uvx = h->uvy = 0; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
+        h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
         analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu); h->dpdu = dpdu; h->dpdv = V(0, 0, 0);
+        { v3 du, dv; analytic_uv(sh, u, v, add(o, scale(d, t)), &h->uvx, &h->uvy, &du, &dv); h->dpdv = dv; }
         h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
         h->tt = cross(h->ns, h->s);
         v3 md = neg(d);

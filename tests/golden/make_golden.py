@@ -86,6 +86,8 @@ def golden_scenes():
         # mask: cut-out screen (checkerboard opacity), tinted half-transparent sheet over plastic, grid-masked rough conductor; ENull pass-through
         "masked_room": scenes.masked_room(width=96, height=64, spp=16),
         "masked_room_hide_indep": scenes.masked_room(width=96, height=64, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=12, hide_emitters=True, rr_depth=2),
+        # textures on analytic shapes (their own uv parameterisations): checkerboard rectangle, grid plastic sphere, bitmap cylinder, checkerboard disk, masked rectangle
+        "textured_shapes": scenes.textured_shapes(width=96, height=96, spp=16),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
@@ -116,7 +118,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)

@@ -706,3 +706,24 @@ def test_mask(mi, oracle, golden_scenes, name):
     bad["bsdfs"][mi_[0]]["distr"] = mi_[1]
     with pytest.raises(mi.MiError, match="nested material record"):
         mi.Scene(bad)
+
+
+def test_textures_on_analytic_shapes(mi, oracle, golden_scenes):
+    """Textures on analytic shapes through the shapes' own (u, v) parameterisations and tangents (rectangle.cpp:161-163, disk.cpp:173-193, sphere.cpp:218-245,
+    cylinder.cpp:204-216), evaluated on demand in the texture block of k_shade: checkerboard rectangle floor, grid-textured plastic sphere, EWA-filtered bitmap on
+    a cylinder (camera-hit footprints from the analytic dp/du, dp/dv), checkerboard disk, checkerboard-masked rectangle.  atan2 / acos of the parameterisations
+    come from the device math library -> tolerance-pinned; the reference's own samples and film next to it."""
+    name = "textured_shapes"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
+    rng = np.random.default_rng(41); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (err < 1e-5).mean() > 0.99 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6, ((err < 1e-5).mean(), (err < 1e-2).mean())
+    got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
+    assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6
+    r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-3
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -76,7 +76,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     elif name == "bitmap_room":
         # MIP-mapped bitmap textures: EWA / trilinear on the camera hit (ray differentials), level 0 afterwards; pyramid = the reference's own
         assert same_path.all() and same_vals.all() and err.max() < 2e-4 and np.median(err) < 1e-6
-    elif name.startswith("textured_plastics"):
+    elif name.startswith("textured_plastics") or name == "textured_shapes":
         # textures on plastic / roughplastic.diffuseReflectance and difftrans.transmittance: lobe weights from the texture's average, local value in the lobes
         assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.998 and err.max() < 1e-3 and np.median(err) < 1e-6
     elif name == "textured_room":
@@ -114,7 +114,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -134,7 +134,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
             assert np.allclose(h[1:4], row[4:7], atol=2e-3) and np.allclose(h[4:13], row[7:16], atol=3e-5 if h[20] >= 0 else 2e-5)
             assert np.allclose(h[15:18], row[18:21], atol=2e-5) and (h[19] == row[22] or h[20] >= 0)   # instanced hit: its.shape is the group member, not a scene shape
             assert h[19] >= len(sc.shapes) or h[18] == row[21]
-            if h[19] < len(sc.shapes) and h[20] < 0: assert np.allclose(h[21:23], row[16:18], atol=2e-5)            # its.uv (interpolated texcoords or barycentrics)      # analytic shapes leave Intersection::primIndex untouched in the reference
+            if h[20] < 0: assert np.allclose(h[21:23], row[16:18], atol=2e-5)            # its.uv (interpolated texcoords, barycentrics, or an analytic shape's own parameterisation)      # analytic shapes leave Intersection::primIndex untouched in the reference
             okb, hb = orc.intersect(ray, brute=True)
             assert okb and (hb.view(np.uint32) == h.view(np.uint32)).all()
     assert nhit > 20
@@ -193,7 +193,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep",
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes",
                                   "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""

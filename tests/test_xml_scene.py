@@ -15,7 +15,7 @@ X = importlib.import_module("mitsuba-im_amd.xml_scene")
 S = importlib.import_module("mitsuba-im_amd.scenes")
 
 GENERATORS = ["cornell_box", "cbox_shapes", "cbox_materials", "cbox_lights", "open_constant", "cbox_translucent", "cbox_roughplastic", "textured_room",
-              "shape_lights", "veach_mis", "veach_microfacets", "textured_plastics", "bitmap_room", "glass_pane", "masked_room"]
+              "shape_lights", "veach_mis", "veach_microfacets", "textured_plastics", "bitmap_room", "glass_pane", "masked_room", "textured_shapes"]
 
 
 def assert_same_scene(a, b, exact_analytic=False):
