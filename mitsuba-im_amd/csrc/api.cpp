@@ -412,9 +412,11 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
     if (p->sampler == MI_SAMPLER_SOBOL) {
         if (!s->h.d.sobol_m32) return fail(MI_ERR_INVALID, "mi_render_create: Sobol tables not loaded before mi_scene_commit (mi_set_sobol_tables)");
-        // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR) + the dim-4 skip (sobol.cpp:218-251 aborts beyond the table)
+        // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR, + 1 where a BSDF draws from the sampler itself: roughdielectric, EUsesSampler) + the dim-4 skip
+        // (sobol.cpp:218-251 aborts beyond the table)
         int depth = p->max_depth < 0 ? 250 : p->max_depth;
-        if (p->max_depth > 0 && (uint32_t) (3 + 5 * depth) > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "Lookup dimension exceeds the direction number table size! You may have to reduce the 'maxDepth' parameter of your integrator.");
+        int perBounce = 5; for (const mi_material &m : s->h.materials) if (m.type == MI_BSDF_ROUGHDIELECTRIC) perBounce = 6;
+        if (p->max_depth > 0 && (uint32_t) (3 + perBounce * depth) > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "Lookup dimension exceeds the direction number table size! You may have to reduce the 'maxDepth' parameter of your integrator.");
         if (p->max_depth < 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth = -1 with the Sobol sampler needs more dimensions than are loaded");
     }
     HIPCHK(hipSetDevice(s->h.device));
@@ -433,9 +435,10 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u)); r->k = p->fast_math ? &kFast : &kPrecise;
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
+        int perBounceDims = 5; for (const mi_material &m : s->h.materials) if (m.type == MI_BSDF_ROUGHDIELECTRIC) perBounceDims = 6;
         uint32_t sppBits = 0; while ((1ull << sppBits) < p->spp) ++sppBits;
         const uint32_t bits = (s->h.logRes > 1 ? 2 * s->h.logRes : 0) + sppBits + 1;
-        const uint32_t nibs = std::max<uint32_t>(1, (bits + 3) / 4), dims = std::min<uint32_t>(s->h.d.sobol_dims, (uint32_t) (4 + 5 * p->max_depth));
+        const uint32_t nibs = std::max<uint32_t>(1, (bits + 3) / 4), dims = std::min<uint32_t>(s->h.d.sobol_dims, (uint32_t) (4 + perBounceDims * p->max_depth));
         std::vector<uint32_t> nib((size_t) dims * nibs * 16);
         for (uint32_t dmn = 0; dmn < dims; ++dmn) for (uint32_t n = 0; n < nibs; ++n) for (uint32_t v = 0; v < 16; ++v) {
             uint32_t x = 0; for (uint32_t b = 0; b < 4; ++b) if (((v >> b) & 1u) && 4 * n + b < MI_SOBOL_SIZE) x ^= g_sobolM32[(size_t) dmn * MI_SOBOL_SIZE + 4 * n + b];

@@ -727,3 +727,14 @@ def test_textures_on_analytic_shapes(mi, oracle, golden_scenes):
     assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
+
+
+def test_sobol_dimension_budget_with_sampler_drawing_bsdfs(mi):
+    """A rough dielectric draws one more sampler value per bounce (EUsesSampler): the Sobol dimension budget and the staged lookup tables count 6 per bounce
+    then, so the reference's "Lookup dimension exceeds the direction number table size" arrives before a path could read past the tables."""
+    S = mi.scenes
+    gs = mi.Scene(S.cbox_translucent(width=32, height=32, spp=2, max_depth=20))
+    mi.Render(gs).run()                                             # 3 + 6 * 20 = 123 <= 128 loaded dimensions
+    with pytest.raises(mi.MiError, match="Lookup dimension exceeds"):
+        mi.Render(gs, max_depth=21)                                 # 129 > 128 (a diffuse-only scene may go to 25)
+    mi.Render(mi.Scene(S.cornell_box(32, 32, 2, max_depth=25))).run()
