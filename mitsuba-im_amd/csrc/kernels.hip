@@ -71,7 +71,7 @@ DEV float safeInv(float d) { float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) 
 // Instance::rayIntersect (src/shapes/instance.cpp:91-108): the ray is taken to the group's object space (direction NOT renormalised, so t keeps
 // its meaning), [mint, maxt] is clipped against the group's kd-tree box (skdtree.h:431-452), then the group's own BVH -- stored in the same
 // node array -- is walked with the same stack; a marker entry brings the walk back to the scene level.  Instances sit alone in their leaves.
-template <bool ANY, bool AN>
+template <bool ANY, int AN>        // AN bit 0: analytic shapes present, bit 1: instances present (each kernel variant carries only the code it needs)
 DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk,
                   float &bestT, uint32_t &bestPrim, float &bestU, float &bestV, int &bestInst) {
     v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
@@ -85,7 +85,7 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
     int sp = 0; int cur = 0;
 #define BVH_POP() do { \
         if (sp > 0) { --sp; cur = stk[sp * WG]; \
-            if (AN && cur == BVH_RET) { o = o0; d = d0; mint = mint0; cap = INFINITY; curInst = -1; \
+            if ((AN & 2) && cur == BVH_RET) { o = o0; d = d0; mint = mint0; cap = INFINITY; curInst = -1; \
                 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z)); oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z); \
                 if (sp > 0) { --sp; cur = stk[sp * WG]; } else cur = BVH_DONE; } \
         } else cur = BVH_DONE; } while (0)
@@ -94,7 +94,7 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
             f4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
             int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
             float t0, t1;
-            const float far = AN ? fminf(best, cap) : best;
+            const float far = (AN & 2) ? fminf(best, cap) : best;
             bool h0 = slab(n0, n1, inv, oi, mint, far, t0), h1 = slab(n2, n3, inv, oi, mint, far, t1);
             if (h0 && h1) {
                 bool swap = t1 < t0;
@@ -113,7 +113,7 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
                 TriAccelD ta; ta.k = __float_as_uint(a.x); ta.n_u = a.y; ta.n_v = a.z; ta.n_d = a.w;
                 ta.a_u = b.x; ta.a_v = b.y; ta.b_nu = b.z; ta.b_nv = b.w; ta.c_nu = c.x; ta.c_nv = c.y; ta.prim = __float_as_uint(c.z);
                 float u, v, t; bool ok;
-                if (AN && ta.k == MI_K_INSTANCE) {
+                if ((AN & 2) && ta.k == MI_K_INSTANCE) {
                     const InstanceD &in = sc.instances[ta.prim];
                     v3 o2 = xfPoint(in.to_object, o0), d2 = xfVector(in.to_object, d0);
                     float nearT, farT;
@@ -128,8 +128,8 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
                     }
                     break;                                                             // an instance is alone in its leaf
                 }
-                const float far = AN ? fminf(best, cap) : best;
-                if (AN && ta.k == MI_K_ANALYTIC) ok = analyticIntersect<ANY>(sc.analytic[ta.prim - sc.n_tris], o, d, mint, far, t, u, v);   // skdtree.h:292-301
+                const float far = (AN & 2) ? fminf(best, cap) : best;
+                if ((AN & 1) && ta.k == MI_K_ANALYTIC) ok = analyticIntersect<ANY>(sc.analytic[ta.prim - sc.n_tris], o, d, mint, far, t, u, v);   // skdtree.h:292-301
                 else ok = triIntersect(ta, o, d, mint, far, u, v, t);
                 if (ok) {
                     if (ANY) return true;
@@ -173,13 +173,13 @@ DEV bool packetLoop(uint32_t first, uint32_t last, v3 o, v3 d, float mint, float
     }
     return false;
 }
-template <bool ANY, bool AN>
+template <bool ANY, int AN>
 DEV bool packetIntersect(const DScene &sc, v3 o, v3 d, float mint, float maxt, float &bestT, uint32_t &bestPrim, float &bestU, float &bestV) {
     float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
     if (packetLoop<ANY, 0>(0, sc.packet_k[0], o, d, mint, best, bprim, bu, bv, found)) return true;
     if (packetLoop<ANY, 1>(sc.packet_k[0], sc.packet_k[1], o, d, mint, best, bprim, bu, bv, found)) return true;
     if (packetLoop<ANY, 2>(sc.packet_k[1], sc.packet_k[2], o, d, mint, best, bprim, bu, bv, found)) return true;
-    if (AN) {
+    if (AN & 1) {
         for (uint32_t i = 0; i < sc.n_analytic; ++i) {
             float u, v, t; const uint32_t prim = sc.n_tris + i;
             if (analyticIntersect<ANY>(c_analytic[i], o, d, mint, best, t, u, v)) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
 
 // ---------------------------------------------------------------------------------------------- extend
 // Scene::rayIntersect -> ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:112-142): closest hit (t, u, v, prim)
-template <int STACK, bool AN>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth); AN: the scene holds analytic shapes
+template <int STACK, int AN>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth); AN: bit 0 analytic shapes, bit 1 instances
 __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     const uint32_t tid = threadIdx.x;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
             else hit = traverse<false, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
         }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
-        if (AN && q.hitInst) q.hitInst[segBase + i] = inst;
+        if ((AN & 2) && q.hitInst) q.hitInst[segBase + i] = inst;
     }
     }
     if (tid == 0 && rays) atomicAdd(&q.counters[0], rays);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 // ---------------------------------------------------------------------------------------------- shadow
 // Visibility test of Scene::sampleEmitterDirect (src/librender/scene.cpp:871-875 -> skdtree.cpp:207-226, any hit) and the
 // deferred `Li += throughput * value * bsdfVal * weight` (path.cpp:196)
-template <int STACK, bool AN>
+template <int STACK, int AN>
 __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     const uint32_t tid = threadIdx.x;
@@ -630,9 +630,9 @@ __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *
     v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
     if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
-        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true, true>(sc, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false, true>(sc, o, d, mint, maxt, t, prim, u, v); }
-        else if (anyHit) hit = traverse<true, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
-        else hit = traverse<false, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        if (sc.packet_n) { if (anyHit) hit = packetIntersect<true, 3>(sc, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false, 3>(sc, o, d, mint, maxt, t, prim, u, v); }
+        else if (anyHit) hit = traverse<true, 3>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        else hit = traverse<false, 3>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
     }
     if (outInst) outInst[i] = hit ? inst : -1;
     out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
@@ -671,7 +671,8 @@ void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, const AnalyticD 
     else if (sc.bvh_depth <= 28) hipLaunchKernelGGL((KERNEL<28, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
 void MI_FN(mi_launch_extend)(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
-    if (sc.n_analytic || sc.n_instances) MI_BY_STACK(k_extend, true, sc, q, buf); else MI_BY_STACK(k_extend, false, sc, q, buf);
+    const int mode = (sc.n_analytic ? 1 : 0) | (sc.n_instances ? 2 : 0);
+    if (mode == 3) MI_BY_STACK(k_extend, 3, sc, q, buf); else if (mode == 2) MI_BY_STACK(k_extend, 2, sc, q, buf); else if (mode == 1) MI_BY_STACK(k_extend, 1, sc, q, buf); else MI_BY_STACK(k_extend, 0, sc, q, buf);
 }
 void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
@@ -687,7 +688,8 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
 #undef MI_SHADE
 }
 void MI_FN(mi_launch_shadow)(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
-    if (sc.n_analytic || sc.n_instances) MI_BY_STACK(k_shadow, true, sc, q); else MI_BY_STACK(k_shadow, false, sc, q);
+    const int mode = (sc.n_analytic ? 1 : 0) | (sc.n_instances ? 2 : 0);
+    if (mode == 3) MI_BY_STACK(k_shadow, 3, sc, q); else if (mode == 2) MI_BY_STACK(k_shadow, 2, sc, q); else if (mode == 1) MI_BY_STACK(k_shadow, 1, sc, q); else MI_BY_STACK(k_shadow, 0, sc, q);
 }
 #undef MI_BY_STACK
 void MI_FN(mi_launch_env_primary)(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) { hipLaunchKernelGGL(k_env_primary, dim3(grid), dim3(WG), 0, st, sc, rc, q, buf); }
