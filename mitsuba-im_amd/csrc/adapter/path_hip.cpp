@@ -525,9 +525,12 @@ struct GpuScene {
         const PerspectiveCamera *cam = static_cast<const PerspectiveCamera *>(sensor);
         const Film *film = sensor->getFilm();
         const Vector2i &filmSize = film->getSize(), &cropSize = film->getCropSize(); const Point2i &cropOffset = film->getCropOffset();
-        if (cropSize != filmSize || cropOffset != Point2i(0)) SLog(EError, "path_hip: crop windows are not implemented");
+        // crop window (perspective.cpp:129-136, 150-152): the film of the path is the crop window, the camera maps it onto its part of the full frame
+        Vector2 relSize((Float) cropSize.x / (Float) filmSize.x, (Float) cropSize.y / (Float) filmSize.y);
+        Point2 relOffset((Float) cropOffset.x / (Float) filmSize.x, (Float) cropOffset.y / (Float) filmSize.y);
         Float aspect = cam->getAspect();
-        Transform cameraToSample = Transform::scale(Vector(-0.5f, -0.5f * aspect, 1.0f)) * Transform::translate(Vector(-1.0f, -1.0f / aspect, 0.0f))
+        Transform cameraToSample = Transform::scale(Vector(1.0f / relSize.x, 1.0f / relSize.y, 1.0f)) * Transform::translate(Vector(-relOffset.x, -relOffset.y, 0.0f))
+                                 * Transform::scale(Vector(-0.5f, -0.5f * aspect, 1.0f)) * Transform::translate(Vector(-1.0f, -1.0f / aspect, 0.0f))
                                  * Transform::perspective(cam->getXFov(), cam->getNearClip(), cam->getFarClip());
         Matrix4x4 s2c = cameraToSample.inverse().getMatrix(), c2w = cam->getWorldTransform(0.0f).getMatrix();
         float a[16], w[16]; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i * 4 + j] = s2c(i, j); w[i * 4 + j] = c2w(i, j); }

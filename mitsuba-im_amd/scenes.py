@@ -142,17 +142,29 @@ def look_at(origin, target, up):
     return m
 
 
-def sample_to_camera(xfov_deg, near, far, aspect):
-    """cameraToSample = scale(-0.5,-0.5*aspect,1) * translate(-1,-1/aspect,0) * perspective(xfov,near,far);
-    returns its inverse (crop window = full film)."""
+def sample_to_camera(xfov_deg, near, far, aspect, rel_size=(1.0, 1.0), rel_offset=(0.0, 0.0)):
+    """cameraToSample = scale(1/relSize) * translate(-relOffset) * scale(-0.5,-0.5*aspect,1) * translate(-1,-1/aspect,0) * perspective(xfov,near,far)
+    (perspective.cpp:129-155); returns its inverse.  `aspect` is the FULL film's; rel_size / rel_offset = crop size / offset over the full film size."""
     recip = 1.0 / (far - near)
     cot = 1.0 / math.tan(math.radians(xfov_deg / 2.0))
     persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0],
                       [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], dtype=np.float64)
     tr = np.eye(4); tr[0, 3] = -1.0; tr[1, 3] = -1.0 / aspect
     sc = np.diag([-0.5, -0.5 * aspect, 1.0, 1.0])
-    cam_to_sample = sc @ tr @ persp
+    crop = np.diag([1.0 / float(f32(rel_size[0])), 1.0 / float(f32(rel_size[1])), 1.0, 1.0]) @ translate(-float(f32(rel_offset[0])), -float(f32(rel_offset[1])), 0.0)
+    cam_to_sample = crop @ sc @ tr @ persp
     return np.linalg.inv(cam_to_sample).astype(f32)
+
+
+def set_crop_window(sc, full_width, full_height, offset_x, offset_y):
+    """Turn `sc` (whose width x height stay the rendered film) into the crop window at (offset_x, offset_y) of a full_width x full_height frame
+    (Film cropOffsetX/Y, cropWidth/Height, src/librender/film.cpp:35-47): only the camera's sample-to-camera mapping changes."""
+    if offset_x < 0 or offset_y < 0 or offset_x + sc.width > full_width or offset_y + sc.height > full_height:
+        raise ValueError("Invalid crop window specification!")
+    sc.crop = (int(full_width), int(full_height), int(offset_x), int(offset_y))
+    sc.sample_to_camera = sample_to_camera(sc.xfov, sc.near, sc.far, full_width / full_height,
+                                           (f32(sc.width) / f32(full_width), f32(sc.height) / f32(full_height)), (f32(offset_x) / f32(full_width), f32(offset_y) / f32(full_height)))
+    return sc
 
 
 def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near, far, width, height,
@@ -1077,6 +1089,8 @@ def save_scene(sc, path):
                 if t["type"] == TEXTURE_BITMAP:              # the harness builds the reference's own BitmapTexture (and MIP pyramid) from the base image
                     base = t["pyramid"]["base"]; f.write(struct.pack("<2I", base.shape[1], base.shape[0])); f.write(base.tobytes())
             f.write(struct.pack("<%di" % len(sc.bsdfs), *[b.get("texture", -1) for b in sc.bsdfs]))
+        if sc.get("crop"):
+            f.write(b"CROP"); f.write(struct.pack("<I", 1)); f.write(struct.pack("<4i", *sc.crop))
         if sc.get("instances"):
             f.write(b"INST"); f.write(struct.pack("<I", len(sc.instances)))
             for a in sc.instances:

@@ -763,13 +763,16 @@ class _SceneBuilder:
         film = sen.child("film"); smp = sen.child("sampler")
         width = int(film.get("width", 768)) if film is not None else 768
         height = int(film.get("height", 576)) if film is not None else 576
+        crop = None
         filter_kind, f_radius, f_stddev = S.FILTER_GAUSSIAN, None, None       # Film: a gaussian filter unless the film names one (src/librender/film.cpp)
         if film is not None:
             if film.type not in ("hdrfilm", "ldrfilm", "mfilm", "tiledhdrfilm"):
                 raise SceneError(f"film \"{film.type}\" is not supported")
-            for k in ("cropOffsetX", "cropOffsetY", "cropWidth", "cropHeight"):
-                if film.has(k):
-                    raise SceneError("film crop windows are not supported")
+            crop = None
+            if any(film.has(k) for k in ("cropOffsetX", "cropOffsetY", "cropWidth", "cropHeight")):      # src/librender/film.cpp:35-47
+                crop = (int(film.get("cropOffsetX", 0)), int(film.get("cropOffsetY", 0)), int(film.get("cropWidth", width)), int(film.get("cropHeight", height)))
+                if crop[0] < 0 or crop[1] < 0 or crop[2] <= 0 or crop[3] <= 0 or crop[0] + crop[2] > width or crop[1] + crop[3] > height:
+                    raise SceneError("Invalid crop window specification!")
             for k in ("banner", "attachLog", "fileFormat", "pixelFormat", "channelNames", "componentFormat", "highQualityEdges", "gamma", "exposure", "tonemapMethod", "key", "burn"):
                 film.get(k)
             rf = film.child("rfilter")
@@ -801,7 +804,10 @@ class _SceneBuilder:
             smp.check_all_used()
         elif self.sampler_override:
             sampler = S.SAMPLER_SOBOL if self.sampler_override == "sobol" else S.SAMPLER_INDEPENDENT
-        aspect = width / height
+        full_w, full_h = width, height
+        aspect = width / height                          # the camera's aspect is the FULL film's (sensor.cpp: m_aspect = size.x / size.y)
+        if crop is not None:
+            width, height = crop[2], crop[3]
         if sen.has("fov") and sen.has("focalLength"):
             raise SceneError("Please specify either a focal length ('focalLength') or a field of view ('fov')!")
         def diag_to_x(d):
@@ -874,6 +880,8 @@ class _SceneBuilder:
         sc = S.finish_scene(verts, tris, self.shapes, self.bsdfs, emitters, cam, xfov, near, far, width, height, spp, sampler, max_depth, rr_depth,
                             filter_kind, seed, normals=normals, uvs=uvs, strict_normals=strict, hide_emitters=hide, envmap=self.envmap, name=name,
                             analytic=self.analytic, instances=self.instances, textures=self.textures)
+        if crop is not None:
+            S.set_crop_window(sc, full_w, full_h, crop[0], crop[1])
         if f_radius is not None:
             sc.filter_radius = float(f_radius)
         if f_stddev is not None:
@@ -920,7 +928,9 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
     out.append(f'\t<sensor type="perspective"><float name="fov" value="{fmt([sc.xfov])}"/><string name="fovAxis" value="x"/>'
                f'<float name="nearClip" value="{fmt([sc.near])}"/><float name="farClip" value="{fmt([sc.far])}"/>{mat("toWorld", sc.cam_to_world)}\n'
                f'\t\t<sampler type="{smp}"><integer name="sampleCount" value="{sc.spp}"/>{seed}</sampler>\n'
-               f'\t\t<film type="hdrfilm"><integer name="width" value="{sc.width}"/><integer name="height" value="{sc.height}"/><boolean name="banner" value="false"/>'
+               f'\t\t<film type="hdrfilm">' + (f'<integer name="width" value="{sc.crop[0]}"/><integer name="height" value="{sc.crop[1]}"/><integer name="cropOffsetX" value="{sc.crop[2]}"/>'
+                                                f'<integer name="cropOffsetY" value="{sc.crop[3]}"/><integer name="cropWidth" value="{sc.width}"/><integer name="cropHeight" value="{sc.height}"/>' if sc.get("crop")
+                                                else f'<integer name="width" value="{sc.width}"/><integer name="height" value="{sc.height}"/>') + '<boolean name="banner" value="false"/>'
                f'<rfilter type="{filt}">{fprops}</rfilter></film>\n\t</sensor>')
     distr = {S.DISTR_BECKMANN: "beckmann", S.DISTR_GGX: "ggx", S.DISTR_PHONG: "phong"}
 

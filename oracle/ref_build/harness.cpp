@@ -78,6 +78,7 @@ struct FInstance { uint32_t group, pad[3]; float toWorld[16], toObject[16]; };
 struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
 struct FScene {
     std::vector<FAnalytic> analytic; std::vector<FInstance> instances; std::vector<FTexture> textures; std::vector<int32_t> bsdfTexture;
+    int32_t crop[4] = {0, 0, 0, 0};       // full film width / height, crop offset x / y (W, H = the crop window); all zero: no crop window
     uint32_t nVerts, nTris, nShapes, nBsdfs, nEmitters, hasN, hasUV, hasEnv;
     std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx;
     std::vector<FShape> shapes; std::vector<FBsdf> bsdfs; std::vector<FEmitter> emitters;
@@ -119,6 +120,7 @@ static FScene loadScene(const char *path) {
             }
             s.bsdfTexture.resize(s.nBsdfs); rd(f, s.bsdfTexture.data(), s.nBsdfs * 4);
         }
+        else if (!memcmp(tag, "CROP", 4)) { rd(f, s.crop, 16); }
         else if (!memcmp(tag, "INST", 4)) { s.instances.resize(n); for (FInstance &a : s.instances) rd(f, &a, sizeof(FInstance)); }
         else { fprintf(stderr, "unknown section\n"); _exit(2); }
     }
@@ -390,6 +392,8 @@ static Built buildScene(const FScene &fs) {
         b.filter = static_cast<ReconstructionFilter *>(create(MTS_CLASS(ReconstructionFilter), fp));
         b.filter->configure();
         Properties p("hdrfilm"); p.setInteger("width", fs.W); p.setInteger("height", fs.H); p.setBoolean("banner", false);
+        if (fs.crop[0]) { p.setInteger("width", fs.crop[0]); p.setInteger("height", fs.crop[1]); p.setInteger("cropOffsetX", fs.crop[2]); p.setInteger("cropOffsetY", fs.crop[3]);
+                          p.setInteger("cropWidth", fs.W); p.setInteger("cropHeight", fs.H); }
         b.film = static_cast<Film *>(create(MTS_CLASS(Film), p));
         b.film->addChild(b.filter); b.filter->setParent(b.film);
         b.film->configure();

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -67,6 +67,10 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         # the whole MicrofacetDistribution under roughconductor: anisotropic Beckmann / GGX (tangent = dp/du of the plates' uv), sampleVisible = false
         # (sampleAll), Phong and Ashikhmin-Shirley; exp / log / pow / atan / tan from libm, the reference adds -ffast-math
         assert same_path.all() and same_vals.all() and (err < 1e-3).mean() > 0.998 and err.max() < 2e-2 and np.median(err) < 1e-6
+    elif name == "cornell_crop":
+        # crop window: the sample-to-camera matrix is composed in double here and in float (with the reference's -ffast-math) there -> camera rays agree to the
+        # last bits, a couple of the 2048 paths fork at a geometric edge
+        assert same_path.mean() > 0.998 and (err < 2e-4).mean() > 0.998 and np.median(err) < 1e-6
     elif name == "cornell_scramble":
         # SobolSampler with scramble = 7: film positions and every sampler value bit-identical (look_up pixel flip + XOR into the samples)
         assert same_path.all() and same_vals.all() and (err < 2e-4).mean() > 0.998 and err.max() < 5e-3 and np.median(err) < 1e-6
@@ -114,7 +118,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         assert err.max() < 2e-4 and np.median(err) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -193,7 +197,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes",
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop",
                                   "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
@@ -203,7 +207,7 @@ def test_film_vs_reference(oracle, golden_scenes, name):
     assert film.shape == ref.shape
     rel = np.linalg.norm(film[..., :3] - ref[..., :3]) / np.linalg.norm(ref[..., :3])
     # cbox_shapes_strict_indep: one of 73 728 samples forks at a strictNormals threshold (0.12 in one pixel)
-    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3, "instanced_garden": 2e-3, "cbox_translucent_indep": 5e-4, "bunny_box": 1e-3}.get(name, 1e-4), rel
+    assert rel < {"closed_box": 2e-2, "atrium_small": 2e-3, "cbox_shapes_strict_indep": 2e-3, "instanced_garden": 2e-3, "cbox_translucent_indep": 5e-4, "bunny_box": 1e-3, "cornell_crop": 5e-3}.get(name, 1e-4), rel
     assert np.allclose(film[..., 4], ref[..., 4], rtol=1e-5, atol=1e-6)        # weight channel
     # the reference's own ray counters (StatsCounter "Normal rays traced" / "Shadow rays traced", skdtree.cpp:46-47)
     stats = str(gd["stats"])

@@ -69,6 +69,22 @@ def test_export_load_round_trip(gen, fmt, tmp_path):
     assert_same_scene(sc, X.load_scene(path))
 
 
+def test_crop_window_round_trip(tmp_path):
+    """Film crop windows (src/librender/film.cpp:35-47, perspective.cpp:129-152): the rendered film is the crop, the camera keeps the full frame's aspect."""
+    sc = S.set_crop_window(S.cornell_box(width=64, height=36, spp=4), 192, 108, 70, 40)
+    sc2 = X.load_scene(X.export_scene(sc, str(tmp_path)))
+    assert sc2.crop == (192, 108, 70, 40) and (sc2.width, sc2.height) == (64, 36)
+    np.testing.assert_allclose(sc.sample_to_camera, sc2.sample_to_camera, rtol=3e-7, atol=1e-9)
+    full = S.cornell_box(width=192, height=108, spp=4)
+    # the crop's pixel (0, 0) looks where the full frame's pixel (70, 40) looks
+    import oracle; oracle.build()
+    a = np.zeros(8, np.float32); b = np.zeros(8, np.float32); L = oracle.lib()
+    L.orc_camera_ray(oracle.Oracle(sc).h, 0.5, 0.5, a.ctypes.data); L.orc_camera_ray(oracle.Oracle(full).h, 70.5, 40.5, b.ctypes.data)
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="Invalid crop window"):
+        S.set_crop_window(S.cornell_box(width=64, height=36, spp=4), 100, 108, 70, 40)
+
+
 def test_round_trip_renders_identically_in_the_oracle(tmp_path):
     """The loaded scene is not just field-equal: the oracle traces the same image from it (Cornell box: bit-identical film)."""
     import oracle
