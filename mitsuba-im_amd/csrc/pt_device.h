@@ -1104,7 +1104,8 @@ DEV float rpPdf(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     v3 H = normalize(wo + wi);
     float probSpecular = rpProbSpecular(sc, m, wi.z), probDiffuse = 1 - probSpecular;
     float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
-    float prob = mfPdfVisible(m.distr, alpha, wi, H);
+    MfD d; d.distr = m.distr; d.au = d.av = alpha; d.visible = (m.flags & 2u) != 0;      // distr.pdf(wi, H): visible normals or all normals (roughplastic.cpp:432)
+    float prob = mfdPdf(d, wi, H);
     float result = prob * dwh_dwo * probSpecular;
     result += probDiffuse * (MI_INV_PI * wo.z);
     return result;
@@ -1115,7 +1116,8 @@ DEV v3 rpSample(const DScene &sc, const MaterialD &mt, v3 wi, float sx, float sy
     float probSpecular = rpProbSpecular(sc, mt, wi.z); bool choseSpecular = true;
     if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = false; }
     if (choseSpecular) {
-        v3 m = mfSampleVisible(mt.distr, alpha, wi, sx, sy);
+        MfD d; d.distr = mt.distr; d.au = d.av = alpha; d.visible = (mt.flags & 2u) != 0; float mpdf;
+        v3 m = mfdSample(d, wi, sx, sy, mpdf);                                                // distr.sample(wi, sample) (roughplastic.cpp:483)
         float c = 2 * dot(wi, m); wo = m * c - wi;
         if (wo.z <= 0) return V(0, 0, 0);
     } else wo = cosHemisphere(sx, sy);

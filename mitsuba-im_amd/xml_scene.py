@@ -413,8 +413,8 @@ def _microfacet(p, full=False):
         raise SceneError("textured roughness is not supported")
     sv = bool(p.get("sampleVisible", True))
     if not full:
-        if kinds[d] == S.DISTR_PHONG or (alpha_v is not None and alpha_v != alpha) or not sv:
-            raise SceneError(f"{p.type}: implemented for isotropic beckmann / ggx with sampleVisible = true (the full distribution: roughconductor, roughdielectric)")
+        if kinds[d] == S.DISTR_PHONG or (alpha_v is not None and alpha_v != alpha):
+            raise SceneError(f"{p.type}: implemented for isotropic beckmann / ggx (the full distribution: roughconductor, roughdielectric)")
         return kinds[d], alpha, sv
     return kinds[d], alpha, sv, alpha_v
 
@@ -956,7 +956,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
     for i, b in enumerate(sc.bsdfs):
         t = b["type"]; mf = f'<string name="distribution" value="{distr.get(b["distr"], "beckmann")}"/>' + (
             f'<float name="alphaU" value="{fmt([b["alpha"]])}"/><float name="alphaV" value="{fmt([b["reflectance"][0] if b["type"] == S.BSDF_ROUGHCONDUCTOR else b["k"][0]])}"/>' if b.get("aniso") else f'<float name="alpha" value="{fmt([b["alpha"]])}"/>')
-        vis = True if t == S.BSDF_ROUGHPLASTIC else bool(b["sample_visible"] & 1)      # roughplastic: the field doubles as the container's nonlinear flag (scenes.make_bsdf)
+        vis = bool(b["sample_visible"] & 1)
         sv = f'<boolean name="sampleVisible" value="{str(vis).lower()}"/>'
         ior = f'<float name="intIOR" value="{fmt([b["eta"][0]])}"/><float name="extIOR" value="1"/>'
         cond = f'{rgb("eta", b["eta"])}{rgb("k", b["k"])}<float name="extEta" value="1"/>{rgb("specularReflectance", b["specular"])}'

@@ -119,7 +119,7 @@ def pack_records(sc):
         shapes[i] = OrcShape(s["first_tri"], s["tri_count"], s["first_vert"], s["vert_count"], s["bsdf"], s["emitter"], (s["face_normals"] & 1) | ((s.get("has_uv", 0) & 1) << 1), s.get("group", 0))
     mats = (OrcMaterial * len(sc.bsdfs))()
     for i, b in enumerate(sc.bsdfs):
-        m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((1 if b["sample_visible"] else 0) << 1) | ((b.get("nonlinear", 0) & 1) << 2) | ((b.get("aniso", 0) & 1) << 3) | ((b.get("texture", -1) + 1) << 8), b["distr"], b["alpha"])
+        m = OrcMaterial(b["type"], (b["twosided"] & 1) | ((b["sample_visible"] & 1) << 1) | ((b.get("nonlinear", 0) & 1) << 2) | ((b.get("aniso", 0) & 1) << 3) | ((b.get("texture", -1) + 1) << 8), b["distr"], b["alpha"])
         m.reflectance[:] = b["reflectance"]; m.eta[:] = b["eta"]; m.k[:] = b["k"]; m.specular[:] = b["specular"]
         mats[i] = m
     ems = (OrcEmitter * max(1, len(sc.emitters)))()

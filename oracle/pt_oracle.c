@@ -1299,7 +1299,8 @@ static float rp_pdf(const orc_material *m, v3 wi, v3 wo) {
     v3 H = normalize(add(wo, wi));
     float probSpecular = rp_prob_specular(m, wi.z), probDiffuse = 1 - probSpecular;
     float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
-    float prob = mf_pdf_visible(m->distr, alpha, wi, H);
+    const mfd_t d = {m->distr, alpha, alpha, (m->flags & 2u) != 0};        /* distr.pdf(wi, H): visible normals or all normals (roughplastic.cpp:432) */
+    float prob = mfd_pdf(&d, wi, H);
     float result = prob * dwh_dwo * probSpecular;
     result += probDiffuse * (INV_PI * wo.z);
     return result;
@@ -1310,7 +1311,8 @@ static v3 rp_sample(const orc_material *mt, v3 wi, float sx, float sy, v3 *wo, f
     float probSpecular = rp_prob_specular(mt, wi.z); int choseSpecular = 1;
     if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = 0; }
     if (choseSpecular) {
-        v3 m = mf_sample_visible(mt->distr, alpha, wi, sx, sy);
+        const mfd_t d = {mt->distr, alpha, alpha, (mt->flags & 2u) != 0}; float mpdf;
+        v3 m = mfd_sample(&d, wi, sx, sy, &mpdf);                             /* distr.sample(wi, sample) (roughplastic.cpp:483) */
         float c = 2 * dot(wi, m); *wo = sub(scale(m, c), wi);
         if (wo->z <= 0) return V(0, 0, 0);
     } else *wo = cos_hemisphere(sx, sy);

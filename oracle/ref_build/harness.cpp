@@ -222,9 +222,9 @@ static Built buildScene(const FScene &fs) {
         } else if (fb.type == 7) {
             Properties p("roughplastic");
             p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx"); p.setFloat("alpha", fb.alpha);
-            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", true);
+            p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("diffuseReflectance", rgb(fb.refl));
-            p.setBoolean("nonlinear", fb.sampleVisible == 2);          // FBsdf::sampleVisible carries the nonlinear flag for roughplastic (2)
+            p.setBoolean("nonlinear", (fb.sampleVisible & 2u) != 0);   // FBsdf::sampleVisible of a roughplastic: bit 0 sampleVisible, bit 1 nonlinear
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 5) {
             Properties p("roughdielectric");

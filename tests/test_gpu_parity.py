@@ -414,10 +414,12 @@ def test_rough_dielectric_and_difftrans(mi, oracle, golden_scenes, name):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
 
 
-def test_roughplastic(mi, oracle, golden_scenes):
+@pytest.mark.parametrize("name", ["cbox_roughplastic", "cbox_roughplastic_allnormals"])
+def test_roughplastic(mi, oracle, golden_scenes, name):
     """`roughplastic`: glossy microfacet coat over a diffuse base; the rough-transmittance slice (100 values, Catmull-Rom lookup over the warped
-    incidence angle) is material input data taken from the reference's own tables.  Microfacet code + powf -> tolerance-pinned."""
-    name = "cbox_roughplastic"; sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    incidence angle) is material input data taken from the reference's own tables.  Microfacet code + powf -> tolerance-pinned.  The second scene
+    samples all normals instead of the visible ones (sampleVisible = false)."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
     gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
     rng = np.random.default_rng(28); n = 20000
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
