@@ -69,7 +69,7 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 typedef struct { uint32_t type; float color0[3], color1[3]; float line_width; float uoffset, voffset, uscale, vscale;
                  uint32_t wrap_u, wrap_v, filter; float max_anisotropy; uint32_t first_level, n_levels; } mi_texture;
 typedef struct {
-    uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx, 2 phong / Ashikhmin-Shirley (roughconductor, roughdielectric; samples all normals, microfacet.h:141-145) */
+    uint32_t type, flags, distr;  /* distr: 0 beckmann, 1 ggx, 2 phong / Ashikhmin-Shirley (roughconductor, roughdielectric, roughplastic; samples all normals, microfacet.h:141-145) */
     float alpha;
     float reflectance[3], eta[3], k[3], specular[3];
 } mi_material;

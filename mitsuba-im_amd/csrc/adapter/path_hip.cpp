@@ -52,7 +52,7 @@ struct RTAccess : RoughTransmittance {
 };
 static std::vector<float> *g_tables = NULL;      // FlatScene::materialTables of the flatten() in progress (single-threaded: preprocess)
 static void roughPlasticTables(mi_material &m) {
-    ref<RTAccess> ext = new RTAccess(m.distr == 1 ? MicrofacetDistribution::EGGX : MicrofacetDistribution::EBeckmann);
+    ref<RTAccess> ext = new RTAccess(m.distr == 1 ? MicrofacetDistribution::EGGX : m.distr == 2 ? MicrofacetDistribution::EPhong : MicrofacetDistribution::EBeckmann);
     ext->checkEta(m.eta[0]); ext->checkAlpha(m.alpha);
     ref<RoughTransmittance> internal = ext->clone();
     ext->setEta(m.eta[0]); internal->setEta(1 / m.eta[0]); ext->setAlpha(m.alpha);
@@ -151,8 +151,8 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         uint32_t distr = rd.ms->readUInt(); bool sampleVisible = rd.ms->readBool();
         std::vector<float> spec = rd.constant("specularReflectance"), diff = rd.texture(); bind(diff);
         std::vector<float> alpha = rd.constant("alpha");
-        if (distr > 1) SLog(EError, "path_hip: roughplastic is implemented for beckmann / ggx");
-        m.type = MI_BSDF_ROUGHPLASTIC; if (sampleVisible) m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = alpha[0];
+        if (distr > 2) SLog(EError, "path_hip: roughplastic: unknown microfacet distribution %u", distr);
+        m.type = MI_BSDF_ROUGHPLASTIC; if (sampleVisible && distr != 2) m.flags |= MI_BSDF_FLAG_SAMPLE_VISIBLE; m.distr = distr; m.alpha = alpha[0];
         memcpy(m.specular, spec.data(), 12);
         m.eta[0] = rd.ms->readFloat(); if (rd.ms->readBool()) m.flags |= MI_BSDF_FLAG_NONLINEAR;
         roughPlasticTables(m);
@@ -300,8 +300,9 @@ static mi_material convertBSDF(const BSDF *bsdf) {
         }
         if (cls == "RoughPlastic") {
             std::string distr = props.getString("distribution", "beckmann"); std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
-            if (distr != "beckmann" && distr != "ggx") SLog(EError, "path_hip: roughplastic is implemented for beckmann / ggx");
-            m.type = MI_BSDF_ROUGHPLASTIC; m.flags = props.getBoolean("sampleVisible", true) ? MI_BSDF_FLAG_SAMPLE_VISIBLE : 0u; m.distr = distr == "ggx" ? 1u : 0u; m.alpha = props.getFloat("alpha", 0.1f);
+            if (distr != "beckmann" && distr != "ggx" && distr != "phong" && distr != "as") SLog(EError, "Specified an invalid distribution \"%s\", must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!", distr.c_str());   // microfacet.h:113-115
+            m.distr = distr == "ggx" ? 1u : distr == "beckmann" ? 0u : 2u;
+            m.type = MI_BSDF_ROUGHPLASTIC; m.flags = (props.getBoolean("sampleVisible", true) && m.distr != 2u) ? MI_BSDF_FLAG_SAMPLE_VISIBLE : 0u; m.alpha = props.getFloat("alpha", 0.1f);
             m.eta[0] = lookupIOR(props, "intIOR", "polypropylene") / lookupIOR(props, "extIOR", "air");
             if (props.getBoolean("nonlinear", false)) m.flags |= MI_BSDF_FLAG_NONLINEAR;
             rgb3(props.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular); rgb3(props.getSpectrum("diffuseReflectance", Spectrum(0.5f)), m.reflectance);

@@ -172,8 +172,8 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_DIFFTRANS || m[i].type == MI_BSDF_THINDIELECTRIC) && (m[i].flags & MI_BSDF_FLAG_TWOSIDED)) return fail(MI_ERR_INVALID, "Only BSDFs without a transmission component can be nested!");   // twosided.cpp:86-88
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC || m[i].type == MI_BSDF_THINDIELECTRIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
-        if (m[i].type == MI_BSDF_ROUGHPLASTIC && (m[i].distr > 1 || (m[i].flags & MI_BSDF_FLAG_ANISOTROPIC)))
-            return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: roughplastic supports isotropic beckmann / ggx (its rough-transmittance slices exist for those)");        // anisotropy: refused by the reference too (roughplastic.cpp:225-227)
+        if (m[i].type == MI_BSDF_ROUGHPLASTIC && (m[i].distr > 2 || (m[i].flags & MI_BSDF_FLAG_ANISOTROPIC)))
+            return fail(MI_ERR_INVALID, "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");        // roughplastic.cpp:225-227
         if ((m[i].type == MI_BSDF_ROUGHCONDUCTOR || m[i].type == MI_BSDF_ROUGHDIELECTRIC) && m[i].distr > 2) return fail(MI_ERR_INVALID, "Specified an invalid distribution, must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!");   // microfacet.h:113-115
         if ((m[i].flags & MI_BSDF_FLAG_ANISOTROPIC) && m[i].type != MI_BSDF_ROUGHCONDUCTOR && m[i].type != MI_BSDF_ROUGHDIELECTRIC) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: anisotropic roughness is implemented for roughconductor and roughdielectric");
     }

@@ -1088,8 +1088,9 @@ DEV v3 rpEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
     const float eta = m.eta[0], alpha = maxf(m.alpha, 1e-4f), invEta2 = 1.0f / (eta * eta);
     v3 H = normalize(wo + wi);
-    float D = mfEval(m.distr, alpha, H), ct, F = fresnelDielectricExt(dot(wi, H), ct, eta);
-    float G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H);
+    float D, G, ct, F = fresnelDielectricExt(dot(wi, H), ct, eta);
+    if (m.distr == 2u) { D = mfEval2(2u, alpha, alpha, H); G = mfSmithG1_2(2u, alpha, alpha, wi, H) * mfSmithG1_2(2u, alpha, alpha, wo, H); }   // Phong: roughness -> exponent (microfacet.h:98-110)
+    else { D = mfEval(m.distr, alpha, H); G = mfSmithG1(m.distr, alpha, wi, H) * mfSmithG1(m.distr, alpha, wo, H); }
     float value = F * D * G / (4.0f * wi.z);
     v3 result = ld3(m.specular) * value;
     v3 diff = ld3(m.reflectance);
@@ -1104,7 +1105,7 @@ DEV float rpPdf(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     v3 H = normalize(wo + wi);
     float probSpecular = rpProbSpecular(sc, m, wi.z), probDiffuse = 1 - probSpecular;
     float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
-    MfD d; d.distr = m.distr; d.au = d.av = alpha; d.visible = (m.flags & 2u) != 0;      // distr.pdf(wi, H): visible normals or all normals (roughplastic.cpp:432)
+    MfD d; d.distr = m.distr; d.au = d.av = alpha; d.visible = (m.flags & 2u) != 0 && m.distr != 2u;      // distr.pdf(wi, H): visible normals or all normals (roughplastic.cpp:432)
     float prob = mfdPdf(d, wi, H);
     float result = prob * dwh_dwo * probSpecular;
     result += probDiffuse * (MI_INV_PI * wo.z);
@@ -1116,7 +1117,7 @@ DEV v3 rpSample(const DScene &sc, const MaterialD &mt, v3 wi, float sx, float sy
     float probSpecular = rpProbSpecular(sc, mt, wi.z); bool choseSpecular = true;
     if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = false; }
     if (choseSpecular) {
-        MfD d; d.distr = mt.distr; d.au = d.av = alpha; d.visible = (mt.flags & 2u) != 0; float mpdf;
+        MfD d; d.distr = mt.distr; d.au = d.av = alpha; d.visible = (mt.flags & 2u) != 0 && mt.distr != 2u; float mpdf;
         v3 m = mfdSample(d, wi, sx, sy, mpdf);                                                // distr.sample(wi, sample) (roughplastic.cpp:483)
         float c = 2 * dot(wi, m); wo = m * c - wi;
         if (wo.z <= 0) return V(0, 0, 0);

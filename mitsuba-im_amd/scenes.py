@@ -113,6 +113,7 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         eta = (float(f32(ior)), 0.0, 0.0); distr = int(nonlinear)
         k = (float(f32(fresnel_diffuse_reflectance(1.0 / float(f32(ior))))), 0.0, 0.0) if kind == BSDF_PLASTIC else (0.0, 0.0, 0.0)
     if kind == BSDF_ROUGHPLASTIC:
+        if distr == DISTR_PHONG: sample_visible = False      # microfacet.h:141-145
         sample_visible = (1 if sample_visible else 0) | (2 if nonlinear else 0)      # container field: bit 0 sampleVisible, bit 1 the nonlinear flag of roughplastic (read by the harness)
     aniso = 0
     if kind in (BSDF_ROUGHCONDUCTOR, BSDF_ROUGHDIELECTRIC):
@@ -576,13 +577,13 @@ def cbox_translucent(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_dep
                         seed=seed, strict_normals=strict_normals, hide_emitters=hide_emitters, name="cbox_translucent", analytic=b.resolve_analytic())
 
 
-def cbox_roughplastic(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False, sample_visible=True):
-    """Cornell box with `roughplastic` blocks and floor (Beckmann / GGX, linear and nonlinear), one of them `twosided`."""
+def cbox_roughplastic(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False, sample_visible=True, phong=False):
+    """Cornell box with `roughplastic` blocks and floor (Beckmann / GGX, linear and nonlinear; phong: all three with the Phong distribution), one of them `twosided`."""
     sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, strict_normals=strict_normals)
     sc.name = "cbox_roughplastic"
-    mats = [make_bsdf(kind=BSDF_ROUGHPLASTIC, reflectance=(0.55, 0.5, 0.4), alpha=0.3, distr=DISTR_BECKMANN, ior=1.49, nonlinear=True, sample_visible=sample_visible),      # floor
-            make_bsdf(kind=BSDF_ROUGHPLASTIC, reflectance=(0.1, 0.3, 0.65), specular=(0.9, 0.9, 0.9), alpha=0.1, distr=DISTR_GGX, ior=1.5046, sample_visible=sample_visible),     # short block
-            make_bsdf(kind=BSDF_ROUGHPLASTIC, reflectance=(0.7, 0.25, 0.1), alpha=0.05, distr=DISTR_BECKMANN, ior=1.9, twosided=True, sample_visible=sample_visible)]             # tall block
+    mats = [make_bsdf(kind=BSDF_ROUGHPLASTIC, reflectance=(0.55, 0.5, 0.4), alpha=0.3, distr=DISTR_PHONG if phong else DISTR_BECKMANN, ior=1.49, nonlinear=True, sample_visible=sample_visible),      # floor
+            make_bsdf(kind=BSDF_ROUGHPLASTIC, reflectance=(0.1, 0.3, 0.65), specular=(0.9, 0.9, 0.9), alpha=0.1, distr=DISTR_PHONG if phong else DISTR_GGX, ior=1.5046, sample_visible=sample_visible),     # short block
+            make_bsdf(kind=BSDF_ROUGHPLASTIC, reflectance=(0.7, 0.25, 0.1), alpha=0.05, distr=DISTR_PHONG if phong else DISTR_BECKMANN, ior=1.9, twosided=True, sample_visible=sample_visible)]             # tall block
     base = len(sc.bsdfs); sc.bsdfs.extend(mats)
     sc.shapes[0]["bsdf"] = base; sc.shapes[6]["bsdf"] = base + 1; sc.shapes[7]["bsdf"] = base + 2
     tabs = []

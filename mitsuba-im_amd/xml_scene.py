@@ -413,9 +413,9 @@ def _microfacet(p, full=False):
         raise SceneError("textured roughness is not supported")
     sv = bool(p.get("sampleVisible", True))
     if not full:
-        if kinds[d] == S.DISTR_PHONG or (alpha_v is not None and alpha_v != alpha):
-            raise SceneError(f"{p.type}: implemented for isotropic beckmann / ggx (the full distribution: roughconductor, roughdielectric)")
-        return kinds[d], alpha, sv
+        if alpha_v is not None and alpha_v != alpha:
+            raise SceneError(f"The '{p.type}' plugin currently does not support anisotropic microfacet distributions!")     # roughplastic.cpp:225-227
+        return kinds[d], alpha, sv and kinds[d] != S.DISTR_PHONG
     return kinds[d], alpha, sv, alpha_v
 
 

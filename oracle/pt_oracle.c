@@ -1283,8 +1283,9 @@ static v3 rp_eval(const orc_material *m, v3 wi, v3 wo) {
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
     const float eta = m->eta[0], alpha = maxf(m->alpha, 1e-4f), invEta2 = 1.0f / (eta * eta);
     v3 H = normalize(add(wo, wi));
-    float D = mf_eval(m->distr, alpha, H), ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, eta);
-    float G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H);
+    float D, G, ct, F = fresnel_dielectric_ext(dot(wi, H), &ct, eta);
+    if (m->distr == 2) { D = mf_eval2(2, alpha, alpha, H); G = mf_smith_g1_2(2, alpha, alpha, wi, H) * mf_smith_g1_2(2, alpha, alpha, wo, H); }   /* Phong: roughness -> exponent (microfacet.h:98-110) */
+    else { D = mf_eval(m->distr, alpha, H); G = mf_smith_g1(m->distr, alpha, wi, H) * mf_smith_g1(m->distr, alpha, wo, H); }
     float value = F * D * G / (4.0f * wi.z);
     v3 result = scale(V(m->specular[0], m->specular[1], m->specular[2]), value);
     v3 diff = V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
@@ -1299,7 +1300,7 @@ static float rp_pdf(const orc_material *m, v3 wi, v3 wo) {
     v3 H = normalize(add(wo, wi));
     float probSpecular = rp_prob_specular(m, wi.z), probDiffuse = 1 - probSpecular;
     float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
-    const mfd_t d = {m->distr, alpha, alpha, (m->flags & 2u) != 0};        /* distr.pdf(wi, H): visible normals or all normals (roughplastic.cpp:432) */
+    const mfd_t d = {m->distr, alpha, alpha, (m->flags & 2u) != 0 && m->distr != 2};        /* distr.pdf(wi, H): visible normals or all normals (roughplastic.cpp:432) */
     float prob = mfd_pdf(&d, wi, H);
     float result = prob * dwh_dwo * probSpecular;
     result += probDiffuse * (INV_PI * wo.z);
@@ -1311,7 +1312,7 @@ static v3 rp_sample(const orc_material *mt, v3 wi, float sx, float sy, v3 *wo, f
     float probSpecular = rp_prob_specular(mt, wi.z); int choseSpecular = 1;
     if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = 0; }
     if (choseSpecular) {
-        const mfd_t d = {mt->distr, alpha, alpha, (mt->flags & 2u) != 0}; float mpdf;
+        const mfd_t d = {mt->distr, alpha, alpha, (mt->flags & 2u) != 0 && mt->distr != 2}; float mpdf;
         v3 m = mfd_sample(&d, wi, sx, sy, &mpdf);                             /* distr.sample(wi, sample) (roughplastic.cpp:483) */
         float c = 2 * dot(wi, m); *wo = sub(scale(m, c), wi);
         if (wo->z <= 0) return V(0, 0, 0);

@@ -221,7 +221,7 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 7) {
             Properties p("roughplastic");
-            p.setString("distribution", fb.distr == 0 ? "beckmann" : "ggx"); p.setFloat("alpha", fb.alpha);
+            p.setString("distribution", fb.distr == 0 ? "beckmann" : fb.distr == 1 ? "ggx" : "phong"); p.setFloat("alpha", fb.alpha);
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("diffuseReflectance", rgb(fb.refl));
             p.setBoolean("nonlinear", (fb.sampleVisible & 2u) != 0);   // FBsdf::sampleVisible of a roughplastic: bit 0 sampleVisible, bit 1 nonlinear
@@ -501,8 +501,8 @@ static void modeTables(const std::string &out) {
     // RoughPlastic::configure (roughplastic.cpp:281-299): the external rough transmittance reduced to a 1-D slice over the incidence angle
     // (setEta(eta), setAlpha(alpha)) and the internal diffuse transmittance (setEta(1/eta), evalDiffuse(alpha)); rows: distr, eta, alpha, Tdiff_int, T[100]
     std::vector<float> rt;
-    for (int distr = 0; distr < 2; ++distr) for (float eta : {1.49f, 1.5046f, 1.9f}) for (float alpha : {0.05f, 0.1f, 0.3f}) {
-        ref<RTAccess> ext = new RTAccess(distr == 0 ? MicrofacetDistribution::EBeckmann : MicrofacetDistribution::EGGX);
+    for (int distr = 0; distr < 3; ++distr) for (float eta : {1.49f, 1.5046f, 1.9f}) for (float alpha : {0.05f, 0.1f, 0.3f}) {
+        ref<RTAccess> ext = new RTAccess(distr == 0 ? MicrofacetDistribution::EBeckmann : distr == 1 ? MicrofacetDistribution::EGGX : MicrofacetDistribution::EPhong);
         ext->checkEta(eta); ext->checkAlpha(alpha);
         ref<RoughTransmittance> internal = ext->clone();
         ext->setEta(eta); internal->setEta(1 / eta); ext->setAlpha(alpha);

@@ -91,6 +91,7 @@ def golden_scenes():
         # a crop window of a larger frame (Film cropOffsetX/Y, cropWidth/Height): the camera maps the rendered film onto its part of the full frame
         "cornell_crop": scenes.set_crop_window(scenes.cornell_box(width=60, height=36, spp=8), 192, 108, 70, 40),      # (60 wide, not 64: see sky_view)
         # roughplastic sampling all normals instead of the visible ones (sampleVisible = false)
+        "cbox_roughplastic_phong": scenes.cbox_roughplastic(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=22, phong=True),
         "cbox_roughplastic_allnormals": scenes.cbox_roughplastic(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=21, sample_visible=False),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened

@@ -414,7 +414,7 @@ def test_rough_dielectric_and_difftrans(mi, oracle, golden_scenes, name):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
 
 
-@pytest.mark.parametrize("name", ["cbox_roughplastic", "cbox_roughplastic_allnormals"])
+@pytest.mark.parametrize("name", ["cbox_roughplastic", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong"])
 def test_roughplastic(mi, oracle, golden_scenes, name):
     """`roughplastic`: glossy microfacet coat over a diffuse base; the rough-transmittance slice (100 values, Catmull-Rom lookup over the warped
     incidence angle) is material input data taken from the reference's own tables.  Microfacet code + powf -> tolerance-pinned.  The second scene

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -197,7 +197,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals",
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong",
                                   "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
