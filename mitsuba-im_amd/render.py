@@ -1,9 +1,9 @@
 """Command-line front end: render a Mitsuba XML scene on the MI355X path tracer (what `mitsuba scene.xml` does for the `path` integrator).
 
-    python -m mitsuba-im_amd.render scene.xml [-o out.pfm|out.npy] [-D name=value ...] [--spp N] [--sampler sobol|independent] [--fast-math] [--device K]
+    python -m mitsuba-im_amd.render scene.xml [-o out.exr|out.pfm|out.npy|out.png] [-D name=value ...] [--spp N] [--sampler sobol|independent] [--fast-math] [--device K]
 
-The image written is the developed film (sum / weight, linear RGB, as HDRFilm::develop would hand to its writer); `.pfm` and `.npy` are the
-formats available without an image library.  There is no CPU fallback: without the HIP library / a GPU this exits with an error.
+The image written is the developed film (sum / weight, linear RGB, as HDRFilm::develop would hand to its writer); `.exr` (FLOAT channels, ZIP), `.pfm` and `.npy`
+keep the linear values; `.png` / `.jpg` get ldrfilm's default sRGB encoding (imageio.py).  There is no CPU fallback: without the HIP library / a GPU this exits with an error.
 """
 import argparse
 import sys
@@ -20,8 +20,14 @@ def write_image(path, rgb):
         with open(path, "wb") as f:
             f.write(b"PF\n%d %d\n-1.0\n" % (rgb.shape[1], rgb.shape[0]))
             f.write(rgb[::-1].astype("<f4").tobytes())
+    elif path.endswith(".exr"):
+        from . import imageio
+        imageio.write_exr(path, rgb)
+    elif path.endswith((".png", ".jpg", ".jpeg")):
+        from . import imageio
+        imageio.write_ldr(path, rgb)
     else:
-        raise SystemExit(f"unsupported output format: {path} (.pfm, .npy)")
+        raise SystemExit(f"unsupported output format: {path} (.exr, .pfm, .npy, .png, .jpg)")
 
 
 def main(argv=None):

@@ -13,7 +13,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
     bsdf        diffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
-    texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .npy / .pfm / .hdr or a precomputed pyramid .npz)
+    texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
 
@@ -327,11 +327,24 @@ def self_resolve(reader, filename):
 
 
 # ---- image files for environment maps ----------------------------------------------------------------------------------------------
-def load_image(path, channel=""):
-    """RGB float image [h, w, 3] from .npy, .pfm or Radiance .hdr (OpenEXR needs a library the image does not have).  `channel` ("r", "g", "b", "a" / "y"):
-    that channel alone, as a grey image (BitmapTexture's `channel` parameter, src/textures/bitmap.cpp:261-266; .npy files may hold 2 or 4 channels)."""
+def load_image(path, channel="", gamma=0.0):
+    """Linear RGB float image [h, w, 3] from .npy, .pfm, Radiance .hdr, OpenEXR (scanline, NONE / RLE / ZIP) or, through PIL, PNG / JPEG / BMP / TGA (see
+    imageio.py).  `channel` ("r", "g", "b", "a" / "y"): that channel alone, as a grey image (BitmapTexture's `channel` parameter,
+    src/textures/bitmap.cpp:261-266).  `gamma`: its `gamma` override for 8 / 16-bit files (0 = sRGB for 8-bit data, linear otherwise)."""
+    from . import imageio
     ext = os.path.splitext(path)[1].lower()
-    if ext == ".npy":
+    try:
+        if ext == ".exr":
+            a = imageio._exr_planes(*imageio.read_exr(path))
+        elif ext in (".png", ".jpg", ".jpeg", ".bmp", ".tga"):
+            a = imageio.read_ldr(path, gamma)
+        else:
+            a = None
+    except imageio.ImageError as e:
+        raise SceneError(str(e))
+    if a is not None:
+        pass
+    elif ext == ".npy":
         a = np.load(path).astype(f32)
     elif ext == ".pfm":
         with open(path, "rb") as f:
@@ -341,7 +354,7 @@ def load_image(path, channel=""):
     elif ext in (".hdr", ".rgbe", ".pic"):
         a = _load_rgbe(path)
     else:
-        raise SceneError(f"image format of \"{os.path.basename(path)}\" is not readable here (supported: .npy, .pfm, .hdr)")
+        raise SceneError(f"image format of \"{os.path.basename(path)}\" is not readable here (supported: .exr, .png, .jpg, .bmp, .tga, .hdr, .pfm, .npy)")
     if a.ndim == 2:
         a = a[:, :, None]
     if channel:
@@ -470,7 +483,8 @@ class _SceneBuilder:
                 for w, h in d["sizes"]:
                     n = int(w) * int(h) * 3; levels.append((int(w), int(h), np.ascontiguousarray(d["texels"][off:off + n], f32))); off += n
             else:                                        # an image: the pyramid as TMIPMap builds it (bitmap.cpp:363-401: 2-lobed Lanczos, values clamped to [0, 1])
-                base = load_image(path, channel=str(t.get("channel", "")).lower()); levels = S.build_mip_pyramid(base, wrap[wu], wrap[wv], 1.0)
+                chan = str(t.get("channel", "")).lower()
+                base = load_image(path, channel=chan, gamma=float(t.get("gamma", 0.0))); levels = S.build_mip_pyramid(base, wrap[wu], wrap[wv], 1.0)
             t.get("gamma", 0.0); t.get("cache", True)
             uvs = t.get("uvscale", 1.0)
             rec = S.make_texture(S.TEXTURE_BITMAP, uoffset=t.get("uoffset", 0.0), voffset=t.get("voffset", 0.0), uscale=t.get("uscale", uvs), vscale=t.get("vscale", uvs),
@@ -729,8 +743,8 @@ class _SceneBuilder:
         elif t == "envmap":
             if self.envmap is not None:
                 raise SceneError("The scene may only contain one environment emitter")          # scene.cpp:541-543
-            e.get("cache", True); e.get("gamma", 0.0)
-            img = load_image(self.r.resolve(e.get("filename")))
+            e.get("cache", True)
+            img = load_image(self.r.resolve(e.get("filename")), gamma=float(e.get("gamma", 0.0)))
             self.envmap = dict(rgb=img.astype(np.float16).astype(f32), to_world=np.eye(4, dtype=f32) if tw is None else tw, scale=float(e.get("scale", 1.0)))   # envmap.cpp:103: half-precision MIP map
             rec = dict(type=S.EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=float(w))
         elif t == "area":

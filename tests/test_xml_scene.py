@@ -222,7 +222,7 @@ def test_images_for_environment_maps(tmp_path):
         f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 2\n"); f.write(bytes([128, 64, 32, 129] * 4))
     np.testing.assert_allclose(X.load_image(str(tmp_path / "e.hdr")), np.tile([1.0, 0.5, 0.25], (2, 2, 1)), rtol=1e-6)
     with pytest.raises(X.SceneError, match="not readable"):
-        X.load_image(str(tmp_path / "e.exr"))
+        X.load_image(str(tmp_path / "e.tiff"))
     body = '<emitter type="envmap"><string name="filename" value="e.pfm"/><float name="scale" value="2"/></emitter>'
     sc = load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body))
     assert sc.envmap["scale"] == 2.0 and sc.envmap["rgb"].shape == (4, 8, 3) and sc.emitters[0]["type"] == S.EMITTER_ENVMAP
