@@ -3,9 +3,9 @@
 The reference reads images through `Bitmap(Bitmap::EAuto, stream)` (src/libcore/bitmap.cpp:2461-2560: OpenEXR, PNG, JPEG, RGBE, PFM, TGA, BMP)
 and hands textures to the MIP map as linear floats (`Bitmap::convert(..., EFloat, gamma 1.0)`, include/mitsuba/core/mipmap.h:160-176).  Here:
 
-  * OpenEXR   -- own reader for single-part scanline files with NONE / RLE / ZIPS / ZIP compression and UINT / HALF / FLOAT channels (the layout of
+  * OpenEXR   -- own reader for single-part scanline files with NONE / RLE / ZIPS / ZIP / PIZ compression and UINT / HALF / FLOAT channels (the layout of
                  the OpenEXR file format: magic 0x01312f76, attribute list, line-offset table, per-block [y, size, data], channels stored line by
-                 line in name order; ZIP / RLE blocks are byte-delta predicted and split into even / odd halves).  PIZ / PXR24 / B44 / DWA and tiled
+                 line in name order; ZIP / RLE blocks are byte-delta predicted and split into even / odd halves).  PXR24 / B44 / DWA and tiled
                  or multi-part files are refused by name.  Own writer (FLOAT channels, ZIP) for rendered films.
   * PNG / JPEG / BMP / TGA -- through PIL when it is importable (it is in this image); 8-bit data is sRGB-encoded by default exactly as the
                  reference assumes (bitmap.cpp:284-287: gamma -1 for EUInt8) and is linearised with its curve (fmtconv.cpp:1092-1102); alpha stays linear.
@@ -72,6 +72,146 @@ def _unrle(buf, expected):
     return bytes(out)
 
 
+# PIZ blocks (the OpenEXR PIZ codec): [minNonZero u16, maxNonZero u16, bitmap bytes, length i32, Huffman stream]; the Huffman stream decodes to
+# 16-bit values, per channel a 2-D Haar-like wavelet (14-bit variant when the block uses fewer than 2^14 distinct values), then a lookup
+# table built from the bitmap of used values maps them back.
+def _huf_decode(d, nraw):
+    im, iM, _tlen, nbits = struct.unpack_from("<4I", d, 0)
+    if im > 65536 or iM > 65536 or im > iM:
+        raise ImageError("OpenEXR: corrupt PIZ Huffman header")
+    p = 20; c = 0; lc = 0
+    lengths = [0] * 65537
+    i = im
+    while i <= iM:                                       # code lengths, 6 bits each; 59..62 = short runs of zeros, 63 = long run (8 more bits)
+        while lc < 6:
+            c = (c << 8) | d[p]; p += 1; lc += 8
+        lc -= 6; l = (c >> lc) & 63
+        if l == 63:
+            while lc < 8:
+                c = (c << 8) | d[p]; p += 1; lc += 8
+            lc -= 8; run = ((c >> lc) & 255) + 6
+            i += run
+        elif l >= 59:
+            i += l - 59 + 2
+        else:
+            lengths[i] = l; i += 1
+        c &= (1 << lc) - 1
+    if i > iM + 1:
+        raise ImageError("OpenEXR: corrupt PIZ Huffman table")
+    count = [0] * 59
+    for l in lengths[im:iM + 1]:
+        count[l] += 1
+    code = 0; first = [0] * 59
+    for l in range(58, 0, -1):                           # canonical codes, longest first
+        nc = (code + count[l]) >> 1; first[l] = code; code = nc
+    table = [0] * (1 << 14); long_codes = {}
+    for sym in range(im, iM + 1):
+        l = lengths[sym]
+        if l == 0:
+            continue
+        cd = first[l]; first[l] += 1
+        if l <= 14:
+            base = cd << (14 - l); e = (sym << 6) | l
+            table[base:base + (1 << (14 - l))] = [e] * (1 << (14 - l))
+        else:
+            long_codes[(l, cd)] = sym
+    rlc = iM; out = []; n = len(d); c = 0; lc = 0; used = 0; app = out.append
+    while len(out) < nraw:
+        while lc < 14 and p < n:
+            c = (c << 8) | d[p]; p += 1; lc += 8
+        e = table[(c >> (lc - 14)) & 0x3FFF] if lc >= 14 else table[(c << (14 - lc)) & 0x3FFF]
+        if e:
+            l = e & 63; sym = e >> 6
+            if l > lc:
+                raise ImageError("OpenEXR: PIZ Huffman stream ends early")
+            lc -= l
+        else:
+            sym = -1
+            for l in range(15, 59):
+                while lc < l and p < n:
+                    c = (c << 8) | d[p]; p += 1; lc += 8
+                if lc < l:
+                    break
+                s2 = long_codes.get((l, (c >> (lc - l)) & ((1 << l) - 1)))
+                if s2 is not None:
+                    sym = s2; lc -= l; break
+            if sym < 0:
+                raise ImageError("OpenEXR: corrupt PIZ Huffman stream")
+        used += l
+        if sym == rlc:
+            while lc < 8 and p < n:
+                c = (c << 8) | d[p]; p += 1; lc += 8
+            lc -= 8; used += 8; run = (c >> lc) & 255
+            if not out or len(out) + run > nraw:
+                raise ImageError("OpenEXR: corrupt PIZ run")
+            out.extend([out[-1]] * run)
+        else:
+            app(sym)
+        c &= (1 << lc) - 1
+    if used != nbits:
+        raise ImageError("OpenEXR: PIZ Huffman stream of unexpected length")
+    return np.asarray(out, np.uint16)
+
+
+def _wdec(l, h, w14):
+    if w14:
+        ls = l.astype(np.int16).astype(np.int32); hs = h.astype(np.int16).astype(np.int32)
+        ai = ls + (hs & 1) + (hs >> 1)
+        return (ai & 0xFFFF).astype(np.uint16), ((ai - hs) & 0xFFFF).astype(np.uint16)
+    m = l.astype(np.int32); dd = h.astype(np.int32)
+    bb = (m - (dd >> 1)) & 0xFFFF
+    aa = (dd + bb - 0x8000) & 0xFFFF
+    return aa.astype(np.uint16), bb.astype(np.uint16)
+
+
+def _wav2_decode(a, max_value):
+    """In-place inverse wavelet of one 2-D plane a[ny, nx] (uint16 view)."""
+    ny, nx = a.shape; w14 = max_value < (1 << 14)
+    n = min(nx, ny); p = 1
+    while p <= n:
+        p <<= 1
+    p >>= 1; p2 = p; p >>= 1
+    while p >= 1:
+        rows = np.arange(0, ny - p2 + 1, p2); cols = np.arange(0, nx - p2 + 1, p2)
+        if len(rows) and len(cols):
+            R, C = np.ix_(rows, cols); R1, C1 = np.ix_(rows + p, cols + p)
+            px, p01, p10, p11 = a[R, C], a[R, C1], a[R1, C], a[R1, C1]
+            i00, i10 = _wdec(px, p10, w14); i01, i11 = _wdec(p01, p11, w14)
+            a[R, C], a[R, C1] = _wdec(i00, i01, w14)
+            a[R1, C], a[R1, C1] = _wdec(i10, i11, w14)
+        if (nx & p) and len(rows):
+            cx = len(cols) * p2
+            a[rows, cx], a[rows + p, cx] = _wdec(a[rows, cx], a[rows + p, cx], w14)
+        if ny & p:
+            ry = len(rows) * p2
+            if len(cols):
+                a[ry, cols], a[ry, cols + p] = _wdec(a[ry, cols], a[ry, cols + p], w14)
+        p2 = p; p >>= 1
+
+
+def _unpiz(data, channels, w, lines):
+    """One PIZ block -> the block's bytes in the plain scanline layout."""
+    min_nz, max_nz = struct.unpack_from("<HH", data, 0); p = 4
+    bitmap = np.zeros(8192, np.uint8)
+    if min_nz <= max_nz:
+        if max_nz >= 8192:
+            raise ImageError("OpenEXR: corrupt PIZ bitmap")
+        bitmap[min_nz:max_nz + 1] = np.frombuffer(data, np.uint8, max_nz - min_nz + 1, p); p += max_nz - min_nz + 1
+    used = np.unpackbits(bitmap, bitorder="little").astype(bool); used[0] = True
+    lut = np.zeros(65536, np.uint16); vals = np.nonzero(used)[0]; lut[:len(vals)] = vals; max_value = len(vals) - 1
+    length = struct.unpack_from("<i", data, p)[0]; p += 4
+    sizes = [dt.itemsize // 2 for _, dt in channels]
+    nraw = sum(sizes) * w * lines
+    tmp = _huf_decode(data[p:p + length], nraw) if nraw else np.zeros(0, np.uint16)
+    planes = []; q = 0
+    for sz in sizes:
+        block = tmp[q:q + lines * w * sz].reshape(lines, w * sz); q += lines * w * sz
+        for j in range(sz):
+            sub = np.ascontiguousarray(block[:, j::sz]); _wav2_decode(sub, max_value); block[:, j::sz] = sub
+        planes.append(lut[block])
+    return b"".join(planes[ci][ly].astype("<u2").tobytes() for ly in range(lines) for ci in range(len(channels)))
+
+
 def read_exr(path):
     """-> (pixels float32 [h, w, n], channel names in file order)."""
     with open(path, "rb") as f:
@@ -101,7 +241,7 @@ def read_exr(path):
         channels.append((name, _PIXEL[ptype]))
     comp = attrs["compression"][1][0]
     cname, lines_per_block = _COMPRESSION.get(comp, ("?", 1))
-    if cname not in ("NONE", "RLE", "ZIPS", "ZIP"):
+    if cname not in ("NONE", "RLE", "ZIPS", "ZIP", "PIZ"):
         raise ImageError(f"OpenEXR: {cname} compression is not supported (re-save with ZIP or no compression)")
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
@@ -122,6 +262,8 @@ def read_exr(path):
                 data = _unpredict(zlib.decompress(data))
             elif cname == "RLE":
                 data = _unpredict(_unrle(data, expected))
+            elif cname == "PIZ":
+                data = _unpiz(data, channels, w, lines)
         if len(data) != expected:
             raise ImageError("OpenEXR: block of unexpected size")
         q = 0

@@ -328,7 +328,7 @@ def self_resolve(reader, filename):
 
 # ---- image files for environment maps ----------------------------------------------------------------------------------------------
 def load_image(path, channel="", gamma=0.0):
-    """Linear RGB float image [h, w, 3] from .npy, .pfm, Radiance .hdr, OpenEXR (scanline, NONE / RLE / ZIP) or, through PIL, PNG / JPEG / BMP / TGA (see
+    """Linear RGB float image [h, w, 3] from .npy, .pfm, Radiance .hdr, OpenEXR (scanline, NONE / RLE / ZIP / PIZ) or, through PIL, PNG / JPEG / BMP / TGA (see
     imageio.py).  `channel` ("r", "g", "b", "a" / "y"): that channel alone, as a grey image (BitmapTexture's `channel` parameter,
     src/textures/bitmap.cpp:261-266).  `gamma`: its `gamma` override for 8 / 16-bit files (0 = sRGB for 8-bit data, linear otherwise)."""
     from . import imageio
