@@ -100,16 +100,20 @@ def srgb_to_linear(v):
 _HAT_TABLE = None
 
 
-def spectrum_to_rgb(pairs):
-    """<spectrum value="wavelength:value, ..."> in an RGB build: InterpolatedSpectrum + zeroExtend + Spectrum::fromContinuousSpectrum
-    (src/libcore/spectrum.cpp:172-185, :630-650).  The conversion is linear in the spectrum, so it is applied through the reference's own response
-    to hat functions on a 10-nm grid over 360..830 nm (mitsuba-im_amd/data/spectrum_hat_response.npy, dumped by oracle/_ref/harness `tables`)."""
+def _load_hat_table():
     global _HAT_TABLE
     if _HAT_TABLE is None:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "spectrum_hat_response.npy")
         if not os.path.exists(path):
             raise SceneError("wavelength:value spectra need mitsuba-im_amd/data/spectrum_hat_response.npy")
         _HAT_TABLE = np.load(path).astype(np.float64)
+
+
+def spectrum_to_rgb(pairs):
+    """<spectrum value="wavelength:value, ..."> in an RGB build: InterpolatedSpectrum + zeroExtend + Spectrum::fromContinuousSpectrum
+    (src/libcore/spectrum.cpp:172-185, :630-650).  The conversion is linear in the spectrum, so it is applied through the reference's own response
+    to hat functions on a 10-nm grid over 360..830 nm (mitsuba-im_amd/data/spectrum_hat_response.npy, dumped by oracle/_ref/harness `tables`)."""
+    _load_hat_table()
     wl = [float(f32(w)) for w, _ in pairs]; val = [float(f32(v)) for _, v in pairs]
     if len(wl) < 2:
         raise SceneError("InterpolatedSpectrum::zeroExtend() -- at least 2 entries are needed!")
@@ -118,14 +122,33 @@ def spectrum_to_rgb(pairs):
         wl.insert(0, wl[0] - spacing); val.insert(0, 0.0)
     if val[-1] != 0:
         wl.append(wl[-1] + spacing); val.append(0.0)
+    return _continuous_to_rgb(lambda x: np.interp(x, wl, val, left=0.0, right=0.0))
+
+
+def blackbody_to_rgb(temperature, scale=1.0):
+    """<blackbody temperature="5000K" scale=".."/> (scenehandler.cpp:618-631): BlackBodySpectrum::eval (src/libcore/spectrum.cpp:483-495, Planck's law
+    in W m^-2 nm^-1 sr^-1) through fromContinuousSpectrum + clampNegative, times scale."""
+    _load_hat_table()
+    t = float(f32(temperature))
+    if not t > 0:
+        raise SceneError("<blackbody>: the temperature must be positive")
+    c, k, h = 299792458.0, 1.3806488e-23, 6.62606957e-34
+
+    def planck(x):
+        lam = np.asarray(x, np.float64) * 1e-9
+        return ((2 * h * c * c) * lam ** -5.0 / (np.expm1((h / k) * c / (lam * t)) * 1e9)).astype(f32).astype(np.float64)
+    return tuple(float(f32(f32(v) * f32(scale))) for v in _continuous_to_rgb(planck))
+
+
+def _continuous_to_rgb(f):
     step = 470.0 / (len(_HAT_TABLE) - 1)
     grid = 360.0 + step * np.arange(len(_HAT_TABLE))
-    coarse = np.interp(grid, wl, val, left=0.0, right=0.0)            # the spectrum's interpolant on the table's knots: converted by the table
+    coarse = f(grid)                                                  # the spectrum's interpolant on the table's knots: converted by the table
     rgb = coarse @ _HAT_TABLE
     # what the 10-nm interpolant misses (detail between its knots) is small and oscillating; it is integrated against an analytic fit of the CIE 1931
     # observer (Wyman, Sloan, Shirley, "Simple Analytic Approximations to the CIE XYZ Color Matching Functions", JCGT 2013) and converted like fromXYZ
     fine = np.linspace(360.0, 830.0, 470 * 8 + 1)
-    resid = np.interp(fine, wl, val, left=0.0, right=0.0) - np.interp(fine, grid, coarse)
+    resid = f(fine) - np.interp(fine, grid, coarse)
 
     def lobe(mu, s1, s2):
         t = (fine - mu) / np.where(fine < mu, s1, s2)
@@ -282,8 +305,11 @@ class _Reader:
             return _parse_transform(elem, self.subst)
         if tag == "animation":
             raise SceneError("animated transforms are not supported (the path renders one shutter instant)")
-        if tag == "blackbody":
-            raise SceneError("<blackbody> spectra are not supported")
+        if tag == "blackbody":                                # scenehandler.cpp:618-631: temperature with an optional trailing K, optional scale
+            t = self.subst(a.get("temperature", "")).strip()
+            if t[-1:].upper() == "K":
+                t = t[:-1]
+            return blackbody_to_rgb(_float(t, "blackbody"), _float(self.subst(a["scale"]), "blackbody") if "scale" in a else 1.0)
         tok = _tokens(v)
         if tag in ("rgb", "srgb"):
             if len(tok) == 1 and len(tok[0]) == 7 and tok[0][0] == "#":

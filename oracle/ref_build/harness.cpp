@@ -814,6 +814,16 @@ static void modeSpectrum(int argc, char **argv) {
     printf("%.9g %.9g %.9g\n", r, g, b);
 }
 
+/// <blackbody temperature=.. /> as the scene loader converts it (scenehandler.cpp:618-631): one "r g b" line per temperature
+static void modeBlackbody(int argc, char **argv) {
+    for (int i = 2; i < argc; ++i) {
+        BlackBodySpectrum bb((Float) atof(argv[i]));
+        Spectrum d; d.fromContinuousSpectrum(bb); d.clampNegative();
+        Float r, g, b; d.toLinearRGB(r, g, b);
+        printf("%.9g %.9g %.9g\n", r, g, b);
+    }
+}
+
 int main(int argc, char **argv) {
     Class::staticInitialization();
     Object::staticInitialization();
@@ -828,9 +838,10 @@ int main(int argc, char **argv) {
     Thread::getThread()->getLogger()->setLogLevel(EWarn);
     Thread::getThread()->getFileResolver()->appendPath(fs::pathstr(MI_REF_ROOT));   // data/microfacet/*.dat, data/ior/*.spd (roughplastic, named conductors)
     if (argc >= 8 && std::string(argv[1]) == "mipmap") { modeMipmap(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), argv[7], argc >= 9 ? (std::string(argv[8]) == "inf" ? std::numeric_limits<Float>::infinity() : (Float) atof(argv[8])) : 1.0f); fflush(NULL); _exit(0); }
+    if (argc >= 3 && std::string(argv[1]) == "blackbody") { modeBlackbody(argc, argv); fflush(NULL); _exit(0); }
     if (argc >= 6 && std::string(argv[1]) == "spectrum") { modeSpectrum(argc, argv); fflush(NULL); _exit(0); }
     if (argc >= 10 && std::string(argv[1]) == "mesh") { modeMesh(argc, argv); fflush(NULL); _exit(0); }
-    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | spectrum <wl value>... | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> [maxValue|inf] | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
+    if (argc < 3) { fprintf(stderr, "usage: harness tables <outdir> | spectrum <wl value>... | blackbody <kelvin>... | mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [toWorld x16] | mipmap <rgb.bin> <w> <h> <bcu> <bcv> <out> [maxValue|inf] | <scene> samples <pairs.bin> <out> | <scene> image <threads> <out> | <scene> hits <step> <out> | <scene> camera <out> | <scene> units <out> | <scene> responsive <plugin> <stopAfterProgressCalls|-1> <out>\n"); _exit(1); }
     std::string a1 = argv[1];
     if (a1 == "tables") { modeTables(argv[2]); fflush(stdout); _exit(0); }
     FScene fs = loadScene(argv[1]);

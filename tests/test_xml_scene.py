@@ -274,3 +274,20 @@ def test_mask_with_alpha_channel_texture(tmp_path):
     assert t["color0"] == pytest.approx((0.25, 0.25, 0.25))                  # the average opacity (16 of 64 texels)
     with pytest.raises(X.SceneError, match='Channel "q" not found'):
         load_text(tmp_path, MINIMAL.format(sensor="", film="", body=body.replace('value="a"', 'value="q"')))
+
+
+def test_blackbody_spectra_match_reference(tmp_path):
+    """<blackbody temperature="..K" scale=".."/> (scenehandler.cpp:618-631) against the reference's own conversion of BlackBodySpectrum
+    (tests/golden/blackbody_rgb.npz, from oracle/_ref/harness `blackbody`): within 5e-5 of the largest channel."""
+    g = np.load(os.path.join(HERE, "golden", "blackbody_rgb.npz"))
+    for t, rgb in zip(g["temperature"], g["rgb"]):
+        mine = np.array(X.blackbody_to_rgb(float(t)))
+        assert np.abs(mine - rgb).max() / rgb.max() < 5e-5, (t, mine, rgb)
+    p = tmp_path / "bb.xml"
+    p.write_text("""<scene version="0.5.0"><integrator type="path"/><sensor type="perspective"><sampler type="independent"/><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>
+<shape type="rectangle"><emitter type="area"><blackbody name="radiance" temperature="$temp" scale="1e-4"/></emitter></shape></scene>""")
+    sc = X.load_scene(str(p), params={"temp": "5000K"})
+    want = np.array(X.blackbody_to_rgb(5000.0, 1e-4))
+    assert np.allclose(sc.emitters[0]["radiance"], want, rtol=1e-6) and abs(want[0] - 1.52633) < 1e-3
+    with pytest.raises(X.SceneError):
+        X.load_scene(str(p), params={"temp": "warm"})
