@@ -3,7 +3,7 @@ HIP path tracer uploads (the same `scenes.Scene` record the synthetic generators
 be rendered without it.
 
 What is read (reference: src/librender/scenehandler.cpp:104-140 tag table, :300-800 property handlers): <scene>, <default> / $name
-substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <vector> <rgb> <srgb> <spectrum>, <transform> with
+substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <vector> <rgb> <srgb> <spectrum> <blackbody>, <transform> with
 <translate> <rotate> <scale> <matrix> <lookat>, and the plugin tags <integrator> <sensor> <sampler> <film> <rfilter> <shape> <bsdf>
 <texture> <emitter>.  Plugins understood = the ones the hot path implements:
     integrator  path
