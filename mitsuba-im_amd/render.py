@@ -62,7 +62,7 @@ def main(argv=None):
     except (xml_scene.SceneError, MiError, OSError) as e:
         print(f"error: {e}", file=sys.stderr)
         return 1
-    out = a.output or (a.scene.rsplit(".", 1)[0] + ".pfm")
+    out = a.output or (a.scene.rsplit(".", 1)[0] + ".exr")          # hdrfilm's default fileFormat (src/films/hdrfilm.cpp: openexr)
     write_image(out, rgb)
     n = sc.width * sc.height * sc.spp
     print(f"{sc.name}: {sc.width}x{sc.height}, {sc.spp} spp, {len(sc.idx)} triangles; load {t1 - t0:.2f} s, upload+BVH {t2 - t1:.2f} s, "
