@@ -58,3 +58,23 @@ def test_two_rank_tiles_reduce_to_single_rank_film(tmp_path):
     assert inner.mean() > 0.999
     got2 = np.load(tmp_path / "film_interleaved.npy")
     assert np.allclose(got2, full, rtol=1e-6, atol=1e-7) and (got2[1:-1, 1:-1].view(np.uint32) == full[1:-1, 1:-1].view(np.uint32)).mean() > 0.99
+
+
+def test_bench_launcher_self_spawns_ranks():
+    """`python bench.py --gpus 2` called plainly must start its own ranks (the driver's scaling run calls it that way): the parent spawns two
+    children with RANK / WORLD_SIZE set, they rendezvous (gloo here, RCCL on the GPUs), interleave the film rows, reduce, and rank 0 prints ONE JSON line.
+    --dry-run stops before the GPU work, everything up to it is the code path of the real run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--scaling", "strong"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rows_covered_once"] and out["scaling"] == "strong"
+    # under an external launcher (torch.distributed.run sets WORLD_SIZE) the script must NOT spawn again
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo"],
+                       env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
