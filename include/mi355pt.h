@@ -106,7 +106,7 @@ typedef struct {
     int32_t max_depth, rr_depth;
     uint32_t strict_normals, hide_emitters;
     uint32_t sampler, spp;
-    uint64_t seed;               /* independent: seed; sobol: scramble (must be 0) */
+    uint64_t seed;               /* independent: seed of the counter stream; sobol: the sampler's `scramble` value (0 = unscrambled; src/samplers/sobol.cpp:92-102) */
     uint32_t device;             /* HIP device ordinal */
     uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
     uint32_t opacity;            /* 1: alpha = 1 where the camera ray hits a surface, else 0 (RadianceQueryRecord::EOpacity, records.inl:121-137:
@@ -176,7 +176,8 @@ int mi_render_run(mi_render *r, mi_tile tile, uint32_t sample_begin, uint32_t sa
  * (rank k of N renders tile {0, k, W, H} with row_stride N). */
 int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t row_stride, uint32_t sample_begin, uint32_t sample_end);
 int mi_render_clear(mi_render *r);                  /* ImageBlock::clear */
-void mi_render_cancel(mi_render *r);                /* Integrator::cancel: thread-safe flag, observed between batches */
+void mi_render_cancel(mi_render *r);                /* Integrator::cancel: thread-safe flag, observed before every batch: the run that sees it returns MI_CANCELLED
+                                                       and consumes it (a cancel issued between two runs stops the next one); mi_render_clear drops a pending cancel */
 /* Film read-back.  layout 0: raw ImageBlock sums (H+2b) x (W+2b) x 5 {R,G,B,alpha,weight} incl. border (classic, ESpectrumAlphaWeight);
  * layout 1: (H+2b) x (W+2b) x 4 RGBA sums (responsive target, src/im-mts/scene.cpp:317-321); layout 2: H x W x 3 developed RGB = sum/weight. */
 int mi_render_film_size(mi_render *r, int layout, uint32_t *height, uint32_t *width, uint32_t *channels, uint32_t *border);
@@ -185,13 +186,14 @@ int mi_render_read_film_device(mi_render *r, int layout, void *device_out);   /*
 /* Debug / parity: Li of individual (px, py, sampleIndex) triples through the very same kernels; out_li[n*3] */
 int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *out_li);
 int mi_render_stats(mi_render *r, mi_stats *out);
-int mi_render_set_profiling(mi_render *r, int enabled);   /* per-stage HIP-event timing (serialises stages; off by default) */
+int mi_render_set_profiling(mi_render *r, int enabled);   /* per-stage HIP-event timing: events are recorded between the stage launches of the first stream, nothing is serialised (off by default) */
 
 /* Unit-level device entry points used by the parity tests (each runs a small kernel over n items) */
 int mi_debug_intersect(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4);   /* t,u,v,prim (prim<0: miss) */
 int mi_debug_intersect_inst(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4, int32_t *out_instance);   /* + instance index of the hit (-1: scene-level primitive) */
 int mi_debug_sobol(mi_scene *s, const uint32_t *px_py_k, uint64_t n, uint32_t ndims, uint64_t *out_index, float *out_values);
 int mi_debug_camera_rays(mi_scene *s, const float *sample_pos2, uint64_t n, float *out_rays8);
+int mi_debug_sincosf(const float *x, uint64_t n, float *out_sin_cos2);   /* the device restatement of glibc's sincosf (warps): out[2i] = sin, out[2i+1] = cos */
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,7 @@ EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_s
            "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_envmap_filter", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
-           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays"]
+           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays", "mi_debug_sincosf"]
 HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
 
 
@@ -117,6 +117,7 @@ class Lib:
         L.mi_debug_intersect_inst.argtypes = [vp, vp, u64, i32, vp, vp]
         L.mi_debug_sobol.argtypes = [vp, vp, u64, u32, vp, vp]
         L.mi_debug_camera_rays.argtypes = [vp, vp, u64, vp]
+        L.mi_debug_sincosf.argtypes = [vp, u64, vp]
 
     def check(self, rc):
         if rc != 0:
@@ -148,6 +149,12 @@ def load_sobol_tables(L, path=SOBOL_PATH):
 
 def _p(a):
     return None if a is None else a.ctypes.data
+
+
+def device_sincosf(x):
+    """glibcSincosf of pt_device.h on an array of floats -> (sin, cos)."""
+    L = lib(); a = np.ascontiguousarray(x, np.float32).reshape(-1); out = np.zeros((len(a), 2), np.float32)
+    L.check(L.L.mi_debug_sincosf(_p(a), len(a), _p(out))); return out[:, 0], out[:, 1]
 
 
 class Scene:

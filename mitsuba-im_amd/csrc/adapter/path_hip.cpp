@@ -625,7 +625,7 @@ public:
         m_host.reset(new mi355::MIPathTracerHIP(hp));
         m_gpu.build(scene, sensor, m_host->getProperties().device);
         m_host->preprocess(m_gpu.scene);
-        int stop = 0; mi355::Controls c{nullptr, &stop, nullptr};
+        mi355::Controls c{nullptr, nullptr, nullptr};     // no preview, no interrupt: one submission (RenderJob::cancel reaches it through cancel() below)
         int rc;
         try { rc = m_host->render(nullptr, c, 0, 1); } catch (const std::exception &e) { Log(EError, "%s", e.what()); return false; }
         if (rc != 0) return false;                                                      // cancelled

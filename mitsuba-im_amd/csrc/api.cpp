@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "scene_host.h"
@@ -24,6 +25,7 @@ void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float 
 void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, int *, hipStream_t);
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
 void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
+void mi_launch_debug_sincosf(const float *, uint64_t, float *, hipStream_t);
 // fast-arithmetic twins (kernels_fast.hip)
 void mi_launch_generate_fast(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend_fast(const DScene &, const Queues &, int, uint32_t, hipStream_t);
@@ -403,6 +405,11 @@ static int allocPool(mi_render *r, uint64_t paths) {
     return MI_OK;
 }
 
+// LDS bytes k_shade stages for a small scene (shading records, materials, emitters, CDFs); must match mi_launch_shade (kernels.hip)
+static size_t smallTableBytes(const mi::SceneHost &h) {
+    if (!h.d.small_tables) return 0;
+    return 16 + 4 * ((size_t) h.d.n_tris * 24 + h.d.n_materials * 16 + h.d.n_emitters * 12 + ((h.d.n_emitters + 4) & ~3u) + h.d.area_cdf_len);
+}
 int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (!s || !p || !out) return fail(MI_ERR_INVALID, "mi_render_create: null argument");
     if (!s->h.committed) return fail(MI_ERR_INVALID, "mi_render_create: scene not committed");
@@ -421,6 +428,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     }
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
+    struct Guard { mi_render *r; ~Guard() { if (r) mi_render_destroy(r); } } guard{r};      // every early return below releases what was created so far
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
     r->rc.sobol_scramble = 0;
     if (p->sampler == MI_SAMPLER_SOBOL && p->seed) {          // SobolSampler: a nonzero `scramble` goes through sampleTEA (sobol.cpp:96-102; qmc.h:146-156, 4 rounds)
@@ -444,7 +452,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
             uint32_t x = 0; for (uint32_t b = 0; b < 4; ++b) if (((v >> b) & 1u) && 4 * n + b < MI_SOBOL_SIZE) x ^= g_sobolM32[(size_t) dmn * MI_SOBOL_SIZE + 4 * n + b];
             nib[((size_t) dmn * nibs + n) * 16 + v] = x;
         }
-        if ((size_t) dims * nibs * 64 > 64 * 1024) { delete r; return fail(MI_ERR_UNSUPPORTED, "mi_render_create: Sobol lookup tables exceed the LDS budget (reduce maxDepth)"); }
+        if ((size_t) dims * nibs * 64 + smallTableBytes(s->h) + 64 > 64 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the Sobol lookup tables (maxDepth x index bits) and the staged scene tables exceed the 64 KB of LDS a workgroup may request (reduce maxDepth or spp)");
         HIPCHK(hipMalloc((void **) &r->dNib, nib.size() * 4)); HIPCHK(hipMemcpy(r->dNib, nib.data(), nib.size() * 4, hipMemcpyHostToDevice));
         r->rc.sobol_nib = r->dNib; r->rc.nib_count = nibs; r->rc.nib_dims = dims;
     }
@@ -460,7 +468,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     HIPCHK(hipMalloc((void **) &r->film, r->filmFloats * 4)); HIPCHK(hipMemset(r->film, 0, r->filmFloats * 4));
     HIPCHK(hipMalloc((void **) &r->spill, r->filmFloats * 4)); HIPCHK(hipMemset(r->spill, 0, r->filmFloats * 4));
     HIPCHK(hipMalloc((void **) &r->layoutTmp, r->filmFloats * 4));
-    *out = r; return MI_OK;
+    guard.r = nullptr; *out = r; return MI_OK;
 }
 void mi_render_destroy(mi_render *r) {
     if (!r) return;
@@ -485,7 +493,7 @@ int mi_render_clear(mi_render *r) {
     HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream)); HIPCHK(hipMemsetAsync(r->spill, 0, r->filmFloats * 4, r->stream));
     if (r->q.counters) HIPCHK(hipMemsetAsync(r->q.counters, 0, 32, r->stream));
     if (r->q2.counters) HIPCHK(hipMemsetAsync(r->q2.counters, 0, 32, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; return MI_OK;
+    HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; r->cancel.store(0); return MI_OK;
 }
 void mi_render_cancel(mi_render *r) { if (r) r->cancel.store(1); }
 int mi_render_set_profiling(mi_render *r, int enabled) { if (!r) return fail(MI_ERR_INVALID, "null"); r->profiling = enabled != 0; return MI_OK; }
@@ -524,8 +532,13 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
 
 int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) { return mi_render_run_rows(r, tile, 1, s0, s1); }
 
+// The triangle packet of a small scene lives in ONE __constant__ symbol per process and device (kernels.hip c_packet): renders of packet-mode
+// scenes are serialised process-wide so that two handles on different small scenes cannot overwrite each other's packet mid-batch.
+static std::mutex g_packetMutex;
 int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t s0, uint32_t s1) {
     if (!r) return fail(MI_ERR_INVALID, "mi_render_run: null");
+    std::unique_lock<std::mutex> packetLock(g_packetMutex, std::defer_lock);
+    if (r->scene->h.d.packet_n) packetLock.lock();
     if (rowStride == 0) return fail(MI_ERR_INVALID, "mi_render_run_rows: row stride must be >= 1");
     const mi::SceneHost &h = r->scene->h;
     if (tile.x1 <= tile.x0 || tile.y1 <= tile.y0 || tile.x1 > h.width || tile.y1 > h.height) return fail(MI_ERR_INVALID, "mi_render_run: tile outside the film");
@@ -539,15 +552,14 @@ int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t 
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
     const uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
-    if (need != r->poolPaths) { int rc = allocPool(r, need); if (rc) return rc; }
-    r->cancel.store(0);
+    if (need > r->poolPaths) { int rc = allocPool(r, need); if (rc) return rc; }      // the pool only grows: a short last batch or a smaller tile reuses it
     size_t evUsed = 0; r->launchesAll = 0;
     HIPCHK(hipEventRecord(r->evBegin, r->stream));
     const bool dual = r->nStreams > 1 && (s1 - s0) > planes;          // more than one batch: alternate the two pools / streams
     if (dual) { HIPCHK(hipEventRecord(r->joinEv, r->stream)); HIPCHK(hipStreamWaitEvent(r->stream2, r->joinEv, 0)); }
     int batch = 0; bool filmPending[2] = {false, false};
     for (uint32_t s = s0; s < s1; s += planes, ++batch) {
-        if (r->cancel.load()) { HIPCHK(hipDeviceSynchronize()); return fail(MI_CANCELLED, "render cancelled"); }
+        if (r->cancel.exchange(0)) { HIPCHK(hipDeviceSynchronize()); return fail(MI_CANCELLED, "render cancelled"); }      // consumed where it is observed
         const int pool = dual ? (batch & 1) : 0; hipStream_t st = pool ? r->stream2 : r->stream;
         BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr; bd.row_stride = rowStride;
         int rc = traceBatch(r, bd, nullptr, evUsed, pool); if (rc) return rc;
@@ -611,13 +623,15 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     if (!r || !pairs || !outLi || !n) return fail(MI_ERR_INVALID, "mi_render_samples: null argument");
     const mi::SceneHost &h = r->scene->h; HIPCHK(hipSetDevice(h.device));
     for (uint64_t i = 0; i < n; ++i) if (pairs[i * 3] >= h.width || pairs[i * 3 + 1] >= h.height) return fail(MI_ERR_INVALID, "mi_render_samples: pixel outside the film");
-    if (n != r->poolPaths) { int rc = allocPool(r, n); if (rc) return rc; }
+    if (n > r->poolPaths) { int rc = allocPool(r, n); if (rc) return rc; }
     uint32_t *dList = nullptr; float *dOut = nullptr; uint32_t *dSlots = nullptr;
     HIPCHK(hipMalloc((void **) &dList, n * 12)); HIPCHK(hipMalloc((void **) &dOut, n * 12)); HIPCHK(hipMalloc((void **) &dSlots, n * 4));
     HIPCHK(hipMemcpy(dList, pairs, n * 12, hipMemcpyHostToDevice));
     std::vector<uint32_t> slots(n); for (uint64_t i = 0; i < n; ++i) slots[i] = (uint32_t) i;
     HIPCHK(hipMemcpy(dSlots, slots.data(), n * 4, hipMemcpyHostToDevice));
     BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList; bd.row_stride = 1;
+    std::unique_lock<std::mutex> packetLock(g_packetMutex, std::defer_lock);
+    if (h.d.packet_n) packetLock.lock();
     size_t evUsed = 0; bool prof = r->profiling; r->profiling = false;
     unsigned long long keep[4]; HIPCHK(hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost));     // the parity entry point leaves the ray counters untouched
     int rc = traceBatch(r, bd, dList, evUsed); r->profiling = prof;
@@ -659,6 +673,10 @@ int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, 
     int rc = withBuffers(in, n * 12, outVals, n * ndims * 4, [&](void *i, void *o) { mi_launch_debug_sobol(s->h.d, (const uint32_t *) i, n, ndims, (unsigned long long *) dIdx, (float *) o, nullptr); });
     if (!rc) { hipError_t e = hipMemcpy(outIdx, dIdx, n * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
     (void) hipFree(dIdx); return rc;
+}
+int mi_debug_sincosf(const float *x, uint64_t n, float *out) {
+    if (!x || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_sincosf: bad argument");
+    return withBuffers(x, n * 4, out, n * 8, [&](void *i, void *o) { mi_launch_debug_sincosf((const float *) i, n, (float *) o, nullptr); });
 }
 int mi_debug_camera_rays(mi_scene *s, const float *pos, uint64_t n, float *out) {
     if (!s || !s->h.committed || !pos || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_camera_rays: bad argument");

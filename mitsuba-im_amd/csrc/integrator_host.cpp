@@ -29,23 +29,31 @@ bool MIPathTracerHIP::allocate(int threadCount) { m_threads = threadCount; retur
 int MIPathTracerHIP::render(float *target, Controls controls, int threadIdx, int threadCount) {
     if (threadIdx != 0) return 0;
     if (!m_render) throw std::runtime_error("MIPathTracerHIP::render: preprocess() was not called");
+    m_cancel.store(0);
     check(mi_render_clear(m_render), "MIPathTracerHIP::render");
     uint32_t h, w, c, b; check(mi_render_film_size(m_render, 1, &h, &w, &c, &b), "MIPathTracerHIP::render");
     const uint32_t spp = m_props.sampleCount;
     uint32_t planes = m_props.planesPerBatch ? m_props.planesPerBatch : std::max<uint32_t>(1, (16u << 20) / ((w - 2 * b) * (h - 2 * b)));
     mi_tile tile{0, 0, w - 2 * b, h - 2 * b};
-    for (uint32_t s = 0; s < spp; s += planes) {
+    // Classic face (no target, no controls: Scene::render has neither a preview nor an interrupt): the whole job is ONE submission, so consecutive
+    // batches alternate between the two path pools / HIP streams inside mi_render_run.  Responsive face: two batches per progress() call -- still both
+    // streams busy, the film is read back (and progress() called on a new sample plane, integrator.cpp:376-378) once per pair.
+    const bool interactive = target || controls.interrupt || controls.abort || controls.continu;
+    const uint32_t chunk = interactive ? (planes >= spp ? planes : 2 * planes) : spp;
+    for (uint32_t s = 0; s < spp; s += chunk) {
+        if (m_cancel.load()) return -1;                                        // Integrator::cancel (any thread, any time)
         if (controls.abort && *controls.abort) return -1;
         if (controls.continu && !*controls.continu) return -2;
         if (controls.interrupt) { int rc = controls.interrupt->progress(this, target, (double) s, controls, threadIdx, threadCount); if (rc != 0) return rc; }
-        int rc = mi_render_run(m_render, tile, s, std::min(spp, s + planes));
+        if (m_cancel.load()) return -1;
+        int rc = mi_render_run(m_render, tile, s, std::min(spp, s + chunk));
         if (rc == MI_CANCELLED) return -1;
         check(rc, "MIPathTracerHIP::render");
         if (target) check(mi_render_read_film(m_render, 1, target), "MIPathTracerHIP::render");
     }
-    return 0;
+    return m_cancel.load() ? -1 : 0;
 }
-void MIPathTracerHIP::cancel() { if (m_render) mi_render_cancel(m_render); }
+void MIPathTracerHIP::cancel() { m_cancel.store(1); if (m_render) mi_render_cancel(m_render); }
 
 const char *MIPathTracerHIP::getRealtimeStatistics() {
     if (!m_render) return nullptr;

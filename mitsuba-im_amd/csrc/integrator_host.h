@@ -10,6 +10,7 @@
 // It sits directly on the C-ABI (include/mi355pt.h) and carries no reference types, so it builds without the reference; the adapter plugin
 // (adapter/path_hip.cpp) wraps it in the real mitsuba::Integrator / ResponsiveIntegrator classes.
 #pragma once
+#include <atomic>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -53,6 +54,7 @@ public:
     std::string toString() const;
 private:
     Properties m_props; mi_scene *m_scene = nullptr; mi_render *m_render = nullptr; std::string m_stats; int m_threads = 1;
+    std::atomic<int> m_cancel{0};   // set by cancel(), reset at the start of render(): a cancel between two batches or two mi_render_run calls is never lost
 };
 
 }  // namespace mi355

@@ -644,6 +644,10 @@ __global__ void k_debug_sobol(DScene sc, const uint32_t *in, uint64_t n, uint32_
     outIdx[i] = idx;
     for (uint32_t dmn = 0; dmn < ndims; ++dmn) outVals[i * ndims + dmn] = sobolSample(sc.sobol_m32, idx, dmn);
 }
+__global__ void k_debug_sincosf(const float *in, uint64_t n, float *out) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float s, c; glibcSincosf(in[i], s, c); out[i * 2] = s; out[i * 2 + 1] = c; }
+}
 __global__ void k_debug_camera(DScene sc, const float *pos, uint64_t n, float *out) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -661,12 +665,13 @@ void MI_FN(mi_upload_packet)(const TriAccelD *tris, uint32_t n, const AnalyticD 
     if (n) (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_packet), tris, n * sizeof(TriAccelD), 0, hipMemcpyHostToDevice, st);
     if (na) (void) hipMemcpyToSymbolAsync(HIP_SYMBOL(c_analytic), an, na * sizeof(AnalyticD), 0, hipMemcpyHostToDevice, st);
 }
+static const bool kForceStack24 = getenv("MI355PT_STACK24") != nullptr;      // A/B switch, read once
 #define MI_BY_STACK(KERNEL, AN, ...) do { \
     if (sc.packet_n) hipLaunchKernelGGL((KERNEL<0, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 8) hipLaunchKernelGGL((KERNEL<8, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 12) hipLaunchKernelGGL((KERNEL<12, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((KERNEL<16, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 20 && !getenv("MI355PT_STACK24")) hipLaunchKernelGGL((KERNEL<20, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 20 && !kForceStack24) hipLaunchKernelGGL((KERNEL<20, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 24) hipLaunchKernelGGL((KERNEL<24, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else if (sc.bvh_depth <= 28) hipLaunchKernelGGL((KERNEL<28, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
@@ -679,7 +684,10 @@ void MI_FN(mi_launch_shade)(const DScene &sc, const RenderConst &rc, const Queue
     const bool env = sc.env_index >= 0, small = sc.small_tables != 0;
     if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
     RenderConst rcl = rc; rcl.order_offset_words = 0;
-    if (sc.has_roughconductor && q.cap <= 8192u) { rcl.order_offset_words = (uint32_t) ((lds + 15) / 16 * 4); lds = (size_t) rcl.order_offset_words * 4 + (size_t) q.cap * 2 * (WG / 64) + 16; }
+    if (sc.has_roughconductor && q.cap <= 8192u) {      // material-order list: only where it still fits the 64 KB a launch may request (else unsorted shading)
+        const uint32_t off = (uint32_t) ((lds + 15) / 16 * 4); const size_t total = (size_t) off * 4 + (size_t) q.cap * 2 * (WG / 64) + 16;
+        if (total <= 64 * 1024) { rcl.order_offset_words = off; lds = total; }
+    }
 #define MI_SHADE(RC, ENV, SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
                                    else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
                                    else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); } while (0)
@@ -701,6 +709,7 @@ void mi_launch_film_layout(const float *film, const float *spill, float *out, in
 void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_gather_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, q, slots, n, out); }
 void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out, outInst); }
 void mi_launch_debug_sobol(const DScene &sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *oi, float *ov, hipStream_t st) { hipLaunchKernelGGL(k_debug_sobol, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, in, n, ndims, oi, ov); }
+void mi_launch_debug_sincosf(const float *in, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_sincosf, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, in, n, out); }
 void mi_launch_debug_camera(const DScene &sc, const float *pos, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_camera, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, pos, n, out); }
 #endif
 }

@@ -1,6 +1,6 @@
 // pt_device.h -- device-side arithmetic of the path tracer (gfx950).  Each function names the reference code it
 // implements (paths relative to the reference tree).  Compiled with -ffp-contract=off and IEEE division / sqrt
-// (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt): together with the polynomial sin/cos below this makes
+// (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt): together with the fp64 restatement of glibc's sincosf below this makes
 // every radiance sample reproducible bit for bit against a strict-IEEE CPU evaluation of the same formulas
 // (DESIGN.md §"arithmetic contract"), which is what the parity tests check.
 #pragma once
@@ -124,15 +124,41 @@ DEV void next2D(SamplerState &s, uint32_t kind, SobolTabT<P> st, float &x, float
 }
 
 // ---------------------------------------------------------------------------------------------- warps
-// sin/cos on [-pi/4, pi/4] by fixed polynomials (Cephes single-precision coefficients), evaluated without contraction
-DEV float sinp(float x) { float z = x * x; float y = -1.9515295891e-4f * z; y = y + 8.3321608736e-3f; y = y * z; y = y - 1.6666654611e-1f; y = y * z; y = y * x; return y + x; }
-DEV float cosp(float x) { float z = x * x; float y = 2.443315711809948e-5f * z; y = y - 1.388731625493765e-3f; y = y * z; y = y + 4.166664568298827e-2f; y = y * z; y = y * z; float h = 0.5f * z; y = y - h; return y + 1.0f; }
-// src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric (second branch through sin(pi/2-x) = cos x, cos(pi/2-x) = sin x)
+// glibc's sincosf, restated: the reference calls math::sincos = ::sincosf (include/mitsuba/core/math.h:219-221) in its warps, and a radiance
+// sample can only equal the reference's bit for bit if the sine / cosine do.  glibc >= 2.28 (sysdeps/ieee754/flt-32/s_sincosf.c, the algorithm
+// of ARM's optimized-routines) evaluates both in binary64: |y| < pi/4 -> two short polynomials in y; otherwise n = round(y * 2/pi),
+// r = y - n * pi/2, the polynomials in r, swapped / negated by the quadrant.  Same operations, same order, no contraction: identical to glibc 2.35
+// for EVERY float in [-8, 8] (2.18e9 arguments, scripts/check_sincosf.c; arguments on the path are <= 2 pi).  |y| >= 120 (never reached) falls
+// back to the device library.
+DEV void glibcSincosf(float y, float &sn, float &cs) {
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    double x = (double) y, x2; int n = 0; bool neg = false;
+    if (top < 0x3f4u) {                        // |y| < pi/4
+        if (top < 0x398u) { sn = y; cs = 1.0f; return; }      // |y| < 2^-12
+        x2 = x * x;
+    } else if (top < 0x42fu) {                 // |y| < 120: reduce_fast
+        const double r = x * 0x1.45F306DC9C883p+23;
+        n = ((int) r + 0x800000) >> 24;
+        x = x - (double) n * 0x1.921FB54442D18p0;
+        x2 = x * x;
+        if (((n & 3) == 1) || ((n & 3) == 2)) x = -x;         // sign[n & 3] = {1, -1, -1, 1}
+        neg = (n & 2) != 0;
+    } else { sn = sinf(y); cs = cosf(y); return; }
+    const double c0 = neg ? -0x1p0 : 0x1p0, c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2, c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5,
+                 c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10, c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double x4 = x2 * x2, x3 = x2 * x, cc2 = c3 + x2 * c4, ss1 = s2 + x2 * s3, cc1 = c0 + x2 * c1, x5 = x3 * x2, x6 = x4 * x2;
+    const double s = x + x3 * s1, c = cc1 + x4 * c2;
+    const float sv = (float) (s + x5 * ss1), cv = (float) (c + x6 * cc2);
+    if (n & 1) { sn = cv; cs = sv; } else { sn = sv; cs = cv; }
+}
+// src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric
 DEV void diskConcentric(float sx, float sy, float &ox, float &oy) {
-    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, sn, cs;
-    if (r1 == 0 && r2 == 0) { ox = 0; oy = 0; return; }
-    if (r1 * r1 > r2 * r2) { r = r1; float x = (MI_PI / 4.0f) * (r2 / r1); sn = sinp(x); cs = cosp(x); }
-    else { r = r2; float x = (r1 / r2) * (MI_PI / 4.0f); sn = cosp(x); cs = sinp(x); }
+    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, phi, sn, cs;
+    if (r1 == 0 && r2 == 0) r = phi = 0;
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (MI_PI / 4.0f) * (r2 / r1); }
+    else { r = r2; phi = (MI_PI / 2.0f) - (r1 / r2) * (MI_PI / 4.0f); }
+    glibcSincosf(phi, sn, cs);
     ox = r * cs; oy = r * sn;
 }
 // warp.cpp:43-52 squareToCosineHemisphere
@@ -435,15 +461,8 @@ DEV v3 toLocal(const Hit &h, v3 w) { return V(dot(w, h.s), dot(w, h.t), dot(w, h
 // fill :421-427): src/shapes/rectangle.cpp, disk.cpp, sphere.cpp, cylinder.cpp.  The quadrics are solved in double precision like
 // the reference (solveQuadraticDouble, src/libcore/util.cpp:489-527).
 // include/mitsuba/core/transform.h:126-135 transformAffine(Point), :172-181 operator()(Vector), :199-207 operator()(Normal); m = rows 0..2 of the 4x4
-// sin / cos of 2*pi*u, u in [0, 1]: quadrant reduction + the polynomial pair (the reference calls sincosf(2*pi*u); arithmetic contract)
-DEV void sincos2pi(float u, float &sn, float &cs) {
-    float k = floorf(u * 4.0f + 0.5f);
-    float a = (u - k * 0.25f) * (2.0f * MI_PI);
-    float sa = sinp(a), ca = cosp(a);
-    int q = ((int) k) & 3;
-    sn = q == 0 ? sa : (q == 1 ? ca : (q == 2 ? -sa : -ca));
-    cs = q == 0 ? ca : (q == 1 ? -sa : (q == 2 ? -ca : sa));
-}
+// math::sincos(2.0f * M_PI * u) of squareToUniformSphere / squareToUniformCone (warp.cpp:29, :59) and Cylinder::samplePosition (cylinder.cpp:234)
+DEV void sincos2pi(float u, float &sn, float &cs) { glibcSincosf((2.0f * MI_PI) * u, sn, cs); }
 DEV bool solveQuadraticDouble(double a, double b, double c, double &x0, double &x1) {
     if (a == 0) { if (b != 0) { x0 = x1 = -c / b; return true; } return false; }
     double discrim = b * b - 4.0 * a * c;

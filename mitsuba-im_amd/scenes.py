@@ -143,18 +143,89 @@ def look_at(origin, target, up):
     return m
 
 
+_LIBM = None
+
+
+def _tanf(x):
+    """glibc tanf: std::tan(float) of the reference's Transform::perspective (numpy's float32 tan is its own SIMD routine)."""
+    global _LIBM
+    if _LIBM is None:
+        import ctypes
+        _LIBM = ctypes.CDLL("libm.so.6"); _LIBM.tanf.restype = ctypes.c_float; _LIBM.tanf.argtypes = [ctypes.c_float]
+    return f32(_LIBM.tanf(float(x)))
+
+
+def _mat_mul_f32(a, b):
+    """Matrix<4,4,float> operator* (include/mitsuba/core/matrix.h:743-756): float accumulation, k ascending, sum starts at 0."""
+    r = np.zeros((4, 4), f32)
+    for i in range(4):
+        for j in range(4):
+            acc = f32(0)
+            for k in range(4):
+                acc = f32(acc + f32(a[i, k] * b[k, j]))
+            r[i, j] = acc
+    return r
+
+
+def _mat_invert_f32(m):
+    """Matrix::invert (include/mitsuba/core/matrix.inl:138-191): Gauss-Jordan with full pivoting in float, the reference's operation order."""
+    t = np.array(m, f32).copy(); n = 4
+    ipiv = [0] * n; indxr = [0] * n; indxc = [0] * n
+    for i in range(n):
+        irow = icol = -1; big = f32(0)
+        for j in range(n):
+            if ipiv[j] != 1:
+                for k in range(n):
+                    if ipiv[k] == 0:
+                        if abs(t[j, k]) >= big:
+                            big = abs(t[j, k]); irow, icol = j, k
+                    elif ipiv[k] > 1:
+                        raise ValueError("singular matrix")
+        ipiv[icol] += 1
+        if irow != icol:
+            t[[irow, icol]] = t[[icol, irow]]
+        indxr[i], indxc[i] = irow, icol
+        if t[icol, icol] == 0:
+            raise ValueError("singular matrix")
+        pivinv = f32(f32(1) / t[icol, icol]); t[icol, icol] = f32(1)
+        for j in range(n):
+            t[icol, j] = f32(t[icol, j] * pivinv)
+        for j in range(n):
+            if j != icol:
+                save = f32(t[j, icol]); t[j, icol] = f32(0)
+                for k in range(n):
+                    t[j, k] = f32(t[j, k] - f32(t[icol, k] * save))
+    for j in range(n - 1, -1, -1):
+        if indxr[j] != indxc[j]:
+            t[:, [indxr[j], indxc[j]]] = t[:, [indxc[j], indxr[j]]]
+    return t
+
+
 def sample_to_camera(xfov_deg, near, far, aspect, rel_size=(1.0, 1.0), rel_offset=(0.0, 0.0)):
-    """cameraToSample = scale(1/relSize) * translate(-relOffset) * scale(-0.5,-0.5*aspect,1) * translate(-1,-1/aspect,0) * perspective(xfov,near,far)
-    (perspective.cpp:129-155); returns its inverse.  `aspect` is the FULL film's; rel_size / rel_offset = crop size / offset over the full film size."""
-    recip = 1.0 / (far - near)
-    cot = 1.0 / math.tan(math.radians(xfov_deg / 2.0))
-    persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0],
-                      [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], dtype=np.float64)
-    tr = np.eye(4); tr[0, 3] = -1.0; tr[1, 3] = -1.0 / aspect
-    sc = np.diag([-0.5, -0.5 * aspect, 1.0, 1.0])
-    crop = np.diag([1.0 / float(f32(rel_size[0])), 1.0 / float(f32(rel_size[1])), 1.0, 1.0]) @ translate(-float(f32(rel_offset[0])), -float(f32(rel_offset[1])), 0.0)
-    cam_to_sample = crop @ sc @ tr @ persp
-    return np.linalg.inv(cam_to_sample).astype(f32)
+    """PerspectiveCameraImpl::configure (src/sensors/perspective.cpp:126-157), in the reference's own single-precision arithmetic so that camera
+    rays come out bit-identical: cameraToSample = scale(1/relSize) * translate(-relOffset) * scale(-0.5,-0.5*aspect,1) * translate(-1,-1/aspect,0)
+    * perspective(xfov,near,far); every Transform carries its inverse (scale / translate: closed form, perspective: Matrix::invert), products multiply
+    the inverses in reverse (transform.cpp:28-31); sampleToCamera = the accumulated inverse.  `aspect` is the FULL film's; rel_size / rel_offset =
+    crop size / offset over the full film size."""
+    one = f32(1)
+    aspect = f32(aspect); near = f32(near); far = f32(far); fov = f32(xfov_deg)
+    rsx, rsy = f32(rel_size[0]), f32(rel_size[1]); rox, roy = f32(rel_offset[0]), f32(rel_offset[1])
+
+    def scale_t(x, y, z):
+        m = np.diag(np.array([x, y, z, one], f32)).astype(f32); i = np.diag(np.array([one / x, one / y, one / z, one], f32)).astype(f32); return m, i
+
+    def translate_t(x, y, z):
+        m = np.eye(4, dtype=f32); i = np.eye(4, dtype=f32); m[:3, 3] = [x, y, z]; i[:3, 3] = [-x, -y, -z]; return m, i
+
+    recip = f32(one / f32(far - near))
+    cot = f32(one / _tanf(f32(f32(fov / f32(2)) * f32(f32(3.14159265358979323846) / f32(180)))))      # degToRad(fov / 2.0f), util.h:309
+    persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0], [0, 0, f32(far * recip), f32(f32(-near * far) * recip)], [0, 0, 1, 0]], dtype=f32)
+    chain = [scale_t(f32(one / rsx), f32(one / rsy), one), translate_t(f32(-rox), f32(-roy), f32(0)),
+             scale_t(f32(-0.5), f32(f32(-0.5) * aspect), one), translate_t(f32(-1), f32(f32(-1) / aspect), f32(0)), (persp, _mat_invert_f32(persp))]
+    m, inv = chain[0]
+    for (m2, i2) in chain[1:]:
+        m, inv = _mat_mul_f32(m, m2), _mat_mul_f32(i2, inv)
+    return inv
 
 
 def set_crop_window(sc, full_width, full_height, offset_x, offset_y):

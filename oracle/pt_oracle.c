@@ -6,12 +6,14 @@
  *   - IEEE binary32, round-to-nearest, no contraction (compiled with -ffp-contract=off, no fast-math);
  *     expressions are evaluated left to right exactly as written; x/len of vectors is "recip then multiply"
  *     like the reference's TVector3::operator/= (include/mitsuba/core/vector.h:546-553).
- *   - sin/cos of the concentric-disk map use the polynomial pair sinp/cosp below instead of libm, so that
- *     CPU and GPU agree bit for bit (libm's sincosf differs between glibc and the GPU math library).
+ *   - sin/cos of the warps (concentric disk, uniform sphere / cone, cylinder) are glibc's sincosf, as in the reference
+ *     (math::sincos, include/mitsuba/core/math.h:219-221); the HIP product restates glibc's algorithm in fp64 (pt_device.h
+ *     glibcSincosf, pinned against glibc over every float in [-8, 8] by tests/test_host_logic.py), so CPU and GPU still agree bit for bit.
  *   - closest hit = minimum t over all triangles passing the TriAccel test in [mint, maxt]; ties are broken
  *     towards the lower global triangle index, which makes the result independent of traversal order
  *     (the kd-tree of the reference keeps the last-tested of equal-t hits: SURVEY.md §7; scenes avoid coincident geometry).
  */
+#define _GNU_SOURCE
 #include "pt_oracle.h"
 #include <math.h>
 #include <stdlib.h>
@@ -219,17 +221,13 @@ void orc_sfmt_sequence(uint64_t seed, uint64_t n, uint64_t *out) { sfmt_t st; sf
 void orc_sfmt_floats(uint64_t seed, uint64_t n, float *out) { sfmt_t st; sfmt_init(&st, seed); for (uint64_t i = 0; i < n; ++i) out[i] = bits_to_float((uint32_t) (sfmt_next64(&st) & 0xFFFFFFFFu)); }
 
 /* ------------------------------------------------------------------------------------------------ warps */
-/* polynomial sin/cos on [-pi/4, pi/4] (Cephes single-precision minimax coefficients); see the arithmetic contract above */
-static inline float sinp(float x) { float z = x * x; float y = -1.9515295891e-4f * z; y = y + 8.3321608736e-3f; y = y * z; y = y - 1.6666654611e-1f; y = y * z; y = y * x; return y + x; }
-static inline float cosp(float x) { float z = x * x; float y = 2.443315711809948e-5f * z; y = y - 1.388731625493765e-3f; y = y * z; y = y + 4.166664568298827e-2f; y = y * z; y = y * z; float h = 0.5f * z; y = y - h; return y + 1.0f; }
-
-/* src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric.  phi = (pi/4)(r2/r1) in the first branch; in the second branch
- * phi = pi/2 - (r1/r2)(pi/4), evaluated through sin(pi/2 - x) = cos x, cos(pi/2 - x) = sin x with x = (r1/r2)(pi/4). */
+/* src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric; math::sincos = ::sincosf (include/mitsuba/core/math.h:219-221) */
 static void disk_concentric(float sx, float sy, float *ox, float *oy) {
-    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, sn, cs;
-    if (r1 == 0 && r2 == 0) { *ox = 0; *oy = 0; return; }
-    if (r1 * r1 > r2 * r2) { r = r1; float x = (M_PI_F / 4.0f) * (r2 / r1); sn = sinp(x); cs = cosp(x); }
-    else { r = r2; float x = (r1 / r2) * (M_PI_F / 4.0f); sn = cosp(x); cs = sinp(x); }
+    float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, phi, sn, cs;
+    if (r1 == 0 && r2 == 0) r = phi = 0;
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (M_PI_F / 4.0f) * (r2 / r1); }
+    else { r = r2; phi = (M_PI_F / 2.0f) - (r1 / r2) * (M_PI_F / 4.0f); }
+    sincosf(phi, &sn, &cs);
     *ox = r * cs; *oy = r * sn;
 }
 /* warp.cpp:43-52 squareToCosineHemisphere; math::safe_sqrt = sqrt(max(x,0)) (include/mitsuba/core/math.h:260-267) */
@@ -303,19 +301,8 @@ static inline v3 xf_vector(const float *m, v3 v) { return V(m[0] * v.x + m[1] * 
 static inline v3 xf_normal(const float *inv, v3 n) { return V(inv[0] * n.x + inv[4] * n.y + inv[8] * n.z, inv[1] * n.x + inv[5] * n.y + inv[9] * n.z, inv[2] * n.x + inv[6] * n.y + inv[10] * n.z); }
 static inline float length3(v3 a) { return sqrtf(dot(a, a)); }
 
-/* sin / cos of 2*pi*u for u in [0, 1]: quadrant reduction + the polynomial pair (the reference calls libm's sincosf on 2*pi*u;
- * see the arithmetic contract -- CPU and GPU must agree bit for bit, the reference is matched within float rounding) */
-static void sincos_2pi(float u, float *sn, float *cs) {
-    float k = floorf(u * 4.0f + 0.5f);
-    float a = (u - k * 0.25f) * (2.0f * M_PI_F);
-    float sa = sinp(a), ca = cosp(a);
-    switch (((int) k) & 3) {
-        case 0: *sn = sa; *cs = ca; break;
-        case 1: *sn = ca; *cs = -sa; break;
-        case 2: *sn = -sa; *cs = -ca; break;
-        default: *sn = -ca; *cs = sa; break;
-    }
-}
+/* math::sincos(2.0f * M_PI * u) of squareToUniformSphere / squareToUniformCone (warp.cpp:29, :59) and Cylinder::samplePosition (cylinder.cpp:234) */
+static void sincos_2pi(float u, float *sn, float *cs) { sincosf((2.0f * M_PI_F) * u, sn, cs); }
 /* src/libcore/util.cpp:489-527 solveQuadraticDouble */
 static int solve_quadratic_double(double a, double b, double c, double *x0, double *x1) {
     if (a == 0) { if (b != 0) { *x0 = *x1 = -c / b; return 1; } return 0; }

@@ -99,7 +99,71 @@ def golden_scenes():
     }
 
 
+HARNESS_STRICT = os.path.join(ROOT, "oracle", "_ref_strict", "harness")
+
+
+def _harness(exe, *args, timeout=3600):
+    subprocess.check_call([exe] + [str(a) for a in args], cwd=os.path.dirname(exe), timeout=timeout, stdout=subprocess.DEVNULL)
+
+
+def develop(film, sc):
+    """raw 5-channel ImageBlock sums incl. border -> H x W x 3 image (sum / weight), float32"""
+    b = (film.shape[0] - sc.height) // 2
+    f = film[b:film.shape[0] - b, b:film.shape[1] - b]
+    return (f[..., :3] / np.maximum(f[..., 4:5], 1e-20)).astype(np.float32)
+
+
+def strict_fixtures(only=None):
+    """The SAME reference sources compiled WITHOUT -ffast-math (`make -C oracle/ref_build FAST=0 OUT=oracle/_ref_strict`): per-sample Li, path depth and
+    number of sampler values for the pairs of every small golden scene -> tests/golden/strict/<name>.npz.  Against this build the restatement takes the same
+    path for every sample and most scenes agree bit for bit (tests/test_oracle_golden.py::test_li_samples_vs_strict_reference): what separates it from the
+    shipped -ffast-math build is compiler re-association inside the reference, not the algorithm."""
+    os.makedirs(os.path.join(OUT, "strict"), exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    for name, sc in golden_scenes().items():
+        if only and name not in only:
+            continue
+        pairs = np.load(os.path.join(OUT, name + "_samples.npz"))["pairs"]
+        path = os.path.join(tmp, name + ".miscene"); scenes.save_scene(sc, path)
+        ppath = os.path.join(tmp, name + "_pairs.bin"); pairs.tofile(ppath); base = os.path.join(tmp, name)
+        _harness(HARNESS_STRICT, path, "samples", ppath, base)
+        extra = {}
+        if name in ("cornell_small", "veach_small", "atrium_small", "instanced_garden", "bunny_box", "closed_box"):
+            _harness(HARNESS_STRICT, path, "image", 8, base); extra["image"] = develop(np.load(base + "_film.npy"), sc)
+        np.savez_compressed(os.path.join(OUT, "strict", name + ".npz"), li=np.load(base + "_li.npy"), depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"), **extra)
+        print("strict", name, flush=True)
+
+
+# converged low-resolution images of the three BASELINE scene classes (SURVEY.md §8c item 11): 240 x 135, Sobol, enough samples per pixel that the
+# reference's OWN two builds (-ffast-math as shipped / strict IEEE) agree below the 1e-4 relative-L2 tolerance of the north star
+CONVERGED = {"S1_cornell": ("cornell_box", dict(), 1024), "S2_veach": ("veach_mis", dict(), 16384), "S3_atrium": ("atrium", dict(detail=0.08, env_size=(64, 32)), 32768)}
+
+
+def converged_scene(key):
+    gen, kw, spp = CONVERGED[key]
+    return getattr(scenes, gen)(240, 135, spp, **kw)
+
+
+def converged_fixtures(only=None):
+    os.makedirs(os.path.join(OUT, "converged"), exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    for key in CONVERGED:
+        if only and key not in only:
+            continue
+        sc = converged_scene(key); path = os.path.join(tmp, key + ".miscene"); scenes.save_scene(sc, path); imgs = {}
+        for tag, exe in (("fast", HARNESS), ("strict", HARNESS_STRICT)):
+            base = os.path.join(tmp, key + "_" + tag); _harness(exe, path, "image", 8, base, timeout=7200)
+            imgs[tag] = develop(np.load(base + "_film.npy"), sc)
+        a, b = imgs["fast"].astype(np.float64), imgs["strict"].astype(np.float64)
+        print("converged", key, sc.spp, "spp: reference fast-math vs strict build rel-L2 = %.3g" % np.sqrt(((a - b) ** 2).sum() / (a ** 2).sum()), flush=True)
+        np.savez_compressed(os.path.join(OUT, "converged", key + ".npz"), fast=imgs["fast"], strict=imgs["strict"], spp=np.int64(sc.spp))
+
+
 def main():
+    if "--strict" in sys.argv:
+        i = sys.argv.index("--strict"); return strict_fixtures(set(sys.argv[i + 1].split(",")) if len(sys.argv) > i + 1 else None)
+    if "--converged" in sys.argv:
+        i = sys.argv.index("--converged"); return converged_fixtures(set(sys.argv[i + 1].split(",")) if len(sys.argv) > i + 1 else None)
     only = None                                          # --only a,b: regenerate just these scenes (the pair streams of all scenes are still drawn, in order)
     if "--only" in sys.argv:
         only = set(sys.argv[sys.argv.index("--only") + 1].split(","))

@@ -42,7 +42,10 @@ def test_li_samples_vs_reference_golden(mi, golden_scenes, name):
     sc = golden_scenes[name]; gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
     got = mi.Render(mi.Scene(sc)).samples(gd["pairs"])
     err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
-    assert err.max() < 2e-4 and np.median(err) < 1e-6
+    assert (err < 2e-4).mean() > 0.995 and err.max() < 5e-3 and np.median(err) < 1e-6
+    # ... and against the SAME reference sources compiled without -ffast-math (tests/golden/strict/): bit for bit
+    st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
+    assert (bits(got) == bits(st["li"])).all()
 
 
 def test_sobol_and_camera_units(mi, oracle, scenes):
@@ -174,8 +177,13 @@ def test_edge_cases_and_errors(mi, scenes):
         r.run(tile=(0, 0, sc.width + 1, 10))
     with pytest.raises(mi.MiError, match="sample range"):
         r.run(s0=0, s1=sc.spp + 1)
-    # cancel flag is observed between batches and cleared by the next run
-    r.cancel(); r.run(); assert r.stats()["samples"] > 0
+    # Integrator::cancel: a cancel issued between two runs is not lost -- the next run sees it, returns MI_CANCELLED and consumes it
+    r.clear(); r.cancel()
+    with pytest.raises(mi.MiError, match="cancelled"):
+        r.run()
+    assert r.stats()["samples"] == 0
+    r.run(); assert r.stats()["samples"] > 0
+    r.cancel(); r.clear(); r.run(); assert r.stats()["samples"] > 0        # mi_render_clear drops a pending cancel
 
 
 def test_opacity_alpha_channel(mi, oracle, golden_scenes):
@@ -779,3 +787,20 @@ def test_crop_window(mi, oracle, golden_scenes):
     gd = np.load(os.path.join(GOLDEN, name + "_samples.npz"))
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
     assert (err < 2e-4).mean() > 0.998
+
+
+def test_device_sincosf_equals_glibc(mi):
+    """pt_device.h glibcSincosf (fp64 restatement of glibc's sincosf, the reference's math::sincos) against the host's glibc, bit for bit:
+    every float of a dense sweep over the arguments the warps produce ([-pi/4, 3 pi/4] for the concentric disk, [0, 2 pi] for sphere / cone /
+    cylinder sampling) plus random bit patterns in [-8, 8].  scripts/check_sincosf.c is the exhaustive version of this test for the CPU restatement."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.sincosf.argtypes = [ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    rng = np.random.default_rng(11)
+    x = np.concatenate([np.linspace(-0.8, 6.4, 200001, dtype=np.float32), (rng.random(200000, dtype=np.float32) * 16 - 8).astype(np.float32),
+                        np.float32([0.0, -0.0, 1e-5, 2.4e-4, 2.5e-4, np.pi / 4, np.nextafter(np.float32(np.pi / 4), np.float32(0)), np.pi / 2, np.pi, 2 * np.pi, 7.9999])])
+    s, c = mi.device_sincosf(x)
+    rs, rc = np.zeros_like(x), np.zeros_like(x); a, b = ctypes.c_float(), ctypes.c_float()
+    for i in range(0, len(x), 7):       # every 7th value: ~57 k libm calls through ctypes
+        libm.sincosf(float(x[i]), ctypes.byref(a), ctypes.byref(b)); rs[i], rc[i] = a.value, b.value
+    sel = slice(0, len(x), 7)
+    assert (bits(s[sel]) == bits(rs[sel])).all() and (bits(c[sel]) == bits(rc[sel])).all()

@@ -114,8 +114,51 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
         # kd-tree keeps the last-tested triangle (SURVEY.md §7 "nearest-hit tie-breaking") -> a handful of paths legitimately fork
         assert same_path.mean() > 0.995 and same_vals.mean() > 0.995 and (err < 1e-4).mean() > 0.995
     else:
+        # the shipped reference is a -ffast-math build: single samples sit up to ~2e-3 away (its own strict build differs from it by as much);
+        # the tight statement is test_li_samples_vs_strict_reference (bit for bit)
         assert same_path.all() and same_vals.all()
-        assert err.max() < 2e-4 and np.median(err) < 1e-6
+        assert (err < 2e-4).mean() > 0.995 and err.max() < 5e-3 and np.median(err) < 1e-6
+
+
+STRICT_BIT_EXACT = ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide", "cornell_small_tent", "cornell_small_mitchell",
+                    "cornell_small_catmullrom", "cornell_small_lanczos", "textured_room", "bitmap_room", "cornell_scramble", "cornell_crop", "bunny_box"]
+STRICT_OTHERS = ["closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep", "cbox_materials",
+                 "cbox_materials_strict_indep", "instanced_garden", "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "sky_view", "sky_view_indep", "veach_microfacets",
+                 "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room",
+                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals"]
+
+
+@pytest.mark.parametrize("name", STRICT_BIT_EXACT + STRICT_OTHERS)
+def test_li_samples_vs_strict_reference(oracle, golden_scenes, name):
+    """The SAME reference sources compiled without -ffast-math (oracle/ref_build `make FAST=0`; fixtures tests/golden/strict/, generator
+    tests/golden/make_golden.py --strict).  Against that build the restatement follows the same path for EVERY sample of every scene, and the
+    scenes built from triangles, diffuse BSDFs, area / environment lights and (bitmap) textures agree BIT FOR BIT -- incl. the atrium with its
+    smooth-shaded columns and the 69 k-triangle bunny.  What separates the oracle from the shipped -ffast-math build (test_li_samples_vs_reference)
+    is therefore the compiler's re-association inside the reference, not the algorithm."""
+    sc = golden_scenes[name]; gd = g(name + "_samples.npz"); st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
+    r = oracle.Oracle(sc).render_samples(gd["pairs"], log=True)
+    same_path = (r["nvals"] == st["nvals"]) & (r["depth"] == st["depth"])
+    exact = (r["li"].view(np.uint32) == st["li"].view(np.uint32)).all(1)
+    err = np.abs(r["li"] - st["li"]).max(1) / (np.abs(st["li"]).max(1) + 1e-6)
+    if name in STRICT_BIT_EXACT:
+        assert same_path.all() and exact.all()
+    elif name == "closed_box":
+        # exact ties on the quad diagonals / the film diagonal of the axis-aligned probe box: the kd-tree keeps whichever coplanar triangle its leaf order tests last
+        assert same_path.mean() > 0.998 and exact.mean() > 0.995
+    else:
+        # other BSDFs / analytic shapes / filtered lookups: same paths, values within a few ulp of intermediate results (operation order inside the plugins)
+        assert same_path.all() and (err < 1e-5).mean() > 0.98 and err.max() < 2e-3 and np.median(err) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["cornell_small", "veach_small", "atrium_small", "instanced_garden", "bunny_box"])
+def test_image_vs_strict_reference(oracle, golden_scenes, name):
+    """Developed images at the fixtures' 16 spp: against the strict build the S3-class scenes sit at 1e-5 .. 3e-4 (a handful of forked paths in 80 k samples),
+    an order of magnitude below the same comparison with the -ffast-math build (atrium 2e-3)."""
+    sc = golden_scenes[name]; ref = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))["image"].astype(np.float64)
+    film, _ = oracle.Oracle(sc).render_image(threads=8); b = (film.shape[0] - sc.height) // 2
+    f = film[b:film.shape[0] - b, b:film.shape[1] - b]; img = f[..., :3] / np.maximum(f[..., 4:5], 1e-20)
+    rel = np.sqrt(((img - ref) ** 2).sum() / (ref ** 2).sum())
+    assert rel < {"cornell_small": 2e-5, "veach_small": 2e-5}.get(name, 4e-4), rel
 
 
 @pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop"])
