@@ -6,7 +6,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <vector>
 #include "scene_host.h"
@@ -15,7 +14,6 @@
 extern "C" {
 void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-void mi_upload_packet(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, hipStream_t);
 void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
@@ -26,26 +24,7 @@ void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, flo
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
 void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
 void mi_launch_debug_sincosf(const float *, uint64_t, float *, hipStream_t);
-// fast-arithmetic twins (kernels_fast.hip)
-void mi_launch_generate_fast(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
-void mi_launch_extend_fast(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-void mi_upload_packet_fast(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, hipStream_t);
-void mi_launch_shade_fast(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
-void mi_launch_shadow_fast(const DScene &, const Queues &, uint32_t, hipStream_t);
-void mi_launch_film_fast(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
-void mi_launch_env_primary_fast(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 }
-struct LaunchSet {
-    void (*generate)(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
-    void (*extend)(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-    void (*packet)(const TriAccelD *, uint32_t, const AnalyticD *, uint32_t, hipStream_t);
-    void (*shade)(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
-    void (*shadow)(const DScene &, const Queues &, uint32_t, hipStream_t);
-    void (*film)(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
-    void (*envPrimary)(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
-};
-static const LaunchSet kPrecise = {mi_launch_generate, mi_launch_extend, mi_upload_packet, mi_launch_shade, mi_launch_shadow, mi_launch_film, mi_launch_env_primary};
-static const LaunchSet kFast = {mi_launch_generate_fast, mi_launch_extend_fast, mi_upload_packet_fast, mi_launch_shade_fast, mi_launch_shadow_fast, mi_launch_film_fast, mi_launch_env_primary_fast};
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -63,8 +42,8 @@ struct mi_render {
     std::atomic<int> cancel{0};
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
     mi_stats stats{};
-    uint64_t samplesTotal = 0, launchesAll = 0; const LaunchSet *k = &kPrecise;
-    uint32_t *dNib = nullptr;
+    uint64_t samplesTotal = 0, launchesAll = 0;
+    uint32_t *dNib = nullptr; void *dSobolTabs = nullptr;   // dSobolTabs: the three look_up tables of k_generate (frame, px, py), one allocation
     // optional second path pool + stream: consecutive batches alternate between the two, so the ALU-bound traversal kernels of one batch
     // overlap the latency-bound shading kernels of the other on the same CUs (MI355PT_STREAMS=2, default)
     Queues q2{}; std::vector<void *> allocs2; hipStream_t stream2 = nullptr; hipEvent_t filmDone[2] = {nullptr, nullptr}, joinEv = nullptr; int nStreams = 1;
@@ -223,7 +202,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dPacketGroups, &dPacketExact, &dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -304,7 +283,9 @@ int SceneHost::upload(int dev) {
     d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1;   // any non-diffuse material -> k_shade<RC = true>
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
-    for (int i = 0; i < 3; ++i) d.packet_k[i] = packetK[i];
+    if (up(&dPacketGroups, packetGroups) | up(&dPacketExact, packetExact)) return 1;
+    d.packet_groups = (const PacketGroupD *) dPacketGroups; d.packet_exact = (const TriAccelD *) dPacketExact; d.packet_scale = packetScale;
+    for (int i = 0; i < 3; ++i) d.packet_gk[i] = packetGK[i];
     committed = true;
     return 0;
 }
@@ -417,6 +398,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
+    if (p->fast_math) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: fast_math = 1 is not built: one set of kernels (strict IEEE arithmetic, bit-identical to the oracle) ships");
     if (p->sampler == MI_SAMPLER_SOBOL) {
         if (!s->h.d.sobol_m32) return fail(MI_ERR_INVALID, "mi_render_create: Sobol tables not loaded before mi_scene_commit (mi_set_sobol_tables)");
         // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR, + 1 where a BSDF draws from the sampler itself: roughdielectric, EUsesSampler) + the dim-4 skip
@@ -440,7 +422,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         }
         r->rc.sobol_scramble = v0;                           // single precision build: the low 32 bits of (v1 << 32) + v0 (sobolseq.h:87-96)
     }
-    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u)); r->k = p->fast_math ? &kFast : &kPrecise;
+    r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u));
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
         int perBounceDims = 5; for (const mi_material &m : s->h.materials) if (m.type == MI_BSDF_ROUGHDIELECTRIC) perBounceDims = 6;
@@ -455,6 +437,24 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         if ((size_t) dims * nibs * 64 + smallTableBytes(s->h) + 64 > 64 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the Sobol lookup tables (maxDepth x index bits) and the staged scene tables exceed the 64 KB of LDS a workgroup may request (reduce maxDepth or spp)");
         HIPCHK(hipMalloc((void **) &r->dNib, nib.size() * 4)); HIPCHK(hipMemcpy(r->dNib, nib.data(), nib.size() * 4, hipMemcpyHostToDevice));
         r->rc.sobol_nib = r->dNib; r->rc.nib_count = nibs; r->rc.nib_dims = dims;
+        // look_up tables of k_generate.  index(frame, px, py) = (frame << 2m) ^ Inv * ((px << m | py) ^ Delta * frame)  (sobolseq.h:99-131, all XOR-linear) =
+        // F[frame] ^ PX[px] ^ PY[py] with F = (frame << 2m) ^ Inv Delta frame, PX = Inv (px << m), PY = Inv py; and dimension d of the sample is M_d * index,
+        // linear as well: every table entry carries {index lo, hi, M_0 * index, M_1 * index}.  The scramble flips pixel bits before the lookup and is XORed
+        // into the sample afterwards (k_generate), so the tables do not depend on it.
+        const uint32_t m = s->h.logRes;
+        if (m > 1) {
+            if (2 * m + sppBits > 52 || p->spp > (1u << 22)) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: Sobol index beyond 52 bits (film resolution x sample count)");
+            const uint64_t *vdc = g_sobolVdc.data() + (size_t) (m - 1) * MI_SOBOL_SIZE, *vdi = g_sobolVdcInv.data() + (size_t) (m - 1) * MI_SOBOL_SIZE;
+            auto mulVec = [&](const uint64_t *cols, uint64_t b) { uint64_t x = 0; for (uint32_t c = 0; b; b >>= 1, ++c) if (b & 1) x ^= cols[c]; return x; };
+            auto dimBits = [&](uint32_t dmn, uint64_t index) { uint32_t x = 0; for (uint32_t c = 0; index; index >>= 1, ++c) if (index & 1) x ^= g_sobolM32[(size_t) dmn * MI_SOBOL_SIZE + c]; return x; };
+            const size_t res = (size_t) 1 << m, nF = std::max<uint32_t>(p->spp, 1u);
+            std::vector<uint32_t> tab((nF + 2 * res) * 4);
+            auto put = [&](size_t e, uint64_t idx) { tab[e * 4] = (uint32_t) idx; tab[e * 4 + 1] = (uint32_t) (idx >> 32); tab[e * 4 + 2] = dimBits(0, idx); tab[e * 4 + 3] = dimBits(1, idx); };
+            for (size_t f = 0; f < nF; ++f) put(f, ((uint64_t) f << (2 * m)) ^ mulVec(vdi, mulVec(vdc, f)));
+            for (size_t x = 0; x < res; ++x) { put(nF + x, mulVec(vdi, (uint64_t) x << m)); put(nF + res + x, mulVec(vdi, (uint64_t) x)); }
+            HIPCHK(hipMalloc(&r->dSobolTabs, tab.size() * 4)); HIPCHK(hipMemcpy(r->dSobolTabs, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            r->rc.sobol_frame = (const uint4 *) r->dSobolTabs; r->rc.sobol_px = r->rc.sobol_frame + nF; r->rc.sobol_py = r->rc.sobol_px + res;
+        }
     }
     HIPCHK(hipStreamCreate(&r->stream)); HIPCHK(hipEventCreate(&r->evBegin)); HIPCHK(hipEventCreate(&r->evEnd));
     { const char *ns = getenv("MI355PT_STREAMS"); r->nStreams = (ns && ns[0] == '1') ? 1 : 2; }
@@ -482,6 +482,7 @@ void mi_render_destroy(mi_render *r) {
     if (r->spill) (void) hipFree(r->spill);
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
     if (r->dNib) (void) hipFree(r->dNib);
+    if (r->dSobolTabs) (void) hipFree(r->dSobolTabs);
     for (hipEvent_t e : r->evPool) (void) hipEventDestroy(e);
     if (r->evBegin) (void) hipEventDestroy(r->evBegin);
     if (r->evEnd) (void) hipEventDestroy(r->evEnd);
@@ -508,15 +509,14 @@ static void mark(mi_render *r, int tag, size_t &used, hipStream_t st = nullptr) 
 static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed, int pool = 0) {
     const DScene &sc = r->scene->h.d; hipStream_t st = pool ? r->stream2 : r->stream; Queues &Q = pool ? r->q2 : r->q;
     (void) list;
-    if (sc.packet_n) r->k->packet(r->scene->h.packet.data(), r->scene->h.packetK[2], r->scene->h.analyticD.data(), (uint32_t) r->scene->h.analyticD.size(), st);   // constant-memory packet (one symbol per process: re-sent per batch, <= 3 KB)
     mark(r, 0, evUsed, st);
-    r->k->generate(sc, r->rc, Q, bd, r->grid, st);
+    mi_launch_generate(sc, r->rc, Q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
-        mark(r, 1, evUsed, st); r->k->extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
-        if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) r->k->envPrimary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
-        mark(r, 2, evUsed, st); r->k->shade(sc, r->rc, Q, buf, r->gridShade, st);
-        if (depth < maxDepth) { mark(r, 3, evUsed, st); r->k->shadow(sc, Q, r->gridShadow, st); }
+        mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
+        if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) mi_launch_env_primary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
+        mark(r, 2, evUsed, st); mi_launch_shade(sc, r->rc, Q, buf, r->gridShade, st);
+        if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
             std::vector<uint32_t> cnt(r->grid);
@@ -532,13 +532,8 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
 
 int mi_render_run(mi_render *r, mi_tile tile, uint32_t s0, uint32_t s1) { return mi_render_run_rows(r, tile, 1, s0, s1); }
 
-// The triangle packet of a small scene lives in ONE __constant__ symbol per process and device (kernels.hip c_packet): renders of packet-mode
-// scenes are serialised process-wide so that two handles on different small scenes cannot overwrite each other's packet mid-batch.
-static std::mutex g_packetMutex;
 int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t s0, uint32_t s1) {
     if (!r) return fail(MI_ERR_INVALID, "mi_render_run: null");
-    std::unique_lock<std::mutex> packetLock(g_packetMutex, std::defer_lock);
-    if (r->scene->h.d.packet_n) packetLock.lock();
     if (rowStride == 0) return fail(MI_ERR_INVALID, "mi_render_run_rows: row stride must be >= 1");
     const mi::SceneHost &h = r->scene->h;
     if (tile.x1 <= tile.x0 || tile.y1 <= tile.y0 || tile.x1 > h.width || tile.y1 > h.height) return fail(MI_ERR_INVALID, "mi_render_run: tile outside the film");
@@ -565,7 +560,7 @@ int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t 
         int rc = traceBatch(r, bd, nullptr, evUsed, pool); if (rc) return rc;
         // film accumulation stays in batch order (own-pixel sums are plain read-modify-writes): wait for the other pool's film kernel
         if (dual && filmPending[pool ^ 1]) HIPCHK(hipStreamWaitEvent(st, r->filmDone[pool ^ 1], 0));
-        r->k->film(h.d, pool ? r->q2 : r->q, bd, r->film, r->spill, st);
+        mi_launch_film(h.d, pool ? r->q2 : r->q, bd, r->film, r->spill, st);
         if (dual) { HIPCHK(hipEventRecord(r->filmDone[pool], st)); filmPending[pool] = true; }
         r->samplesTotal += bd.n_paths;
     }
@@ -623,6 +618,7 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     if (!r || !pairs || !outLi || !n) return fail(MI_ERR_INVALID, "mi_render_samples: null argument");
     const mi::SceneHost &h = r->scene->h; HIPCHK(hipSetDevice(h.device));
     for (uint64_t i = 0; i < n; ++i) if (pairs[i * 3] >= h.width || pairs[i * 3 + 1] >= h.height) return fail(MI_ERR_INVALID, "mi_render_samples: pixel outside the film");
+    for (uint64_t i = 0; i < n; ++i) if (pairs[i * 3 + 2] >= std::max(r->p.spp, 1u)) return fail(MI_ERR_INVALID, "mi_render_samples: sample index outside [0, spp)");
     if (n > r->poolPaths) { int rc = allocPool(r, n); if (rc) return rc; }
     uint32_t *dList = nullptr; float *dOut = nullptr; uint32_t *dSlots = nullptr;
     HIPCHK(hipMalloc((void **) &dList, n * 12)); HIPCHK(hipMalloc((void **) &dOut, n * 12)); HIPCHK(hipMalloc((void **) &dSlots, n * 4));
@@ -630,8 +626,6 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     std::vector<uint32_t> slots(n); for (uint64_t i = 0; i < n; ++i) slots[i] = (uint32_t) i;
     HIPCHK(hipMemcpy(dSlots, slots.data(), n * 4, hipMemcpyHostToDevice));
     BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList; bd.row_stride = 1;
-    std::unique_lock<std::mutex> packetLock(g_packetMutex, std::defer_lock);
-    if (h.d.packet_n) packetLock.lock();
     size_t evUsed = 0; bool prof = r->profiling; r->profiling = false;
     unsigned long long keep[4]; HIPCHK(hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost));     // the parity entry point leaves the ray counters untouched
     int rc = traceBatch(r, bd, dList, evUsed); r->profiling = prof;
@@ -658,7 +652,6 @@ extern "C" {
 int mi_debug_intersect_inst(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out, int32_t *outInst) {
     if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_intersect: bad argument");
     HIPCHK(hipSetDevice(s->h.device));
-    if (s->h.d.packet_n) { mi_upload_packet(s->h.packet.data(), s->h.packetK[2], s->h.analyticD.data(), (uint32_t) s->h.analyticD.size(), nullptr); HIPCHK(hipDeviceSynchronize()); }
     void *dInst = nullptr; if (outInst) HIPCHK(hipMalloc(&dInst, n * 4));
     int rc = withBuffers(rays, n * 32, out, n * 16, [&](void *i, void *o) { mi_launch_debug_intersect(s->h.d, (const float *) i, n, anyHit, (float *) o, (int *) dInst, nullptr); });
     if (!rc && outInst) { hipError_t e = hipMemcpy(outInst, dInst, n * 4, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }

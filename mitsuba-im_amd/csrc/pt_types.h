@@ -1,6 +1,7 @@
 // pt_types.h -- POD records shared by the host-side scene build and the gfx950 kernels.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #define MI_EPSILON 1e-4f                    // reference include/mitsuba/core/constants.h:28
 #define MI_SHADOW_EPSILON 1e-3f             // constants.h:29
@@ -16,6 +17,16 @@ struct TriAccelD {
     uint32_t k; float n_u, n_v, n_d;
     float a_u, a_v, b_nu, b_nv;
     float c_nu, c_nv; uint32_t prim; uint32_t pad;
+};
+
+// Packet mode, pass 1: the approximate Wald record of a coplanar PAIR of triangles forming a parallelogram, or of a single triangle (prim1 = 0xFFFFFFFF), 48 B =
+// three 16-B scalar loads.  The record is TriAccel::load of the first triangle with its vertices cyclically relabelled (A*, B*, C*) so that the shared edge
+// is A*C* (u* = 0): with s = u* + v* both triangles lie in 0 <= s <= 1, 0 <= v* <= 1, triangle prim0 on the side u* >= 0, its partner prim1 on u* <= 0.
+// margin = 1.1 (|b_nu| + |b_nv| + |c_nu| + |c_nv|): barycentric error per unit of distance error (trace.h).
+struct PacketGroupD {
+    float n_u, n_v, n_d, a_u;
+    float a_v, b_nu, b_nv, c_nu;
+    float c_nv, margin; uint32_t prim0, prim1;
 };
 
 // BVH2 node, 64 B: both child boxes live in the parent, so one node fetch decides both descents.
@@ -116,7 +127,9 @@ struct DScene {
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
     uint32_t packet_n, bvh_depth;
-    uint32_t packet_k[3];                 // packet records are sorted by projection axis: [0,k[0]) axis 0, [k[0],k[1]) axis 1, [k[1],k[2]) axis 2 (degenerate ones dropped)
+    // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
+    // triangles dropped), exact Wald records in ORIGINAL triangle order for pass 2, largest |coordinate| of the scene box (error-margin scale)
+    const struct PacketGroupD *packet_groups; const TriAccelD *packet_exact; uint32_t packet_gk[3]; float packet_scale;
     uint32_t has_roughconductor;          // selects the shade kernel variant
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none
@@ -133,6 +146,9 @@ struct RenderConst {
     uint32_t sobol_scramble;              // Sobol: low 32 bits of sampleTEA(scramble) (src/samplers/sobol.cpp:92-102), 0 = unscrambled
     // Sobol' direction matrices folded into 4-bit lookup tables: nib[dim][n][v] = XOR of matrices32[dim*52 + 4n + b] over the bits b of v
     const uint32_t *sobol_nib; uint32_t nib_count, nib_dims;
+    // sobol::look_up (src/samplers/sobolseq.h:99-131) and the first two sample dimensions are XOR-linear in (frame, px, py): three tables of
+    // {index lo, index hi, dim-0 bits, dim-1 bits} (api.cpp buildSobolLookupTables), XORed together in k_generate; null when log_res <= 1
+    const uint4 *sobol_frame, *sobol_px, *sobol_py;
     float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)
     uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
 };

@@ -307,10 +307,47 @@ void SceneHost::commitHost() {
     struct Depth { const std::vector<BvhNode> &n; int of(int i) const { if (i < 0) return 0; int a = of(n[i].c0), b = of(n[i].c1); return 1 + (a > b ? a : b); } } dep{nodes};
     int groupDepth = 0; for (uint32_t g = 0; g < ng; ++g) groupDepth = std::max(groupDepth, dep.of(groupRoot[g]));
     bvhDepth = dep.of(0) + (ni ? 1 + groupDepth : 0);
-    // packet mode (no instances): records sorted by projection axis (stable: original order inside an axis); degenerate triangles (k = 3) never hit -> dropped
-    packet.clear(); packetK[0] = packetK[1] = packetK[2] = 0;
-    for (uint32_t axis = 0; axis < 3; ++axis) { for (const TriAccelD &ta : accel) if (ta.k == axis) packet.push_back(ta); packetK[axis] = (uint32_t) packet.size(); }
-    if (packet.empty()) packet.push_back(TriAccelD{});
+    // packet mode (no instances, <= MI_PACKET_MAX triangles): exact records in original order + pass-1 group records (pt_types.h PacketGroupD).  Coplanar
+    // pairs that form a parallelogram (the two halves of a quad) share one record: for the vertices (X, Y, Z) of a triangle, taken cyclically, the partner is
+    // the triangle on {Y, Z, Y + Z - X}.  Degenerate triangles (k = 3) never hit and are dropped.
+    packetExact.assign(accel.begin(), accel.begin() + nt); packetGroups.clear(); packetGK[0] = packetGK[1] = packetGK[2] = 0;
+    {
+        float sx = 0; for (int i = 0; i < 3; ++i) sx = std::max(sx, std::max(std::fabs(aabbLo[i]), std::fabs(aabbHi[i])));
+        packetScale = sx;
+        if (nt <= MI_PACKET_MAX && ni == 0) {
+            const float tol = 1e-6f * std::max(sx, 1e-20f);
+            auto near = [&](V3 a, V3 b) { return std::fabs(a.x - b.x) <= tol && std::fabs(a.y - b.y) <= tol && std::fabs(a.z - b.z) <= tol; };
+            std::vector<uint8_t> used(nt, 0); std::vector<PacketGroupD> byAxis[3];
+            for (uint32_t t1 = 0; t1 < nt; ++t1) {
+                if (used[t1] || accel[t1].k > 2) continue;
+                used[t1] = 1;
+                const V3 P[3] = {vert(idx[t1 * 3]), vert(idx[t1 * 3 + 1]), vert(idx[t1 * 3 + 2])};
+                int partner = -1, rot = 0;
+                for (uint32_t t2 = t1 + 1; t2 < nt && partner < 0; ++t2) {
+                    if (used[t2] || accel[t2].k != accel[t1].k) continue;
+                    const V3 Q[3] = {vert(idx[t2 * 3]), vert(idx[t2 * 3 + 1]), vert(idx[t2 * 3 + 2])};
+                    for (int r = 0; r < 3 && partner < 0; ++r) {
+                        const V3 X = P[r], Y = P[(r + 1) % 3], Z = P[(r + 2) % 3], X2 = Y + Z - X;
+                        for (int a = 0; a < 3 && partner < 0; ++a)      // t2's vertex set == {Y, Z, X2} in any order
+                            for (int b = 0; b < 3 && partner < 0; ++b) { if (b == a) continue; const int c = 3 - a - b;
+                                if (near(Q[a], Y) && near(Q[b], Z) && near(Q[c], X2)) { partner = (int) t2; rot = r; } }
+                    }
+                }
+                // relabel (X, Y, Z) -> (A*, B*, C*) = (Z, X, Y): a cyclic rotation (same plane, same orientation), shared edge YZ = C*A* <-> u* = 0
+                const V3 X = P[rot], Y = P[(rot + 1) % 3], Z = P[(rot + 2) % 3];
+                TriAccelD ta; triaccelLoad(ta, partner >= 0 ? Z : P[0], partner >= 0 ? X : P[1], partner >= 0 ? Y : P[2]);
+                if (ta.k > 2) continue;
+                if (partner >= 0) used[partner] = 1;
+                PacketGroupD g; g.n_u = ta.n_u; g.n_v = ta.n_v; g.n_d = ta.n_d; g.a_u = ta.a_u; g.a_v = ta.a_v; g.b_nu = ta.b_nu; g.b_nv = ta.b_nv; g.c_nu = ta.c_nu; g.c_nv = ta.c_nv;
+                g.margin = 1.1f * (std::fabs(ta.b_nu) + std::fabs(ta.b_nv) + std::fabs(ta.c_nu) + std::fabs(ta.c_nv));
+                g.prim0 = t1; g.prim1 = partner >= 0 ? (uint32_t) partner : 0xFFFFFFFFu;
+                byAxis[ta.k].push_back(g);
+            }
+            for (int axis = 0; axis < 3; ++axis) { packetGroups.insert(packetGroups.end(), byAxis[axis].begin(), byAxis[axis].end()); packetGK[axis] = (uint32_t) packetGroups.size(); }
+        }
+    }
+    if (packetGroups.empty()) packetGroups.push_back(PacketGroupD{});
+    if (packetExact.empty()) packetExact.push_back(TriAccelD{});
 
     // --- emitters (scene.cpp:383-388; pmf.h:56-58,103-116; trimesh.cpp:389-402; triangle.cpp:61-67)
     const uint32_t ne = (uint32_t) emitters.size();

@@ -16,11 +16,11 @@ struct SceneHost {
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16] = {0}, envScale = 1.0f;
     // derived on the host (scene_build.cpp)
     std::vector<uint32_t> triShape, i2; std::vector<TriAccelD> tris; std::vector<TriShade> shade; std::vector<BvhNode> nodes;
-    uint32_t packetK[3] = {0, 0, 0};
     std::vector<TriUV> triuv; bool anyUV = false;   // per-triangle uv + UV tangents (only when some mesh has texcoords)
     std::vector<InstanceD> instancesD; int bvhDepth = 0;   // stack entries the traversal needs (scene tree + return marker + deepest group tree)
     std::vector<AnalyticD> analyticD; uint32_t nTris = 0;   // analytic shapes: primitive index nTris + i; `tris` (BVH leaf order) holds a k = MI_K_ANALYTIC record for each
-    std::vector<TriAccelD> packet;   // Wald records in ORIGINAL triangle order (packet mode, <= MI_PACKET_MAX triangles)
+    std::vector<TriAccelD> packetExact;   // Wald records in ORIGINAL triangle order (packet mode, <= MI_PACKET_MAX triangles): pass 2 of trace.h
+    std::vector<PacketGroupD> packetGroups; uint32_t packetGK[3] = {0, 0, 0}; float packetScale = 1.0f;   // pass-1 records sorted by projection axis
     std::vector<EmitterD> emittersD; std::vector<float> emitterCdf, areaCdf, emitterX; float emitterNorm = 0;
     bool envConstant = false, hasDeltaEmitters = false; float dirBsCenter[3] = {0, 0, 0}, dirBsRadius = 0;
     float aabbLo[3], aabbHi[3];
@@ -30,7 +30,7 @@ struct SceneHost {
     // device
     bool committed = false; int device = 0;
     void *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr, *dI2 = nullptr, *dNrm = nullptr, *dMaterials = nullptr, *dEmitters = nullptr,
-         *dEmitterCdf = nullptr, *dAnalytic = nullptr, *dInstances = nullptr, *dMaterialTables = nullptr, *dTriUV = nullptr, *dTextures = nullptr, *dTexLevels = nullptr, *dTexTexels = nullptr, *dMipLut = nullptr, *dEmitterX = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dEnvRGB = nullptr, *dEnvCols = nullptr, *dEnvRows = nullptr, *dEnvWeights = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
+         *dEmitterCdf = nullptr, *dAnalytic = nullptr, *dInstances = nullptr, *dMaterialTables = nullptr, *dTriUV = nullptr, *dTextures = nullptr, *dTexLevels = nullptr, *dTexTexels = nullptr, *dMipLut = nullptr, *dEmitterX = nullptr, *dAreaCdf = nullptr, *dFilter = nullptr, *dEnvRGB = nullptr, *dEnvCols = nullptr, *dEnvRows = nullptr, *dEnvWeights = nullptr, *dPacketGroups = nullptr, *dPacketExact = nullptr, *dSobolM32 = nullptr, *dSobolVdc = nullptr, *dSobolVdcInv = nullptr;
     DScene d{};
 
     void commitHost();          // scene_build.cpp

@@ -22,7 +22,7 @@ def test_plugin_drop_in_through_reference_driver(mi, golden_scenes, tmp_path):
     got = np.load(out + "_target.npy"); meta = np.load(out + "_meta.npy")
     ref = np.load(os.path.join(GOLDEN, "cornell_small_responsive.npz"))["target"]
     assert meta[0] == 0                                   # return code 0 = all sample planes done (integrator.cpp:349-401)
-    assert meta[2] == 4 and list(meta[3:7]) == [0.0, 4.0, 8.0, 12.0]   # one per 4-plane batch;               # progress() called, first call at the start of plane 0
+    assert meta[2] == 2 and list(meta[3:5]) == [0.0, 8.0]   # one progress() per PAIR of 4-plane batches (the pair keeps both path pools / streams busy), first call at the start of plane 0
     assert got.shape == ref.shape == (sc.height + 2, sc.width + 2, 4)
     # interior without the last row/column: the reference's ImageOrderIntegrator also enumerates the bitmap's BORDER cells as pixels
     # (integrator.cpp:337-338 takes the bordered bitmap size as resolution), whose samples can splat into the last row/column
@@ -96,11 +96,17 @@ def test_host_mirror_controls(mi, golden_scenes):
     calls = []
     cont, abort = C.c_int(1), C.c_int(0)
     rc = L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: calls.append(spp) or 0), None, 0, 1)
-    assert rc == 0 and calls == [0.0, 4.0, 8.0, 12.0]
+    assert rc == 0 and calls == [0.0, 8.0]                # one progress() per pair of batches (two path pools / streams), always on a new sample plane
     r = mi.Render(gs, opacity=True); r.run(); assert (r.read_film(1).view(np.uint32) == target.view(np.uint32)).all()
     assert b"rays/sample" in L.mi_host_statistics(h)
     assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 1, 4) == 0     # non-zero threads idle
     abort.value = 1; assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 0, 1) == -1
     abort.value = 0; cont.value = 0; assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 0, 1) == -2
     cont.value = 1; assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 100 if spp >= 4 else 0), None, 0, 1) == 100
+    # Integrator::cancel from another context (here: the progress callback) while the render is under way: not lost, render returns -1 early
+    L.mi_host_cancel.argtypes = [C.c_void_p]; L.mi_host_cancel.restype = None
+    seen = []
+    rc = L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: (seen.append(spp), L.mi_host_cancel(h) if spp >= 8 else None, 0)[2]), None, 0, 1)
+    assert rc == -1 and seen == [0.0, 8.0]
+    assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 0, 1) == 0     # the flag is reset at the start of the next render()
     L.mi_host_destroy(h)

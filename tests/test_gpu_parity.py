@@ -99,6 +99,51 @@ def test_intersection_bit_exact(mi, oracle, scenes, name):
     assert nhit > n // 20
 
 
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small"])
+def test_packet_candidate_search_is_conservative(mi, oracle, golden_scenes, scenes, name):
+    """Packet mode (trace.h): pass 1 marks candidate triangles with an approximate, margin-padded test, pass 2 runs the exact Wald test on them.  A false
+    negative of pass 1 would change (t, u, v, prim), so aim rays where the margins matter: exactly at vertices and at points on edges (from random origins
+    and from origins ON other surfaces), grazing along the planes of the triangles (|D| small), through the quad diagonals, with mint / maxt ending right at
+    the hit.  Compared bit for bit with the oracle's test over ALL triangles (veach_small: the same rays through the BVH path)."""
+    sc = (golden_scenes if name == "veach_small" else scenes)[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); rng = np.random.default_rng(17)
+    P = sc.pos[sc.idx.reshape(-1, 3)].astype(np.float64)                      # (nt, 3, 3)
+    nt = len(P); lo, hi = sc.pos.min(0), sc.pos.max(0); ext = (hi - lo).max()
+    rays = []
+    for rep in range(24 * max(1, 192 // nt)):
+        t = rng.integers(0, nt, nt); w = rng.dirichlet([1, 1, 1], nt)
+        for kind in range(6):
+            if kind == 0: target = P[t, rng.integers(0, 3, nt)]                                    # a vertex
+            elif kind == 1: a = rng.random((nt, 1)); e = rng.integers(0, 3, nt); target = P[t, e] * a + P[t, (e + 1) % 3] * (1 - a)      # a point on an edge
+            elif kind == 2: target = (P[t] * w[:, :, None]).sum(1)                                 # an interior point
+            elif kind == 3: target = (P[t, 0] + P[t, 1] + P[t, 2]) / 3 + (P[t, 1] - P[t, 0]) * 1e-4      # next to the centroid
+            elif kind == 4: a = rng.random((nt, 1)); target = P[t, 1] * a + P[t, 2] * (1 - a) + (P[t, 0] - P[t, 1]) * 1e-6 * rng.normal(size=(nt, 1))   # within 1e-6 of the edge opposite vertex 0
+            else: target = P[t, 0] + (P[t, 1] - P[t, 0]) * rng.random((nt, 1)) * 3 - (P[t, 2] - P[t, 0]) * rng.random((nt, 1))      # in the plane, mostly outside
+            if rep % 3 == 0: o = lo + rng.random((nt, 3)) * (hi - lo)                              # origin inside the scene box
+            elif rep % 3 == 1:
+                t2 = rng.integers(0, nt, nt); o = (P[t2] * rng.dirichlet([1, 1, 1], nt)[:, :, None]).sum(1)      # origin ON another surface
+            else:                                                                                   # grazing: origin (almost) in the target triangle's plane
+                nrm = np.cross(P[t, 1] - P[t, 0], P[t, 2] - P[t, 0]); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True) + 1e-30
+                side = P[t, 0] + (P[t, 1] - P[t, 0]) * (rng.random((nt, 1)) * 4 - 2) + (P[t, 2] - P[t, 0]) * (rng.random((nt, 1)) * 4 - 2)
+                o = side + nrm * ext * 10.0 ** rng.uniform(-7, -2, (nt, 1)) * rng.choice([-1, 1], (nt, 1))
+            d = target - o; ln = np.linalg.norm(d, axis=1, keepdims=True); ok = ln[:, 0] > 1e-9
+            d = d / np.maximum(ln, 1e-30)
+            mint = np.full(nt, 1e-4); maxt = np.full(nt, np.inf)
+            if rep % 4 == 3: maxt = ln[:, 0] * (1 + rng.choice([-1e-6, 0, 1e-6], nt))             # the interval ends (almost) at the target
+            rays.append(np.concatenate([o, mint[:, None], d, maxt[:, None]], 1)[ok])
+    rays = np.concatenate(rays).astype(np.float32)
+    got = gs.intersect(rays); occ = gs.intersect(rays, any_hit=True)
+    nhit = 0
+    for i in range(len(rays)):
+        ok, h = orc.intersect(rays[i])
+        assert ok == (got[i, 3] >= 0), (i, rays[i])
+        if ok:
+            nhit += 1
+            assert (bits(got[i, :3]) == bits(np.array([h[0], h[13], h[14]], np.float32))).all(), (i, rays[i])
+            assert int(got[i, 3]) == sc.shapes[int(h[19])]["first_tri"] + int(h[18]), (i, rays[i])
+        assert orc.occluded(rays[i]) == (occ[i, 3] >= 0), (i, rays[i])
+    assert nhit > len(rays) // 4
+
+
 @pytest.mark.parametrize("name,spp", [("cornell_small", 16), ("cornell_small_gauss", 4), ("closed_box", 16), ("cornell_small_tent", 4),
                                       ("cornell_small_mitchell", 4), ("cornell_small_catmullrom", 4), ("cornell_small_lanczos", 4)])
 def test_film_vs_oracle_and_reference(mi, oracle, golden_scenes, name, spp):
