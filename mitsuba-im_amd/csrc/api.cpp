@@ -44,9 +44,12 @@ struct mi_render {
     mi_stats stats{};
     uint64_t samplesTotal = 0, launchesAll = 0;
     uint32_t *dNib = nullptr; void *dSobolTabs = nullptr;   // dSobolTabs: the three look_up tables of k_generate (frame, px, py), one allocation
-    // optional second path pool + stream: consecutive batches alternate between the two, so the ALU-bound traversal kernels of one batch
-    // overlap the latency-bound shading kernels of the other on the same CUs (MI355PT_STREAMS=2, default)
-    Queues q2{}; std::vector<void *> allocs2; hipStream_t stream2 = nullptr; hipEvent_t filmDone[2] = {nullptr, nullptr}, joinEv = nullptr; int nStreams = 1;
+    // optional further path pools + streams: consecutive batches go round-robin through them, so the ALU-bound traversal kernels of one batch
+    // overlap the latency-bound shading kernels of the others on the same CUs (MI355PT_STREAMS = 1..4 pools, default 2)
+    enum { kMaxPools = 4 };
+    Queues qx[kMaxPools - 1]{}; std::vector<void *> allocsx[kMaxPools - 1]; hipStream_t streamx[kMaxPools - 1] = {}; hipEvent_t filmDone[kMaxPools] = {}, joinEv[kMaxPools] = {}; int nStreams = 1;
+    Queues &pool(int i) { return i ? qx[i - 1] : q; }
+    hipStream_t poolStream(int i) { return i ? streamx[i - 1] : stream; }
 };
 
 extern "C" {
@@ -377,12 +380,12 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     return MI_OK;
 }
 static int allocPool(mi_render *r, uint64_t paths) {
-    unsigned long long keep[4] = {0, 0, 0, 0}, keep2[4] = {0, 0, 0, 0};      // ray counters survive a re-allocation (they are cleared by mi_render_clear only)
-    if (r->q.counters) (void) hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost);
-    if (r->q2.counters) (void) hipMemcpy(keep2, r->q2.counters, 32, hipMemcpyDeviceToHost);
-    int rc = allocPoolQ(r, paths, r->q, r->allocs); if (rc) return rc;
-    HIPCHK(hipMemcpy(r->q.counters, keep, 32, hipMemcpyHostToDevice));
-    if (r->nStreams > 1) { rc = allocPoolQ(r, paths, r->q2, r->allocs2); if (rc) return rc; HIPCHK(hipMemcpy(r->q2.counters, keep2, 32, hipMemcpyHostToDevice)); }
+    for (int i = 0; i < r->nStreams; ++i) {
+        Queues &Q = r->pool(i); unsigned long long keep[4] = {0, 0, 0, 0};      // ray counters survive a re-allocation (they are cleared by mi_render_clear only)
+        if (Q.counters) (void) hipMemcpy(keep, Q.counters, 32, hipMemcpyDeviceToHost);
+        int rc = allocPoolQ(r, paths, Q, i ? r->allocsx[i - 1] : r->allocs); if (rc) return rc;
+        HIPCHK(hipMemcpy(Q.counters, keep, 32, hipMemcpyHostToDevice));
+    }
     return MI_OK;
 }
 
@@ -422,6 +425,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         }
         r->rc.sobol_scramble = v0;                           // single precision build: the low 32 bits of (v1 << 32) + v0 (sobolseq.h:87-96)
     }
+    { const char *sf = getenv("MI355PT_SHADE_FLAGS"); r->rc.shade_flags = sf && sf[0] ? (uint32_t) atoi(sf) : 3u; }
     r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u));
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
@@ -453,16 +457,13 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
             for (size_t f = 0; f < nF; ++f) put(f, ((uint64_t) f << (2 * m)) ^ mulVec(vdi, mulVec(vdc, f)));
             for (size_t x = 0; x < res; ++x) { put(nF + x, mulVec(vdi, (uint64_t) x << m)); put(nF + res + x, mulVec(vdi, (uint64_t) x)); }
             HIPCHK(hipMalloc(&r->dSobolTabs, tab.size() * 4)); HIPCHK(hipMemcpy(r->dSobolTabs, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-            r->rc.sobol_frame = (const uint4 *) r->dSobolTabs; r->rc.sobol_px = r->rc.sobol_frame + nF; r->rc.sobol_py = r->rc.sobol_px + res;
+            r->rc.sobol_frame = (const uint4 *) r->dSobolTabs; r->rc.sobol_nframes = (uint32_t) nF; r->rc.sobol_px = r->rc.sobol_frame + nF; r->rc.sobol_py = r->rc.sobol_px + res;
         }
     }
     HIPCHK(hipStreamCreate(&r->stream)); HIPCHK(hipEventCreate(&r->evBegin)); HIPCHK(hipEventCreate(&r->evEnd));
-    { const char *ns = getenv("MI355PT_STREAMS"); r->nStreams = (ns && ns[0] == '1') ? 1 : 2; }
-    if (r->nStreams > 1) {
-        HIPCHK(hipStreamCreate(&r->stream2));
-        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&r->filmDone[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&r->joinEv, hipEventDisableTiming));
-    }
+    { const char *ns = getenv("MI355PT_STREAMS"); r->nStreams = ns && ns[0] >= '1' && ns[0] <= '4' ? ns[0] - '0' : 2; }
+    for (int i = 1; i < r->nStreams; ++i) HIPCHK(hipStreamCreate(&r->streamx[i - 1]));
+    for (int i = 0; i < r->nStreams; ++i) { HIPCHK(hipEventCreateWithFlags(&r->filmDone[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&r->joinEv[i], hipEventDisableTiming)); }
     const int W = (int) s->h.width + 2 * s->h.border, H = (int) s->h.height + 2 * s->h.border;
     r->filmFloats = (size_t) W * H * 5;
     HIPCHK(hipMalloc((void **) &r->film, r->filmFloats * 4)); HIPCHK(hipMemset(r->film, 0, r->filmFloats * 4));
@@ -474,10 +475,10 @@ void mi_render_destroy(mi_render *r) {
     if (!r) return;
     (void) hipSetDevice(r->scene->h.device);
     for (void *p : r->allocs) (void) hipFree(p);
-    for (void *p : r->allocs2) (void) hipFree(p);
-    for (int i = 0; i < 2; ++i) if (r->filmDone[i]) (void) hipEventDestroy(r->filmDone[i]);
-    if (r->joinEv) (void) hipEventDestroy(r->joinEv);
-    if (r->stream2) (void) hipStreamDestroy(r->stream2);
+    for (auto &a : r->allocsx) for (void *p : a) (void) hipFree(p);
+    for (hipEvent_t e : r->filmDone) if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : r->joinEv) if (e) (void) hipEventDestroy(e);
+    for (hipStream_t st : r->streamx) if (st) (void) hipStreamDestroy(st);
     if (r->film) (void) hipFree(r->film);
     if (r->spill) (void) hipFree(r->spill);
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
@@ -493,7 +494,7 @@ int mi_render_clear(mi_render *r) {
     if (!r) return fail(MI_ERR_INVALID, "mi_render_clear: null"); HIPCHK(hipSetDevice(r->scene->h.device));
     HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream)); HIPCHK(hipMemsetAsync(r->spill, 0, r->filmFloats * 4, r->stream));
     if (r->q.counters) HIPCHK(hipMemsetAsync(r->q.counters, 0, 32, r->stream));
-    if (r->q2.counters) HIPCHK(hipMemsetAsync(r->q2.counters, 0, 32, r->stream));
+    for (Queues &Q : r->qx) if (Q.counters) HIPCHK(hipMemsetAsync(Q.counters, 0, 32, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; r->cancel.store(0); return MI_OK;
 }
 void mi_render_cancel(mi_render *r) { if (r) r->cancel.store(1); }
@@ -507,7 +508,7 @@ static void mark(mi_render *r, int tag, size_t &used, hipStream_t st = nullptr) 
 
 // trace one batch: paths = tile pixels x planes (or an explicit list), all bounces
 static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed, int pool = 0) {
-    const DScene &sc = r->scene->h.d; hipStream_t st = pool ? r->stream2 : r->stream; Queues &Q = pool ? r->q2 : r->q;
+    const DScene &sc = r->scene->h.d; hipStream_t st = r->poolStream(pool); Queues &Q = r->pool(pool);
     (void) list;
     mark(r, 0, evUsed, st);
     mi_launch_generate(sc, r->rc, Q, bd, r->grid, st);
@@ -543,28 +544,30 @@ int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t 
     const uint32_t nrows = (tile.y1 - tile.y0 + rowStride - 1) / rowStride;          // rows y0, y0 + stride, ... below y1
     const uint32_t npix = (tile.x1 - tile.x0) * nrows;
     uint32_t planes = r->p.planes_per_batch;
-    if (!planes) { const uint64_t target = 16u << 20; planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
+    if (!planes) { static const uint64_t target = [] { const char *v = getenv("MI355PT_BATCH_PATHS"); return v && atoll(v) > 0 ? (uint64_t) atoll(v) : (uint64_t) (16u << 20); }(); planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
     const uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
     if (need > r->poolPaths) { int rc = allocPool(r, need); if (rc) return rc; }      // the pool only grows: a short last batch or a smaller tile reuses it
     size_t evUsed = 0; r->launchesAll = 0;
     HIPCHK(hipEventRecord(r->evBegin, r->stream));
-    const bool dual = r->nStreams > 1 && (s1 - s0) > planes;          // more than one batch: alternate the two pools / streams
-    if (dual) { HIPCHK(hipEventRecord(r->joinEv, r->stream)); HIPCHK(hipStreamWaitEvent(r->stream2, r->joinEv, 0)); }
-    int batch = 0; bool filmPending[2] = {false, false};
+    const uint32_t nBatches = (s1 - s0 + planes - 1) / planes;
+    const int nPools = (int) std::min<uint32_t>((uint32_t) r->nStreams, std::max(nBatches, 1u));      // more than one batch: round-robin over the pools / streams
+    if (nPools > 1) HIPCHK(hipEventRecord(r->joinEv[0], r->stream));
+    for (int i = 1; i < nPools; ++i) HIPCHK(hipStreamWaitEvent(r->poolStream(i), r->joinEv[0], 0));
+    int batch = 0, lastFilmPool = -1;
     for (uint32_t s = s0; s < s1; s += planes, ++batch) {
         if (r->cancel.exchange(0)) { HIPCHK(hipDeviceSynchronize()); return fail(MI_CANCELLED, "render cancelled"); }      // consumed where it is observed
-        const int pool = dual ? (batch & 1) : 0; hipStream_t st = pool ? r->stream2 : r->stream;
+        const int pool = batch % nPools; hipStream_t st = r->poolStream(pool);
         BatchDesc bd{}; bd.tile = tile; bd.n_pix = npix; bd.n_planes = std::min(planes, s1 - s); bd.sample_begin = s; bd.n_paths = (uint64_t) npix * bd.n_planes; bd.list = nullptr; bd.row_stride = rowStride;
         int rc = traceBatch(r, bd, nullptr, evUsed, pool); if (rc) return rc;
-        // film accumulation stays in batch order (own-pixel sums are plain read-modify-writes): wait for the other pool's film kernel
-        if (dual && filmPending[pool ^ 1]) HIPCHK(hipStreamWaitEvent(st, r->filmDone[pool ^ 1], 0));
-        mi_launch_film(h.d, pool ? r->q2 : r->q, bd, r->film, r->spill, st);
-        if (dual) { HIPCHK(hipEventRecord(r->filmDone[pool], st)); filmPending[pool] = true; }
+        // film accumulation stays in batch order (own-pixel sums are plain read-modify-writes): wait for the previous batch's film kernel
+        if (nPools > 1 && lastFilmPool >= 0) HIPCHK(hipStreamWaitEvent(st, r->filmDone[lastFilmPool], 0));
+        mi_launch_film(h.d, r->pool(pool), bd, r->film, r->spill, st);
+        if (nPools > 1) { HIPCHK(hipEventRecord(r->filmDone[pool], st)); lastFilmPool = pool; }
         r->samplesTotal += bd.n_paths;
     }
-    if (dual) { HIPCHK(hipEventRecord(r->joinEv, r->stream2)); HIPCHK(hipStreamWaitEvent(r->stream, r->joinEv, 0)); }
+    for (int i = 1; i < nPools; ++i) { HIPCHK(hipEventRecord(r->joinEv[i], r->poolStream(i))); HIPCHK(hipStreamWaitEvent(r->stream, r->joinEv[i], 0)); }
     mark(r, 0, evUsed);
     HIPCHK(hipEventRecord(r->evEnd, r->stream));
     HIPCHK(hipStreamSynchronize(r->stream));
@@ -585,7 +588,7 @@ int mi_render_stats(mi_render *r, mi_stats *out) {
     HIPCHK(hipSetDevice(r->scene->h.device));
     unsigned long long c[4] = {0, 0, 0, 0};
     if (r->q.counters) HIPCHK(hipMemcpy(c, r->q.counters, 32, hipMemcpyDeviceToHost));
-    if (r->q2.counters) { unsigned long long c2[4]; HIPCHK(hipMemcpy(c2, r->q2.counters, 32, hipMemcpyDeviceToHost)); for (int i = 0; i < 4; ++i) c[i] += c2[i]; }
+    for (Queues &Q : r->qx) if (Q.counters) { unsigned long long c2[4]; HIPCHK(hipMemcpy(c2, Q.counters, 32, hipMemcpyDeviceToHost)); for (int i = 0; i < 4; ++i) c[i] += c2[i]; }
     r->stats.rays = c[0]; r->stats.shadow_rays = c[1]; r->stats.path_length_sum = c[2]; r->stats.samples = r->samplesTotal; r->stats.extend_rays = c[0]; r->stats.extend_launches_all = r->launchesAll;
     *out = r->stats; return MI_OK;
 }
@@ -618,7 +621,6 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     if (!r || !pairs || !outLi || !n) return fail(MI_ERR_INVALID, "mi_render_samples: null argument");
     const mi::SceneHost &h = r->scene->h; HIPCHK(hipSetDevice(h.device));
     for (uint64_t i = 0; i < n; ++i) if (pairs[i * 3] >= h.width || pairs[i * 3 + 1] >= h.height) return fail(MI_ERR_INVALID, "mi_render_samples: pixel outside the film");
-    for (uint64_t i = 0; i < n; ++i) if (pairs[i * 3 + 2] >= std::max(r->p.spp, 1u)) return fail(MI_ERR_INVALID, "mi_render_samples: sample index outside [0, spp)");
     if (n > r->poolPaths) { int rc = allocPool(r, n); if (rc) return rc; }
     uint32_t *dList = nullptr; float *dOut = nullptr; uint32_t *dSlots = nullptr;
     HIPCHK(hipMalloc((void **) &dList, n * 12)); HIPCHK(hipMalloc((void **) &dOut, n * 12)); HIPCHK(hipMalloc((void **) &dSlots, n * 4));

@@ -19,13 +19,14 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
         SamplerState ss; float jx, jy;
         if (rc.sampler == 1) {
             uint32_t r0, r1;
-            if (rc.sobol_frame) {      // look_up + dimensions 0 / 1 through the XOR-linear tables (RenderConst; bit-identical to sobolLookUp + sampleSingle)
+            if (rc.sobol_frame && sidx < rc.sobol_nframes) {      // look_up + dimensions 0 / 1 through the XOR-linear tables (RenderConst; bit-identical to sobolLookUp + sampleSingle)
                 const uint32_t scr = rc.sobol_scramble >> (32u - sc.log_res);
                 const uint4 a = rc.sobol_frame[sidx], b = rc.sobol_px[px ^ scr], c = rc.sobol_py[py ^ scr];
                 ss.a = a.x ^ b.x ^ c.x; ss.b = a.y ^ b.y ^ c.y; r0 = rc.sobol_scramble ^ a.z ^ b.z ^ c.z; r1 = rc.sobol_scramble ^ a.w ^ b.w ^ c.w;
                 jx = minf((float) r0 * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS); jy = minf((float) r1 * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
             } else {
-                ss.a = sidx; ss.b = 0;
+                const uint64_t idx = sc.log_res > 1 ? sobolLookUp(sc.sobol_vdc, sc.sobol_vdc_inv, sc.log_res, sidx, px, py, rc.sobol_scramble) : (uint64_t) sidx;
+                ss.a = (uint32_t) idx; ss.b = (uint32_t) (idx >> 32);
                 const SobolTab gt{rc.sobol_nib, rc.nib_count, rc.sobol_scramble};
                 jx = sobolSampleNib(gt, ss.a, ss.b, 0); jy = sobolSampleNib(gt, ss.a, ss.b, 1);
             }

@@ -67,8 +67,26 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             done0 += (uint32_t) __popcll(m0); done1 += (uint32_t) __popcll(m1);
         }
     }
+    // Software pipeline over the 64-path chunks of the segment (RenderConst::shade_flags bit 0): the five queue records of chunk c + 1 are requested before
+    // chunk c is shaded, so their HBM round trip overlaps the ~1000 vector instructions of a bounce instead of heading every chunk; bit 1: the path's
+    // accumulator (needed only by paths that add radiance in this bounce) is requested at the head of the chunk as well, not in the middle of it.
+    const bool pipeLoads = (rc.shade_flags & 1u) != 0, earlyAcc = (rc.shade_flags & 2u) != 0;
+    float4 nx_rd = make_float4(0, 0, 0, 0), nx_hr = nx_rd, nx_s1 = nx_rd; uint4 nx_s0 = make_uint4(0, 0, 0, 0); float nx_pdf = 0; uint32_t nx_slot = 0;
+    auto fetch = [&](uint32_t base_) {
+        const uint32_t j = base_ + lane;
+        if (j < n) {
+            nx_slot = doSort ? (uint32_t) s_order[j] : j; const uint64_t sl = segBase + nx_slot;
+            nx_rd = q.rayD[buf][sl]; nx_hr = q.hit[sl]; nx_s0 = q.st0[buf][sl]; nx_s1 = q.st1[buf][sl]; nx_pdf = q.st2[buf][sl];
+        }
+    };
+    if (pipeLoads && n) fetch(0);
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
+        if (!pipeLoads) fetch(base);
+        const float4 c_rd = nx_rd, c_hr = nx_hr, c_s1 = nx_s1; const uint4 c_s0 = nx_s0; const float c_pdf = nx_pdf; const uint32_t c_slot = nx_slot;
+        float4 accEarly = make_float4(0, 0, 0, 0);
+        if (earlyAcc && i < n) accEarly = q.acc[c_s0.x];
+        if (pipeLoads && base + 64 < n) fetch(base + 64);
         // Two phases per chunk, each closed by its own wave64 ballot, so that the 12 registers of a shadow record are written out before
         // the BSDF-sampling code runs (register budget -> one more resident wave per SIMD):
         //   A: tail of the previous bounce, emitted radiance, emitter sampling  -> shadow queue
@@ -77,9 +95,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         float4 shO, shD, shC;
         Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false;   // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
         if (i < n) {
-            const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
-            float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
-            float prevPdf = q.st2[buf][slot];
+            const uint64_t slot = segBase + c_slot;
+            const float4 rd = c_rd, hr = c_hr, s1 = c_s1; const uint4 s0 = c_s0;
+            const float prevPdf = c_pdf;
             pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
             depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
             const bool prevDelta = RC && ((s0.w >> 17) & 1u) != 0;      // the BSDF sample that spawned this ray was a delta component -> lumPdf = 0 (path.cpp:259-260)
@@ -90,7 +108,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             do {
                 if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :234-248
                     pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
-                    if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
+                    if (depth == 1 && rc.opacity) {                                // records.inl:121-137: alpha = 0 on a camera-ray miss
+                        if (earlyAcc) { accEarly.w = 0.0f; haveAdd = true; } else { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; } }
                     if (ENV) {
                         if (depth == 1) { if (!rc.hide_emitters && !sc.env_texture) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141; with a MIP pyramid k_env_primary has added the filtered lookup
                         else {
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 toSample = true;
             } while (false);
-            if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
+            if (haveAdd) { float4 a = earlyAcc ? accEarly : q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
         }
         // wave64 ballots: order-preserving compaction inside the (wave-owned) segment
         const unsigned long long mS = __ballot(wantShadow);

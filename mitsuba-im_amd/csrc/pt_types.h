@@ -148,7 +148,8 @@ struct RenderConst {
     const uint32_t *sobol_nib; uint32_t nib_count, nib_dims;
     // sobol::look_up (src/samplers/sobolseq.h:99-131) and the first two sample dimensions are XOR-linear in (frame, px, py): three tables of
     // {index lo, index hi, dim-0 bits, dim-1 bits} (api.cpp buildSobolLookupTables), XORed together in k_generate; null when log_res <= 1
-    const uint4 *sobol_frame, *sobol_px, *sobol_py;
+    const uint4 *sobol_frame, *sobol_px, *sobol_py; uint32_t sobol_nframes;   // frames beyond the table (parity entry point only) take sobolLookUp
     float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)
     uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
+    uint32_t shade_flags;                 // k_shade: bit 0 software-pipelined queue loads, bit 1 accumulator requested at the head of a chunk (MI355PT_SHADE_FLAGS, default 3)
 };

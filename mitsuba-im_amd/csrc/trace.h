@@ -161,15 +161,20 @@ DEV bool packetIntersectM(const DScene &sc, AS<true>::p4 s_exact, v3 o, v3 d, fl
     packetPass1<0, MaskT>(groups, sc.packet_gk[0], o, d, mint, maxt, so1e5, mask);
     packetPass1<1, MaskT>(groups + sc.packet_gk[0], sc.packet_gk[1] - sc.packet_gk[0], o, d, mint, maxt, so1e5, mask);
     packetPass1<2, MaskT>(groups + sc.packet_gk[1], sc.packet_gk[2] - sc.packet_gk[1], o, d, mint, maxt, so1e5, mask);
-    while (mask) {
+    while (mask) {      // pass 2, per lane: the reference's test (triaccel.h:96-158) on this lane's next candidate, written without branches (selects only)
         const uint32_t i = sizeof(MaskT) == 8 ? (uint32_t) __builtin_ctzll((unsigned long long) mask) : (uint32_t) __builtin_ctz((uint32_t) mask); mask &= mask - 1;
-        const f4 a = s_exact[i * 3u], b = s_exact[i * 3u + 1u], c = s_exact[i * 3u + 2u];
-        TriAccelD ta; ta.k = __float_as_uint(a.x); ta.n_u = a.y; ta.n_v = a.z; ta.n_d = a.w;
-        ta.a_u = b.x; ta.a_v = b.y; ta.b_nu = b.z; ta.b_nv = b.w; ta.c_nu = c.x; ta.c_nv = c.y; ta.prim = i;
-        float u, v, t;
-        if (triIntersect(ta, o, d, mint, best, u, v, t)) {
-            if (ANY) { found = true; mask = 0; }
-            else if (!found || t < best) { best = t; bprim = i; bu = u; bv = v; found = true; }   // t <= best here; equal t: the earlier (lower) index stays
+        const f4 a = s_exact[i * 3u], b = s_exact[i * 3u + 1u], c = s_exact[i * 3u + 2u];      // k n_u n_v n_d | a_u a_v b_nu b_nv | c_nu c_nv prim pad
+        const bool k0 = __float_as_uint(a.x) == 0u, k1 = __float_as_uint(a.x) == 1u;
+        const float o_u = k0 ? o.y : (k1 ? o.z : o.x), o_v = k0 ? o.z : (k1 ? o.x : o.y), o_k = k0 ? o.x : (k1 ? o.y : o.z);
+        const float d_u = k0 ? d.y : (k1 ? d.z : d.x), d_v = k0 ? d.z : (k1 ? d.x : d.y), d_k = k0 ? d.x : (k1 ? d.y : d.z);
+        const float tt = (a.w - o_u * a.y - o_v * a.z - o_k) / (d_u * a.y + d_v * a.z + d_k);
+        const float hu = o_u + tt * d_u - b.x, hv = o_v + tt * d_v - b.y;
+        const float uu = hv * b.z + hu * b.w, vv = hu * c.x + hv * c.y;
+        const bool ok = !(tt < mint) & !(tt > best) & (uu >= 0) & (vv >= 0) & (uu + vv <= 1.0f);
+        if (ANY) { found |= ok; mask = ok ? (MaskT) 0 : mask; }
+        else {
+            const bool better = ok & (!found | (tt < best));      // tt <= best here; equal t: the earlier (lower) index stays
+            best = better ? tt : best; bprim = better ? i : bprim; bu = better ? uu : bu; bv = better ? vv : bv; found |= ok;
         }
     }
     if (ANY && found) return true;
