@@ -14,7 +14,10 @@
 extern "C" {
 void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-void mi_launch_shade(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
+void mi_launch_shade_d(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
+void mi_launch_shade_d_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
+void mi_launch_shade_rc(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
+void mi_launch_shade_rc_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
@@ -26,6 +29,24 @@ void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hi
 void mi_launch_debug_sincosf(const float *, uint64_t, float *, hipStream_t);
 }
 
+// Shading stage dispatch.  Dynamic LDS: Sobol nibble tables + (small scenes) the scene tables + (scenes with non-diffuse BSDFs) the per-wave path-order list.
+// Scenes that MIX plain diffuse surfaces with other BSDFs are shaded by two launches per bounce: class 1 (diffuse hits and misses, the 128-register
+// diffuse-only kernel) and class 2 (everything else, the full kernel, appending behind class 1); see shade.h.
+static const bool kNoClassSplit = getenv("MI355PT_NO_CLASS_SPLIT") != nullptr;      // A/B switch, read once
+static void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+    size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
+    const bool env = sc.env_index >= 0;
+    if (sc.small_tables) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
+    RenderConst rcl = rc; rcl.order_offset_words = 0;
+    if (sc.has_roughconductor && q.cap <= 8192u) {      // path-order list: only where it still fits the 64 KB a launch may request (else unsorted shading)
+        const uint32_t off = (uint32_t) ((lds + 15) / 16 * 4); const size_t total = (size_t) off * 4 + (size_t) q.cap * 2 * 4 + 16;
+        if (total <= 64 * 1024) { rcl.order_offset_words = off; lds = total; }
+    }
+    auto simple = env ? mi_launch_shade_d_env : mi_launch_shade_d; auto full = env ? mi_launch_shade_rc_env : mi_launch_shade_rc;
+    if (!sc.has_roughconductor) simple(sc, rcl, q, buf, grid, lds, 0, st);
+    else if (sc.has_diffuse && rcl.order_offset_words && !kNoClassSplit) { simple(sc, rcl, q, buf, grid, lds, 1, st); full(sc, rcl, q, buf, grid, lds, 2, st); }
+    else full(sc, rcl, q, buf, grid, lds, 0, st);
+}
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MI_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -283,7 +304,8 @@ int SceneHost::upload(int dev) {
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
-    d.has_roughconductor = 0; for (const mi_material &m : materials) if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1;   // any non-diffuse material -> k_shade<RC = true>
+    d.has_roughconductor = 0; d.has_diffuse = 0;
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     if (up(&dPacketGroups, packetGroups) | up(&dPacketExact, packetExact)) return 1;
@@ -425,7 +447,6 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         }
         r->rc.sobol_scramble = v0;                           // single precision build: the low 32 bits of (v1 << 32) + v0 (sobolseq.h:87-96)
     }
-    { const char *sf = getenv("MI355PT_SHADE_FLAGS"); r->rc.shade_flags = sf && sf[0] ? (uint32_t) atoi(sf) : 3u; }
     r->rc.sampler = p->sampler; r->rc.seed_mix = (uint32_t) p->seed * 0x9E3779B9u; r->rc.inv_sqrt_spp = 1.0f / std::sqrt((float) (p->spp ? p->spp : 1u));
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch

@@ -130,7 +130,7 @@ struct DScene {
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
     // triangles dropped), exact Wald records in ORIGINAL triangle order for pass 2, largest |coordinate| of the scene box (error-margin scale)
     const struct PacketGroupD *packet_groups; const TriAccelD *packet_exact; uint32_t packet_gk[3]; float packet_scale;
-    uint32_t has_roughconductor;          // selects the shade kernel variant
+    uint32_t has_roughconductor, has_diffuse;   // non-diffuse / plain diffuse materials present: select the shade kernel variants (both: two launches per bounce, shade.h)
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none
     const float *env_rgb, *env_cdf_cols, *env_cdf_rows, *env_row_weights;
@@ -151,5 +151,4 @@ struct RenderConst {
     const uint4 *sobol_frame, *sobol_px, *sobol_py; uint32_t sobol_nframes;   // frames beyond the table (parity entry point only) take sobolLookUp
     float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)
     uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
-    uint32_t shade_flags;                 // k_shade: bit 0 software-pipelined queue loads, bit 1 accumulator requested at the head of a chunk (MI355PT_SHADE_FLAGS, default 3)
 };

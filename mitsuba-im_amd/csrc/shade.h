@@ -1,4 +1,6 @@
-// kernels_shade.hip -- shading stage: one bounce of MIPathTracer::Li per launch (see kernels_common.h)
+// shade.h -- the shading stage: one bounce of MIPathTracer::Li per launch (see kernels_common.h).  Instantiated by kernels_shade_*.hip, one translation
+// unit per (RC, ENV) pair so that `make -j` compiles the variants side by side.
+#pragma once
 #include "kernels_common.h"
 
 // ---------------------------------------------------------------------------------------------- shade
@@ -6,7 +8,10 @@
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
+// CLS (scenes that MIX BSDF classes): 0 = shade every path of the segment; 1 = only the paths that hit a plain diffuse surface (or nothing), with the
+// diffuse-only code (RC = false: 128 VGPRs); 2 = only the paths on any other BSDF, with the full code (RC = true), appending its survivors / shadow records
+// behind those of the class-1 launch.  The diffuse majority of a mixed scene no longer runs the 200+-register kernel.
+template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX, int CLS>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     // (uniform) registers -- no LDS exchange and no workgroup barrier anywhere in the loop; the four waves of a workgroup only share the
     // LDS copies of the tables above.
     uint16_t *s_order = reinterpret_cast<uint16_t *>(s_dyn + rc.order_offset_words) + (size_t) wave * q.cap;
-    const bool doSort = RC && rc.order_offset_words != 0 && q.cap <= 0xFFFFu;
+    const bool doSort = (RC || CLS != 0) && rc.order_offset_words != 0 && q.cap <= 0xFFFFu;      // CLS != 0 is only launched with the list in place
     unsigned long long pathLen = 0, shadowRays = 0;
     __syncthreads();                                         // tables staged
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -51,8 +56,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
     uint32_t outA = 0, outS = 0;                             // survivors / shadow records written so far (uniform)
+    if (CLS == 2) { outA = q.count[nb][seg]; outS = q.shCount[seg]; }      // append behind the class-1 launch
+    uint32_t done0 = 0, done1 = 0;                           // uniform running counts (front / back)
     if (doSort) {
-        uint32_t done0 = 0, done1 = 0;                       // uniform running counts (front / back)
         for (uint32_t base = 0; base < n; base += 64) {
             const uint32_t i = base + lane; int cls = 2;
             if (i < n) {
@@ -67,26 +73,10 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             done0 += (uint32_t) __popcll(m0); done1 += (uint32_t) __popcll(m1);
         }
     }
-    // Software pipeline over the 64-path chunks of the segment (RenderConst::shade_flags bit 0): the five queue records of chunk c + 1 are requested before
-    // chunk c is shaded, so their HBM round trip overlaps the ~1000 vector instructions of a bounce instead of heading every chunk; bit 1: the path's
-    // accumulator (needed only by paths that add radiance in this bounce) is requested at the head of the chunk as well, not in the middle of it.
-    const bool pipeLoads = (rc.shade_flags & 1u) != 0, earlyAcc = (rc.shade_flags & 2u) != 0;
-    float4 nx_rd = make_float4(0, 0, 0, 0), nx_hr = nx_rd, nx_s1 = nx_rd; uint4 nx_s0 = make_uint4(0, 0, 0, 0); float nx_pdf = 0; uint32_t nx_slot = 0;
-    auto fetch = [&](uint32_t base_) {
-        const uint32_t j = base_ + lane;
-        if (j < n) {
-            nx_slot = doSort ? (uint32_t) s_order[j] : j; const uint64_t sl = segBase + nx_slot;
-            nx_rd = q.rayD[buf][sl]; nx_hr = q.hit[sl]; nx_s0 = q.st0[buf][sl]; nx_s1 = q.st1[buf][sl]; nx_pdf = q.st2[buf][sl];
-        }
-    };
-    if (pipeLoads && n) fetch(0);
-    for (uint32_t base = 0; base < n; base += 64) {
+    const bool useList = doSort;
+    const uint32_t listBase = CLS == 2 ? n - done1 : 0u, nList = CLS == 1 ? done0 : (CLS == 2 ? done1 : n);
+    for (uint32_t base = 0; base < nList; base += 64) {
         const uint32_t i = base + lane;
-        if (!pipeLoads) fetch(base);
-        const float4 c_rd = nx_rd, c_hr = nx_hr, c_s1 = nx_s1; const uint4 c_s0 = nx_s0; const float c_pdf = nx_pdf; const uint32_t c_slot = nx_slot;
-        float4 accEarly = make_float4(0, 0, 0, 0);
-        if (earlyAcc && i < n) accEarly = q.acc[c_s0.x];
-        if (pipeLoads && base + 64 < n) fetch(base + 64);
         // Two phases per chunk, each closed by its own wave64 ballot, so that the 12 registers of a shadow record are written out before
         // the BSDF-sampling code runs (register budget -> one more resident wave per SIMD):
         //   A: tail of the previous bounce, emitted radiance, emitter sampling  -> shadow queue
@@ -94,10 +84,10 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
         Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false;   // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
-        if (i < n) {
-            const uint64_t slot = segBase + c_slot;
-            const float4 rd = c_rd, hr = c_hr, s1 = c_s1; const uint4 s0 = c_s0;
-            const float prevPdf = c_pdf;
+        if (i < nList) {
+            const uint64_t slot = segBase + (useList ? (uint32_t) s_order[listBase + i] : i);
+            float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
+            float prevPdf = q.st2[buf][slot];
             pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
             depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
             const bool prevDelta = RC && ((s0.w >> 17) & 1u) != 0;      // the BSDF sample that spawned this ray was a delta component -> lumPdf = 0 (path.cpp:259-260)
@@ -108,8 +98,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             do {
                 if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :234-248
                     pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
-                    if (depth == 1 && rc.opacity) {                                // records.inl:121-137: alpha = 0 on a camera-ray miss
-                        if (earlyAcc) { accEarly.w = 0.0f; haveAdd = true; } else { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; } }
+                    if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
                     if (ENV) {
                         if (depth == 1) { if (!rc.hide_emitters && !sc.env_texture) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141; with a MIP pyramid k_env_primary has added the filtered lookup
                         else {
@@ -206,7 +195,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 toSample = true;
             } while (false);
-            if (haveAdd) { float4 a = earlyAcc ? accEarly : q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
+            if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
         }
         // wave64 ballots: order-preserving compaction inside the (wave-owned) segment
         const unsigned long long mS = __ballot(wantShadow);
@@ -263,22 +252,14 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 }
 
 
-// ---------------------------------------------------------------------------------------------- launch wrapper (used by api.cpp)
-extern "C" {
-void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
-    size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
-    const bool env = sc.env_index >= 0, small = sc.small_tables != 0;
-    if (small) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
-    RenderConst rcl = rc; rcl.order_offset_words = 0;
-    if (sc.has_roughconductor && q.cap <= 8192u) {      // material-order list: only where it still fits the 64 KB a launch may request (else unsorted shading)
-        const uint32_t off = (uint32_t) ((lds + 15) / 16 * 4); const size_t total = (size_t) off * 4 + (size_t) q.cap * 2 * (WG / 64) + 16;
-        if (total <= 64 * 1024) { rcl.order_offset_words = off; lds = total; }
-    }
-#define MI_SHADE(RC, ENV, SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
-                                   else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); \
-                                   else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false>), dim3(grid), dim3(WG), lds, st, sc, rcl, q, buf); } while (0)
-    if (small) { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, true); else MI_SHADE(true, false, true); } else { if (env) MI_SHADE(false, true, true); else MI_SHADE(false, false, true); } }
-    else { if (sc.has_roughconductor) { if (env) MI_SHADE(true, true, false); else MI_SHADE(true, false, false); } else { if (env) MI_SHADE(false, true, false); else MI_SHADE(false, false, false); } }
+
+// launch every (SMALL, AN, TEX) variant of one (RC, ENV, CLS) combination
+template <bool RC, bool ENV, int CLS>
+static void launchShadeVariant(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
+    const bool small = sc.small_tables != 0;
+#define MI_SHADE(SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true, CLS>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
+                          else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false, CLS>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
+                          else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false, CLS>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); } while (0)
+    if (small) MI_SHADE(true); else MI_SHADE(false);
 #undef MI_SHADE
-}
 }
