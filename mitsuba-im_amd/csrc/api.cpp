@@ -14,10 +14,10 @@
 extern "C" {
 void mi_launch_generate(const DScene &, const RenderConst &, const Queues &, const BatchDesc &, uint32_t, hipStream_t);
 void mi_launch_extend(const DScene &, const Queues &, int, uint32_t, hipStream_t);
-void mi_launch_shade_d(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
-void mi_launch_shade_d_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
-void mi_launch_shade_rc(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
-void mi_launch_shade_rc_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, int, hipStream_t);
+void mi_launch_shade_d(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shade_d_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shade_rc(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shade_rc_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
@@ -30,10 +30,11 @@ void mi_launch_debug_sincosf(const float *, uint64_t, float *, hipStream_t);
 }
 
 // Shading stage dispatch.  Dynamic LDS: Sobol nibble tables + (small scenes) the scene tables + (scenes with non-diffuse BSDFs) the per-wave path-order list.
-// Scenes that MIX plain diffuse surfaces with other BSDFs are shaded by two launches per bounce: class 1 (diffuse hits and misses, the 128-register
-// diffuse-only kernel) and class 2 (everything else, the full kernel, appending behind class 1); see shade.h.
-static const bool kNoClassSplit = getenv("MI355PT_NO_CLASS_SPLIT") != nullptr;      // A/B switch, read once
-static void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+// (Round 2 experiment, removed: two launches per bounce -- diffuse hits through the diffuse-only kernel, the rest through the full kernel -- measured SLOWER
+// than one launch of the full kernel over the class-sorted list, 1579 vs 1675 Msamples/s on the Veach scene: a wave of diffuse hits already skips the other
+// BSDFs' code at run time, and the stage runs at two waves per SIMD either way)
+static void mi_launch_shade(const DScene &scIn, bool ldsTables, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
+    DScene sc = scIn; sc.small_tables = ldsTables ? 1u : 0u;
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
     const bool env = sc.env_index >= 0;
     if (sc.small_tables) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
@@ -42,10 +43,8 @@ static void mi_launch_shade(const DScene &sc, const RenderConst &rc, const Queue
         const uint32_t off = (uint32_t) ((lds + 15) / 16 * 4); const size_t total = (size_t) off * 4 + (size_t) q.cap * 2 * 4 + 16;
         if (total <= 64 * 1024) { rcl.order_offset_words = off; lds = total; }
     }
-    auto simple = env ? mi_launch_shade_d_env : mi_launch_shade_d; auto full = env ? mi_launch_shade_rc_env : mi_launch_shade_rc;
-    if (!sc.has_roughconductor) simple(sc, rcl, q, buf, grid, lds, 0, st);
-    else if (sc.has_diffuse && rcl.order_offset_words && !kNoClassSplit) { simple(sc, rcl, q, buf, grid, lds, 1, st); full(sc, rcl, q, buf, grid, lds, 2, st); }
-    else full(sc, rcl, q, buf, grid, lds, 0, st);
+    if (!sc.has_roughconductor) (env ? mi_launch_shade_d_env : mi_launch_shade_d)(sc, rcl, q, buf, grid, lds, st);
+    else (env ? mi_launch_shade_rc_env : mi_launch_shade_rc)(sc, rcl, q, buf, grid, lds, st);
 }
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -64,6 +63,7 @@ struct mi_render {
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
     mi_stats stats{};
     uint64_t samplesTotal = 0, launchesAll = 0;
+    bool ldsTables = false;   // this render stages the scene tables in LDS (scene eligible and everything fits 64 KB together with the Sobol tables and the order list)
     uint32_t *dNib = nullptr; void *dSobolTabs = nullptr;   // dSobolTabs: the three look_up tables of k_generate (frame, px, py), one allocation
     // optional further path pools + streams: consecutive batches go round-robin through them, so the ALU-bound traversal kernels of one batch
     // overlap the latency-bound shading kernels of the others on the same CUs (MI355PT_STREAMS = 1..4 pools, default 2)
@@ -303,7 +303,7 @@ int SceneHost::upload(int dev) {
     d.bvh_depth = (uint32_t) bvhDepth;
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
-      d.small_tables = (nTris <= 128 && mats.size() <= 16 && emittersD.size() <= 8 && areaCdf.size() <= 512 && !(ns && ns[0] == '1')) ? 1u : 0u; }
+      d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
     for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     const char *noPacket = getenv("MI355PT_NO_PACKET");
@@ -459,7 +459,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
             uint32_t x = 0; for (uint32_t b = 0; b < 4; ++b) if (((v >> b) & 1u) && 4 * n + b < MI_SOBOL_SIZE) x ^= g_sobolM32[(size_t) dmn * MI_SOBOL_SIZE + 4 * n + b];
             nib[((size_t) dmn * nibs + n) * 16 + v] = x;
         }
-        if ((size_t) dims * nibs * 64 + smallTableBytes(s->h) + 64 > 64 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the Sobol lookup tables (maxDepth x index bits) and the staged scene tables exceed the 64 KB of LDS a workgroup may request (reduce maxDepth or spp)");
+        if ((size_t) dims * nibs * 64 + 64 > 64 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the Sobol lookup tables (maxDepth x index bits) exceed the 64 KB of LDS a workgroup may request (reduce maxDepth or spp)");
         HIPCHK(hipMalloc((void **) &r->dNib, nib.size() * 4)); HIPCHK(hipMemcpy(r->dNib, nib.data(), nib.size() * 4, hipMemcpyHostToDevice));
         r->rc.sobol_nib = r->dNib; r->rc.nib_count = nibs; r->rc.nib_dims = dims;
         // look_up tables of k_generate.  index(frame, px, py) = (frame << 2m) ^ Inv * ((px << m | py) ^ Delta * frame)  (sobolseq.h:99-131, all XOR-linear) =
@@ -485,6 +485,10 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     { const char *ns = getenv("MI355PT_STREAMS"); r->nStreams = ns && ns[0] >= '1' && ns[0] <= '4' ? ns[0] - '0' : 2; }
     for (int i = 1; i < r->nStreams; ++i) HIPCHK(hipStreamCreate(&r->streamx[i - 1]));
     for (int i = 0; i < r->nStreams; ++i) { HIPCHK(hipEventCreateWithFlags(&r->filmDone[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&r->joinEv[i], hipEventDisableTiming)); }
+    {   // scene tables in LDS: only if they fit next to the Sobol tables, leaving room for the order list of mixed-material scenes (8 KB at the default segment size)
+        const size_t nibBytes = p->sampler == MI_SAMPLER_SOBOL ? (size_t) r->rc.nib_dims * r->rc.nib_count * 64 : 16;
+        r->ldsTables = s->h.d.small_tables && nibBytes + smallTableBytes(s->h) + (s->h.d.has_roughconductor ? 8192 + 64 : 64) <= 64 * 1024;
+    }
     const int W = (int) s->h.width + 2 * s->h.border, H = (int) s->h.height + 2 * s->h.border;
     r->filmFloats = (size_t) W * H * 5;
     HIPCHK(hipMalloc((void **) &r->film, r->filmFloats * 4)); HIPCHK(hipMemset(r->film, 0, r->filmFloats * 4));
@@ -537,7 +541,7 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     for (int depth = 1; depth <= maxDepth; ++depth) {
         mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
         if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) mi_launch_env_primary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
-        mark(r, 2, evUsed, st); mi_launch_shade(sc, r->rc, Q, buf, r->gridShade, st);
+        mark(r, 2, evUsed, st); mi_launch_shade(sc, r->ldsTables, r->rc, Q, buf, r->gridShade, st);
         if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces

@@ -1,5 +1,5 @@
-// kernels_shade_d_env.hip -- k_shade<RC = false, ENV = true>: path classes 0 and 1 (diffuse-only code); see shade.h
+// kernels_shade_d_env.hip -- k_shade<RC = false, ENV = true>; see shade.h
 #include "shade.h"
-extern "C" void mi_launch_shade_d_env(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, int cls, hipStream_t st) {
-    if (cls == 0) launchShadeVariant<false, true, 0>(sc, rc, q, buf, grid, lds, st); else launchShadeVariant<false, true, 1>(sc, rc, q, buf, grid, lds, st);
+extern "C" void mi_launch_shade_d_env(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
+    launchShadeVariant<false, true>(sc, rc, q, buf, grid, lds, st);
 }

@@ -1,5 +1,5 @@
-// kernels_shade_rc_env.hip -- k_shade<RC = true, ENV = true>: path classes 0 and 2 (every BSDF); see shade.h
+// kernels_shade_rc_env.hip -- k_shade<RC = true, ENV = true>; see shade.h
 #include "shade.h"
-extern "C" void mi_launch_shade_rc_env(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, int cls, hipStream_t st) {
-    if (cls == 0) launchShadeVariant<true, true, 0>(sc, rc, q, buf, grid, lds, st); else launchShadeVariant<true, true, 2>(sc, rc, q, buf, grid, lds, st);
+extern "C" void mi_launch_shade_rc_env(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
+    launchShadeVariant<true, true>(sc, rc, q, buf, grid, lds, st);
 }

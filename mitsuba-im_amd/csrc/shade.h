@@ -8,10 +8,7 @@
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-// CLS (scenes that MIX BSDF classes): 0 = shade every path of the segment; 1 = only the paths that hit a plain diffuse surface (or nothing), with the
-// diffuse-only code (RC = false: 128 VGPRs); 2 = only the paths on any other BSDF, with the full code (RC = true), appending its survivors / shadow records
-// behind those of the class-1 launch.  The diffuse majority of a mixed scene no longer runs the 200+-register kernel.
-template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX, int CLS>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
+template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -48,7 +45,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     // (uniform) registers -- no LDS exchange and no workgroup barrier anywhere in the loop; the four waves of a workgroup only share the
     // LDS copies of the tables above.
     uint16_t *s_order = reinterpret_cast<uint16_t *>(s_dyn + rc.order_offset_words) + (size_t) wave * q.cap;
-    const bool doSort = (RC || CLS != 0) && rc.order_offset_words != 0 && q.cap <= 0xFFFFu;      // CLS != 0 is only launched with the list in place
+    const bool doSort = RC && rc.order_offset_words != 0 && q.cap <= 0xFFFFu;
     unsigned long long pathLen = 0, shadowRays = 0;
     __syncthreads();                                         // tables staged
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -56,7 +53,6 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     const uint32_t n = q.count[buf][seg];
     const uint64_t segBase = (uint64_t) seg * q.cap;
     uint32_t outA = 0, outS = 0;                             // survivors / shadow records written so far (uniform)
-    if (CLS == 2) { outA = q.count[nb][seg]; outS = q.shCount[seg]; }      // append behind the class-1 launch
     uint32_t done0 = 0, done1 = 0;                           // uniform running counts (front / back)
     if (doSort) {
         for (uint32_t base = 0; base < n; base += 64) {
@@ -73,9 +69,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             done0 += (uint32_t) __popcll(m0); done1 += (uint32_t) __popcll(m1);
         }
     }
-    const bool useList = doSort;
-    const uint32_t listBase = CLS == 2 ? n - done1 : 0u, nList = CLS == 1 ? done0 : (CLS == 2 ? done1 : n);
-    for (uint32_t base = 0; base < nList; base += 64) {
+    for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
         // Two phases per chunk, each closed by its own wave64 ballot, so that the 12 registers of a shadow record are written out before
         // the BSDF-sampling code runs (register budget -> one more resident wave per SIMD):
@@ -84,8 +78,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
         Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false;   // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
-        if (i < nList) {
-            const uint64_t slot = segBase + (useList ? (uint32_t) s_order[listBase + i] : i);
+        if (i < n) {
+            const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
             float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
             float prevPdf = q.st2[buf][slot];
             pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
@@ -253,13 +247,13 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 
 
 
-// launch every (SMALL, AN, TEX) variant of one (RC, ENV, CLS) combination
-template <bool RC, bool ENV, int CLS>
+// launch the (SMALL, AN, TEX) variant of one (RC, ENV) combination that fits the scene
+template <bool RC, bool ENV>
 static void launchShadeVariant(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool small = sc.small_tables != 0;
-#define MI_SHADE(SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true, CLS>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
-                          else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false, CLS>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
-                          else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false, CLS>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); } while (0)
+#define MI_SHADE(SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
+                          else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
+                          else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); } while (0)
     if (small) MI_SHADE(true); else MI_SHADE(false);
 #undef MI_SHADE
 }
