@@ -21,6 +21,9 @@ BSDF_DIFFTRANS = 6        # src/bsdfs/difftrans.cpp: reflectance = transmittance
 BSDF_ROUGHPLASTIC = 7     # src/bsdfs/roughplastic.cpp: alpha, distr, eta[0], specular, reflectance = diffuseReflectance, k = (Tdiff_int, table offset, table length)
 BSDF_THINDIELECTRIC = 8   # src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance
 BSDF_MASK = 9             # src/bsdfs/mask.cpp: reflectance = opacity (constant or textured), distr = index of the nested material record (an earlier one)
+BSDF_MIXTURE = 10         # src/bsdfs/mixturebsdf.cpp: distr = number of children (2..4); their material indices in reflectance[0..2], eta[0] (as numbers), weights in k[0..2], specular[0]
+BSDF_BUMPMAP = 11         # src/bsdfs/bumpmap.cpp: distr = index of the nested material record, bound texture = the displacement, alpha = factor of an enclosing `scale` texture
+BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
 EMITTER_ENVMAP = 1
@@ -99,9 +102,18 @@ def rough_transmittance_slice(distr, ior, alpha):
 
 def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
               distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
-              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False, alpha_v=None, nested=None):
+              specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False, alpha_v=None, nested=None, weights=None, texture=-1, scale=1.0):
     if kind == BSDF_MASK:
         distr = int(nested)                           # reflectance = opacity
+    if kind in (BSDF_BUMPMAP, BSDF_NORMALMAP):        # wrapper around record `nested`; `texture` = displacement / normal map, `scale` = ScaleTexture factor (bumpmap)
+        d = dict(type=kind, twosided=0, distr=int(nested), sample_visible=0, nonlinear=0, table=None, texture=int(texture), aniso=0,
+                 reflectance=(0.0, 0.0, 0.0), alpha=float(scale), eta=(0.0, 0.0, 0.0), k=(0.0, 0.0, 0.0), specular=(0.0, 0.0, 0.0))
+        return d
+    if kind == BSDF_MIXTURE:                          # children = `nested` (list of 2..4 earlier records), `weights` as given (rescaled by the BSDF itself when they sum to > 1)
+        ch = [float(int(c)) for c in nested] + [0.0] * (4 - len(nested)); w = [float(f32(x)) for x in weights] + [0.0] * (4 - len(weights))
+        if not (2 <= len(nested) <= 4) or len(nested) != len(weights): raise ValueError("mixturebsdf: 2..4 children with one weight each")
+        return dict(type=kind, twosided=int(twosided), distr=len(nested), sample_visible=0, nonlinear=0, table=None, texture=-1, aniso=0,
+                    reflectance=tuple(ch[:3]), alpha=0.0, eta=(ch[3], 0.0, 0.0), k=tuple(w[:3]), specular=(w[3], 0.0, 0.0))
     if kind == BSDF_ROUGHDIELECTRIC:
         eta = (float(f32(ior)), 0.0, 0.0)
     table = None
@@ -716,6 +728,54 @@ def bitmap_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6,
     out = finish_scene(sc.pos, sc.idx, sc.shapes, sc.bsdfs, sc.emitters, sc.cam_to_world, sc.xfov, sc.near, sc.far, width, height, spp, sampler, max_depth, rr_depth,
                        seed=seed, normals=sc.nrm, uvs=sc.uv, name="bitmap_room", textures=tex)
     return out
+
+
+def normal_map_image(w=64, h=48):
+    """A tangent-space normal map (RGB = 0.5 + 0.5 n) of a rippled height field, closed form."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64); u = (x + 0.5) / w; v = (y + 0.5) / h
+    hx = 0.35 * np.cos(2 * np.pi * 3 * u) * np.sin(2 * np.pi * 2 * v); hy = 0.35 * np.sin(2 * np.pi * 3 * u) * np.cos(2 * np.pi * 2 * v)
+    n = np.stack([-hx, -hy, np.ones_like(hx)], -1); n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    return np.ascontiguousarray((0.5 + 0.5 * n).astype(f32))
+
+
+def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, strict_normals=False):
+    """The textured room with the three BSDF adapters of SURVEY §8 f2: `bumpmap` floor (bitmap displacement under a `scale` texture, bilinear gradient),
+    `normalmap` wall over a twosided rough conductor, a `mixturebsdf` mound (plastic + checkerboard diffuse), a twosided three-way mixture whose weights sum to
+    1.4 (rescaled by the BSDF), a bump-mapped mixture (grid displacement: finite-difference gradient) and a mask over a bump-mapped diffuse."""
+    sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed)
+    pyr = load_texture_pyramid(); nimg = normal_map_image()
+    tex = [make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=2.0, vscale=1.5, uoffset=0.05, filter_type=MIP_BILINEAR),
+           make_texture(TEXTURE_BITMAP, pyramid=dict(base=nimg, levels=build_mip_pyramid(nimg, WRAP_REPEAT, WRAP_REPEAT)), uscale=1.5, vscale=1.0, filter_type=MIP_BILINEAR),
+           make_texture(TEXTURE_CHECKERBOARD, (0.75, 0.7, 0.2), (0.15, 0.25, 0.6), uscale=4.0, vscale=4.0),
+           make_texture(TEXTURE_GRID, (0.9, 0.9, 0.9), (0.1, 0.1, 0.1), line_width=0.08, uscale=3.0, vscale=3.0)]
+    B = []
+    def add(**kw): B.append(make_bsdf(**kw)); return len(B) - 1
+    m0 = add(reflectance=(0.6, 0.6, 0.6))
+    floor = add(kind=BSDF_BUMPMAP, nested=m0, texture=0, scale=0.25)
+    m2 = add(kind=BSDF_ROUGHCONDUCTOR, alpha=0.2, distr=DISTR_GGX, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), twosided=True)
+    wall = add(kind=BSDF_NORMALMAP, nested=m2, texture=1)
+    m4 = add(kind=BSDF_PLASTIC, reflectance=(0.25, 0.5, 0.3), ior=1.49)
+    m5 = add(reflectance=(0.5, 0.5, 0.5)); B[m5]["texture"] = 2
+    mound = add(kind=BSDF_MIXTURE, nested=[m4, m5], weights=[0.7, 0.3])
+    m7 = add(kind=BSDF_ROUGHCONDUCTOR, alpha=0.15, distr=DISTR_BECKMANN, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
+    m8 = add(reflectance=(0.7, 0.15, 0.1))
+    panel = add(kind=BSDF_MIXTURE, nested=[m7, m8, m0], weights=[0.6, 0.5, 0.3], twosided=True)
+    light = add(reflectance=(0.5, 0.5, 0.5))
+    bumpmix = add(kind=BSDF_BUMPMAP, nested=mound, texture=3, scale=0.03)
+    masked = add(kind=BSDF_MASK, reflectance=(0.55, 0.6, 0.7), nested=floor)
+    shapes = [dict(s) for s in sc.shapes]
+    for sh, m in zip(shapes, (floor, wall, mound, panel, light)): sh["bsdf"] = m
+    shapes[3]["has_uv"] = 1
+    uv = sc.uv.copy(); uv[shapes[3]["first_vert"]:shapes[3]["first_vert"] + 4] = np.array([(0, 0), (0, 1), (1, 1), (1, 0)], f32)
+    # two more quads: a bump-mapped mixture leaning against the left side, a masked bump-mapped sheet in front of the mound
+    verts = [tuple(v) for v in sc.pos]; tris = [tuple(t) for t in sc.idx]; nrm = [tuple(n) for n in sc.nrm]; uvl = [tuple(t) for t in uv]
+    def quad(pts, n, mat):
+        b0 = len(verts); verts.extend(pts); nrm.extend([n] * 4); uvl.extend([(0, 0), (0, 1), (1, 1), (1, 0)]); tris.extend([(b0, b0 + 1, b0 + 2), (b0, b0 + 2, b0 + 3)])
+        shapes.append(dict(first_tri=len(tris) - 2, tri_count=2, first_vert=b0, vert_count=4, bsdf=mat, emitter=-1, face_normals=1, has_uv=1))
+    quad([(-3.2, 0.0, 0.5), (-3.2, 1.6, 1.3), (-1.9, 1.6, 1.3), (-1.9, 0.0, 0.5)], (0.0, 0.0, -1.0), bumpmix)
+    quad([(0.6, 0.0, -2.2), (0.6, 1.1, -2.2), (1.9, 1.1, -1.9), (1.9, 0.0, -1.9)], (0.0, 0.0, -1.0), masked)
+    return finish_scene(verts, tris, shapes, B, sc.emitters, sc.cam_to_world, sc.xfov, sc.near, sc.far, width, height, spp, sampler, max_depth, rr_depth,
+                        seed=seed, normals=nrm, uvs=uvl, name="layered_room", textures=tex, strict_normals=strict_normals)
 
 
 def textured_plastics(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, rough=True):

@@ -799,7 +799,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC; }
@@ -1355,7 +1355,10 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
     return w;
 }
-typedef struct { mat_t inner; int masked; v3 opacity; float prob; } smat_t;       /* a hit's material with its textures evaluated and a `mask` wrapper resolved (below) */
+/* a hit's material with its textures evaluated and its wrappers resolved (below): mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDFs */
+typedef struct { mat_t inner; int masked; v3 opacity; float prob;
+                 int bumped; v3 ps, pt, pn; const hit_t *its;           /* bumpmap / normalmap: the perturbed shading frame; the hit's own frame stays the query frame */
+                 int n_mix; mat_t mix[4]; float w[4], p[4]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
 static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo);
 static float sm_pdf(const smat_t *sm, v3 wi, v3 wo);
@@ -1772,31 +1775,163 @@ static void apply_texture(const orc_scene *s, mat_t *m, const hit_t *its, const 
     if (want_partials && s->textures[tex - 1].type == 2) { compute_partials(its, o, *rxd, *ryd, &pa[0], &pa[1], &pa[2], &pa[3]); partials = pa; }
     v3 c = texture_eval(s, &s->textures[tex - 1], its->uvx, its->uvy, partials); m->m.reflectance[0] = c.x; m->m.reflectance[1] = c.y; m->m.reflectance[2] = c.z;
 }
+/* ---- bumpmap / normalmap: src/bsdfs/bumpmap.cpp:140-250, normalmap.cpp:108-260.  A record of type 11 / 12 perturbs the shading frame of the nested record
+ * `distr` from its bound texture (bumpmap: luminance of the displacement's uv gradient, `alpha` = the factor of an enclosing `scale` texture; normalmap: the
+ * texel as a tangent-space normal); eval / pdf / sample run the nested BSDF in the perturbed frame and reject directions whose cosines differ in sign between
+ * the two frames.  Texture2D::evalGradient (src/librender/texture.cpp:123-141): finite differences over eps = 1e-4 for the procedural textures, the bilinear
+ * gradient of MIP level 0 for bitmaps (src/textures/bitmap.cpp:459-483, include/mitsuba/render/mipmap.h:602-627). */
+static void mip_gradient_bilinear(const orc_scene *s, const orc_texture *t, float uvx, float uvy, v3 *gu, v3 *gv) {
+    *gu = *gv = V(0, 0, 0);
+    if (!isfinite(uvx) || !isfinite(uvy)) return;
+    const uint32_t *L = &s->tex_levels[t->first_level * 3]; const float sx = (float) (int) L[0], sy = (float) (int) L[1];
+    float u = uvx * sx - 0.5f, v = uvy * sy - 0.5f;
+    int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    float dx = u - (float) xPos, dy = v - (float) yPos;
+    v3 p00 = mip_texel(s, t, 0, xPos, yPos), p10 = mip_texel(s, t, 0, xPos + 1, yPos), p01 = mip_texel(s, t, 0, xPos, yPos + 1), p11 = mip_texel(s, t, 0, xPos + 1, yPos + 1);
+    v3 tmp = sub(add(p01, p10), p11);
+    *gu = scale(sub(add(p10, scale(p00, dy - 1)), scale(tmp, dy)), sx);
+    *gv = scale(sub(add(p01, scale(p00, dx - 1)), scale(tmp, dx)), sy);
+}
+static void texture_gradient(const orc_scene *s, const orc_texture *t, float u, float v, v3 *gu, v3 *gv) {
+    float uvx = u * t->uscale + t->uoffset, uvy = v * t->vscale + t->voffset;
+    if (t->type == 2) { if (t->filter != 0) mip_gradient_bilinear(s, t, uvx, uvy, gu, gv); else *gu = *gv = V(0, 0, 0); }
+    else {
+        orc_texture raw = *t; raw.uscale = raw.vscale = 1.0f; raw.uoffset = raw.voffset = 0.0f;      /* eval(uv) on the already transformed coordinates */
+        const float eps = EPSILON;
+        v3 value = texture_eval(s, &raw, uvx, uvy, NULL), valueU = texture_eval(s, &raw, uvx + eps, uvy, NULL), valueV = texture_eval(s, &raw, uvx, uvy + eps, NULL);
+        *gu = scale(sub(valueU, value), 1 / eps); *gv = scale(sub(valueV, value), 1 / eps);
+    }
+    *gu = scale(*gu, t->uscale); *gv = scale(*gv, t->vscale);
+}
+static void perturb_frame(const orc_scene *s, const orc_material *m, const hit_t *its, v3 *ps, v3 *pt, v3 *pn) {
+    const orc_texture *tx = &s->textures[((m->flags >> 8) & 0xFFFFu) - 1];
+    if (m->type == BSDF_BUMPMAP) {                                        /* BumpMap::getFrame (bumpmap.cpp:140-163) */
+        v3 gu, gv; texture_gradient(s, tx, its->uvx, its->uvy, &gu, &gv);
+        gu = scale(gu, m->alpha); gv = scale(gv, m->alpha);               /* ScaleTexture::evalGradient (src/textures/scale.cpp:93-97) */
+        float dDispDu = luminance(gu), dDispDv = luminance(gv);
+        v3 dpdu = add(its->dpdu, scale(its->ns, dDispDu - dot(its->ns, its->dpdu)));
+        v3 dpdv = add(its->dpdv, scale(its->ns, dDispDv - dot(its->ns, its->dpdv)));
+        v3 n = normalize(cross(dpdu, dpdv));
+        *ps = normalize(sub(dpdu, scale(n, dot(n, dpdu)))); *pt = cross(n, *ps);
+        if (dot(n, its->ng) < 0) n = scale(n, -1.0f);
+        *pn = n;
+    } else {                                                              /* NormalMap::getFrame (normalmap.cpp:108-127): Texture::eval(its, false) */
+        v3 c = texture_eval(s, tx, its->uvx, its->uvy, NULL);
+        v3 nl = V(2 * c.x - 1, 2 * c.y - 1, 2 * c.z - 1);
+        v3 n = normalize(add(add(scale(its->s, nl.x), scale(its->tt, nl.y)), scale(its->ns, nl.z)));
+        *ps = normalize(sub(its->dpdu, scale(n, dot(n, its->dpdu)))); *pt = cross(n, *ps); *pn = n;
+    }
+}
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd) {
-    smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.opacity = V(1, 1, 1); sm.prob = 1.0f;
-    if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its;
+    if (its && sm.inner.m.type != BSDF_BUMPMAP && sm.inner.m.type != BSDF_NORMALMAP) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     if (sm.inner.m.type == BSDF_MASK) {
         sm.masked = 1; sm.opacity = V(sm.inner.m.reflectance[0], sm.inner.m.reflectance[1], sm.inner.m.reflectance[2]); sm.prob = luminance(sm.opacity);
         sm.inner = s->materials[sm.inner.m.distr];
+        if (its && sm.inner.m.type != BSDF_BUMPMAP && sm.inner.m.type != BSDF_NORMALMAP) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    }
+    if (sm.inner.m.type == BSDF_BUMPMAP || sm.inner.m.type == BSDF_NORMALMAP) {
+        if (its) { sm.bumped = 1; perturb_frame(s, &sm.inner.m, its, &sm.ps, &sm.pt, &sm.pn); }
+        sm.inner = s->materials[sm.inner.m.distr];
         if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    }
+    if (sm.inner.m.type == BSDF_MIXTURE) {                                /* MixtureBSDF::configure (mixturebsdf.cpp:115-169) */
+        const orc_material *mx = &sm.inner.m; sm.n_mix = (int) mx->distr; float total = 0;
+        for (int i = 0; i < sm.n_mix; ++i) {
+            sm.mix[i] = s->materials[(uint32_t) (i < 3 ? mx->reflectance[i] : mx->eta[0])]; sm.w[i] = i < 3 ? mx->k[i] : mx->specular[0];
+            if (its) apply_texture(s, &sm.mix[i], its, NULL, want_partials, o, rxd, ryd);
+            total += sm.w[i];
+        }
+        if (total > 1) { float sc = 1.0f / total; for (int i = 0; i < sm.n_mix; ++i) sm.w[i] *= sc; }      /* ensureEnergyConservation (default true) */
+        /* DiscreteDistribution: append + normalize (include/mitsuba/core/pmf.h:56-58, 103-116): cdf by running sums, normalised by the total */
+        float cdf[5]; cdf[0] = 0; for (int i = 0; i < sm.n_mix; ++i) cdf[i + 1] = cdf[i] + sm.w[i];
+        float norm = 1.0f / cdf[sm.n_mix]; for (int i = 1; i <= sm.n_mix; ++i) cdf[i] *= norm; cdf[sm.n_mix] = 1.0f;
+        for (int i = 0; i < sm.n_mix; ++i) sm.p[i] = cdf[i + 1] - cdf[i];
     }
     return sm;
 }
-static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo) { v3 e = bsdf_eval(&sm->inner.m, wi, wo); return sm->masked ? mul(e, sm->opacity) : e; }
-static float sm_pdf(const smat_t *sm, v3 wi, v3 wo) { float p = bsdf_pdf(&sm->inner.m, wi, wo); return sm->masked ? p * sm->prob : p; }
+/* the nested level below mask and bump / normal map: a plain BSDF or a mixture of plain BSDFs (mixturebsdf.cpp:171-276, path tracer: component = -1) */
+static v3 mx_eval(const smat_t *sm, v3 wi, v3 wo) {
+    if (!sm->n_mix) return bsdf_eval(&sm->inner.m, wi, wo);
+    int flip = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) { wi.z = -wi.z; wo.z = -wo.z; }     /* twosided(mixture) */
+    v3 r = V(0, 0, 0); for (int i = 0; i < sm->n_mix; ++i) r = add(r, scale(bsdf_eval(&sm->mix[i].m, wi, wo), sm->w[i]));
+    return r;
+}
+static float mx_pdf(const smat_t *sm, v3 wi, v3 wo) {
+    if (!sm->n_mix) return bsdf_pdf(&sm->inner.m, wi, wo);
+    int flip = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) { wi.z = -wi.z; wo.z = -wo.z; }
+    float r = 0; for (int i = 0; i < sm->n_mix; ++i) r += bsdf_pdf(&sm->mix[i].m, wi, wo) * sm->p[i];
+    return r;
+}
+static v3 mx_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
+    if (!sm->n_mix) return bsdf_sample(&sm->inner.m, wi, u, v, wo, pdf, eta, delta, sp);
+    int flip = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) wi.z = -wi.z;
+    /* m_pdf.sampleReuse(sample.x) (pmf.h:124-190): lower_bound over the cdf, then rescale */
+    float cdf[5]; cdf[0] = 0; for (int i = 0; i < sm->n_mix; ++i) cdf[i + 1] = cdf[i] + sm->p[i]; cdf[sm->n_mix] = 1.0f;
+    int entry = 0; { int lo = 0, hi = sm->n_mix + 1; while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
+                     entry = lo > 0 ? lo - 1 : 0; if (entry > sm->n_mix - 1) entry = sm->n_mix - 1;
+                     while (cdf[entry + 1] - cdf[entry] == 0 && entry < sm->n_mix) ++entry; }
+    u = (u - cdf[entry]) / (cdf[entry + 1] - cdf[entry]);
+    v3 result = bsdf_sample(&sm->mix[entry].m, wi, u, v, wo, pdf, eta, delta, sp);
+    if (is_zero(result)) return result;
+    result = scale(result, sm->w[entry] * *pdf); *pdf *= sm->p[entry];
+    if (!*delta)                                                          /* measure of the sampled component: the others contribute in solid angle only */
+        for (int i = 0; i < sm->n_mix; ++i) {
+            if (i == entry) continue;
+            *pdf += bsdf_pdf(&sm->mix[i].m, wi, *wo) * sm->p[i];
+            result = add(result, scale(bsdf_eval(&sm->mix[i].m, wi, *wo), sm->w[i]));
+        }
+    { float r = 1.0f / *pdf; result = scale(result, r); }                 /* Spectrum::operator/(Float): reciprocal, then multiply */
+    if (flip) wo->z = -wo->z;
+    return result;
+}
+static inline v3 frame_to_local(v3 fs, v3 ft, v3 fn, v3 w) { return V(dot(w, fs), dot(w, ft), dot(w, fn)); }
+static inline v3 frame_to_world(v3 fs, v3 ft, v3 fn, v3 w) { return add(add(scale(fs, w.x), scale(ft, w.y)), scale(fn, w.z)); }
+/* bump / normal map level (bumpmap.cpp:165-250): wi, wo are given in the hit's own frame */
+static v3 bp_eval(const smat_t *sm, v3 wi, v3 wo) {
+    if (!sm->bumped) return mx_eval(sm, wi, wo);
+    const hit_t *h = sm->its; v3 wiP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wi)), woP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wo));
+    if (wo.z * woP.z <= 0) return V(0, 0, 0);
+    return mx_eval(sm, wiP, woP);
+}
+static float bp_pdf(const smat_t *sm, v3 wi, v3 wo) {
+    if (!sm->bumped) return mx_pdf(sm, wi, wo);
+    const hit_t *h = sm->its; v3 wiP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wi)), woP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wo));
+    if (wo.z * woP.z <= 0) return 0.0f;
+    return mx_pdf(sm, wiP, woP);
+}
+static v3 bp_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
+    if (!sm->bumped) return mx_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
+    const hit_t *h = sm->its; v3 wiP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wi)), woP = V(0, 0, 0);
+    v3 result = mx_sample(sm, wiP, u, v, &woP, pdf, eta, delta, sp);
+    if (!is_zero(result)) {
+        *wo = frame_to_local(h->s, h->tt, h->ns, frame_to_world(sm->ps, sm->pt, sm->pn, woP));
+        if (wo->z * woP.z <= 0) return V(0, 0, 0);
+    }
+    return result;
+}
+static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo) { v3 e = bp_eval(sm, wi, wo); return sm->masked ? mul(e, sm->opacity) : e; }
+static float sm_pdf(const smat_t *sm, v3 wi, v3 wo) { float p = bp_pdf(sm, wi, wo); return sm->masked ? p * sm->prob : p; }
 static v3 sm_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
-    if (!sm->masked) return bsdf_sample(&sm->inner.m, wi, u, v, wo, pdf, eta, delta, sp);
+    if (!sm->masked) return bp_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
     if (u < sm->prob) {                                                  /* mask.cpp:196-201 */
         u /= sm->prob;
-        v3 w = bsdf_sample(&sm->inner.m, wi, u, v, wo, pdf, eta, delta, sp);
+        v3 w = bp_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
         v3 r = V(w.x * sm->opacity.x / sm->prob, w.y * sm->opacity.y / sm->prob, w.z * sm->opacity.z / sm->prob);
         *pdf *= sm->prob; return r;
     }
     *wo = neg(wi); *eta = 1.0f; *delta = 2; *pdf = 1 - sm->prob;       /* :202-208 */
     return V((1.0f - sm->opacity.x) / *pdf, (1.0f - sm->opacity.y) / *pdf, (1.0f - sm->opacity.z) / *pdf);
 }
-static int sm_is_smooth(const smat_t *sm) { return material_is_smooth(&sm->inner.m); }
-static int sm_has_backside(const smat_t *sm) { return sm->masked || material_has_backside(&sm->inner.m); }
+static int sm_is_smooth(const smat_t *sm) {
+    if (!sm->n_mix) return material_is_smooth(&sm->inner.m);
+    int r = 0; for (int i = 0; i < sm->n_mix; ++i) r |= material_is_smooth(&sm->mix[i].m); return r;      /* the mixture's components are its children's (mixturebsdf.cpp:150-166) */
+}
+static int sm_has_backside(const smat_t *sm) {
+    if (sm->masked) return 1;
+    if (!sm->n_mix) return material_has_backside(&sm->inner.m);
+    int r = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) != 0; for (int i = 0; i < sm->n_mix; ++i) r |= material_has_backside(&sm->mix[i].m); return r;
+}
 
 /* envmap.cpp:384-416 evalEnvironment WITH ray differentials (the sensor ray, path.cpp:139-141): texture-space partials, then TMIPMap::eval over the
  * map's pyramid (input data; record s->d.env_texture - 1 of the texture table) */

@@ -204,9 +204,47 @@ static Built buildScene(const FScene &fs) {
     b.scene = new Scene();
     // BSDFs
     std::vector<ref<BSDF> > bsdfs;
+    // texture record -> the reference's texture plugin (bitmaps from an in-memory image: the plugin builds its own MIP pyramid); asNormals: the bump / normal
+    // map adapters insist on an explicit gamma for bitmaps (bumpmap.cpp:122-126)
+    auto makeTexture = [&](const FTexture &ft, bool explicitGamma) -> ref<Texture> {
+        Properties tp(ft.type == 0 ? "checkerboard" : ft.type == 1 ? "gridtexture" : "bitmap");
+        ref<Bitmap> bmp;
+        if (ft.type == 2) {
+            static const char *wraps[] = {"clamp", "repeat", "mirror", "zero", "one"}; static const char *filters[] = {"nearest", "bilinear", "trilinear", "ewa"};
+            bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(ft.baseW, ft.baseH)); memcpy(bmp->getFloat32Data(), ft.base.data(), ft.base.size() * 4);
+            tp.setData("bitmap", Properties::Data{(uint8_t *) bmp.get(), sizeof(Bitmap)});
+            tp.setString("wrapModeU", wraps[ft.wrapU]); tp.setString("wrapModeV", wraps[ft.wrapV]); tp.setString("filterType", filters[ft.filter]);
+            tp.setFloat("maxAnisotropy", ft.maxAnisotropy);
+            if (explicitGamma) tp.setFloat("gamma", 1.0f);
+        } else { tp.setSpectrum("color0", rgb(ft.color0)); tp.setSpectrum("color1", rgb(ft.color1)); }
+        if (ft.type == 1) tp.setFloat("lineWidth", ft.lineWidth);
+        tp.setFloat("uoffset", ft.uoffset); tp.setFloat("voffset", ft.voffset); tp.setFloat("uscale", ft.uscale); tp.setFloat("vscale", ft.vscale);
+        ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp)); tex->configure();
+        return tex;
+    };
     for (const FBsdf &fb : fs.bsdfs) {
         ref<BSDF> bsdf;
-        if (fb.type == 0) {
+        if (fb.type == 10) {          // mixturebsdf: children = EARLIER records (indices in refl[0..2], eta[0]), weights in k[0..2], spec[0]
+            std::string w;
+            for (uint32_t i = 0; i < fb.distr; ++i) { char buf[64]; snprintf(buf, sizeof(buf), "%s%.9g", i ? ", " : "", (double) (i < 3 ? fb.k[i] : fb.spec[0])); w += buf; }
+            Properties p("mixturebsdf"); p.setString("weights", w);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+            for (uint32_t i = 0; i < fb.distr; ++i) {
+                size_t c = (size_t) (i < 3 ? fb.refl[i] : fb.eta[0]);
+                if (c >= bsdfs.size()) { fprintf(stderr, "mixturebsdf: the children must precede it\n"); _exit(2); }
+                bsdf->addChild(bsdfs[c]); bsdfs[c]->setParent(bsdf);
+            }
+        } else if (fb.type == 11 || fb.type == 12) {      // bumpmap / normalmap: nested = an earlier record, the bound texture = displacement / normals
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), Properties(fb.type == 11 ? "bumpmap" : "normalmap")));
+            if (fb.distr >= bsdfs.size()) { fprintf(stderr, "bumpmap: the nested material must precede it\n"); _exit(2); }
+            bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
+            ref<Texture> tex = makeTexture(fs.textures[fs.bsdfTexture[bsdfs.size()]], true);
+            if (fb.type == 11 && fb.alpha != 1.0f) {        // <texture type="scale"> around the displacement
+                Properties sp("scale"); sp.setFloat("scale", fb.alpha);
+                ref<Texture> st = static_cast<Texture *>(create(MTS_CLASS(Texture), sp)); st->addChild(tex); tex->setParent(st); st->configure(); tex = st;
+            }
+            bsdf->addChild(tex); tex->setParent(bsdf);
+        } else if (fb.type == 0) {
             Properties p("diffuse"); p.setSpectrum("reflectance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 2) {
@@ -264,21 +302,9 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         }
         { size_t bi = bsdfs.size();
-          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0) {      // 2-D procedural texture bound to the diffuse reflectance
-              const FTexture &ft = fs.textures[fs.bsdfTexture[bi]];
-              Properties tp(ft.type == 0 ? "checkerboard" : ft.type == 1 ? "gridtexture" : "bitmap");
-              ref<Bitmap> bmp;
-              if (ft.type == 2) {          // BitmapTexture from an in-memory bitmap (bitmap.cpp:95-96); it builds its own MIP pyramid (2-lobed Lanczos)
-                  static const char *wraps[] = {"clamp", "repeat", "mirror", "zero", "one"}; static const char *filters[] = {"nearest", "bilinear", "trilinear", "ewa"};
-                  bmp = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, Vector2i(ft.baseW, ft.baseH)); memcpy(bmp->getFloat32Data(), ft.base.data(), ft.base.size() * 4);
-                  tp.setData("bitmap", Properties::Data{(uint8_t *) bmp.get(), sizeof(Bitmap)});
-                  tp.setString("wrapModeU", wraps[ft.wrapU]); tp.setString("wrapModeV", wraps[ft.wrapV]); tp.setString("filterType", filters[ft.filter]);
-                  tp.setFloat("maxAnisotropy", ft.maxAnisotropy);
-              } else { tp.setSpectrum("color0", rgb(ft.color0)); tp.setSpectrum("color1", rgb(ft.color1)); }
-              if (ft.type == 1) tp.setFloat("lineWidth", ft.lineWidth);
-              tp.setFloat("uoffset", ft.uoffset); tp.setFloat("voffset", ft.voffset); tp.setFloat("uscale", ft.uscale); tp.setFloat("vscale", ft.vscale);
-              ref<Texture> tex = static_cast<Texture *>(create(MTS_CLASS(Texture), tp)); tex->configure();
-              // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance or difftrans.transmittance (the material record's `reflectance`)
+          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0 && fb.type != 11 && fb.type != 12) {      // texture bound to the record's `reflectance`
+              ref<Texture> tex = makeTexture(fs.textures[fs.bsdfTexture[bi]], false);
+              // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance or mask.opacity (the material record's `reflectance`)
               bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : fb.type == 9 ? "opacity" : "reflectance", tex); tex->setParent(bsdf);
           } }
         bsdf->configure();

@@ -93,6 +93,10 @@ def golden_scenes():
         # roughplastic sampling all normals instead of the visible ones (sampleVisible = false)
         "cbox_roughplastic_phong": scenes.cbox_roughplastic(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=22, phong=True),
         "cbox_roughplastic_allnormals": scenes.cbox_roughplastic(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=21, sample_visible=False),
+        # the BSDF adapters: bumpmap (bitmap displacement under a scale texture; grid displacement by finite differences), normalmap, mixturebsdf (2 and 3 children,
+        # weights rescaled, twosided), bumpmap(mixture), mask(bumpmap)
+        "layered_room": scenes.layered_room(width=96, height=64, spp=16),
+        "layered_room_strict_indep": scenes.layered_room(width=96, height=64, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=13, strict_normals=True, rr_depth=2),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
@@ -187,7 +191,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop", "layered_room"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)
@@ -195,7 +199,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop"):
+        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", "path", -1, base + "_resp")

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -83,6 +83,9 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     elif name.startswith("textured_plastics") or name == "textured_shapes":
         # textures on plastic / roughplastic.diffuseReflectance and difftrans.transmittance: lobe weights from the texture's average, local value in the lobes
         assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.998 and err.max() < 1e-3 and np.median(err) < 1e-6
+    elif name.startswith("layered_room"):
+        # bumpmap / normalmap / mixturebsdf (incl. bumpmap(mixture), mask(bumpmap), twosided mixture with rescaled weights): same paths, same sampler values
+        assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.995 and err.max() < 5e-3 and np.median(err) < 1e-6
     elif name == "textured_room":
         # UV tangents + procedural textures: same paths; a sample landing on a texture edge may pick the other colour (last bit of uv)
         assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.998 and np.median(err) < 1e-6
@@ -125,7 +128,7 @@ STRICT_BIT_EXACT = ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_
 STRICT_OTHERS = ["closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep", "cbox_materials",
                  "cbox_materials_strict_indep", "instanced_garden", "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "sky_view", "sky_view_indep", "veach_microfacets",
                  "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room",
-                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals"]
+                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals", "layered_room", "layered_room_strict_indep"]
 
 
 @pytest.mark.parametrize("name", STRICT_BIT_EXACT + STRICT_OTHERS)
@@ -161,7 +164,7 @@ def test_image_vs_strict_reference(oracle, golden_scenes, name):
     assert rel < {"cornell_small": 2e-5, "veach_small": 2e-5}.get(name, 4e-4), rel
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop", "layered_room"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -221,7 +224,13 @@ def test_units_vs_reference(oracle, golden_scenes, name):
     o8 = np.zeros(8, np.float32); o4 = np.zeros(4, np.float32)
     for row in u["bsdf"]:
         si = int(row[0]); mat = sc.shapes[si]["bsdf"] if si < len(sc.shapes) else sc.analytic[si - len(sc.shapes)]["bsdf"]
-        if sc.bsdfs[mat].get("texture", -1) >= 0: continue                     # textured reflectance: covered by the radiance / image comparisons
+        def needs_hit(m):                                                      # textured parameters and the bump / normal map adapters need a real hit record (uv, tangents)
+            b = sc.bsdfs[m]
+            if b.get("texture", -1) >= 0 or b["type"] in (11, 12): return True
+            if b["type"] == 9: return needs_hit(b["distr"])
+            if b["type"] == 10: return any(needs_hit(int(c)) for c in (list(b["reflectance"]) + [b["eta"][0]])[:b["distr"]])
+            return False
+        if needs_hit(mat): continue                                            # covered by the radiance / image comparisons
         wi = np.ascontiguousarray(row[1:4]); wo = np.ascontiguousarray(row[14:17])
         L.orc_bsdf_sample(orc.h, mat, wi.ctypes.data, float(row[4]), float(row[5]), o8.ctypes.data)
         assert np.allclose(o8[0:4], row[6:10], rtol=5e-4 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf")) else 1e-5, atol=1e-7)     # all-normal sampling: weight = D(m) G (wi.m) / (pdf cos) with D(m) recomputed from m; for alpha = 0.03 sin^2 = 1 - cos^2 cancels (1e-4 relative, in the reference too)
