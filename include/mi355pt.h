@@ -52,6 +52,13 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
                                      buffer of mi_scene_set_material_tables */
 #define MI_BSDF_THINDIELECTRIC 8  /* src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extIOR, specular = specularReflectance, reflectance = specularTransmittance (ENull transmission) */
 #define MI_BSDF_MASK 9            /* src/bsdfs/mask.cpp: reflectance = opacity (constant or a bound texture), distr = index of the nested material record; ENull pass-through lobe */
+#define MI_BSDF_MIXTURE 10        /* src/bsdfs/mixturebsdf.cpp: distr = number of children (2..4); their material record indices as numbers in reflectance[0..2], eta[0],
+                                     their weights in k[0..2], specular[0] (rescaled when they sum to more than one, ensureEnergyConservation).  Children are plain
+                                     BSDF records without textures, at most one of them with a Dirac delta component */
+#define MI_BSDF_BUMPMAP 11        /* src/bsdfs/bumpmap.cpp: distr = index of the nested record (a plain BSDF or a mixturebsdf), bound texture (MI_BSDF_TEXTURE) = the displacement,
+                                     alpha = the factor of an enclosing <texture type="scale"> (1 = none); meshes need texture coordinates */
+#define MI_BSDF_NORMALMAP 12      /* src/bsdfs/normalmap.cpp: distr = nested record, bound texture = tangent-space normals (rgb = 0.5 + 0.5 n).  Adapters nest in the
+                                     order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

@@ -172,9 +172,30 @@ int mi_scene_set_instances(mi_scene *s, const mi_instance *a, uint32_t n) {
 }
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
+    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP; };
+    auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_MASK) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_NORMALMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
+        if (m[i].type == MI_BSDF_BUMPMAP || m[i].type == MI_BSDF_NORMALMAP) {
+            // adapters nest in the order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF
+            if (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || m[m[i].distr].type == MI_BSDF_BUMPMAP || m[m[i].distr].type == MI_BSDF_NORMALMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a bumpmap / normalmap nests a plain BSDF or a mixturebsdf (record index in `distr`)");
+            if (m[i].flags & MI_BSDF_FLAG_TWOSIDED) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: put `twosided` on the BSDF nested in a bumpmap / normalmap, not on the adapter");
+            if (!((m[i].flags >> 8) & 0xFFFFu)) return fail(MI_ERR_INVALID, m[i].type == MI_BSDF_BUMPMAP ? "A displacement texture must be specified" : "A normal map texture must be specified");   // bumpmap.cpp:88-89
+        }
+        if (m[i].type == MI_BSDF_MIXTURE) {
+            if (m[i].distr < 2 || m[i].distr > 4) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a mixturebsdf holds 2..4 BSDFs");
+            float total = 0; int deltas = 0;
+            for (uint32_t c = 0; c < m[i].distr; ++c) {
+                const float idxf = c < 3 ? m[i].reflectance[c] : m[i].eta[0], w = c < 3 ? m[i].k[c] : m[i].specular[0];
+                if (!(idxf >= 0) || idxf >= (float) n || isWrapper(m[(uint32_t) idxf].type)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: the children of a mixturebsdf are plain BSDF records (indices in reflectance[0..2], eta[0])");
+                if (((m[(uint32_t) idxf].flags >> 8) & 0xFFFFu)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: textures on the children of a mixturebsdf are not implemented");
+                if (!(w >= 0)) return fail(MI_ERR_INVALID, "Invalid BSDF weight!");                                    // mixturebsdf.cpp:82-83
+                total += w; deltas += hasDelta(m[(uint32_t) idxf].type);
+            }
+            if (!(total > 0)) return fail(MI_ERR_INVALID, "The weights must sum to a value greater than zero!");       // mixturebsdf.cpp:126-127
+            if (deltas > 1) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a mixturebsdf with more than one child that has a Dirac delta component is not implemented");
+        }
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_DIFFTRANS || m[i].type == MI_BSDF_THINDIELECTRIC) && (m[i].flags & MI_BSDF_FLAG_TWOSIDED)) return fail(MI_ERR_INVALID, "Only BSDFs without a transmission component can be nested!");   // twosided.cpp:86-88
         if ((m[i].type == MI_BSDF_DIELECTRIC || m[i].type == MI_BSDF_PLASTIC || m[i].type == MI_BSDF_ROUGHDIELECTRIC || m[i].type == MI_BSDF_ROUGHPLASTIC || m[i].type == MI_BSDF_THINDIELECTRIC) && !(m[i].eta[0] > 0)) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive!");
         if (m[i].type == MI_BSDF_ROUGHPLASTIC && (m[i].distr > 2 || (m[i].flags & MI_BSDF_FLAG_ANISOTROPIC)))
@@ -330,8 +351,8 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
         if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
             (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
-        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK)))
-            return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance or mask.opacity (and must exist)");
+        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK && m.type != MI_BSDF_BUMPMAP && m.type != MI_BSDF_NORMALMAP)))
+            return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance, mask.opacity or are the map of a bumpmap / normalmap (and must exist)");
     }
     if (s->h.envTexture >= 0) {       // MIP pyramid of the environment map (camera-ray lookups, envmap.cpp:398-411)
         if (!s->h.envW) return fail(MI_ERR_INVALID, "mi_scene_commit: mi_scene_set_envmap_filter without an environment map");
@@ -340,8 +361,14 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         if (t.type != MI_TEXTURE_BITMAP || (size_t) t.first_level + t.n_levels > s->h.texLevels.size() / 3 || s->h.texLevels[(size_t) t.first_level * 3] != s->h.envW || s->h.texLevels[(size_t) t.first_level * 3 + 1] != s->h.envH)
             return fail(MI_ERR_INVALID, "mi_scene_commit: the environment map's pyramid must be a bitmap texture record whose level 0 has the map's size");
     }
-    for (const mi_shape &sh : s->h.shapes)         // TriMesh::computeUVTangents (trimesh.cpp:683-692): an anisotropic BSDF takes its tangent from the texture coordinates
-        if (sh.bsdf >= 0 && (size_t) sh.bsdf < s->h.materials.size() && (s->h.materials[sh.bsdf].flags & MI_BSDF_FLAG_ANISOTROPIC) && !((sh.flags & 2u) && !s->h.uv.empty()))
+    auto wantsTangents = [&](int32_t b) {          // anisotropic roughness, or a bumpmap / normalmap anywhere under the shape's material (their components are EAnisotropic, bumpmap.cpp:99-100)
+        if (b < 0 || (size_t) b >= s->h.materials.size()) return false;
+        const mi_material *mm = &s->h.materials[b];
+        if (mm->type == MI_BSDF_MASK && mm->distr < s->h.materials.size()) mm = &s->h.materials[mm->distr];
+        return (mm->flags & MI_BSDF_FLAG_ANISOTROPIC) != 0 || mm->type == MI_BSDF_BUMPMAP || mm->type == MI_BSDF_NORMALMAP;
+    };
+    for (const mi_shape &sh : s->h.shapes)         // TriMesh::computeUVTangents (trimesh.cpp:683-692): such BSDFs take their tangents from the texture coordinates
+        if (wantsTangents(sh.bsdf) && !((sh.flags & 2u) && !s->h.uv.empty()))
             return fail(MI_ERR_INVALID, "computeUVTangents(): texture coordinates are required to generate tangent vectors. If you want to render with an anisotropic material, please make sure that all associated shapes have valid texture coordinates.");
     for (const mi_material &m : s->h.materials)
         if (m.type == MI_BSDF_ROUGHPLASTIC && (m.k[2] < 2 || m.k[1] < 0 || (size_t) m.k[1] + (size_t) m.k[2] > s->h.materialTables.size()))

@@ -1210,6 +1210,123 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
     return V(m.reflectance[0], m.reflectance[1], m.reflectance[2]);
 }
 
+// ---------------------------------------------------------------------------------------------- BSDF adapters: mixturebsdf, bumpmap, normalmap
+// src/bsdfs/mixturebsdf.cpp:115-276 (path tracer: component = -1).  Record: distr = number of children (2..4), their material indices as numbers in
+// reflectance[0..2], eta[0], their weights in k[0..2], specular[0]; flags bit0: the mixture sits inside a `twosided`.  Children are plain BSDF records (no
+// textures, at most one of them with a delta component: validated by mi_scene_set_materials).  Weights are rescaled when they sum to more than one
+// (ensureEnergyConservation), selection probabilities = the normalised running sums of a DiscreteDistribution (include/mitsuba/core/pmf.h:56-58, 103-116).
+#define MI_BSDF_T_MIXTURE 10u
+#define MI_BSDF_T_BUMPMAP 11u
+#define MI_BSDF_T_NORMALMAP 12u
+struct MixD { int n; float w0, w1, w2, w3, c1, c2, c3; uint32_t i0, i1, i2, i3; };      // weights, cdf[1..3] (cdf[0] = 0, cdf[n] = 1), child records
+DEV MixD mixOf(const MaterialD &m) {
+    MixD x; x.n = (int) m.distr; x.w0 = m.k[0]; x.w1 = m.k[1]; x.w2 = x.n > 2 ? m.k[2] : 0.0f; x.w3 = x.n > 3 ? m.specular[0] : 0.0f;
+    x.i0 = (uint32_t) m.reflectance[0]; x.i1 = (uint32_t) m.reflectance[1]; x.i2 = (uint32_t) m.reflectance[2]; x.i3 = (uint32_t) m.eta[0];
+    float total = x.w0 + x.w1; if (x.n > 2) total += x.w2; if (x.n > 3) total += x.w3;
+    if (total > 1) { const float sc_ = 1.0f / total; x.w0 *= sc_; x.w1 *= sc_; x.w2 *= sc_; x.w3 *= sc_; }
+    float c1 = 0.0f + x.w0, c2 = c1 + x.w1, c3 = c2 + x.w2, c4 = c3 + x.w3;
+    const float sum = x.n == 2 ? c2 : (x.n == 3 ? c3 : c4), norm = 1.0f / sum;
+    c1 *= norm; c2 *= norm; c3 *= norm;
+    x.c1 = c1; x.c2 = x.n == 2 ? 1.0f : c2; x.c3 = x.n <= 3 ? 1.0f : c3;
+    return x;
+}
+DEV float mixCdf(const MixD &x, int i) { return i <= 0 ? 0.0f : (i == 1 ? x.c1 : (i == 2 ? x.c2 : (i == 3 ? x.c3 : 1.0f))); }      // cdf[n] = 1 is baked into c2 / c3
+DEV float mixProb(const MixD &x, int i) { return (i + 1 >= x.n ? 1.0f : mixCdf(x, i + 1)) - mixCdf(x, i); }
+DEV float mixWeight(const MixD &x, int i) { return i == 0 ? x.w0 : (i == 1 ? x.w1 : (i == 2 ? x.w2 : x.w3)); }
+DEV uint32_t mixChild(const MixD &x, int i) { return i == 0 ? x.i0 : (i == 1 ? x.i1 : (i == 2 ? x.i2 : x.i3)); }
+template <bool RC, bool L> DEV v3 mxEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
+    if (!RC || m.type != MI_BSDF_T_MIXTURE) return bsdfEval<RC>(sc, m, wi, wo);
+    if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    const MixD x = mixOf(m); v3 r = V(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < x.n) r = r + bsdfEval<RC>(sc, loadMaterial(tb, (int) mixChild(x, i)), wi, wo) * mixWeight(x, i);
+    return r;
+}
+template <bool RC, bool L> DEV float mxPdf(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
+    if (!RC || m.type != MI_BSDF_T_MIXTURE) return bsdfPdf<RC>(sc, m, wi, wo);
+    if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    const MixD x = mixOf(m); float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < x.n) r += bsdfPdf<RC>(sc, loadMaterial(tb, (int) mixChild(x, i)), wi, wo) * mixProb(x, i);
+    return r;
+}
+// `extra`: functor drawing one more sampler value, called only if the chosen BSDF asks for it (BSDF::EUsesSampler)
+template <bool RC, bool L, typename F> DEV v3 mxSample(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &eta, bool &delta, bool &nullComp) {
+    if (!RC || m.type != MI_BSDF_T_MIXTURE) { const float e = (RC && bsdfUsesSampler(m)) ? extra() : 0.0f; return bsdfSample<RC>(sc, m, wi, u, v, e, wo, pdf, eta, delta, nullComp); }
+    const bool flip = (m.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
+    const MixD x = mixOf(m);
+    // m_pdf.sampleReuse(sample.x) (pmf.h:124-190): lower_bound over the cdf = number of entries below u, minus one; zero-probability entries are skipped forward
+    int lo = 0;
+#pragma unroll
+    for (int j = 0; j <= 4; ++j) if (j <= x.n && (j >= x.n ? 1.0f : mixCdf(x, j)) < u) ++lo;
+    int entry = lo > 0 ? lo - 1 : 0; if (entry > x.n - 1) entry = x.n - 1;
+    while (entry < x.n && mixProb(x, entry) == 0) ++entry;
+    const float c0 = mixCdf(x, entry), c1 = entry + 1 >= x.n ? 1.0f : mixCdf(x, entry + 1);
+    u = (u - c0) / (c1 - c0);
+    const MaterialD child = loadMaterial(tb, (int) mixChild(x, entry));
+    const float e = bsdfUsesSampler(child) ? extra() : 0.0f;
+    v3 result = bsdfSample<RC>(sc, child, wi, u, v, e, wo, pdf, eta, delta, nullComp);
+    if (isZero(result)) return result;
+    result = result * (mixWeight(x, entry) * pdf); pdf *= mixProb(x, entry);
+    if (!delta) {                                    // measure of the sampled component: the other BSDFs contribute in solid angle only
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < x.n && i != entry) {
+            const MaterialD other = loadMaterial(tb, (int) mixChild(x, i));
+            pdf += bsdfPdf<RC>(sc, other, wi, wo) * mixProb(x, i);
+            result = result + bsdfEval<RC>(sc, other, wi, wo) * mixWeight(x, i);
+        }
+    }
+    { const float r = 1.0f / pdf; result = result * r; }
+    if (flip) wo.z = -wo.z;
+    return result;
+}
+// bumpmap / normalmap (src/bsdfs/bumpmap.cpp:140-250, normalmap.cpp:108-260): the nested BSDF runs in a perturbed shading frame (ps, pt, pn); directions whose
+// cosines differ in sign between the hit's frame and the perturbed one are rejected.  Texture2D::evalGradient (src/librender/texture.cpp:123-141): finite
+// differences over eps = 1e-4 for procedural textures, the bilinear gradient of MIP level 0 for bitmaps (bitmap.cpp:459-483, mipmap.h:602-627).
+DEV void mipGradientBilinear(const DScene &sc, const TextureD &t, float uvx, float uvy, v3 &gu, v3 &gv) {
+    gu = gv = V(0, 0, 0);
+    if (!isfinite(uvx) || !isfinite(uvy)) return;
+    const uint32_t *L = sc.tex_levels + t.first_level * 3u; const float sx = (float) (int) L[0], sy = (float) (int) L[1];
+    float u = uvx * sx - 0.5f, v = uvy * sy - 0.5f;
+    int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    float dx = u - (float) xPos, dy = v - (float) yPos;
+    v3 p00 = mipTexel(sc, t, 0, xPos, yPos), p10 = mipTexel(sc, t, 0, xPos + 1, yPos), p01 = mipTexel(sc, t, 0, xPos, yPos + 1), p11 = mipTexel(sc, t, 0, xPos + 1, yPos + 1);
+    v3 tmp = (p01 + p10) - p11;
+    gu = ((p10 + p00 * (dy - 1)) - tmp * dy) * sx;
+    gv = ((p01 + p00 * (dx - 1)) - tmp * dx) * sy;
+}
+DEV void textureGradient(const DScene &sc, const TextureD &t, float u, float v, v3 &gu, v3 &gv) {
+    const float uvx = u * t.uscale + t.uoffset, uvy = v * t.vscale + t.voffset;
+    if (t.type == 2u) { if (t.filter != 0u) mipGradientBilinear(sc, t, uvx, uvy, gu, gv); else gu = gv = V(0, 0, 0); }
+    else {
+        TextureD raw = t; raw.uscale = raw.vscale = 1.0f; raw.uoffset = raw.voffset = 0.0f;
+        const float eps = MI_EPSILON;
+        v3 value = textureEval(raw, uvx, uvy), valueU = textureEval(raw, uvx + eps, uvy), valueV = textureEval(raw, uvx, uvy + eps);
+        gu = (valueU - value) * (1 / eps); gv = (valueV - value) * (1 / eps);
+    }
+    gu = gu * t.uscale; gv = gv * t.vscale;
+}
+DEV void perturbFrame(const DScene &sc, const MaterialD &m, const Hit &h, float uvx, float uvy, v3 dpdu, v3 dpdv, v3 &ps, v3 &pt, v3 &pn) {
+    const TextureD &tx = sc.textures[((m.flags >> 8) & 0xFFFFu) - 1u];
+    if (m.type == MI_BSDF_T_BUMPMAP) {
+        v3 gu, gv; textureGradient(sc, tx, uvx, uvy, gu, gv);
+        gu = gu * m.alpha; gv = gv * m.alpha;                                 // ScaleTexture::evalGradient (src/textures/scale.cpp:93-97)
+        const float dDispDu = luminance3(gu), dDispDv = luminance3(gv);
+        v3 du = dpdu + h.ns * (dDispDu - dot(h.ns, dpdu)), dv = dpdv + h.ns * (dDispDv - dot(h.ns, dpdv));
+        v3 n = normalize(cross(du, dv));
+        ps = normalize(du - n * dot(n, du)); pt = cross(n, ps);
+        if (dot(n, h.ng) < 0) n = n * -1.0f;
+        pn = n;
+    } else {
+        v3 c = tx.type == 2u ? (tx.filter != 0u ? mipBilinear(sc, tx, 0, uvx * tx.uscale + tx.uoffset, uvy * tx.vscale + tx.voffset) : mipBox(sc, tx, 0, uvx * tx.uscale + tx.uoffset, uvy * tx.vscale + tx.voffset)) : textureEval(tx, uvx, uvy);
+        v3 nl = V(2 * c.x - 1, 2 * c.y - 1, 2 * c.z - 1);
+        v3 n = normalize((h.s * nl.x + h.t * nl.y) + h.ns * nl.z);
+        ps = normalize(dpdu - n * dot(n, dpdu)); pt = cross(n, ps); pn = n;
+    }
+}
+DEV v3 frameToLocal(v3 fs, v3 ft, v3 fn, v3 w) { return V(dot(w, fs), dot(w, ft), dot(w, fn)); }
+DEV v3 frameToWorld(v3 fs, v3 ft, v3 fn, v3 w) { return (fs * w.x + ft * w.y) + fn * w.z; }
+
 // ---------------------------------------------------------------------------------------------- environment emitter
 // src/emitters/envmap.cpp (level-0 bilinear lookups only; the reference EWA-filters camera rays that see the sky directly, :398-411).
 // atan2/acos/sin/cos come from the device math library: tolerance-pinned like the rough conductor.

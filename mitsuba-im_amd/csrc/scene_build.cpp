@@ -169,16 +169,23 @@ void SceneHost::commitHost() {
     std::vector<TriAccelD> accel(nt); shade.assign(nt, TriShade{}); i2.assign(nt, 0);
     triuv.assign(uv.empty() ? 0 : nt, TriUV{}); anyUV = false;
     std::vector<V3> tlo(np), thi(np), cen(np);
+    // flags of a shape's material as MIPathTracer::Li sees the (possibly nested) BSDF: bit1 EBackSide / ETransmission somewhere (dRec.refN = 0, records.inl:160-164),
+    // bit2 no smooth component (no emitter sampling, path.cpp:173-174), bit3 anything but a plain diffuse record (class bit of the shading stage)
+    auto leafBackside = [&](const mi_material &mat) { return (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS || mat.type == MI_BSDF_THINDIELECTRIC; };
+    // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
+    // conductor / dielectric register delta components only
+    auto leafSmooth = [&](const mi_material &mat) { return mat.type == MI_BSDF_DIFFUSE ? (((mat.flags >> 8) & 0xFFFFu) != 0 || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0)
+                                                                                         : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC && mat.type != MI_BSDF_THINDIELECTRIC); };
     auto materialFlags = [&](int bsdf) {
-        const bool masked = materials[bsdf].type == MI_BSDF_MASK;                  // mask.cpp:104-121: the nested BSDF's components + an ENull | EFrontSide | EBackSide one
-        const mi_material &mat = masked ? materials[materials[bsdf].distr] : materials[bsdf];
-        // dRec.refN = 0 when the BSDF has ETransmission or EBackSide (records.inl:160-164): twosided wrapper, dielectric
-        bool backside = (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS || mat.type == MI_BSDF_THINDIELECTRIC;
-        // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
-        // conductor / dielectric register delta components only
-        bool smooth = mat.type == MI_BSDF_DIFFUSE ? (((mat.flags >> 8) & 0xFFFFu) != 0 || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0)
-                                                  : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC && mat.type != MI_BSDF_THINDIELECTRIC);
-        return ((backside || masked) ? 2u : 0u) | (smooth ? 0u : 4u) | ((mat.type != MI_BSDF_DIFFUSE || masked) ? 8u : 0u);
+        const mi_material *mat = &materials[bsdf]; bool masked = false, wrapped = false;
+        if (mat->type == MI_BSDF_MASK) { masked = true; mat = &materials[mat->distr]; }          // mask.cpp:104-121: the nested BSDF's components + an ENull | EFrontSide | EBackSide one
+        if (mat->type == MI_BSDF_BUMPMAP || mat->type == MI_BSDF_NORMALMAP) { wrapped = true; mat = &materials[mat->distr]; }     // the nested BSDF's component types (bumpmap.cpp:97-100)
+        bool backside, smooth;
+        if (mat->type == MI_BSDF_MIXTURE) {                                                         // the children's components (mixturebsdf.cpp:150-166)
+            backside = (mat->flags & MI_BSDF_FLAG_TWOSIDED) != 0; smooth = false; wrapped = true;
+            for (uint32_t c = 0; c < mat->distr; ++c) { const mi_material &ch = materials[(uint32_t) (c < 3 ? mat->reflectance[c] : mat->eta[0])]; backside |= leafBackside(ch); smooth |= leafSmooth(ch); }
+        } else { backside = leafBackside(*mat); smooth = leafSmooth(*mat); }
+        return ((backside || masked) ? 2u : 0u) | (smooth ? 0u : 4u) | ((mat->type != MI_BSDF_DIFFUSE || masked || wrapped) ? 8u : 0u);
     };
     for (uint32_t t = 0; t < nt; ++t) {
         uint32_t a = idx[t * 3], b = idx[t * 3 + 1], c = idx[t * 3 + 2];

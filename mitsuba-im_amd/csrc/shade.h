@@ -77,7 +77,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         //   B: BSDF sampling                                                     -> next ray / state
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
-        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false;   // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
+        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false; bool bumped = false; v3 bps = V(0, 0, 0), bpt = bps, bpn = bps;   // bumpmap / normalmap: perturbed frame (RC variants)
+          // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
         if (i < n) {
             const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
             float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 bsdf = loadMaterial(tb, h.material);
                 auto applyTexture = [&](MaterialD &mm) {
                 if (TEX) {                                                   // a textured parameter: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121) and its siblings
-                    const uint32_t tex = (mm.flags >> 8) & 0xFFFFu;
+                    const uint32_t tex = (mm.type == MI_BSDF_T_BUMPMAP || mm.type == MI_BSDF_T_NORMALMAP) ? 0u : (mm.flags >> 8) & 0xFFFFu;      // (an adapter's texture is its displacement / normal map)
                     if (tex) {
                         const TextureD &tx = sc.textures[tex - 1]; v3 c;
                         float huvx = h.uvx, huvy = h.uvy;
@@ -161,6 +162,15 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 if (RC && bsdf.type == MI_BSDF_T_MASK) {                     // mask.cpp: this record's (textured) `reflectance` is the opacity in front of the nested record `distr`
                     opac = ld3(bsdf.reflectance); masked = true; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
                 }
+                if (RC && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record
+                    float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
+                    if (AN && inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, ro3 + d * hr.x, huvx, huvy, dpdu, dpdv);
+                    else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
+                    else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                    if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
+                    perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
+                    bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
+                }
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }
@@ -173,10 +183,14 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     if (dr.pdf != 0) {
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
-                        v3 bsdfVal = bsdfEval<RC>(sc, bsdf, h.wi, wo);
+                        v3 wiQ = h.wi, woQ = wo; bool rejected = false;
+                        if (RC && bumped) {                                                  // bumpmap.cpp:165-180: the query in the perturbed frame
+                            wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0;
+                        }
+                        v3 bsdfVal = rejected ? V(0, 0, 0) : mxEval<RC>(sc, tb, bsdf, wiQ, woQ);
                         if (RC && masked) bsdfVal = bsdfVal * opac;                          // mask.cpp:124-127
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = dr.delta ? 0.0f : bsdfPdf<RC>(sc, bsdf, h.wi, wo);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
+                            float bp = (dr.delta || rejected) ? 0.0f : mxPdf<RC>(sc, tb, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
                             if (RC && masked) bp *= luminance3(opac);                          // mask.cpp:141-146
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
@@ -211,8 +225,13 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 woL = V(-h.wi.x, -h.wi.y, -h.wi.z); bEta = 1.0f; bPdf = p; sampledDelta = true; sampledNull = true;
                 bw = V((1.0f - opac.x) / p, (1.0f - opac.y) / p, (1.0f - opac.z) / p);
             } else {
-                if (RC && bsdfUsesSampler(bsdf)) extra = next1D(ss, rc.sampler, m32);  // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler)
-                bw = bsdfSample<RC>(sc, bsdf, h.wi, sx, sy, extra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };        // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler), only if the sampled BSDF asks
+                (void) extra;
+                if (RC && bumped) {                                                    // bumpmap.cpp:199-222
+                    const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
+                    bw = mxSample<RC>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
+                    if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
+                } else bw = mxSample<RC>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (RC && masked) { const float prob = luminance3(opac); bw = V(bw.x * opac.x / prob, bw.y * opac.y / prob, bw.z * opac.z / prob); bPdf *= prob; }
             }
             v3 wo = toWorld(h, woL);

@@ -740,7 +740,7 @@ def normal_map_image(w=64, h=48):
 
 def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, strict_normals=False):
     """The textured room with the three BSDF adapters of SURVEY §8 f2: `bumpmap` floor (bitmap displacement under a `scale` texture, bilinear gradient),
-    `normalmap` wall over a twosided rough conductor, a `mixturebsdf` mound (plastic + checkerboard diffuse), a twosided three-way mixture whose weights sum to
+    `normalmap` wall over a twosided rough conductor, a `mixturebsdf` mound (plastic + diffuse), a twosided three-way mixture whose weights sum to
     1.4 (rescaled by the BSDF), a bump-mapped mixture (grid displacement: finite-difference gradient) and a mask over a bump-mapped diffuse."""
     sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed)
     pyr = load_texture_pyramid(); nimg = normal_map_image()
@@ -755,7 +755,7 @@ def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6
     m2 = add(kind=BSDF_ROUGHCONDUCTOR, alpha=0.2, distr=DISTR_GGX, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), twosided=True)
     wall = add(kind=BSDF_NORMALMAP, nested=m2, texture=1)
     m4 = add(kind=BSDF_PLASTIC, reflectance=(0.25, 0.5, 0.3), ior=1.49)
-    m5 = add(reflectance=(0.5, 0.5, 0.5)); B[m5]["texture"] = 2
+    m5 = add(reflectance=(0.45, 0.2, 0.6))
     mound = add(kind=BSDF_MIXTURE, nested=[m4, m5], weights=[0.7, 0.3])
     m7 = add(kind=BSDF_ROUGHCONDUCTOR, alpha=0.15, distr=DISTR_BECKMANN, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14))
     m8 = add(reflectance=(0.7, 0.15, 0.1))

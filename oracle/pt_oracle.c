@@ -1358,7 +1358,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
 /* a hit's material with its textures evaluated and its wrappers resolved (below): mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDFs */
 typedef struct { mat_t inner; int masked; v3 opacity; float prob;
                  int bumped; v3 ps, pt, pn; const hit_t *its;           /* bumpmap / normalmap: the perturbed shading frame; the hit's own frame stays the query frame */
-                 int n_mix; mat_t mix[4]; float w[4], p[4]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
+                 int n_mix; mat_t mix[4]; float w[4], p[4], cdf[5]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
 static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo);
 static float sm_pdf(const smat_t *sm, v3 wi, v3 wo);
@@ -1839,12 +1839,11 @@ static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_
         const orc_material *mx = &sm.inner.m; sm.n_mix = (int) mx->distr; float total = 0;
         for (int i = 0; i < sm.n_mix; ++i) {
             sm.mix[i] = s->materials[(uint32_t) (i < 3 ? mx->reflectance[i] : mx->eta[0])]; sm.w[i] = i < 3 ? mx->k[i] : mx->specular[0];
-            if (its) apply_texture(s, &sm.mix[i], its, NULL, want_partials, o, rxd, ryd);
             total += sm.w[i];
         }
         if (total > 1) { float sc = 1.0f / total; for (int i = 0; i < sm.n_mix; ++i) sm.w[i] *= sc; }      /* ensureEnergyConservation (default true) */
         /* DiscreteDistribution: append + normalize (include/mitsuba/core/pmf.h:56-58, 103-116): cdf by running sums, normalised by the total */
-        float cdf[5]; cdf[0] = 0; for (int i = 0; i < sm.n_mix; ++i) cdf[i + 1] = cdf[i] + sm.w[i];
+        float *cdf = sm.cdf; cdf[0] = 0; for (int i = 0; i < sm.n_mix; ++i) cdf[i + 1] = cdf[i] + sm.w[i];
         float norm = 1.0f / cdf[sm.n_mix]; for (int i = 1; i <= sm.n_mix; ++i) cdf[i] *= norm; cdf[sm.n_mix] = 1.0f;
         for (int i = 0; i < sm.n_mix; ++i) sm.p[i] = cdf[i + 1] - cdf[i];
     }
@@ -1867,7 +1866,7 @@ static v3 mx_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pd
     if (!sm->n_mix) return bsdf_sample(&sm->inner.m, wi, u, v, wo, pdf, eta, delta, sp);
     int flip = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) wi.z = -wi.z;
     /* m_pdf.sampleReuse(sample.x) (pmf.h:124-190): lower_bound over the cdf, then rescale */
-    float cdf[5]; cdf[0] = 0; for (int i = 0; i < sm->n_mix; ++i) cdf[i + 1] = cdf[i] + sm->p[i]; cdf[sm->n_mix] = 1.0f;
+    const float *cdf = sm->cdf;
     int entry = 0; { int lo = 0, hi = sm->n_mix + 1; while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
                      entry = lo > 0 ? lo - 1 : 0; if (entry > sm->n_mix - 1) entry = sm->n_mix - 1;
                      while (cdf[entry + 1] - cdf[entry] == 0 && entry < sm->n_mix) ++entry; }
