@@ -18,6 +18,8 @@ void mi_launch_shade_d(const DScene &, const RenderConst &, const Queues &, int,
 void mi_launch_shade_d_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shade_rc(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shade_rc_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shade_rcw(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shade_rcw_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
@@ -44,6 +46,7 @@ static void mi_launch_shade(const DScene &scIn, bool ldsTables, const RenderCons
         if (total <= 64 * 1024) { rcl.order_offset_words = off; lds = total; }
     }
     if (!sc.has_roughconductor) (env ? mi_launch_shade_d_env : mi_launch_shade_d)(sc, rcl, q, buf, grid, lds, st);
+    else if (sc.has_adapters) (env ? mi_launch_shade_rcw_env : mi_launch_shade_rcw)(sc, rcl, q, buf, grid, lds, st);      // mixturebsdf / bumpmap / normalmap present
     else (env ? mi_launch_shade_rc_env : mi_launch_shade_rc)(sc, rcl, q, buf, grid, lds, st);
 }
 static thread_local std::string g_err;
@@ -326,7 +329,8 @@ int SceneHost::upload(int dev) {
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
-    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    d.has_adapters = 0;
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type >= MI_BSDF_MIXTURE) d.has_adapters = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     if (up(&dPacketGroups, packetGroups) | up(&dPacketExact, packetExact)) return 1;

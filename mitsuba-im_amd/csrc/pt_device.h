@@ -1234,16 +1234,16 @@ DEV float mixCdf(const MixD &x, int i) { return i <= 0 ? 0.0f : (i == 1 ? x.c1 :
 DEV float mixProb(const MixD &x, int i) { return (i + 1 >= x.n ? 1.0f : mixCdf(x, i + 1)) - mixCdf(x, i); }
 DEV float mixWeight(const MixD &x, int i) { return i == 0 ? x.w0 : (i == 1 ? x.w1 : (i == 2 ? x.w2 : x.w3)); }
 DEV uint32_t mixChild(const MixD &x, int i) { return i == 0 ? x.i0 : (i == 1 ? x.i1 : (i == 2 ? x.i2 : x.i3)); }
-template <bool RC, bool L> DEV v3 mxEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
-    if (!RC || m.type != MI_BSDF_T_MIXTURE) return bsdfEval<RC>(sc, m, wi, wo);
+template <bool RC, bool MIX, bool L> DEV v3 mxEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
+    if (!MIX || m.type != MI_BSDF_T_MIXTURE) return bsdfEval<RC>(sc, m, wi, wo);
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     const MixD x = mixOf(m); v3 r = V(0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (i < x.n) r = r + bsdfEval<RC>(sc, loadMaterial(tb, (int) mixChild(x, i)), wi, wo) * mixWeight(x, i);
     return r;
 }
-template <bool RC, bool L> DEV float mxPdf(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
-    if (!RC || m.type != MI_BSDF_T_MIXTURE) return bsdfPdf<RC>(sc, m, wi, wo);
+template <bool RC, bool MIX, bool L> DEV float mxPdf(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
+    if (!MIX || m.type != MI_BSDF_T_MIXTURE) return bsdfPdf<RC>(sc, m, wi, wo);
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     const MixD x = mixOf(m); float r = 0.0f;
 #pragma unroll
@@ -1251,8 +1251,8 @@ template <bool RC, bool L> DEV float mxPdf(const DScene &sc, const Tabs<L> &tb, 
     return r;
 }
 // `extra`: functor drawing one more sampler value, called only if the chosen BSDF asks for it (BSDF::EUsesSampler)
-template <bool RC, bool L, typename F> DEV v3 mxSample(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &eta, bool &delta, bool &nullComp) {
-    if (!RC || m.type != MI_BSDF_T_MIXTURE) { const float e = (RC && bsdfUsesSampler(m)) ? extra() : 0.0f; return bsdfSample<RC>(sc, m, wi, u, v, e, wo, pdf, eta, delta, nullComp); }
+template <bool RC, bool MIX, bool L, typename F> DEV v3 mxSample(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &eta, bool &delta, bool &nullComp) {
+    if (!MIX || m.type != MI_BSDF_T_MIXTURE) { const float e = (RC && bsdfUsesSampler(m)) ? extra() : 0.0f; return bsdfSample<RC>(sc, m, wi, u, v, e, wo, pdf, eta, delta, nullComp); }
     const bool flip = (m.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
     const MixD x = mixOf(m);
     // m_pdf.sampleReuse(sample.x) (pmf.h:124-190): lower_bound over the cdf = number of entries below u, minus one; zero-probability entries are skipped forward

@@ -130,6 +130,7 @@ struct DScene {
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
     // triangles dropped), exact Wald records in ORIGINAL triangle order for pass 2, largest |coordinate| of the scene box (error-margin scale)
     const struct PacketGroupD *packet_groups; const TriAccelD *packet_exact; uint32_t packet_gk[3]; float packet_scale;
+    uint32_t has_adapters;   // mixturebsdf / bumpmap / normalmap records present: the WRAP variants of k_shade
     uint32_t has_roughconductor, has_diffuse;   // non-diffuse / plain diffuse materials present: select the shade kernel variants (both: two launches per bounce, shade.h)
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none

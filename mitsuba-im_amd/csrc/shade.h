@@ -8,7 +8,8 @@
 //   tail of the previous iteration (emitter hit by the BSDF ray -> MIS term :257-264, Russian roulette :276-286), then
 //   emitted radiance :148-150, depth test :156-165, emitter sampling :172-200 (visibility deferred to the shadow queue),
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
-template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
+// WRAP: the BSDF adapters mixturebsdf / bumpmap / normalmap are present (only with RC and AN): scenes without them keep the leaner kernels
+template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX, bool WRAP>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
 __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 if (RC && bsdf.type == MI_BSDF_T_MASK) {                     // mask.cpp: this record's (textured) `reflectance` is the opacity in front of the nested record `distr`
                     opac = ld3(bsdf.reflectance); masked = true; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
                 }
-                if (RC && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record
+                if (WRAP && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record
                     float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
                     if (AN && inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, ro3 + d * hr.x, huvx, huvy, dpdu, dpdv);
                     else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
@@ -184,13 +185,13 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                         ++shadowRays;                                        // scene.cpp:871-875: a shadow ray is cast whenever pdf != 0
                         v3 wo = toLocal(h, dr.d);
                         v3 wiQ = h.wi, woQ = wo; bool rejected = false;
-                        if (RC && bumped) {                                                  // bumpmap.cpp:165-180: the query in the perturbed frame
+                        if (WRAP && bumped) {                                                // bumpmap.cpp:165-180: the query in the perturbed frame
                             wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0;
                         }
-                        v3 bsdfVal = rejected ? V(0, 0, 0) : mxEval<RC>(sc, tb, bsdf, wiQ, woQ);
+                        v3 bsdfVal = rejected ? V(0, 0, 0) : mxEval<RC, WRAP>(sc, tb, bsdf, wiQ, woQ);
                         if (RC && masked) bsdfVal = bsdfVal * opac;                          // mask.cpp:124-127
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = (dr.delta || rejected) ? 0.0f : mxPdf<RC>(sc, tb, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
+                            float bp = (dr.delta || rejected) ? 0.0f : mxPdf<RC, WRAP>(sc, tb, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
                             if (RC && masked) bp *= luminance3(opac);                          // mask.cpp:141-146
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             } else {
                 auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };        // bRec.sampler->next1D() inside BSDF::sample (EUsesSampler), only if the sampled BSDF asks
                 (void) extra;
-                if (RC && bumped) {                                                    // bumpmap.cpp:199-222
+                if (WRAP && bumped) {                                                  // bumpmap.cpp:199-222
                     const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
-                    bw = mxSample<RC>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
+                    bw = mxSample<RC, WRAP>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
                     if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
-                } else bw = mxSample<RC>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                } else bw = mxSample<RC, WRAP>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (RC && masked) { const float prob = luminance3(opac); bw = V(bw.x * opac.x / prob, bw.y * opac.y / prob, bw.z * opac.z / prob); bPdf *= prob; }
             }
             v3 wo = toWorld(h, woL);
@@ -266,13 +267,13 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 
 
 
-// launch the (SMALL, AN, TEX) variant of one (RC, ENV) combination that fits the scene
-template <bool RC, bool ENV>
+// launch the (SMALL, AN, TEX) variant of one (RC, ENV, WRAP) combination that fits the scene; WRAP variants exist for AN = true only
+template <bool RC, bool ENV, bool WRAP>
 static void launchShadeVariant(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool small = sc.small_tables != 0;
-#define MI_SHADE(SM) do { if (sc.ext && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
-                          else if (sc.ext) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
-                          else hipLaunchKernelGGL((k_shade<RC, ENV, SM, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); } while (0)
+#define MI_SHADE(SM) do { if ((sc.ext || WRAP) && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true, WRAP>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
+                          else if (sc.ext || WRAP) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false, WRAP>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
+                          else hipLaunchKernelGGL((k_shade<RC, ENV, SM, WRAP, false, WRAP>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); } while (0)
     if (small) MI_SHADE(true); else MI_SHADE(false);
 #undef MI_SHADE
 }
