@@ -171,6 +171,9 @@ int mi_scene_set_camera(mi_scene *s, const float *sample_to_camera16, const floa
  * 3 mitchell (B in `radius`, C in `stddev`), 4 catmullrom, 5 lanczos (lobes in `radius`) */
 int mi_scene_set_film(mi_scene *s, uint32_t width, uint32_t height, uint32_t filter_kind, float radius, float stddev);
 int mi_scene_commit(mi_scene *s, uint32_t device);   /* BVH build + TriAccel table + upload */
+/* A replica of a committed scene on HIP device `device` (may be the source's own): multi-device renders keep one scene copy per device, as the reference
+ * ships the scene to every worker (src/librender/renderjob.cpp, sched_remote.cpp).  The host-side build is reused, only the upload is repeated. */
+int mi_scene_clone(mi_scene *s, uint32_t device, mi_scene **out);
 
 /* -- render: replaces SamplingIntegrator::renderBlock / ImageOrderIntegrator::render over MIPathTracer::Li
  *    (src/librender/integrator.cpp:141-189, :336-402, :469-486; src/integrators/path/path.cpp:119-294) -- */
@@ -190,10 +193,25 @@ void mi_render_cancel(mi_render *r);                /* Integrator::cancel: threa
 int mi_render_film_size(mi_render *r, int layout, uint32_t *height, uint32_t *width, uint32_t *channels, uint32_t *border);
 int mi_render_read_film(mi_render *r, int layout, float *host_out);
 int mi_render_read_film_device(mi_render *r, int layout, void *device_out);   /* device pointer (e.g. a torch tensor) for the RCCL reduce */
+/* dst += src (raw film sums + ray counters): merge step of a render whose rows were split over several handles / devices with mi_render_run_rows; replaces
+ * Film::put(block) under the RenderQueue mutex (src/librender/renderproc.cpp:142-149).  Other device: peer copy over xGMI, then one add kernel.  Both idle. */
+int mi_render_merge_film(mi_render *dst, mi_render *src);
 /* Debug / parity: Li of individual (px, py, sampleIndex) triples through the very same kernels; out_li[n*3] */
 int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *out_li);
 int mi_render_stats(mi_render *r, mi_stats *out);
 int mi_render_set_profiling(mi_render *r, int enabled);   /* per-stage HIP-event timing: events are recorded between the stage launches of the first stream, nothing is serialised (off by default) */
+
+/* bool Scene::rayIntersect(const Ray &ray, Intersection &its) for a batch of rays (include/mitsuba/render/scene.h:187-243): rays8 = (o.xyz, mint, d.xyz, maxt) per
+ * ray, host pointers; the scene must be committed.  Record = the fields of mitsuba::Intersection the path consumes (include/mitsuba/render/shape.h:36-170). */
+typedef struct {
+    uint32_t valid;                      /* 0: no intersection in [mint, maxt]; the other fields are then unset */
+    float t, p[3], ng[3];                /* its.t, its.p, its.geoFrame.n */
+    float ns[3], s[3], tt[3];            /* its.shFrame.n / .s / .t */
+    float uv[2], wi[3], bary[2];         /* its.uv, its.wi (local), the barycentrics (u, v) of a triangle hit / the shape's temp data */
+    uint32_t prim; int32_t instance;     /* global primitive index (triangles first, then analytic shapes); instance index or -1 */
+    int32_t material, emitter;           /* material / emitter table index (its.shape->getBSDF() / getEmitter()), -1: none */
+} mi_intersection;
+int mi_scene_ray_intersect(mi_scene *s, const float *rays8, uint64_t n, mi_intersection *out);
 
 /* Unit-level device entry points used by the parity tests (each runs a small kernel over n items) */
 int mi_debug_intersect(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4);   /* t,u,v,prim (prim<0: miss) */

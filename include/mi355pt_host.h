@@ -11,6 +11,9 @@ extern "C" {
 const char *mi_host_last_error(void);
 /* returns NULL (message in mi_host_last_error) when rrDepth <= 0 or maxDepth is neither -1 nor > 0 -- the reference's Log(EError) texts */
 void *mi_host_create(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, uint32_t device, uint32_t planes_per_batch);
+/* the same with the build-specific `devices` property: the film rows are spread over these HIP devices (an entry may repeat); the scene given to
+ * mi_host_preprocess must live on devices[0], the other devices receive replicas (mi_scene_clone) and their films are merged (mi_render_merge_film) */
+void *mi_host_create_devices(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, const uint32_t *devices, uint32_t n_devices, uint32_t planes_per_batch);
 void mi_host_destroy(void *integrator);
 int mi_host_preprocess(void *integrator, mi_scene *scene);
 /* Controls = {continu, abort, interrupt}: returns 0 done, -1 *abort set, -2 *continu cleared, otherwise progress()'s non-zero value;

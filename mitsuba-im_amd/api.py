@@ -64,10 +64,10 @@ class MiStats(C.Structure):
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
            "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_envmap_filter", "mi_scene_set_camera", "mi_scene_set_film",
-           "mi_scene_commit", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
+           "mi_scene_commit", "mi_scene_ray_intersect", "mi_scene_clone", "mi_render_merge_film", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays", "mi_debug_sincosf"]
-HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
+HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_create_devices", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
 
 
 def build(force=False):
@@ -101,6 +101,9 @@ class Lib:
         L.mi_scene_set_camera.argtypes = [vp, vp, vp, f32, f32]
         L.mi_scene_set_film.argtypes = [vp, u32, u32, u32, f32, f32]
         L.mi_scene_commit.argtypes = [vp, u32]
+        L.mi_scene_clone.argtypes = [vp, u32, C.POINTER(vp)]
+        L.mi_scene_ray_intersect.argtypes = [vp, vp, u64, vp]
+        L.mi_render_merge_film.argtypes = [vp, vp]
         L.mi_render_create.argtypes = [vp, C.POINTER(MiRenderParams), C.POINTER(vp)]
         L.mi_render_destroy.argtypes = [vp]; L.mi_render_destroy.restype = None
         L.mi_render_run.argtypes = [vp, MiTile, u32, u32]
@@ -222,6 +225,14 @@ class Scene:
 
     def __del__(self):
         self.close()
+
+    def ray_intersect(self, rays8):
+        """Scene::rayIntersect for a batch of rays -> structured array of mi_intersection records."""
+        rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)
+        dt = np.dtype([("valid", "<u4"), ("t", "<f4"), ("p", "<f4", 3), ("ng", "<f4", 3), ("ns", "<f4", 3), ("s", "<f4", 3), ("tt", "<f4", 3), ("uv", "<f4", 2), ("wi", "<f4", 3), ("bary", "<f4", 2),
+                       ("prim", "<u4"), ("instance", "<i4"), ("material", "<i4"), ("emitter", "<i4")])
+        out = np.zeros(len(rays8), dt)
+        self.L.check(self.L.L.mi_scene_ray_intersect(self.h, _p(rays8), len(rays8), out.ctypes.data)); return out
 
     # unit-level device entry points
     def intersect(self, rays8, any_hit=False, with_instance=False):

@@ -554,6 +554,15 @@ static mi355::Properties convertProps(const Properties &props, const Sampler *sa
     p.maxDepth = props.getInteger("maxDepth", -1); p.rrDepth = props.getInteger("rrDepth", 5);
     p.strictNormals = props.getBoolean("strictNormals", false); p.hideEmitters = props.getBoolean("hideEmitters", false);
     p.device = (uint32_t) props.getInteger("device", 0); p.planesPerBatch = (uint32_t) props.getInteger("planesPerBatch", 0);
+    {   // build-specific `devices` = "0,1,2,...": HIP devices to spread the film rows over (one scene replica + one host thread each); default: `device` alone
+        const std::string list = props.getString("devices", "");
+        for (size_t i = 0; i < list.size();) {
+            size_t j = list.find_first_of(", ;", i); if (j == std::string::npos) j = list.size();
+            if (j > i) p.devices.push_back((uint32_t) atoi(list.substr(i, j - i).c_str()));
+            i = j + 1;
+        }
+        if (!p.devices.empty()) p.device = p.devices[0];
+    }
     p.sampleCount = (uint32_t) sampler->getSampleCount();
     std::string sname = sampler->getClass()->getName();
     if (sname == "SobolSampler") { p.sampler = MI_SAMPLER_SOBOL; p.seed = (uint64_t) sampler->getProperties().getSize("scramble", 0); }

@@ -25,7 +25,9 @@ void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, 
 void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_film_layout(const float *, const float *, float *, int, int, int, int, hipStream_t);
 void mi_launch_gather_samples(const Queues &, const uint32_t *, uint64_t, float *, hipStream_t);
+void mi_launch_film_add(float *, const float *, size_t, hipStream_t);
 void mi_launch_debug_intersect(const DScene &, const float *, uint64_t, int, float *, int *, hipStream_t);
+void mi_launch_ray_intersect(const DScene &, const float *, uint64_t, mi_intersection *, hipStream_t);
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
 void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
 void mi_launch_debug_sincosf(const float *, uint64_t, float *, hipStream_t);
@@ -60,12 +62,12 @@ struct mi_scene { mi::SceneHost h; };
 struct mi_render {
     mi_scene *scene = nullptr; mi_render_params p{}; RenderConst rc{};
     Queues q{}; std::vector<void *> allocs; uint64_t poolPaths = 0; uint32_t grid = 0, gridExtend = 0, gridShade = 0, gridShadow = 0;
-    float *film = nullptr, *spill = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr;   // film: own-pixel sums; spill: cross-pixel splats (atomics)
+    float *film = nullptr, *spill = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr, *mergeTmp = nullptr;   // mergeTmp: staging for another device's film (mi_render_merge_film)   // film: own-pixel sums; spill: cross-pixel splats (atomics)
     hipStream_t stream = nullptr; hipEvent_t evBegin = nullptr, evEnd = nullptr;
     std::atomic<int> cancel{0};
     bool profiling = false; std::vector<hipEvent_t> evPool; std::vector<int> evTag;   // tag: 0 generate/film, 1 extend, 2 shade, 3 shadow
     mi_stats stats{};
-    uint64_t samplesTotal = 0, launchesAll = 0;
+    uint64_t samplesTotal = 0, launchesAll = 0; uint64_t mergedRays = 0, mergedShadow = 0, mergedPathLen = 0, mergedSamples = 0;   // counters of replicas merged into this film
     bool ldsTables = false;   // this render stages the scene tables in LDS (scene eligible and everything fits 64 KB together with the Sobol tables and the order list)
     uint32_t *dNib = nullptr; void *dSobolTabs = nullptr;   // dSobolTabs: the three look_up tables of k_generate (frame, px, py), one allocation
     // optional further path pools + streams: consecutive batches go round-robin through them, so the ALU-bound traversal kernels of one batch
@@ -401,6 +403,24 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     return MI_OK;
 }
 
+// A replica of a committed scene on another (or the same) HIP device: multi-device renders hold one full scene copy per device (the reference ships the
+// serialized scene to every worker, src/librender/renderjob.cpp + sched_remote.cpp).  The host-side build (BVH, tables) is reused, only the upload is repeated.
+int mi_scene_clone(mi_scene *s, uint32_t device, mi_scene **out) {
+    if (!s || !out) return fail(MI_ERR_INVALID, "mi_scene_clone: null argument");
+    if (!s->h.committed) return fail(MI_ERR_INVALID, "mi_scene_clone: scene not committed");
+    int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
+    if ((int) device >= devCount) return fail(MI_ERR_DEVICE, "mi_scene_clone: no such HIP device");
+    mi_scene *c = new mi_scene();
+    c->h = s->h;                                    // inputs + host-derived data
+    {   // the copy must not own the source's device allocations
+        void **ps[] = {&c->h.dPacketGroups, &c->h.dPacketExact, &c->h.dTexLevels, &c->h.dTexTexels, &c->h.dMipLut, &c->h.dTriUV, &c->h.dTextures, &c->h.dMaterialTables, &c->h.dInstances, &c->h.dEmitterX, &c->h.dAnalytic, &c->h.dNodes, &c->h.dTris, &c->h.dShade, &c->h.dI2, &c->h.dNrm, &c->h.dMaterials, &c->h.dEmitters, &c->h.dEmitterCdf, &c->h.dAreaCdf, &c->h.dFilter, &c->h.dSobolM32, &c->h.dSobolVdc, &c->h.dSobolVdcInv, &c->h.dEnvRGB, &c->h.dEnvCols, &c->h.dEnvRows, &c->h.dEnvWeights};
+        for (void **p : ps) *p = nullptr;
+        c->h.committed = false;
+    }
+    if (c->h.upload((int) device)) { std::string msg = std::string("mi_scene_clone: upload failed: ") + hipGetErrorString(hipGetLastError()); delete c; return fail(MI_ERR_DEVICE, msg); }
+    *out = c; return MI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ render
 static int allocQ(std::vector<void *> &allocs, void **p, size_t bytes) {
     HIPCHK(hipMalloc(p, bytes)); allocs.push_back(*p); return MI_OK;
@@ -538,6 +558,7 @@ void mi_render_destroy(mi_render *r) {
     if (r->film) (void) hipFree(r->film);
     if (r->spill) (void) hipFree(r->spill);
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
+    if (r->mergeTmp) (void) hipFree(r->mergeTmp);
     if (r->dNib) (void) hipFree(r->dNib);
     if (r->dSobolTabs) (void) hipFree(r->dSobolTabs);
     for (hipEvent_t e : r->evPool) (void) hipEventDestroy(e);
@@ -551,7 +572,7 @@ int mi_render_clear(mi_render *r) {
     HIPCHK(hipMemsetAsync(r->film, 0, r->filmFloats * 4, r->stream)); HIPCHK(hipMemsetAsync(r->spill, 0, r->filmFloats * 4, r->stream));
     if (r->q.counters) HIPCHK(hipMemsetAsync(r->q.counters, 0, 32, r->stream));
     for (Queues &Q : r->qx) if (Q.counters) HIPCHK(hipMemsetAsync(Q.counters, 0, 32, r->stream));
-    HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; r->cancel.store(0); return MI_OK;
+    HIPCHK(hipStreamSynchronize(r->stream)); r->samplesTotal = 0; r->mergedRays = r->mergedShadow = r->mergedPathLen = r->mergedSamples = 0; r->cancel.store(0); return MI_OK;
 }
 void mi_render_cancel(mi_render *r) { if (r) r->cancel.store(1); }
 int mi_render_set_profiling(mi_render *r, int enabled) { if (!r) return fail(MI_ERR_INVALID, "null"); r->profiling = enabled != 0; return MI_OK; }
@@ -645,7 +666,7 @@ int mi_render_stats(mi_render *r, mi_stats *out) {
     unsigned long long c[4] = {0, 0, 0, 0};
     if (r->q.counters) HIPCHK(hipMemcpy(c, r->q.counters, 32, hipMemcpyDeviceToHost));
     for (Queues &Q : r->qx) if (Q.counters) { unsigned long long c2[4]; HIPCHK(hipMemcpy(c2, Q.counters, 32, hipMemcpyDeviceToHost)); for (int i = 0; i < 4; ++i) c[i] += c2[i]; }
-    r->stats.rays = c[0]; r->stats.shadow_rays = c[1]; r->stats.path_length_sum = c[2]; r->stats.samples = r->samplesTotal; r->stats.extend_rays = c[0]; r->stats.extend_launches_all = r->launchesAll;
+    r->stats.rays = c[0] + r->mergedRays; r->stats.shadow_rays = c[1] + r->mergedShadow; r->stats.path_length_sum = c[2] + r->mergedPathLen; r->stats.samples = r->samplesTotal + r->mergedSamples; r->stats.extend_rays = c[0]; r->stats.extend_launches_all = r->launchesAll;
     *out = r->stats; return MI_OK;
 }
 
@@ -670,6 +691,28 @@ int mi_render_read_film(mi_render *r, int layout, float *host) {
     if (!r || !host) return fail(MI_ERR_INVALID, "mi_render_read_film: null");
     int rc = mi_render_read_film_device(r, layout, r->layoutTmp); if (rc) return rc;
     HIPCHK(hipMemcpy(host, r->layoutTmp, layoutFloats(r, layout) * 4, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// dst += src (raw film sums: own-pixel planes and spill planes).  The merge step of a multi-device render, where every device renders its own rows of the
+// frame (mi_render_run_rows) into its own film: the reference merges worker blocks with Film::put under a mutex (src/librender/renderproc.cpp:142-149).
+// Same device: one add kernel; different devices: peer copy (xGMI) into a staging buffer on dst's device, then the add.  Both renders must be idle.
+int mi_render_merge_film(mi_render *dst, mi_render *src) {
+    if (!dst || !src || dst == src) return fail(MI_ERR_INVALID, "mi_render_merge_film: two different render handles are needed");
+    if (dst->filmFloats != src->filmFloats) return fail(MI_ERR_INVALID, "mi_render_merge_film: the two renders have different films");
+    const int dd = dst->scene->h.device, sd = src->scene->h.device; const size_t n = dst->filmFloats;
+    HIPCHK(hipSetDevice(dd));
+    const float *sFilm = src->film, *sSpill = src->spill;
+    if (dd != sd) {
+        if (!dst->mergeTmp) HIPCHK(hipMalloc((void **) &dst->mergeTmp, 2 * n * 4));
+        HIPCHK(hipMemcpyPeerAsync(dst->mergeTmp, dd, src->film, sd, n * 4, dst->stream));
+        HIPCHK(hipMemcpyPeerAsync(dst->mergeTmp + n, dd, src->spill, sd, n * 4, dst->stream));
+        sFilm = dst->mergeTmp; sSpill = dst->mergeTmp + n;
+    }
+    mi_launch_film_add(dst->film, sFilm, n, dst->stream); mi_launch_film_add(dst->spill, sSpill, n, dst->stream);
+    HIPCHK(hipStreamSynchronize(dst->stream)); HIPCHK(hipGetLastError());
+    unsigned long long c[4]; mi_stats st{};      // the merged handle reports the sum of the ray counters too
+    (void) c; if (mi_render_stats(src, &st) == MI_OK) { dst->mergedRays += st.rays; dst->mergedShadow += st.shadow_rays; dst->mergedPathLen += st.path_length_sum; dst->mergedSamples += st.samples; }
     return MI_OK;
 }
 
@@ -715,6 +758,11 @@ int mi_debug_intersect_inst(mi_scene *s, const float *rays, uint64_t n, int anyH
     if (!rc && outInst) { hipError_t e = hipMemcpy(outInst, dInst, n * 4, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }
     if (dInst) (void) hipFree(dInst);
     return rc;
+}
+int mi_scene_ray_intersect(mi_scene *s, const float *rays, uint64_t n, mi_intersection *out) {
+    if (!s || !s->h.committed || !rays || !out || !n) return fail(MI_ERR_INVALID, "mi_scene_ray_intersect: bad argument (the scene must be committed)");
+    HIPCHK(hipSetDevice(s->h.device));
+    return withBuffers(rays, n * 32, out, n * sizeof(mi_intersection), [&](void *i, void *o) { mi_launch_ray_intersect(s->h.d, (const float *) i, n, (mi_intersection *) o, nullptr); });
 }
 int mi_debug_intersect(mi_scene *s, const float *rays, uint64_t n, int anyHit, float *out) { return mi_debug_intersect_inst(s, rays, n, anyHit, out, nullptr); }
 int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, uint64_t *outIdx, float *outVals) {

@@ -1,6 +1,7 @@
 // integrator_host.cpp -- see integrator_host.h
 #include "integrator_host.h"
 #include <cstdio>
+#include <thread>
 
 namespace mi355 {
 
@@ -13,15 +14,26 @@ MIPathTracerHIP::MIPathTracerHIP(const Properties &props) : m_props(props) {
     if (m_props.maxDepth <= 0 && m_props.maxDepth != -1)
         throw std::runtime_error("'maxDepth' must be set to -1 (infinite) or a value greater than zero!");                            // integrator.cpp:224-225
 }
-MIPathTracerHIP::~MIPathTracerHIP() { if (m_render) mi_render_destroy(m_render); }
+MIPathTracerHIP::~MIPathTracerHIP() { releaseReplicas(); if (m_render) mi_render_destroy(m_render); }
+void MIPathTracerHIP::releaseReplicas() {
+    for (mi_render *r : m_replicaRenders) mi_render_destroy(r);
+    for (mi_scene *s : m_replicaScenes) mi_scene_destroy(s);
+    m_replicaRenders.clear(); m_replicaScenes.clear();
+}
 
 bool MIPathTracerHIP::preprocess(mi_scene *scene) {
+    releaseReplicas();
     if (m_render) { mi_render_destroy(m_render); m_render = nullptr; }
     m_scene = scene;
     mi_render_params p{};
     p.max_depth = m_props.maxDepth; p.rr_depth = m_props.rrDepth; p.strict_normals = m_props.strictNormals; p.hide_emitters = m_props.hideEmitters;
     p.sampler = (uint32_t) m_props.sampler; p.spp = m_props.sampleCount; p.seed = m_props.seed; p.device = m_props.device; p.planes_per_batch = m_props.planesPerBatch; p.opacity = m_props.opacity ? 1 : 0;
     check(mi_render_create(scene, &p, &m_render), "MIPathTracerHIP::preprocess");
+    // `devices`: every further entry gets a replica of the scene and a render handle of its own; film rows are interleaved over the replicas
+    for (size_t i = 1; i < m_props.devices.size(); ++i) {
+        mi_scene *rs = nullptr; check(mi_scene_clone(scene, m_props.devices[i], &rs), "MIPathTracerHIP::preprocess"); m_replicaScenes.push_back(rs);
+        mi_render *rr = nullptr; p.device = m_props.devices[i]; check(mi_render_create(rs, &p, &rr), "MIPathTracerHIP::preprocess"); m_replicaRenders.push_back(rr);
+    }
     return true;
 }
 bool MIPathTracerHIP::allocate(int threadCount) { m_threads = threadCount; return m_render != nullptr; }
@@ -40,20 +52,38 @@ int MIPathTracerHIP::render(float *target, Controls controls, int threadIdx, int
     // streams busy, the film is read back (and progress() called on a new sample plane, integrator.cpp:376-378) once per pair.
     const bool interactive = target || controls.interrupt || controls.abort || controls.continu;
     const uint32_t chunk = interactive ? (planes >= spp ? planes : 2 * planes) : spp;
+    const uint32_t nRep = 1 + (uint32_t) m_replicaRenders.size();
+    for (mi_render *rr : m_replicaRenders) check(mi_render_clear(rr), "MIPathTracerHIP::render");
+    // one submission of sample planes [a, b): every replica traces its rows (k, k + nRep, ...) from a host thread of its own; the replicas' films are then
+    // summed into the first one in replica order (renderproc.cpp:142-149 merges worker blocks the same way, by addition)
+    auto submit = [&](uint32_t a, uint32_t b) -> int {
+        if (nRep == 1) return mi_render_run(m_render, tile, a, b);
+        std::vector<int> rcs(nRep, MI_OK); std::vector<std::string> errs(nRep); std::vector<std::thread> th;
+        for (uint32_t k = 0; k < nRep; ++k)
+            th.emplace_back([&, k] { mi_render *r = k ? m_replicaRenders[k - 1] : m_render; mi_tile t{0, k, tile.x1, tile.y1};
+                                     if (k < tile.y1) { rcs[k] = mi_render_run_rows(r, t, nRep, a, b); if (rcs[k] != MI_OK) errs[k] = mi_last_error(); } });
+        for (std::thread &t : th) t.join();
+        for (uint32_t k = 0; k < nRep; ++k) if (rcs[k] != MI_OK) { if (rcs[k] == MI_CANCELLED) return MI_CANCELLED; throw std::runtime_error("MIPathTracerHIP::render: " + errs[k]); }
+        return MI_OK;
+    };
+    auto merge = [&]() {      // replica films -> the first film; the replicas start the next submission from zero
+        for (mi_render *rr : m_replicaRenders) { check(mi_render_merge_film(m_render, rr), "MIPathTracerHIP::render"); check(mi_render_clear(rr), "MIPathTracerHIP::render"); }
+    };
     for (uint32_t s = 0; s < spp; s += chunk) {
         if (m_cancel.load()) return -1;                                        // Integrator::cancel (any thread, any time)
         if (controls.abort && *controls.abort) return -1;
         if (controls.continu && !*controls.continu) return -2;
         if (controls.interrupt) { int rc = controls.interrupt->progress(this, target, (double) s, controls, threadIdx, threadCount); if (rc != 0) return rc; }
         if (m_cancel.load()) return -1;
-        int rc = mi_render_run(m_render, tile, s, std::min(spp, s + chunk));
+        int rc = submit(s, std::min(spp, s + chunk));
         if (rc == MI_CANCELLED) return -1;
         check(rc, "MIPathTracerHIP::render");
+        if (nRep > 1) merge();
         if (target) check(mi_render_read_film(m_render, 1, target), "MIPathTracerHIP::render");
     }
     return m_cancel.load() ? -1 : 0;
 }
-void MIPathTracerHIP::cancel() { m_cancel.store(1); if (m_render) mi_render_cancel(m_render); }
+void MIPathTracerHIP::cancel() { m_cancel.store(1); if (m_render) mi_render_cancel(m_render); for (mi_render *rr : m_replicaRenders) mi_render_cancel(rr); }
 
 const char *MIPathTracerHIP::getRealtimeStatistics() {
     if (!m_render) return nullptr;
@@ -77,6 +107,14 @@ extern "C" {
 struct mi_host_integrator { mi355::MIPathTracerHIP *p; std::string err; };
 static thread_local std::string g_hostErr;
 const char *mi_host_last_error(void) { return g_hostErr.c_str(); }
+void *mi_host_create_devices(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, const uint32_t *devices, uint32_t nDevices, uint32_t planes) {
+    try {
+        mi355::Properties pr; pr.maxDepth = maxDepth; pr.rrDepth = rrDepth; pr.strictNormals = strictNormals != 0; pr.hideEmitters = hideEmitters != 0;
+        pr.sampler = sampler; pr.sampleCount = spp; pr.seed = seed; pr.planesPerBatch = planes;
+        if (devices && nDevices) { pr.devices.assign(devices, devices + nDevices); pr.device = devices[0]; }
+        return new mi355::MIPathTracerHIP(pr);
+    } catch (const std::exception &e) { g_hostErr = e.what(); return nullptr; }
+}
 void *mi_host_create(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, uint32_t device, uint32_t planes) {
     try {
         mi355::Properties pr; pr.maxDepth = maxDepth; pr.rrDepth = rrDepth; pr.strictNormals = strictNormals != 0; pr.hideEmitters = hideEmitters != 0;

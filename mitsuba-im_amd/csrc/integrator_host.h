@@ -24,6 +24,8 @@ struct Properties {                 // the subset of mitsuba::Properties this in
     int maxDepth = -1, rrDepth = 5; bool strictNormals = false, hideEmitters = false;
     int sampler = MI_SAMPLER_SOBOL; uint32_t sampleCount = 4; uint64_t seed = 0;   // the scene's sampler (Sampler::getSampleCount, getProperties)
     uint32_t device = 0, planesPerBatch = 0;                                       // build-specific
+    std::vector<uint32_t> devices;   // build-specific (SURVEY §8b `devices`): HIP devices to spread the film rows over; empty = {device}.  An entry may repeat (two
+                                     // replicas on one GPU).  The scene handed to preprocess() lives on devices[0]; the others get clones (mi_scene_clone)
     bool opacity = true;   // RadianceQueryRecord::EOpacity: the responsive drivers always request it (integrator.cpp:474)
 };
 
@@ -54,6 +56,8 @@ public:
     std::string toString() const;
 private:
     Properties m_props; mi_scene *m_scene = nullptr; mi_render *m_render = nullptr; std::string m_stats; int m_threads = 1;
+    std::vector<mi_scene *> m_replicaScenes; std::vector<mi_render *> m_replicaRenders;   // devices[1..]: one scene clone + one render handle each, driven by one host thread each
+    void releaseReplicas();
     std::atomic<int> m_cancel{0};   // set by cancel(), reset at the start of render(): a cancel between two batches or two mi_render_run calls is never lost
 };
 

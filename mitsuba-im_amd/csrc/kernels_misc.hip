@@ -125,6 +125,12 @@ __global__ __launch_bounds__(WG) void k_film(DScene sc, Queues q, BatchDesc bd, 
     for (int k = 0; k < 5; ++k) film[k * plane + ownIdx] = own[k];
 }
 
+// merge of two replicas' films (multi-device renders: mi_render_merge_film): plain sums, element by element
+__global__ void k_film_add(float *dst, const float *src, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // film read-back helpers: SoA planes -> interleaved layouts of mi_render_read_film
 __global__ void k_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout) {
     const size_t plane = (size_t) W * H;
@@ -173,6 +179,7 @@ void mi_launch_film(const DScene &sc, const Queues &q, const BatchDesc &bd, floa
 void mi_launch_film_layout(const float *film, const float *spill, float *out, int W, int H, int border, int layout, hipStream_t st) {
     size_t n = (size_t) W * H; hipLaunchKernelGGL(k_film_layout, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, film, spill, out, W, H, border, layout);
 }
+void mi_launch_film_add(float *dst, const float *src, size_t n, hipStream_t st) { hipLaunchKernelGGL(k_film_add, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, dst, src, n); }
 void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_gather_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, q, slots, n, out); }
 void mi_launch_debug_sobol(const DScene &sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *oi, float *ov, hipStream_t st) { hipLaunchKernelGGL(k_debug_sobol, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, in, n, ndims, oi, ov); }
 void mi_launch_debug_sincosf(const float *in, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_sincosf, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, in, n, out); }

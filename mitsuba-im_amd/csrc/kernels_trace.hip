@@ -78,6 +78,38 @@ __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *
     out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
 }
 
+// ---------------------------------------------------------------------------------------------- Scene::rayIntersect, full records
+// bool Scene::rayIntersect(const Ray &, Intersection &) (include/mitsuba/render/scene.h:187-243 -> ShapeKDTree::rayIntersect + fillIntersectionRecord,
+// src/librender/skdtree.cpp:112-142, include/mitsuba/render/skdtree.h:343-428) for a batch of rays: the record of mi_intersection (include/mi355pt.h)
+__global__ __launch_bounds__(WG) void k_ray_intersect(DScene sc, const float *rays, uint64_t n, mi_intersection *out) {
+    __shared__ int s_stk[STACK_DEPTH * WG];
+    __shared__ f4 s_exact[MI_PACKET_MAX * 3];
+    if (sc.packet_n) packetStage(sc, s_exact);
+    const uint64_t i = (uint64_t) blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + i * 8;
+    v3 o = V(r[0], r[1], r[2]), d = V(r[4], r[5], r[6]);
+    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
+    if (clipInterval(sc, o, d, r[3], r[7], false, mint, maxt)) {
+        if (sc.packet_n) hit = packetIntersect<false, 1>(sc, (AS<true>::p4) s_exact, o, d, mint, maxt, t, prim, u, v);
+        else hit = traverse<false, 3>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+    }
+    mi_intersection rec; memset(&rec, 0, sizeof(rec)); rec.valid = hit ? 1u : 0u; rec.prim = 0xFFFFFFFFu; rec.instance = -1; rec.material = -1; rec.emitter = -1;
+    if (hit) {
+        Tabs<false> tb; tb.shade4 = (AS<false>::p4) sc.shade; tb.materials4 = (AS<false>::p4) sc.materials; tb.emitters4 = (AS<false>::p4) sc.emitters; tb.emitter_cdf = sc.emitter_cdf; tb.area_cdf = sc.area_cdf;
+        Hit h;
+        if (inst >= 0) fillHitInstanced(sc, tb, sc.instances[inst], o, d, t, prim, u, v, h);
+        else if (prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], o, d, t, u, v, h);
+        else fillHit<false, true>(sc, tb, d, t, prim, u, v, h);
+        if (inst < 0 && prim >= sc.n_tris) { v3 du, dv; analyticUV(sc.analytic[prim - sc.n_tris], u, v, o + d * t, h.uvx, h.uvy, du, dv); }
+        rec.t = t; rec.p[0] = h.p.x; rec.p[1] = h.p.y; rec.p[2] = h.p.z; rec.ng[0] = h.ng.x; rec.ng[1] = h.ng.y; rec.ng[2] = h.ng.z;
+        rec.ns[0] = h.ns.x; rec.ns[1] = h.ns.y; rec.ns[2] = h.ns.z; rec.s[0] = h.s.x; rec.s[1] = h.s.y; rec.s[2] = h.s.z; rec.tt[0] = h.t.x; rec.tt[1] = h.t.y; rec.tt[2] = h.t.z;
+        rec.uv[0] = h.uvx; rec.uv[1] = h.uvy; rec.wi[0] = h.wi.x; rec.wi[1] = h.wi.y; rec.wi[2] = h.wi.z; rec.bary[0] = u; rec.bary[1] = v;
+        rec.prim = prim; rec.instance = inst; rec.material = h.material; rec.emitter = h.emitter;
+    }
+    out[i] = rec;
+}
+
 // ---------------------------------------------------------------------------------------------- launch wrappers (used by api.cpp)
 extern "C" {
 static const bool kForceStack24 = getenv("MI355PT_STACK24") != nullptr;      // A/B switch, read once
@@ -99,5 +131,6 @@ void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStrea
     if (mode == 3) MI_BY_STACK(k_shadow, 3, sc, q); else if (mode == 2) MI_BY_STACK(k_shadow, 2, sc, q); else if (mode == 1) MI_BY_STACK(k_shadow, 1, sc, q); else MI_BY_STACK(k_shadow, 0, sc, q);
 }
 #undef MI_BY_STACK
+void mi_launch_ray_intersect(const DScene &sc, const float *rays, uint64_t n, mi_intersection *out, hipStream_t st) { hipLaunchKernelGGL(k_ray_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, out); }
 void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out, outInst); }
 }

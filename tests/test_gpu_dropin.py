@@ -110,3 +110,37 @@ def test_host_mirror_controls(mi, golden_scenes):
     assert rc == -1 and seen == [0.0, 8.0]
     assert L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: 0), None, 0, 1) == 0     # the flag is reset at the start of the next render()
     L.mi_host_destroy(h)
+
+
+def test_host_mirror_devices_replicas(mi, golden_scenes):
+    """Multi-device inside the product (SURVEY §8b `devices`, §8e): MIPathTracerHIP with devices = [0, 0] renders with TWO replicas -- a scene clone and a render
+    handle each, one host thread each, film rows interleaved (mi_render_run_rows), films merged by addition (mi_render_merge_film; the reference merges worker
+    blocks in src/librender/renderproc.cpp:142-149).  On one GPU both replicas share the device; the film must equal the single-replica film: bit for bit in
+    every pixel whose samples were accumulated by one replica (all of them, for the box filter's own-pixel sums)."""
+    import ctypes as C
+    L = mi.lib().L
+    L.mi_host_create_devices.restype = C.c_void_p
+    L.mi_host_create_devices.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32]
+    L.mi_host_preprocess.argtypes = [C.c_void_p, C.c_void_p]; L.mi_host_destroy.argtypes = [C.c_void_p]
+    L.mi_host_statistics.restype = C.c_char_p; L.mi_host_statistics.argtypes = [C.c_void_p]
+    CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_void_p)
+    L.mi_host_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), CB, C.c_void_p, C.c_int, C.c_int]
+    for name in ("cornell_small", "cornell_small_gauss", "veach_small"):
+        sc = golden_scenes[name]; gs = mi.Scene(sc)
+        single = mi.Render(gs, opacity=True); single.run(); ref = single.read_film(1); rst = single.stats()
+        devs = (C.c_uint32 * 3)(0, 0, 0)
+        h = L.mi_host_create_devices(sc.max_depth, sc.rr_depth, 0, 0, sc.sampler, sc.spp, sc.seed, devs, 3, 4)
+        assert h and L.mi_host_preprocess(h, gs.h) == 0
+        target = np.zeros_like(ref); cont, abort = C.c_int(1), C.c_int(0); calls = []
+        rc = L.mi_host_render(h, target.ctypes.data, C.byref(cont), C.byref(abort), CB(lambda spp, u: calls.append(spp) or 0), None, 0, 1)
+        assert rc == 0 and len(calls) >= 1
+        same = (target.view(np.uint32) == ref.view(np.uint32)).all(2)
+        if name == "cornell_small":
+            assert same[1:-1, 1:-1].mean() > 0.999 and np.allclose(target, ref, rtol=1e-6, atol=1e-7)      # box filter: own-pixel sums only (edge splats aside)
+        else:
+            assert np.allclose(target, ref, rtol=2e-5, atol=2e-6)      # wide filter / libm BSDFs: cross-pixel splats are float atomics in either case
+        stats = L.mi_host_statistics(h).decode(); assert "rays/sample" in stats
+        assert abs(float(stats.split("|")[1].split()[0]) - rst["rays"] / rst["samples"]) < 0.02      # the merged handle reports the replicas' ray counters too
+        # classic face (no target, no controls): one submission per replica
+        assert L.mi_host_render(h, None, None, None, CB(), None, 0, 1) == 0
+        L.mi_host_destroy(h)

@@ -907,3 +907,33 @@ def test_bsdf_adapters(mi, oracle, golden_scenes, name):
             mi.Scene(broken(lambda B: B[mix[0]].update(reflectance=(float(bump[0]), B[mix[0]]["reflectance"][1], 0.0))))
         with pytest.raises(mi.MiError, match="texture coordinates are required"):
             bad = type(sc)(sc); bad["shapes"] = [dict(s) for s in sc.shapes]; bad["shapes"][0]["has_uv"] = 0; mi.Scene(bad)
+
+
+@pytest.mark.parametrize("name", ["cornell_small", "atrium_small", "instanced_garden", "textured_shapes", "bunny_box"])
+def test_scene_ray_intersect_full_records(mi, oracle, golden_scenes, name):
+    """`bool Scene::rayIntersect(const Ray &, Intersection &)` for a batch of rays (mi_scene_ray_intersect; include/mitsuba/render/scene.h:187-243 over
+    fillIntersectionRecord, skdtree.h:343-428): t, p, geometric and shading frame, uv, wi, primitive / instance / material / emitter of every hit equal the
+    oracle's record bit for bit (packet scenes, BVH scenes, smooth normals, instances, analytic shapes with their own parameterisations)."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); rng = np.random.default_rng(31); n = 4000
+    pos = rng.random((n, 2)).astype(np.float32) * np.array([sc.width, sc.height], np.float32)
+    rays = gs.camera_rays(pos)                                     # camera rays ...
+    recs = gs.ray_intersect(rays)
+    sec = []                                                       # ... and rays leaving the first hits in random directions
+    for i in range(0, n, 4):
+        if recs["valid"][i]:
+            d = rng.normal(size=3); d /= np.linalg.norm(d); sec.append(np.concatenate([recs["p"][i], [1e-4], d, [np.inf]]))
+    rays = np.concatenate([rays, np.array(sec, np.float32)]); recs = gs.ray_intersect(rays)
+    nhit = 0
+    for i in range(len(rays)):
+        ok, h = orc.intersect(rays[i])
+        assert ok == bool(recs["valid"][i]), i
+        if not ok: continue
+        nhit += 1; r = recs[i]
+        mine = np.concatenate([[r["t"]], r["p"], r["ng"], r["ns"], r["s"], r["bary"], r["wi"]]).astype(np.float32)
+        ref = np.concatenate([h[0:1], h[1:4], h[4:7], h[7:10], h[10:13], h[13:15], h[15:18]]).astype(np.float32)
+        assert (bits(mine) == bits(ref)).all(), (i, mine, ref)
+        assert (bits(r["uv"]) == bits(h[21:23])).all(), (i, r["uv"], h[21:23])
+        assert int(r["instance"]) == int(h[20])
+        si = int(h[19]); first = sc.shapes[si]["first_tri"] if si < len(sc.shapes) else len(sc.idx) + (si - len(sc.shapes))
+        assert int(r["prim"]) == (first + int(h[18]) if si < len(sc.shapes) else first)
+    assert nhit > len(rays) // 3
