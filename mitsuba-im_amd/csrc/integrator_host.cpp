@@ -66,8 +66,14 @@ int MIPathTracerHIP::render(float *target, Controls controls, int threadIdx, int
         for (uint32_t k = 0; k < nRep; ++k) if (rcs[k] != MI_OK) { if (rcs[k] == MI_CANCELLED) return MI_CANCELLED; throw std::runtime_error("MIPathTracerHIP::render: " + errs[k]); }
         return MI_OK;
     };
-    auto merge = [&]() {      // replica films -> the first film; the replicas start the next submission from zero
-        for (mi_render *rr : m_replicaRenders) { check(mi_render_merge_film(m_render, rr), "MIPathTracerHIP::render"); check(mi_render_clear(rr), "MIPathTracerHIP::render"); }
+    // Every replica keeps accumulating into its OWN film over the whole render, so each pixel's samples are summed in sample order by one device, exactly as a
+    // single device would.  Previews (the responsive face's target between submissions) add the replicas' films on the host without touching them; the final
+    // film is produced once, at the end, by adding the replica films into the first one on the device (mi_render_merge_film).
+    std::vector<float> scratch;
+    auto preview = [&]() {
+        check(mi_render_read_film(m_render, 1, target), "MIPathTracerHIP::render");
+        const size_t nf = (size_t) h * w * c; scratch.resize(nf);
+        for (mi_render *rr : m_replicaRenders) { check(mi_render_read_film(rr, 1, scratch.data()), "MIPathTracerHIP::render"); for (size_t i = 0; i < nf; ++i) target[i] += scratch[i]; }
     };
     for (uint32_t s = 0; s < spp; s += chunk) {
         if (m_cancel.load()) return -1;                                        // Integrator::cancel (any thread, any time)
@@ -78,8 +84,9 @@ int MIPathTracerHIP::render(float *target, Controls controls, int threadIdx, int
         int rc = submit(s, std::min(spp, s + chunk));
         if (rc == MI_CANCELLED) return -1;
         check(rc, "MIPathTracerHIP::render");
-        if (nRep > 1) merge();
-        if (target) check(mi_render_read_film(m_render, 1, target), "MIPathTracerHIP::render");
+        const bool last = s + chunk >= spp;
+        if (last) for (mi_render *rr : m_replicaRenders) check(mi_render_merge_film(m_render, rr), "MIPathTracerHIP::render");
+        if (target) { if (last || nRep == 1) check(mi_render_read_film(m_render, 1, target), "MIPathTracerHIP::render"); else preview(); }
     }
     return m_cancel.load() ? -1 : 0;
 }
