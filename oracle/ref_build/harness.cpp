@@ -781,6 +781,63 @@ static void modeResponsive(Built &b, const FScene &fs, const std::string &plugin
     printf("responsive[%s]: rc %d, %.3f s, %zu progress calls%s%s\n", plugin.c_str(), rc, sec, in.calls.size(), st ? ", " : "", st ? st : "");
 }
 
+// Drop-in check of the CLASSIC face: Scene::render (src/librender/scene.cpp:475-479) calls Integrator::render(scene, queue, job, ...) from the RenderJob thread
+// and the integrator delivers its result with Film::put(const ImageBlock *).  CaptureFilm is a Film that keeps what it is given (HDRFilm's storage is private and
+// its develop() needs the format converter this build lacks): the mode swaps it into the sensor, runs <plugin>::render and dumps the accumulated block.
+class CaptureFilm : public Film {
+public:
+    CaptureFilm(const Properties &p) : Film(p) { }
+    void configure() { Film::configure(); m_block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, m_cropSize); m_block->setOffset(m_cropOffset); m_block->clear(); }
+    void clear() { m_block->clear(); }
+    void put(const ImageBlock *block) { m_block->put(block); ++puts; }
+    void setBitmap(const Bitmap *, Float) { }
+    void addBitmap(const Bitmap *, Float) { }
+    void setDestinationFile(const fs::pathstr &, uint32_t) { }
+    void develop(const Scene *, Float) { }
+    bool develop(const Point2i &, const Vector2i &, const Point2i &, Bitmap *) const { return false; }
+    bool destinationExists(const fs::pathstr &) const { return false; }
+    bool hasAlpha() const { return true; }
+    std::string toString() const { return "CaptureFilm[]"; }
+    ref<ImageBlock> m_block; int puts = 0;
+    MTS_DECLARE_CLASS()
+};
+MTS_IMPLEMENT_CLASS(CaptureFilm, false, Film)
+#include <mitsuba/render/renderjob.h>
+#include <mitsuba/render/renderqueue.h>
+#include <mitsuba/core/sched.h>
+static void modeClassic(Built &b, const FScene &fs, const std::string &plugin, int threads, const std::string &out) {
+    Properties fp("capture"); fp.setInteger("width", fs.W); fp.setInteger("height", fs.H);
+    if (fs.crop[0]) { fp.setInteger("width", fs.crop[0]); fp.setInteger("height", fs.crop[1]); fp.setInteger("cropOffsetX", fs.crop[2]); fp.setInteger("cropOffsetY", fs.crop[3]);
+                      fp.setInteger("cropWidth", fs.W); fp.setInteger("cropHeight", fs.H); }
+    ref<CaptureFilm> film = new CaptureFilm(fp);
+    film->addChild(b.filter); film->configure();
+    b.sensor->addChild(film); film->setParent(b.sensor); b.sensor->configure();
+    Properties p(plugin); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
+    p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
+    if (fs.sampler == 0) p.setSize("seed", (size_t) fs.seed);
+    ref<Integrator> integ = static_cast<Integrator *>(create(MTS_CLASS(Integrator), p));
+    integ->configure();
+    b.scene->setIntegrator(integ);
+    // the reference's own driver: RenderJob::run (src/librender/renderjob.cpp:66-120) registers the scene / sensor / sampler with the scheduler, then
+    // Scene::preprocess -> Scene::render -> Integrator::render -> Scene::postprocess; `path` renders through the scheduler's local workers, path_hip by itself
+    Scheduler *sched = Scheduler::getInstance();
+    for (int i = 0; i < threads; ++i) sched->registerWorker(new LocalWorker(i, "wrk" + std::to_string(i)));
+    sched->start();
+    ref<RenderQueue> queue = new RenderQueue();
+    ref<Timer> timer = new Timer();
+    ref<RenderJob> job = new RenderJob("rend", b.scene, queue, -1, -1, -1, true, false);
+    job->start();
+    queue->waitLeft(0); queue->join();
+    double sec = timer->getMicroseconds() * 1e-6;
+    bool ok = true;
+    sched->stop();
+    const Bitmap *bmp = film->m_block->getBitmap();
+    std::vector<float> data(bmp->getFloatData(), bmp->getFloatData() + (size_t) bmp->getSize().x * bmp->getSize().y * bmp->getChannelCount());
+    save(out + "_film.npy", "<f4", {(size_t) bmp->getSize().y, (size_t) bmp->getSize().x, (size_t) bmp->getChannelCount()}, data);
+    std::vector<double> meta = {ok ? 1.0 : 0.0, sec, (double) film->puts}; save(out + "_meta.npy", "<f8", {meta.size()}, meta);
+    printf("classic[%s]: render() returned %d, %.3f s, %d Film::put call(s)\n", plugin.c_str(), (int) ok, sec, film->puts);
+}
+
 // mesh loaders (src/shapes/{obj,ply,serialized,cube}.cpp over TriMesh::configure): dump every mesh the plugin creates, after configure()
 static void modeMesh(int argc, char **argv) {
     // mesh <plugin> <file|-> <out> <faceNormals> <flipNormals> <maxSmoothAngle|-1> <shapeIndex|-1> <flipTexCoords> [16 floats toWorld, row major]
@@ -879,6 +936,7 @@ int main(int argc, char **argv) {
     else if (mode == "camera") modeCamera(b, fs, argv[3]);
     else if (mode == "units") modeUnits(b, fs, argv[3]);
     else if (mode == "responsive") modeResponsive(b, fs, argv[3], atoi(argv[4]), argv[5]);
+    else if (mode == "classic") modeClassic(b, fs, argv[3], atoi(argv[4]), argv[5]);
     else { fprintf(stderr, "unknown mode\n"); _exit(1); }
     fflush(stdout);
     _exit(0);   // skip the static shutdown sequence (the process hangs in thread cleanup otherwise)

@@ -144,3 +144,26 @@ def test_host_mirror_devices_replicas(mi, golden_scenes):
         # classic face (no target, no controls): one submission per replica
         assert L.mi_host_render(h, None, None, None, CB(), None, 0, 1) == 0
         L.mi_host_destroy(h)
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
+@pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "cbox_materials"])
+def test_plugin_classic_face_through_renderjob(mi, golden_scenes, tmp_path, name):
+    """The CLASSIC interface end to end (SURVEY §8b): the reference's own RenderJob::run (src/librender/renderjob.cpp:66-120) -> Scene::preprocess -> Scene::render
+    (scene.cpp:475-479) -> Integrator::render -> Film::put drives first the reference's `path` (BlockedRenderProcess over the scheduler's local workers), then
+    `path_hip` (PathTracerHIP::render: one submission, one Film::put of the whole frame, queue->signalRefresh).  A capturing Film records what each delivers."""
+    sc = golden_scenes[name]
+    path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path)
+    films = {}
+    for plugin in ("path", "path_hip"):
+        out = str(tmp_path / plugin)
+        subprocess.run([HARNESS, path, "classic", plugin, "4", out], cwd=os.path.dirname(HARNESS), check=True, timeout=300)
+        meta = np.load(out + "_meta.npy"); films[plugin] = np.load(out + "_film.npy")
+        assert meta[0] == 1 and meta[2] >= 1                    # render() succeeded, Film::put was called
+    a, b = films["path_hip"], films["path"]
+    assert a.shape == b.shape == (sc.height, sc.width, 5)
+    ia, ib = a[1:-1, 1:-1], b[1:-1, 1:-1]                      # interior: at the film edge the classic driver's blocks also carry samples of border pixels (high-quality edges)
+    assert np.allclose(ia[..., 3:], ib[..., 3:], rtol=1e-5)    # alpha and weight sums
+    rel = np.abs(ia[..., :3] - ib[..., :3]).max(2) / (np.abs(ib[..., :3]).max(2) + 1e-6)
+    assert (rel < 1e-4).mean() > 0.99                          # the reference is a -ffast-math build: a handful of forked paths
+    assert np.linalg.norm(ia[..., :3] - ib[..., :3]) / np.linalg.norm(ib[..., :3]) < 5e-3
