@@ -166,13 +166,37 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
     } else if (cls == "Mask") {                                         // mask.cpp:92-96: opacity texture, then the nested BSDF
         std::vector<float> op = rd.texture(); const int opTex = rd.lastTexture;
         mi_material nested; memset(&nested, 0, sizeof(nested));
-        if (!readNestedInstance(rd, nested)) SLog(EError, "path_hip: the BSDF nested in `mask` is not implemented");
+        if (!readNestedInstance(rd, nested)) SLog(EError, "path_hip: the BSDF nested in `mask` is not implemented");      // (a plain BSDF, a mixturebsdf or a bumpmap / normalmap)
         if (nested.type == MI_BSDF_MASK) SLog(EError, "path_hip: a mask nested in a mask is not implemented");
         const uint32_t keepFlags = m.flags;
         memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MASK; m.flags = keepFlags; m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
         memcpy(m.reflectance, op.data(), 12); if (opTex >= 0) m.flags |= MI_BSDF_TEXTURE(opTex);
     } else if (cls == "DiffuseTransmitter") {
         std::vector<float> tr = rd.texture(); m.type = MI_BSDF_DIFFTRANS; bind(tr);
+    } else if (cls == "MixtureBSDF") {                                  // mixturebsdf.cpp:104-113: count, then (weight, BSDF) pairs; the children become records of their own
+        const size_t count = rd.ms->readSize();
+        if (count < 2 || count > 4) SLog(EError, "path_hip: a mixturebsdf with %i BSDFs is not implemented (2..4)", (int) count);
+        const uint32_t keepFlags = m.flags; memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MIXTURE; m.flags = keepFlags; m.distr = (uint32_t) count;
+        for (size_t i = 0; i < count; ++i) {
+            const float w = rd.ms->readFloat(); mi_material child; memset(&child, 0, sizeof(child));
+            if (!readNestedInstance(rd, child) || child.type >= MI_BSDF_MASK) SLog(EError, "path_hip: this BSDF inside a mixturebsdf is not implemented (plain BSDFs, optionally twosided)");
+            const float idx = (float) g_materials->size(); g_materials->push_back(child);
+            if (i < 3) { m.reflectance[i] = idx; m.k[i] = w; } else { m.eta[0] = idx; m.specular[0] = w; }
+        }
+    } else if (cls == "BumpMap" || cls == "NormalMap") {                // bumpmap.cpp:104-109 / normalmap.cpp:75-80: the nested BSDF, then the displacement / normal texture
+        mi_material nested; memset(&nested, 0, sizeof(nested));
+        if (!readNestedInstance(rd, nested) || nested.type == MI_BSDF_MASK || nested.type == MI_BSDF_BUMPMAP || nested.type == MI_BSDF_NORMALMAP) SLog(EError, "path_hip: the BSDF nested in `%s` is not implemented", cls.c_str());
+        const uint32_t keepFlags = m.flags; memset(&m, 0, sizeof(m)); m.type = cls == "BumpMap" ? MI_BSDF_BUMPMAP : MI_BSDF_NORMALMAP; m.flags = keepFlags; m.alpha = 1.0f;
+        m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
+        // the map: a 2-D texture, for the bump map optionally inside one <texture type="scale"> (src/textures/scale.cpp:153-157: nested texture, then the factor)
+        const size_t at = rd.ms->getPos(); const uint32_t id = rd.ms->readUInt(); const std::string tcls = id ? rd.ms->readString() : std::string();
+        if (tcls == "ScaleTexture" && m.type == MI_BSDF_BUMPMAP) {
+            rd.texture(); float sc3[3]; rd.rgb(sc3);
+            if (sc3[0] != sc3[1] || sc3[0] != sc3[2]) SLog(EError, "path_hip: a coloured `scale` around a bump map is not implemented");
+            m.alpha = sc3[0];
+        } else { rd.ms->seek(at); rd.texture(); }
+        if (rd.lastTexture < 0) SLog(EError, "path_hip: the map of a `%s` must be a checkerboard, gridtexture or bitmap texture", cls.c_str());
+        m.flags |= MI_BSDF_TEXTURE(rd.lastTexture);
     } else return false;
     return true;
 }
@@ -214,9 +238,9 @@ static bool convertSpatiallyVarying(const BSDF *bsdf, mi_material &m) {
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
     if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
-    if (bsdf->getClass()->getName() == "Mask") {                       // nested BSDF and opacity are private: serialised form
+    if (bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
         if (convertSpatiallyVarying(bsdf, m)) return m;
-        SLog(EError, "path_hip: this `mask` is not implemented");
+        SLog(EError, "path_hip: this `%s` is not implemented", bsdf->getClass()->getName().c_str());
     }
     if ((bsdf->getType() & BSDF::ESpatiallyVarying) && bsdf->getClass()->getName() != "TwoSidedBRDF") {      // textures are private members: never fall through to the Properties (constants only)
         if (convertSpatiallyVarying(bsdf, m)) return m;
