@@ -738,7 +738,7 @@ def normal_map_image(w=64, h=48):
     return np.ascontiguousarray((0.5 + 0.5 * n).astype(f32))
 
 
-def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, strict_normals=False):
+def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, strict_normals=False, procedural_maps=False):
     """The textured room with the three BSDF adapters of SURVEY §8 f2: `bumpmap` floor (bitmap displacement under a `scale` texture, bilinear gradient),
     `normalmap` wall over a twosided rough conductor, a `mixturebsdf` mound (plastic + diffuse), a twosided three-way mixture whose weights sum to
     1.4 (rescaled by the BSDF), a bump-mapped mixture (grid displacement: finite-difference gradient) and a mask over a bump-mapped diffuse."""
@@ -748,6 +748,9 @@ def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6
            make_texture(TEXTURE_BITMAP, pyramid=dict(base=nimg, levels=build_mip_pyramid(nimg, WRAP_REPEAT, WRAP_REPEAT)), uscale=1.5, vscale=1.0, filter_type=MIP_BILINEAR),
            make_texture(TEXTURE_CHECKERBOARD, (0.75, 0.7, 0.2), (0.15, 0.25, 0.6), uscale=4.0, vscale=4.0),
            make_texture(TEXTURE_GRID, (0.9, 0.9, 0.9), (0.1, 0.1, 0.1), line_width=0.08, uscale=3.0, vscale=3.0)]
+    if procedural_maps:      # the same adapters over procedural maps only (a reference build without image codecs cannot serialise bitmap textures for the plugin adapter)
+        tex[0] = make_texture(TEXTURE_GRID, (0.8, 0.8, 0.8), (0.2, 0.2, 0.2), line_width=0.11, uscale=5.0, vscale=4.0, uoffset=0.05)
+        tex[1] = make_texture(TEXTURE_CHECKERBOARD, (0.5, 0.5, 1.0), (0.64, 0.42, 0.9), uscale=5.0, vscale=3.0)
     B = []
     def add(**kw): B.append(make_bsdf(**kw)); return len(B) - 1
     m0 = add(reflectance=(0.6, 0.6, 0.6))

@@ -96,6 +96,7 @@ def golden_scenes():
         # the BSDF adapters: bumpmap (bitmap displacement under a scale texture; grid displacement by finite differences), normalmap, mixturebsdf (2 and 3 children,
         # weights rescaled, twosided), bumpmap(mixture), mask(bumpmap)
         "layered_room": scenes.layered_room(width=96, height=64, spp=16),
+        "layered_room_procedural": scenes.layered_room(width=96, height=64, spp=16, procedural_maps=True),
         "layered_room_strict_indep": scenes.layered_room(width=96, height=64, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=13, strict_normals=True, rr_depth=2),
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
@@ -199,7 +200,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room"):
+        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", "path", -1, base + "_resp")

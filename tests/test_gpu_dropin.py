@@ -63,12 +63,12 @@ def test_plugin_drop_in_analytic_shapes(mi, golden_scenes, tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
-@pytest.mark.parametrize("name", ["cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room"])
+@pytest.mark.parametrize("name", ["cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room_procedural"])
 def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
     """Same driver; live PointEmitter / SpotEmitter / DirectionalEmitter / ConstantBackgroundEmitter objects, and (cbox_materials) SmoothDielectric /
     SmoothConductor / SmoothPlastic BSDFs, flattened from their Properties; twosided(conductor) and (veach_small, BASELINE config 3 at test size)
     twosided(roughconductor) wrappers are read through their serialised form.  sky_view: EnvironmentMap whose MIP pyramid the adapter rebuilds with the
-    reference's own TMIPMap for the filtered camera-ray lookups.  layered_room: live MixtureBSDF / BumpMap (inside a ScaleTexture) / NormalMap objects, incl.
+    reference's own TMIPMap for the filtered camera-ray lookups.  layered_room_procedural: live MixtureBSDF / BumpMap (inside a ScaleTexture) / NormalMap objects, incl.
     bumpmap(mixture) and mask(bumpmap), flattened from their serialised forms."""
     sc = golden_scenes[name]
     path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path); out = str(tmp_path / "hip")

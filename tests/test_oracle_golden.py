@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep", "layered_room_procedural"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -128,7 +128,7 @@ STRICT_BIT_EXACT = ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_
 STRICT_OTHERS = ["closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep", "cbox_materials",
                  "cbox_materials_strict_indep", "instanced_garden", "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "sky_view", "sky_view_indep", "veach_microfacets",
                  "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room",
-                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals", "layered_room", "layered_room_strict_indep"]
+                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals", "layered_room", "layered_room_strict_indep", "layered_room_procedural"]
 
 
 @pytest.mark.parametrize("name", STRICT_BIT_EXACT + STRICT_OTHERS)
