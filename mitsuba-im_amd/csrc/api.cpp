@@ -326,7 +326,7 @@ int SceneHost::upload(int dev) {
         d.env_pixel_w = 2 * MI_PI / (float) envW; d.env_pixel_h = MI_PI / (float) envH; d.env_bs_radius = envBsRadius;
         memcpy(d.env_to_world, envToWorld3, 36); memcpy(d.env_to_local, envToLocal3, 36); memcpy(d.env_bs_center, envBsCenter, 12);
     }
-    d.bvh_depth = (uint32_t) bvhDepth;
+    d.bvh_depth = (uint32_t) bvhDepth; d.bvh_wide = wideBvh ? 1u : 0u;
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
@@ -396,6 +396,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     ensureSobolTables();
     s->h.commitHost();
     if (s->h.bvhDepth > 32) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: BVH deeper than the traversal stack (32)");
+    if (s->h.wideBvh && s->h.nodes.size() >= (1u << 23)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: more than 2^23 BVH nodes");
     if (getenv("MI355PT_VERBOSE")) fprintf(stderr, "[mi355pt] %zu triangles, %zu analytic shapes, %zu instances, %zu BVH nodes, depth %d\n", s->h.idx.size() / 3, s->h.analytic.size(), s->h.instances.size(), s->h.nodes.size(), s->h.bvhDepth);
     int devCount = 0; HIPCHK(hipGetDeviceCount(&devCount));
     if ((int) device >= devCount) return fail(MI_ERR_DEVICE, "mi_scene_commit: no such HIP device");

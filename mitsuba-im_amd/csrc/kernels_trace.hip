@@ -4,7 +4,7 @@
 
 // ---------------------------------------------------------------------------------------------- extend
 // Scene::rayIntersect -> ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:112-142): closest hit (t, u, v, prim)
-template <int STACK, int AN>   // STACK = 0: packet mode; else LDS stack entries per lane (>= BVH depth); AN: bit 0 analytic shapes, bit 1 instances
+template <int STACK, int AN, bool WIDE>   // STACK = 0: packet mode; else LDS stack entries per lane (>= the tree's stack need); AN: bit 0 analytic shapes, bit 1 instances; WIDE: 4-wide quantised nodes
 __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     __shared__ f4 s_exact[STACK > 0 ? 1 : MI_PACKET_MAX * 3];
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
         float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
         if (clipInterval(sc, o, d, ro.w, rd.w, false, mint, maxt)) {
             if (STACK == 0) hit = packetIntersect<false, AN>(sc, (AS<true>::p4) s_exact, o, d, mint, maxt, t, prim, u, v);
-            else hit = traverse<false, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
+            else hit = traverse<false, AN, WIDE>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
         }
         q.hit[segBase + i] = make_float4(t, u, v, __uint_as_float(hit ? prim : 0xFFFFFFFFu));
         if ((AN & 2) && q.hitInst) q.hitInst[segBase + i] = inst;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(WG) void k_extend(DScene sc, Queues q, int buf) {
 // ---------------------------------------------------------------------------------------------- shadow
 // Visibility test of Scene::sampleEmitterDirect (src/librender/scene.cpp:871-875 -> skdtree.cpp:207-226, any hit) and the
 // deferred `Li += throughput * value * bsdfVal * weight` (path.cpp:196)
-template <int STACK, int AN>
+template <int STACK, int AN, bool WIDE>
 __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
     __shared__ int s_stk[(STACK > 0 ? STACK : 1) * WG];
     __shared__ f4 s_exact[STACK > 0 ? 1 : MI_PACKET_MAX * 3];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
         float mint, maxt, t, u, v; uint32_t prim; bool occluded = false; int inst;
         if (clipInterval(sc, o, d, MI_EPSILON, so.w, true, mint, maxt)) {
             if (STACK == 0) occluded = packetIntersect<true, AN>(sc, (AS<true>::p4) s_exact, o, d, mint, maxt, t, prim, u, v);
-            else occluded = traverse<true, AN>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
+            else occluded = traverse<true, AN, WIDE>(sc, o, d, mint, maxt, s_stk + tid, t, prim, u, v, inst);
         }
         if (!occluded) {
             float4 c = q.shC[segBase + i]; const uint32_t pid = __float_as_uint(sd.w);
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
     if (clipInterval(sc, o, d, r[3], r[7], anyHit != 0, mint, maxt)) {
         if (sc.packet_n) { if (anyHit) hit = packetIntersect<true, 1>(sc, (AS<true>::p4) s_exact, o, d, mint, maxt, t, prim, u, v); else hit = packetIntersect<false, 1>(sc, (AS<true>::p4) s_exact, o, d, mint, maxt, t, prim, u, v); }
-        else if (anyHit) hit = traverse<true, 3>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
-        else hit = traverse<false, 3>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        else if (sc.bvh_wide) { if (anyHit) hit = traverse<true, 3, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst); else hit = traverse<false, 3, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst); }
+        else if (anyHit) hit = traverse<true, 3, false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        else hit = traverse<false, 3, false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
     }
     if (outInst) outInst[i] = hit ? inst : -1;
     out[i * 4] = t; out[i * 4 + 1] = u; out[i * 4 + 2] = v; out[i * 4 + 3] = hit ? (anyHit ? 1.0f : (float) prim) : -1.0f;
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(WG) void k_ray_intersect(DScene sc, const float *ra
     float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0xFFFFFFFFu; bool hit = false; int inst = -1;
     if (clipInterval(sc, o, d, r[3], r[7], false, mint, maxt)) {
         if (sc.packet_n) hit = packetIntersect<false, 1>(sc, (AS<true>::p4) s_exact, o, d, mint, maxt, t, prim, u, v);
-        else hit = traverse<false, 3>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        else if (sc.bvh_wide) hit = traverse<false, 3, true>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
+        else hit = traverse<false, 3, false>(sc, o, d, mint, maxt, s_stk + threadIdx.x, t, prim, u, v, inst);
     }
     mi_intersection rec; memset(&rec, 0, sizeof(rec)); rec.valid = hit ? 1u : 0u; rec.prim = 0xFFFFFFFFu; rec.instance = -1; rec.material = -1; rec.emitter = -1;
     if (hit) {
@@ -113,15 +115,18 @@ __global__ __launch_bounds__(WG) void k_ray_intersect(DScene sc, const float *ra
 // ---------------------------------------------------------------------------------------------- launch wrappers (used by api.cpp)
 extern "C" {
 static const bool kForceStack24 = getenv("MI355PT_STACK24") != nullptr;      // A/B switch, read once
+#define MI_BY_STACK_W(KERNEL, AN, W, ...) do { \
+    if (sc.bvh_depth <= 8) hipLaunchKernelGGL((KERNEL<8, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 12) hipLaunchKernelGGL((KERNEL<12, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((KERNEL<16, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 20 && !kForceStack24) hipLaunchKernelGGL((KERNEL<20, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 24) hipLaunchKernelGGL((KERNEL<24, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_depth <= 28) hipLaunchKernelGGL((KERNEL<28, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN, W>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
 #define MI_BY_STACK(KERNEL, AN, ...) do { \
-    if (sc.packet_n) hipLaunchKernelGGL((KERNEL<0, (AN) & 1>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 8) hipLaunchKernelGGL((KERNEL<8, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 12) hipLaunchKernelGGL((KERNEL<12, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 16) hipLaunchKernelGGL((KERNEL<16, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 20 && !kForceStack24) hipLaunchKernelGGL((KERNEL<20, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 24) hipLaunchKernelGGL((KERNEL<24, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else if (sc.bvh_depth <= 28) hipLaunchKernelGGL((KERNEL<28, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<STACK_DEPTH, AN>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); } while (0)
+    if (sc.packet_n) hipLaunchKernelGGL((KERNEL<0, (AN) & 1, false>), dim3(grid), dim3(WG), 0, st, __VA_ARGS__); \
+    else if (sc.bvh_wide) MI_BY_STACK_W(KERNEL, AN, true, __VA_ARGS__); \
+    else MI_BY_STACK_W(KERNEL, AN, false, __VA_ARGS__); } while (0)
 void mi_launch_extend(const DScene &sc, const Queues &q, int buf, uint32_t grid, hipStream_t st) {
     const int mode = (sc.n_analytic ? 1 : 0) | (sc.n_instances ? 2 : 0);
     if (mode == 3) MI_BY_STACK(k_extend, 3, sc, q, buf); else if (mode == 2) MI_BY_STACK(k_extend, 2, sc, q, buf); else if (mode == 1) MI_BY_STACK(k_extend, 1, sc, q, buf); else MI_BY_STACK(k_extend, 0, sc, q, buf);
@@ -131,6 +136,7 @@ void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStrea
     if (mode == 3) MI_BY_STACK(k_shadow, 3, sc, q); else if (mode == 2) MI_BY_STACK(k_shadow, 2, sc, q); else if (mode == 1) MI_BY_STACK(k_shadow, 1, sc, q); else MI_BY_STACK(k_shadow, 0, sc, q);
 }
 #undef MI_BY_STACK
+#undef MI_BY_STACK_W
 void mi_launch_ray_intersect(const DScene &sc, const float *rays, uint64_t n, mi_intersection *out, hipStream_t st) { hipLaunchKernelGGL(k_ray_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, out); }
 void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out, outInst); }
 }

@@ -38,6 +38,15 @@ struct BvhNode {
     float hi1[3]; int32_t pad1;
 };
 
+// 4-wide node with quantised child boxes, 64 B (same size and array as BvhNode): child box c = org + q * 2^(e - 127) per axis, q in 0..255 (lo rounded down,
+// hi rounded up: the boxes only grow).  child: >= 0 inner node index, < 0 leaf code as in BvhNode; an unused slot has an inverted box (lo 255, hi 0).
+struct Bvh4Node {
+    float org[3]; uint32_t exps;          // exps: biased exponents of the x / y / z quantisation step in bytes 0 / 1 / 2
+    uint32_t qlo[3], qhi[3];              // per axis: the four children's bytes, child c in bits 8c..8c+7
+    uint32_t pad[2];
+    int32_t child[4];
+};
+
 // Per-triangle shading record in ORIGINAL triangle order, 96 B = six 16-B loads.
 // ng/s/t are the face frame (used as-is by face-normal meshes; recomputed at run time for smooth meshes).
 struct TriShade {
@@ -126,7 +135,7 @@ struct DScene {
     uint32_t sobol_dims, log_res; float resolution;
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
-    uint32_t packet_n, bvh_depth;
+    uint32_t packet_n, bvh_depth, bvh_wide;   // bvh_depth: traversal stack entries the tree(s) can need; bvh_wide: the node array holds Bvh4Node records
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
     // triangles dropped), exact Wald records in ORIGINAL triangle order for pass 2, largest |coordinate| of the scene box (error-margin scale)
     const struct PacketGroupD *packet_groups; const TriAccelD *packet_exact; uint32_t packet_gk[3]; float packet_scale;

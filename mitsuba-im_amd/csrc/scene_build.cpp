@@ -10,6 +10,7 @@
 #include "scene_host.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -157,6 +158,7 @@ struct Builder {
 };
 
 static inline int32_t leafCode(int first, int count) { return ~(int32_t) (first * 8 + (count - 1)); }
+#define BVH_EMPTY_CHILD 0x7FFFFFFD      // unused slot of a 4-wide node (its box is inverted, so it is never taken)
 
 void SceneHost::commitHost() {
     const uint32_t nt = (uint32_t) (idx.size() / 3), na = (uint32_t) analytic.size(), ni = (uint32_t) instances.size(), np = nt + na + ni;
@@ -281,11 +283,60 @@ void SceneHost::commitHost() {
     nodes.clear(); tris.clear();
     std::vector<int> depthOf;     // depth of each emitted tree
     // builds the tree over `prims`, appends its nodes / leaf records, returns the device index of its root (always an inner node)
+    { const char *e2 = getenv("MI355PT_BVH2"); wideBvh = !(e2 && e2[0] == '1'); }
+    std::vector<int> treeNeed;    // traversal stack entries each emitted tree can need
     auto emitTree = [&](const std::vector<uint32_t> &prims) -> int {
         Builder bld; bld.order = prims; bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.single = &single; bld.nodes.reserve(2 * prims.size() + 2);
         const int nodeBase = (int) nodes.size(), triBase = (int) tris.size();
         int root = prims.empty() ? -1 : bld.build(0, (int) prims.size(), 0);
         for (uint32_t i = 0; i < prims.size(); ++i) tris.push_back(accel[bld.order[i]]);
+        if (wideBvh) {
+            // Collapse the binary tree into 4-wide nodes (the inner child with the largest surface area is replaced by its two children until four slots are
+            // taken), quantise the child boxes against the node's own box.  Returns the device index; `need` = stack entries from this node down.
+            static_assert(sizeof(Bvh4Node) == sizeof(BvhNode), "both node kinds share one array");
+            auto area = [](const BuildNode &n) { V3 e = n.hi - n.lo; return e.x * e.y + e.y * e.z + e.z * e.x; };
+            struct Emit { std::vector<BvhNode> &nodes; Builder &bld; int triBase; decltype(area) &areaOf;
+                int run(int id, int &need) {
+                    std::vector<int> kids;
+                    if (id < 0) { /* empty tree */ } else if (bld.nodes[id].count > 0) kids.push_back(id); else { kids.push_back(bld.nodes[id].left); kids.push_back(bld.nodes[id].right); }
+                    while (kids.size() < 4) {
+                        int pick = -1; float best = -1;
+                        for (size_t i = 0; i < kids.size(); ++i) if (bld.nodes[kids[i]].count == 0 && areaOf(bld.nodes[kids[i]]) > best) { best = areaOf(bld.nodes[kids[i]]); pick = (int) i; }
+                        if (pick < 0) break;
+                        const int k = kids[pick]; kids[pick] = bld.nodes[k].left; kids.insert(kids.begin() + pick + 1, bld.nodes[k].right);
+                    }
+                    const int dev = (int) nodes.size(); nodes.emplace_back();
+                    const float inf = std::numeric_limits<float>::infinity(); V3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf);
+                    for (int k : kids) { lo = vmin(lo, bld.nodes[k].lo); hi = vmax(hi, bld.nodes[k].hi); }
+                    if (kids.empty()) { lo = mk(0, 0, 0); hi = mk(0, 0, 0); }
+                    Bvh4Node w; std::memset(&w, 0, sizeof(w)); w.org[0] = lo.x; w.org[1] = lo.y; w.org[2] = lo.z;
+                    int ex[3];
+                    for (int a = 0; a < 3; ++a) {      // step 2^e with 255 steps covering the extent (+ one step of slack for the rounding of org + q * step)
+                        const float ext = comp(hi, a) - comp(lo, a); int e = 0; std::frexp(ext > 0 ? ext / 254.0f : 1e-30f, &e);      // ext / 254 = m 2^e, m in [0.5, 1): 2^e >= ext / 254
+                        e = std::min(std::max(e + 127, 1), 254); ex[a] = e; w.exps |= (uint32_t) e << (8 * a);
+                    }
+                    int sub = 0;
+                    for (int c = 0; c < 4; ++c) {
+                        if (c >= (int) kids.size()) { for (int a = 0; a < 3; ++a) { w.qlo[a] |= 255u << (8 * c); } w.child[c] = BVH_EMPTY_CHILD; continue; }
+                        const BuildNode &k = bld.nodes[kids[c]];
+                        for (int a = 0; a < 3; ++a) {
+                            const double step = std::ldexp(1.0, ex[a] - 127), o = comp(lo, a);
+                            int ql = (int) std::floor(((double) comp(k.lo, a) - o) / step), qh = (int) std::ceil(((double) comp(k.hi, a) - o) / step);
+                            ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
+                            while (ql > 0 && (float) ((float) o + (float) ql * (float) step) > comp(k.lo, a)) --ql;          // the float reconstruction must enclose the child box
+                            while (qh < 255 && (float) ((float) o + (float) qh * (float) step) < comp(k.hi, a)) ++qh;
+                            w.qlo[a] |= (uint32_t) ql << (8 * c); w.qhi[a] |= (uint32_t) qh << (8 * c);
+                        }
+                        if (k.count > 0) w.child[c] = leafCode(triBase + k.first, k.count);
+                        else { int need = 0; w.child[c] = run(kids[c], need); sub = std::max(sub, need); }
+                    }
+                    std::memcpy(&nodes[dev], &w, sizeof(w));
+                    need = sub + (kids.size() > 1 ? 1 : 0);      // one stack entry per level: the node's pending children (trace.h)
+                    return dev;
+                } };
+            Emit em{nodes, bld, triBase, area}; int need = 0; const int dev = em.run(root, need); treeNeed.push_back(need + 1);
+            (void) nodeBase; return dev;
+        }
         std::vector<int> devIndex(bld.nodes.size(), -1); int nInner = 0;
         for (size_t i = 0; i < bld.nodes.size(); ++i) if (bld.nodes[i].count == 0) devIndex[i] = nodeBase + nInner++;
         auto childCode = [&](int c) { const BuildNode &n = bld.nodes[c]; return n.count > 0 ? leafCode(triBase + n.first, n.count) : (int32_t) devIndex[c]; };
@@ -311,9 +362,14 @@ void SceneHost::commitHost() {
     for (uint32_t g = 0; g < ng; ++g) groupRoot[g] = emitTree(members[g]);
     for (uint32_t i = 0; i < ni; ++i) instancesD[i].root = groupRoot[instances[i].group];
     // traversal stack need: scene tree + one return marker + the deepest group tree
-    struct Depth { const std::vector<BvhNode> &n; int of(int i) const { if (i < 0) return 0; int a = of(n[i].c0), b = of(n[i].c1); return 1 + (a > b ? a : b); } } dep{nodes};
-    int groupDepth = 0; for (uint32_t g = 0; g < ng; ++g) groupDepth = std::max(groupDepth, dep.of(groupRoot[g]));
-    bvhDepth = dep.of(0) + (ni ? 1 + groupDepth : 0);
+    if (wideBvh) {      // treeNeed[0]: the scene level, then one entry per group
+        int groupNeed = 0; for (uint32_t g = 0; g < ng; ++g) groupNeed = std::max(groupNeed, treeNeed[1 + g]);
+        bvhDepth = treeNeed[0] + (ni ? 1 + groupNeed : 0);
+    } else {
+        struct Depth { const std::vector<BvhNode> &n; int of(int i) const { if (i < 0) return 0; int a = of(n[i].c0), b = of(n[i].c1); return 1 + (a > b ? a : b); } } dep{nodes};
+        int groupDepth = 0; for (uint32_t g = 0; g < ng; ++g) groupDepth = std::max(groupDepth, dep.of(groupRoot[g]));
+        bvhDepth = dep.of(0) + (ni ? 1 + groupDepth : 0);
+    }
     // packet mode (no instances, <= MI_PACKET_MAX triangles): exact records in original order + pass-1 group records (pt_types.h PacketGroupD).  Coplanar
     // pairs that form a parallelogram (the two halves of a quad) share one record: for the vertices (X, Y, Z) of a triangle, taken cyclically, the partner is
     // the triangle on {Y, Z, Y + Z - X}.  Degenerate triangles (k = 3) never hit and are dropped.

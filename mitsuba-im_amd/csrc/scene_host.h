@@ -17,6 +17,7 @@ struct SceneHost {
     // derived on the host (scene_build.cpp)
     std::vector<uint32_t> triShape, i2; std::vector<TriAccelD> tris; std::vector<TriShade> shade; std::vector<BvhNode> nodes;
     std::vector<TriUV> triuv; bool anyUV = false;   // per-triangle uv + UV tangents (only when some mesh has texcoords)
+    bool wideBvh = true;   // 4-wide quantised nodes (default) or the binary tree (MI355PT_BVH2=1)
     std::vector<InstanceD> instancesD; int bvhDepth = 0;   // stack entries the traversal needs (scene tree + return marker + deepest group tree)
     std::vector<AnalyticD> analyticD; uint32_t nTris = 0;   // analytic shapes: primitive index nTris + i; `tris` (BVH leaf order) holds a k = MI_K_ANALYTIC record for each
     std::vector<TriAccelD> packetExact;   // Wald records in ORIGINAL triangle order (packet mode, <= MI_PACKET_MAX triangles): pass 2 of trace.h

@@ -43,7 +43,11 @@ DEV float safeInv(float d) { float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) 
 // Instance::rayIntersect (src/shapes/instance.cpp:91-108): the ray is taken to the group's object space (direction NOT renormalised, so t keeps
 // its meaning), [mint, maxt] is clipped against the group's kd-tree box (skdtree.h:431-452), then the group's own BVH -- stored in the same
 // node array -- is walked with the same stack; a marker entry brings the walk back to the scene level.  Instances sit alone in their leaves.
-template <bool ANY, int AN>        // AN bit 0: analytic shapes present, bit 1: instances present (each kernel variant carries only the code it needs)
+// WIDE: 4-wide nodes with child boxes quantised to 8 bits per coordinate (pt_types.h Bvh4Node, 64 B like a BVH2 node): one node fetch decides four descents,
+// the tree is half as deep -- the incoherent traversal of a large scene is bound by node traffic from L2 / Infinity Cache, and this halves it.  Children that
+// are hit are visited nearest first (a 5-comparator sorting network on (entry distance | slot) keys); the quantised boxes only ever grow, so the exact
+// triangle tests below see every triangle they saw before.
+template <bool ANY, int AN, bool WIDE>        // AN bit 0: analytic shapes present, bit 1: instances present (each kernel variant carries only the code it needs)
 DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk,
                   float &bestT, uint32_t &bestPrim, float &bestU, float &bestV, int &bestInst) {
     v3 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z));
@@ -55,13 +59,55 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
     const f4 *tris4 = reinterpret_cast<const f4 *>(sc.tris);
     float best = maxt; uint32_t bprim = 0xFFFFFFFFu; bool found = false; float bu = 0, bv = 0;
     int sp = 0; int cur = 0;
+    // BVH2: a stack entry is a child code.  WIDE: an entry stands for the children of ONE node that are still to be visited -- node index in bits 0..22, their
+    // slot numbers (nearest first, 2 bits each) in bits 23..28, how many beyond the first in bits 29..30 -- so the stack never holds more than one entry per
+    // tree level; popping re-reads the node's child pointers (16 B).  The markers BVH_DONE / BVH_RET carry 3 in bits 29..30, which no entry does.
 #define BVH_POP() do { \
         if (sp > 0) { --sp; cur = stk[sp * WG]; \
             if ((AN & 2) && cur == BVH_RET) { o = o0; d = d0; mint = mint0; cap = INFINITY; curInst = -1; \
                 inv = V(safeInv(d.x), safeInv(d.y), safeInv(d.z)); oi = V(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z); \
                 if (sp > 0) { --sp; cur = stk[sp * WG]; } else cur = BVH_DONE; } \
+            if (WIDE && cur != BVH_DONE) { \
+                const uint32_t e_ = (uint32_t) cur, node_ = e_ & 0x7FFFFFu, slots_ = (e_ >> 23) & 0x3Fu, more_ = (e_ >> 29) & 3u; \
+                if (more_) { stk[sp * WG] = (int) (node_ | ((slots_ >> 2) << 23) | ((more_ - 1u) << 29)); ++sp; } \
+                const f4 ch_ = nodes4[node_ * 4u + 3u]; const uint32_t sl_ = slots_ & 3u; \
+                cur = __float_as_int(sl_ == 0u ? ch_.x : (sl_ == 1u ? ch_.y : (sl_ == 2u ? ch_.z : ch_.w))); } \
         } else cur = BVH_DONE; } while (0)
     while (true) {
+        if (WIDE) {
+            while (cur >= 0 && cur != BVH_DONE) {
+                const f4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
+                const uint32_t ex = __float_as_uint(n0.w);
+                const float sx = __uint_as_float((ex & 0xFFu) << 23), sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23), sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
+                // plane distance t = (org + q s - o) inv = q (s inv) + (org inv - o inv)
+                const float bx = sx * inv.x, by = sy * inv.y, bz = sz * inv.z;
+                const float ax = __builtin_fmaf(n0.x, inv.x, oi.x), ay = __builtin_fmaf(n0.y, inv.y, oi.y), az = __builtin_fmaf(n0.z, inv.z, oi.z);
+                const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z), hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
+                const uint32_t nxq = inv.x >= 0 ? lx : hx, fxq = inv.x >= 0 ? hx : lx, nyq = inv.y >= 0 ? ly : hy, fyq = inv.y >= 0 ? hy : ly, nzq = inv.z >= 0 ? lz : hz, fzq = inv.z >= 0 ? hz : lz;
+                const float far = (AN & 2) ? fminf(best, cap) : best;
+                uint32_t key[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float tn = fmaxf(fmaxf(__builtin_fmaf((float) ((nxq >> (8 * c)) & 0xFFu), bx, ax), __builtin_fmaf((float) ((nyq >> (8 * c)) & 0xFFu), by, ay)),
+                                           fmaxf(__builtin_fmaf((float) ((nzq >> (8 * c)) & 0xFFu), bz, az), mint));
+                    const float tf = fminf(fminf(__builtin_fmaf((float) ((fxq >> (8 * c)) & 0xFFu), bx, ax), __builtin_fmaf((float) ((fyq >> (8 * c)) & 0xFFu), by, ay)),
+                                           fminf(__builtin_fmaf((float) ((fzq >> (8 * c)) & 0xFFu), bz, az), far));
+                    key[c] = (tn <= tf * 1.000002f + 1e-30f) ? ((__float_as_uint(tn) & ~3u) | (uint32_t) c) : 0xFFFFFFFFu;      // tn >= mint > 0: its bit pattern orders like the value
+                }
+                {   // ascending (misses last): (0,1) (2,3) (0,2) (1,3) (1,2)
+                    uint32_t a = min(key[0], key[1]), b = max(key[0], key[1]), c = min(key[2], key[3]), e = max(key[2], key[3]);
+                    key[0] = min(a, c); const uint32_t m1 = max(a, c), m2 = min(b, e); key[3] = max(b, e); key[1] = min(m1, m2); key[2] = max(m1, m2);
+                }
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y), c2 = __float_as_int(n3.z), c3 = __float_as_int(n3.w);
+                auto childOf = [&](uint32_t k) { const uint32_t sl = k & 3u; return sl == 0u ? c0 : (sl == 1u ? c1 : (sl == 2u ? c2 : c3)); };
+                if (key[0] == 0xFFFFFFFFu) BVH_POP();
+                else {
+                    const uint32_t more = (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
+                    if (more) { stk[sp * WG] = (int) ((uint32_t) cur | ((key[1] & 3u) << 23) | ((key[2] & 3u) << 25) | ((key[3] & 3u) << 27) | ((more - 1u) << 29)); ++sp; }
+                    cur = childOf(key[0]);
+                }
+            }
+        } else
         while (cur >= 0 && cur != BVH_DONE) {
             f4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
             int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
