@@ -190,7 +190,7 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
         // the map: a 2-D texture, for the bump map optionally inside one <texture type="scale"> (src/textures/scale.cpp:153-157: nested texture, then the factor)
         const size_t at = rd.ms->getPos(); const uint32_t id = rd.ms->readUInt(); const std::string tcls = id ? rd.ms->readString() : std::string();
-        if (tcls == "ScaleTexture" && m.type == MI_BSDF_BUMPMAP) {
+        if (tcls == "ScalingTexture" && m.type == MI_BSDF_BUMPMAP) {
             rd.texture(); float sc3[3]; rd.rgb(sc3);
             if (sc3[0] != sc3[1] || sc3[0] != sc3[2]) SLog(EError, "path_hip: a coloured `scale` around a bump map is not implemented");
             m.alpha = sc3[0];
