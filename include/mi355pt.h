@@ -118,9 +118,8 @@ typedef struct {
     uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
     uint32_t opacity;            /* 1: alpha = 1 where the camera ray hits a surface, else 0 (RadianceQueryRecord::EOpacity, records.inl:121-137:
                                     the responsive drivers and films with an alpha channel); 0: alpha = 1 (classic film without alpha, integrator.cpp:160-161) */
-    uint32_t fast_math;          /* 0: strict IEEE kernels (no contraction, exact divide/sqrt): radiance bit-identical to the oracle;
-                                    1: the same kernels compiled with fused multiply-adds and approximate divide/sqrt (the reference's own
-                                    build is -ffast-math): results agree within float rounding, rare path forks aside */
+    uint32_t reserved0;          /* must be 0 (round 1: fast_math; one set of kernels ships -- strict IEEE arithmetic, no contraction, exact divide / sqrt,
+                                    radiance bit-identical to the oracle and to a strict-IEEE build of the reference; anything else: MI_ERR_UNSUPPORTED) */
 } mi_render_params;
 
 typedef struct { uint32_t x0, y0, x1, y1; } mi_tile;   /* pixel rectangle [x0,x1) x [y0,y1) in GLOBAL film coordinates */
@@ -167,7 +166,7 @@ int mi_scene_set_envmap(mi_scene *s, const float *rgb, uint32_t w, uint32_t h, c
 int mi_scene_set_envmap_filter(mi_scene *s, int32_t texture);
 /* PerspectiveCameraImpl: m_sampleToCamera, world transform, clip planes (src/sensors/perspective.cpp:126-178) */
 int mi_scene_set_camera(mi_scene *s, const float *sample_to_camera16, const float *to_world16, float near_clip, float far_clip);
-/* Film crop size + reconstruction filter (src/librender/film.cpp:92; src/rfilters/*.cpp): kind 0 box(radius), 1 gaussian(stddev), 2 tent,
+/* Film crop size + reconstruction filter (src/librender/film.cpp:92; src/rfilters/<name>.cpp): kind 0 box(radius), 1 gaussian(stddev), 2 tent,
  * 3 mitchell (B in `radius`, C in `stddev`), 4 catmullrom, 5 lanczos (lobes in `radius`) */
 int mi_scene_set_film(mi_scene *s, uint32_t width, uint32_t height, uint32_t filter_kind, float radius, float stddev);
 int mi_scene_commit(mi_scene *s, uint32_t device);   /* BVH build + TriAccel table + upload */

@@ -49,7 +49,7 @@ class MiInstance(C.Structure):
 
 class MiRenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
-                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("fast_math", C.c_uint32)]
+                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class MiTile(C.Structure):
@@ -255,13 +255,13 @@ class Render:
     """mi_render handle: the integrator instance (MonteCarloIntegrator properties + sampler)."""
 
     def __init__(self, scene, max_depth=None, rr_depth=None, sampler=None, spp=None, seed=None, device=0, planes_per_batch=0,
-                 strict_normals=None, hide_emitters=None, opacity=False, fast_math=False):
+                 strict_normals=None, hide_emitters=None, opacity=False):
         sc = scene.sc; L = scene.L; self.L = L; self.scene = scene
         p = MiRenderParams(sc.max_depth if max_depth is None else max_depth, sc.rr_depth if rr_depth is None else rr_depth,
                            sc.strict_normals if strict_normals is None else int(strict_normals),
                            sc.hide_emitters if hide_emitters is None else int(hide_emitters),
                            sc.sampler if sampler is None else sampler, sc.spp if spp is None else spp,
-                           sc.seed if seed is None else seed, device, planes_per_batch, int(opacity), int(fast_math))
+                           sc.seed if seed is None else seed, device, planes_per_batch, int(opacity), 0)
         self.params = p
         h = C.c_void_p(); L.check(L.L.mi_render_create(scene.h, C.byref(p), C.byref(h))); self.h = h
 

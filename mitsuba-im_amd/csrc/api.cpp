@@ -475,7 +475,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
-    if (p->fast_math) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: fast_math = 1 is not built: one set of kernels (strict IEEE arithmetic, bit-identical to the oracle) ships");
+    if (p->reserved0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: reserved0 must be 0 (the fast_math kernel set of round 1 is gone: one set of kernels, strict IEEE arithmetic)");
     if (p->sampler == MI_SAMPLER_SOBOL) {
         if (!s->h.d.sobol_m32) return fail(MI_ERR_INVALID, "mi_render_create: Sobol tables not loaded before mi_scene_commit (mi_set_sobol_tables)");
         // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR, + 1 where a BSDF draws from the sampler itself: roughdielectric, EUsesSampler) + the dim-4 skip

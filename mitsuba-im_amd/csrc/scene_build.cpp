@@ -283,7 +283,10 @@ void SceneHost::commitHost() {
     nodes.clear(); tris.clear();
     std::vector<int> depthOf;     // depth of each emitted tree
     // builds the tree over `prims`, appends its nodes / leaf records, returns the device index of its root (always an inner node)
-    { const char *e2 = getenv("MI355PT_BVH2"); wideBvh = !(e2 && e2[0] == '1'); }
+    // Node kind (measured, DESIGN.md "Tree scenes"): 4-wide quantised nodes win once the tree outgrows the caches close to the CUs (atrium, 0.6 M triangles:
+    // +12 %); on small trees and on the two-level trees of instanced scenes the binary nodes' cheaper per-node arithmetic wins (instanced garden: +5 %).
+    // MI355PT_BVH2 = 1 / 0 forces binary / wide (A/B runs, parity tests of both kinds).
+    { const char *e2 = getenv("MI355PT_BVH2"); wideBvh = e2 && e2[0] ? e2[0] == '0' : (ni == 0 && nt >= 16384u); }
     std::vector<int> treeNeed;    // traversal stack entries each emitted tree can need
     auto emitTree = [&](const std::vector<uint32_t> &prims) -> int {
         Builder bld; bld.order = prims; bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.single = &single; bld.nodes.reserve(2 * prims.size() + 2);

@@ -1,6 +1,6 @@
 """Command-line front end: render a Mitsuba XML scene on the MI355X path tracer (what `mitsuba scene.xml` does for the `path` integrator).
 
-    python -m mitsuba-im_amd.render scene.xml [-o out.exr|out.pfm|out.npy|out.png] [-D name=value ...] [--spp N] [--sampler sobol|independent] [--fast-math] [--device K]
+    python -m mitsuba-im_amd.render scene.xml [-o out.exr|out.pfm|out.npy|out.png] [-D name=value ...] [--spp N] [--sampler sobol|independent] [--device K]
 
 The image written is the developed film (sum / weight, linear RGB, as HDRFilm::develop would hand to its writer); `.exr` (FLOAT channels, ZIP), `.pfm` and `.npy`
 keep the linear values; `.png` / `.jpg` get ldrfilm's default sRGB encoding (imageio.py).  There is no CPU fallback: without the HIP library / a GPU this exits with an error.
@@ -40,7 +40,6 @@ def main(argv=None):
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--sampler", choices=["sobol", "independent"], default=None, help="replace the scene's sampler plugin (keeps its sampleCount)")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--fast-math", action="store_true")
     a = ap.parse_args(argv)
     params = {}
     for d in a.defines:
@@ -54,7 +53,7 @@ def main(argv=None):
             sc.spp = a.spp
         t1 = time.perf_counter()
         scene = Scene(sc, device=a.device)
-        render = Render(scene, device=a.device, fast_math=a.fast_math)
+        render = Render(scene, device=a.device)
         t2 = time.perf_counter()
         render.run()
         rgb = render.read_film(2)

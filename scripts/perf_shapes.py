@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mi = importlib.import_module("mitsuba-im_amd")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 sc = getattr(mi.scenes, os.environ.get("SCENE", "cbox_shapes"))(1920, 1080, spp)
-gs = mi.Scene(sc); r = mi.Render(gs, planes_per_batch=int(os.environ.get("PLANES", "0")), fast_math=os.environ.get("FAST", "0") == "1")
+gs = mi.Scene(sc); r = mi.Render(gs, planes_per_batch=int(os.environ.get("PLANES", "0")))
 r.run(s1=8); r.set_profiling(True)
 r.clear(); r.run(s1=spp); st = r.stats()
 n = 1920 * 1080 * spp

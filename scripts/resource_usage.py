@@ -1,7 +1,7 @@
 """Per-kernel register / scratch / occupancy table of the precise TU (hipcc -Rpass-analysis=kernel-resource-usage)."""
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = subprocess.run(["make", "-C", os.path.join(root, "mitsuba-im_amd", "csrc"), "resource-usage"], capture_output=True, text=True).stderr
+out = subprocess.run(["make", "-C", os.path.join(root, "mitsuba-im_amd", "csrc"), "resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
 cur = None; rows = {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
