@@ -23,6 +23,7 @@ BSDF_THINDIELECTRIC = 8   # src/bsdfs/thindielectric.cpp: eta[0] = intIOR / extI
 BSDF_MASK = 9             # src/bsdfs/mask.cpp: reflectance = opacity (constant or textured), distr = index of the nested material record (an earlier one)
 BSDF_MIXTURE = 10         # src/bsdfs/mixturebsdf.cpp: distr = number of children (2..4); their material indices in reflectance[0..2], eta[0] (as numbers), weights in k[0..2], specular[0]
 BSDF_BUMPMAP = 11         # src/bsdfs/bumpmap.cpp: distr = index of the nested material record, bound texture = the displacement, alpha = factor of an enclosing `scale` texture
+BSDF_NULL = 13            # src/bsdfs/null.cpp: index-matched boundary of a participating medium (passes straight through, ENull)
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -100,9 +101,39 @@ def rough_transmittance_slice(distr, ior, alpha):
     raise ValueError("no rough-transmittance slice for distr=%s ior=%s alpha=%s (extend the grid in oracle/ref_build/harness.cpp modeTables)" % (distr, ior, alpha))
 
 
+INTEGRATOR_PATH = 0            # src/integrators/path/path.cpp
+INTEGRATOR_VOLPATH_SIMPLE = 1  # src/integrators/path/volpath_simple.cpp
+MEDIUM_BALANCE, MEDIUM_SINGLE, MEDIUM_MANUAL = 0, 1, 2      # HomogeneousMedium sampling strategies (homogeneous.cpp:192-226; `maximum` is not built)
+PHASE_ISOTROPIC, PHASE_HG = 0, 1
+
+
+def make_medium(sigma_a, sigma_s, strategy=MEDIUM_BALANCE, phase=PHASE_ISOTROPIC, g=0.0, medium_sampling_weight=None, sampling_density=None, channel=None):
+    """`homogeneous` medium (src/medium/homogeneous.cpp) with an `isotropic` / `hg` phase function.  sigma_a / sigma_s are the final coefficients (the reference's
+    `scale` and material presets are folded in by the caller).  The derived sampling parameters follow the constructor (homogeneous.cpp:168-222) in float arithmetic."""
+    sa = np.asarray(sigma_a, f32); ss = np.asarray(sigma_s, f32); st = (sa + ss).astype(f32)
+    w = -1.0 if medium_sampling_weight is None else float(medium_sampling_weight)
+    if w == -1.0:
+        w = f32(-1.0)
+        for i in range(3):
+            albedo = f32(ss[i] / st[i]) if st[i] != 0 else f32(np.inf)
+            if albedo > w and st[i] != 0: w = albedo
+        if w > 0: w = max(w, f32(0.5))
+        w = float(w)
+    density = 0.0
+    if strategy == MEDIUM_SINGLE:
+        ch = int(np.argmin(st)) if channel is None else int(channel)         # the first smallest sigma_t (strict < in the reference's loop)
+        density = float(st[ch])
+    elif strategy == MEDIUM_MANUAL:
+        density = float(f32(sampling_density))
+    return dict(sigma_a=tuple(map(float, sa)), sigma_s=tuple(map(float, ss)), strategy=int(strategy), sampling_density=density, medium_sampling_weight=float(f32(w)),
+                phase=int(phase), g=float(f32(g)))
+
+
 def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, alpha=0.1,
               distr=DISTR_BECKMANN, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
               specular=(1.0, 1.0, 1.0), sample_visible=True, ior=1.5046, nonlinear=False, alpha_v=None, nested=None, weights=None, texture=-1, scale=1.0):
+    if kind == BSDF_NULL:
+        reflectance = (0.0, 0.0, 0.0)
     if kind == BSDF_MASK:
         distr = int(nested)                           # reflectance = opacity
     if kind in (BSDF_BUMPMAP, BSDF_NORMALMAP):        # wrapper around record `nested`; `texture` = displacement / normal map, `scale` = ScaleTexture factor (bumpmap)
@@ -254,7 +285,7 @@ def set_crop_window(sc, full_width, full_height, offset_x, offset_y):
 def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near, far, width, height,
                  spp, sampler, max_depth, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
                  normals=None, uvs=None, strict_normals=False, hide_emitters=False, envmap=None,
-                 name="scene", analytic=None, instances=None, textures=None):
+                 name="scene", analytic=None, instances=None, textures=None, media=None, sensor_medium=-1, integrator=INTEGRATOR_PATH):
     sc = Scene()
     sc.name = name
     sc.pos = np.ascontiguousarray(np.asarray(verts, dtype=f32).reshape(-1, 3))
@@ -303,6 +334,9 @@ def finish_scene(verts, tris, shapes, bsdfs, emitters, cam_to_world, xfov, near,
     for si, s in enumerate(shapes):
         tri_shape[s["first_tri"]:s["first_tri"] + s["tri_count"]] = si
     sc.tri_shape = tri_shape
+    # participating media (make_medium); a shape / analytic record names its "interior" / "exterior" medium by index (-1: none), the sensor its own
+    sc.media = list(media or []); sc.sensor_medium = int(sensor_medium) if sc.media else -1; sc.integrator = int(integrator)
+    sc.shape_media = np.asarray([[r.get("interior", -1), r.get("exterior", -1)] for r in list(shapes) + list(sc.analytic)], np.int32).reshape(-1, 2) if sc.media else None
     return sc
 
 
@@ -402,10 +436,10 @@ class _Builder:
         self.normals = None
         self.analytic = []
 
-    def add_analytic(self, kind, to_world, bsdf, radiance=None, flip=False, radius=1.0, length=1.0):
+    def add_analytic(self, kind, to_world, bsdf, radiance=None, flip=False, radius=1.0, length=1.0, interior=-1, exterior=-1):
         """call after all meshes: the shape index of an analytic shape is len(shapes) + its position."""
         rec = make_analytic(kind, to_world, bsdf, -1, flip, radius, length)
-        rec["_radiance"] = None if radiance is None else tuple(map(float, radiance))
+        rec["_radiance"] = None if radiance is None else tuple(map(float, radiance)); rec["interior"] = int(interior); rec["exterior"] = int(exterior)
         self.analytic.append(rec)
 
     def resolve_analytic(self):
@@ -426,7 +460,7 @@ class _Builder:
     def quad(self, pts):
         _quad(self.verts, self.tris, None, [tuple(map(float, p)) for p in pts])
 
-    def end(self, bsdf, radiance=None, face_normals=True, group=0):
+    def end(self, bsdf, radiance=None, face_normals=True, group=0, interior=-1, exterior=-1):
         em = -1
         si = len(self.shapes)
         if radiance is not None:
@@ -434,7 +468,7 @@ class _Builder:
             em = len(self.emitters) - 1
         self.shapes.append(dict(first_tri=self._ft, tri_count=len(self.tris) - self._ft,
                                 first_vert=self._fv, vert_count=len(self.verts) - self._fv,
-                                bsdf=bsdf, emitter=em, face_normals=int(face_normals), group=int(group)))
+                                bsdf=bsdf, emitter=em, face_normals=int(face_normals), group=int(group), interior=int(interior), exterior=int(exterior)))
 
 
 def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5,
@@ -472,6 +506,44 @@ def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0,
                         width, height, spp, sampler, max_depth, rr_depth, filter_kind, seed, strict_normals=strict_normals,
                         hide_emitters=hide_emitters, name="cornell")
+
+
+def _closed_box(b, top, y0, y1):
+    """closed box over the quadrilateral `top` = four (x, z) corners in the Cornell blocks' order (normal up); all faces point outwards"""
+    P = [tuple(map(float, p)) for p in top]
+    b.quad([(p[0], y1, p[1]) for p in P])
+    for i in range(4):
+        j = (i + 1) % 4
+        b.quad([(P[j][0], y0, P[j][1]), (P[j][0], y1, P[j][1]), (P[i][0], y1, P[i][1]), (P[i][0], y0, P[i][1])])
+    b.quad([(p[0], y0, p[1]) for p in reversed(P)])
+
+
+def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, global_fog=False, strict_normals=False, hide_emitters=False):
+    """Cornell room for the volumetric path tracer (volpath_simple): a smoke cube behind an index-matched (`null`) boundary (isotropic, `balance`
+    sampling), a glass block filled with a forward-scattering medium (hg, `single`), a `null` sphere of thin haze (hg backwards, `manual`); with global_fog the
+    sensor sits in a thin isotropic medium that fills the room (the shapes name it as their exterior medium)."""
+    b = _Builder()
+    white = b.bsdf(reflectance=(0.725, 0.71, 0.68)); red = b.bsdf(reflectance=(0.63, 0.065, 0.05)); green = b.bsdf(reflectance=(0.14, 0.45, 0.091))
+    lightm = b.bsdf(reflectance=(0.78, 0.78, 0.78)); null = b.bsdf(kind=BSDF_NULL); glass = b.bsdf(kind=BSDF_DIELECTRIC, ior=1.5, reflectance=(1.0, 1.0, 1.0))
+    media = [make_medium((0.001, 0.002, 0.004), (0.012, 0.010, 0.008)),
+             make_medium((0.002, 0.0005, 0.002), (0.004, 0.008, 0.004), strategy=MEDIUM_SINGLE, phase=PHASE_HG, g=0.6),
+             make_medium((0.0005, 0.0005, 0.0005), (0.006, 0.006, 0.007), strategy=MEDIUM_MANUAL, sampling_density=0.008, phase=PHASE_HG, g=-0.3)]
+    ext = -1
+    if global_fog:
+        media.append(make_medium((0.0001, 0.0001, 0.00015), (0.0006, 0.0006, 0.0005))); ext = 3
+    b.begin(); b.quad([(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)]); b.end(white)
+    b.begin(); b.quad([(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)]); b.end(white)
+    b.begin(); b.quad([(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)]); b.end(white)
+    b.begin(); b.quad([(0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2)]); b.end(green)
+    b.begin(); b.quad([(552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0)]); b.end(red)
+    b.begin(); b.quad([(343, 548.3, 227), (343, 548.3, 332), (213, 548.3, 332), (213, 548.3, 227)]); b.end(lightm, radiance=(17.0, 12.0, 4.0))
+    b.begin(); _closed_box(b, [(130, 65), (82, 225), (240, 272), (290, 114)], 0.5, 165.0); b.end(null, interior=0, exterior=ext)
+    b.begin(); _closed_box(b, [(423, 247), (265, 296), (314, 456), (472, 406)], 0.5, 330.0); b.end(glass, interior=1, exterior=ext)
+    b.add_analytic(SHAPE_SPHERE, translate(150.0, 390.0, 300.0), null, radius=70.0, interior=2, exterior=ext)
+    cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
+    return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth, FILTER_BOX, seed,
+                        strict_normals=strict_normals, hide_emitters=hide_emitters, name="fog_box", analytic=b.resolve_analytic(), media=media,
+                        sensor_medium=ext, integrator=INTEGRATOR_VOLPATH_SIMPLE)
 
 
 def cbox_shapes(width=256, height=256, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, filter_kind=FILTER_BOX, seed=0,
@@ -1226,6 +1298,11 @@ def save_scene(sc, path):
             f.write(struct.pack("<%di" % len(sc.bsdfs), *[b.get("texture", -1) for b in sc.bsdfs]))
         if sc.get("crop"):
             f.write(b"CROP"); f.write(struct.pack("<I", 1)); f.write(struct.pack("<4i", *sc.crop))
+        if sc.get("media"):
+            f.write(b"MEDI"); f.write(struct.pack("<I", len(sc.media)))
+            for m in sc.media:
+                f.write(struct.pack("<6fI2fIfI", *m["sigma_a"], *m["sigma_s"], m["strategy"], m["sampling_density"], m["medium_sampling_weight"], m["phase"], m["g"], 0))
+            f.write(struct.pack("<2iI", sc.integrator, sc.sensor_medium, len(sc.shape_media))); f.write(np.ascontiguousarray(sc.shape_media, np.int32).tobytes())
         if sc.get("instances"):
             f.write(b"INST"); f.write(struct.pack("<I", len(sc.instances)))
             for a in sc.instances:

@@ -34,6 +34,20 @@ class OrcEmitter(C.Structure):
                 ("to_world", C.c_float * 16)]
 
 
+class OrcMedium(C.Structure):
+    _fields_ = [("sigma_a", C.c_float * 3), ("sigma_s", C.c_float * 3), ("strategy", C.c_uint32), ("sampling_density", C.c_float), ("medium_sampling_weight", C.c_float),
+                ("phase", C.c_uint32), ("g", C.c_float), ("pad", C.c_uint32)]
+
+
+def pack_media(sc):
+    recs = sc.get("media") or []
+    arr = (OrcMedium * max(1, len(recs)))()
+    for i, m in enumerate(recs):
+        r = OrcMedium(); r.sigma_a[:] = m["sigma_a"]; r.sigma_s[:] = m["sigma_s"]; r.strategy = m["strategy"]; r.sampling_density = m["sampling_density"]
+        r.medium_sampling_weight = m["medium_sampling_weight"]; r.phase = m["phase"]; r.g = m["g"]; arr[i] = r
+    return arr, len(recs)
+
+
 class OrcAnalytic(C.Structure):
     _fields_ = [("type", C.c_uint32), ("bsdf", C.c_int32), ("emitter", C.c_int32), ("flags", C.c_uint32),
                 ("to_world", C.c_float * 16), ("to_object", C.c_float * 16), ("radius", C.c_float), ("length", C.c_float), ("pad", C.c_float * 2)]
@@ -50,7 +64,8 @@ class OrcSceneDesc(C.Structure):
                 ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64),
                 ("sobol_matrices32", C.c_void_p), ("sobol_dims", C.c_uint32), ("sobol_vdc", C.c_void_p), ("sobol_vdc_inv", C.c_void_p),
                 ("env_rgb", C.c_void_p), ("env_w", C.c_uint32), ("env_h", C.c_uint32), ("env_to_world", C.c_float * 16), ("env_scale", C.c_float),
-                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_texture_levels", C.c_uint32), ("texture_levels", C.c_void_p), ("n_texture_texels", C.c_uint32), ("texture_texels", C.c_void_p), ("env_texture", C.c_uint32)]
+                ("n_analytic", C.c_uint32), ("analytic", C.c_void_p), ("n_instances", C.c_uint32), ("instances", C.c_void_p), ("n_material_tables", C.c_uint32), ("material_tables", C.c_void_p), ("n_textures", C.c_uint32), ("textures", C.c_void_p), ("n_texture_levels", C.c_uint32), ("texture_levels", C.c_void_p), ("n_texture_texels", C.c_uint32), ("texture_texels", C.c_void_p),
+                ("integrator", C.c_uint32), ("n_media", C.c_uint32), ("media", C.c_void_p), ("shape_media", C.c_void_p), ("sensor_medium", C.c_int32), ("env_texture", C.c_uint32)]
 
 
 def build():
@@ -192,6 +207,10 @@ class Oracle:
                 self._keep += [sc.texture_levels, sc.texture_texels]
                 d.n_texture_levels, d.texture_levels, d.n_texture_texels, d.texture_texels = len(sc.texture_levels), _ptr(sc.texture_levels), len(sc.texture_texels), _ptr(sc.texture_texels)
         d.env_texture = int(sc.get("env_texture", 0) or 0)
+        med, n_med = pack_media(sc); self._keep.append(med)
+        d.integrator, d.n_media, d.media, d.sensor_medium = int(sc.get("integrator", 0) or 0), n_med, C.cast(med, C.c_void_p), int(sc.get("sensor_medium", -1) if n_med else -1)
+        if n_med:
+            sm = np.ascontiguousarray(sc.shape_media, np.int32); self._keep.append(sm); d.shape_media = _ptr(sm)
         mt = sc.get("material_tables")
         if mt is not None:
             self._keep.append(mt); d.n_material_tables, d.material_tables = len(mt), _ptr(mt)

@@ -52,6 +52,7 @@ typedef struct {
     v3 dpdu, dpdv;    /* its.dpdu / its.dpdv (world space): feed Intersection::computePartials */
     float uvx, uvy;   /* its.uv: interpolated texture coordinates (meshes with texcoords), else the barycentrics */
     int valid; float t; v3 p, ng, ns, s, tt; float u, v; v3 wi; uint32_t prim, shape; int32_t material, emitter; int32_t instance;
+    v3 ng_raw;        /* the `n` of ShapeKDTree::rayIntersect(ray, t, shape, n, uv) (skdtree.cpp:144-205): the triangle's face normal BEFORE it is flipped to the shading side; analytic shapes / instances: ng */
 } hit_t;
 
 /* a material + the table it refers to (roughplastic); bsdf_* functions receive &mat->m and may cast back */
@@ -61,7 +62,7 @@ struct orc_scene {
     uint32_t *tex_levels; float *tex_texels; float mip_lut[64]; v3 cam_dx, cam_dy;   /* MIP pyramids (input data); EWA weight table; perspective.cpp:159-163 */
     float *uv; float *tangents; /* per triangle: dpdu xyz, dpdv xyz (TriMesh::computeUVTangents) */ orc_texture *textures;
     float *pos, *nrm; uint32_t *idx; orc_shape *shapes; struct mat_s *materials; orc_emitter *emitters; float *material_tables;
-    uint32_t *tri_shape;
+    uint32_t *tri_shape; orc_medium *media;
     struct analytic_s *analytic; uint32_t n_analytic, n_prims;
     orc_instance *instances; uint32_t n_instances, n_groups; int *group_root; v3 *group_lo, *group_hi;   /* per shape group: BVH root, kd-tree box (enlarged) */
     uint32_t *group_first, *group_count;     /* per group: its range in group_prims (for the brute-force cross-check) */ uint32_t *group_prims;   /* primitive index space: [0, n_tris) triangles, then the analytic shapes */
@@ -679,7 +680,7 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     if (prim >= s->d.n_tris) {                       /* skdtree.h:421-427: shape->fillIntersectionRecord, computeShadingFrame, wi */
         const analytic_t *sh = &s->analytic[prim - s->d.n_tris]; v3 dpdu;
         h->valid = 1; h->t = t; h->u = u; h->v = v; h->prim = 0; h->shape = s->d.n_shapes + (prim - s->d.n_tris);
-        analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu); h->dpdu = dpdu; h->dpdv = V(0, 0, 0);
+        analytic_fill(sh, o, d, t, u, v, &h->p, &h->ng, &h->ns, &dpdu); h->dpdu = dpdu; h->dpdv = V(0, 0, 0); h->ng_raw = h->ng;
         { v3 du, dv; analytic_uv(sh, u, v, add(o, scale(d, t)), &h->uvx, &h->uvy, &du, &dv); h->dpdv = dv; }
         h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
         h->tt = cross(h->ns, h->s);
@@ -703,6 +704,7 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     v3 fn = cross(side1, side2);
     float len = sqrtf(dot(fn, fn));
     if (!is_zero(fn)) { float r = 1.0f / len; fn = scale(fn, r); }
+    h->ng_raw = fn;
     int smooth = s->nrm != NULL && !(sh->flags & 1u);
     if (smooth) {
         v3 n = add(add(scale(vnrm(s, i0), bx), scale(vnrm(s, i1), by)), scale(vnrm(s, i2), bz));
@@ -722,6 +724,7 @@ static void fill_hit(const orc_scene *s, v3 o, v3 d, float t, uint32_t prim, int
     if (in) {   /* instance.cpp:134-139: normals through the inverse transpose, dpdu / p through the forward transform; then the scene-level computeShadingFrame + wi */
         h->ns = normalize(xf_normal(in->to_object, h->ns)); h->ng = normalize(xf_normal(in->to_object, h->ng));
         dpdu = xf_vector(in->to_world, dpdu); dpdv = xf_vector(in->to_world, dpdv); h->p = xf_point(in->to_world, h->p);
+        h->ng_raw = h->ng;
     }
     h->dpdu = dpdu; h->dpdv = dpdv;
     h->s = normalize(sub(dpdu, scale(h->ns, dot(h->ns, dpdu))));
@@ -799,15 +802,15 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
-static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC; }
+static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
 /* BSDF::ESmooth: a `diffuse` whose reflectance is identically zero registers NO component (src/bsdfs/diffuse.cpp:99-102), so its type
  * is 0 and MIPathTracer::Li skips emitter sampling -- and the sampler request that goes with it (path.cpp:174-176) */
 static int material_is_smooth(const orc_material *m) {
     if (m->type == BSDF_DIFFUSE) return ((m->flags >> 8) & 0xFFFFu) != 0 || maxf(maxf(m->reflectance[0], m->reflectance[1]), m->reflectance[2]) > 0;   /* a textured reflectance always registers the component */
-    if (m->type == BSDF_CONDUCTOR || m->type == BSDF_DIELECTRIC || m->type == BSDF_THINDIELECTRIC) return 0;     /* delta components only (conductor.cpp:201-202, dielectric.cpp:199-202, thindielectric.cpp:117-120) */
+    if (m->type == BSDF_CONDUCTOR || m->type == BSDF_DIELECTRIC || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL) return 0;     /* delta components only (conductor.cpp:201-202, dielectric.cpp:199-202, thindielectric.cpp:117-120) */
     return 1;
 }
 
@@ -1314,7 +1317,7 @@ static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
         case BSDF_ROUGHCONDUCTOR: return rc_eval(m, wi, wo);
-        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: case BSDF_THINDIELECTRIC: return V(0, 0, 0);
+        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: case BSDF_THINDIELECTRIC: case BSDF_NULL: return V(0, 0, 0);
         case BSDF_PLASTIC: return plastic_eval(m, wi, wo);
         case BSDF_ROUGHDIELECTRIC: return rd_eval(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_eval(m, wi, wo);
@@ -1326,7 +1329,7 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
         case BSDF_ROUGHCONDUCTOR: return rc_pdf(m, wi, wo);
-        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: case BSDF_THINDIELECTRIC: return 0.0f;
+        case BSDF_CONDUCTOR: case BSDF_DIELECTRIC: case BSDF_THINDIELECTRIC: case BSDF_NULL: return 0.0f;
         case BSDF_PLASTIC: return plastic_pdf(m, wi, wo);
         case BSDF_ROUGHDIELECTRIC: return rd_pdf(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_pdf(wi, wo);
@@ -1350,6 +1353,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_DIFFTRANS: w = dt_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_ROUGHPLASTIC: w = rp_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_THINDIELECTRIC: w = thindielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
+        case BSDF_NULL: *wo = neg(wi); *pdf = 1.0f; *eta = 1.0f; *delta = 2; w = V(1, 1, 1); break;      /* src/bsdfs/null.cpp:56-66: the index-matched boundary, sampledType = ENull */
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;
     }
     if (flipped && !is_zero(w) && *pdf != 0) wo->z = -wo->z;      /* twosided.cpp:176-180 */
@@ -1476,7 +1480,7 @@ static uint32_t cdf_sample(const float *cdf, uint32_t n, float x) {
     while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
     return index;
 }
-typedef struct { v3 ref, p, n, d; float dist, pdf; int32_t emitter; int delta; /* !isOnSurface: point / spot / directional */ } direct_t;
+typedef struct { v3 ref, p, n, d; float dist, pdf; float em_pdf; /* probability of the chosen emitter (attenuated mode) */ int32_t emitter; int delta; /* !isOnSurface: point / spot / directional */ } direct_t;
 
 /* src/emitters/area.cpp:106-111 AreaLight::eval */
 static v3 emitter_eval(const orc_scene *s, int32_t e, v3 ns, v3 d) {
@@ -1534,12 +1538,12 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
             value = V(em->radiance[0], em->radiance[1], em->radiance[2]);
         }
         if (dr->pdf != 0) {                                                     /* scene.cpp:870-883 */
-            if (test_visibility) {
+            if (test_visibility == 1) {
                 if (shadow_rays) ++*shadow_rays;
                 if (ray_occluded(s, ref, dr->d, EPSILON, dr->dist * (1 - SHADOW_EPSILON))) return V(0, 0, 0);
             }
             dr->emitter = (int32_t) ei; dr->pdf *= emPdf;
-            { float r = 1.0f / emPdf; value = scale(value, r); }
+            dr->em_pdf = emPdf; if (test_visibility != 2) { float r = 1.0f / emPdf; value = scale(value, r); }
             return value;
         }
         return V(0, 0, 0);
@@ -1554,12 +1558,12 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
         }
         dr->pdf = pdf; dr->p = add(ref, scale(dw, farT)); dr->n = normalize(sub(s->env_bs_center, dr->p)); dr->dist = farT; dr->d = dw;
         { float r = 1.0f / pdf; value = scale(value, r); }
-        if (test_visibility) {
+        if (test_visibility == 1) {
             if (shadow_rays) ++*shadow_rays;
             if (ray_occluded(s, ref, dr->d, EPSILON, dr->dist * (1 - SHADOW_EPSILON))) return V(0, 0, 0);
         }
         dr->emitter = (int32_t) ei; dr->pdf *= emPdf;
-        { float r = 1.0f / emPdf; value = scale(value, r); }
+        dr->em_pdf = emPdf; if (test_visibility != 2) { float r = 1.0f / emPdf; value = scale(value, r); }
         return value;
     }
     dr->ref = ref;
@@ -1591,13 +1595,13 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
         float r = 1.0f / dr->pdf; value = V(em->radiance[0] * r, em->radiance[1] * r, em->radiance[2] * r);   /* Spectrum / Float */
     } else { dr->pdf = 0.0f; value = V(0, 0, 0); }
     if (dr->pdf != 0) {
-        if (test_visibility) {
+        if (test_visibility == 1) {
             if (shadow_rays) ++*shadow_rays;
             if (ray_occluded(s, ref, dr->d, EPSILON, dr->dist * (1 - SHADOW_EPSILON))) return V(0, 0, 0);
         }
         dr->emitter = (int32_t) ei;
         dr->pdf *= emPdf;
-        { float r = 1.0f / emPdf; value = scale(value, r); }     /* Spectrum /= Float */
+        dr->em_pdf = emPdf; if (test_visibility != 2) { float r = 1.0f / emPdf; value = scale(value, r); }     /* Spectrum /= Float */
         return value;
     }
     return V(0, 0, 0);
@@ -2032,6 +2036,189 @@ static v3 path_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sample
     return Li;
 }
 
+/* ------------------------------------------------------------------------------------------------ participating media */
+/* include/mitsuba/core/math.h:185-195 (Linux x86_64): fastexp / fastlog go through the double-precision routines */
+static inline float mi_fastexp(float v) { return (float) exp((double) v); }
+static inline float mi_fastlog(float v) { return (float) log((double) v); }
+typedef struct { float t; v3 p; v3 transmittance; float pdf_success, pdf_failure; } mrec_t;
+static inline void medium_sigma_t(const orc_medium *m, float *st) { for (int i = 0; i < 3; ++i) st[i] = m->sigma_a[i] + m->sigma_s[i]; }     /* medium.cpp:36 */
+/* HomogeneousMedium::evalTransmittance (homogeneous.cpp:266-273) over [mint, maxt] of a ray */
+static v3 medium_transmittance(const orc_medium *m, float mint, float maxt) {
+    float st[3], r[3]; medium_sigma_t(m, st); const float negLength = mint - maxt;
+    for (int i = 0; i < 3; ++i) r[i] = st[i] != 0 ? mi_fastexp(st[i] * negLength) : 1.0f;
+    return V(r[0], r[1], r[2]);
+}
+/* HomogeneousMedium::sampleDistance (homogeneous.cpp:275-349), strategies balance / single / manual */
+static int medium_sample_distance(const orc_medium *m, v3 o, v3 d, float mint, float maxt, sampler_t *sp, mrec_t *r) {
+    float st[3]; medium_sigma_t(m, st);
+    float rnd = next1D(sp), sampled, density = m->sampling_density;
+    if (rnd < m->medium_sampling_weight) {
+        rnd /= m->medium_sampling_weight;
+        if (m->strategy == 0) { int ch = (int) (next1D(sp) * 3); if (ch > 2) ch = 2; density = st[ch]; }
+        sampled = -mi_fastlog(1 - rnd) / density;
+    } else sampled = INFINITY;
+    const float distSurf = maxt - mint; int success = 1;
+    if (sampled < distSurf) {
+        r->t = sampled + mint; r->p = add(o, scale(d, r->t));
+        if (r->p.x == o.x && r->p.y == o.y && r->p.z == o.z) success = 0;
+    } else { sampled = distSurf; success = 0; }
+    if (m->strategy == 0) {
+        r->pdf_failure = 0; r->pdf_success = 0;
+        for (int i = 0; i < 3; ++i) { float tmp = mi_fastexp(-st[i] * sampled); r->pdf_failure += tmp; r->pdf_success += st[i] * tmp; }
+        r->pdf_failure /= 3; r->pdf_success /= 3;
+    } else { r->pdf_failure = mi_fastexp(-density * sampled); r->pdf_success = density * r->pdf_failure; }
+    r->transmittance = V(mi_fastexp(st[0] * (-sampled)), mi_fastexp(st[1] * (-sampled)), mi_fastexp(st[2] * (-sampled)));
+    r->pdf_success = r->pdf_success * m->medium_sampling_weight;
+    r->pdf_failure = m->medium_sampling_weight * r->pdf_failure + (1 - m->medium_sampling_weight);
+    if (maxf(maxf(r->transmittance.x, r->transmittance.y), r->transmittance.z) < 1e-20f) r->transmittance = V(0, 0, 0);
+    return success;
+}
+/* IsotropicPhaseFunction::eval (isotropic.cpp:74-76), HGPhaseFunction::eval (hg.cpp:108-111); wi = -ray.d, wo = the sampled direction */
+static float phase_eval(const orc_medium *m, v3 wi, v3 wo) {
+    if (m->phase == 0) return INV_FOURPI;
+    const float g = m->g, temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
+    return INV_FOURPI * (1 - g * g) / (temp * sqrtf(temp));
+}
+/* IsotropicPhaseFunction::sample (isotropic.cpp:61-66), HGPhaseFunction::sample (hg.cpp:74-99): weight 1 */
+static v3 phase_sample(const orc_medium *m, v3 wi, sampler_t *sp) {
+    float sx, sy; next2D(sp, &sx, &sy);
+    if (m->phase == 0) return uniform_sphere(sx, sy);
+    const float g = m->g; float cosTheta;
+    if (fabsf(g) < EPSILON) cosTheta = 1 - 2 * sx;
+    else { float sqrTerm = (1 - g * g) / (1 - g + 2 * g * sx); cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g); }
+    float sinTheta = sqrtf(maxf(1.0f - cosTheta * cosTheta, 0.0f)), sinPhi, cosPhi;
+    sincos_2pi(sy, &sinPhi, &cosPhi);
+    v3 n = neg(wi), fs, ft; coordinate_system(n, &fs, &ft);           /* Frame(-pRec.wi).toWorld */
+    v3 l = V(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+    return add(add(scale(fs, l.x), scale(ft, l.y)), scale(n, l.z));
+}
+static inline int shape_interior(const orc_scene *s, uint32_t shape) { return s->d.shape_media ? s->d.shape_media[shape * 2] : -1; }
+static inline int shape_exterior(const orc_scene *s, uint32_t shape) { return s->d.shape_media ? s->d.shape_media[shape * 2 + 1] : -1; }
+static inline int is_medium_transition(const orc_scene *s, uint32_t shape) { return shape_interior(s, shape) >= 0 || shape_exterior(s, shape) >= 0; }   /* shape.h isMediumTransition */
+static inline int target_medium(const orc_scene *s, uint32_t shape, v3 n, v3 d) { return dot(d, n) > 0 ? shape_exterior(s, shape) : shape_interior(s, shape); }   /* records.inl:81-86 */
+/* ShapeKDTree::rayIntersect(ray, t, shape, n, uv) (skdtree.cpp:144-205): closest hit under the shadow-ray epsilon rule, counted as a shadow ray */
+static int ray_intersect_n(const orc_scene *s, v3 o, v3 d, float rmint, float rmaxt, hit_t *h, uint64_t *shadow_rays) {
+    float mint, maxt, t = 0, u = 0, v = 0; uint32_t prim = 0; int32_t inst = -1;
+    h->valid = 0; h->t = INFINITY; if (shadow_rays) ++*shadow_rays;
+    if (!clip_interval(s, o, d, rmint, rmaxt, 1, &mint, &maxt)) return 0;
+    int found = g_brute ? traverse_brute(s, o, d, mint, maxt, 0, &t, &prim, &inst, &u, &v) : traverse(s, o, d, mint, maxt, 0, &t, &prim, &inst, &u, &v);
+    if (!found) return 0;
+    fill_hit(s, o, d, t, prim, inst, u, v, h);
+    return 1;
+}
+/* Scene::evalTransmittance (scene.cpp:650-713): walk from p1 to p2 through index-matched (`null`) boundaries, attenuating by the media in between */
+static v3 eval_transmittance(const orc_scene *s, v3 p1, int p1OnSurface, v3 p2, int p2OnSurface, int medium, int *interactions, uint64_t *shadow_rays) {
+    v3 d = sub(p2, p1); float remaining = length3(d); { float r = 1.0f / remaining; d = scale(d, r); }
+    const float lengthFactor = p2OnSurface ? (1 - SHADOW_EPSILON) : 1;
+    v3 o = p1; float mint = p1OnSurface ? EPSILON : 0, maxt = remaining * lengthFactor;
+    v3 transmittance = V(1, 1, 1); hit_t its; const int maxInteractions = *interactions; *interactions = 0;
+    while (remaining > 0) {
+        int surface = ray_intersect_n(s, o, d, mint, maxt, &its, shadow_rays);
+        if (surface && (*interactions == maxInteractions || s->materials[its.material].m.type != BSDF_NULL)) return V(0, 0, 0);     /* !(bsdf->getType() & BSDF::ENull) */
+        if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, minf(its.t, remaining)));
+        if (!surface || is_zero(transmittance)) break;
+        /* bsdf->eval(bRec, EDiscrete) with typeMask = ENull: 1 for `null` (null.cpp:48-50) */
+        if (is_medium_transition(s, its.shape)) {
+            if (medium != target_medium(s, its.shape, its.ng_raw, neg(d))) return V(0, 0, 0);        /* medium inconsistency */
+            medium = target_medium(s, its.shape, its.ng_raw, d);
+        }
+        if (++*interactions > 100) break;
+        o = add(o, scale(d, its.t)); remaining -= its.t; maxt = remaining * lengthFactor; mint = EPSILON;
+    }
+    return transmittance;
+}
+/* Scene::sampleAttenuatedEmitterDirect (scene.cpp:886-931), both overloads: `its` = NULL for a medium interaction */
+static v3 sample_attenuated_emitter_direct(const orc_scene *s, v3 ref, v3 refN, const hit_t *its, int medium, int *interactions, float sx, float sy, direct_t *dr, uint64_t *shadow_rays) {
+    v3 value = sample_emitter_direct(s, ref, refN, sx, sy, dr, 2, NULL);
+    if (dr->pdf == 0) return V(0, 0, 0);
+    if (its && is_medium_transition(s, its->shape)) medium = target_medium(s, its->shape, its->ng, dr->d);
+    v3 tr = eval_transmittance(s, ref, its != NULL, dr->p, !dr->delta, medium, interactions, shadow_rays);
+    float r = 1.0f / dr->em_pdf;
+    return mul(value, scale(tr, r));                  /* value *= evalTransmittance(...) / emPdf */
+}
+
+/* src/integrators/path/volpath_simple.cpp:84-289 SimpleVolumetricPathTracer::Li (no subsurface) */
+static v3 volpath_simple_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters, float *alpha, const v3 *rxd, const v3 *ryd) {
+    const int maxDepth = s->d.max_depth, rrDepth = s->d.rr_depth;
+    const int strict = s->d.strict_normals != 0, hide = s->d.hide_emitters != 0;
+    hit_t its; v3 Li = V(0, 0, 0); int depth = 1, medium = s->d.sensor_medium;
+    int nullChain = 1, scattered = 0; float eta = 1.0f;
+    ++counters[0];
+    if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
+    *alpha = (s->d.opacity && !its.valid) ? 0.0f : 1.0f;         /* the transmittance-based alpha of records.inl:125-134 is not restated (classic film: no alpha) */
+    v3 throughput = V(1, 1, 1);
+    int emitted = 1, others = 1;                                  /* rRec.type: EEmittedRadiance / the bits of ERadianceNoEmission (they only ever change together) */
+    if (maxDepth == 1) others = 0;
+    int differentials = 1;                                        /* the sensor ray carries them; every later `ray = Ray(...)` does not */
+    while (depth <= maxDepth || maxDepth < 0) {
+        mrec_t mRec;
+        if (medium >= 0 && medium_sample_distance(&s->media[medium], o, d, 0, its.t, sp, &mRec)) {
+            const orc_medium *m = &s->media[medium];
+            { float r = 1.0f / mRec.pdf_success; throughput = mul(throughput, scale(mul(V(m->sigma_s[0], m->sigma_s[1], m->sigma_s[2]), mRec.transmittance), r)); }
+            if (others) {                                        /* EDirectMediumRadiance */
+                direct_t dRec; memset(&dRec, 0, sizeof(dRec)); dRec.ref = mRec.p;
+                int interactions = maxDepth - depth - 1; float sx, sy; next2D(sp, &sx, &sy);
+                v3 value = sample_attenuated_emitter_direct(s, mRec.p, V(0, 0, 0), NULL, medium, &interactions, sx, sy, &dRec, &counters[1]);
+                if (!is_zero(value)) Li = add(Li, scale(mul(throughput, value), phase_eval(m, neg(d), dRec.d)));
+            }
+            if ((depth + 1 >= maxDepth && maxDepth > 0) || !others) break;
+            v3 wo = phase_sample(m, neg(d), sp);                /* weight 1 for both phase functions */
+            o = mRec.p; d = wo; mint = 0; maxt = INFINITY; differentials = 0;
+            ++counters[0];
+            if (!ray_intersect(s, o, d, 0.0f, INFINITY, &its, 0)) its.t = INFINITY;
+            nullChain = 0; scattered = 1;
+        } else {
+            if (medium >= 0) { float r = 1.0f / mRec.pdf_failure; throughput = mul(throughput, scale(mRec.transmittance, r)); }
+            if (!its.valid) {
+                if (s->env_index >= 0 && emitted && (!hide || scattered)) {
+                    v3 value = mul(throughput, (s->d.env_texture && !s->env_constant && differentials) ? env_eval_filtered(s, d, *rxd, *ryd) : env_eval(s, d));
+                    if (medium >= 0) value = mul(value, medium_transmittance(&s->media[medium], mint, maxt));
+                    Li = add(Li, value);
+                }
+                break;
+            }
+            if (its.emitter >= 0 && emitted && (!hide || scattered))
+                Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
+            if (strict && (-dot(its.ng, d)) * its.wi.z < 0) break;
+            const smat_t smat = resolve_material(s, its.material, &its, differentials, o, rxd, ryd); const smat_t *bsdf = &smat;
+            if (others && sm_is_smooth(bsdf)) {                  /* EDirectSurfaceRadiance */
+                v3 refN = sm_has_backside(bsdf) ? V(0, 0, 0) : its.ns;
+                direct_t dRec; memset(&dRec, 0, sizeof(dRec)); dRec.ref = its.p;
+                int interactions = maxDepth - depth - 1; float sx, sy; next2D(sp, &sx, &sy);
+                v3 value = sample_attenuated_emitter_direct(s, its.p, refN, &its, medium, &interactions, sx, sy, &dRec, &counters[1]);
+                if (!is_zero(value)) {
+                    v3 wo = to_local(&its, dRec.d);
+                    if (!strict || dot(its.ng, dRec.d) * wo.z > 0) Li = add(Li, mul(mul(throughput, value), sm_eval(bsdf, its.wi, wo)));
+                }
+            }
+            float bsdfPdf = 0, bEta = 1; v3 woL = V(0, 0, 0); float sx, sy; next2D(sp, &sx, &sy); int sampledDelta = 0;
+            v3 bsdfVal = sm_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta, sp);
+            if (is_zero(bsdfVal)) break;
+            int rt_others = (depth + 1 < maxDepth || maxDepth < 0) && others, rt_emitted = 0;
+            if ((depth < maxDepth || maxDepth < 0) && others && sampledDelta && (sampledDelta != 2 || nullChain)) { rt_emitted = 1; nullChain = 1; }
+            else nullChain &= sampledDelta == 2;
+            if (!rt_others && !rt_emitted) break;
+            others = rt_others; emitted = rt_emitted;
+            v3 wo = to_world(&its, woL);
+            if (dot(its.ng, wo) * woL.z <= 0 && strict) break;
+            throughput = mul(throughput, bsdfVal); eta *= bEta;
+            if (is_medium_transition(s, its.shape)) medium = target_medium(s, its.shape, its.ng, wo);
+            o = its.p; d = wo; mint = EPSILON; maxt = INFINITY; differentials = 0;
+            ++counters[0];
+            if (!ray_intersect(s, o, d, EPSILON, INFINITY, &its, 0)) its.t = INFINITY;
+            scattered |= sampledDelta != 2;
+        }
+        if (depth++ >= rrDepth) {
+            float q = minf(maxf(maxf(throughput.x, throughput.y), throughput.z) * eta * eta, 0.95f);
+            if (next1D(sp) >= q) break;
+            float r = 1.0f / q; throughput = scale(throughput, r);
+        }
+    }
+    counters[2] += (uint64_t) depth;
+    *out_depth = depth;
+    return Li;
+}
+
 /* one pixel sample: src/librender/integrator.cpp:171-186 (renderBlock body) */
 static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t sidx, float *pos, int *depth, uint64_t *counters, float *log, int *nlog, float *alpha) {
     sampler_t sp; sampler_begin(&sp, s, px, py, sidx, log);
@@ -2039,7 +2226,7 @@ static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t si
     pos[0] = (float) (int32_t) px + jx; pos[1] = (float) (int32_t) py + jy;
     v3 o, d; float mint, maxt; camera_ray(s, pos[0], pos[1], &o, &d, &mint, &maxt);
     v3 rxd, ryd; camera_differentials(s, pos[0], pos[1], d, &rxd, &ryd);
-    v3 li = path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd);
+    v3 li = s->d.integrator == 1 ? volpath_simple_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd) : path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd);
     if (nlog) *nlog = sp.nlog;
     return li;
 }
@@ -2159,6 +2346,9 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_materials; ++i) { s->materials[i].m = d->materials[i]; s->materials[i].table = s->material_tables ? s->material_tables + (size_t) d->materials[i].k[1] : NULL; }
     s->d.material_tables = NULL;
     s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
+    s->media = (orc_medium *) dup(d->media, (size_t) (d->media ? d->n_media : 0) * sizeof(orc_medium)); s->d.media = NULL;
+    s->d.shape_media = (const int32_t *) dup(d->shape_media, (size_t) (d->shape_media ? (d->n_shapes + d->n_analytic) : 0) * 8);
+    if (!d->n_media) s->d.sensor_medium = -1;
     s->uv = (float *) dup(d->uv, (size_t) d->n_verts * 8);
     s->textures = (orc_texture *) dup(d->textures, (size_t) (d->textures ? d->n_textures : 0) * sizeof(orc_texture)); s->d.textures = NULL;
     for (uint32_t i = 0; i < d->n_materials; ++i) {       /* Texture::getAverage(): checkerboard.cpp:102-104, gridtexture.cpp:116-121, bitmap.cpp:504-514 (the bitmap's average is input: color0) */

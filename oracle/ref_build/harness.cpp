@@ -23,6 +23,8 @@
 #include <mitsuba/render/scene.h>
 #include <mitsuba/render/trimesh.h>
 #include <mitsuba/render/integrator.h>
+#include <mitsuba/render/medium.h>
+#include <mitsuba/render/phase.h>
 #include <mitsuba/render/sampler.h>
 #include <mitsuba/render/sensor.h>
 #include <mitsuba/render/film.h>
@@ -76,7 +78,9 @@ struct FEmitter { uint32_t type; int32_t shape; float radiance[3], weight, cutof
 struct FTexture { uint32_t type; float color0[3], color1[3], lineWidth, uoffset, voffset, uscale, vscale; uint32_t wrapU, wrapV, filter; float maxAnisotropy; uint32_t baseW, baseH; std::vector<float> base; };
 struct FInstance { uint32_t group, pad[3]; float toWorld[16], toObject[16]; };
 struct FAnalytic { uint32_t type; int32_t bsdf, emitter; uint32_t flags; float toWorld[16], toObject[16], radius, length; };
+struct FMedium { float sigmaA[3], sigmaS[3]; uint32_t strategy; float samplingDensity, mediumSamplingWeight; uint32_t phase; float g; uint32_t pad; };
 struct FScene {
+    std::vector<FMedium> media; std::vector<int32_t> shapeMedia; int32_t integrator = 0, sensorMedium = -1;     // MEDI section: volpath_simple scenes
     std::vector<FAnalytic> analytic; std::vector<FInstance> instances; std::vector<FTexture> textures; std::vector<int32_t> bsdfTexture;
     int32_t crop[4] = {0, 0, 0, 0};       // full film width / height, crop offset x / y (W, H = the crop window); all zero: no crop window
     uint32_t nVerts, nTris, nShapes, nBsdfs, nEmitters, hasN, hasUV, hasEnv;
@@ -121,6 +125,10 @@ static FScene loadScene(const char *path) {
             s.bsdfTexture.resize(s.nBsdfs); rd(f, s.bsdfTexture.data(), s.nBsdfs * 4);
         }
         else if (!memcmp(tag, "CROP", 4)) { rd(f, s.crop, 16); }
+        else if (!memcmp(tag, "MEDI", 4)) {
+            s.media.resize(n); for (FMedium &m : s.media) rd(f, &m, sizeof(FMedium));
+            rd(f, &s.integrator, 4); rd(f, &s.sensorMedium, 4); uint32_t pairs; rd(f, &pairs, 4); s.shapeMedia.resize(pairs * 2); rd(f, s.shapeMedia.data(), pairs * 8);
+        }
         else if (!memcmp(tag, "INST", 4)) { s.instances.resize(n); for (FInstance &a : s.instances) rd(f, &a, sizeof(FInstance)); }
         else { fprintf(stderr, "unknown section\n"); _exit(2); }
     }
@@ -276,6 +284,8 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
             if (fb.distr >= bsdfs.size()) { fprintf(stderr, "mask: the nested material must precede it\n"); _exit(2); }
             bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
+        } else if (fb.type == 13) {
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), Properties("null")));
         } else if (fb.type == 8) {
             Properties p("thindielectric");
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
@@ -343,6 +353,24 @@ static Built buildScene(const FScene &fs) {
         // configured after the scene knows its bounds (Scene::initialize -> emitter->createShape)
         em->configure();
     }
+    // participating media: `homogeneous` + its phase function (the constructor derives mediumSamplingWeight / the `single` channel itself)
+    std::vector<ref<Medium> > media;
+    for (const FMedium &fm : fs.media) {
+        static const char *strategies[] = {"balance", "single", "manual"};
+        Properties p("homogeneous"); p.setSpectrum("sigmaA", rgb(fm.sigmaA)); p.setSpectrum("sigmaS", rgb(fm.sigmaS)); p.setFloat("g", 0.0f);    // g: else the default preset's anisotropy rescales sigmaS (medium.cpp:30-34)
+        p.setString("strategy", strategies[fm.strategy]); if (fm.strategy == 2) p.setFloat("samplingDensity", fm.samplingDensity);
+        ref<Medium> med = static_cast<Medium *>(create(MTS_CLASS(Medium), p));
+        Properties pp(fm.phase == 1 ? "hg" : "isotropic"); if (fm.phase == 1) pp.setFloat("g", fm.g);
+        ref<PhaseFunction> ph = static_cast<PhaseFunction *>(create(MTS_CLASS(PhaseFunction), pp)); ph->configure();
+        med->addChild(ph); ph->setParent(med); med->configure();
+        media.push_back(med);
+    }
+    auto attachMedia = [&](Shape *shape, size_t index) {
+        if (fs.shapeMedia.empty()) return;
+        int32_t in = fs.shapeMedia[index * 2], ex = fs.shapeMedia[index * 2 + 1];
+        if (in >= 0) shape->addChild("interior", media[in]);
+        if (ex >= 0) shape->addChild("exterior", media[ex]);
+    };
     // shapes
     std::vector<ref<Shape> > groups, instancesKeep;
     for (uint32_t si = 0; si < fs.nShapes; ++si) {
@@ -360,6 +388,7 @@ static Built buildScene(const FScene &fs) {
             for (int k = 0; k < 3; ++k)
                 mesh->getTriangles()[t].idx[k] = fs.idx[(sh.firstTri + t) * 3 + k] - sh.firstVert;
         mesh->addChild(bsdfs[sh.bsdf]); bsdfs[sh.bsdf]->setParent(mesh);
+        attachMedia(mesh, si);
         if (sh.emitter >= 0) {
             const FEmitter &fe = fs.emitters[sh.emitter];
             Properties p("area"); p.setSpectrum("radiance", rgb(fe.radiance)); p.setFloat("samplingWeight", fe.weight);
@@ -398,6 +427,7 @@ static Built buildScene(const FScene &fs) {
         if (a.type >= 2) p.setBoolean("flipNormals", (a.flags & 1) != 0);
         ref<Shape> shape = static_cast<Shape *>(create(MTS_CLASS(Shape), p));
         shape->addChild(bsdfs[a.bsdf]); bsdfs[a.bsdf]->setParent(shape);
+        attachMedia(shape, fs.nShapes + ai);
         if (a.emitter >= 0) {
             const FEmitter &fe = fs.emitters[a.emitter];
             Properties ep("area"); ep.setSpectrum("radiance", rgb(fe.radiance)); ep.setFloat("samplingWeight", fe.weight);
@@ -442,12 +472,13 @@ static Built buildScene(const FScene &fs) {
         b.sensor = static_cast<Sensor *>(create(MTS_CLASS(Sensor), p));
         b.sensor->addChild(b.film); b.film->setParent(b.sensor);
         b.sensor->addChild(b.sampler); b.sampler->setParent(b.sensor);
+        if (fs.sensorMedium >= 0) b.sensor->addChild(media[fs.sensorMedium]);
         b.sensor->configure();
         b.scene->addChild(b.sensor); b.sensor->setParent(b.scene);
     }
     // integrator
     {
-        Properties p("path"); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
+        Properties p(fs.integrator == 1 ? "volpath_simple" : "path"); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
         p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
         b.integrator = static_cast<SamplingIntegrator *>(create(MTS_CLASS(Integrator), p));
         b.integrator->configure();

@@ -101,6 +101,11 @@ def golden_scenes():
         # a scene FILE: hand-written XML around the reference's own test asset (data/tests/bunny.ply, 69451 triangles, generated vertex normals), read by
         # mitsuba-im_amd/xml_scene.py + meshio.py and handed to the reference flattened
         "bunny_box": importlib.import_module("mitsuba-im_amd.xml_scene").load_scene(os.path.join(OUT, "meshes", "bunny_box.xml")),
+        # volpath_simple over homogeneous media: smoke cube behind a `null` boundary (isotropic, balance), glass block with a forward-scattering
+        # interior (hg, single), `null` sphere of haze (hg, manual); _global: the sensor sits in a thin fog that fills the room
+        "fog_box": scenes.fog_box(width=96, height=96, spp=16),
+        "fog_box_global": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=14, rr_depth=2),
+        "fog_box_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5),
     }
 
 
