@@ -37,6 +37,17 @@ typedef struct {
 /* src/shapes/instance.cpp: one placement of shape group `group`; to_world = the instance transform, to_object = its inverse as the
  * reference computes it.  Groups hold triangle meshes; nested instancing is not permitted (shapegroup.cpp:71-72). */
 typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[16]; } mi_instance;
+/* Participating medium: HomogeneousMedium (src/medium/homogeneous.cpp) with its phase function (src/phase/isotropic.cpp, src/phase/hg.cpp).  sigma_a / sigma_s:
+ * the final coefficients (`scale` and presets folded in by the caller, medium.cpp:27-37); strategy: MI_MEDIUM_BALANCE / SINGLE / MANUAL (`maximum` is refused);
+ * sampling_density, medium_sampling_weight: as the constructor derives them (homogeneous.cpp:168-222); phase: MI_PHASE_ISOTROPIC / MI_PHASE_HG with mean cosine g */
+#define MI_MEDIUM_BALANCE 0
+#define MI_MEDIUM_SINGLE 1
+#define MI_MEDIUM_MANUAL 2
+#define MI_PHASE_ISOTROPIC 0
+#define MI_PHASE_HG 1
+typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling_density, medium_sampling_weight; uint32_t phase; float g; uint32_t pad; } mi_medium;
+#define MI_INTEGRATOR_PATH 0            /* MIPathTracer, src/integrators/path/path.cpp */
+#define MI_INTEGRATOR_VOLPATH_SIMPLE 1  /* SimpleVolumetricPathTracer, src/integrators/path/volpath_simple.cpp */
 
 #define MI_BSDF_DIFFUSE 0         /* src/bsdfs/diffuse.cpp: reflectance                                                              */
 #define MI_BSDF_ROUGHCONDUCTOR 1  /* src/bsdfs/roughconductor.cpp + microfacet.h: alpha (alphaU), distr, eta, k, specular; flags: sampleVisible, anisotropic */
@@ -59,6 +70,7 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
                                      alpha = the factor of an enclosing <texture type="scale"> (1 = none); meshes need texture coordinates */
 #define MI_BSDF_NORMALMAP 12      /* src/bsdfs/normalmap.cpp: distr = nested record, bound texture = tangent-space normals (rgb = 0.5 + 0.5 n).  Adapters nest in the
                                      order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF */
+#define MI_BSDF_NULL 13           /* src/bsdfs/null.cpp: the index-matched boundary of a participating medium (straight pass-through, ENull; no parameters) */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
@@ -118,8 +130,8 @@ typedef struct {
     uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
     uint32_t opacity;            /* 1: alpha = 1 where the camera ray hits a surface, else 0 (RadianceQueryRecord::EOpacity, records.inl:121-137:
                                     the responsive drivers and films with an alpha channel); 0: alpha = 1 (classic film without alpha, integrator.cpp:160-161) */
-    uint32_t reserved0;          /* must be 0 (round 1: fast_math; one set of kernels ships -- strict IEEE arithmetic, no contraction, exact divide / sqrt,
-                                    radiance bit-identical to the oracle and to a strict-IEEE build of the reference; anything else: MI_ERR_UNSUPPORTED) */
+    uint32_t integrator;         /* MI_INTEGRATOR_PATH (0, default) or MI_INTEGRATOR_VOLPATH_SIMPLE: the same loop over participating media (mi_scene_set_media);
+                                    anything else: MI_ERR_UNSUPPORTED.  (Round 1 had `fast_math` here; one set of kernels ships: strict IEEE arithmetic) */
 } mi_render_params;
 
 typedef struct { uint32_t x0, y0, x1, y1; } mi_tile;   /* pixel rectangle [x0,x1) x [y0,y1) in GLOBAL film coordinates */
@@ -153,6 +165,10 @@ int mi_scene_set_triangles(mi_scene *s, const float *pos, const float *nrm, cons
 int mi_scene_set_analytic(mi_scene *s, const mi_analytic *shapes, uint32_t n);
 /* instances of shape groups; primitive index of the i-th: n_tris + n_analytic + i (they come last in Scene::getShapes order here) */
 int mi_scene_set_instances(mi_scene *s, const mi_instance *instances, uint32_t n);
+/* Media of the scene and who refers to them (Shape::addChild "interior" / "exterior", src/librender/shape.cpp:156-170; Sensor medium, src/librender/emitter.cpp:51-54):
+ * shape_media[(n_shapes + n_analytic)][2] = (interior, exterior) medium index of every mesh, then every analytic shape, -1 = none; sensor_medium = the medium the
+ * camera sits in or -1.  Only the volumetric integrators look at them. */
+int mi_scene_set_media(mi_scene *s, const mi_medium *media, uint32_t n, const int32_t *shape_media, uint32_t n_pairs, int32_t sensor_medium);
 int mi_scene_set_materials(mi_scene *s, const mi_material *materials, uint32_t n);
 int mi_scene_set_textures(mi_scene *s, const mi_texture *textures, uint32_t n);
 /* MIP levels of the bitmap textures: levels[n_levels][3] = (width, height, offset of the level's first float in `texels`), RGB floats row-major */

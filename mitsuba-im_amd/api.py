@@ -49,7 +49,7 @@ class MiInstance(C.Structure):
 
 class MiRenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_uint32), ("hide_emitters", C.c_uint32),
-                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("sampler", C.c_uint32), ("spp", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_uint32), ("planes_per_batch", C.c_uint32), ("opacity", C.c_uint32), ("integrator", C.c_uint32)]
 
 
 class MiTile(C.Structure):
@@ -63,7 +63,7 @@ class MiStats(C.Structure):
 
 
 EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_scene_create", "mi_scene_destroy", "mi_scene_set_triangles",
-           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_envmap_filter", "mi_scene_set_camera", "mi_scene_set_film",
+           "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_media", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_envmap_filter", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_scene_ray_intersect", "mi_scene_clone", "mi_render_merge_film", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays", "mi_debug_sincosf"]
@@ -91,6 +91,7 @@ class Lib:
         L.mi_scene_set_triangles.argtypes = [vp, vp, vp, vp, vp, u32, u32, vp, u32]
         L.mi_scene_set_analytic.argtypes = [vp, vp, u32]
         L.mi_scene_set_instances.argtypes = [vp, vp, u32]
+        L.mi_scene_set_media.argtypes = [vp, vp, u32, vp, u32, C.c_int32]
         L.mi_scene_set_material_tables.argtypes = [vp, vp, u32]
         L.mi_scene_set_textures.argtypes = [vp, vp, u32]
         L.mi_scene_set_texture_data.argtypes = [vp, vp, u32, vp, u64]
@@ -195,6 +196,14 @@ class Scene:
             for i, a in enumerate(insts):
                 r = MiInstance(a["group"]); r.to_world[:] = a["to_world"].reshape(-1).tolist(); r.to_object[:] = a["to_object"].reshape(-1).tolist(); arr[i] = r
             L.check(L.L.mi_scene_set_instances(h, C.cast(arr, C.c_void_p), len(insts)))
+        media = sc.get("media") or []
+        if media:                                       # mi_medium has the layout of the oracle's record (oracle/binding.py OrcMedium): 6 floats, uint, 2 floats, uint, float, uint
+            buf = np.zeros(len(media), dtype=[("sigma_a", np.float32, 3), ("sigma_s", np.float32, 3), ("strategy", np.uint32), ("sampling_density", np.float32),
+                                              ("medium_sampling_weight", np.float32), ("phase", np.uint32), ("g", np.float32), ("pad", np.uint32)])
+            for i, m in enumerate(media):
+                buf[i] = (m["sigma_a"], m["sigma_s"], m["strategy"], m["sampling_density"], m["medium_sampling_weight"], m["phase"], m["g"], 0)
+            sm = np.ascontiguousarray(sc.shape_media, np.int32)
+            L.check(L.L.mi_scene_set_media(h, buf.ctypes.data_as(C.c_void_p), len(media), sm.ctypes.data_as(C.c_void_p), len(sm), int(sc.sensor_medium)))
         L.check(L.L.mi_scene_set_materials(h, C.cast(mats, C.c_void_p), len(sc.bsdfs)))
         texs = sc.get("textures") or []
         if texs:
@@ -255,13 +264,13 @@ class Render:
     """mi_render handle: the integrator instance (MonteCarloIntegrator properties + sampler)."""
 
     def __init__(self, scene, max_depth=None, rr_depth=None, sampler=None, spp=None, seed=None, device=0, planes_per_batch=0,
-                 strict_normals=None, hide_emitters=None, opacity=False):
+                 strict_normals=None, hide_emitters=None, opacity=False, integrator=None):
         sc = scene.sc; L = scene.L; self.L = L; self.scene = scene
         p = MiRenderParams(sc.max_depth if max_depth is None else max_depth, sc.rr_depth if rr_depth is None else rr_depth,
                            sc.strict_normals if strict_normals is None else int(strict_normals),
                            sc.hide_emitters if hide_emitters is None else int(hide_emitters),
                            sc.sampler if sampler is None else sampler, sc.spp if spp is None else spp,
-                           sc.seed if seed is None else seed, device, planes_per_batch, int(opacity), 0)
+                           sc.seed if seed is None else seed, device, planes_per_batch, int(opacity), int(sc.get("integrator", 0) or 0) if integrator is None else int(integrator))
         self.params = p
         h = C.c_void_p(); L.check(L.L.mi_render_create(scene.h, C.byref(p), C.byref(h))); self.h = h
 

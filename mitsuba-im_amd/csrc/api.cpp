@@ -21,6 +21,8 @@ void mi_launch_shade_rc_env(const DScene &, const RenderConst &, const Queues &,
 void mi_launch_shade_rcw(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shade_rcw_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
+void mi_launch_shade_vol(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shadow_vol(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_film_layout(const float *, const float *, float *, int, int, int, int, hipStream_t);
@@ -175,12 +177,25 @@ int mi_scene_set_instances(mi_scene *s, const mi_instance *a, uint32_t n) {
         if (a[i].to_world[12] != 0 || a[i].to_world[13] != 0 || a[i].to_world[14] != 0 || a[i].to_world[15] != 1.0f) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_instances: toWorld must be affine");
     s->h.instances.assign(a, a + n); s->h.committed = false; return MI_OK;
 }
+int mi_scene_set_media(mi_scene *s, const mi_medium *media, uint32_t n, const int32_t *shapeMedia, uint32_t nPairs, int32_t sensorMedium) {
+    if (!s || (n && (!media || !shapeMedia))) return fail(MI_ERR_INVALID, "mi_scene_set_media: null argument");
+    if (n > 254) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_media: at most 254 media");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (media[i].strategy > MI_MEDIUM_MANUAL) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_media: sampling strategies balance, single and manual are implemented (not `maximum`)");   // homogeneous.cpp:192-226
+        if (media[i].phase > MI_PHASE_HG) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_media: phase functions isotropic and hg are implemented");
+        if (media[i].phase == MI_PHASE_HG && !(media[i].g > -1 && media[i].g < 1)) return fail(MI_ERR_INVALID, "The anisotropy parameter 'g' must be in the range (-1, 1)!");   // hg.cpp:50-51
+        for (int c = 0; c < 3; ++c) if (!(media[i].sigma_a[c] >= 0) || !(media[i].sigma_s[c] >= 0)) return fail(MI_ERR_INVALID, "mi_scene_set_media: negative coefficient");
+    }
+    for (uint32_t i = 0; i < nPairs * 2u; ++i) if (shapeMedia[i] < -1 || shapeMedia[i] >= (int32_t) n) return fail(MI_ERR_INVALID, "mi_scene_set_media: a shape refers to a missing medium");
+    if (sensorMedium < -1 || sensorMedium >= (int32_t) n) return fail(MI_ERR_INVALID, "mi_scene_set_media: the sensor refers to a missing medium");
+    s->h.media.assign(media, media + n); s->h.shapeMedia.assign(shapeMedia, shapeMedia + (size_t) nPairs * 2u); s->h.sensorMedium = sensorMedium; s->h.committed = false; return MI_OK;
+}
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
     auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_NORMALMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_NULL) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if (m[i].type == MI_BSDF_BUMPMAP || m[i].type == MI_BSDF_NORMALMAP) {
             // adapters nest in the order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF
@@ -252,7 +267,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dPacketGroups, &dPacketExact, &dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dMedia, &dPrimMedia, &dPacketGroups, &dPacketExact, &dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -332,10 +347,13 @@ int SceneHost::upload(int dev) {
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
     d.has_adapters = 0;
-    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type >= MI_BSDF_MIXTURE) d.has_adapters = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) d.has_adapters = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     const char *noPacket = getenv("MI355PT_NO_PACKET");
-    d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
+    d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && media.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     if (up(&dPacketGroups, packetGroups) | up(&dPacketExact, packetExact)) return 1;
+    // participating media: scenes that carry them always walk the tree (the transmittance walk of the volumetric shadow stage is a closest-hit traversal)
+    if (!media.empty()) { if (up(&dMedia, mediaD) | up(&dPrimMedia, primMedia)) return 1; }
+    d.media = (const MediumD *) dMedia; d.prim_media = (const uint32_t *) dPrimMedia; d.n_media = (uint32_t) mediaD.size(); d.sensor_medium = media.empty() ? -1 : sensorMedium;
     d.packet_groups = (const PacketGroupD *) dPacketGroups; d.packet_exact = (const TriAccelD *) dPacketExact; d.packet_scale = packetScale;
     for (int i = 0; i < 3; ++i) d.packet_gk[i] = packetGK[i];
     committed = true;
@@ -391,6 +409,11 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
     for (const mi_emitter &e : s->h.emitters) {
         if (e.type == MI_EMITTER_AREA && (e.shape < 0 || (size_t) e.shape >= s->h.shapes.size() + s->h.analytic.size())) return fail(MI_ERR_INVALID, "mi_scene_commit: area emitter without a shape");
         if (e.type == MI_EMITTER_ENVMAP && s->h.envRGB.empty()) return fail(MI_ERR_INVALID, "mi_scene_commit: envmap emitter listed but mi_scene_set_envmap was not called");
+    }
+    if (!s->h.media.empty()) {
+        if (s->h.shapeMedia.size() != (s->h.shapes.size() + s->h.analytic.size()) * 2u) return fail(MI_ERR_INVALID, "mi_scene_commit: mi_scene_set_media needs one (interior, exterior) pair per mesh and per analytic shape");
+        for (size_t i = 0; i < s->h.shapes.size(); ++i)
+            if (s->h.shapes[i].group && (s->h.shapeMedia[i * 2] >= 0 || s->h.shapeMedia[i * 2 + 1] >= 0)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: media on the members of a shape group are not implemented");
     }
     if (s->h.emitters.empty()) return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: scene without emitters (the reference would add a sunsky emitter)");
     ensureSobolTables();
@@ -448,6 +471,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     }
     if (r->scene->h.d.n_instances) ALLOC(Q.hitInst, int32_t, slots); else Q.hitInst = nullptr;
     ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, slots); ALLOC(Q.shD, float4, slots); ALLOC(Q.shC, float4, slots);
+    if (r->rc.integrator == MI_INTEGRATOR_VOLPATH_SIMPLE) { ALLOC(Q.shT, float4, slots); ALLOC(Q.shX, float4, slots); } else { Q.shT = nullptr; Q.shX = nullptr; }
     ALLOC(Q.acc, float4, slots); ALLOC(Q.pos, float2, slots); ALLOC(Q.shCount, uint32_t, grid);
     ALLOC(Q.counters, unsigned long long, 4);
     HIPCHK(hipMemset(Q.counters, 0, 32));
@@ -475,13 +499,23 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
-    if (p->reserved0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: reserved0 must be 0 (the fast_math kernel set of round 1 is gone: one set of kernels, strict IEEE arithmetic)");
+    if (p->integrator > MI_INTEGRATOR_VOLPATH_SIMPLE) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0) and volpath_simple (1) are implemented");
+    const bool vol = p->integrator == MI_INTEGRATOR_VOLPATH_SIMPLE;
+    if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for
+        if (s->h.envIndex >= 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple with an environment emitter (envmap / constant) is not implemented");
+        for (const mi_material &m : s->h.materials)
+            if (m.type == MI_BSDF_MASK || m.type == MI_BSDF_THINDIELECTRIC || m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP)
+                return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple with mask / thindielectric / mixturebsdf / bumpmap / normalmap materials is not implemented");
+        if (s->h.d.packet_n) return fail(MI_ERR_INVALID, "mi_render_create: volpath_simple needs the tree traversal (scenes with media always have it; set MI355PT_NO_PACKET=1 for a scene without media)");
+        if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth beyond 250");
+    }
     if (p->sampler == MI_SAMPLER_SOBOL) {
         if (!s->h.d.sobol_m32) return fail(MI_ERR_INVALID, "mi_render_create: Sobol tables not loaded before mi_scene_commit (mi_set_sobol_tables)");
         // dimensions consumed: 2 + per bounce (2 NEE + 2 BSDF + 1 RR, + 1 where a BSDF draws from the sampler itself: roughdielectric, EUsesSampler) + the dim-4 skip
         // (sobol.cpp:218-251 aborts beyond the table)
         int depth = p->max_depth < 0 ? 250 : p->max_depth;
         int perBounce = 5; for (const mi_material &m : s->h.materials) if (m.type == MI_BSDF_ROUGHDIELECTRIC) perBounce = 6;
+        if (vol) perBounce += 2;      // + the one or two draws of HomogeneousMedium::sampleDistance per iteration
         if (p->max_depth > 0 && (uint32_t) (3 + perBounce * depth) > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "Lookup dimension exceeds the direction number table size! You may have to reduce the 'maxDepth' parameter of your integrator.");
         if (p->max_depth < 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth = -1 with the Sobol sampler needs more dimensions than are loaded");
     }
@@ -490,6 +524,8 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     struct Guard { mi_render *r; ~Guard() { if (r) mi_render_destroy(r); } } guard{r};      // every early return below releases what was created so far
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
     r->rc.sobol_scramble = 0;
+    // volumetric integrators: the radiance-type bits and the sensor's medium of a fresh path (kernels_vol.hip; volpath_simple.cpp:103-104: maxDepth = 1 gathers emitted radiance only)
+    r->rc.integrator = p->integrator; r->rc.state_init = vol ? ((1u << 16) | (p->max_depth == 1 ? 0u : (1u << 17)) | (1u << 18) | ((uint32_t) (s->h.d.sensor_medium + 1) << 20)) : 0u;
     if (p->sampler == MI_SAMPLER_SOBOL && p->seed) {          // SobolSampler: a nonzero `scramble` goes through sampleTEA (sobol.cpp:96-102; qmc.h:146-156, 4 rounds)
         uint32_t v0 = (uint32_t) p->seed, v1 = (uint32_t) (p->seed >> 32), sum = 0;
         for (int i = 0; i < 4; ++i) {
@@ -503,6 +539,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->sampler == MI_SAMPLER_SOBOL) {
         // fold the direction matrices into 4-bit lookup tables for the dimensions / index bits this render can touch
         int perBounceDims = 5; for (const mi_material &m : s->h.materials) if (m.type == MI_BSDF_ROUGHDIELECTRIC) perBounceDims = 6;
+        if (vol) perBounceDims += 2;
         uint32_t sppBits = 0; while ((1ull << sppBits) < p->spp) ++sppBits;
         const uint32_t bits = (s->h.logRes > 1 ? 2 * s->h.logRes : 0) + sppBits + 1;
         const uint32_t nibs = std::max<uint32_t>(1, (bits + 3) / 4), dims = std::min<uint32_t>(s->h.d.sobol_dims, (uint32_t) (4 + perBounceDims * p->max_depth));
@@ -593,9 +630,15 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
         mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
+        if (r->rc.integrator == MI_INTEGRATOR_VOLPATH_SIMPLE) {      // the same loop over media: its own shade and shadow stages (kernels_vol.hip)
+            const size_t lds = r->rc.sampler == MI_SAMPLER_SOBOL ? (size_t) r->rc.nib_dims * r->rc.nib_count * 64 : 16;
+            mark(r, 2, evUsed, st); mi_launch_shade_vol(sc, r->rc, Q, buf, r->gridShade, lds, st);
+            if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow_vol(sc, Q, r->gridShadow, st); }
+        } else {
         if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) mi_launch_env_primary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
         mark(r, 2, evUsed, st); mi_launch_shade(sc, r->ldsTables, r->rc, Q, buf, r->gridShade, st);
         if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
+        }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
             std::vector<uint32_t> cnt(r->grid);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WG) void k_generate(DScene sc, RenderConst rc, Queu
         q.rayO[0][slot] = make_float4(o.x, o.y, o.z, mint);
         q.rayD[0][slot] = make_float4(d.x, d.y, d.z, maxt);
         // packed: dim | depth << 8 | flags << 16   (flags bit0: facingRef of the previous vertex)
-        q.st0[0][slot] = make_uint4((uint32_t) pid, ss.a, ss.b, ss.dim | (1u << 8));
+        q.st0[0][slot] = make_uint4((uint32_t) pid, ss.a, ss.b, ss.dim | (1u << 8) | rc.state_init);
         q.st1[0][slot] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);      // throughput rgb, eta
         q.st2[0][slot] = 0.0f;                                      // bsdfPdf of the segment that produced this ray
         q.pos[pid] = make_float2(sx, sy);

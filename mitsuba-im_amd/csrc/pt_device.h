@@ -940,6 +940,7 @@ DEV v3 rcSample(const MaterialD &mt, v3 wi, float u, float v, v3 &wo, float &pdf
 #define MI_BSDF_T_DIELECTRIC 3u
 #define MI_BSDF_T_THINDIELECTRIC 8u
 #define MI_BSDF_T_MASK 9u
+#define MI_BSDF_T_NULL 13u
 #define MI_BSDF_T_PLASTIC 4u
 // src/libcore/util.cpp:653-683 fresnelDielectricExt
 DEV float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {
@@ -1200,6 +1201,7 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
         else if (m.type == MI_BSDF_T_DIFFTRANS) w = dtSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_ROUGHPLASTIC) w = rpSample(sc, m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_THINDIELECTRIC) w = thinDielectricSample(m, wi, u, wo, pdf, eta, delta, nullComp);
+        else if (m.type == MI_BSDF_T_NULL) { wo = V(-wi.x, -wi.y, -wi.z); pdf = 1.0f; eta = 1.0f; delta = true; nullComp = true; w = V(1, 1, 1); }      // src/bsdfs/null.cpp:56-66
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);
         if (flipped && !isZero(w) && pdf != 0) wo.z = -wo.z;      // twosided.cpp:176-180
         return w;
@@ -1424,7 +1426,7 @@ DEV uint32_t cdfSample(P cdf, uint32_t n, float x) {
     while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
     return index;
 }
-struct Direct { v3 p, n, d; float dist, pdf; int emitter; bool delta; /* !isOnSurface: point / spot / directional */ };
+struct Direct { v3 p, n, d; float dist, pdf; float em_pdf; /* probability of the chosen emitter (RAW) */ int emitter; bool delta; /* !isOnSurface: point / spot / directional */ };
 // src/emitters/area.cpp:106-111
 template <bool L>
 DEV v3 emitterEval(const Tabs<L> &tb, int e, v3 ns, v3 d) {
@@ -1434,7 +1436,8 @@ DEV v3 emitterEval(const Tabs<L> &tb, int e, v3 ns, v3 d) {
 // Scene::sampleEmitterDirect (src/librender/scene.cpp:860-884) without the visibility test (the shadow queue does it)
 // -> AreaLight::sampleDirect (src/emitters/area.cpp:160-176) -> Shape::sampleDirect (src/librender/shape.cpp:102-115)
 // -> TriMesh::samplePosition (src/librender/trimesh.cpp:413-425) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
-template <bool ENV, bool AN, bool L>
+// RAW (Scene::sampleAttenuatedEmitterDirect, scene.cpp:886-931): the value is NOT yet divided by the emitter-selection probability (dr.em_pdf): the transmittance joins it first
+template <bool ENV, bool AN, bool L, bool RAW = false>
 DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
     uint32_t ei = cdfSample(tb.emitter_cdf, sc.n_emitters, sx);
     float c0 = tb.emitter_cdf[ei], c1 = tb.emitter_cdf[ei + 1];
@@ -1483,7 +1486,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
         }
         if (dr.pdf != 0) {
             dr.emitter = (int) ei; dr.pdf *= emPdf;
-            float r = 1.0f / emPdf; value = value * r;
+            if (RAW) dr.em_pdf = emPdf; else { float r = 1.0f / emPdf; value = value * r; }
             return value;
         }
         return V(0, 0, 0);
@@ -1496,7 +1499,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
         dr.pdf = pdf; dr.p = ref + dw * farT; dr.n = normalize(ld3(sc.env_bs_center) - dr.p); dr.dist = farT; dr.d = dw;
         { float r = 1.0f / pdf; value = value * r; }
         dr.emitter = (int) ei; dr.pdf *= emPdf;
-        { float r = 1.0f / emPdf; value = value * r; }
+        if (RAW) dr.em_pdf = emPdf; else { float r = 1.0f / emPdf; value = value * r; }
         return value;
     }
     if (AN && em.analytic >= 0) {                                // area light on an analytic shape: no sample reuse
@@ -1534,7 +1537,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
     if (dr.pdf != 0) {
         dr.emitter = (int) ei;
         dr.pdf *= emPdf;
-        float r = 1.0f / emPdf; value = value * r;
+        if (RAW) dr.em_pdf = emPdf; else { float r = 1.0f / emPdf; value = value * r; }
         return value;
     }
     return V(0, 0, 0);
@@ -1553,6 +1556,62 @@ DEV float pdfEmitterDirect(const DScene &sc, const Tabs<L> &tb, int e, v3 ref, v
     return pdf * (a.w * sc.emitter_norm);
 }
 DEV float miWeight(float a, float b) { a *= a; b *= b; return a / (a + b); }   // src/integrators/path/path.cpp:296-300
+
+// ---------------------------------------------------------------------------------------------- participating media (volumetric integrators)
+// include/mitsuba/core/math.h:185-195 (Linux x86_64): fastexp / fastlog go through the DOUBLE-precision routines, rounded to float
+DEV float miFastExp(float v) { return (float) exp((double) v); }
+DEV float miFastLog(float v) { return (float) log((double) v); }
+struct MediumRec { float t; v3 p; v3 transmittance; float pdfSuccess, pdfFailure; };
+// HomogeneousMedium::evalTransmittance (src/medium/homogeneous.cpp:266-273) over [mint, maxt] of a ray
+DEV v3 mediumTransmittance(const MediumD &m, float mint, float maxt) {
+    const float negLength = mint - maxt;
+    return V(m.sigma_t[0] != 0 ? miFastExp(m.sigma_t[0] * negLength) : 1.0f, m.sigma_t[1] != 0 ? miFastExp(m.sigma_t[1] * negLength) : 1.0f, m.sigma_t[2] != 0 ? miFastExp(m.sigma_t[2] * negLength) : 1.0f);
+}
+// HomogeneousMedium::sampleDistance (homogeneous.cpp:275-349), strategies balance / single / manual; draws one or two 1-D samples
+template <typename P>
+DEV bool mediumSampleDistance(const MediumD &m, v3 o, v3 d, float mint, float maxt, SamplerState &ss, uint32_t kind, SobolTabT<P> st, MediumRec &r) {
+    float rnd = next1D(ss, kind, st), sampled, density = m.sampling_density;
+    if (rnd < m.medium_sampling_weight) {
+        rnd /= m.medium_sampling_weight;
+        if (m.strategy == 0u) { int ch = (int) (next1D(ss, kind, st) * 3); if (ch > 2) ch = 2; density = ch == 0 ? m.sigma_t[0] : (ch == 1 ? m.sigma_t[1] : m.sigma_t[2]); }
+        sampled = -miFastLog(1 - rnd) / density;
+    } else sampled = INFINITY;
+    const float distSurf = maxt - mint; bool success = true;
+    if (sampled < distSurf) {
+        r.t = sampled + mint; r.p = o + d * r.t;
+        if (r.p.x == o.x && r.p.y == o.y && r.p.z == o.z) success = false;
+    } else { sampled = distSurf; success = false; }
+    if (m.strategy == 0u) {
+        r.pdfFailure = 0; r.pdfSuccess = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float tmp = miFastExp(-m.sigma_t[i] * sampled); r.pdfFailure += tmp; r.pdfSuccess += m.sigma_t[i] * tmp; }
+        r.pdfFailure /= 3; r.pdfSuccess /= 3;
+    } else { r.pdfFailure = miFastExp(-density * sampled); r.pdfSuccess = density * r.pdfFailure; }
+    r.transmittance = V(miFastExp(m.sigma_t[0] * (-sampled)), miFastExp(m.sigma_t[1] * (-sampled)), miFastExp(m.sigma_t[2] * (-sampled)));
+    r.pdfSuccess = r.pdfSuccess * m.medium_sampling_weight;
+    r.pdfFailure = m.medium_sampling_weight * r.pdfFailure + (1 - m.medium_sampling_weight);
+    if (maxf(maxf(r.transmittance.x, r.transmittance.y), r.transmittance.z) < 1e-20f) r.transmittance = V(0, 0, 0);
+    return success;
+}
+// IsotropicPhaseFunction::eval (src/phase/isotropic.cpp:74-76), HGPhaseFunction::eval (src/phase/hg.cpp:108-111); wi = -ray.d
+DEV float phaseEval(const MediumD &m, v3 wi, v3 wo) {
+    if (m.phase == 0u) return MI_INV_FOURPI;
+    const float g = m.g, temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
+    return MI_INV_FOURPI * (1 - g * g) / (temp * sqrtf(temp));
+}
+// IsotropicPhaseFunction::sample (isotropic.cpp:61-66), HGPhaseFunction::sample (hg.cpp:74-99); the weight is 1 for both
+DEV v3 phaseSample(const MediumD &m, v3 wi, float sx, float sy) {
+    if (m.phase == 0u) return uniformSphere(sx, sy);
+    const float g = m.g; float cosTheta;
+    if (fabsf(g) < MI_EPSILON) cosTheta = 1 - 2 * sx;
+    else { const float sqrTerm = (1 - g * g) / (1 - g + 2 * g * sx); cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g); }
+    float sinTheta = sqrtf(maxf(1.0f - cosTheta * cosTheta, 0.0f)), sinPhi, cosPhi;
+    sincos2pi(sy, sinPhi, cosPhi);
+    const v3 n = V(-wi.x, -wi.y, -wi.z); v3 fs, ft; coordinateSystem(n, fs, ft);          // Frame(-pRec.wi).toWorld
+    return (fs * (sinTheta * cosPhi) + ft * (sinTheta * sinPhi)) + n * cosTheta;
+}
+// Shape::isMediumTransition / Intersection::getTargetMedium (include/mitsuba/render/records.inl:77-86): index of the medium on the side `d` points to, -1 = none
+DEV int targetMedium(uint32_t pm, v3 n, v3 d) { return (int) (dot(d, n) > 0 ? (pm >> 16) : (pm & 0xFFFFu)) - 1; }
 
 // include/mitsuba/core/rfilter.h:76-77
 DEV float filterEvalDiscretized(const DScene &sc, float x) {

@@ -106,6 +106,9 @@ struct AnalyticD {
     float length, inv_area; int32_t material, emitter;
 };
 
+// Homogeneous participating medium + phase function (mi_medium), 64 B: sigma_t precomputed (Medium: m_sigmaT = m_sigmaA + m_sigmaS)
+struct MediumD { float sigma_s[3]; uint32_t strategy; float sigma_t[3]; uint32_t phase; float sampling_density, medium_sampling_weight, g, pad; float pad2[4]; };
+
 // Everything a kernel needs to know about the scene; passed by value.
 struct DScene {
     const BvhNode *nodes; const TriAccelD *tris; const TriShade *shade; const uint32_t *i2; const float *nrm;
@@ -139,6 +142,8 @@ struct DScene {
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
     // triangles dropped), exact Wald records in ORIGINAL triangle order for pass 2, largest |coordinate| of the scene box (error-margin scale)
     const struct PacketGroupD *packet_groups; const TriAccelD *packet_exact; uint32_t packet_gk[3]; float packet_scale;
+    // participating media (volumetric integrators only): prim_media[primitive] = (interior + 1) | (exterior + 1) << 16 for triangles, then analytic shapes; 0 = none
+    const MediumD *media; const uint32_t *prim_media; uint32_t n_media; int32_t sensor_medium;
     uint32_t has_adapters;   // mixturebsdf / bumpmap / normalmap records present: the WRAP variants of k_shade
     uint32_t has_roughconductor, has_diffuse;   // non-diffuse / plain diffuse materials present: select the shade kernel variants (both: two launches per bounce, shade.h)
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
@@ -160,5 +165,7 @@ struct RenderConst {
     // {index lo, index hi, dim-0 bits, dim-1 bits} (api.cpp buildSobolLookupTables), XORed together in k_generate; null when log_res <= 1
     const uint4 *sobol_frame, *sobol_px, *sobol_py; uint32_t sobol_nframes;   // frames beyond the table (parity entry point only) take sobolLookUp
     float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)
+    uint32_t integrator;                  // MI_INTEGRATOR_*
+    uint32_t state_init;                  // bits ORed into the state word st0.w of a fresh path (volumetric integrators: radiance-type bits, the sensor's medium)
     uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
 };

@@ -15,6 +15,7 @@ struct Queues {
     float4 *hit;
     int32_t *hitInst;                           // only in scenes with instances: instance index of the hit (-1: a scene-level primitive)
     float4 *shO, *shD, *shC;
+    float4 *shT, *shX;                          // volumetric integrators only: throughput and BSDF / phase value of a shadow record (the transmittance between the two enters before them, shade_vol.h)
     float4 *acc; float2 *pos;
     uint32_t *count[2]; uint32_t *shCount;      // per segment
     unsigned long long *counters;               // [0] closest-hit rays, [1] shadow rays, [2] sum of path depths

@@ -173,11 +173,11 @@ void SceneHost::commitHost() {
     std::vector<V3> tlo(np), thi(np), cen(np);
     // flags of a shape's material as MIPathTracer::Li sees the (possibly nested) BSDF: bit1 EBackSide / ETransmission somewhere (dRec.refN = 0, records.inl:160-164),
     // bit2 no smooth component (no emitter sampling, path.cpp:173-174), bit3 anything but a plain diffuse record (class bit of the shading stage)
-    auto leafBackside = [&](const mi_material &mat) { return (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS || mat.type == MI_BSDF_THINDIELECTRIC; };
+    auto leafBackside = [&](const mi_material &mat) { return (mat.flags & MI_BSDF_FLAG_TWOSIDED) != 0 || mat.type == MI_BSDF_DIELECTRIC || mat.type == MI_BSDF_ROUGHDIELECTRIC || mat.type == MI_BSDF_DIFFTRANS || mat.type == MI_BSDF_THINDIELECTRIC || mat.type == MI_BSDF_NULL; };
     // a `diffuse` with zero reflectance has no component at all -> not ESmooth -> Li skips emitter sampling (diffuse.cpp:99-102, path.cpp:174-176);
     // conductor / dielectric register delta components only
     auto leafSmooth = [&](const mi_material &mat) { return mat.type == MI_BSDF_DIFFUSE ? (((mat.flags >> 8) & 0xFFFFu) != 0 || std::max(std::max(mat.reflectance[0], mat.reflectance[1]), mat.reflectance[2]) > 0)
-                                                                                         : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC && mat.type != MI_BSDF_THINDIELECTRIC); };
+                                                                                         : (mat.type != MI_BSDF_CONDUCTOR && mat.type != MI_BSDF_DIELECTRIC && mat.type != MI_BSDF_THINDIELECTRIC && mat.type != MI_BSDF_NULL); };
     auto materialFlags = [&](int bsdf) {
         const mi_material *mat = &materials[bsdf]; bool masked = false, wrapped = false;
         if (mat->type == MI_BSDF_MASK) { masked = true; mat = &materials[mat->distr]; }          // mask.cpp:104-121: the nested BSDF's components + an ENull | EFrontSide | EBackSide one
@@ -275,6 +275,20 @@ void SceneHost::commitHost() {
     enlarge(glo[ng], ghi[ng]);
     aabbLo[0] = glo[ng].x; aabbLo[1] = glo[ng].y; aabbLo[2] = glo[ng].z; aabbHi[0] = ghi[ng].x; aabbHi[1] = ghi[ng].y; aabbHi[2] = ghi[ng].z;
 
+    // --- participating media: device records; per primitive the (interior, exterior) pair of its shape (triangles, then analytic shapes)
+    mediaD.assign(media.size(), MediumD{});
+    for (size_t i = 0; i < media.size(); ++i) {
+        MediumD &m = mediaD[i]; const mi_medium &in = media[i];
+        for (int c = 0; c < 3; ++c) { m.sigma_s[c] = in.sigma_s[c]; m.sigma_t[c] = in.sigma_a[c] + in.sigma_s[c]; }     // Medium: m_sigmaT = m_sigmaA + m_sigmaS (medium.cpp:36)
+        m.strategy = in.strategy; m.phase = in.phase; m.sampling_density = in.sampling_density; m.medium_sampling_weight = in.medium_sampling_weight; m.g = in.g;
+    }
+    primMedia.clear();
+    if (!media.empty()) {
+        primMedia.assign(nt + na, 0u);
+        auto pairOf = [&](size_t shapeIndex) { return (uint32_t) (shapeMedia[shapeIndex * 2] + 1) | ((uint32_t) (shapeMedia[shapeIndex * 2 + 1] + 1) << 16); };
+        for (uint32_t t = 0; t < nt; ++t) primMedia[t] = pairOf(triShape[t]);
+        for (uint32_t i = 0; i < na; ++i) primMedia[nt + i] = pairOf(shapes.size() + i);
+    }
     // --- BVHs: one per shape group, then the scene level (root = node 0 of its own range; the scene level is built LAST but must be node 0,
     //     so its nodes are emitted first and the groups appended)
     std::vector<uint8_t> single(np, 0); for (uint32_t i = 0; i < ni; ++i) single[nt + na + i] = 1;

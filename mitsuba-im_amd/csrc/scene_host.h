@@ -11,6 +11,9 @@ struct SceneHost {
     // inputs (mi_scene_set_*)
     std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx; std::vector<mi_shape> shapes;
     std::vector<mi_material> materials; std::vector<mi_emitter> emitters; std::vector<mi_analytic> analytic; std::vector<mi_instance> instances; std::vector<float> materialTables; std::vector<mi_texture> textures; std::vector<uint32_t> texLevels; std::vector<float> texTexels; int32_t envTexture = -1;
+    std::vector<mi_medium> media; std::vector<int32_t> shapeMedia; int32_t sensorMedium = -1;   // mi_scene_set_media
+    std::vector<MediumD> mediaD; std::vector<uint32_t> primMedia;   // derived: device records; per primitive (interior + 1) | (exterior + 1) << 16
+    void *dMedia = nullptr, *dPrimMedia = nullptr;
     float s2c[16] = {0}, c2w[16] = {0}; float nearClip = 0, farClip = 0; bool haveCamera = false;
     uint32_t width = 0, height = 0, filterKind = 0; float filterRadius = 0.5f, filterStddev = 0.5f; bool haveFilm = false;
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16] = {0}, envScale = 1.0f;

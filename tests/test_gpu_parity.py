@@ -956,3 +956,50 @@ def test_both_tree_node_kinds(mi, golden_scenes, name, monkeypatch):
         st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
         err = np.abs(got["wide"] - st["li"]).max(1) / (np.abs(st["li"]).max(1) + 1e-6)
         assert (bits(got["wide"]) == bits(st["li"])).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.99
+
+
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide"])
+def test_volpath_simple(mi, oracle, golden_scenes, name):
+    """SURVEY.md 8f-4: SimpleVolumetricPathTracer::Li (src/integrators/path/volpath_simple.cpp) over homogeneous media (src/medium/homogeneous.cpp: balance / single /
+    manual distance sampling; isotropic and Henyey-Greenstein phase functions), `null` boundaries, a dielectric block with an interior medium, a `null` sphere, the
+    sensor inside a medium; emitter sampling attenuated by Scene::evalTransmittance (scene.cpp:650-713) in k_shadow_vol.  exp / log go through the double-precision
+    routines on every side (math.h:185-195), so the radiance samples equal the oracle's and those of the strict-IEEE build of the reference bit for bit."""
+    sc = golden_scenes[name]; gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
+    gs = mi.Scene(sc); r = mi.Render(gs); orc = oracle.Oracle(sc)
+    got = r.samples(gd["pairs"]); ref = orc.render_samples(gd["pairs"])["li"]
+    same = (bits(got) == bits(ref)).all(1)
+    assert same.mean() > 0.999 and np.allclose(got, ref, rtol=1e-5, atol=1e-7), same.mean()          # (a double-rounding difference of the device's exp / log is possible in principle)
+    assert (bits(got) == bits(st["li"])).all(1).mean() > 0.999                                          # the reference itself, strict build
+    err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)                             # the reference as shipped (-ffast-math)
+    assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    rng = np.random.default_rng(5); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    got = r.samples(pairs); ref = orc.render_samples(pairs)["li"]
+    assert (bits(got) == bits(ref)).all(1).mean() > 0.999 and np.allclose(got, ref, rtol=1e-5, atol=1e-7)
+    r.clear(); r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); stt = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-6
+    assert stt["rays"] == int(cnt[0]) and stt["shadow_rays"] == int(cnt[1]) and stt["path_length_sum"] == int(cnt[2])
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]                              # the reference's own image
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-5
+
+
+def test_volpath_simple_refusals(mi, golden_scenes):
+    """what the volumetric stages are not built for is refused by name, never approximated"""
+    S = mi.scenes
+    sc = S.atrium(64, 36, 4, detail=0.08, env_size=(64, 32)); gs = mi.Scene(sc)
+    with pytest.raises(RuntimeError, match="environment emitter"):
+        mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
+    gs = mi.Scene(golden_scenes["masked_room"])
+    with pytest.raises(RuntimeError, match="mask / thindielectric"):
+        mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
+    with pytest.raises(RuntimeError, match="integrators path"):
+        mi.Render(mi.Scene(golden_scenes["cornell_small"]), integrator=7)
+    # a scene without media through the volumetric loop = the same estimator without MIS: converges to the same image (loose check on the mean)
+    os.environ["MI355PT_NO_PACKET"] = "1"
+    try:
+        sc = S.cornell_box(64, 36, 64); gs = mi.Scene(sc)
+        a = mi.Render(gs); a.run(); b = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE); b.run()
+        fa, fb = a.read_film(0), b.read_film(0)
+        assert abs(fa[..., :3].mean() - fb[..., :3].mean()) / fa[..., :3].mean() < 0.05
+    finally:
+        del os.environ["MI355PT_NO_PACKET"]
