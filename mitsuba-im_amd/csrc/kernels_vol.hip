@@ -98,7 +98,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                             bsdf.reflectance[0] = c.x; bsdf.reflectance[1] = c.y; bsdf.reflectance[2] = c.z;
                         }
                     }
-                    pm = sc.prim_media[prim];                                // (interior + 1) | (exterior + 1) << 16 of the shape that was hit; 0: not a medium transition
+                    pm = sc.prim_media ? sc.prim_media[prim] : 0u;           // (interior + 1) | (exterior + 1) << 16 of the shape that was hit; 0: not a medium transition
                     nee = others && !(h.flags & 4u); nref = h.p;            // EDirectSurfaceRadiance, BSDFs with a smooth component
                     if (!(h.flags & 2u)) nrefN = h.ns;                       // records.inl:160-164
                 }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
-            const uint32_t pm = sc.prim_media[prim];                        // `null`: bsdf->eval(bRec, EDiscrete) with typeMask = ENull is 1 (null.cpp:48-50)
+            const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;   // `null`: bsdf->eval(bRec, EDiscrete) with typeMask = ENull is 1 (null.cpp:48-50)
             if (pm) {
                 if (medium != targetMedium(pm, n, -d)) { blocked = true; break; }      // medium inconsistency (scene.cpp:689-692)
                 medium = targetMedium(pm, n, d);

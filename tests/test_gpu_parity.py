@@ -989,7 +989,7 @@ def test_volpath_simple_refusals(mi, golden_scenes):
     sc = S.atrium(64, 36, 4, detail=0.08, env_size=(64, 32)); gs = mi.Scene(sc)
     with pytest.raises(RuntimeError, match="environment emitter"):
         mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
-    gs = mi.Scene(golden_scenes["masked_room"])
+    gs = mi.Scene(golden_scenes["textured_shapes"])
     with pytest.raises(RuntimeError, match="mask / thindielectric"):
         mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
     with pytest.raises(RuntimeError, match="integrators path"):
