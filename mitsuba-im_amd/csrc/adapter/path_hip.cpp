@@ -14,6 +14,8 @@
 #include <mitsuba/render/film.h>
 #include <mitsuba/render/emitter.h>
 #include <mitsuba/render/bsdf.h>
+#include <mitsuba/render/medium.h>
+#include <mitsuba/render/phase.h>
 #include <mitsuba/render/sampler.h>
 #include <mitsuba/render/imageblock.h>
 #include <mitsuba/render/renderqueue.h>
@@ -39,6 +41,7 @@ struct FlatScene {
     std::vector<float> pos, nrm; std::vector<uint32_t> idx; std::vector<mi_shape> shapes; std::vector<mi_material> materials; std::vector<mi_emitter> emitters;
     std::vector<mi_analytic> analytic; std::vector<const Shape *> analyticShapes; std::vector<mi_instance> instances; std::vector<float> materialTables;
     bool anyNormals = false;
+    std::vector<mi_medium> media; std::vector<int32_t> shapeMedia; int32_t sensorMedium = -1;      // participating media (volumetric = true)
     std::vector<float> envRGB; uint32_t envW = 0, envH = 0; float envToWorld[16], envScale = 1.0f;
 };
 
@@ -246,6 +249,7 @@ static mi_material convertBSDF(const BSDF *bsdf) {
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on diffuse.reflectance, plastic / roughplastic.diffuseReflectance and difftrans.transmittance", bsdf->getClass()->getName().c_str());
     }
+    if (bsdf->getClass()->getName() == "Null") { m.type = MI_BSDF_NULL; return m; }      // src/bsdfs/null.cpp: the index-matched boundary of a medium
     if (bsdf->getClass()->getName() == "RoughConductor") {
         // same derivation as RoughConductor's constructor (src/bsdfs/roughconductor.cpp:170-207): eta / k from the properties or from
         // data/ior/<material>.{eta,k}.spd, divided by the exterior IOR; isotropic alpha; Beckmann / GGX with visible-normal sampling
@@ -456,6 +460,33 @@ static void flatten(const Scene *scene, FlatScene &fs) {
         if (!bsdfIndex.count(bsdf)) { const mi_material cm = convertBSDF(bsdf); bsdfIndex[bsdf] = (int) fs.materials.size(); fs.materials.push_back(cm); }   // (a mask appends its nested record first)
         fs.analytic[ai].bsdf = bsdfIndex[bsdf];
     }
+    // participating media: `homogeneous` with an `isotropic` / `hg` phase function, referenced by shapes (interior / exterior) and by the sensor.  Its sampling
+    // parameters are private -> read from the serialised form: Medium::serialize (medium.cpp:67-72: phase function instance, sigmaA, sigmaS) followed by
+    // HomogeneousMedium::serialize (homogeneous.cpp:259-264: strategy, samplingDensity, mediumSamplingWeight)
+    {
+        std::map<const Medium *, int32_t> mediumIndex;
+        auto mediumOf = [&](const Medium *m) -> int32_t {
+            if (!m) return -1;
+            if (mediumIndex.count(m)) return mediumIndex[m];
+            if (m->getClass()->getName() != "HomogeneousMedium") SLog(EError, "path_hip: medium \"%s\" is not implemented (homogeneous)", m->getClass()->getName().c_str());
+            const PhaseFunction *ph = m->getPhaseFunction(); const std::string pcls = ph->getClass()->getName();
+            if (pcls != "IsotropicPhaseFunction" && pcls != "HGPhaseFunction") SLog(EError, "path_hip: phase function \"%s\" is not implemented (isotropic, hg)", pcls.c_str());
+            ref<MemoryStream> ms = new MemoryStream(); ref<InstanceManager> mgr = new InstanceManager(); mgr->serialize(ms, m); ms->seek(0);
+            ms->readUInt(); ms->readString();                                   // the medium's instance id and class name
+            ms->readUInt(); ms->readString(); if (pcls == "HGPhaseFunction") ms->readFloat();     // the phase function instance (hg.cpp:62-66: its g)
+            mi_medium r; memset(&r, 0, sizeof(r));
+            { Spectrum a(ms.get()), s(ms.get()); Float x, y, z; a.toLinearRGB(x, y, z); r.sigma_a[0] = x; r.sigma_a[1] = y; r.sigma_a[2] = z; s.toLinearRGB(x, y, z); r.sigma_s[0] = x; r.sigma_s[1] = y; r.sigma_s[2] = z; }
+            const int strategy = ms->readInt(); r.sampling_density = ms->readFloat(); r.medium_sampling_weight = ms->readFloat();
+            if (strategy > 2) SLog(EError, "path_hip: the `maximum` sampling strategy of the homogeneous medium is not implemented (balance, single, manual)");
+            r.strategy = (uint32_t) strategy; r.phase = pcls == "HGPhaseFunction" ? MI_PHASE_HG : MI_PHASE_ISOTROPIC; r.g = pcls == "HGPhaseFunction" ? (float) ph->getMeanCosine() : 0.0f;
+            mediumIndex[m] = (int32_t) fs.media.size(); fs.media.push_back(r); return mediumIndex[m];
+        };
+        std::vector<int32_t> pairs;
+        for (size_t mi = 0; mi < allMeshes.size(); ++mi) { pairs.push_back(mediumOf(allMeshes[mi]->getInteriorMedium())); pairs.push_back(mediumOf(allMeshes[mi]->getExteriorMedium())); }
+        for (size_t ai = 0; ai < fs.analyticShapes.size(); ++ai) { pairs.push_back(mediumOf(fs.analyticShapes[ai]->getInteriorMedium())); pairs.push_back(mediumOf(fs.analyticShapes[ai]->getExteriorMedium())); }
+        fs.sensorMedium = mediumOf(scene->getSensor()->getMedium());
+        if (!fs.media.empty()) fs.shapeMedia = pairs;
+    }
     // emitters in Scene::getEmitters() order (the order the emitter PDF is built in, scene.cpp:383-388)
     const ref_vector<Emitter> &emitters = scene->getEmitters();
     for (size_t e = 0; e < emitters.size(); ++e) {
@@ -538,6 +569,7 @@ struct GpuScene {
                                         (uint32_t) (fs.pos.size() / 3), (uint32_t) (fs.idx.size() / 3), fs.shapes.data(), (uint32_t) fs.shapes.size()));
         if (!fs.analytic.empty()) MI_CHECK(mi_scene_set_analytic(scene, fs.analytic.data(), (uint32_t) fs.analytic.size()));
         if (!fs.instances.empty()) MI_CHECK(mi_scene_set_instances(scene, fs.instances.data(), (uint32_t) fs.instances.size()));
+        if (!fs.media.empty()) MI_CHECK(mi_scene_set_media(scene, fs.media.data(), (uint32_t) fs.media.size(), fs.shapeMedia.data(), (uint32_t) (fs.shapeMedia.size() / 2), fs.sensorMedium));
         MI_CHECK(mi_scene_set_materials(scene, fs.materials.data(), (uint32_t) fs.materials.size()));
         if (!fs.textures.empty()) MI_CHECK(mi_scene_set_textures(scene, fs.textures.data(), (uint32_t) fs.textures.size()));
         if (!fs.texLevels.empty()) MI_CHECK(mi_scene_set_texture_data(scene, fs.texLevels.data(), (uint32_t) (fs.texLevels.size() / 3), fs.texTexels.data(), fs.texTexels.size()));
@@ -577,6 +609,7 @@ static mi355::Properties convertProps(const Properties &props, const Sampler *sa
     mi355::Properties p;
     p.maxDepth = props.getInteger("maxDepth", -1); p.rrDepth = props.getInteger("rrDepth", 5);
     p.strictNormals = props.getBoolean("strictNormals", false); p.hideEmitters = props.getBoolean("hideEmitters", false);
+    p.volumetric = props.getBoolean("volumetric", false);      // build-specific: the loop of `volpath_simple` over the scene's media
     p.device = (uint32_t) props.getInteger("device", 0); p.planesPerBatch = (uint32_t) props.getInteger("planesPerBatch", 0);
     {   // build-specific `devices` = "0,1,2,...": HIP devices to spread the film rows over (one scene replica + one host thread each); default: `device` alone
         const std::string list = props.getString("devices", "");

@@ -437,7 +437,7 @@ int mi_scene_clone(mi_scene *s, uint32_t device, mi_scene **out) {
     mi_scene *c = new mi_scene();
     c->h = s->h;                                    // inputs + host-derived data
     {   // the copy must not own the source's device allocations
-        void **ps[] = {&c->h.dPacketGroups, &c->h.dPacketExact, &c->h.dTexLevels, &c->h.dTexTexels, &c->h.dMipLut, &c->h.dTriUV, &c->h.dTextures, &c->h.dMaterialTables, &c->h.dInstances, &c->h.dEmitterX, &c->h.dAnalytic, &c->h.dNodes, &c->h.dTris, &c->h.dShade, &c->h.dI2, &c->h.dNrm, &c->h.dMaterials, &c->h.dEmitters, &c->h.dEmitterCdf, &c->h.dAreaCdf, &c->h.dFilter, &c->h.dSobolM32, &c->h.dSobolVdc, &c->h.dSobolVdcInv, &c->h.dEnvRGB, &c->h.dEnvCols, &c->h.dEnvRows, &c->h.dEnvWeights};
+        void **ps[] = {&c->h.dMedia, &c->h.dPrimMedia, &c->h.dPacketGroups, &c->h.dPacketExact, &c->h.dTexLevels, &c->h.dTexTexels, &c->h.dMipLut, &c->h.dTriUV, &c->h.dTextures, &c->h.dMaterialTables, &c->h.dInstances, &c->h.dEmitterX, &c->h.dAnalytic, &c->h.dNodes, &c->h.dTris, &c->h.dShade, &c->h.dI2, &c->h.dNrm, &c->h.dMaterials, &c->h.dEmitters, &c->h.dEmitterCdf, &c->h.dAreaCdf, &c->h.dFilter, &c->h.dSobolM32, &c->h.dSobolVdc, &c->h.dSobolVdcInv, &c->h.dEnvRGB, &c->h.dEnvCols, &c->h.dEnvRows, &c->h.dEnvWeights};
         for (void **p : ps) *p = nullptr;
         c->h.committed = false;
     }

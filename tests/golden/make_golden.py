@@ -205,10 +205,10 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
+        if name in ("fog_box", "fog_box_global", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
-            run(path, "responsive", "path", -1, base + "_resp")
+            run(path, "responsive", "volpath_simple" if sc.get("integrator", 0) == 1 else "path", -1, base + "_resp")
             np.savez_compressed(os.path.join(OUT, name + "_responsive.npz"), target=np.load(base + "_resp_target.npy"), meta=np.load(base + "_resp_meta.npy"))
         if sc.width < 200:
             run(path, "image", 8, base)

@@ -79,6 +79,22 @@ def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
     assert (rel < 1e-3).mean() > 0.99 and np.linalg.norm(g[..., :3] - r[..., :3]) / np.linalg.norm(r[..., :3]) < 1e-2
 
 
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global"])
+def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
+    """`volpath_simple` swapped for `path_hip` with volumetric = true, same responsive driver: live HomogeneousMedium objects (sampling parameters read from their
+    serialised form), IsotropicPhaseFunction / HGPhaseFunction, Null BSDFs, interior / exterior media of meshes and of an analytic sphere, the sensor's medium.
+    (Alpha: 1 on a hit, 0 on a miss; the transmittance-based alpha of records.inl:125-134 is not built -- a handful of corner pixels in the fog variant.)"""
+    sc = golden_scenes[name]
+    path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path); out = str(tmp_path / "hip")
+    subprocess.run([HARNESS, path, "responsive", "path_hip", "-1", out], cwd=os.path.dirname(HARNESS), check=True, timeout=300)
+    got = np.load(out + "_target.npy"); ref = np.load(os.path.join(GOLDEN, name + "_responsive.npz"))["target"]
+    g, r = got[1:-2, 1:-2, :3], ref[1:-2, 1:-2, :3]
+    rel = np.abs(g - r).max(2) / (np.abs(r).max(2) + 1e-6)
+    assert (rel < 1e-4).mean() > 0.99 and np.linalg.norm(g - r) / np.linalg.norm(r) < 1e-3
+    assert (np.abs(got[1:-2, 1:-2, 3] - ref[1:-2, 1:-2, 3]) < 1e-3 * sc.spp).mean() > 0.97
+
+
 def test_host_mirror_controls(mi, golden_scenes):
     """C++ host mirror (csrc/integrator_host.cpp) through its C shim: return codes and error strings of the reference interface."""
     import ctypes as C
