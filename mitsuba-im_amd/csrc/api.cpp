@@ -525,6 +525,14 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
     r->rc.sobol_scramble = 0;
     // volumetric integrators: the radiance-type bits and the sensor's medium of a fresh path (kernels_vol.hip; volpath_simple.cpp:103-104: maxDepth = 1 gathers emitted radiance only)
+    {   // Scene::getBSphere() (aabb.cpp:44-47) of the kd-tree box expanded by the sensor's and the point / spot emitters' positions (scene.cpp:394-421)
+        float lo[3], hi[3]; for (int i = 0; i < 3; ++i) { lo[i] = s->h.aabbLo[i]; hi[i] = s->h.aabbHi[i]; }
+        auto expand = [&](float x, float y, float z) { const float v[3] = {x, y, z}; for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], v[i]); hi[i] = std::max(hi[i], v[i]); } };
+        expand(s->h.c2w[3], s->h.c2w[7], s->h.c2w[11]);
+        for (const mi_emitter &e : s->h.emitters) if (e.type == MI_EMITTER_POINT || e.type == MI_EMITTER_SPOT) expand(e.to_world[3], e.to_world[7], e.to_world[11]);
+        float c[3], d2 = 0; for (int i = 0; i < 3; ++i) { c[i] = (hi[i] + lo[i]) * 0.5f; const float d = c[i] - hi[i]; d2 += d * d; }
+        r->rc.alpha_dist = std::sqrt(d2) * 2;
+    }
     r->rc.integrator = p->integrator; r->rc.state_init = vol ? ((1u << 16) | (p->max_depth == 1 ? 0u : (1u << 17)) | (1u << 18) | ((uint32_t) (s->h.d.sensor_medium + 1) << 20)) : 0u;
     if (p->sampler == MI_SAMPLER_SOBOL && p->seed) {          // SobolSampler: a nonzero `scramble` goes through sampleTEA (sobol.cpp:96-102; qmc.h:146-156, 4 rounds)
         uint32_t v0 = (uint32_t) p->seed, v1 = (uint32_t) (p->seed >> 32), sum = 0;

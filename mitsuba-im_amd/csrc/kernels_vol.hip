@@ -57,6 +57,11 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 const bool others = (fl & VOL_OTHERS) != 0, emitted = (fl & VOL_EMITTED) != 0, scattered = (fl & VOL_SCATTERED) != 0;
                 MediumRec mRec; bool mediumEvent = false; MediumD md;
                 if (medium >= 0) { md = sc.media[medium]; mediumEvent = mediumSampleDistance(md, o, d, 0.0f, tHit, ss, rc.sampler, m32, mRec); }
+                if (depth == 1 && rc.opacity && prim == 0xFFFFFFFFu) {      // records.inl:131-137: EOpacity on a sensor ray that hits nothing -- what the medium in front of the sensor absorbs / scatters, or 0
+                    float al = 0.0f;
+                    if (medium >= 0) { const v3 p2 = o + d * rc.alpha_dist, dd = p2 - o; const v3 tr = mediumTransmittance(md, 0.0f, sqrtf(dot(dd, dd))); al = 1 - ((0.0f + tr.x) + tr.y + tr.z) * (1.0f / 3); }
+                    float4 a = q.acc[pid]; a.w = al; q.acc[pid] = a;
+                }
                 const int interactions = rc.max_depth - depth - 1;
                 // ---- the interaction: a point in the medium, or the surface at the end of the segment
                 bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); Hit h; MaterialD bsdf; uint32_t pm = 0;
@@ -66,7 +71,6 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 } else {
                     if (medium >= 0) { const float r = 1.0f / mRec.pdfFailure; T = T * (mRec.transmittance * r); }
                     if (prim == 0xFFFFFFFFu) {                               // no environment emitters in this build of the stage: the path just ends
-                        if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }
                         pathLen += (unsigned) depth; break;
                     }
                     const int inst = q.hitInst ? q.hitInst[slot] : -1;

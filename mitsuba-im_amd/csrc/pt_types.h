@@ -166,6 +166,7 @@ struct RenderConst {
     const uint4 *sobol_frame, *sobol_px, *sobol_py; uint32_t sobol_nframes;   // frames beyond the table (parity entry point only) take sobolLookUp
     float inv_sqrt_spp;                   // RayDifferential::scaleDifferential amount (integrator.cpp:145-146, 403-405)
     uint32_t integrator;                  // MI_INTEGRATOR_*
+    float alpha_dist;                     // volumetric integrators, EOpacity: twice the radius of the scene's bounding sphere (records.inl:128-134)
     uint32_t state_init;                  // bits ORed into the state word st0.w of a fresh path (volumetric integrators: radiance-type bits, the sensor's medium)
     uint32_t order_offset_words;          // dynamic-LDS offset of the material-sort index list (0 = no sorting); set per launch
 };

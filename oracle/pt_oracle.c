@@ -2145,7 +2145,23 @@ static v3 volpath_simple_li(const orc_scene *s, v3 o, v3 d, float mint, float ma
     int nullChain = 1, scattered = 0; float eta = 1.0f;
     ++counters[0];
     if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
-    *alpha = (s->d.opacity && !its.valid) ? 0.0f : 1.0f;         /* the transmittance-based alpha of records.inl:125-134 is not restated (classic film: no alpha) */
+    *alpha = 1.0f;                                                /* records.inl:121-137 (EOpacity); a hit on a medium-transition shape is taken as opaque (:128-130 not restated) */
+    if (s->d.opacity && !its.valid) {
+        *alpha = 0.0f;
+        if (medium >= 0) {                                        /* :131-134: 1 - average transmittance of the sensor's medium over twice the scene's bounding-sphere radius */
+            v3 lo = s->aabb_lo, hi = s->aabb_hi, c;               /* Scene::getBSphere: the kd-tree box expanded by the sensor's and the point / spot emitters' positions (scene.cpp:394-421, aabb.cpp:44-47) */
+            v3 cam = V(s->d.cam_to_world[3], s->d.cam_to_world[7], s->d.cam_to_world[11]);
+            lo = V(minf(lo.x, cam.x), minf(lo.y, cam.y), minf(lo.z, cam.z)); hi = V(maxf(hi.x, cam.x), maxf(hi.y, cam.y), maxf(hi.z, cam.z));
+            for (uint32_t e = 0; e < s->d.n_emitters; ++e) if (s->emitters[e].type == 3 || s->emitters[e].type == 4) {
+                v3 p = V(s->emitters[e].to_world[3], s->emitters[e].to_world[7], s->emitters[e].to_world[11]);
+                lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
+            }
+            c = scale(add(hi, lo), 0.5f); float dist = length3(sub(c, hi)) * 2;
+            v3 p2 = add(o, scale(d, dist)), dd = sub(p2, o);
+            v3 tr = medium_transmittance(&s->media[medium], 0.0f, length3(dd));
+            *alpha = 1 - ((0.0f + tr.x) + tr.y + tr.z) * (1.0f / 3);
+        }
+    }
     v3 throughput = V(1, 1, 1);
     int emitted = 1, others = 1;                                  /* rRec.type: EEmittedRadiance / the bits of ERadianceNoEmission (they only ever change together) */
     if (maxDepth == 1) others = 0;

@@ -84,7 +84,7 @@ def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
 def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
     """`volpath_simple` swapped for `path_hip` with volumetric = true, same responsive driver: live HomogeneousMedium objects (sampling parameters read from their
     serialised form), IsotropicPhaseFunction / HGPhaseFunction, Null BSDFs, interior / exterior media of meshes and of an analytic sphere, the sensor's medium.
-    (Alpha: 1 on a hit, 0 on a miss; the transmittance-based alpha of records.inl:125-134 is not built -- a handful of corner pixels in the fog variant.)"""
+    Alpha (EOpacity): 1 on a hit, what the sensor's medium removes over two scene radii on a miss (records.inl:131-134); a medium-transition shape counts as opaque."""
     sc = golden_scenes[name]
     path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path); out = str(tmp_path / "hip")
     subprocess.run([HARNESS, path, "responsive", "path_hip", "-1", out], cwd=os.path.dirname(HARNESS), check=True, timeout=300)
