@@ -1108,6 +1108,23 @@ def directional_emitter(direction, irradiance, weight=1.0):
     return dict(type=EMITTER_DIRECTIONAL, shape=-1, radiance=tuple(map(float, irradiance)), weight=float(weight), to_world=look_at((0, 0, 0), d, u))
 
 
+EMITTER_SUNSKY = 6     # src/emitters/sunsky.cpp -- a compound emitter of the reference: it rasterises the Hosek-Wilkie sky (+ sun disc) into an `envmap` (and a `directional`
+                       # sun for sunRadiusScale = 0).  Not restated here: a scene naming it can only be handed to a reference build (oracle/ref_build/harness), where the
+                       # drop-in plugin sees the expanded elements; mi.Scene / the oracle refuse it
+
+
+def sunsky_emitter(sun_direction, turbidity=3.0, scale=1.0, sun_radius_scale=1.0, resolution=256, weight=1.0):
+    d = np.asarray(sun_direction, f32); d = d / f32(np.linalg.norm(d)); m = np.eye(4, dtype=f32); m[:3, 2] = d
+    return dict(type=EMITTER_SUNSKY, shape=-1, radiance=(float(turbidity), float(scale), float(sun_radius_scale)), weight=float(weight), cutoff=float(resolution), beam=0.0, to_world=m)
+
+
+def sunsky_terrace(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, sun_radius_scale=1.0):
+    """the open_constant geometry under the reference's `sunsky` emitter (drop-in tests only: EMITTER_SUNSKY)"""
+    sc = open_constant(width, height, spp, sampler, max_depth, rr_depth, seed); sc.name = "sunsky_terrace"
+    sc.emitters = [e for e in sc.emitters if e["type"] == EMITTER_AREA]
+    return add_scene_emitters(sc, [sunsky_emitter((0.35, 0.6, -0.4), turbidity=3.0, scale=1.0, sun_radius_scale=sun_radius_scale, resolution=128)])
+
+
 def cbox_lights(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, hide_emitters=False):
     """Cornell box lit by its area light plus a `point` and a `spot` emitter (emitter selection over three kinds; delta lights: MIS weight 1)."""
     sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, hide_emitters=hide_emitters)

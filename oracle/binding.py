@@ -215,6 +215,8 @@ class Oracle:
         if mt is not None:
             self._keep.append(mt); d.n_material_tables, d.material_tables = len(mt), _ptr(mt)
         self.h = L.orc_scene_create(C.byref(d))
+        if not self.h:
+            raise ValueError("oracle: the scene names a plugin that is not restated (e.g. the compound `sunsky` emitter)")
         self.border = L.orc_film_border(self.h)
 
     def __del__(self):

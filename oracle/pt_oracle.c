@@ -2352,6 +2352,7 @@ static int build_bvh(orc_scene *s, uint32_t *tris, int first, int count, v3 *cen
 static void *dup(const void *p, size_t n) { if (!p) return NULL; void *q = malloc(n ? n : 1); memcpy(q, p, n); return q; }
 
 orc_scene *orc_scene_create(const orc_scene_desc *d) {
+    for (uint32_t i = 0; i < d->n_emitters; ++i) if (d->emitters[i].type > 5) return NULL;      /* e.g. the reference's compound `sunsky`: not restated */
     orc_scene *s = (orc_scene *) calloc(1, sizeof(orc_scene));
     s->d = *d;
     s->pos = (float *) dup(d->pos, (size_t) d->n_verts * 12); s->nrm = (float *) dup(d->nrm, (size_t) d->n_verts * 12);

@@ -327,6 +327,15 @@ static Built buildScene(const FScene &fs) {
     }
     // scene-level emitters first, as the XML loader would add them before shapes are expanded
     for (const FEmitter &fe : fs.emitters) {
+        if (fe.type == 6) {      // sunsky (src/emitters/sunsky.cpp): a COMPOUND emitter -- Scene::addChild (scene.cpp:530-539) adds its elements: the rasterised `envmap`, and a
+                                 // `directional` sun when sunRadiusScale = 0.  radiance = (turbidity, scale, sunRadiusScale), cutoff = resolution, sun direction = z axis of toWorld
+            Properties p("sunsky"); p.setFloat("samplingWeight", fe.weight);
+            p.setFloat("turbidity", fe.radiance[0]); p.setFloat("scale", fe.radiance[1]); p.setFloat("sunRadiusScale", fe.radiance[2]); p.setInteger("resolution", (int) fe.cutoff);
+            p.setVector("sunDirection", Vector(fe.toWorld[2], fe.toWorld[6], fe.toWorld[10]));
+            ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), p)); em->configure();
+            b.scene->addChild(em);
+            continue;
+        }
         if (fe.type >= 2) {      // constant / point / spot / directional
             static const char *names[] = {"", "", "constant", "point", "spot", "directional"};
             Properties p(names[fe.type]);

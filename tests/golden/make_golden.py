@@ -104,6 +104,10 @@ def golden_scenes():
         # volpath_simple over homogeneous media: smoke cube behind a `null` boundary (isotropic, balance), glass block with a forward-scattering
         # interior (hg, single), `null` sphere of haze (hg, manual); _global: the sensor sits in a thin fog that fills the room
         "fog_box": scenes.fog_box(width=96, height=96, spp=16),
+        # the reference's `sunsky` emitter (compound: rasterised sky + sun -> envmap; sunRadiusScale = 0 -> envmap + directional): drop-in fixtures only, the
+        # integrator sees the expanded elements (scene.cpp:530-539)
+        "sunsky_terrace": scenes.sunsky_terrace(width=96, height=64, spp=16),
+        "sunsky_terrace_dirsun": scenes.sunsky_terrace(width=96, height=64, spp=16, sun_radius_scale=0.0),
         "fog_box_global": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=14, rr_depth=2),
         "fog_box_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5),
     }
@@ -192,6 +196,10 @@ def main():
             continue
         ppath = os.path.join(tmp, name + "_pairs.bin"); pairs.tofile(ppath)
         base = os.path.join(tmp, name)
+        if name.startswith("sunsky"):                   # only the responsive target: neither the oracle nor the standalone front end builds this emitter
+            run(path, "responsive", "path", -1, base + "_resp")
+            np.savez_compressed(os.path.join(OUT, name + "_responsive.npz"), target=np.load(base + "_resp_target.npy"), meta=np.load(base + "_resp_meta.npy"))
+            continue
         run(path, "samples", ppath, base)
         np.savez_compressed(os.path.join(OUT, name + "_samples.npz"), pairs=pairs,
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
