@@ -455,7 +455,9 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     for (void *p : allocs) (void) hipFree(p);
     allocs.clear();
     auto envU = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v && v[0] ? (uint32_t) atoi(v) : dflt; };
-    uint32_t grid = envU("MI355PT_SEGMENTS", 16384u);                      // segments of the path pool (each owned by one wave in the shade stage)
+    // segments of the path pool (each owned by one wave in the shade stage): 16384, or -- where the shade stage sorts a segment's paths by material class and its
+    // index list must fit LDS -- as many as keep a segment at ~1000 slots (C3 at 64 M paths: 1916 Msamples/s with 16384 segments, 1983 with 65536)
+    uint32_t grid = envU("MI355PT_SEGMENTS", r->scene->h.d.has_roughconductor ? (uint32_t) std::min<uint64_t>(std::max<uint64_t>(16384u, paths / 1024u), 1u << 18) : 16384u);
     uint64_t minGrid = (paths + 63) / 64; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 63) / 64 * 64;
     r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
@@ -673,7 +675,7 @@ int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t 
     const uint32_t nrows = (tile.y1 - tile.y0 + rowStride - 1) / rowStride;          // rows y0, y0 + stride, ... below y1
     const uint32_t npix = (tile.x1 - tile.x0) * nrows;
     uint32_t planes = r->p.planes_per_batch;
-    if (!planes) { static const uint64_t target = [] { const char *v = getenv("MI355PT_BATCH_PATHS"); return v && atoll(v) > 0 ? (uint64_t) atoll(v) : (uint64_t) (16u << 20); }(); planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~16 M paths in flight
+    if (!planes) { static const uint64_t target = [] { const char *v = getenv("MI355PT_BATCH_PATHS"); return v && atoll(v) > 0 ? (uint64_t) atoll(v) : (uint64_t) (64u << 20); }(); planes = (uint32_t) std::max<uint64_t>(1, target / npix); }   // ~64 M paths in flight per pool (measured: 16 M 2873, 32 M 3025, 64 M 3055, 128 M 2993 Msamples/s on C2; C4 483 / 501 / 509 / 511)
     if (planes > s1 - s0) planes = std::max<uint32_t>(1, s1 - s0);
     const uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
