@@ -103,6 +103,7 @@ def rough_transmittance_slice(distr, ior, alpha):
 
 INTEGRATOR_PATH = 0            # src/integrators/path/path.cpp
 INTEGRATOR_VOLPATH_SIMPLE = 1  # src/integrators/path/volpath_simple.cpp
+INTEGRATOR_VOLPATH = 2         # src/integrators/path/volpath.cpp (multiple importance sampling, emitters found through index-matched boundaries)
 MEDIUM_BALANCE, MEDIUM_SINGLE, MEDIUM_MANUAL = 0, 1, 2      # HomogeneousMedium sampling strategies (homogeneous.cpp:192-226; `maximum` is not built)
 PHASE_ISOTROPIC, PHASE_HG = 0, 1
 
@@ -518,7 +519,7 @@ def _closed_box(b, top, y0, y1):
     b.quad([(p[0], y0, p[1]) for p in reversed(P)])
 
 
-def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, global_fog=False, strict_normals=False, hide_emitters=False):
+def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, global_fog=False, strict_normals=False, hide_emitters=False, integrator=INTEGRATOR_VOLPATH_SIMPLE):
     """Cornell room for the volumetric path tracer (volpath_simple): a smoke cube behind an index-matched (`null`) boundary (isotropic, `balance`
     sampling), a glass block filled with a forward-scattering medium (hg, `single`), a `null` sphere of thin haze (hg backwards, `manual`); with global_fog the
     sensor sits in a thin isotropic medium that fills the room (the shapes name it as their exterior medium)."""
@@ -543,7 +544,7 @@ def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_
     cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))
     return finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 39.3, 10.0, 2800.0, width, height, spp, sampler, max_depth, rr_depth, FILTER_BOX, seed,
                         strict_normals=strict_normals, hide_emitters=hide_emitters, name="fog_box", analytic=b.resolve_analytic(), media=media,
-                        sensor_medium=ext, integrator=INTEGRATOR_VOLPATH_SIMPLE)
+                        sensor_medium=ext, integrator=integrator)
 
 
 def cbox_shapes(width=256, height=256, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, filter_kind=FILTER_BOX, seed=0,

@@ -2235,6 +2235,124 @@ static v3 volpath_simple_li(const orc_scene *s, v3 o, v3 d, float mint, float ma
     return Li;
 }
 
+/* VolumetricPathTracer::rayIntersectAndLookForEmitter (src/integrators/path/volpath.cpp:370-431): the FIRST intersection of the ray goes to *first (the path continues
+ * from it); the walk goes on through index-matched boundaries looking for an emitter and returns its attenuated emittance (no environment emitters in volumetric scenes here) */
+static void look_for_emitter(const orc_scene *s, int medium, int maxInteractions, v3 o, v3 d, float mint, hit_t *first, direct_t *dRec, v3 *value, uint64_t *counters) {
+    hit_t its2, *its = first; v3 transmittance = V(1, 1, 1); int surface = 0, interactions = 0;
+    *value = V(0, 0, 0);
+    while (1) {
+        ++counters[0];
+        surface = ray_intersect(s, o, d, mint, INFINITY, its, 0); if (!surface) its->t = INFINITY;
+        if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, its->t));
+        if (surface && (interactions == maxInteractions || s->materials[its->material].m.type != BSDF_NULL || its->emitter >= 0)) break;
+        if (!surface) break;
+        if (is_zero(transmittance)) return;
+        if (is_medium_transition(s, its->shape)) medium = target_medium(s, its->shape, its->ng, d);
+        /* bsdf->eval(bRec, EDiscrete) with typeMask = ENull: 1 for `null` */
+        o = add(o, scale(d, its->t)); mint = EPSILON; its = &its2;
+        if (++interactions > 100) return;
+    }
+    if (surface && its->emitter >= 0) {                  /* dRec.setQuery(ray, *its) (records.inl:170-178): dist = the LAST segment's t; ref / refN stay */
+        dRec->p = its->p; dRec->n = its->ns; dRec->d = d; dRec->dist = its->t; dRec->emitter = its->emitter;
+        *value = mul(transmittance, emitter_eval(s, its->emitter, its->ns, neg(d)));
+    }
+}
+static float phase_pdf(const orc_medium *m, v3 wi, v3 wo) { return phase_eval(m, wi, wo); }       /* PhaseFunction::pdf (src/librender/phase.cpp:21-23); isotropic: the same constant */
+
+/* src/integrators/path/volpath.cpp:84-343 VolumetricPathTracer::Li (no subsurface, no environment emitter) */
+static v3 volpath_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters, float *alpha, const v3 *rxd, const v3 *ryd) {
+    const int maxDepth = s->d.max_depth, rrDepth = s->d.rr_depth;
+    const int strict = s->d.strict_normals != 0, hide = s->d.hide_emitters != 0;
+    hit_t its; v3 Li = V(0, 0, 0); int depth = 1, medium = s->d.sensor_medium, scattered = 0; float eta = 1.0f;
+    ++counters[0];
+    if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
+    *alpha = 1.0f;
+    if (s->d.opacity && !its.valid) *alpha = 0.0f;               /* (the sensor-medium case of records.inl:131-134: see volpath_simple_li; not needed by the classic film) */
+    v3 throughput = V(1, 1, 1); int emitted = 1;                  /* rRec.type is ERadiance or ERadianceNoEmission throughout */
+    int differentials = 1;
+    while (depth <= maxDepth || maxDepth < 0) {
+        mrec_t mRec;
+        if (medium >= 0 && medium_sample_distance(&s->media[medium], o, d, 0, its.t, sp, &mRec)) {
+            const orc_medium *m = &s->media[medium];
+            if (depth >= maxDepth && maxDepth != -1) break;
+            { float r = 1.0f / mRec.pdf_success; throughput = mul(throughput, scale(mul(V(m->sigma_s[0], m->sigma_s[1], m->sigma_s[2]), mRec.transmittance), r)); }
+            direct_t dRec; memset(&dRec, 0, sizeof(dRec)); dRec.ref = mRec.p;
+            {   int interactions = maxDepth - depth - 1; float sx, sy; next2D(sp, &sx, &sy);
+                v3 value = sample_attenuated_emitter_direct(s, mRec.p, V(0, 0, 0), NULL, medium, &interactions, sx, sy, &dRec, &counters[1]);
+                if (!is_zero(value)) {
+                    float phaseVal = phase_eval(m, neg(d), dRec.d);
+                    if (phaseVal != 0) {
+                        float phasePdf = dRec.delta ? 0.0f : phase_pdf(m, neg(d), dRec.d);
+                        Li = add(Li, scale(scale(mul(throughput, value), phaseVal), mi_weight(dRec.pdf, phasePdf)));
+                    }
+                }
+            }
+            v3 wi = neg(d); v3 wo = phase_sample(m, wi, sp); float phasePdf = phase_pdf(m, wi, wo);        /* isotropic.cpp:68-72, hg.cpp:101-106: weight 1 */
+            o = mRec.p; d = wo; mint = 0; maxt = INFINITY; differentials = 0;
+            v3 value;
+            look_for_emitter(s, medium, maxDepth - depth - 1, o, d, 0.0f, &its, &dRec, &value, counters);
+            if (!is_zero(value)) {
+                float emitterPdf = pdf_emitter_direct(s, &dRec, V(0, 0, 0));
+                Li = add(Li, scale(mul(throughput, value), mi_weight(phasePdf, emitterPdf)));
+            }
+            emitted = 0;
+        } else {
+            if (medium >= 0) { float r = 1.0f / mRec.pdf_failure; throughput = mul(throughput, scale(mRec.transmittance, r)); }
+            if (!its.valid) break;                                /* (no environment emitter) */
+            if (its.emitter >= 0 && emitted && (!hide || scattered))
+                Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
+            if (depth >= maxDepth && maxDepth != -1) break;
+            if ((-dot(its.ng, d)) * its.wi.z < 0 && strict) break;
+            const smat_t smat = resolve_material(s, its.material, &its, differentials, o, rxd, ryd); const smat_t *bsdf = &smat;
+            v3 refN = sm_has_backside(bsdf) ? V(0, 0, 0) : its.ns;
+            direct_t dRec; memset(&dRec, 0, sizeof(dRec)); dRec.ref = its.p;
+            if (sm_is_smooth(bsdf)) {
+                int interactions = maxDepth - depth - 1; float sx, sy; next2D(sp, &sx, &sy);
+                v3 value = sample_attenuated_emitter_direct(s, its.p, refN, &its, medium, &interactions, sx, sy, &dRec, &counters[1]);
+                if (!is_zero(value)) {
+                    v3 wo = to_local(&its, dRec.d); v3 bsdfVal = sm_eval(bsdf, its.wi, wo);
+                    if (!is_zero(bsdfVal) && (!strict || dot(its.ng, dRec.d) * wo.z > 0)) {
+                        float bsdfPdf = dRec.delta ? 0.0f : sm_pdf(bsdf, its.wi, wo);
+                        Li = add(Li, scale(mul(mul(throughput, value), bsdfVal), mi_weight(dRec.pdf, bsdfPdf)));
+                    }
+                }
+            }
+            float bsdfPdf = 0, bEta = 1; v3 woL = V(0, 0, 0); float sx, sy; next2D(sp, &sx, &sy); int sampledDelta = 0;
+            v3 bsdfWeight = sm_sample(bsdf, its.wi, sx, sy, &woL, &bsdfPdf, &bEta, &sampledDelta, sp);
+            if (is_zero(bsdfWeight)) break;
+            v3 wo = to_world(&its, woL);
+            if (dot(its.ng, wo) * woL.z <= 0 && strict) break;
+            v3 po = its.p;
+            throughput = mul(throughput, bsdfWeight); eta *= bEta;
+            if (is_medium_transition(s, its.shape)) medium = target_medium(s, its.shape, its.ng, wo);
+            o = po; d = wo; mint = EPSILON; maxt = INFINITY; differentials = 0;
+            if (sampledDelta == 2) {                              /* index-matched boundary: no emitter search, no Russian roulette, `scattered` unchanged */
+                emitted = scattered ? 0 : 1;
+                ++counters[0];
+                if (!ray_intersect(s, o, d, EPSILON, INFINITY, &its, 0)) its.t = INFINITY;
+                depth++;
+                continue;
+            }
+            v3 value;
+            look_for_emitter(s, medium, maxDepth - depth - 1, o, d, EPSILON, &its, &dRec, &value, counters);
+            if (!is_zero(value)) {
+                float emitterPdf = sampledDelta ? 0.0f : pdf_emitter_direct(s, &dRec, refN);
+                Li = add(Li, scale(mul(throughput, value), mi_weight(bsdfPdf, emitterPdf)));
+            }
+            emitted = 0;
+        }
+        if (depth++ >= rrDepth) {
+            float q = minf(maxf(maxf(throughput.x, throughput.y), throughput.z) * eta * eta, 0.95f);
+            if (next1D(sp) >= q) break;
+            float r = 1.0f / q; throughput = scale(throughput, r);
+        }
+        scattered = 1;
+    }
+    counters[2] += (uint64_t) depth;
+    *out_depth = depth;
+    return Li;
+}
+
 /* one pixel sample: src/librender/integrator.cpp:171-186 (renderBlock body) */
 static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t sidx, float *pos, int *depth, uint64_t *counters, float *log, int *nlog, float *alpha) {
     sampler_t sp; sampler_begin(&sp, s, px, py, sidx, log);
@@ -2242,7 +2360,7 @@ static v3 pixel_sample(const orc_scene *s, uint32_t px, uint32_t py, uint64_t si
     pos[0] = (float) (int32_t) px + jx; pos[1] = (float) (int32_t) py + jy;
     v3 o, d; float mint, maxt; camera_ray(s, pos[0], pos[1], &o, &d, &mint, &maxt);
     v3 rxd, ryd; camera_differentials(s, pos[0], pos[1], d, &rxd, &ryd);
-    v3 li = s->d.integrator == 1 ? volpath_simple_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd) : path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd);
+    v3 li = s->d.integrator == 2 ? volpath_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd) : s->d.integrator == 1 ? volpath_simple_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd) : path_li(s, o, d, mint, maxt, &sp, depth, counters, alpha, &rxd, &ryd);
     if (nlog) *nlog = sp.nlog;
     return li;
 }

@@ -487,7 +487,7 @@ static Built buildScene(const FScene &fs) {
     }
     // integrator
     {
-        Properties p(fs.integrator == 1 ? "volpath_simple" : "path"); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
+        Properties p(fs.integrator == 2 ? "volpath" : fs.integrator == 1 ? "volpath_simple" : "path"); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
         p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
         b.integrator = static_cast<SamplingIntegrator *>(create(MTS_CLASS(Integrator), p));
         b.integrator->configure();

@@ -110,6 +110,10 @@ def golden_scenes():
         "sunsky_terrace_dirsun": scenes.sunsky_terrace(width=96, height=64, spp=16, sun_radius_scale=0.0),
         "fog_box_global": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=14, rr_depth=2),
         "fog_box_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5),
+        # the same rooms through `volpath` (multiple importance sampling; emitters found through index-matched boundaries)
+        "fog_mis": scenes.fog_box(width=96, height=96, spp=16, integrator=scenes.INTEGRATOR_VOLPATH),
+        "fog_mis_global": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=15, rr_depth=2, integrator=scenes.INTEGRATOR_VOLPATH),
+        "fog_mis_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5, integrator=scenes.INTEGRATOR_VOLPATH),
     }
 
 
@@ -213,10 +217,10 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("fog_box", "fog_box_global", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
+        if name in ("fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
-            run(path, "responsive", "volpath_simple" if sc.get("integrator", 0) == 1 else "path", -1, base + "_resp")
+            run(path, "responsive", {1: "volpath_simple", 2: "volpath"}.get(sc.get("integrator", 0), "path"), -1, base + "_resp")
             np.savez_compressed(os.path.join(OUT, name + "_responsive.npz"), target=np.load(base + "_resp_target.npy"), meta=np.load(base + "_resp_meta.npy"))
         if sc.width < 200:
             run(path, "image", 8, base)
