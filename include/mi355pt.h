@@ -48,6 +48,7 @@ typedef struct { uint32_t group; uint32_t pad[3]; float to_world[16], to_object[
 typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling_density, medium_sampling_weight; uint32_t phase; float g; uint32_t pad; } mi_medium;
 #define MI_INTEGRATOR_PATH 0            /* MIPathTracer, src/integrators/path/path.cpp */
 #define MI_INTEGRATOR_VOLPATH_SIMPLE 1  /* SimpleVolumetricPathTracer, src/integrators/path/volpath_simple.cpp */
+#define MI_INTEGRATOR_VOLPATH 2         /* VolumetricPathTracer, src/integrators/path/volpath.cpp: multiple importance sampling, emitters found through index-matched boundaries */
 
 #define MI_BSDF_DIFFUSE 0         /* src/bsdfs/diffuse.cpp: reflectance                                                              */
 #define MI_BSDF_ROUGHCONDUCTOR 1  /* src/bsdfs/roughconductor.cpp + microfacet.h: alpha (alphaU), distr, eta, k, specular; flags: sampleVisible, anisotropic */
@@ -130,7 +131,7 @@ typedef struct {
     uint32_t planes_per_batch;   /* sample planes traced per wavefront batch (0 = auto) */
     uint32_t opacity;            /* 1: alpha = 1 where the camera ray hits a surface, else 0 (RadianceQueryRecord::EOpacity, records.inl:121-137:
                                     the responsive drivers and films with an alpha channel); 0: alpha = 1 (classic film without alpha, integrator.cpp:160-161) */
-    uint32_t integrator;         /* MI_INTEGRATOR_PATH (0, default) or MI_INTEGRATOR_VOLPATH_SIMPLE: the same loop over participating media (mi_scene_set_media);
+    uint32_t integrator;         /* MI_INTEGRATOR_PATH (0, default), MI_INTEGRATOR_VOLPATH_SIMPLE or MI_INTEGRATOR_VOLPATH: the same loop over participating media (mi_scene_set_media);
                                     anything else: MI_ERR_UNSUPPORTED.  (Round 1 had `fast_math` here; one set of kernels ships: strict IEEE arithmetic) */
 } mi_render_params;
 

@@ -609,7 +609,11 @@ static mi355::Properties convertProps(const Properties &props, const Sampler *sa
     mi355::Properties p;
     p.maxDepth = props.getInteger("maxDepth", -1); p.rrDepth = props.getInteger("rrDepth", 5);
     p.strictNormals = props.getBoolean("strictNormals", false); p.hideEmitters = props.getBoolean("hideEmitters", false);
-    p.volumetric = props.getBoolean("volumetric", false);      // build-specific: the loop of `volpath_simple` over the scene's media
+    {   // build-specific `integrator` = "path" (default) | "volpath_simple" | "volpath": which of the reference's three path-tracing loops runs on the GPU
+        const std::string loop = props.getString("integrator", "path");
+        if (loop == "path") p.integrator = MI_INTEGRATOR_PATH; else if (loop == "volpath_simple") p.integrator = MI_INTEGRATOR_VOLPATH_SIMPLE; else if (loop == "volpath") p.integrator = MI_INTEGRATOR_VOLPATH;
+        else SLog(EError, "path_hip: integrator \"%s\" is not implemented (path, volpath_simple, volpath)", loop.c_str());
+    }
     p.device = (uint32_t) props.getInteger("device", 0); p.planesPerBatch = (uint32_t) props.getInteger("planesPerBatch", 0);
     {   // build-specific `devices` = "0,1,2,...": HIP devices to spread the film rows over (one scene replica + one host thread each); default: `device` alone
         const std::string list = props.getString("devices", "");

@@ -23,6 +23,8 @@ void mi_launch_shade_rcw_env(const DScene &, const RenderConst &, const Queues &
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_shade_vol(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shadow_vol(const DScene &, const Queues &, uint32_t, hipStream_t);
+void mi_launch_shade_volmis(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
+void mi_launch_shadow_volmis(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_film(const DScene &, const Queues &, const BatchDesc &, float *, float *, hipStream_t);
 void mi_launch_env_primary(const DScene &, const RenderConst &, const Queues &, int, uint32_t, hipStream_t);
 void mi_launch_film_layout(const float *, const float *, float *, int, int, int, int, hipStream_t);
@@ -472,8 +474,10 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
         ALLOC(Q.count[b], uint32_t, grid);
     }
     if (r->scene->h.d.n_instances) ALLOC(Q.hitInst, int32_t, slots); else Q.hitInst = nullptr;
-    ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, slots); ALLOC(Q.shD, float4, slots); ALLOC(Q.shC, float4, slots);
-    if (r->rc.integrator == MI_INTEGRATOR_VOLPATH_SIMPLE) { ALLOC(Q.shT, float4, slots); ALLOC(Q.shX, float4, slots); } else { Q.shT = nullptr; Q.shX = nullptr; }
+    // shadow records: 48 B; the volumetric integrators add throughput and BSDF / phase value (80 B); volpath leaves up to two records per path and pass (kernels_volmis.hip)
+    const uint64_t shSlots = r->rc.integrator == MI_INTEGRATOR_VOLPATH ? slots * 2 : slots;
+    ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, shSlots); ALLOC(Q.shD, float4, shSlots); ALLOC(Q.shC, float4, shSlots);
+    if (r->rc.integrator != MI_INTEGRATOR_PATH) { ALLOC(Q.shT, float4, shSlots); ALLOC(Q.shX, float4, shSlots); } else { Q.shT = nullptr; Q.shX = nullptr; }
     ALLOC(Q.acc, float4, slots); ALLOC(Q.pos, float2, slots); ALLOC(Q.shCount, uint32_t, grid);
     ALLOC(Q.counters, unsigned long long, 4);
     HIPCHK(hipMemset(Q.counters, 0, 32));
@@ -501,14 +505,14 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
-    if (p->integrator > MI_INTEGRATOR_VOLPATH_SIMPLE) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0) and volpath_simple (1) are implemented");
-    const bool vol = p->integrator == MI_INTEGRATOR_VOLPATH_SIMPLE;
+    if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
+    const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for
-        if (s->h.envIndex >= 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple with an environment emitter (envmap / constant) is not implemented");
+        if (s->h.envIndex >= 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with an environment emitter (envmap / constant) is not implemented");
         for (const mi_material &m : s->h.materials)
             if (m.type == MI_BSDF_MASK || m.type == MI_BSDF_THINDIELECTRIC || m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP)
-                return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple with mask / thindielectric / mixturebsdf / bumpmap / normalmap materials is not implemented");
-        if (s->h.d.packet_n) return fail(MI_ERR_INVALID, "mi_render_create: volpath_simple needs the tree traversal (scenes with media always have it; set MI355PT_NO_PACKET=1 for a scene without media)");
+                return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with mask / thindielectric / mixturebsdf / bumpmap / normalmap materials is not implemented");
+        if (s->h.d.packet_n) return fail(MI_ERR_INVALID, "mi_render_create: the volumetric integrators need the tree traversal (scenes with media always have it; set MI355PT_NO_PACKET=1 for a scene without media)");
         if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth beyond 250");
     }
     if (p->sampler == MI_SAMPLER_SOBOL) {
@@ -535,7 +539,9 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         float c[3], d2 = 0; for (int i = 0; i < 3; ++i) { c[i] = (hi[i] + lo[i]) * 0.5f; const float d = c[i] - hi[i]; d2 += d * d; }
         r->rc.alpha_dist = std::sqrt(d2) * 2;
     }
-    r->rc.integrator = p->integrator; r->rc.state_init = vol ? ((1u << 16) | (p->max_depth == 1 ? 0u : (1u << 17)) | (1u << 18) | ((uint32_t) (s->h.d.sensor_medium + 1) << 20)) : 0u;
+    r->rc.integrator = p->integrator;
+    r->rc.state_init = p->integrator == MI_INTEGRATOR_VOLPATH_SIMPLE ? ((1u << 16) | (p->max_depth == 1 ? 0u : (1u << 17)) | (1u << 18) | ((uint32_t) (s->h.d.sensor_medium + 1) << 20))
+                     : p->integrator == MI_INTEGRATOR_VOLPATH ? ((1u << 16) | ((uint32_t) (s->h.d.sensor_medium + 1) << 20)) : 0u;      // volpath: ERadiance, nothing else (kernels_volmis.hip)
     if (p->sampler == MI_SAMPLER_SOBOL && p->seed) {          // SobolSampler: a nonzero `scramble` goes through sampleTEA (sobol.cpp:96-102; qmc.h:146-156, 4 rounds)
         uint32_t v0 = (uint32_t) p->seed, v1 = (uint32_t) (p->seed >> 32), sum = 0;
         for (int i = 0; i < 4; ++i) {
@@ -640,10 +646,10 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
         mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
-        if (r->rc.integrator == MI_INTEGRATOR_VOLPATH_SIMPLE) {      // the same loop over media: its own shade and shadow stages (kernels_vol.hip)
-            const size_t lds = r->rc.sampler == MI_SAMPLER_SOBOL ? (size_t) r->rc.nib_dims * r->rc.nib_count * 64 : 16;
-            mark(r, 2, evUsed, st); mi_launch_shade_vol(sc, r->rc, Q, buf, r->gridShade, lds, st);
-            if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow_vol(sc, Q, r->gridShadow, st); }
+        if (r->rc.integrator != MI_INTEGRATOR_PATH) {      // the same loop over media: its own shade and shadow stages (kernels_vol.hip, kernels_volmis.hip)
+            const size_t lds = r->rc.sampler == MI_SAMPLER_SOBOL ? (size_t) r->rc.nib_dims * r->rc.nib_count * 64 : 16; const bool mis = r->rc.integrator == MI_INTEGRATOR_VOLPATH;
+            mark(r, 2, evUsed, st); (mis ? mi_launch_shade_volmis : mi_launch_shade_vol)(sc, r->rc, Q, buf, r->gridShade, lds, st);
+            if (depth < maxDepth) { mark(r, 3, evUsed, st); (mis ? mi_launch_shadow_volmis : mi_launch_shadow_vol)(sc, Q, r->gridShadow, st); }
         } else {
         if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) mi_launch_env_primary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
         mark(r, 2, evUsed, st); mi_launch_shade(sc, r->ldsTables, r->rc, Q, buf, r->gridShade, st);

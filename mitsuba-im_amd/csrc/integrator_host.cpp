@@ -28,7 +28,7 @@ bool MIPathTracerHIP::preprocess(mi_scene *scene) {
     mi_render_params p{};
     p.max_depth = m_props.maxDepth; p.rr_depth = m_props.rrDepth; p.strict_normals = m_props.strictNormals; p.hide_emitters = m_props.hideEmitters;
     p.sampler = (uint32_t) m_props.sampler; p.spp = m_props.sampleCount; p.seed = m_props.seed; p.device = m_props.device; p.planes_per_batch = m_props.planesPerBatch; p.opacity = m_props.opacity ? 1 : 0;
-    p.integrator = m_props.volumetric ? MI_INTEGRATOR_VOLPATH_SIMPLE : MI_INTEGRATOR_PATH;
+    p.integrator = (uint32_t) m_props.integrator;
     check(mi_render_create(scene, &p, &m_render), "MIPathTracerHIP::preprocess");
     // `devices`: every further entry gets a replica of the scene and a render handle of its own; film rows are interleaved over the replicas
     for (size_t i = 1; i < m_props.devices.size(); ++i) {

@@ -26,7 +26,7 @@ struct Properties {                 // the subset of mitsuba::Properties this in
     uint32_t device = 0, planesPerBatch = 0;                                       // build-specific
     std::vector<uint32_t> devices;   // build-specific (SURVEY §8b `devices`): HIP devices to spread the film rows over; empty = {device}.  An entry may repeat (two
                                      // replicas on one GPU).  The scene handed to preprocess() lives on devices[0]; the others get clones (mi_scene_clone)
-    bool volumetric = false;   // build-specific: true = the loop of volpath_simple (SimpleVolumetricPathTracer) over the scene's participating media instead of path's
+    int integrator = MI_INTEGRATOR_PATH;   // build-specific: MI_INTEGRATOR_VOLPATH_SIMPLE / MI_INTEGRATOR_VOLPATH = the loops of volpath_simple / volpath over the scene's participating media
     bool opacity = true;   // RadianceQueryRecord::EOpacity: the responsive drivers always request it (integrator.cpp:474)
 };
 

@@ -796,7 +796,7 @@ static void modeResponsive(Built &b, const FScene &fs, const std::string &plugin
     Properties p(plugin); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
     p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
     if (fs.sampler == 0) p.setSize("seed", (size_t) fs.seed);
-    if (plugin == "path_hip") { p.setInteger("planesPerBatch", 4); if (fs.integrator == 1) p.setBoolean("volumetric", true); }   // several progress() calls on small films
+    if (plugin == "path_hip") { p.setInteger("planesPerBatch", 4); if (fs.integrator) p.setString("integrator", fs.integrator == 2 ? "volpath" : "volpath_simple"); }   // several progress() calls on small films
     ref<Integrator> integ = static_cast<Integrator *>(create(MTS_CLASS(Integrator), p));
     integ->configure();
     ref<ResponsiveIntegrator> resp = integ->makeResponsiveIntegrator();
@@ -855,7 +855,7 @@ static void modeClassic(Built &b, const FScene &fs, const std::string &plugin, i
     Properties p(plugin); p.setInteger("maxDepth", fs.maxDepth); p.setInteger("rrDepth", fs.rrDepth);
     p.setBoolean("strictNormals", fs.strictNormals != 0); p.setBoolean("hideEmitters", fs.hideEmitters != 0);
     if (fs.sampler == 0) p.setSize("seed", (size_t) fs.seed);
-    if (plugin == "path_hip" && fs.integrator == 1) p.setBoolean("volumetric", true);
+    if (plugin == "path_hip" && fs.integrator) p.setString("integrator", fs.integrator == 2 ? "volpath" : "volpath_simple");
     ref<Integrator> integ = static_cast<Integrator *>(create(MTS_CLASS(Integrator), p));
     integ->configure();
     b.scene->setIntegrator(integ);

@@ -80,9 +80,9 @@ def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
-@pytest.mark.parametrize("name", ["fog_box", "fog_box_global"])
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_mis", "fog_mis_global"])
 def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
-    """`volpath_simple` swapped for `path_hip` with volumetric = true, same responsive driver: live HomogeneousMedium objects (sampling parameters read from their
+    """`volpath_simple` / `volpath` swapped for `path_hip` with integrator = "volpath_simple" / "volpath", same responsive driver: live HomogeneousMedium objects (sampling parameters read from their
     serialised form), IsotropicPhaseFunction / HGPhaseFunction, Null BSDFs, interior / exterior media of meshes and of an analytic sphere, the sensor's medium.
     Alpha (EOpacity): 1 on a hit, what the sensor's medium removes over two scene radii on a miss (records.inl:131-134); a medium-transition shape counts as opaque."""
     sc = golden_scenes[name]

@@ -958,12 +958,14 @@ def test_both_tree_node_kinds(mi, golden_scenes, name, monkeypatch):
         assert (bits(got["wide"]) == bits(st["li"])).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.99
 
 
-@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide"])
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide"])
 def test_volpath_simple(mi, oracle, golden_scenes, name):
     """SURVEY.md 8f-4: SimpleVolumetricPathTracer::Li (src/integrators/path/volpath_simple.cpp) over homogeneous media (src/medium/homogeneous.cpp: balance / single /
     manual distance sampling; isotropic and Henyey-Greenstein phase functions), `null` boundaries, a dielectric block with an interior medium, a `null` sphere, the
     sensor inside a medium; emitter sampling attenuated by Scene::evalTransmittance (scene.cpp:650-713) in k_shadow_vol.  exp / log go through the double-precision
-    routines on every side (math.h:185-195), so the radiance samples equal the oracle's and those of the strict-IEEE build of the reference bit for bit."""
+    routines on every side (math.h:185-195), so the radiance samples equal the oracle's and those of the strict-IEEE build of the reference bit for bit.
+    fog_mis*: the same rooms through VolumetricPathTracer::Li (src/integrators/path/volpath.cpp): multiple importance sampling between emitter sampling and
+    phase-function / BSDF sampling, emitters found through index-matched boundaries (rayIntersectAndLookForEmitter; second record kind of k_shadow_volmis)."""
     sc = golden_scenes[name]; gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
     gs = mi.Scene(sc); r = mi.Render(gs); orc = oracle.Oracle(sc)
     got = r.samples(gd["pairs"]); ref = orc.render_samples(gd["pairs"])["li"]
@@ -996,12 +998,16 @@ def test_volpath_simple_refusals(mi, golden_scenes):
         mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
     with pytest.raises(RuntimeError, match="integrators path"):
         mi.Render(mi.Scene(golden_scenes["cornell_small"]), integrator=7)
+    with pytest.raises(RuntimeError, match="environment emitter"):
+        mi.Render(mi.Scene(sc), integrator=S.INTEGRATOR_VOLPATH)
     # a scene without media through the volumetric loop = the same estimator without MIS: converges to the same image (loose check on the mean)
     os.environ["MI355PT_NO_PACKET"] = "1"
     try:
         sc = S.cornell_box(64, 36, 64); gs = mi.Scene(sc)
-        a = mi.Render(gs); a.run(); b = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE); b.run()
-        fa, fb = a.read_film(0), b.read_film(0)
+        a = mi.Render(gs); a.run(); b = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE); b.run(); c = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH); c.run()
+        fa, fb, fc = a.read_film(0), b.read_film(0), c.read_film(0)
         assert abs(fa[..., :3].mean() - fb[..., :3].mean()) / fa[..., :3].mean() < 0.05
+        # ... and volpath without media IS path: same sampler requests, same estimator (volpath.cpp vs path.cpp) -> the same film up to the operation order of the weights
+        assert np.linalg.norm(fa[..., :3] - fc[..., :3]) / np.linalg.norm(fa[..., :3]) < 1e-5
     finally:
         del os.environ["MI355PT_NO_PACKET"]
