@@ -2137,6 +2137,24 @@ static v3 sample_attenuated_emitter_direct(const orc_scene *s, v3 ref, v3 refN, 
     return mul(value, scale(tr, r));                  /* value *= evalTransmittance(...) / emPdf */
 }
 
+/* RadianceQueryRecord::rayIntersect, EOpacity (records.inl:121-137); a hit on a medium-transition shape is taken as opaque (:128-130 not restated) */
+static float sensor_ray_alpha(const orc_scene *s, v3 o, v3 d, int hit, int medium) {
+    if (!s->d.opacity || hit) return 1.0f;
+    if (medium < 0) return 0.0f;
+    /* :131-134: 1 - average transmittance of the sensor's medium over twice the scene's bounding-sphere radius.  Scene::getBSphere: the kd-tree box expanded by the
+     * sensor's and the point / spot emitters' positions (scene.cpp:394-421, aabb.cpp:44-47) */
+    v3 lo = s->aabb_lo, hi = s->aabb_hi, c;
+    v3 cam = V(s->d.cam_to_world[3], s->d.cam_to_world[7], s->d.cam_to_world[11]);
+    lo = V(minf(lo.x, cam.x), minf(lo.y, cam.y), minf(lo.z, cam.z)); hi = V(maxf(hi.x, cam.x), maxf(hi.y, cam.y), maxf(hi.z, cam.z));
+    for (uint32_t e = 0; e < s->d.n_emitters; ++e) if (s->emitters[e].type == 3 || s->emitters[e].type == 4) {
+        v3 p = V(s->emitters[e].to_world[3], s->emitters[e].to_world[7], s->emitters[e].to_world[11]);
+        lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
+    }
+    c = scale(add(hi, lo), 0.5f); float dist = length3(sub(c, hi)) * 2;
+    v3 p2 = add(o, scale(d, dist)), dd = sub(p2, o);
+    v3 tr = medium_transmittance(&s->media[medium], 0.0f, length3(dd));
+    return 1 - ((0.0f + tr.x) + tr.y + tr.z) * (1.0f / 3);
+}
 /* src/integrators/path/volpath_simple.cpp:84-289 SimpleVolumetricPathTracer::Li (no subsurface) */
 static v3 volpath_simple_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sampler_t *sp, int *out_depth, uint64_t *counters, float *alpha, const v3 *rxd, const v3 *ryd) {
     const int maxDepth = s->d.max_depth, rrDepth = s->d.rr_depth;
@@ -2145,23 +2163,7 @@ static v3 volpath_simple_li(const orc_scene *s, v3 o, v3 d, float mint, float ma
     int nullChain = 1, scattered = 0; float eta = 1.0f;
     ++counters[0];
     if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
-    *alpha = 1.0f;                                                /* records.inl:121-137 (EOpacity); a hit on a medium-transition shape is taken as opaque (:128-130 not restated) */
-    if (s->d.opacity && !its.valid) {
-        *alpha = 0.0f;
-        if (medium >= 0) {                                        /* :131-134: 1 - average transmittance of the sensor's medium over twice the scene's bounding-sphere radius */
-            v3 lo = s->aabb_lo, hi = s->aabb_hi, c;               /* Scene::getBSphere: the kd-tree box expanded by the sensor's and the point / spot emitters' positions (scene.cpp:394-421, aabb.cpp:44-47) */
-            v3 cam = V(s->d.cam_to_world[3], s->d.cam_to_world[7], s->d.cam_to_world[11]);
-            lo = V(minf(lo.x, cam.x), minf(lo.y, cam.y), minf(lo.z, cam.z)); hi = V(maxf(hi.x, cam.x), maxf(hi.y, cam.y), maxf(hi.z, cam.z));
-            for (uint32_t e = 0; e < s->d.n_emitters; ++e) if (s->emitters[e].type == 3 || s->emitters[e].type == 4) {
-                v3 p = V(s->emitters[e].to_world[3], s->emitters[e].to_world[7], s->emitters[e].to_world[11]);
-                lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
-            }
-            c = scale(add(hi, lo), 0.5f); float dist = length3(sub(c, hi)) * 2;
-            v3 p2 = add(o, scale(d, dist)), dd = sub(p2, o);
-            v3 tr = medium_transmittance(&s->media[medium], 0.0f, length3(dd));
-            *alpha = 1 - ((0.0f + tr.x) + tr.y + tr.z) * (1.0f / 3);
-        }
-    }
+    *alpha = sensor_ray_alpha(s, o, d, its.valid, medium);
     v3 throughput = V(1, 1, 1);
     int emitted = 1, others = 1;                                  /* rRec.type: EEmittedRadiance / the bits of ERadianceNoEmission (they only ever change together) */
     if (maxDepth == 1) others = 0;
@@ -2266,8 +2268,7 @@ static v3 volpath_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sam
     hit_t its; v3 Li = V(0, 0, 0); int depth = 1, medium = s->d.sensor_medium, scattered = 0; float eta = 1.0f;
     ++counters[0];
     if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
-    *alpha = 1.0f;
-    if (s->d.opacity && !its.valid) *alpha = 0.0f;               /* (the sensor-medium case of records.inl:131-134: see volpath_simple_li; not needed by the classic film) */
+    *alpha = sensor_ray_alpha(s, o, d, its.valid, medium);
     v3 throughput = V(1, 1, 1); int emitted = 1;                  /* rRec.type is ERadiance or ERadianceNoEmission throughout */
     int differentials = 1;
     while (depth <= maxDepth || maxDepth < 0) {
