@@ -121,30 +121,38 @@ struct Builder {
             nodes[id].left = l; nodes[id].right = r; return id;
         }
         if (count <= 2 || depth > 60) { if (count <= 8) return makeLeaf(); }
-        // binned SAH over the widest centroid axis, 16 bins
-        V3 ce = chi - clo; int axis = ce.x > ce.y ? (ce.x > ce.z ? 0 : 2) : (ce.y > ce.z ? 1 : 2);
-        float cmin = comp(clo, axis), cext = comp(ce, axis);
+        // binned SAH, 16 bins per axis, all three centroid axes tried (round 1 / early round 2: the widest axis only; MI355PT_SAH1=1 restores that for A/B runs)
+        static const bool widestOnly = [] { const char *e = getenv("MI355PT_SAH1"); return e && e[0] == '1'; }();
+        V3 ce = chi - clo; const int widest = ce.x > ce.y ? (ce.x > ce.z ? 0 : 2) : (ce.y > ce.z ? 1 : 2);
         int mid = -1;
-        if (cext > 0) {
-            const int NB = 16; int cnt[NB] = {0}; V3 blo[NB], bhi[NB];
-            for (int b = 0; b < NB; ++b) { blo[b] = mk(inf, inf, inf); bhi[b] = mk(-inf, -inf, -inf); }
-            auto binOf = [&](uint32_t t) { int b = (int) ((comp((*cen)[t], axis) - cmin) / cext * NB); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };
-            for (int i = first; i < first + count; ++i) { uint32_t t = order[i]; int b = binOf(t); cnt[b]++; blo[b] = vmin(blo[b], (*tlo)[t]); bhi[b] = vmax(bhi[b], (*thi)[t]); }
-            auto area = [](V3 l, V3 h) { V3 e = h - l; return 2.0f * (e.x * e.y + e.y * e.z + e.z * e.x); };
-            float rightArea[NB]; int rightCnt[NB]; V3 rl = mk(inf, inf, inf), rh = mk(-inf, -inf, -inf); int rc = 0;
-            for (int b = NB - 1; b > 0; --b) { if (cnt[b]) { rl = vmin(rl, blo[b]); rh = vmax(rh, bhi[b]); } rc += cnt[b]; rightArea[b] = rc ? area(rl, rh) : 0; rightCnt[b] = rc; }
-            V3 ll = mk(inf, inf, inf), lh = mk(-inf, -inf, -inf); int lc = 0; float best = inf; int bestSplit = -1;
-            for (int b = 0; b < NB - 1; ++b) {
-                if (cnt[b]) { ll = vmin(ll, blo[b]); lh = vmax(lh, bhi[b]); } lc += cnt[b];
-                if (lc == 0 || rightCnt[b + 1] == 0) continue;
-                float cost = area(ll, lh) * lc + rightArea[b + 1] * rightCnt[b + 1];
-                if (cost < best) { best = cost; bestSplit = b; }
+        {
+            const int NB = 16; auto area = [](V3 l, V3 h) { V3 e = h - l; return 2.0f * (e.x * e.y + e.y * e.z + e.z * e.x); };
+            float best = inf; int bestSplit = -1, bestAxis = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                if (widestOnly && axis != widest) continue;
+                const float cmin = comp(clo, axis), cext = comp(ce, axis);
+                if (!(cext > 0)) continue;
+                int cnt[NB] = {0}; V3 blo[NB], bhi[NB];
+                for (int b = 0; b < NB; ++b) { blo[b] = mk(inf, inf, inf); bhi[b] = mk(-inf, -inf, -inf); }
+                auto binOf = [&](uint32_t t) { int b = (int) ((comp((*cen)[t], axis) - cmin) / cext * NB); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };
+                for (int i = first; i < first + count; ++i) { uint32_t t = order[i]; int b = binOf(t); cnt[b]++; blo[b] = vmin(blo[b], (*tlo)[t]); bhi[b] = vmax(bhi[b], (*thi)[t]); }
+                float rightArea[NB]; int rightCnt[NB]; V3 rl = mk(inf, inf, inf), rh = mk(-inf, -inf, -inf); int rc = 0;
+                for (int b = NB - 1; b > 0; --b) { if (cnt[b]) { rl = vmin(rl, blo[b]); rh = vmax(rh, bhi[b]); } rc += cnt[b]; rightArea[b] = rc ? area(rl, rh) : 0; rightCnt[b] = rc; }
+                V3 ll = mk(inf, inf, inf), lh = mk(-inf, -inf, -inf); int lc = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    if (cnt[b]) { ll = vmin(ll, blo[b]); lh = vmax(lh, bhi[b]); } lc += cnt[b];
+                    if (lc == 0 || rightCnt[b + 1] == 0) continue;
+                    const float cost = area(ll, lh) * lc + rightArea[b + 1] * rightCnt[b + 1];
+                    if (cost < best) { best = cost; bestSplit = b; bestAxis = axis; }
+                }
             }
-            float leafCost = area(lo, hi) * count;
+            const float leafCost = area(lo, hi) * count;
             if (bestSplit >= 0 && (count > 4 ? true : best + area(lo, hi) * 1.0f < leafCost)) {
+                const int axis = bestAxis; const float cmin = comp(clo, axis), cext = comp(ce, axis);
+                auto binOf = [&](uint32_t t) { int b = (int) ((comp((*cen)[t], axis) - cmin) / cext * NB); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };
                 auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) { return binOf(t) <= bestSplit; });
                 mid = (int) (it - order.begin());
-            } else if (count <= 8) return makeLeaf();
+            } else if (count <= 8 && (comp(ce, 0) > 0 || comp(ce, 1) > 0 || comp(ce, 2) > 0)) return makeLeaf();
         }
         if (mid <= first || mid >= first + count) {   // degenerate: all centroids equal -> split in the middle
             if (count <= 8) return makeLeaf();
