@@ -269,7 +269,7 @@ template <typename T> static int up(void **dst, const std::vector<T> &v) {
     return 0;
 }
 void SceneHost::release() {
-    void **ps[] = {&dMedia, &dPrimMedia, &dPacketGroups, &dPacketExact, &dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights};
+    void **ps[] = {&dMedia, &dPrimMedia, &dPacketGroups, &dPacketExact, &dTexLevels, &dTexTexels, &dMipLut, &dTriUV, &dTextures, &dMaterialTables, &dInstances, &dEmitterX, &dAnalytic, &dNodes, &dTris, &dShade, &dI2, &dNrm, &dMaterials, &dEmitters, &dEmitterCdf, &dAreaCdf, &dFilter, &dSobolM32, &dSobolVdc, &dSobolVdcInv, &dEnvRGB, &dEnvCols, &dEnvRows, &dEnvWeights, &dEnvGuideRows, &dEnvGuideCols};
     for (void **p : ps) if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 int SceneHost::upload(int dev) {
@@ -338,6 +338,8 @@ int SceneHost::upload(int dev) {
     d.env_bs_radius = envBsRadius; memcpy(d.env_bs_center, envBsCenter, 12);
     if (envIndex >= 0 && !envConstant) {
         if (up(&dEnvRGB, envRGB) | up(&dEnvCols, envCdfCols) | up(&dEnvRows, envCdfRows) | up(&dEnvWeights, envRowWeights)) return 1;
+        if (!envGuideRows.empty()) { if (up(&dEnvGuideRows, envGuideRows) | up(&dEnvGuideCols, envGuideCols)) return 1;
+            d.env_guide_rows_t = (const uint16_t *) dEnvGuideRows; d.env_guide_cols_t = (const uint16_t *) dEnvGuideCols; d.env_guide_rows = envGuideKR; d.env_guide_cols = envGuideKC; }
         d.env_rgb = (const float *) dEnvRGB; d.env_cdf_cols = (const float *) dEnvCols; d.env_cdf_rows = (const float *) dEnvRows; d.env_row_weights = (const float *) dEnvWeights;
         d.env_w = (int) envW; d.env_h = (int) envH; d.env_normalization = envNormalization; d.env_scale = envScale;
         d.env_pixel_w = 2 * MI_PI / (float) envW; d.env_pixel_h = MI_PI / (float) envH; d.env_bs_radius = envBsRadius;
@@ -439,7 +441,7 @@ int mi_scene_clone(mi_scene *s, uint32_t device, mi_scene **out) {
     mi_scene *c = new mi_scene();
     c->h = s->h;                                    // inputs + host-derived data
     {   // the copy must not own the source's device allocations
-        void **ps[] = {&c->h.dMedia, &c->h.dPrimMedia, &c->h.dPacketGroups, &c->h.dPacketExact, &c->h.dTexLevels, &c->h.dTexTexels, &c->h.dMipLut, &c->h.dTriUV, &c->h.dTextures, &c->h.dMaterialTables, &c->h.dInstances, &c->h.dEmitterX, &c->h.dAnalytic, &c->h.dNodes, &c->h.dTris, &c->h.dShade, &c->h.dI2, &c->h.dNrm, &c->h.dMaterials, &c->h.dEmitters, &c->h.dEmitterCdf, &c->h.dAreaCdf, &c->h.dFilter, &c->h.dSobolM32, &c->h.dSobolVdc, &c->h.dSobolVdcInv, &c->h.dEnvRGB, &c->h.dEnvCols, &c->h.dEnvRows, &c->h.dEnvWeights};
+        void **ps[] = {&c->h.dMedia, &c->h.dPrimMedia, &c->h.dPacketGroups, &c->h.dPacketExact, &c->h.dTexLevels, &c->h.dTexTexels, &c->h.dMipLut, &c->h.dTriUV, &c->h.dTextures, &c->h.dMaterialTables, &c->h.dInstances, &c->h.dEmitterX, &c->h.dAnalytic, &c->h.dNodes, &c->h.dTris, &c->h.dShade, &c->h.dI2, &c->h.dNrm, &c->h.dMaterials, &c->h.dEmitters, &c->h.dEmitterCdf, &c->h.dAreaCdf, &c->h.dFilter, &c->h.dSobolM32, &c->h.dSobolVdc, &c->h.dSobolVdcInv, &c->h.dEnvRGB, &c->h.dEnvCols, &c->h.dEnvRows, &c->h.dEnvWeights, &c->h.dEnvGuideRows, &c->h.dEnvGuideCols};
         for (void **p : ps) *p = nullptr;
         c->h.committed = false;
     }

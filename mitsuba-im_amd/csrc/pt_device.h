@@ -1367,6 +1367,15 @@ DEV uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
     sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
     return index;
 }
+// the same search started from a guide table: lower_bound(cdf, sample) lies in [guide[b], guide[b + 1]] for b = floor(sample * K) -- identical index, fewer dependent loads
+DEV uint32_t envSampleReuseG(const float *cdf, uint32_t size, const uint16_t *guide, uint32_t K, float &sample) {
+    uint32_t b = (uint32_t) (sample * (float) K); if (b >= K) b = K - 1u;
+    uint32_t lo = guide[b], hi = guide[b + 1u];
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (cdf[mid] < sample) lo = mid + 1; else hi = mid; }
+    uint32_t index = lo > 0 ? lo - 1 : 0; if (index > size - 1) index = size - 1;
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
 DEV float intervalToTent(float sample) {               // src/libcore/warp.cpp:142-155
     float sign;
     if (sample < 0.5f) { sign = 1; sample *= 2; } else { sign = -1; sample = 2 * (sample - 0.5f); }
@@ -1381,8 +1390,14 @@ DEV void envBilinearPair(const DScene &sc, float px, float py, v3 &value1, v3 &v
 DEV int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 // envmap.cpp:571-608 internalSampleDirection
 DEV void envSampleDirection(const DScene &sc, float sx, float sy, v3 &d, v3 &value, float &pdf) {
-    uint32_t row = envSampleReuse(sc.env_cdf_rows, (uint32_t) sc.env_h, sy);
-    uint32_t col = envSampleReuse(sc.env_cdf_cols + (size_t) row * (sc.env_w + 1), (uint32_t) sc.env_w, sx);
+    uint32_t row, col;
+    if (sc.env_guide_rows) {
+        row = envSampleReuseG(sc.env_cdf_rows, (uint32_t) sc.env_h, sc.env_guide_rows_t, sc.env_guide_rows, sy);
+        col = envSampleReuseG(sc.env_cdf_cols + (size_t) row * (sc.env_w + 1), (uint32_t) sc.env_w, sc.env_guide_cols_t + (size_t) row * (sc.env_guide_cols + 1u), sc.env_guide_cols, sx);
+    } else {
+        row = envSampleReuse(sc.env_cdf_rows, (uint32_t) sc.env_h, sy);
+        col = envSampleReuse(sc.env_cdf_cols + (size_t) row * (sc.env_w + 1), (uint32_t) sc.env_w, sx);
+    }
     float px = (float) col + intervalToTent(sx), py = (float) row + intervalToTent(sy);
     v3 v1, v2; int yPos; envBilinearPair(sc, px, py, v1, v2, yPos);
     value = (v1 + v2) * sc.env_scale;

@@ -149,6 +149,9 @@ struct DScene {
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none
     const float *env_rgb, *env_cdf_cols, *env_cdf_rows, *env_row_weights;
+    // guide tables of the two CDF searches (scene_build.cpp): guide[b] = lower_bound(cdf, b / K) for K = env_guide_rows / env_guide_cols buckets (powers of two), so a
+    // search starts in [guide[b], guide[b + 1]] instead of [0, size + 1] -- the same index, a third of the dependent loads
+    const uint16_t *env_guide_rows_t, *env_guide_cols_t; uint32_t env_guide_rows, env_guide_cols;
     int32_t env_index, env_w, env_h;
     float env_normalization, env_scale, env_pixel_w, env_pixel_h, env_bs_radius;
     float env_to_world[9], env_to_local[9], env_bs_center[3];

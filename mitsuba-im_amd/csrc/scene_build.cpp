@@ -551,6 +551,17 @@ void SceneHost::commitHost() {
         float normalization = 1.0f / rowSum;
         for (int y = 1; y < H; ++y) envCdfRows[rowPos - y - 1] *= normalization;
         envCdfRows[rowPos - 1] = 1.0f;
+        // guide tables: the index lower_bound(cdf, b / K) for every bucket boundary (b / K is exact: K is a power of two), one table for the rows, one per row for the columns
+        auto pow2ge = [](uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; };
+        envGuideKR = std::min<uint32_t>(pow2ge((uint32_t) H), 4096u); envGuideKC = std::min<uint32_t>(pow2ge((uint32_t) W) / 4u > 0 ? pow2ge((uint32_t) W) / 4u : 1u, 1024u);
+        auto guideOf = [](const float *cdf, uint32_t size, uint32_t K, uint16_t *out) {
+            for (uint32_t b = 0; b <= K; ++b) { const float x = (float) b / (float) K; out[b] = b == K ? (uint16_t) (size + 1) : (uint16_t) (std::lower_bound(cdf, cdf + size + 1, x) - cdf); }
+        };
+        if ((uint32_t) W + 1 < 65535u && (uint32_t) H + 1 < 65535u) {
+            envGuideRows.assign(envGuideKR + 1, 0); guideOf(envCdfRows.data(), (uint32_t) H, envGuideKR, envGuideRows.data());
+            envGuideCols.assign((size_t) H * (envGuideKC + 1), 0);
+            for (int y = 0; y < H; ++y) guideOf(envCdfCols.data() + (size_t) y * (W + 1), (uint32_t) W, envGuideKC, envGuideCols.data() + (size_t) y * (envGuideKC + 1));
+        } else { envGuideRows.clear(); envGuideCols.clear(); envGuideKR = envGuideKC = 0; }
         envNormalization = 1.0f / (rowSum * (2 * MI_PI / (float) W) * (MI_PI / (float) H));
     }
     // Sobol film resolution (src/samplers/sobol.cpp:147-157)

@@ -12,6 +12,7 @@ struct SceneHost {
     std::vector<float> pos, nrm, uv; std::vector<uint32_t> idx; std::vector<mi_shape> shapes;
     std::vector<mi_material> materials; std::vector<mi_emitter> emitters; std::vector<mi_analytic> analytic; std::vector<mi_instance> instances; std::vector<float> materialTables; std::vector<mi_texture> textures; std::vector<uint32_t> texLevels; std::vector<float> texTexels; int32_t envTexture = -1;
     std::vector<mi_medium> media; std::vector<int32_t> shapeMedia; int32_t sensorMedium = -1;   // mi_scene_set_media
+    std::vector<uint16_t> envGuideRows, envGuideCols; uint32_t envGuideKR = 0, envGuideKC = 0; void *dEnvGuideRows = nullptr, *dEnvGuideCols = nullptr;
     std::vector<MediumD> mediaD; std::vector<uint32_t> primMedia;   // derived: device records; per primitive (interior + 1) | (exterior + 1) << 16
     void *dMedia = nullptr, *dPrimMedia = nullptr;
     float s2c[16] = {0}, c2w[16] = {0}; float nearClip = 0, farClip = 0; bool haveCamera = false;
