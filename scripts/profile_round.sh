@@ -7,7 +7,7 @@ R=${1:-r02}; CFGS=${2:-"C2 C3 C4"}; OUT=gpurun_out/$R; mkdir -p $OUT; export TMP
 run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -ge 124 ]; then echo "[profile_round] '$*' timed out / was killed (rc $rc): stopping" >&2; exit $rc; fi; return $rc; }
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 for C in $CFGS; do
-  case $C in C2) SPP=32; BASE="";; C3) SPP=32; BASE="--no-cpu-baseline";; *) SPP=8; BASE="--no-cpu-baseline";; esac
+  case $C in C2) SPP=64; BASE="";; C3) SPP=64; BASE="--no-cpu-baseline";; *) SPP=16; BASE="--no-cpu-baseline";; esac      # two full-size batches (one per path pool), as in the full job
   echo "== $C bench"; run 600 python3 bench.py --config $C $BASE > $OUT/${C}_bench.json 2> $OUT/${C}_bench.err || exit 1
   cat $OUT/${C}_bench.json | cut -c1-400
   echo "== $C kernel trace"; run 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${C}_trace -o t -- python3 bench.py --config $C --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${C}_bench_under_rocprof.json 2> $OUT/${C}_trace.err || exit 1
