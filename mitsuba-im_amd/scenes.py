@@ -509,6 +509,29 @@ def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth
                         hide_emitters=hide_emitters, name="cornell")
 
 
+def fog_sky(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, global_fog=False, hide_emitters=False, integrator=INTEGRATOR_VOLPATH, env_size=(64, 32)):
+    """Volumetric loops under an environment map: ground, a diffuse block, a `null` sphere of haze, a glass block with a scattering interior, an area light; with
+    global_fog the sensor sits in a thin medium (the reference then sees the sky through emitter sampling only: a ray that leaves the scene inside an unbounded
+    medium has zero transmittance, volpath.cpp:383-384 with its->t = infinity)."""
+    b = _Builder()
+    grey = b.bsdf(reflectance=(0.5, 0.5, 0.5)); red = b.bsdf(reflectance=(0.65, 0.2, 0.15)); null = b.bsdf(kind=BSDF_NULL); glass = b.bsdf(kind=BSDF_DIELECTRIC, ior=1.5, reflectance=(1.0, 1.0, 1.0))
+    lightm = b.bsdf(reflectance=(0.5, 0.5, 0.5))
+    media = [make_medium((0.05, 0.1, 0.2), (0.9, 0.8, 0.7), phase=PHASE_HG, g=0.4), make_medium((0.2, 0.05, 0.2), (0.5, 1.0, 0.5), strategy=MEDIUM_SINGLE)]
+    ext = -1
+    if global_fog:
+        media.append(make_medium((0.005, 0.005, 0.008), (0.03, 0.03, 0.025))); ext = 2
+    b.begin(); b.quad([(8, 0, -8), (-8, 0, -8), (-8, 0, 8), (8, 0, 8)]); b.end(grey)
+    b.begin(); _closed_box(b, [(-1.2, 0.8), (-1.2, 2.0), (0.2, 2.0), (0.2, 0.8)], 0.001, 1.4); b.end(red)
+    b.begin(); _closed_box(b, [(0.9, 0.2), (0.9, 1.3), (2.0, 1.3), (2.0, 0.2)], 0.001, 1.1); b.end(glass, interior=1, exterior=ext)
+    b.begin(); b.quad([(-0.5, 3.2, 0.5), (0.5, 3.2, 0.5), (0.5, 3.2, 1.5), (-0.5, 3.2, 1.5)]); b.end(lightm, radiance=(6.0, 5.0, 4.0))
+    b.add_analytic(SHAPE_SPHERE, translate(-0.3, 0.9, -0.6), null, radius=0.7, interior=0, exterior=ext)
+    cam = look_at((0.8, 1.3, -4.5), (0.1, 1.0, 1.0), (0, 1, 0))
+    env = dict(rgb=detailed_sky(*env_size), to_world=(rotate((0, 1, 0), 25.0) @ rotate((1, 0, 0), 8.0)).astype(f32), scale=0.8)
+    sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 55.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
+                      seed=seed, hide_emitters=hide_emitters, envmap=env, name="fog_sky", analytic=b.resolve_analytic(), media=media, sensor_medium=ext, integrator=integrator)
+    return add_scene_emitters(sc, [dict(type=EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=1.0)])
+
+
 def _closed_box(b, top, y0, y1):
     """closed box over the quadrilateral `top` = four (x, z) corners in the Cornell blocks' order (normal up); all faces point outwards"""
     P = [tuple(map(float, p)) for p in top]

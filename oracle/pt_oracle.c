@@ -2257,6 +2257,12 @@ static void look_for_emitter(const orc_scene *s, int medium, int maxInteractions
     if (surface && its->emitter >= 0) {                  /* dRec.setQuery(ray, *its) (records.inl:170-178): dist = the LAST segment's t; ref / refN stay */
         dRec->p = its->p; dRec->n = its->ns; dRec->d = d; dRec->dist = its->t; dRec->emitter = its->emitter;
         *value = mul(transmittance, emitter_eval(s, its->emitter, its->ns, neg(d)));
+    } else if (!surface && s->env_index >= 0) {          /* volpath.cpp:421-426: env->fillDirectSamplingRecord(dRec, ray) (envmap.cpp:362-378, from the ADVANCED origin), evalEnvironment without differentials */
+        float nearT, farT;
+        if (bsphere_intersect(s->env_bs_center, s->env_bs_radius, o, d, &nearT, &farT) && !(nearT > 0) && !(farT < 0)) {
+            dRec->p = add(o, scale(d, farT)); dRec->n = normalize(sub(s->env_bs_center, dRec->p)); dRec->d = d; dRec->dist = farT; dRec->emitter = s->env_index;
+            *value = mul(transmittance, env_eval(s, d));
+        }
     }
 }
 static float phase_pdf(const orc_medium *m, v3 wi, v3 wo) { return phase_eval(m, wi, wo); }       /* PhaseFunction::pdf (src/librender/phase.cpp:21-23); isotropic: the same constant */
@@ -2299,7 +2305,14 @@ static v3 volpath_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sam
             emitted = 0;
         } else {
             if (medium >= 0) { float r = 1.0f / mRec.pdf_failure; throughput = mul(throughput, scale(mRec.transmittance, r)); }
-            if (!its.valid) break;                                /* (no environment emitter) */
+            if (!its.valid) {                                     /* volpath.cpp:181-192 */
+                if (s->env_index >= 0 && emitted && (!hide || scattered)) {
+                    v3 value = mul(throughput, (s->d.env_texture && !s->env_constant && differentials) ? env_eval_filtered(s, d, *rxd, *ryd) : env_eval(s, d));
+                    if (medium >= 0) value = mul(value, medium_transmittance(&s->media[medium], mint, maxt));
+                    Li = add(Li, value);
+                }
+                break;
+            }
             if (its.emitter >= 0 && emitted && (!hide || scattered))
                 Li = add(Li, mul(throughput, emitter_eval(s, its.emitter, its.ns, neg(d))));
             if (depth >= maxDepth && maxDepth != -1) break;

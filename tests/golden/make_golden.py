@@ -113,6 +113,10 @@ def golden_scenes():
         # the same rooms through `volpath` (multiple importance sampling; emitters found through index-matched boundaries)
         "fog_mis": scenes.fog_box(width=96, height=96, spp=16, integrator=scenes.INTEGRATOR_VOLPATH),
         "fog_mis_global": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=15, rr_depth=2, integrator=scenes.INTEGRATOR_VOLPATH),
+        # the volumetric loops under an environment map (sky seen through media, emitter sampling of the map attenuated by the media)
+        "fog_sky": scenes.fog_sky(width=96, height=64, spp=16),
+        "fog_sky_simple": scenes.fog_sky(width=96, height=64, spp=16, integrator=scenes.INTEGRATOR_VOLPATH_SIMPLE),
+        "fog_sky_global_hide": scenes.fog_sky(width=96, height=64, spp=8, global_fog=True, hide_emitters=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=16, rr_depth=2),
         "fog_mis_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5, integrator=scenes.INTEGRATOR_VOLPATH),
     }
 
