@@ -10,16 +10,28 @@
 // 20..27 current medium + 1.  Shadow record: shO = p1 | medium + 1, maxInteractions (int16), p1OnSurface, p2OnSurface; shD = p2 | path id; shC = emitter value BEFORE the
 // division by the emitter-selection probability | that probability; shT = throughput; shX = BSDF value (or the phase value in all three channels).
 // Built for: meshes + analytic shapes (media on scene-level shapes), every plain BSDF incl. `null`, textures, area / point / spot / directional emitters.  Refused at
-// mi_render_create: environment emitters, mask / thindielectric (their ENull lobes would have to be evaluated inside the transmittance walk), the BSDF adapters.
+// mi_render_create: the `constant` environment emitter, mask / thindielectric (their ENull lobes would have to be evaluated inside the transmittance walk), the BSDF adapters.
 #include "kernels_common.h"
 #include "trace.h"
+
+// EnvironmentMap::evalEnvironment for a ray that carries differentials (the sensor ray; envmap.cpp:398-411 -> TMIPMap::eval over the map's pyramid), as k_env_primary
+DEV v3 envEvalSensorRay(const DScene &sc, const RenderConst &rc, v3 d, float2 sp) {
+    if (!sc.env_texture) return envEval(sc, d);
+    const TextureD tx = sc.textures[sc.env_texture - 1u];
+    v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
+    const v3 v = mat3(sc.env_to_local, d);
+    const float uvx = atan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
+    const v3 dvdx = mat3(sc.env_to_local, rxd) - v, dvdy = mat3(sc.env_to_local, ryd) - v;
+    const float t1 = MI_INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -MI_INV_PI / maxf(sqrtf(maxf(0.0f, 1.0f - v.y * v.y)), MI_EPSILON);
+    return mipEval(sc, tx, uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y) * sc.env_scale;
+}
 
 #define VOL_EMITTED (1u << 16)
 #define VOL_OTHERS (1u << 17)
 #define VOL_NULLCHAIN (1u << 18)
 #define VOL_SCATTERED (1u << 19)
 
-template <bool TEX>
+template <bool TEX, bool ENV>      // TEX: textures bound to materials; ENV: an environment map among the emitters
 __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -70,7 +82,12 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                     nee = others; nref = mRec.p;                             // EDirectMediumRadiance
                 } else {
                     if (medium >= 0) { const float r = 1.0f / mRec.pdfFailure; T = T * (mRec.transmittance * r); }
-                    if (prim == 0xFFFFFFFFu) {                               // no environment emitters in this build of the stage: the path just ends
+                    if (prim == 0xFFFFFFFFu) {                               // volpath_simple.cpp:172-183: possibly attenuated radiance from the environment
+                        if (ENV && emitted && (!rc.hide_emitters || scattered)) {
+                            v3 value = T * (depth == 1 ? envEvalSensorRay(sc, rc, d, q.pos[pid]) : envEval(sc, d));
+                            if (medium >= 0) value = value * mediumTransmittance(md, ro.w, rd.w);
+                            add = value; haveAdd = true;
+                        }
                         pathLen += (unsigned) depth; break;
                     }
                     const int inst = q.hitInst ? q.hitInst[slot] : -1;
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 // ---- emitter sampling for either interaction (volpath_simple.cpp:127-138 / :197-216): the record goes to k_shadow_vol, which attenuates and adds it
                 if (nee) {
                     float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                    Direct dr; const v3 value = sampleEmitterDirect<false, true, false, true>(sc, tb, nref, nrefN, sx, sy, dr);
+                    Direct dr; const v3 value = sampleEmitterDirect<ENV, true, false, true>(sc, tb, nref, nrefN, sx, sy, dr);
                     if (dr.pdf != 0) {
                         v3 x; int m2 = medium; uint32_t onSurface = 0u;
                         if (mediumEvent) { const float ph = phaseEval(md, -d, dr.d); x = V(ph, ph, ph); }
@@ -233,8 +250,9 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
 
 extern "C" {
 void mi_launch_shade_vol(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
-    if (sc.n_textures) hipLaunchKernelGGL((k_shade_vol<true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
-    else hipLaunchKernelGGL((k_shade_vol<false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
+    const bool env = sc.env_index >= 0;
+    if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else { if (env) hipLaunchKernelGGL((k_shade_vol<false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_vol(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     if (sc.bvh_wide) hipLaunchKernelGGL((k_shadow_vol<true>), dim3(grid), dim3(WG), 0, st, sc, q);

@@ -13,6 +13,18 @@
 #include "kernels_common.h"
 #include "trace.h"
 
+// EnvironmentMap::evalEnvironment for a ray that carries differentials (the sensor ray; envmap.cpp:398-411 -> TMIPMap::eval over the map's pyramid), as k_env_primary
+DEV v3 envEvalSensorRay(const DScene &sc, const RenderConst &rc, v3 d, float2 sp) {
+    if (!sc.env_texture) return envEval(sc, d);
+    const TextureD tx = sc.textures[sc.env_texture - 1u];
+    v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
+    const v3 v = mat3(sc.env_to_local, d);
+    const float uvx = atan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
+    const v3 dvdx = mat3(sc.env_to_local, rxd) - v, dvdy = mat3(sc.env_to_local, ryd) - v;
+    const float t1 = MI_INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -MI_INV_PI / maxf(sqrtf(maxf(0.0f, 1.0f - v.y * v.y)), MI_EPSILON);
+    return mipEval(sc, tx, uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y) * sc.env_scale;
+}
+
 #define VM_EMITTED (1u << 16)
 #define VM_DELTA (1u << 17)
 #define VM_SEARCH (1u << 18)
@@ -21,7 +33,7 @@
 #define VM_SKIPRR (1u << 29)
 // shadow record bits (shO.w): 0..7 medium + 1, 8..23 maxInteractions (int16), 24 p1OnSurface, 25 p2OnSurface, 26 kind = emitter search, 27 facingRef, 28 delta sample
 
-template <bool TEX>
+template <bool TEX, bool ENV>
 __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -80,6 +92,16 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                         seT = make_float4(T.x, T.y, T.z, 0.0f); seX = make_float4(o.x, o.y, o.z, 0.0f);     // dRec.ref = the spawning vertex
                     }
                 }
+                if (ENV && (fl & VM_SEARCH) && prim == 0xFFFFFFFFu && medium < 0) {      // :421-426: the ray left the scene -> the environment map (inside a medium the unbounded segment has zero transmittance)
+                    float nearT, farT;
+                    if (bsphereIntersect(sc, o, d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {        // EnvironmentMap::fillDirectSamplingRecord (envmap.cpp:362-378)
+                        const v3 value = envEval(sc, d);
+                        if (!isZero(value)) {
+                            const float lumPdf = (fl & VM_DELTA) ? 0.0f : envPdfDirection(sc, mat3(sc.env_to_local, d)) * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+                            add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
+                        }
+                    }
+                }
                 if (depth > 1 && !(fl & VM_SKIPRR) && depth - 1 >= rc.rr_depth) {     // volpath.cpp:326-337 (the previous iteration's tail)
                     const float qq = minf(maxf(maxf(T.x, T.y), T.z) * eta * eta, 0.95f);
                     if (next1D(ss, rc.sampler, m32) >= qq) { pathLen += (unsigned) depth; break; }
@@ -102,7 +124,14 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     nee = true; nref = mRec.p;
                 } else {
                     if (medium >= 0) { const float r = 1.0f / mRec.pdfFailure; T = T * (mRec.transmittance * r); }
-                    if (prim == 0xFFFFFFFFu) { pathLen += (unsigned) depth; break; }
+                    if (prim == 0xFFFFFFFFu) {                               // volpath.cpp:181-192
+                        if (ENV && emitted && (!rc.hide_emitters || scattered)) {
+                            v3 value = T * (depth == 1 ? envEvalSensorRay(sc, rc, d, q.pos[pid]) : envEval(sc, d));
+                            if (medium >= 0) value = value * mediumTransmittance(md, ro.w, rd.w);
+                            add = haveAdd ? add + value : value; haveAdd = true;
+                        }
+                        pathLen += (unsigned) depth; break;
+                    }
                     fill();
                     if (h.emitter >= 0 && emitted && (!rc.hide_emitters || scattered)) { const v3 e = T * emitterEval(tb, h.emitter, h.ns, -d); add = haveAdd ? add + e : e; haveAdd = true; }
                     if (depth >= rc.max_depth && rc.max_depth != -1) { pathLen += (unsigned) depth; break; }      // :203-204
@@ -137,7 +166,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                 // ---- emitter sampling with the power heuristic (volpath.cpp:127-150 / :215-250)
                 if (nee) {
                     float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
-                    Direct dr; const v3 value = sampleEmitterDirect<false, true, false, true>(sc, tb, nref, nrefN, sx, sy, dr);
+                    Direct dr; const v3 value = sampleEmitterDirect<ENV, true, false, true>(sc, tb, nref, nrefN, sx, sy, dr);
                     if (dr.pdf != 0) {
                         v3 x; float w; int m2 = medium; uint32_t onSurface = 0u;
                         if (mediumEvent) { const float ph = phaseEval(md, -d, dr.d); x = V(ph, ph, ph); w = miWeight(dr.pdf, dr.delta ? 0.0f : ph); }      // PhaseFunction::pdf = eval (phase.cpp:21-23)
@@ -202,7 +231,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
     if (lane == 0 && pathLen) atomicAdd(&q.counters[2], pathLen);
 }
 
-template <bool WIDE>
+template <bool WIDE, bool ENV>
 __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
     __shared__ int s_stk[STACK_DEPTH * WG];
     const uint32_t tid = threadIdx.x;
@@ -235,6 +264,18 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                 if (pm) medium = targetMedium(pm, h.ng, d);
                 o = o + d * t;
                 if (++interactions > 100) { surface = false; break; }
+            }
+            if (ENV && !surface && interactions <= 100 && !isZero(tr)) {        // the search left the scene: the environment map, from the ADVANCED origin (volpath.cpp:421-426)
+                float nearT, farT;
+                if (bsphereIntersect(sc, o, d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {
+                    const v3 value = tr * envEval(sc, d);
+                    if (!isZero(value)) {
+                        const float4 tt = q.shT[shBase + i];
+                        const float lumPdf = (bits & (1u << 28)) ? 0.0f : envPdfDirection(sc, mat3(sc.env_to_local, d)) * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+                        const v3 li = (V(tt.x, tt.y, tt.z) * value) * miWeight(c.w, lumPdf);
+                        float4 a = q.acc[pid]; a.x += li.x; a.y += li.y; a.z += li.z; q.acc[pid] = a;
+                    }
+                }
             }
             if (surface && h.emitter >= 0) {
                 const v3 value = tr * emitterEval(tb, h.emitter, h.ns, -d);
@@ -293,11 +334,13 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
 
 extern "C" {
 void mi_launch_shade_volmis(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
-    if (sc.n_textures) hipLaunchKernelGGL((k_shade_volmis<true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
-    else hipLaunchKernelGGL((k_shade_volmis<false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf);
+    const bool env = sc.env_index >= 0;
+    if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else { if (env) hipLaunchKernelGGL((k_shade_volmis<false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_volmis(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
-    if (sc.bvh_wide) hipLaunchKernelGGL((k_shadow_volmis<true>), dim3(grid), dim3(WG), 0, st, sc, q);
-    else hipLaunchKernelGGL((k_shadow_volmis<false>), dim3(grid), dim3(WG), 0, st, sc, q);
+    const bool env = sc.env_index >= 0;
+    if (sc.bvh_wide) { if (env) hipLaunchKernelGGL((k_shadow_volmis<true, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_volmis<true, false>), dim3(grid), dim3(WG), 0, st, sc, q); }
+    else { if (env) hipLaunchKernelGGL((k_shadow_volmis<false, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_volmis<false, false>), dim3(grid), dim3(WG), 0, st, sc, q); }
 }
 }
