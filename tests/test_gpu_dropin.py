@@ -80,7 +80,7 @@ def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
-@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_mis", "fog_mis_global"])
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky"])
 def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
     """`volpath_simple` / `volpath` swapped for `path_hip` with integrator = "volpath_simple" / "volpath", same responsive driver: live HomogeneousMedium objects (sampling parameters read from their
     serialised form), IsotropicPhaseFunction / HGPhaseFunction, Null BSDFs, interior / exterior media of meshes and of an analytic sphere, the sensor's medium.
@@ -91,7 +91,7 @@ def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
     got = np.load(out + "_target.npy"); ref = np.load(os.path.join(GOLDEN, name + "_responsive.npz"))["target"]
     g, r = got[1:-2, 1:-2, :3], ref[1:-2, 1:-2, :3]
     rel = np.abs(g - r).max(2) / (np.abs(r).max(2) + 1e-6)
-    assert (rel < 1e-4).mean() > 0.99 and np.linalg.norm(g - r) / np.linalg.norm(r) < 1e-3
+    assert (rel < (1e-3 if name == "fog_sky" else 1e-4)).mean() > 0.99 and np.linalg.norm(g - r) / np.linalg.norm(r) < (1e-2 if name == "fog_sky" else 1e-3)      # fog_sky: an environment map (device atan2 / acos, -ffast-math forks as in the other envmap drop-ins)
     assert (np.abs(got[1:-2, 1:-2, 3] - ref[1:-2, 1:-2, 3]) < 1e-3 * sc.spp).mean() > 0.97
 
 
