@@ -463,6 +463,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     // index list must fit LDS -- as many as keep a segment at ~1000 slots (C3 at 64 M paths: 1916 Msamples/s with 16384 segments, 1983 with 65536)
     uint32_t grid = envU("MI355PT_SEGMENTS", r->scene->h.d.has_roughconductor ? (uint32_t) std::min<uint64_t>(std::max<uint64_t>(16384u, paths / 1024u), 1u << 18) : 16384u);
     uint64_t minGrid = (paths + 63) / 64; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
+    if (r->rc.integrator != MI_INTEGRATOR_PATH && (paths + grid - 1) / grid > 65472u) grid = (uint32_t) ((paths + 65471u) / 65472u);      // the volumetric stages count two kinds of shadow records per segment in 16 bits each
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 63) / 64 * 64;
     r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
     // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
@@ -477,7 +478,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     }
     if (r->scene->h.d.n_instances) ALLOC(Q.hitInst, int32_t, slots); else Q.hitInst = nullptr;
     // shadow records: 48 B; the volumetric integrators add throughput and BSDF / phase value (80 B); volpath leaves up to two records per path and pass (kernels_volmis.hip)
-    const uint64_t shSlots = r->rc.integrator == MI_INTEGRATOR_VOLPATH ? slots * 2 : slots;
+    const uint64_t shSlots = r->rc.integrator != MI_INTEGRATOR_PATH ? slots * 2 : slots;
     ALLOC(Q.hit, float4, slots); ALLOC(Q.shO, float4, shSlots); ALLOC(Q.shD, float4, shSlots); ALLOC(Q.shC, float4, shSlots);
     if (r->rc.integrator != MI_INTEGRATOR_PATH) { ALLOC(Q.shT, float4, shSlots); ALLOC(Q.shX, float4, shSlots); } else { Q.shT = nullptr; Q.shX = nullptr; }
     ALLOC(Q.acc, float4, slots); ALLOC(Q.pos, float2, slots); ALLOC(Q.shCount, uint32_t, grid);
@@ -651,7 +652,7 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
         if (r->rc.integrator != MI_INTEGRATOR_PATH) {      // the same loop over media: its own shade and shadow stages (kernels_vol.hip, kernels_volmis.hip)
             const size_t lds = r->rc.sampler == MI_SAMPLER_SOBOL ? (size_t) r->rc.nib_dims * r->rc.nib_count * 64 : 16; const bool mis = r->rc.integrator == MI_INTEGRATOR_VOLPATH;
             mark(r, 2, evUsed, st); (mis ? mi_launch_shade_volmis : mi_launch_shade_vol)(sc, r->rc, Q, buf, r->gridShade, lds, st);
-            if (depth < maxDepth) { mark(r, 3, evUsed, st); (mis ? mi_launch_shadow_volmis : mi_launch_shadow_vol)(sc, Q, r->gridShadow, st); }
+            if (depth < maxDepth || (depth == 1 && r->rc.opacity)) { mark(r, 3, evUsed, st); (mis ? mi_launch_shadow_volmis : mi_launch_shadow_vol)(sc, Q, r->gridShadow, st); }      // (depth 1 with EOpacity: the alpha walks)
         } else {
         if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) mi_launch_env_primary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
         mark(r, 2, evUsed, st); mi_launch_shade(sc, r->ldsTables, r->rc, Q, buf, r->gridShade, st);

@@ -45,12 +45,12 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t seg = blockIdx.x * (WG / 64) + wave; seg < q.n_seg; seg += gridDim.x * (WG / 64)) {     // a segment is owned by one wave (shade.h)
     const uint32_t n = q.count[buf][seg];
-    const uint64_t segBase = (uint64_t) seg * q.cap;
-    uint32_t outA = 0, outS = 0;
+    const uint64_t segBase = (uint64_t) seg * q.cap, shBase = segBase * 2u;      // the shadow queue holds two records per path slot (emitter sampling + the alpha walk of a sensor ray)
+    uint32_t outA = 0, outS = 0, outE = 0;
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
-        bool alive = false, wantShadow = false;
-        float4 shO, shD, shC, shT, shX, nrO, nrD, nS1; uint4 nS0;
+        bool alive = false, wantShadow = false, wantAlpha = false;
+        float4 shO, shD, shC, shT, shX, alO, alD, nrO, nrD, nS1; uint4 nS0;
         if (i < n) {
             const uint64_t slot = segBase + i;
             const float4 ro = q.rayO[buf][slot], rd = q.rayD[buf][slot], hr = q.hit[slot]; const uint4 s0 = q.st0[buf][slot]; const float4 s1 = q.st1[buf][slot];
@@ -73,6 +73,19 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                     float al = 0.0f;
                     if (medium >= 0) { const v3 p2 = o + d * rc.alpha_dist, dd = p2 - o; const v3 tr = mediumTransmittance(md, 0.0f, sqrtf(dot(dd, dd))); al = 1 - ((0.0f + tr.x) + tr.y + tr.z) * (1.0f / 3); }
                     float4 a = q.acc[pid]; a.w = al; q.acc[pid] = a;
+                }
+                if (depth == 1 && rc.opacity && prim != 0xFFFFFFFFu) {      // records.inl:124-130: a sensor ray that hits a medium-transition shape -- alpha = 1 - the transmittance of what lies behind it
+                    const uint32_t pmA = sc.prim_media ? sc.prim_media[prim] : 0u;
+                    if (pmA) {
+                        Hit ha; const int instA = q.hitInst ? q.hitInst[slot] : -1;
+                        if (instA >= 0) fillHitInstanced(sc, tb, sc.instances[instA], o, d, hr.x, prim, hr.y, hr.z, ha);
+                        else if (prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], o, d, hr.x, hr.y, hr.z, ha);
+                        else fillHit<false, true>(sc, tb, d, hr.x, prim, hr.y, hr.z, ha);
+                        const v3 p2 = o + d * rc.alpha_dist; const int mA = targetMedium(pmA, ha.ng, d);
+                        wantAlpha = true;
+                        alO = make_float4(ha.p.x, ha.p.y, ha.p.z, __uint_as_float((uint32_t) (mA + 1) | (0x7FFFu << 8) | (1u << 24) | (1u << 29)));
+                        alD = make_float4(p2.x, p2.y, p2.z, __uint_as_float(pid));
+                    }
                 }
                 const int interactions = rc.max_depth - depth - 1;
                 // ---- the interaction: a point in the medium, or the surface at the end of the segment
@@ -176,14 +189,17 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
             }
             if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
         }
+        const unsigned long long mE = __ballot(wantAlpha);
+        if (wantAlpha) { const uint64_t w = shBase + 2u * q.cap - 1u - (outE + (uint32_t) __popcll(mE & lt)); q.shO[w] = alO; q.shD[w] = alD; }      // from the back of the segment's area: k_shadow_vol runs them BEFORE the emitter-sampling records
+        outE += (uint32_t) __popcll(mE);
         const unsigned long long mS = __ballot(wantShadow);
-        if (wantShadow) { const uint64_t w = segBase + outS + (uint32_t) __popcll(mS & lt); q.shO[w] = shO; q.shD[w] = shD; q.shC[w] = shC; q.shT[w] = shT; q.shX[w] = shX; }
+        if (wantShadow) { const uint64_t w = shBase + outS + (uint32_t) __popcll(mS & lt); q.shO[w] = shO; q.shD[w] = shD; q.shC[w] = shC; q.shT[w] = shT; q.shX[w] = shX; }
         outS += (uint32_t) __popcll(mS);
         const unsigned long long mA = __ballot(alive);
         if (alive) { const uint64_t w = segBase + outA + (uint32_t) __popcll(mA & lt); q.rayO[nb][w] = nrO; q.rayD[nb][w] = nrD; q.st0[nb][w] = nS0; q.st1[nb][w] = nS1; q.st2[nb][w] = 0.0f; }
         outA += (uint32_t) __popcll(mA);
     }
-    if (lane == 0) { q.count[nb][seg] = outA; q.shCount[seg] = outS; }
+    if (lane == 0) { q.count[nb][seg] = outA; q.shCount[seg] = outS | (outE << 16); }      // (cap <= 65535 in the volumetric modes, api.cpp)
     }
     for (int off = 32; off > 0; off >>= 1) pathLen += __shfl_down(pathLen, off);
     if (lane == 0 && pathLen) atomicAdd(&q.counters[2], pathLen);
@@ -197,9 +213,15 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
     Tabs<false> tb; tb.shade4 = (AS<false>::p4) sc.shade; tb.materials4 = (AS<false>::p4) sc.materials; tb.emitters4 = (AS<false>::p4) sc.emitters; tb.emitter_cdf = sc.emitter_cdf; tb.area_cdf = sc.area_cdf;
     unsigned long long rays = 0;
     for (uint32_t seg = blockIdx.x; seg < q.n_seg; seg += gridDim.x) {
-    const uint32_t n = q.shCount[seg];
-    const uint64_t segBase = (uint64_t) seg * q.cap;
-    for (uint32_t i = tid; i < n; i += WG) {
+    // two passes over the segment's records, a barrier in between: first the alpha walks (written from the back of the area), then the emitter-sampling records -- a
+    // path can own one of each, and its accumulator is a plain read-modify-write
+    const uint32_t cnt = q.shCount[seg], nFront = cnt & 0xFFFFu, nBack = cnt >> 16;
+    const uint64_t areaBase = (uint64_t) seg * q.cap * 2u;
+    for (int phase = 0; phase < 2; ++phase) {
+    if (phase == 1) __syncthreads();
+    const uint32_t n = phase == 0 ? nBack : nFront;
+    for (uint32_t i0 = tid; i0 < n; i0 += WG) {
+        const uint64_t segBase = phase == 0 ? areaBase + 2u * q.cap - 1u - i0 : areaBase + i0; const uint32_t i = 0;
         const float4 so = q.shO[segBase + i], sd = q.shD[segBase + i];
         const uint32_t bits = __float_as_uint(so.w), pid = __float_as_uint(sd.w);
         int medium = (int) (bits & 0xFFu) - 1; const int maxInteractions = (int) (int16_t) ((bits >> 8) & 0xFFFFu); const bool p1OnSurface = (bits >> 24) & 1u, p2OnSurface = (bits >> 25) & 1u;
@@ -234,6 +256,10 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
             if (++interactions > 100) break;
             o = o + d * t; remaining -= t; rmaxt = remaining * lengthFactor; rmint = MI_EPSILON;
         }
+        if (bits & (1u << 29)) {                                                 // the alpha walk of a sensor ray (records.inl:128-130)
+            const v3 tf = blocked ? V(0, 0, 0) : tr; float4 a = q.acc[pid]; a.w = 1 - ((0.0f + tf.x) + tf.y + tf.z) * (1.0f / 3); q.acc[pid] = a;
+            continue;
+        }
         if (blocked) continue;
         const float4 c = q.shC[segBase + i], tt = q.shT[segBase + i], xx = q.shX[segBase + i];
         const float r = 1.0f / c.w;
@@ -242,6 +268,7 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
             const v3 li = (V(tt.x, tt.y, tt.z) * value) * V(xx.x, xx.y, xx.z);
             float4 a = q.acc[pid]; a.x += li.x; a.y += li.y; a.z += li.z; q.acc[pid] = a;
         }
+    }
     }
     }
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);

@@ -2137,10 +2137,11 @@ static v3 sample_attenuated_emitter_direct(const orc_scene *s, v3 ref, v3 refN, 
     return mul(value, scale(tr, r));                  /* value *= evalTransmittance(...) / emPdf */
 }
 
-/* RadianceQueryRecord::rayIntersect, EOpacity (records.inl:121-137); a hit on a medium-transition shape is taken as opaque (:128-130 not restated) */
-static float sensor_ray_alpha(const orc_scene *s, v3 o, v3 d, int hit, int medium) {
-    if (!s->d.opacity || hit) return 1.0f;
-    if (medium < 0) return 0.0f;
+/* RadianceQueryRecord::rayIntersect, EOpacity (records.inl:121-137) */
+static float sensor_ray_alpha(const orc_scene *s, v3 o, v3 d, const hit_t *its, int medium, uint64_t *shadow_rays) {
+    const int hit = its->valid;
+    if (!s->d.opacity || (hit && !is_medium_transition(s, its->shape))) return 1.0f;
+    if (!hit && medium < 0) return 0.0f;
     /* :131-134: 1 - average transmittance of the sensor's medium over twice the scene's bounding-sphere radius.  Scene::getBSphere: the kd-tree box expanded by the
      * sensor's and the point / spot emitters' positions (scene.cpp:394-421, aabb.cpp:44-47) */
     v3 lo = s->aabb_lo, hi = s->aabb_hi, c;
@@ -2151,8 +2152,11 @@ static float sensor_ray_alpha(const orc_scene *s, v3 o, v3 d, int hit, int mediu
         lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
     }
     c = scale(add(hi, lo), 0.5f); float dist = length3(sub(c, hi)) * 2;
-    v3 p2 = add(o, scale(d, dist)), dd = sub(p2, o);
-    v3 tr = medium_transmittance(&s->media[medium], 0.0f, length3(dd));
+    v3 p2 = add(o, scale(d, dist)), tr;
+    if (hit) {                                           /* :128-130: what lies behind the boundary, seen from the hit point */
+        int unused = 0x7FFFFFFF;
+        tr = eval_transmittance(s, its->p, 1, p2, 0, target_medium(s, its->shape, its->ng, d), &unused, shadow_rays);
+    } else { v3 dd = sub(p2, o); tr = medium_transmittance(&s->media[medium], 0.0f, length3(dd)); }     /* (no surface on the way: the walk of :131-134 reduces to this) */
     return 1 - ((0.0f + tr.x) + tr.y + tr.z) * (1.0f / 3);
 }
 /* src/integrators/path/volpath_simple.cpp:84-289 SimpleVolumetricPathTracer::Li (no subsurface) */
@@ -2163,7 +2167,7 @@ static v3 volpath_simple_li(const orc_scene *s, v3 o, v3 d, float mint, float ma
     int nullChain = 1, scattered = 0; float eta = 1.0f;
     ++counters[0];
     if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
-    *alpha = sensor_ray_alpha(s, o, d, its.valid, medium);
+    *alpha = sensor_ray_alpha(s, o, d, &its, medium, &counters[1]);
     v3 throughput = V(1, 1, 1);
     int emitted = 1, others = 1;                                  /* rRec.type: EEmittedRadiance / the bits of ERadianceNoEmission (they only ever change together) */
     if (maxDepth == 1) others = 0;
@@ -2274,7 +2278,7 @@ static v3 volpath_li(const orc_scene *s, v3 o, v3 d, float mint, float maxt, sam
     hit_t its; v3 Li = V(0, 0, 0); int depth = 1, medium = s->d.sensor_medium, scattered = 0; float eta = 1.0f;
     ++counters[0];
     if (!ray_intersect(s, o, d, mint, maxt, &its, 0)) its.t = INFINITY;
-    *alpha = sensor_ray_alpha(s, o, d, its.valid, medium);
+    *alpha = sensor_ray_alpha(s, o, d, &its, medium, &counters[1]);
     v3 throughput = V(1, 1, 1); int emitted = 1;                  /* rRec.type is ERadiance or ERadianceNoEmission throughout */
     int differentials = 1;
     while (depth <= maxDepth || maxDepth < 0) {

@@ -983,8 +983,9 @@ def test_volpath_simple(mi, oracle, golden_scenes, name):
     assert stt["rays"] == int(cnt[0]) and stt["shadow_rays"] == int(cnt[1]) and stt["path_length_sum"] == int(cnt[2])
     ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]                              # the reference's own image
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 1e-5
-    ro = mi.Render(gs, opacity=True); ro.run(); oo = oracle.Oracle(sc, opacity=True).render_image(threads=4)[0]      # EOpacity: alpha of sensor rays that end in the fog / hit nothing
+    ro = mi.Render(gs, opacity=True); ro.run(); oo = oracle.Oracle(sc, opacity=True).render_image(threads=4)[0]      # EOpacity: alpha of sensor rays that end in the fog, hit nothing, or hit a medium-transition shape (1 - transmittance of what lies behind, records.inl:124-137)
     assert np.allclose(ro.read_film(0)[..., 3], oo[..., 3], rtol=1e-6, atol=1e-6)
+    assert (bits(ro.read_film(0)[..., :3]) == bits(film[..., :3])).all()                            # ... and the radiance does not notice
 
 
 @pytest.mark.parametrize("name", ["fog_sky", "fog_sky_simple", "fog_sky_global_hide"])
