@@ -1574,8 +1574,8 @@ DEV float miWeight(float a, float b) { a *= a; b *= b; return a / (a + b); }   /
 
 // ---------------------------------------------------------------------------------------------- participating media (volumetric integrators)
 // include/mitsuba/core/math.h:185-195 (Linux x86_64): fastexp / fastlog go through the DOUBLE-precision routines, rounded to float
-DEV float miFastExp(float v) { return (float) exp((double) v); }
-DEV float miFastLog(float v) { return (float) log((double) v); }
+__device__ __noinline__ static float miFastExp(float v) { return (float) exp((double) v); }
+__device__ __noinline__ static float miFastLog(float v) { return (float) log((double) v); }
 struct MediumRec { float t; v3 p; v3 transmittance; float pdfSuccess, pdfFailure; };
 // HomogeneousMedium::evalTransmittance (src/medium/homogeneous.cpp:266-273) over [mint, maxt] of a ray
 DEV v3 mediumTransmittance(const MediumD &m, float mint, float maxt) {
