@@ -130,11 +130,14 @@ DEV void next2D(SamplerState &s, uint32_t kind, SobolTabT<P> st, float &x, float
 // r = y - n * pi/2, the polynomials in r, swapped / negated by the quadrant.  Same operations, same order, no contraction: identical to glibc 2.35
 // for EVERY float in [-8, 8] (2.18e9 arguments, scripts/check_sincosf.c; arguments on the path are <= 2 pi).  |y| >= 120 (never reached) falls
 // back to the device library.
-DEV void glibcSincosf(float y, float &sn, float &cs) {
+// A real function call (not inlined): the fp64 polynomial's registers then count once, not on top of the calling kernel's -- the all-diffuse shade kernel
+// drops from 148 to 126 VGPRs (3 -> 4 waves per SIMD).  Returns (sin, cos) by value so that nothing goes through scratch memory.
+__device__ __noinline__ static float2 glibcSincosf2(float y) {
+    float sn, cs;
     const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
     double x = (double) y, x2; int n = 0; bool neg = false;
     if (top < 0x3f4u) {                        // |y| < pi/4
-        if (top < 0x398u) { sn = y; cs = 1.0f; return; }      // |y| < 2^-12
+        if (top < 0x398u) return make_float2(y, 1.0f);      // |y| < 2^-12
         x2 = x * x;
     } else if (top < 0x42fu) {                 // |y| < 120: reduce_fast
         const double r = x * 0x1.45F306DC9C883p+23;
@@ -143,7 +146,7 @@ DEV void glibcSincosf(float y, float &sn, float &cs) {
         x2 = x * x;
         if (((n & 3) == 1) || ((n & 3) == 2)) x = -x;         // sign[n & 3] = {1, -1, -1, 1}
         neg = (n & 2) != 0;
-    } else { sn = sinf(y); cs = cosf(y); return; }
+    } else return make_float2(sinf(y), cosf(y));
     const double c0 = neg ? -0x1p0 : 0x1p0, c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2, c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5,
                  c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10, c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
     const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
@@ -151,7 +154,9 @@ DEV void glibcSincosf(float y, float &sn, float &cs) {
     const double s = x + x3 * s1, c = cc1 + x4 * c2;
     const float sv = (float) (s + x5 * ss1), cv = (float) (c + x6 * cc2);
     if (n & 1) { sn = cv; cs = sv; } else { sn = sv; cs = cv; }
+    return make_float2(sn, cs);
 }
+DEV void glibcSincosf(float y, float &sn, float &cs) { const float2 r = glibcSincosf2(y); sn = r.x; cs = r.y; }
 // src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric
 DEV void diskConcentric(float sx, float sy, float &ox, float &oy) {
     float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, phi, sn, cs;
