@@ -1345,6 +1345,10 @@ DEV v3 envTexel(const DScene &sc, int x, int y) {
     y = y < 0 ? 0 : (y >= sc.env_h ? sc.env_h - 1 : y);
     return ld3(sc.env_rgb + ((size_t) y * sc.env_w + x) * 3);
 }
+// The device library's atan2f / acosf / sinf / cosf as real calls (not inlined): their expansions are register-hungry and sit inside the environment-map code of k_shade<ENV>
+__device__ __noinline__ static float miAtan2f(float y, float x) { return atan2f(y, x); }
+__device__ __noinline__ static float miAcosf(float x) { return acosf(x); }
+__device__ __noinline__ static float2 miSinCosf(float x) { return make_float2(sinf(x), cosf(x)); }
 // mipmap.h:576-597 evalBilinear(0, uv)
 DEV v3 envBilinear(const DScene &sc, float uvx, float uvy) {
     if (!isfinite(uvx) || !isfinite(uvy)) return V(0, 0, 0);
@@ -1361,7 +1365,7 @@ DEV v3 envBilinear(const DScene &sc, float uvx, float uvy) {
 DEV v3 envEval(const DScene &sc, v3 d) {
     if (sc.env_constant) return ld3(sc.emitters[sc.env_index].radiance);      // ConstantBackgroundEmitter::evalEnvironment (constant.cpp:244-246)
     v3 v = mat3(sc.env_to_local, d);
-    float uvx = atan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
+    float uvx = miAtan2f(v.x, -v.z) * MI_INV_TWOPI, uvy = miAcosf(minf(1.0f, maxf(-1.0f, v.y))) * MI_INV_PI;
     return envBilinear(sc, uvx, uvy) * sc.env_scale;
 }
 // envmap.cpp:664-669 sampleReuse
@@ -1408,13 +1412,13 @@ DEV void envSampleDirection(const DScene &sc, float sx, float sy, v3 &d, v3 &val
     value = (v1 + v2) * sc.env_scale;
     pdf = (luminance(v1) * sc.env_row_weights[clampi(yPos, 0, sc.env_h - 1)] + luminance(v2) * sc.env_row_weights[clampi(yPos + 1, 0, sc.env_h - 1)]) * sc.env_normalization;
     float ph = sc.env_pixel_w * (px + 0.5f), th = sc.env_pixel_h * (py + 0.5f);
-    float sinPhi = sinf(ph), cosPhi = cosf(ph), sinTheta = sinf(th), cosTheta = cosf(th);
+    const float2 scp = miSinCosf(ph), sct = miSinCosf(th); const float sinPhi = scp.x, cosPhi = scp.y, sinTheta = sct.x, cosTheta = sct.y;
     d = V(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
     pdf /= maxf(fabsf(sinTheta), MI_EPSILON);
 }
 // envmap.cpp:611-638 internalPdfDirection
 DEV float envPdfDirection(const DScene &sc, v3 d) {
-    float uvx = atan2f(d.x, -d.z) * MI_INV_TWOPI, uvy = acosf(minf(1.0f, maxf(-1.0f, d.y))) * MI_INV_PI;
+    float uvx = miAtan2f(d.x, -d.z) * MI_INV_TWOPI, uvy = miAcosf(minf(1.0f, maxf(-1.0f, d.y))) * MI_INV_PI;
     if (!isfinite(uvx) || !isfinite(uvy)) return 0.0f;
     float u = uvx * (float) sc.env_w - 0.5f, v = uvy * (float) sc.env_h - 0.5f;
     v3 v1, v2; int yPos; envBilinearPair(sc, u, v, v1, v2, yPos);
