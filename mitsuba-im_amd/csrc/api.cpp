@@ -511,7 +511,6 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for
-        if (s->h.envIndex >= 0 && s->h.envConstant) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with a `constant` environment emitter is not implemented (envmap is)");
         for (const mi_material &m : s->h.materials)
             if (m.type == MI_BSDF_MASK || m.type == MI_BSDF_THINDIELECTRIC || m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP)
                 return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with mask / thindielectric / mixturebsdf / bumpmap / normalmap materials is not implemented");

@@ -10,7 +10,7 @@
 // 20..27 current medium + 1.  Shadow record: shO = p1 | medium + 1, maxInteractions (int16), p1OnSurface, p2OnSurface; shD = p2 | path id; shC = emitter value BEFORE the
 // division by the emitter-selection probability | that probability; shT = throughput; shX = BSDF value (or the phase value in all three channels).
 // Built for: meshes + analytic shapes (media on scene-level shapes), every plain BSDF incl. `null`, textures, area / point / spot / directional emitters.  Refused at
-// mi_render_create: the `constant` environment emitter, mask / thindielectric (their ENull lobes would have to be evaluated inside the transmittance walk), the BSDF adapters.
+// mi_render_create: mask / thindielectric (their ENull lobes would have to be evaluated inside the transmittance walk), the BSDF adapters.
 #include "kernels_common.h"
 #include "trace.h"
 

@@ -24,6 +24,12 @@ DEV v3 envEvalSensorRay(const DScene &sc, const RenderConst &rc, v3 d, float2 sp
     const float t1 = MI_INV_TWOPI / (v.x * v.x + v.z * v.z), t2 = -MI_INV_PI / maxf(sqrtf(maxf(0.0f, 1.0f - v.y * v.y)), MI_EPSILON);
     return mipEval(sc, tx, uvx, uvy, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y) * sc.env_scale;
 }
+// density of the environment emitter for the direction d as Scene::pdfEmitterDirect reports it: EnvironmentMap::pdfDirect (envmap.cpp:549-560) or
+// ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233: cosine-weighted about the spawning vertex' reference normal -- `cosRef` = dot(d, refN), 2 = none)
+template <bool L> DEV float envLumPdf(const DScene &sc, const Tabs<L> &tb, v3 d, float cosRef) {
+    const float pdfSA = sc.env_constant ? (cosRef != 2.0f ? MI_INV_PI * maxf(0.0f, cosRef) : MI_INV_FOURPI) : envPdfDirection(sc, mat3(sc.env_to_local, d));
+    return pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+}
 
 #define VM_EMITTED (1u << 16)
 #define VM_DELTA (1u << 17)
@@ -52,10 +58,10 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
     for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
         bool alive = false, wantShadow = false, wantSearch = false, wantAlpha = false; float4 alO, alD;
-        float4 shO, shD, shC, shT, shX, seO, seD, seC, seT, seX, nrO, nrD, nS1; uint4 nS0; float nS2 = 0;
+        float4 shO, shD, shC, shT, shX, seO, seD, seC, seT, seX, nrO, nrD, nS1; uint4 nS0; float nS2 = 0, nS3 = 2.0f;
         if (i < n) {
             const uint64_t slot = segBase + i;
-            const float4 ro = q.rayO[buf][slot], rd = q.rayD[buf][slot], hr = q.hit[slot]; const uint4 s0 = q.st0[buf][slot]; const float4 s1 = q.st1[buf][slot]; const float prevPdf = q.st2[buf][slot];
+            const float4 ro = q.rayO[buf][slot], rd = q.rayD[buf][slot], hr = q.hit[slot]; const uint4 s0 = q.st0[buf][slot]; const float4 s1 = q.st1[buf][slot]; const float prevPdf = q.st2[buf][slot]; const float prevCos = (ENV && sc.env_constant) ? q.st3[buf][slot] : 2.0f;
             SamplerState ss; const uint32_t pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
             const int depth = (int) ((s0.w >> 8) & 0xFFu); uint32_t fl = s0.w; int medium = (int) ((s0.w >> 20) & 0xFFu) - 1;
             const v3 o = V(ro.x, ro.y, ro.z), d = V(rd.x, rd.y, rd.z); v3 T = V(s1.x, s1.y, s1.z); float eta = s1.w;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                         wantSearch = true;
                         seO = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t) (m2 + 1) | (((uint32_t) maxInteractions & 0xFFFFu) << 8) | (1u << 26) | ((fl & VM_FACING) ? (1u << 27) : 0u) | ((fl & VM_DELTA) ? (1u << 28) : 0u)));
                         seD = make_float4(d.x, d.y, d.z, __uint_as_float(pid)); seC = make_float4(segT.x, segT.y, segT.z, prevPdf);
-                        seT = make_float4(T.x, T.y, T.z, 0.0f); seX = make_float4(o.x, o.y, o.z, 0.0f);     // dRec.ref = the spawning vertex
+                        seT = make_float4(T.x, T.y, T.z, 0.0f); seX = make_float4(o.x, o.y, o.z, prevCos);     // dRec.ref = the spawning vertex (+ the cosine a `constant` environment's density needs)
                     }
                 }
                 if (ENV && (fl & VM_SEARCH) && prim == 0xFFFFFFFFu && medium < 0) {      // :421-426: the ray left the scene -> the environment map (inside a medium the unbounded segment has zero transmittance)
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     if (bsphereIntersect(sc, o, d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {        // EnvironmentMap::fillDirectSamplingRecord (envmap.cpp:362-378)
                         const v3 value = envEval(sc, d);
                         if (!isZero(value)) {
-                            const float lumPdf = (fl & VM_DELTA) ? 0.0f : envPdfDirection(sc, mat3(sc.env_to_local, d)) * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+                            const float lumPdf = (fl & VM_DELTA) ? 0.0f : envLumPdf(sc, tb, d, prevCos);
                             add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                         }
                     }
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     const v3 wo = phaseSample(md, -d, sx, sy);
                     nS2 = phaseEval(md, -d, wo);
                     fl = VM_SEARCH | VM_SCATTERED | VM_FACING;              // type = ERadianceNoEmission; refN = 0 -> dot(d, refN) >= 0 holds
+                    nS3 = 2.0f;
                     alive = true;
                     nrO = make_float4(mRec.p.x, mRec.p.y, mRec.p.z, 0.0f); nrD = make_float4(wo.x, wo.y, wo.z, INFINITY);
                     break;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                 if (pm) medium = targetMedium(pm, h.ng, wo);
                 if (sampledNull) fl = (scattered ? VM_SCATTERED : VM_EMITTED) | VM_SKIPRR;           // :268-276: type = scattered ? ERadianceNoEmission : ERadiance; no emitter search; depth++ without the roulette
                 else fl = VM_SEARCH | VM_SCATTERED | (sampledDelta ? VM_DELTA : 0u) | (dot(wo, nrefN) >= 0 ? VM_FACING : 0u);
-                nS2 = bPdf;
+                nS2 = bPdf; nS3 = (h.flags & 2u) ? 2.0f : dot(wo, nrefN);
                 alive = true;
                 nrO = make_float4(h.p.x, h.p.y, h.p.z, MI_EPSILON); nrD = make_float4(wo.x, wo.y, wo.z, INFINITY);
             } while (false);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
         if (wantShadow) { const uint64_t w = shBase + outS + (uint32_t) __popcll(mS & lt); q.shO[w] = shO; q.shD[w] = shD; q.shC[w] = shC; q.shT[w] = shT; q.shX[w] = shX; }
         outS += (uint32_t) __popcll(mS);
         const unsigned long long mA = __ballot(alive);
-        if (alive) { const uint64_t w = segBase + outA + (uint32_t) __popcll(mA & lt); q.rayO[nb][w] = nrO; q.rayD[nb][w] = nrD; q.st0[nb][w] = nS0; q.st1[nb][w] = nS1; q.st2[nb][w] = nS2; }
+        if (alive) { const uint64_t w = segBase + outA + (uint32_t) __popcll(mA & lt); q.rayO[nb][w] = nrO; q.rayD[nb][w] = nrD; q.st0[nb][w] = nS0; q.st1[nb][w] = nS1; q.st2[nb][w] = nS2; if (ENV && sc.env_constant) q.st3[nb][w] = nS3; }
         outA += (uint32_t) __popcll(mA);
     }
     if (lane == 0) { q.count[nb][seg] = outA; q.shCount[seg] = outS | (outE << 16); }      // (cap <= 65535 in the volumetric modes, api.cpp)
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                     const v3 value = tr * envEval(sc, d);
                     if (!isZero(value)) {
                         const float4 tt = q.shT[shBase + i];
-                        const float lumPdf = (bits & (1u << 28)) ? 0.0f : envPdfDirection(sc, mat3(sc.env_to_local, d)) * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
+                        const float lumPdf = (bits & (1u << 28)) ? 0.0f : envLumPdf(sc, tb, d, q.shX[shBase + i].w);
                         const v3 li = (V(tt.x, tt.y, tt.z) * value) * miWeight(c.w, lumPdf);
                         float4 a = q.acc[pid]; a.x += li.x; a.y += li.y; a.z += li.z; q.acc[pid] = a;
                     }

@@ -509,7 +509,7 @@ def cornell_box(width=1920, height=1080, spp=8, sampler=SAMPLER_SOBOL, max_depth
                         hide_emitters=hide_emitters, name="cornell")
 
 
-def fog_sky(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, global_fog=False, hide_emitters=False, integrator=INTEGRATOR_VOLPATH, env_size=(64, 32)):
+def fog_sky(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, global_fog=False, hide_emitters=False, integrator=INTEGRATOR_VOLPATH, env_size=(64, 32), constant_env=False):
     """Volumetric loops under an environment map: ground, a diffuse block, a `null` sphere of haze, a glass block with a scattering interior, an area light; with
     global_fog the sensor sits in a thin medium (the reference then sees the sky through emitter sampling only: a ray that leaves the scene inside an unbounded
     medium has zero transmittance, volpath.cpp:383-384 with its->t = infinity)."""
@@ -526,10 +526,10 @@ def fog_sky(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_
     b.begin(); b.quad([(-0.5, 3.2, 0.5), (0.5, 3.2, 0.5), (0.5, 3.2, 1.5), (-0.5, 3.2, 1.5)]); b.end(lightm, radiance=(6.0, 5.0, 4.0))
     b.add_analytic(SHAPE_SPHERE, translate(-0.3, 0.9, -0.6), null, radius=0.7, interior=0, exterior=ext)
     cam = look_at((0.8, 1.3, -4.5), (0.1, 1.0, 1.0), (0, 1, 0))
-    env = dict(rgb=detailed_sky(*env_size), to_world=(rotate((0, 1, 0), 25.0) @ rotate((1, 0, 0), 8.0)).astype(f32), scale=0.8)
+    env = None if constant_env else dict(rgb=detailed_sky(*env_size), to_world=(rotate((0, 1, 0), 25.0) @ rotate((1, 0, 0), 8.0)).astype(f32), scale=0.8)
     sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 55.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
                       seed=seed, hide_emitters=hide_emitters, envmap=env, name="fog_sky", analytic=b.resolve_analytic(), media=media, sensor_medium=ext, integrator=integrator)
-    return add_scene_emitters(sc, [dict(type=EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=1.0)])
+    return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)) if constant_env else dict(type=EMITTER_ENVMAP, shape=-1, radiance=(0.0, 0.0, 0.0), weight=1.0)])
 
 
 def _closed_box(b, top, y0, y1):

@@ -958,14 +958,15 @@ def test_both_tree_node_kinds(mi, golden_scenes, name, monkeypatch):
         assert (bits(got["wide"]) == bits(st["li"])).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.99
 
 
-@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide"])
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_constant", "fog_constant_simple_indep"])
 def test_volpath_simple(mi, oracle, golden_scenes, name):
     """SURVEY.md 8f-4: SimpleVolumetricPathTracer::Li (src/integrators/path/volpath_simple.cpp) over homogeneous media (src/medium/homogeneous.cpp: balance / single /
     manual distance sampling; isotropic and Henyey-Greenstein phase functions), `null` boundaries, a dielectric block with an interior medium, a `null` sphere, the
     sensor inside a medium; emitter sampling attenuated by Scene::evalTransmittance (scene.cpp:650-713) in k_shadow_vol.  exp / log go through the double-precision
     routines on every side (math.h:185-195), so the radiance samples equal the oracle's and those of the strict-IEEE build of the reference bit for bit.
     fog_mis*: the same rooms through VolumetricPathTracer::Li (src/integrators/path/volpath.cpp): multiple importance sampling between emitter sampling and
-    phase-function / BSDF sampling, emitters found through index-matched boundaries (rayIntersectAndLookForEmitter; second record kind of k_shadow_volmis)."""
+    phase-function / BSDF sampling, emitters found through index-matched boundaries (rayIntersectAndLookForEmitter; second record kind of k_shadow_volmis).
+    fog_constant*: under a `constant` environment emitter (no trigonometry: bit-exact as well; its density needs the cosine to the spawning vertex' normal)."""
     sc = golden_scenes[name]; gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
     gs = mi.Scene(sc); r = mi.Render(gs); orc = oracle.Oracle(sc)
     got = r.samples(gd["pairs"]); ref = orc.render_samples(gd["pairs"])["li"]
@@ -1010,16 +1011,12 @@ def test_volumetric_under_envmap(mi, oracle, golden_scenes, name):
 def test_volpath_simple_refusals(mi, golden_scenes):
     """what the volumetric stages are not built for is refused by name, never approximated"""
     S = mi.scenes
-    sc = golden_scenes["open_constant"]; gs = mi.Scene(sc)
-    with pytest.raises(RuntimeError, match="constant"):
-        mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
+    sc = golden_scenes["open_constant"]
     gs = mi.Scene(golden_scenes["textured_shapes"])
     with pytest.raises(RuntimeError, match="mask / thindielectric"):
         mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
     with pytest.raises(RuntimeError, match="integrators path"):
         mi.Render(mi.Scene(golden_scenes["cornell_small"]), integrator=7)
-    with pytest.raises(RuntimeError, match="constant"):
-        mi.Render(mi.Scene(sc), integrator=S.INTEGRATOR_VOLPATH)
     # a scene without media through the volumetric loop = the same estimator without MIS: converges to the same image (loose check on the mean)
     os.environ["MI355PT_NO_PACKET"] = "1"
     try:
