@@ -1044,7 +1044,6 @@ def test_volumetric_full_size_properties(mi, oracle, integrator):
     assert (bits(got) == bits(ref)).all(1).mean() > 0.999 and np.allclose(got, ref, rtol=1e-5, atol=1e-7)
     r.clear(); r.run(); full = r.read_film(0).copy(); st = r.stats()
     r.clear(); r.run(s0=0, s1=8); r.run(s0=8, s1=16); parts = r.read_film(0)
-    own = np.abs(full[..., 4] - 16 * full[..., 4].max() / 16) < 1e-3                               # interior pixels (box filter: all sixteen samples land on their own pixel)
     assert (bits(full[1:-1, 1:-1, :3]) == bits(parts[1:-1, 1:-1, :3])).mean() > 0.9999
     r.clear(); r.run(); again = r.read_film(0)
     assert (bits(full[1:-1, 1:-1]) == bits(again[1:-1, 1:-1])).mean() > 0.9999
