@@ -481,6 +481,7 @@ class _SceneBuilder:
         self.scene_emitters, self.area = [], []          # area: (document order, kind 'mesh' / 'analytic', index, radiance, weight)
         self.envmap = None
         self.order = 0
+        self.media, self.medium_index = [], {}          # participating media (homogeneous), by plugin identity
 
     # -- materials
     def texture(self, t):
@@ -546,6 +547,8 @@ class _SceneBuilder:
             if self.bsdfs[ni]["type"] == S.BSDF_MASK:
                 raise SceneError("mask: a mask nested in a mask is not supported")
             rec = S.make_bsdf(S.BSDF_MASK, reflectance=op or (0.5, 0.5, 0.5), nested=ni)
+        elif t == "null":                                 # src/bsdfs/null.cpp: the index-matched boundary of a medium
+            rec = S.make_bsdf(S.BSDF_NULL)
         elif t == "diffuse":
             refl, tex = _spectrum_or_texture(p, ("reflectance", "diffuseReflectance"), (0.5, 0.5, 0.5))
             rec = S.make_bsdf(S.BSDF_DIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), twosided=twosided)
@@ -612,6 +615,11 @@ class _SceneBuilder:
         self.bsdf_index[key] = len(self.bsdfs) - 1
         return len(self.bsdfs) - 1
 
+    def null_bsdf(self):
+        if "__null__" not in self.bsdf_index:
+            self.bsdf_index["__null__"] = len(self.bsdfs); self.bsdfs.append(S.make_bsdf(kind=S.BSDF_NULL))
+        return self.bsdf_index["__null__"]
+
     def default_bsdf(self):
         key = ("default", False)
         if key not in self.bsdf_index:       # Shape::configure(): a shape without a BSDF gets a diffuse one (src/librender/shape.cpp)
@@ -654,8 +662,11 @@ class _SceneBuilder:
         em = p.children_of("emitter")
         if len(em) > 1 or (em and em[0][1].type != "area"):
             raise SceneError("a shape takes at most one nested emitter, of type 'area'")
-        if p.children_of("medium") or p.children_of("subsurface") or p.children_of("sensor"):
-            raise SceneError("participating media, subsurface and shape-attached sensors are outside the surface path tracer")
+        if p.children_of("subsurface") or p.children_of("sensor"):
+            raise SceneError("subsurface integrators and shape-attached sensors are outside the path tracer")
+        inside, outside = self.shape_media(p)
+        if group and (inside >= 0 or outside >= 0):
+            raise SceneError("media on the members of a shape group are not supported")
         radiance = None
         if em:
             e = em[0][1]
@@ -696,8 +707,8 @@ class _SceneBuilder:
                 if b is None and unnamed:
                     b = self.bsdf(unnamed[-1])
                 if b is None:
-                    b = self.default_bsdf()
-                si = self.add_mesh(m, b, group)
+                    b = self.default_bsdf() if (inside < 0 and outside < 0) else self.null_bsdf()     # Shape::configure: a medium transition without a BSDF gets `null` (shape.cpp:66-70)
+                si = self.add_mesh(m, b, group); self.shapes[si]["interior"], self.shapes[si]["exterior"] = inside, outside
                 if radiance is not None:
                     self.area.append((order, "mesh", si, radiance, weight))
         elif t in ("rectangle", "disk", "sphere", "cylinder"):
@@ -705,7 +716,7 @@ class _SceneBuilder:
                 raise SceneError("analytic shapes inside a shape group are not supported")
             if len(named) > 1:
                 raise SceneError("a shape takes one BSDF")
-            b = self.bsdf(named[0][1]) if named else self.default_bsdf()
+            b = self.bsdf(named[0][1]) if named else (self.default_bsdf() if (inside < 0 and outside < 0) else self.null_bsdf())
             flip = bool(p.get("flipNormals", False))
             m = np.eye(4) if tw is None else tw.astype(np.float64)
             if t in ("rectangle", "disk"):
@@ -729,12 +740,71 @@ class _SceneBuilder:
                     o2w = m @ o2w
                 r = float(np.linalg.norm(o2w[:3, 0])); l = float(np.linalg.norm(o2w[:3, 2]))      # cylinder.cpp:99-103
                 rec = S.make_analytic(S.SHAPE_CYLINDER, o2w @ S.scale(1.0 / r, 1.0 / r, 1.0 / l), b, flip=flip, radius=r, length=l)
+            rec["interior"], rec["exterior"] = inside, outside
             self.analytic.append(rec)
             if radiance is not None:
                 self.area.append((order, "analytic", len(self.analytic) - 1, radiance, weight))
         else:
             raise SceneError(f"shape plugin \"{t}\" is not supported (obj, ply, serialized, cube, rectangle, disk, sphere, cylinder, shapegroup, instance)")
         p.check_all_used()
+
+    # -- participating media: `homogeneous` (src/medium/homogeneous.cpp over Medium / lookupMaterial, src/medium/materials.h:88-192) with an `isotropic` / `hg` phase function
+    def medium(self, p):
+        if p is None:
+            return -1
+        if id(p) in self.medium_index:
+            return self.medium_index[id(p)]
+        if p.type != "homogeneous":
+            raise SceneError(f"medium \"{p.type}\" is not supported (homogeneous)")
+        if p.has("material"):
+            raise SceneError("homogeneous medium: the measured material presets are not built in; give sigmaS / sigmaA (or sigmaT / albedo)")
+        def spec(name):
+            v = p.get(name); return np.full(3, v, np.float64) if isinstance(v, float) else np.asarray(v, np.float64)
+        if (p.has("sigmaS") or p.has("sigmaA")) and (p.has("sigmaT") or p.has("albedo")):
+            raise SceneError("You can either specify sigmaS & sigmaA *or* sigmaT & albedo, but no other combinations!")
+        if p.has("sigmaS") and p.has("sigmaA"):
+            sigma_s, sigma_a = spec("sigmaS").astype(f32), spec("sigmaA").astype(f32)
+        elif p.has("sigmaT") and p.has("albedo"):
+            st, al = spec("sigmaT").astype(f32), spec("albedo").astype(f32); sigma_s = (al * st).astype(f32); sigma_a = (st - sigma_s).astype(f32)
+        else:
+            raise SceneError("homogeneous medium: sigmaS and sigmaA (or sigmaT and albedo) are expected (the reference would fill the missing one from its `skin1` preset)")
+        scale = f32(p.get("scale", 1.0)); sigma_s = (sigma_s * scale).astype(f32); sigma_a = (sigma_a * scale).astype(f32)
+        phase, g = S.PHASE_ISOTROPIC, 0.0
+        ph = p.children_of("phase")
+        if len(ph) > 1:
+            raise SceneError("a medium takes one phase function")
+        if ph:
+            q = ph[0][1]
+            if q.type == "hg":
+                phase, g = S.PHASE_HG, float(q.get("g", 0.8))
+                if not -1 < g < 1:
+                    raise SceneError("The anisotropy parameter 'g' must be in the range (-1, 1)!")
+            elif q.type != "isotropic":
+                raise SceneError(f"phase function \"{q.type}\" is not supported (isotropic, hg)")
+            q.check_all_used()
+        if p.has("g"):                                    # the medium's own `g` rescales sigmaS (reduced scattering coefficient, medium.cpp:30-34)
+            gm = p.get("g"); gm = np.full(3, gm, f32) if isinstance(gm, float) else np.asarray(gm, f32)
+            sigma_s = (sigma_s * (f32(1.0) - gm)).astype(f32)
+        strategy = {"balance": S.MEDIUM_BALANCE, "single": S.MEDIUM_SINGLE, "manual": S.MEDIUM_MANUAL}.get(p.get("strategy", "balance"))
+        if strategy is None:
+            raise SceneError("homogeneous medium: sampling strategies balance, single and manual are supported (not `maximum`)")
+        if p.get("monochromatic", False):
+            raise SceneError("homogeneous medium: `monochromatic` is not supported")
+        m = S.make_medium(sigma_a, sigma_s, strategy=strategy, phase=phase, g=g, medium_sampling_weight=p.get("mediumSamplingWeight", None),
+                          sampling_density=p.get("samplingDensity", None) if strategy == S.MEDIUM_MANUAL else None,
+                          channel=int(p.get("channel")) if (strategy == S.MEDIUM_SINGLE and p.has("channel")) else None)
+        p.check_all_used()
+        self.medium_index[id(p)] = len(self.media); self.media.append(m)
+        return self.medium_index[id(p)]
+
+    def shape_media(self, p):
+        """(interior, exterior) medium indices of a shape: children named `interior` / `exterior` (Shape::addChild, src/librender/shape.cpp:156-170)"""
+        inside = outside = -1
+        for n, c in p.children_of("medium"):
+            if n == "interior": inside = self.medium(c)
+            elif n == "exterior": outside = self.medium(c)
+            else: raise SceneError("Shape: Invalid medium child (must be named 'interior' or 'exterior')!")
+        return inside, outside
 
     # -- scene-level emitters
     def emitter(self, e):
@@ -789,8 +859,9 @@ class _SceneBuilder:
         integ = root.child("integrator")
         if integ is None:
             raise SceneError("the scene has no <integrator> (the reference would insert a direct-illumination integrator, which is not this path)")
-        if integ.type != "path":
-            raise SceneError(f"integrator \"{integ.type}\" is not supported: this framework implements the 'path' integrator (MIPathTracer)")
+        integrators = {"path": S.INTEGRATOR_PATH, "volpath_simple": S.INTEGRATOR_VOLPATH_SIMPLE, "volpath": S.INTEGRATOR_VOLPATH}
+        if integ.type not in integrators:
+            raise SceneError(f"integrator \"{integ.type}\" is not supported: this framework implements path, volpath_simple and volpath")
         max_depth, rr_depth = int(integ.get("maxDepth", -1)), int(integ.get("rrDepth", 5))
         strict, hide = bool(integ.get("strictNormals", False)), bool(integ.get("hideEmitters", False))
         integ.check_all_used()
@@ -884,6 +955,10 @@ class _SceneBuilder:
             raise SceneError("Scale factors in the camera-to-world transformation are not allowed!")      # perspective.cpp:116-118
         for k in ("shutterOpen", "shutterClose", "focusDistance"):
             sen.get(k)
+        sm = sen.children_of("medium")
+        if len(sm) > 1:
+            raise SceneError("a sensor takes one medium")
+        sensor_medium = self.medium(sm[0][1]) if sm else -1
         sen.check_all_used()
 
         for _, c in root.children:       # scene-level BSDF definitions become materials in document order (the reference instantiates them as it parses)
@@ -894,10 +969,10 @@ class _SceneBuilder:
                 self.shape(c)
             elif c.tag == "emitter":
                 self.emitter(c)
-            elif c.tag in ("bsdf", "texture", "integrator", "sensor"):
+            elif c.tag in ("bsdf", "texture", "integrator", "sensor", "medium", "phase"):
                 pass                                    # definitions for later <ref>s; instantiated on use
-            elif c.tag in ("medium", "subsurface", "volume", "phase"):
-                raise SceneError(f"<{c.tag}>: participating media are outside the surface path tracer")
+            elif c.tag in ("subsurface", "volume"):
+                raise SceneError(f"<{c.tag}>: subsurface integrators and volume data sources are not supported")
             else:
                 raise SceneError(f"<{c.tag}> is not expected at scene level")
         root.check_all_used()
@@ -919,7 +994,10 @@ class _SceneBuilder:
             uvs = np.concatenate([u if u is not None else np.zeros((len(v), 2), f32) for u, v in zip(self.uvs, self.verts)])
         sc = S.finish_scene(verts, tris, self.shapes, self.bsdfs, emitters, cam, xfov, near, far, width, height, spp, sampler, max_depth, rr_depth,
                             filter_kind, seed, normals=normals, uvs=uvs, strict_normals=strict, hide_emitters=hide, envmap=self.envmap, name=name,
-                            analytic=self.analytic, instances=self.instances, textures=self.textures)
+                            analytic=self.analytic, instances=self.instances, textures=self.textures, media=self.media, sensor_medium=sensor_medium,
+                            integrator=integrators[integ.type])
+        if sc.integrator != S.INTEGRATOR_PATH and not self.media:
+            pass                                        # a volumetric integrator over a scene without media is legal (it renders what `path` renders)
         if crop is not None:
             S.set_crop_window(sc, full_w, full_h, crop[0], crop[1])
         if f_radius is not None:
@@ -957,8 +1035,20 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
     rgb = lambda n, v: f'<rgb name="{n}" value="{fmt(v).replace(" ", ", ")}"/>'
     mat = lambda n, m: f'<transform name="{n}"><matrix value="{fmt(m)}"/></transform>'
     out = ['<?xml version="1.0" encoding="utf-8"?>', '<scene version="0.5.0">']
-    out.append(f'\t<integrator type="path"><integer name="maxDepth" value="{sc.max_depth}"/><integer name="rrDepth" value="{sc.rr_depth}"/>'
+    integ_name = {S.INTEGRATOR_PATH: "path", S.INTEGRATOR_VOLPATH_SIMPLE: "volpath_simple", S.INTEGRATOR_VOLPATH: "volpath"}[sc.get("integrator", 0) or 0]
+    out.append(f'\t<integrator type="{integ_name}"><integer name="maxDepth" value="{sc.max_depth}"/><integer name="rrDepth" value="{sc.rr_depth}"/>'
                f'<boolean name="strictNormals" value="{str(bool(sc.strict_normals)).lower()}"/><boolean name="hideEmitters" value="{str(bool(sc.hide_emitters)).lower()}"/></integrator>')
+    media = sc.get("media") or []
+    for mi_, m in enumerate(media):                       # the derived sampling parameters are written explicitly, so a reader reproduces them whatever its defaults
+        strat = {S.MEDIUM_BALANCE: "balance", S.MEDIUM_SINGLE: "single", S.MEDIUM_MANUAL: "manual"}[m["strategy"]]
+        extra = f'<float name="samplingDensity" value="{fmt([m["sampling_density"]])}"/>' if m["strategy"] == S.MEDIUM_MANUAL else ""
+        if m["strategy"] == S.MEDIUM_SINGLE:
+            st = np.asarray(m["sigma_a"], f32) + np.asarray(m["sigma_s"], f32); extra = f'<integer name="channel" value="{int(np.argmin(np.abs(st - f32(m["sampling_density"]))))}"/>'
+        phase = f'<phase type="hg"><float name="g" value="{fmt([m["g"]])}"/></phase>' if m["phase"] == S.PHASE_HG else '<phase type="isotropic"/>'
+        out.append(f'\t<medium type="homogeneous" id="medium{mi_}">{rgb("sigmaA", m["sigma_a"])}{rgb("sigmaS", m["sigma_s"])}<string name="strategy" value="{strat}"/>{extra}'
+                   f'<float name="mediumSamplingWeight" value="{fmt([m["medium_sampling_weight"]])}"/>{phase}</medium>')
+    def media_refs(rec):
+        return "".join(f'<ref name="{n}" id="medium{rec.get(n, -1)}"/>' for n in ("interior", "exterior") if rec.get(n, -1) >= 0)
     filt = {S.FILTER_BOX: "box", S.FILTER_GAUSSIAN: "gaussian", S.FILTER_TENT: "tent", S.FILTER_MITCHELL: "mitchell", S.FILTER_CATMULLROM: "catmullrom", S.FILTER_LANCZOS: "lanczos"}[sc.filter]
     fprops = {"box": f'<float name="radius" value="{fmt([sc.filter_radius])}"/>', "gaussian": f'<float name="stddev" value="{fmt([sc.filter_stddev])}"/>',
               "mitchell": f'<float name="B" value="{fmt([sc.filter_radius])}"/><float name="C" value="{fmt([sc.filter_stddev])}"/>',
@@ -971,7 +1061,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
                f'\t\t<film type="hdrfilm">' + (f'<integer name="width" value="{sc.crop[0]}"/><integer name="height" value="{sc.crop[1]}"/><integer name="cropOffsetX" value="{sc.crop[2]}"/>'
                                                 f'<integer name="cropOffsetY" value="{sc.crop[3]}"/><integer name="cropWidth" value="{sc.width}"/><integer name="cropHeight" value="{sc.height}"/>' if sc.get("crop")
                                                 else f'<integer name="width" value="{sc.width}"/><integer name="height" value="{sc.height}"/>') + '<boolean name="banner" value="false"/>'
-               f'<rfilter type="{filt}">{fprops}</rfilter></film>\n\t</sensor>')
+               f'<rfilter type="{filt}">{fprops}</rfilter></film>' + (f'<ref id="medium{sc.sensor_medium}"/>' if media and sc.get("sensor_medium", -1) >= 0 else "") + '\n\t</sensor>')
     distr = {S.DISTR_BECKMANN: "beckmann", S.DISTR_GGX: "ggx", S.DISTR_PHONG: "phong"}
 
     wrap_names = {S.WRAP_REPEAT: "repeat", S.WRAP_CLAMP: "clamp", S.WRAP_MIRROR: "mirror", S.WRAP_ZERO: "zero", S.WRAP_ONE: "one"}
@@ -1022,6 +1112,8 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="roughplastic">{mf}{sv}{ior}{nl}{rgb("specularReflectance", b["specular"])}{diffuse_param("diffuseReflectance")}</bsdf>'
         elif t == S.BSDF_DIFFTRANS:
             inner = f'<bsdf type="difftrans">{diffuse_param("transmittance")}</bsdf>'
+        elif t == S.BSDF_NULL:
+            inner = '<bsdf type="null"></bsdf>'
         else:
             raise SceneError(f"export_scene: material type {t}")
         if b["twosided"]:
@@ -1056,7 +1148,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
         else:
             meshio.save_obj(os.path.join(directory, f"{name}_shape{si}.obj"), m)
             src = f'<shape type="obj"><string name="filename" value="{name}_shape{si}.obj"/><boolean name="flipTexCoords" value="false"/>'
-        out.append(f'\t{src}<boolean name="faceNormals" value="{str(fn).lower()}"/><ref id="bsdf{sh["bsdf"]}"/>{area.get(si, "")}</shape>')
+        out.append(f'\t{src}<boolean name="faceNormals" value="{str(fn).lower()}"/><ref id="bsdf{sh["bsdf"]}"/>{media_refs(sh)}{area.get(si, "")}</shape>')
     if mesh_format == "serialized" and meshes:
         meshio.save_serialized(os.path.join(directory, f"{name}.serialized"), meshes)
     kinds = {S.SHAPE_RECTANGLE: "rectangle", S.SHAPE_DISK: "disk", S.SHAPE_SPHERE: "sphere", S.SHAPE_CYLINDER: "cylinder"}
@@ -1069,7 +1161,7 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             tw = tw @ S.scale(a["radius"], a["radius"], a["length"])
         if k in ("sphere", "cylinder") and a["flags"] & 1:
             extra = '<boolean name="flipNormals" value="true"/>'
-        out.append(f'\t<shape type="{k}">{mat("toWorld", tw)}{extra}<ref id="bsdf{a["bsdf"]}"/>{area.get(len(sc.shapes) + ai, "")}</shape>')
+        out.append(f'\t<shape type="{k}">{mat("toWorld", tw)}{extra}<ref id="bsdf{a["bsdf"]}"/>{media_refs(a)}{area.get(len(sc.shapes) + ai, "")}</shape>')
     out.append("</scene>")
     path = os.path.join(directory, f"{name}.xml")
     with open(path, "w") as f:

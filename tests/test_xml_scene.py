@@ -199,7 +199,7 @@ def test_obj_materials_groups_and_instances(tmp_path):
     (MINIMAL.format(sensor='<float name="fov" value="30"/><string name="focalLength" value="35mm"/>', film="", body=""), "either a focal length"),
     (MINIMAL.format(sensor='<transform name="toWorld"><scale value="2"/></transform>', film="", body=""), "Scale factors in the camera-to-world"),
     (MINIMAL.format(sensor="", film="", body='<emitter type="sunsky"/>'), 'emitter plugin "sunsky" is not supported'),
-    (MINIMAL.format(sensor="", film="", body='<medium type="homogeneous" id="m"/>'), "participating media"),
+    (MINIMAL.format(sensor="", film="", body='<subsurface type="dipole" id="m"/>'), "subsurface"),
     (MINIMAL.replace('type="path"', 'type="bdpt"').format(sensor="", film="", body=""), 'integrator "bdpt" is not supported'),
     (MINIMAL.format(sensor="", film="", body='<shape type="sphere"><transform name="toWorld"><scale x="1" value="2"/></transform></shape>'), "both xyz and value"),
     ("<scene version='0.5.0'><integrator type='path'/><sensor type='perspective'/><shape type='sphere'/></scene>", "no emitters"),
@@ -291,3 +291,42 @@ def test_blackbody_spectra_match_reference(tmp_path):
     assert np.allclose(sc.emitters[0]["radiance"], want, rtol=1e-6) and abs(want[0] - 1.52633) < 1e-3
     with pytest.raises(X.SceneError):
         X.load_scene(str(p), params={"temp": "warm"})
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(global_fog=True, integrator=S.INTEGRATOR_VOLPATH)])
+def test_media_round_trip(kw, tmp_path):
+    """Participating media in scene files: <medium type="homogeneous"> with its <phase>, `interior` / `exterior` references on meshes and analytic shapes, the
+    sensor's medium, `null` BSDFs, the volumetric integrators -- written by export_scene, read back, and traced to the same radiance by the oracle."""
+    import oracle
+    oracle.build()
+    sc = S.fog_box(48, 48, 4, **kw)
+    sc.xfov = float(np.float32(sc.xfov)); sc.sample_to_camera = S.sample_to_camera(sc.xfov, sc.near, sc.far, sc.width / sc.height)
+    sc2 = X.load_scene(X.export_scene(sc, str(tmp_path), name="fog"))
+    assert sc2.integrator == sc.integrator and len(sc2.media) == len(sc.media) and (sc2.sensor_medium >= 0) == (sc.sensor_medium >= 0)
+    assert sorted(map(repr, sc2.media)) == sorted(map(repr, sc.media))                  # (the file's order of first use may differ from the generator's)
+    pairs = np.stack([np.arange(400) % 48, (np.arange(400) * 7) % 48, np.arange(400) % 4], 1).astype(np.uint32)
+    a = oracle.Oracle(sc).render_samples(pairs)["li"]; b = oracle.Oracle(sc2).render_samples(pairs)["li"]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_media_conventions(tmp_path):
+    """What the reference's constructors derive (src/medium/homogeneous.cpp:156-226, src/medium/materials.h:88-192, src/librender/shape.cpp:47-75): sigmaT / albedo,
+    `scale`, the sampling weight from the largest albedo (at least 1/2), `single` picking the smallest sigma_t, a `null` BSDF for a medium transition without one."""
+    head = ('<scene version="0.5.0"><integrator type="volpath"><integer name="maxDepth" value="4"/></integrator>'
+            '<sensor type="perspective"><transform name="toWorld"><lookat origin="0,0,-5" target="0,0,0" up="0,1,0"/></transform><sampler type="independent"><integer name="sampleCount" value="2"/></sampler>'
+            '<film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>'
+            '<emitter type="point"><rgb name="intensity" value="1,1,1"/></emitter>')
+    def load(body):
+        p = tmp_path / "m.xml"; p.write_text(head + body + "</scene>"); return X.load_scene(str(p))
+    sc = load('<medium type="homogeneous" id="fog"><rgb name="sigmaT" value="2, 4, 8"/><rgb name="albedo" value="0.5, 0.25, 0.75"/><float name="scale" value="0.5"/><string name="strategy" value="single"/>'
+              '<phase type="hg"><float name="g" value="0.3"/></phase></medium><shape type="sphere"><ref name="interior" id="fog"/></shape>')
+    m = sc.media[0]
+    np.testing.assert_allclose(m["sigma_s"], [0.5, 0.5, 3.0], rtol=1e-6); np.testing.assert_allclose(m["sigma_a"], [0.5, 1.5, 1.0], rtol=1e-6)
+    assert m["strategy"] == S.MEDIUM_SINGLE and m["sampling_density"] == pytest.approx(1.0) and m["medium_sampling_weight"] == pytest.approx(0.75) and m["phase"] == S.PHASE_HG and m["g"] == pytest.approx(0.3)
+    assert sc.integrator == S.INTEGRATOR_VOLPATH and sc.bsdfs[sc.analytic[0]["bsdf"]]["type"] == S.BSDF_NULL and list(sc.shape_media[0]) == [0, -1]
+    with pytest.raises(X.SceneError, match="maximum"):
+        load('<shape type="sphere"><medium name="interior" type="homogeneous"><rgb name="sigmaS" value="1,1,1"/><rgb name="sigmaA" value="1,1,1"/><string name="strategy" value="maximum"/></medium></shape>')
+    with pytest.raises(X.SceneError, match="interior"):
+        load('<shape type="sphere"><medium type="homogeneous"><rgb name="sigmaS" value="1,1,1"/><rgb name="sigmaA" value="1,1,1"/></medium></shape>')
+    with pytest.raises(X.SceneError, match="heterogeneous"):
+        load('<shape type="sphere"><medium name="interior" type="heterogeneous"/></shape>')
