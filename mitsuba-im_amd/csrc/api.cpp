@@ -467,7 +467,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 63) / 64 * 64;
     r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
     // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
-    r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", 512u));
+    r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", r->scene->h.d.has_roughconductor ? 512u : 768u));      // 3 workgroups per CU since the diffuse kernels hold 4 waves per SIMD (C2: 512 -> 2970, 640 -> 3022, 768 -> 3078, 896 -> 2890 Msamples/s); the 2-wave microfacet kernels stay at 2
     r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
     const uint64_t slots = cap * grid;
     for (int b = 0; b < 2; ++b) {
