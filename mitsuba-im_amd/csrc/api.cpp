@@ -470,6 +470,10 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", r->scene->h.d.has_roughconductor ? 512u : 768u));      // 3 workgroups per CU since the diffuse kernels hold 4 waves per SIMD (C2: 512 -> 2970, 640 -> 3022, 768 -> 3078, 896 -> 2890 Msamples/s); the 2-wave microfacet kernels stay at 2
     r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
     const uint64_t slots = cap * grid;
+    {   // MI355PT_POOL_LIMIT (bytes per pool; tests): behave as if the card had no more room than this -- mi_render_run then falls back to smaller batches
+        const char *lim = getenv("MI355PT_POOL_LIMIT");
+        if (lim && atoll(lim) > 0 && slots * 224ull > (uint64_t) atoll(lim)) return fail(MI_ERR_DEVICE, "mi_render_run: path pool larger than MI355PT_POOL_LIMIT");
+    }
     for (int b = 0; b < 2; ++b) {
         ALLOC(Q.rayO[b], float4, slots); ALLOC(Q.rayD[b], float4, slots);
         ALLOC(Q.st0[b], uint4, slots); ALLOC(Q.st1[b], float4, slots); ALLOC(Q.st2[b], float, slots);
@@ -690,9 +694,16 @@ int mi_render_run_rows(mi_render *r, mi_tile tile, uint32_t rowStride, uint32_t 
         uint32_t nb = (total + planes - 1) / planes; nb = (nb + ns - 1) / ns * ns;
         planes = (total + nb - 1) / nb;
     }
-    const uint64_t need = (uint64_t) npix * planes;
+    uint64_t need = (uint64_t) npix * planes;
     if (need > 0xFFFFFF00ull) return fail(MI_ERR_INVALID, "mi_render_run: batch larger than 2^32 paths");
-    if (need > r->poolPaths) { int rc = allocPool(r, need); if (rc) return rc; }      // the pool only grows: a short last batch or a smaller tile reuses it
+    while (need > r->poolPaths) {      // the pool only grows: a short last batch or a smaller tile reuses it
+        int rc = allocPool(r, need);
+        if (!rc) break;
+        // not enough free device memory for pools of this size (another process on the card, a smaller part): halve the automatic batch and try again
+        (void) hipGetLastError(); r->poolPaths = 0;
+        if (r->p.planes_per_batch || planes <= 1) return rc;
+        planes = (planes + 1) / 2; need = (uint64_t) npix * planes;
+    }
     size_t evUsed = 0; r->launchesAll = 0;
     HIPCHK(hipEventRecord(r->evBegin, r->stream));
     const uint32_t nBatches = (s1 - s0 + planes - 1) / planes;

@@ -1066,3 +1066,16 @@ def test_scene_file_with_media(mi, oracle):
     r.clear(); r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
     assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-6
     assert st["rays"] == int(cnt[0]) and st["shadow_rays"] == int(cnt[1]) and st["path_length_sum"] == int(cnt[2])
+
+
+def test_batch_size_falls_back_when_memory_is_short(mi, monkeypatch):
+    """mi_render_run sizes its path pools for 64 M paths in flight; when the card has no room for that (MI355PT_POOL_LIMIT stands in for a failing hipMalloc) it halves
+    the automatic batch until the pools fit.  The film does not depend on how the sample planes are cut into batches: bit-identical to the unlimited render."""
+    sc = mi.scenes.cornell_box(640, 360, 64); gs = mi.Scene(sc)
+    a = mi.Render(gs); a.run(); fa = a.read_film(0)
+    monkeypatch.setenv("MI355PT_POOL_LIMIT", str(300 << 20))                  # 300 MB per pool: ~1.4 M paths instead of the 7.4 M this job would take per batch
+    b = mi.Render(gs); b.run(); fb = b.read_film(0)
+    assert (bits(fa) == bits(fb)).all()
+    monkeypatch.setenv("MI355PT_POOL_LIMIT", "1000")                          # nothing fits: the error of the last attempt comes back
+    with pytest.raises(RuntimeError, match="MI355PT_POOL_LIMIT"):
+        mi.Render(gs).run()
