@@ -160,7 +160,8 @@ def strict_fixtures(only=None):
 
 # converged low-resolution images of the three BASELINE scene classes: 240 x 135, Sobol, enough samples per pixel that the
 # reference's OWN two builds (-ffast-math as shipped / strict IEEE) agree below the 1e-4 relative-L2 tolerance of the north star
-CONVERGED = {"S1_cornell": ("cornell_box", dict(), 1024), "S2_veach": ("veach_mis", dict(), 32768), "S3_atrium": ("atrium", dict(detail=0.08, env_size=(64, 32)), 32768)}
+CONVERGED = {"S1_cornell": ("cornell_box", dict(), 1024), "S2_veach": ("veach_mis", dict(), 32768), "S3_atrium": ("atrium", dict(detail=0.08, env_size=(64, 32)), 32768),
+             "S4_fog": ("fog_box", dict(global_fog=True, integrator=scenes.INTEGRATOR_VOLPATH), 2048)}      # the volumetric loop (volpath) over the fog_box room
 
 
 def converged_scene(key):

@@ -851,13 +851,14 @@ def test_device_sincosf_equals_glibc(mi):
     assert (bits(s[sel]) == bits(rs[sel])).all() and (bits(c[sel]) == bits(rc[sel])).all()
 
 
-@pytest.mark.parametrize("key", ["S1_cornell", "S2_veach", "S3_atrium"])
+@pytest.mark.parametrize("key", ["S1_cornell", "S2_veach", "S3_atrium", "S4_fog"])
 def test_converged_images_vs_reference(mi, key):
     """SURVEY.md §8c item 11 / the north star's image tolerance: the three BASELINE scene classes at 240 x 135, Sobol, converged (1024 / 32768 / 32768 spp),
     rendered by the REFERENCE itself (fixtures tests/golden/converged/, generator tests/golden/make_golden.py --converged) -- once as shipped
     (-ffast-math) and once from the same sources under strict IEEE arithmetic.  The HIP film must be within 1e-4 relative L2 of the reference.
     The fixture also records how far the reference's two builds are from EACH OTHER (S1 3.6e-5, S2 6.9e-5, S3 6.7e-5): that is the floor any
-    implementation that is not the same binary can reach against the fast-math build; against the strict build the HIP path is an order of magnitude closer."""
+    implementation that is not the same binary can reach against the fast-math build; against the strict build the HIP path is an order of magnitude closer.
+    S4_fog: the volumetric loop (volpath over the fog_box room with the sensor inside a medium, 2048 spp)."""
     from tests.golden.make_golden import converged_scene
     fx = np.load(os.path.join(GOLDEN, "converged", key + ".npz")); sc = converged_scene(key)
     assert int(fx["spp"]) == sc.spp
