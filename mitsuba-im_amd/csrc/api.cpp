@@ -516,8 +516,8 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for
         for (const mi_material &m : s->h.materials)
-            if (m.type == MI_BSDF_MASK || m.type == MI_BSDF_THINDIELECTRIC || m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP)
-                return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with mask / thindielectric / mixturebsdf / bumpmap / normalmap materials is not implemented");
+            if (m.type == MI_BSDF_MASK || m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP)
+                return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with mask / mixturebsdf / bumpmap / normalmap materials is not implemented");
         if (s->h.d.packet_n) return fail(MI_ERR_INVALID, "mi_render_create: the volumetric integrators need the tree traversal (scenes with media always have it; set MI355PT_NO_PACKET=1 for a scene without media)");
         if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth beyond 250");
     }

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0); bool sampledDelta, sampledNull;
                 float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
                 auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };
+                if (bsdf.type == MI_BSDF_T_THINDIELECTRIC) bsdf.flags |= MI_THIN_SIGNED_COS;      // the pdf-less ThinDielectric::sample overload this integrator calls (pt_device.h)
                 const v3 bw = mxSample<true, false>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (isZero(bw)) { pathLen += (unsigned) depth; break; }
                 // which radiance types the next iteration gathers (volpath_simple.cpp:236-257)
@@ -244,10 +245,11 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     n = fn;
                 }
-                if (interactions == maxInteractions || loadMaterial(tb, material).type != MI_BSDF_T_NULL) { blocked = true; break; }   // an occluder: zero transmittance
+                if (interactions == maxInteractions || !materialHasNull(loadMaterial(tb, material).type)) { blocked = true; break; }   // an occluder: zero transmittance
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
+            tr = tr * materialNullEval(loadMaterial(tb, material), -dot(d, n));      // its.geoFrame = Frame(n): cosTheta(wi) = -dot(d, n)
             const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;   // `null`: bsdf->eval(bRec, EDiscrete) with typeMask = ENull is 1 (null.cpp:48-50)
             if (pm) {
                 if (medium != targetMedium(pm, n, -d)) { blocked = true; break; }      // medium inconsistency (scene.cpp:689-692)

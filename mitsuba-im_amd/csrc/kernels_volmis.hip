@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     const v3 segT = medium >= 0 ? mediumTransmittance(md, 0.0f, tHit) : V(1, 1, 1);
                     fill();
                     const int maxInteractions = rc.max_depth - depth;           // m_maxDepth - rRec.depth - 1 at the spawning vertex (depth has advanced by one since)
-                    const bool isNull = loadMaterial(tb, h.material).type == MI_BSDF_T_NULL;
+                    const MaterialD hm = loadMaterial(tb, h.material); const bool isNull = materialHasNull(hm.type);
                     if (h.emitter >= 0) {                                        // an emitter (also one behind a `null` BSDF, :388-390)
                         const v3 value = segT * emitterEval(tb, h.emitter, h.ns, -d);
                         if (!isZero(value)) {
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                         const v3 p = o + d * hr.x;                              // ray.o = ray(its->t)
                         wantSearch = true;
                         seO = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t) (m2 + 1) | (((uint32_t) maxInteractions & 0xFFFFu) << 8) | (1u << 26) | ((fl & VM_FACING) ? (1u << 27) : 0u) | ((fl & VM_DELTA) ? (1u << 28) : 0u)));
-                        seD = make_float4(d.x, d.y, d.z, __uint_as_float(pid)); seC = make_float4(segT.x, segT.y, segT.z, prevPdf);
+                        const v3 segN = segT * materialNullEval(hm, -dot(d, h.ns));      // wo = shFrame.toLocal(ray.d): cosTheta(wi) = -dot(d, ns) (volpath.cpp:399-402)
+                        seD = make_float4(d.x, d.y, d.z, __uint_as_float(pid)); seC = make_float4(segN.x, segN.y, segN.z, prevPdf);
                         seT = make_float4(T.x, T.y, T.z, 0.0f); seX = make_float4(o.x, o.y, o.z, prevCos);     // dRec.ref = the spawning vertex (+ the cosine a `constant` environment's density needs)
                     }
                 }
@@ -286,10 +287,12 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                 if (inst >= 0) fillHitInstanced(sc, tb, sc.instances[inst], o, d, t, prim, u, v, h);
                 else if (prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], o, d, t, u, v, h);
                 else fillHit<false, true>(sc, tb, d, t, prim, u, v, h);
-                if (interactions == maxInteractions || loadMaterial(tb, h.material).type != MI_BSDF_T_NULL || h.emitter >= 0) break;
+                const MaterialD hm = loadMaterial(tb, h.material);
+                if (interactions == maxInteractions || !materialHasNull(hm.type) || h.emitter >= 0) break;
                 if (isZero(tr)) { surface = false; break; }
                 const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
                 if (pm) medium = targetMedium(pm, h.ng, d);
+                tr = tr * materialNullEval(hm, -dot(d, h.ns));
                 o = o + d * t;
                 if (++interactions > 100) { surface = false; break; }
             }
@@ -337,10 +340,11 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     nn = fn;
                 }
-                if (interactions == maxInteractions || loadMaterial(tb, material).type != MI_BSDF_T_NULL) { blocked = true; break; }
+                if (interactions == maxInteractions || !materialHasNull(loadMaterial(tb, material).type)) { blocked = true; break; }
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
+            tr = tr * materialNullEval(loadMaterial(tb, material), -dot(d, nn));
             const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
             if (pm) { if (medium != targetMedium(pm, nn, -d)) { blocked = true; break; } medium = targetMedium(pm, nn, d); }
             if (++interactions > 100) break;

@@ -1157,8 +1157,12 @@ DEV v3 rpSample(const DScene &sc, const MaterialD &mt, v3 wi, float sx, float sy
 // src/bsdfs/diffuse.cpp:112-153; src/bsdfs/twosided.cpp:110-190 (flip to the front side).  RC = the scene holds non-diffuse materials
 // (rough conductor, conductor, dielectric, plastic): the diffuse-only kernel variants carry none of that code.
 // src/bsdfs/thindielectric.cpp:206-258: delta reflection or straight-through transmission (an ENull component: `nullComp`), internal bounces summed
+// MI_THIN_SIGNED_COS (a flag the volpath_simple stage sets on its copy of the record): ThinDielectric has two sample() overloads; the one WITHOUT a pdf argument --
+// the one volpath_simple calls (volpath_simple.cpp:234) -- feeds the SIGNED cosine to fresnelDielectricExt (thindielectric.cpp:263; the other takes |cos|, :212), so a
+// pane hit from its back side reflects as if seen from inside the glass.  Restated as it is.
+#define MI_THIN_SIGNED_COS (1u << 30)
 DEV v3 thinDielectricSample(const MaterialD &m, v3 wi, float sx, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
-    float ct, R = fresnelDielectricExt(fabsf(wi.z), ct, m.eta[0]), T = 1 - R;
+    float ct, R = fresnelDielectricExt((m.flags & MI_THIN_SIGNED_COS) ? wi.z : fabsf(wi.z), ct, m.eta[0]), T = 1 - R;
     if (R < 1) R += T * T * R / (1 - R * R);
     etaOut = 1.0f; delta = true;
     if (sx <= R) { wo = V(-wi.x, -wi.y, wi.z); pdf = R; return ld3(m.specular); }
@@ -1633,6 +1637,15 @@ DEV v3 phaseSample(const MediumD &m, v3 wi, float sx, float sy) {
     sincos2pi(sy, sinPhi, cosPhi);
     const v3 n = V(-wi.x, -wi.y, -wi.z); v3 fs, ft; coordinateSystem(n, fs, ft);          // Frame(-pRec.wi).toWorld
     return (fs * (sinTheta * cosPhi) + ft * (sinTheta * sinPhi)) + n * cosTheta;
+}
+// bsdf->eval(bRec, EDiscrete) with typeMask = ENull for a straight pass-through (scene.cpp:679-685, volpath.cpp:399-402): `null` -> 1, `thindielectric` -> its transmittance
+// with the internal bounces summed (thindielectric.cpp:155-178); cosWi = Frame::cosTheta(bRec.wi)
+DEV bool materialHasNull(uint32_t type) { return type == MI_BSDF_T_NULL || type == MI_BSDF_T_THINDIELECTRIC; }
+DEV v3 materialNullEval(const MaterialD &m, float cosWi) {
+    if (m.type == MI_BSDF_T_NULL) return V(1, 1, 1);
+    float ct, R = fresnelDielectricExt(fabsf(cosWi), ct, m.eta[0]), T = 1 - R;
+    if (R < 1) R += T * T * R / (1 - R * R);
+    return ld3(m.reflectance) * (1 - R);
 }
 // Shape::isMediumTransition / Intersection::getTargetMedium (include/mitsuba/render/records.inl:77-86): index of the medium on the side `d` points to, -1 = none
 DEV int targetMedium(uint32_t pm, v3 n, v3 d) { return (int) (dot(d, n) > 0 ? (pm >> 16) : (pm & 0xFFFFu)) - 1; }

@@ -1121,8 +1121,11 @@ static v3 conductor_sample(const orc_material *m, v3 wi, v3 *wo, float *pdf, flo
 }
 /* src/bsdfs/thindielectric.cpp:206-258: a thin slab -- delta reflection or straight-through transmission (an ENull component: the path counts as unscattered,
  * *delta = 2), reflectance with the internal bounces summed (R' = R + TRT + TR^3T + ...).  Fields: eta[0], specular = specularReflectance, reflectance = specularTransmittance */
+/* THIN_SIGNED_COS (set on the scene's thindielectric records when the integrator is volpath_simple): that integrator calls the sample() overload WITHOUT a pdf argument
+ * (volpath_simple.cpp:234), which feeds the SIGNED cosine to fresnelDielectricExt (thindielectric.cpp:263; the other overload takes |cos|, :212) */
+#define THIN_SIGNED_COS (1u << 30)
 static v3 thindielectric_sample(const orc_material *m, v3 wi, float sx, v3 *wo, float *pdf, float *etaOut, int *delta) {
-    float ct, R = fresnel_dielectric_ext(fabsf(wi.z), &ct, m->eta[0]), T = 1 - R;
+    float ct, R = fresnel_dielectric_ext((m->flags & THIN_SIGNED_COS) ? wi.z : fabsf(wi.z), &ct, m->eta[0]), T = 1 - R;
     if (R < 1) R += T * T * R / (1 - R * R);
     *etaOut = 1.0f;
     if (sx <= R) { *delta = 1; *wo = V(-wi.x, -wi.y, wi.z); *pdf = R; return V(m->specular[0], m->specular[1], m->specular[2]); }
@@ -2106,6 +2109,15 @@ static int ray_intersect_n(const orc_scene *s, v3 o, v3 d, float rmint, float rm
     fill_hit(s, o, d, t, prim, inst, u, v, h);
     return 1;
 }
+/* bsdf->eval(bRec, EDiscrete) with typeMask = ENull for a straight pass-through (wo = -wi): `null` -> 1 (null.cpp:48-50), `thindielectric` -> its transmittance with
+ * the internal bounces summed (thindielectric.cpp:155-178); cosWi = Frame::cosTheta(bRec.wi).  has_null: the BSDF's type carries ENull at all */
+static int material_has_null(const orc_material *m) { return m->type == BSDF_NULL || m->type == BSDF_THINDIELECTRIC; }
+static v3 material_null_eval(const orc_material *m, float cosWi) {
+    if (m->type == BSDF_NULL) return V(1, 1, 1);
+    float ct, R = fresnel_dielectric_ext(fabsf(cosWi), &ct, m->eta[0]), T = 1 - R;
+    if (R < 1) R += T * T * R / (1 - R * R);
+    return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), 1 - R);
+}
 /* Scene::evalTransmittance (scene.cpp:650-713): walk from p1 to p2 through index-matched (`null`) boundaries, attenuating by the media in between */
 static v3 eval_transmittance(const orc_scene *s, v3 p1, int p1OnSurface, v3 p2, int p2OnSurface, int medium, int *interactions, uint64_t *shadow_rays) {
     v3 d = sub(p2, p1); float remaining = length3(d); { float r = 1.0f / remaining; d = scale(d, r); }
@@ -2114,10 +2126,11 @@ static v3 eval_transmittance(const orc_scene *s, v3 p1, int p1OnSurface, v3 p2, 
     v3 transmittance = V(1, 1, 1); hit_t its; const int maxInteractions = *interactions; *interactions = 0;
     while (remaining > 0) {
         int surface = ray_intersect_n(s, o, d, mint, maxt, &its, shadow_rays);
-        if (surface && (*interactions == maxInteractions || s->materials[its.material].m.type != BSDF_NULL)) return V(0, 0, 0);     /* !(bsdf->getType() & BSDF::ENull) */
+        if (surface && (*interactions == maxInteractions || !material_has_null(&s->materials[its.material].m))) return V(0, 0, 0);     /* !(bsdf->getType() & BSDF::ENull) */
         if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, minf(its.t, remaining)));
         if (!surface || is_zero(transmittance)) break;
-        /* bsdf->eval(bRec, EDiscrete) with typeMask = ENull: 1 for `null` (null.cpp:48-50) */
+        /* its.geoFrame = Frame(n); wo = toLocal(ray.d); bRec(its, -wo, wo) with typeMask = ENull (scene.cpp:679-685): cosTheta(wi) = -dot(d, n) */
+        transmittance = mul(transmittance, material_null_eval(&s->materials[its.material].m, -dot(d, its.ng_raw)));
         if (is_medium_transition(s, its.shape)) {
             if (medium != target_medium(s, its.shape, its.ng_raw, neg(d))) return V(0, 0, 0);        /* medium inconsistency */
             medium = target_medium(s, its.shape, its.ng_raw, d);
@@ -2250,11 +2263,12 @@ static void look_for_emitter(const orc_scene *s, int medium, int maxInteractions
         ++counters[0];
         surface = ray_intersect(s, o, d, mint, INFINITY, its, 0); if (!surface) its->t = INFINITY;
         if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, its->t));
-        if (surface && (interactions == maxInteractions || s->materials[its->material].m.type != BSDF_NULL || its->emitter >= 0)) break;
+        if (surface && (interactions == maxInteractions || !material_has_null(&s->materials[its->material].m) || its->emitter >= 0)) break;
         if (!surface) break;
         if (is_zero(transmittance)) return;
         if (is_medium_transition(s, its->shape)) medium = target_medium(s, its->shape, its->ng, d);
-        /* bsdf->eval(bRec, EDiscrete) with typeMask = ENull: 1 for `null` */
+        /* wo = its->shFrame.toLocal(ray.d); bRec(*its, -wo, wo), typeMask = ENull (volpath.cpp:399-402): cosTheta(wi) = -dot(d, ns) */
+        transmittance = mul(transmittance, material_null_eval(&s->materials[its->material].m, -dot(d, its->ns)));
         o = add(o, scale(d, its->t)); mint = EPSILON; its = &its2;
         if (++interactions > 100) return;
     }
@@ -2498,6 +2512,7 @@ orc_scene *orc_scene_create(const orc_scene_desc *d) {
     s->materials = (mat_t *) calloc(d->n_materials ? d->n_materials : 1, sizeof(mat_t));
     for (uint32_t i = 0; i < d->n_materials; ++i) { s->materials[i].m = d->materials[i]; s->materials[i].table = s->material_tables ? s->material_tables + (size_t) d->materials[i].k[1] : NULL; }
     s->d.material_tables = NULL;
+    if (d->integrator == 1) for (uint32_t i = 0; i < d->n_materials; ++i) if (s->materials[i].m.type == BSDF_THINDIELECTRIC) s->materials[i].m.flags |= THIN_SIGNED_COS;
     s->emitters = (orc_emitter *) dup(d->emitters, d->n_emitters * sizeof(orc_emitter));
     s->media = (orc_medium *) dup(d->media, (size_t) (d->media ? d->n_media : 0) * sizeof(orc_medium)); s->d.media = NULL;
     s->d.shape_media = (const int32_t *) dup(d->shape_media, (size_t) (d->shape_media ? (d->n_shapes + d->n_analytic) : 0) * 8);

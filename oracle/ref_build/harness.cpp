@@ -974,6 +974,11 @@ int main(int argc, char **argv) {
     if (mode == "samples") modeSamples(b, fs, argv[3], argv[4]);
     else if (mode == "image") modeImage(b, fs, atoi(argv[3]), argv[4]);
     else if (mode == "hits") modeHits(b, fs, atoi(argv[3]), argv[4]);
+    else if (mode == "probe") {      // debugging aid: one ray through Scene::rayIntersect -- probe ox oy oz dx dy dz
+        Ray ray(Point(atof(argv[3]), atof(argv[4]), atof(argv[5])), normalize(Vector(atof(argv[6]), atof(argv[7]), atof(argv[8]))), 0.0f); Intersection its;
+        bool hit = b.scene->rayIntersect(ray, its);
+        printf("probe: hit %d t %g p %g %g %g shape %s\n", (int) hit, (double) its.t, (double) its.p.x, (double) its.p.y, (double) its.p.z, hit ? its.shape->getName().c_str() : "-");
+    }
     else if (mode == "camera") modeCamera(b, fs, argv[3]);
     else if (mode == "units") modeUnits(b, fs, argv[3]);
     else if (mode == "responsive") modeResponsive(b, fs, argv[3], atoi(argv[4]), argv[5]);

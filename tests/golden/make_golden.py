@@ -119,6 +119,9 @@ def golden_scenes():
         "fog_sky_global_hide": scenes.fog_sky(width=96, height=64, spp=8, global_fog=True, hide_emitters=True, sampler=scenes.SAMPLER_INDEPENDENT, seed=16, rr_depth=2),
         "fog_constant": scenes.fog_sky(width=96, height=64, spp=16, constant_env=True),
         "fog_constant_simple_indep": scenes.fog_sky(width=96, height=64, spp=8, constant_env=True, integrator=scenes.INTEGRATOR_VOLPATH_SIMPLE, sampler=scenes.SAMPLER_INDEPENDENT, seed=17, rr_depth=2),
+        # a thin glass pane (thindielectric: ENull transmission) in the room: transmittance walks and the emitter search pass through it, attenuated
+        "fog_pane": scenes.fog_box(width=96, height=96, spp=16, pane=True),
+        "fog_pane_mis": scenes.fog_box(width=96, height=96, spp=8, pane=True, global_fog=True, integrator=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=18),
         "fog_mis_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5, integrator=scenes.INTEGRATOR_VOLPATH),
     }
 
