@@ -10,7 +10,7 @@
 // 20..27 current medium + 1.  Shadow record: shO = p1 | medium + 1, maxInteractions (int16), p1OnSurface, p2OnSurface; shD = p2 | path id; shC = emitter value BEFORE the
 // division by the emitter-selection probability | that probability; shT = throughput; shX = BSDF value (or the phase value in all three channels).
 // Built for: meshes + analytic shapes (media on scene-level shapes), every plain BSDF incl. `null`, textures, area / point / spot / directional emitters.  Refused at
-// mi_render_create: mask / thindielectric (their ENull lobes would have to be evaluated inside the transmittance walk), the BSDF adapters.
+// mi_render_create: mask (its textured ENull lobe would have to be evaluated inside the transmittance walk), adapters that nest a `null` / `thindielectric`.
 #include "kernels_common.h"
 #include "trace.h"
 
@@ -31,7 +31,7 @@ DEV v3 envEvalSensorRay(const DScene &sc, const RenderConst &rc, v3 d, float2 sp
 #define VOL_NULLCHAIN (1u << 18)
 #define VOL_SCATTERED (1u << 19)
 
-template <bool TEX, bool ENV>      // TEX: textures bound to materials; ENV: an environment map among the emitters
+template <bool TEX, bool ENV, bool WRAP>      // TEX: textures bound to materials; ENV: an environment map among the emitters; WRAP: mixturebsdf / bumpmap / normalmap records present (with TEX)
 __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 }
                 const int interactions = rc.max_depth - depth - 1;
                 // ---- the interaction: a point in the medium, or the surface at the end of the segment
-                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); Hit h; MaterialD bsdf; uint32_t pm = 0;
+                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); Hit h; MaterialD bsdf; uint32_t pm = 0; bool bumped = false; v3 bps = V(0, 0, 0), bpt = V(0, 0, 0), bpn = V(0, 0, 0);
                 if (mediumEvent) {
                     { const float r = 1.0f / mRec.pdfSuccess; T = T * ((ld3(md.sigma_s) * mRec.transmittance) * r); }
                     nee = others; nref = mRec.p;                             // EDirectMediumRadiance
@@ -110,8 +110,9 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                     if (h.emitter >= 0 && emitted && (!rc.hide_emitters || scattered)) { add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true; }
                     if (rc.strict_normals && (-dot(h.ng, d)) * h.wi.z < 0) { pathLen += (unsigned) depth; break; }
                     bsdf = loadMaterial(tb, h.material);
+                    auto applyTexture = [&](MaterialD &mm) {
                     if (TEX) {                                               // a textured reflectance (shade.h applyTexture); only the sensor ray carries differentials
-                        const uint32_t tex = (bsdf.flags >> 8) & 0xFFFFu;
+                        const uint32_t tex = (WRAP && (mm.type == MI_BSDF_T_BUMPMAP || mm.type == MI_BSDF_T_NORMALMAP)) ? 0u : (mm.flags >> 8) & 0xFFFFu;      // (an adapter's texture is its displacement / normal map)
                         if (tex) {
                             const TextureD &tx = sc.textures[tex - 1]; v3 c; float huvx = h.uvx, huvy = h.uvy;
                             const bool onAnalytic = inst < 0 && prim >= sc.n_tris;
@@ -129,8 +130,19 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                                     c = mipEval(sc, tx, uvx, uvy, pa[0] * tx.uscale, pa[1] * tx.vscale, pa[2] * tx.uscale, pa[3] * tx.vscale);
                                 } else c = tx.filter != 0u ? mipBilinear(sc, tx, 0, uvx, uvy) : mipBox(sc, tx, 0, uvx, uvy);
                             } else c = textureEval(tx, huvx, huvy);
-                            bsdf.reflectance[0] = c.x; bsdf.reflectance[1] = c.y; bsdf.reflectance[2] = c.z;
+                            mm.reflectance[0] = c.x; mm.reflectance[1] = c.y; mm.reflectance[2] = c.z;
                         }
+                    }
+                    };
+                    applyTexture(bsdf);
+                    if (WRAP && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record (shade.h)
+                        float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
+                        if (inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, o + d * hr.x, huvx, huvy, dpdu, dpdv);
+                        else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
+                        else { AS<false>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                        if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
+                        perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
+                        bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
                     }
                     pm = sc.prim_media ? sc.prim_media[prim] : 0u;           // (interior + 1) | (exterior + 1) << 16 of the shape that was hit; 0: not a medium transition
                     nee = others && !(h.flags & 4u); nref = h.p;            // EDirectSurfaceRadiance, BSDFs with a smooth component
@@ -145,7 +157,9 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                         if (mediumEvent) { const float ph = phaseEval(md, -d, dr.d); x = V(ph, ph, ph); }
                         else {
                             const v3 wo = toLocal(h, dr.d);
-                            x = (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0) ? mxEval<true, false>(sc, tb, bsdf, h.wi, wo) : V(0, 0, 0);
+                            v3 wiQ = h.wi, woQ = wo; bool rejected = false;
+                            if (WRAP && bumped) { wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0; }      // bumpmap.cpp:165-180
+                            x = (!rejected && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) ? mxEval<true, WRAP>(sc, tb, bsdf, wiQ, woQ) : V(0, 0, 0);
                             if (pm) m2 = targetMedium(pm, h.ng, dr.d);      // scene.cpp:920-921
                             onSurface = 1u << 24;
                         }
@@ -169,7 +183,12 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
                 auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };
                 if (bsdf.type == MI_BSDF_T_THINDIELECTRIC) bsdf.flags |= MI_THIN_SIGNED_COS;      // the pdf-less ThinDielectric::sample overload this integrator calls (pt_device.h)
-                const v3 bw = mxSample<true, false>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                v3 bw;
+                if (WRAP && bumped) {                                        // bumpmap.cpp:196-216
+                    const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
+                    bw = mxSample<true, WRAP>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
+                    if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
+                } else bw = mxSample<true, WRAP>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (isZero(bw)) { pathLen += (unsigned) depth; break; }
                 // which radiance types the next iteration gathers (volpath_simple.cpp:236-257)
                 const bool rtOthers = (depth + 1 < rc.max_depth || rc.max_depth < 0) && others; bool rtEmitted = false; bool nullChain = (fl & VOL_NULLCHAIN) != 0;
@@ -280,8 +299,9 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
 extern "C" {
 void mi_launch_shade_vol(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool env = sc.env_index >= 0;
-    if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
-    else { if (env) hipLaunchKernelGGL((k_shade_vol<false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    if (sc.has_adapters) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else { if (env) hipLaunchKernelGGL((k_shade_vol<false, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<false, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_vol(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     if (sc.bvh_wide) hipLaunchKernelGGL((k_shadow_vol<true>), dim3(grid), dim3(WG), 0, st, sc, q);

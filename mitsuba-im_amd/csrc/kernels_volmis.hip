@@ -39,7 +39,7 @@ template <bool L> DEV float envLumPdf(const DScene &sc, const Tabs<L> &tb, v3 d,
 #define VM_SKIPRR (1u << 29)
 // shadow record bits (shO.w): 0..7 medium + 1, 8..23 maxInteractions (int16), 24 p1OnSurface, 25 p2OnSurface, 26 kind = emitter search, 27 facingRef, 28 delta sample
 
-template <bool TEX, bool ENV>
+template <bool TEX, bool ENV, bool WRAP>      // WRAP: mixturebsdf / bumpmap / normalmap records present (with TEX), as in kernels_vol.hip
 __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     }
                 }
                 const int interactions = rc.max_depth - depth - 1;
-                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); MaterialD bsdf; uint32_t pm = 0;
+                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); MaterialD bsdf; uint32_t pm = 0; bool bumped = false; v3 bps = V(0, 0, 0), bpt = V(0, 0, 0), bpn = V(0, 0, 0);
                 if (mediumEvent) {
                     if (depth >= rc.max_depth && rc.max_depth != -1) { pathLen += (unsigned) depth; break; }      // :112-113
                     { const float r = 1.0f / mRec.pdfSuccess; T = T * ((ld3(md.sigma_s) * mRec.transmittance) * r); }
@@ -157,8 +157,9 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     if (depth >= rc.max_depth && rc.max_depth != -1) { pathLen += (unsigned) depth; break; }      // :203-204
                     if ((-dot(h.ng, d)) * h.wi.z < 0 && rc.strict_normals) { pathLen += (unsigned) depth; break; }
                     bsdf = loadMaterial(tb, h.material);
+                    auto applyTexture = [&](MaterialD &mm) {
                     if (TEX) {
-                        const uint32_t tex = (bsdf.flags >> 8) & 0xFFFFu;
+                        const uint32_t tex = (WRAP && (mm.type == MI_BSDF_T_BUMPMAP || mm.type == MI_BSDF_T_NORMALMAP)) ? 0u : (mm.flags >> 8) & 0xFFFFu;
                         if (tex) {
                             const TextureD &tx = sc.textures[tex - 1]; v3 c; float huvx = h.uvx, huvy = h.uvy;
                             const bool onAnalytic = inst < 0 && prim >= sc.n_tris;
@@ -176,8 +177,19 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                                     c = mipEval(sc, tx, uvx, uvy, pa[0] * tx.uscale, pa[1] * tx.vscale, pa[2] * tx.uscale, pa[3] * tx.vscale);
                                 } else c = tx.filter != 0u ? mipBilinear(sc, tx, 0, uvx, uvy) : mipBox(sc, tx, 0, uvx, uvy);
                             } else c = textureEval(tx, huvx, huvy);
-                            bsdf.reflectance[0] = c.x; bsdf.reflectance[1] = c.y; bsdf.reflectance[2] = c.z;
+                            mm.reflectance[0] = c.x; mm.reflectance[1] = c.y; mm.reflectance[2] = c.z;
                         }
+                    }
+                    };
+                    applyTexture(bsdf);
+                    if (WRAP && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record (shade.h)
+                        float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
+                        if (inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, o + d * hr.x, huvx, huvy, dpdu, dpdv);
+                        else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
+                        else { AS<false>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                        if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
+                        perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
+                        bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
                     }
                     pm = sc.prim_media ? sc.prim_media[prim] : 0u;
                     nee = !(h.flags & 4u); nref = h.p;
@@ -192,9 +204,11 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                         if (mediumEvent) { const float ph = phaseEval(md, -d, dr.d); x = V(ph, ph, ph); w = miWeight(dr.pdf, dr.delta ? 0.0f : ph); }      // PhaseFunction::pdf = eval (phase.cpp:21-23)
                         else {
                             const v3 wo = toLocal(h, dr.d);
-                            const v3 bv = mxEval<true, false>(sc, tb, bsdf, h.wi, wo);
+                            v3 wiQ = h.wi, woQ = wo; bool rejected = false;
+                            if (WRAP && bumped) { wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0; }      // bumpmap.cpp:165-180
+                            const v3 bv = rejected ? V(0, 0, 0) : mxEval<true, WRAP>(sc, tb, bsdf, wiQ, woQ);
                             const bool ok = !isZero(bv) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0);
-                            x = ok ? bv : V(0, 0, 0); w = ok ? miWeight(dr.pdf, dr.delta ? 0.0f : mxPdf<true, false>(sc, tb, bsdf, h.wi, wo)) : 0.0f;
+                            x = ok ? bv : V(0, 0, 0); w = ok ? miWeight(dr.pdf, dr.delta ? 0.0f : mxPdf<true, WRAP>(sc, tb, bsdf, wiQ, woQ)) : 0.0f;
                             if (pm) m2 = targetMedium(pm, h.ng, dr.d);
                             onSurface = 1u << 24;
                         }
@@ -218,7 +232,12 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                 float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0); bool sampledDelta, sampledNull;
                 float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
                 auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };
-                const v3 bw = mxSample<true, false>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                v3 bw;
+                if (WRAP && bumped) {                                        // bumpmap.cpp:218-240
+                    const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
+                    bw = mxSample<true, WRAP>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
+                    if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
+                } else bw = mxSample<true, WRAP>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (isZero(bw)) { pathLen += (unsigned) depth; break; }
                 const v3 wo = toWorld(h, woL);
                 if (dot(h.ng, wo) * woL.z <= 0 && rc.strict_normals) { pathLen += (unsigned) depth; break; }
@@ -372,8 +391,9 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
 extern "C" {
 void mi_launch_shade_volmis(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool env = sc.env_index >= 0;
-    if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
-    else { if (env) hipLaunchKernelGGL((k_shade_volmis<false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    if (sc.has_adapters) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    else { if (env) hipLaunchKernelGGL((k_shade_volmis<false, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<false, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_volmis(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     const bool env = sc.env_index >= 0;

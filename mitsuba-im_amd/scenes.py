@@ -838,10 +838,12 @@ def normal_map_image(w=64, h=48):
     return np.ascontiguousarray((0.5 + 0.5 * n).astype(f32))
 
 
-def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, strict_normals=False, procedural_maps=False):
+def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, strict_normals=False, procedural_maps=False, fog=None):
     """The textured room with the three BSDF adapters of SURVEY §8 f2: `bumpmap` floor (bitmap displacement under a `scale` texture, bilinear gradient),
     `normalmap` wall over a twosided rough conductor, a `mixturebsdf` mound (plastic + diffuse), a twosided three-way mixture whose weights sum to
-    1.4 (rescaled by the BSDF), a bump-mapped mixture (grid displacement: finite-difference gradient) and a mask over a bump-mapped diffuse."""
+    1.4 (rescaled by the BSDF), a bump-mapped mixture (grid displacement: finite-difference gradient) and a mask over a bump-mapped diffuse.
+    fog = INTEGRATOR_VOLPATH_SIMPLE / INTEGRATOR_VOLPATH: the room for the volumetric integrators -- the sensor sits in a thin medium that fills the room, a `null`
+    sphere of denser forward-scattering haze hangs over the mound, and the masked sheet (refused in volumetric renders) is a plain bump-mapped one."""
     sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed)
     pyr = load_texture_pyramid(); nimg = normal_map_image()
     tex = [make_texture(TEXTURE_BITMAP, pyramid=pyr, uscale=2.0, vscale=1.5, uoffset=0.05, filter_type=MIP_BILINEAR),
@@ -876,9 +878,16 @@ def layered_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6
         b0 = len(verts); verts.extend(pts); nrm.extend([n] * 4); uvl.extend([(0, 0), (0, 1), (1, 1), (1, 0)]); tris.extend([(b0, b0 + 1, b0 + 2), (b0, b0 + 2, b0 + 3)])
         shapes.append(dict(first_tri=len(tris) - 2, tri_count=2, first_vert=b0, vert_count=4, bsdf=mat, emitter=-1, face_normals=1, has_uv=1))
     quad([(-3.2, 0.0, 0.5), (-3.2, 1.6, 1.3), (-1.9, 1.6, 1.3), (-1.9, 0.0, 0.5)], (0.0, 0.0, -1.0), bumpmix)
-    quad([(0.6, 0.0, -2.2), (0.6, 1.1, -2.2), (1.9, 1.1, -1.9), (1.9, 0.0, -1.9)], (0.0, 0.0, -1.0), masked)
+    quad([(0.6, 0.0, -2.2), (0.6, 1.1, -2.2), (1.9, 1.1, -1.9), (1.9, 0.0, -1.9)], (0.0, 0.0, -1.0), floor if fog else masked)
+    extra = {}
+    if fog:
+        B.pop()                                   # (the mask record: last one added, unused here)
+        null = add(kind=BSDF_NULL)
+        haze = make_analytic(SHAPE_SPHERE, translate(0.4, 1.5, -0.6), null, radius=0.8); haze["interior"] = 1; haze["exterior"] = 0
+        extra = dict(media=[make_medium((0.004, 0.004, 0.006), (0.05, 0.05, 0.04)), make_medium((0.02, 0.01, 0.02), (0.5, 0.6, 0.5), phase=PHASE_HG, g=0.5)],
+                     sensor_medium=0, integrator=fog, analytic=[haze])
     return finish_scene(verts, tris, shapes, B, sc.emitters, sc.cam_to_world, sc.xfov, sc.near, sc.far, width, height, spp, sampler, max_depth, rr_depth,
-                        seed=seed, normals=nrm, uvs=uvl, name="layered_room", textures=tex, strict_normals=strict_normals)
+                        seed=seed, normals=nrm, uvs=uvl, name="layered_room", textures=tex, strict_normals=strict_normals, **extra)
 
 
 def textured_plastics(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, rough=True):

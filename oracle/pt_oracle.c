@@ -2503,6 +2503,14 @@ static void *dup(const void *p, size_t n) { if (!p) return NULL; void *q = mallo
 
 orc_scene *orc_scene_create(const orc_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_emitters; ++i) if (d->emitters[i].type > 5) return NULL;      /* e.g. the reference's compound `sunsky`: not restated */
+    if (d->integrator != 0) for (uint32_t i = 0; i < d->n_materials; ++i) {                      /* volumetric walks: ENull lobes of plain `null` / `thindielectric` records only (material_has_null) */
+        const orc_material *m = &d->materials[i]; int bad = m->type == BSDF_MASK;
+        #define ORC_NULL_LOBE(j) ((j) < d->n_materials && (d->materials[j].type == BSDF_NULL || d->materials[j].type == BSDF_THINDIELECTRIC))
+        if (m->type == BSDF_BUMPMAP || m->type == BSDF_NORMALMAP) bad |= ORC_NULL_LOBE(m->distr);
+        if (m->type == BSDF_MIXTURE) for (uint32_t c = 0; c < m->distr && c < 4; ++c) bad |= ORC_NULL_LOBE((uint32_t) (c < 3 ? m->reflectance[c] : m->eta[0]));
+        #undef ORC_NULL_LOBE
+        if (bad) return NULL;
+    }
     orc_scene *s = (orc_scene *) calloc(1, sizeof(orc_scene));
     s->d = *d;
     s->pos = (float *) dup(d->pos, (size_t) d->n_verts * 12); s->nrm = (float *) dup(d->nrm, (size_t) d->n_verts * 12);

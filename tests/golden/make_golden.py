@@ -122,6 +122,9 @@ def golden_scenes():
         # a thin glass pane (thindielectric: ENull transmission) in the room: transmittance walks and the emitter search pass through it, attenuated
         "fog_pane": scenes.fog_box(width=96, height=96, spp=16, pane=True),
         "fog_pane_mis": scenes.fog_box(width=96, height=96, spp=8, pane=True, global_fog=True, integrator=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=18),
+        # the BSDF adapters (mixturebsdf / bumpmap / normalmap) inside volumetric renders: the layered room filled with fog, a `null` sphere of haze over the mound
+        "fog_layered": scenes.layered_room(width=96, height=64, spp=16, fog=scenes.INTEGRATOR_VOLPATH_SIMPLE),
+        "fog_layered_mis": scenes.layered_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=23, strict_normals=True),
         "fog_mis_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5, integrator=scenes.INTEGRATOR_VOLPATH),
     }
 

@@ -992,6 +992,37 @@ def test_volpath_simple(mi, oracle, golden_scenes, name):
     assert (bits(ro.read_film(0)[..., :3]) == bits(film[..., :3])).all()                            # ... and the radiance does not notice
 
 
+@pytest.mark.parametrize("name", ["fog_layered", "fog_layered_mis"])
+def test_volumetric_bsdf_adapters(mi, oracle, golden_scenes, name):
+    """mixturebsdf / bumpmap / normalmap (and bumpmap(mixture)) inside volpath_simple / volpath: the layered room filled with fog, a `null` sphere of haze over the
+    mound (WRAP variants of k_shade_vol / k_shade_volmis).  Tolerances as test_bsdf_adapters (the rough conductors' libm calls); ray counters equal the oracle's.
+    Adapters over a `null` / `thindielectric` are refused in volumetric renders (their ENull lobe would have to be evaluated inside the transmittance walks)."""
+    sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
+    gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); st_ = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
+    rng = np.random.default_rng(29); n = 20000
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert (bits(got) == bits(ref)).all(1).mean() > 0.6 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-7, ((bits(got) == bits(ref)).all(1).mean(), (err < 1e-4).mean())
+    got = r.samples(gd["pairs"])
+    err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)            # the reference as shipped (-ffast-math)
+    assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6
+    err = np.abs(got - st_["li"]).max(1) / (np.abs(st_["li"]).max(1) + 1e-6)          # the same sources, strict IEEE build
+    assert (err < 1e-4).mean() > 0.998 and np.median(err) < 1e-7
+    r.clear(); r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-4
+    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    ref_film = np.load(os.path.join(GOLDEN, name + "_image.npz"))["film"]
+    assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
+    if name == "fog_layered":
+        S = mi.scenes
+        bad = type(sc)(sc); bad["bsdfs"] = [dict(b) for b in sc.bsdfs]
+        null = [i for i, b in enumerate(sc.bsdfs) if b["type"] == S.BSDF_NULL][0]; bump = [i for i, b in enumerate(sc.bsdfs) if b["type"] == S.BSDF_BUMPMAP][0]
+        bad["bsdfs"][bump]["distr"] = null
+        with pytest.raises(RuntimeError, match="null / thindielectric BSDF inside"):
+            mi.Render(mi.Scene(bad))
+
+
 @pytest.mark.parametrize("name", ["fog_sky", "fog_sky_simple", "fog_sky_global_hide"])
 def test_volumetric_under_envmap(mi, oracle, golden_scenes, name):
     """volpath / volpath_simple under an environment map: the sky seen through media (EWA-filtered lookup for the sensor ray, volpath.cpp:181-192), emitter sampling of
