@@ -515,10 +515,9 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for
-        // a `mask` has a textured ENull lobe, and so has an adapter over a `null` / `thindielectric`: the transmittance walks would have to evaluate them
+        // an adapter over a `null` / `thindielectric` has an ENull lobe the transmittance walks would have to evaluate through the adapter (plain records and `mask` are)
         auto nullLobe = [&](uint32_t i) { return i < s->h.materials.size() && (s->h.materials[i].type == MI_BSDF_NULL || s->h.materials[i].type == MI_BSDF_THINDIELECTRIC); };
         for (const mi_material &m : s->h.materials) {
-            if (m.type == MI_BSDF_MASK) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with mask materials is not implemented");
             bool bad = false;
             if (m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) bad = nullLobe(m.distr);
             if (m.type == MI_BSDF_MIXTURE) for (uint32_t c = 0; c < m.distr && c < 4; ++c) bad |= nullLobe((uint32_t) (c < 3 ? m.reflectance[c] : m.eta[0]));

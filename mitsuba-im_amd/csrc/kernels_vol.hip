@@ -10,7 +10,7 @@
 // 20..27 current medium + 1.  Shadow record: shO = p1 | medium + 1, maxInteractions (int16), p1OnSurface, p2OnSurface; shD = p2 | path id; shC = emitter value BEFORE the
 // division by the emitter-selection probability | that probability; shT = throughput; shX = BSDF value (or the phase value in all three channels).
 // Built for: meshes + analytic shapes (media on scene-level shapes), every plain BSDF incl. `null`, textures, area / point / spot / directional emitters.  Refused at
-// mi_render_create: mask (its textured ENull lobe would have to be evaluated inside the transmittance walk), adapters that nest a `null` / `thindielectric`.
+// mi_render_create: adapters (mixturebsdf / bumpmap / normalmap) that nest a `null` / `thindielectric`.  A `mask` attenuates the walks by 1 - opacity (surfaceNullEval).
 #include "kernels_common.h"
 #include "trace.h"
 
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 }
                 const int interactions = rc.max_depth - depth - 1;
                 // ---- the interaction: a point in the medium, or the surface at the end of the segment
-                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); Hit h; MaterialD bsdf; uint32_t pm = 0; bool bumped = false; v3 bps = V(0, 0, 0), bpt = V(0, 0, 0), bpn = V(0, 0, 0);
+                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); Hit h; MaterialD bsdf; uint32_t pm = 0; bool bumped = false, masked = false; v3 bps = V(0, 0, 0), bpt = V(0, 0, 0), bpn = V(0, 0, 0), opac = V(1, 1, 1);
                 if (mediumEvent) {
                     { const float r = 1.0f / mRec.pdfSuccess; T = T * ((ld3(md.sigma_s) * mRec.transmittance) * r); }
                     nee = others; nref = mRec.p;                             // EDirectMediumRadiance
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                     }
                     };
                     applyTexture(bsdf);
+                    if (bsdf.type == MI_BSDF_T_MASK) { opac = ld3(bsdf.reflectance); masked = true; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf); }      // mask.cpp (shade.h)
                     if (WRAP && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record (shade.h)
                         float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
                         if (inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, o + d * hr.x, huvx, huvy, dpdu, dpdv);
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                             v3 wiQ = h.wi, woQ = wo; bool rejected = false;
                             if (WRAP && bumped) { wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0; }      // bumpmap.cpp:165-180
                             x = (!rejected && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) ? mxEval<true, WRAP>(sc, tb, bsdf, wiQ, woQ) : V(0, 0, 0);
+                            if (masked) x = x * opac;                            // mask.cpp:117-118
                             if (pm) m2 = targetMedium(pm, h.ng, dr.d);      // scene.cpp:920-921
                             onSurface = 1u << 24;
                         }
@@ -183,12 +185,19 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
                 float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
                 auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };
                 if (bsdf.type == MI_BSDF_T_THINDIELECTRIC) bsdf.flags |= MI_THIN_SIGNED_COS;      // the pdf-less ThinDielectric::sample overload this integrator calls (pt_device.h)
-                v3 bw;
+                v3 bw; bool passThrough = false; float invProb = 1.0f;      // mask.cpp:152-172, the overload WITHOUT a pdf: sample.x *= 1 / prob, result * opacity * (1 / prob)
+                if (masked) { const float prob = luminance3(opac); if (sx < prob) { invProb = 1.0f / prob; sx *= invProb; } else passThrough = true; }
+                if (passThrough) {
+                    const float p = 1 - luminance3(opac);
+                    woL = V(-h.wi.x, -h.wi.y, -h.wi.z); bEta = 1.0f; bPdf = p; sampledDelta = true; sampledNull = true;
+                    bw = V((1.0f - opac.x) / p, (1.0f - opac.y) / p, (1.0f - opac.z) / p);
+                } else
                 if (WRAP && bumped) {                                        // bumpmap.cpp:196-216
                     const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
                     bw = mxSample<true, WRAP>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
                     if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
                 } else bw = mxSample<true, WRAP>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                if (masked && !passThrough) bw = V(bw.x * opac.x * invProb, bw.y * opac.y * invProb, bw.z * opac.z * invProb);
                 if (isZero(bw)) { pathLen += (unsigned) depth; break; }
                 // which radiance types the next iteration gathers (volpath_simple.cpp:236-257)
                 const bool rtOthers = (depth + 1 < rc.max_depth || rc.max_depth < 0) && others; bool rtEmitted = false; bool nullChain = (fl & VOL_NULLCHAIN) != 0;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
-            tr = tr * materialNullEval(loadMaterial(tb, material), -dot(d, n));      // its.geoFrame = Frame(n): cosTheta(wi) = -dot(d, n)
+            tr = tr * surfaceNullEval(sc, tb, loadMaterial(tb, material), o, d, t, prim, u, v, inst, -dot(d, n), true);      // its.geoFrame = Frame(n): cosTheta(wi) = -dot(d, n)
             const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;   // `null`: bsdf->eval(bRec, EDiscrete) with typeMask = ENull is 1 (null.cpp:48-50)
             if (pm) {
                 if (medium != targetMedium(pm, n, -d)) { blocked = true; break; }      // medium inconsistency (scene.cpp:689-692)

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                         const v3 p = o + d * hr.x;                              // ray.o = ray(its->t)
                         wantSearch = true;
                         seO = make_float4(p.x, p.y, p.z, __uint_as_float((uint32_t) (m2 + 1) | (((uint32_t) maxInteractions & 0xFFFFu) << 8) | (1u << 26) | ((fl & VM_FACING) ? (1u << 27) : 0u) | ((fl & VM_DELTA) ? (1u << 28) : 0u)));
-                        const v3 segN = segT * materialNullEval(hm, -dot(d, h.ns));      // wo = shFrame.toLocal(ray.d): cosTheta(wi) = -dot(d, ns) (volpath.cpp:399-402)
+                        const v3 segN = segT * surfaceNullEval(sc, tb, hm, o, d, hr.x, prim, hr.y, hr.z, inst, -dot(d, h.ns), false);      // wo = shFrame.toLocal(ray.d): cosTheta(wi) = -dot(d, ns) (volpath.cpp:399-402)
                         seD = make_float4(d.x, d.y, d.z, __uint_as_float(pid)); seC = make_float4(segN.x, segN.y, segN.z, prevPdf);
                         seT = make_float4(T.x, T.y, T.z, 0.0f); seX = make_float4(o.x, o.y, o.z, prevCos);     // dRec.ref = the spawning vertex (+ the cosine a `constant` environment's density needs)
                     }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     }
                 }
                 const int interactions = rc.max_depth - depth - 1;
-                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); MaterialD bsdf; uint32_t pm = 0; bool bumped = false; v3 bps = V(0, 0, 0), bpt = V(0, 0, 0), bpn = V(0, 0, 0);
+                bool nee = false; v3 nref = V(0, 0, 0), nrefN = V(0, 0, 0); MaterialD bsdf; uint32_t pm = 0; bool bumped = false, masked = false; v3 bps = V(0, 0, 0), bpt = V(0, 0, 0), bpn = V(0, 0, 0), opac = V(1, 1, 1);
                 if (mediumEvent) {
                     if (depth >= rc.max_depth && rc.max_depth != -1) { pathLen += (unsigned) depth; break; }      // :112-113
                     { const float r = 1.0f / mRec.pdfSuccess; T = T * ((ld3(md.sigma_s) * mRec.transmittance) * r); }
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     }
                     };
                     applyTexture(bsdf);
+                    if (bsdf.type == MI_BSDF_T_MASK) { opac = ld3(bsdf.reflectance); masked = true; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf); }      // mask.cpp (shade.h)
                     if (WRAP && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record (shade.h)
                         float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
                         if (inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, o + d * hr.x, huvx, huvy, dpdu, dpdv);
@@ -206,9 +207,12 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                             const v3 wo = toLocal(h, dr.d);
                             v3 wiQ = h.wi, woQ = wo; bool rejected = false;
                             if (WRAP && bumped) { wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0; }      // bumpmap.cpp:165-180
-                            const v3 bv = rejected ? V(0, 0, 0) : mxEval<true, WRAP>(sc, tb, bsdf, wiQ, woQ);
+                            v3 bv = rejected ? V(0, 0, 0) : mxEval<true, WRAP>(sc, tb, bsdf, wiQ, woQ);
+                            if (masked) bv = bv * opac;                           // mask.cpp:117-118
                             const bool ok = !isZero(bv) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0);
-                            x = ok ? bv : V(0, 0, 0); w = ok ? miWeight(dr.pdf, dr.delta ? 0.0f : mxPdf<true, WRAP>(sc, tb, bsdf, wiQ, woQ)) : 0.0f;
+                            float bp = 0.0f;
+                            if (ok && !dr.delta) { bp = mxPdf<true, WRAP>(sc, tb, bsdf, wiQ, woQ); if (masked) bp *= luminance3(opac); }      // mask.cpp:141-146
+                            x = ok ? bv : V(0, 0, 0); w = ok ? miWeight(dr.pdf, bp) : 0.0f;
                             if (pm) m2 = targetMedium(pm, h.ng, dr.d);
                             onSurface = 1u << 24;
                         }
@@ -232,12 +236,19 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                 float bPdf = 0, bEta = 1; v3 woL = V(0, 0, 0); bool sampledDelta, sampledNull;
                 float sx, sy; next2D(ss, rc.sampler, m32, sx, sy);
                 auto drawExtra = [&]() { return next1D(ss, rc.sampler, m32); };
-                v3 bw;
+                v3 bw; bool passThrough = false;                            // mask.cpp:174-214 (shade.h)
+                if (masked) { const float prob = luminance3(opac); if (sx < prob) sx /= prob; else passThrough = true; }
+                if (passThrough) {
+                    const float p = 1 - luminance3(opac);
+                    woL = V(-h.wi.x, -h.wi.y, -h.wi.z); bEta = 1.0f; bPdf = p; sampledDelta = true; sampledNull = true;
+                    bw = V((1.0f - opac.x) / p, (1.0f - opac.y) / p, (1.0f - opac.z) / p);
+                } else
                 if (WRAP && bumped) {                                        // bumpmap.cpp:218-240
                     const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
                     bw = mxSample<true, WRAP>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
                     if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
                 } else bw = mxSample<true, WRAP>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                if (masked && !passThrough) { const float prob = luminance3(opac); bw = V(bw.x * opac.x / prob, bw.y * opac.y / prob, bw.z * opac.z / prob); bPdf *= prob; }
                 if (isZero(bw)) { pathLen += (unsigned) depth; break; }
                 const v3 wo = toWorld(h, woL);
                 if (dot(h.ng, wo) * woL.z <= 0 && rc.strict_normals) { pathLen += (unsigned) depth; break; }
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                 if (isZero(tr)) { surface = false; break; }
                 const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
                 if (pm) medium = targetMedium(pm, h.ng, d);
-                tr = tr * materialNullEval(hm, -dot(d, h.ns));
+                tr = tr * surfaceNullEval(sc, tb, hm, o, d, t, prim, u, v, inst, -dot(d, h.ns), false);
                 o = o + d * t;
                 if (++interactions > 100) { surface = false; break; }
             }
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
-            tr = tr * materialNullEval(loadMaterial(tb, material), -dot(d, nn));
+            tr = tr * surfaceNullEval(sc, tb, loadMaterial(tb, material), o, d, t, prim, u, v, inst, -dot(d, nn), true);
             const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
             if (pm) { if (medium != targetMedium(pm, nn, -d)) { blocked = true; break; } medium = targetMedium(pm, nn, d); }
             if (++interactions > 100) break;

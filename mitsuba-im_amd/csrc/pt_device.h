@@ -1640,12 +1640,29 @@ DEV v3 phaseSample(const MediumD &m, v3 wi, float sx, float sy) {
 }
 // bsdf->eval(bRec, EDiscrete) with typeMask = ENull for a straight pass-through (scene.cpp:679-685, volpath.cpp:399-402): `null` -> 1, `thindielectric` -> its transmittance
 // with the internal bounces summed (thindielectric.cpp:155-178); cosWi = Frame::cosTheta(bRec.wi)
-DEV bool materialHasNull(uint32_t type) { return type == MI_BSDF_T_NULL || type == MI_BSDF_T_THINDIELECTRIC; }
+DEV bool materialHasNull(uint32_t type) { return type == MI_BSDF_T_NULL || type == MI_BSDF_T_THINDIELECTRIC || type == MI_BSDF_T_MASK; }      // mask.cpp:107-108: a mask always has an ENull component
 DEV v3 materialNullEval(const MaterialD &m, float cosWi) {
     if (m.type == MI_BSDF_T_NULL) return V(1, 1, 1);
     float ct, R = fresnelDielectricExt(fabsf(cosWi), ct, m.eta[0]), T = 1 - R;
     if (R < 1) R += T * T * R / (1 - R * R);
     return ld3(m.reflectance) * (1 - R);
+}
+// the same at a hit: a `mask` answers 1 - opacity (mask.cpp:120-121), its opacity texture looked up at the hit's uv without differentials (level 0 of a bitmap).  walk:
+// the hit comes from ShapeKDTree::rayIntersect(ray, t, shape, n, uv), which gives a scene-level triangle mesh WITHOUT texture coordinates uv = (0, 0)
+// (skdtree.cpp:182-184), not the barycentrics
+template <bool L> DEV v3 surfaceNullEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 o, v3 d, float t, uint32_t prim, float u, float v, int inst, float cosWi, bool walk) {
+    if (m.type != MI_BSDF_T_MASK) return materialNullEval(m, cosWi);
+    float uvx = 0, uvy = 0;
+    if (inst >= 0) { Hit hh; fillHitInstanced(sc, tb, sc.instances[inst], o, d, t, prim, u, v, hh); uvx = hh.uvx; uvy = hh.uvy; }
+    else if (prim >= sc.n_tris) { v3 du, dv; analyticUV(sc.analytic[prim - sc.n_tris], u, v, o + d * t, uvx, uvy, du, dv); }
+    else { Hit hh; fillHit<L, true>(sc, tb, d, t, prim, u, v, hh); if (!walk || (hh.flags & 16u)) { uvx = hh.uvx; uvy = hh.uvy; } }
+    v3 op = ld3(m.reflectance); const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
+    if (tex) {
+        const TextureD &tx = sc.textures[tex - 1];
+        if (tx.type == 2u) { const float a = uvx * tx.uscale + tx.uoffset, b = uvy * tx.vscale + tx.voffset; op = tx.filter != 0u ? mipBilinear(sc, tx, 0, a, b) : mipBox(sc, tx, 0, a, b); }
+        else op = textureEval(tx, uvx, uvy);
+    }
+    return V(1.0f - op.x, 1.0f - op.y, 1.0f - op.z);
 }
 // Shape::isMediumTransition / Intersection::getTargetMedium (include/mitsuba/render/records.inl:77-86): index of the medium on the side `d` points to, -1 = none
 DEV int targetMedium(uint32_t pm, v3 n, v3 d) { return (int) (dot(d, n) > 0 ? (pm >> 16) : (pm & 0xFFFFu)) - 1; }

@@ -1218,10 +1218,13 @@ def glass_pane(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, 
     return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
 
 
-def masked_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, hide_emitters=False):
+def masked_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, hide_emitters=False, fog=None):
     """`mask` BSDFs (src/bsdfs/mask.cpp) in the open scene: a cut-out screen in front of the camera (checkerboard opacity 1 / 0 over a twosided diffuse), a
     tinted half-transparent sheet over `plastic` (coloured opacity: the pass-through lobe carries 1 - opacity), and a grid-masked rough conductor panel.
-    Passing through is an ENull event: with hideEmitters the sky stays hidden through the holes."""
+    Passing through is an ENull event: with hideEmitters the sky stays hidden through the holes.
+    fog = INTEGRATOR_VOLPATH_SIMPLE / INTEGRATOR_VOLPATH: the sensor sits in a thin medium that fills the scene; the masks' ENull lobes then attenuate the transmittance
+    walks of emitter sampling and the emitter search (1 - opacity at the hit's uv); the sheet -- a mesh WITHOUT texture coordinates -- gets the grid texture too: the
+    walks look it up at uv = (0, 0) (skdtree.cpp:182-184) while shading uses the barycentrics."""
     b = _Builder(); uvs = []
     def quad_uv(pts, uv=((0, 0), (1, 0), (1, 1), (0, 1))):
         b.quad(pts); uvs.extend(uv)
@@ -1248,8 +1251,12 @@ def masked_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6,
     for sh in b.shapes: sh["has_uv"] = 0
     for si in (2, 4): b.shapes[si]["has_uv"] = 1
     cam = look_at((0.5, 2.2, -5.0), (0.0, 0.9, 0.8), (0, 1, 0))
+    extra = {}
+    if fog:
+        b.bsdfs[sheet]["texture"] = 1
+        extra = dict(media=[make_medium((0.004, 0.004, 0.006), (0.04, 0.04, 0.035))], sensor_medium=0, integrator=fog)
     sc = finish_scene(b.verts, b.tris, b.shapes, b.bsdfs, b.emitters, cam, 50.0, 0.05, 100.0, width, height, spp, sampler, max_depth, rr_depth,
-                      seed=seed, hide_emitters=hide_emitters, uvs=uvs, name="masked_room", textures=tex)
+                      seed=seed, hide_emitters=hide_emitters, uvs=uvs, name="masked_room", textures=tex, **extra)
     return add_scene_emitters(sc, [constant_emitter((0.55, 0.7, 0.95)), directional_emitter((-0.4, -1.0, 0.35), (3.0, 2.6, 2.0))])
 
 

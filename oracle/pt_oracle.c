@@ -1363,7 +1363,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
     return w;
 }
 /* a hit's material with its textures evaluated and its wrappers resolved (below): mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDFs */
-typedef struct { mat_t inner; int masked; v3 opacity; float prob;
+typedef struct { mat_t inner; int masked; int pdfless; v3 opacity; float prob;
                  int bumped; v3 ps, pt, pn; const hit_t *its;           /* bumpmap / normalmap: the perturbed shading frame; the hit's own frame stays the query frame */
                  int n_mix; mat_t mix[4]; float w[4], p[4], cdf[5]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
@@ -1830,7 +1830,8 @@ static void perturb_frame(const orc_scene *s, const orc_material *m, const hit_t
     }
 }
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd) {
-    smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its;
+    smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.pdfless = s->d.integrator == 1;      /* volpath_simple calls BSDF::sample(bRec, sample), the overload without a pdf */
+     sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its;
     if (its && sm.inner.m.type != BSDF_BUMPMAP && sm.inner.m.type != BSDF_NORMALMAP) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     if (sm.inner.m.type == BSDF_MASK) {
         sm.masked = 1; sm.opacity = V(sm.inner.m.reflectance[0], sm.inner.m.reflectance[1], sm.inner.m.reflectance[2]); sm.prob = luminance(sm.opacity);
@@ -1920,10 +1921,12 @@ static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo) { v3 e = bp_eval(sm, wi, wo); 
 static float sm_pdf(const smat_t *sm, v3 wi, v3 wo) { float p = bp_pdf(sm, wi, wo); return sm->masked ? p * sm->prob : p; }
 static v3 sm_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
     if (!sm->masked) return bp_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
-    if (u < sm->prob) {                                                  /* mask.cpp:196-201 */
-        u /= sm->prob;
+    if (u < sm->prob) {                                                  /* mask.cpp:196-201; the pdf-less overload multiplies by 1 / prob instead (:164-167) */
+        const float invProb = 1.0f / sm->prob;
+        if (sm->pdfless) u *= invProb; else u /= sm->prob;
         v3 w = bp_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
-        v3 r = V(w.x * sm->opacity.x / sm->prob, w.y * sm->opacity.y / sm->prob, w.z * sm->opacity.z / sm->prob);
+        v3 r = sm->pdfless ? V(w.x * sm->opacity.x * invProb, w.y * sm->opacity.y * invProb, w.z * sm->opacity.z * invProb)
+                           : V(w.x * sm->opacity.x / sm->prob, w.y * sm->opacity.y / sm->prob, w.z * sm->opacity.z / sm->prob);
         *pdf *= sm->prob; return r;
     }
     *wo = neg(wi); *eta = 1.0f; *delta = 2; *pdf = 1 - sm->prob;       /* :202-208 */
@@ -2111,12 +2114,22 @@ static int ray_intersect_n(const orc_scene *s, v3 o, v3 d, float rmint, float rm
 }
 /* bsdf->eval(bRec, EDiscrete) with typeMask = ENull for a straight pass-through (wo = -wi): `null` -> 1 (null.cpp:48-50), `thindielectric` -> its transmittance with
  * the internal bounces summed (thindielectric.cpp:155-178); cosWi = Frame::cosTheta(bRec.wi).  has_null: the BSDF's type carries ENull at all */
-static int material_has_null(const orc_material *m) { return m->type == BSDF_NULL || m->type == BSDF_THINDIELECTRIC; }
+static int material_has_null(const orc_material *m) { return m->type == BSDF_NULL || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_MASK; }      /* mask.cpp:107-108: always an ENull component */
 static v3 material_null_eval(const orc_material *m, float cosWi) {
     if (m->type == BSDF_NULL) return V(1, 1, 1);
     float ct, R = fresnel_dielectric_ext(fabsf(cosWi), &ct, m->eta[0]), T = 1 - R;
     if (R < 1) R += T * T * R / (1 - R * R);
     return scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), 1 - R);
+}
+/* the same at a hit: a `mask` answers 1 - opacity (mask.cpp:120-121), its opacity texture looked up at the hit's uv without differentials.  walk: the hit comes from
+ * ShapeKDTree::rayIntersect(ray, t, shape, n, uv), which gives a scene-level triangle mesh WITHOUT texture coordinates uv = (0, 0) (skdtree.cpp:182-184), not the barycentrics */
+static v3 surface_null_eval(const orc_scene *s, const hit_t *its, float cosWi, int walk) {
+    const mat_t *mt = &s->materials[its->material];
+    if (mt->m.type != BSDF_MASK) return material_null_eval(&mt->m, cosWi);
+    mat_t tmp = *mt; hit_t h = *its;
+    if (walk && its->instance < 0 && its->prim < s->d.n_tris && !(s->uv && (s->shapes[its->shape].flags & 2u))) { h.uvx = 0; h.uvy = 0; }
+    apply_texture(s, &tmp, &h, NULL, 0, V(0, 0, 0), NULL, NULL);
+    return V(1.0f - tmp.m.reflectance[0], 1.0f - tmp.m.reflectance[1], 1.0f - tmp.m.reflectance[2]);
 }
 /* Scene::evalTransmittance (scene.cpp:650-713): walk from p1 to p2 through index-matched (`null`) boundaries, attenuating by the media in between */
 static v3 eval_transmittance(const orc_scene *s, v3 p1, int p1OnSurface, v3 p2, int p2OnSurface, int medium, int *interactions, uint64_t *shadow_rays) {
@@ -2130,7 +2143,7 @@ static v3 eval_transmittance(const orc_scene *s, v3 p1, int p1OnSurface, v3 p2, 
         if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, minf(its.t, remaining)));
         if (!surface || is_zero(transmittance)) break;
         /* its.geoFrame = Frame(n); wo = toLocal(ray.d); bRec(its, -wo, wo) with typeMask = ENull (scene.cpp:679-685): cosTheta(wi) = -dot(d, n) */
-        transmittance = mul(transmittance, material_null_eval(&s->materials[its.material].m, -dot(d, its.ng_raw)));
+        transmittance = mul(transmittance, surface_null_eval(s, &its, -dot(d, its.ng_raw), 1));
         if (is_medium_transition(s, its.shape)) {
             if (medium != target_medium(s, its.shape, its.ng_raw, neg(d))) return V(0, 0, 0);        /* medium inconsistency */
             medium = target_medium(s, its.shape, its.ng_raw, d);
@@ -2268,7 +2281,7 @@ static void look_for_emitter(const orc_scene *s, int medium, int maxInteractions
         if (is_zero(transmittance)) return;
         if (is_medium_transition(s, its->shape)) medium = target_medium(s, its->shape, its->ng, d);
         /* wo = its->shFrame.toLocal(ray.d); bRec(*its, -wo, wo), typeMask = ENull (volpath.cpp:399-402): cosTheta(wi) = -dot(d, ns) */
-        transmittance = mul(transmittance, material_null_eval(&s->materials[its->material].m, -dot(d, its->ns)));
+        transmittance = mul(transmittance, surface_null_eval(s, its, -dot(d, its->ns), 0));
         o = add(o, scale(d, its->t)); mint = EPSILON; its = &its2;
         if (++interactions > 100) return;
     }
@@ -2504,7 +2517,7 @@ static void *dup(const void *p, size_t n) { if (!p) return NULL; void *q = mallo
 orc_scene *orc_scene_create(const orc_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_emitters; ++i) if (d->emitters[i].type > 5) return NULL;      /* e.g. the reference's compound `sunsky`: not restated */
     if (d->integrator != 0) for (uint32_t i = 0; i < d->n_materials; ++i) {                      /* volumetric walks: ENull lobes of plain `null` / `thindielectric` records only (material_has_null) */
-        const orc_material *m = &d->materials[i]; int bad = m->type == BSDF_MASK;
+        const orc_material *m = &d->materials[i]; int bad = 0;
         #define ORC_NULL_LOBE(j) ((j) < d->n_materials && (d->materials[j].type == BSDF_NULL || d->materials[j].type == BSDF_THINDIELECTRIC))
         if (m->type == BSDF_BUMPMAP || m->type == BSDF_NORMALMAP) bad |= ORC_NULL_LOBE(m->distr);
         if (m->type == BSDF_MIXTURE) for (uint32_t c = 0; c < m->distr && c < 4; ++c) bad |= ORC_NULL_LOBE((uint32_t) (c < 3 ? m->reflectance[c] : m->eta[0]));

@@ -992,11 +992,13 @@ def test_volpath_simple(mi, oracle, golden_scenes, name):
     assert (bits(ro.read_film(0)[..., :3]) == bits(film[..., :3])).all()                            # ... and the radiance does not notice
 
 
-@pytest.mark.parametrize("name", ["fog_layered", "fog_layered_mis"])
+@pytest.mark.parametrize("name", ["fog_layered", "fog_layered_mis", "fog_masked", "fog_masked_mis"])
 def test_volumetric_bsdf_adapters(mi, oracle, golden_scenes, name):
     """mixturebsdf / bumpmap / normalmap (and bumpmap(mixture)) inside volpath_simple / volpath: the layered room filled with fog, a `null` sphere of haze over the
     mound (WRAP variants of k_shade_vol / k_shade_volmis).  Tolerances as test_bsdf_adapters (the rough conductors' libm calls); ray counters equal the oracle's.
-    Adapters over a `null` / `thindielectric` are refused in volumetric renders (their ENull lobe would have to be evaluated inside the transmittance walks)."""
+    Adapters over a `null` / `thindielectric` are refused in volumetric renders (their ENull lobe would have to be evaluated inside the transmittance walks).
+    fog_masked*: `mask` in the fogged open scene -- its ENull lobe attenuates the transmittance walks and the emitter search by 1 - opacity, the opacity texture looked
+    up at the walk's uv ((0, 0) on a mesh without texture coordinates, skdtree.cpp:182-184); volpath_simple samples it through the pdf-less overload (mask.cpp:152-172)."""
     sc = golden_scenes[name]; gs = mi.Scene(sc); orc = oracle.Oracle(sc); r = mi.Render(gs)
     gd = np.load(os.path.join(GOLDEN, name + "_samples.npz")); st_ = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
     rng = np.random.default_rng(29); n = 20000
@@ -1046,9 +1048,6 @@ def test_volpath_simple_refusals(mi, golden_scenes):
     """what the volumetric stages are not built for is refused by name, never approximated"""
     S = mi.scenes
     sc = golden_scenes["open_constant"]
-    gs = mi.Scene(golden_scenes["textured_shapes"])
-    with pytest.raises(RuntimeError, match="with mask"):
-        mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE)
     with pytest.raises(RuntimeError, match="integrators path"):
         mi.Render(mi.Scene(golden_scenes["cornell_small"]), integrator=7)
     # a scene without media through the volumetric loop = the same estimator without MIS: converges to the same image (loose check on the mean)

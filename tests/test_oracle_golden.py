@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_layered", "fog_layered_mis"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_layered", "fog_layered_mis", "fog_masked", "fog_masked_mis"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -83,7 +83,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
     elif name.startswith("textured_plastics") or name == "textured_shapes":
         # textures on plastic / roughplastic.diffuseReflectance and difftrans.transmittance: lobe weights from the texture's average, local value in the lobes
         assert same_path.all() and same_vals.all() and (err < 1e-4).mean() > 0.998 and err.max() < 1e-3 and np.median(err) < 1e-6
-    elif name.startswith("fog_layered"):
+    elif name.startswith("fog_layered") or name.startswith("fog_masked"):
         # the adapters inside volpath_simple / volpath: one of the 2048 paths of the shipped (-ffast-math) build forks at a distance-sampling decision; its strict
         # build takes the oracle's branch on every sample (test_li_samples_vs_strict_reference)
         assert same_path.mean() > 0.999 and (err < 1e-4).mean() > 0.995 and err.max() < 5e-3 and np.median(err) < 1e-6
@@ -133,7 +133,7 @@ STRICT_BIT_EXACT = ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_
 STRICT_OTHERS = ["closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep", "cbox_materials",
                  "cbox_materials_strict_indep", "instanced_garden", "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "sky_view", "sky_view_indep", "veach_microfacets",
                  "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room",
-                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_sky", "fog_sky_simple", "fog_layered", "fog_layered_mis"]      # fog_sky*: the sky seen directly goes through the EWA-filtered lookup like sky_view
+                 "masked_room_hide_indep", "textured_shapes", "cbox_roughplastic_phong", "cbox_roughplastic_allnormals", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_sky", "fog_sky_simple", "fog_layered", "fog_layered_mis", "fog_masked", "fog_masked_mis"]      # fog_sky*: the sky seen directly goes through the EWA-filtered lookup like sky_view
 
 
 @pytest.mark.parametrize("name", STRICT_BIT_EXACT + STRICT_OTHERS)
@@ -255,7 +255,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
                                   "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong",
-                                  "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_layered", "fog_layered_mis"])
+                                  "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_layered", "fog_layered_mis", "fog_masked", "fog_masked_mis"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
@@ -276,7 +276,14 @@ def test_film_vs_reference(oracle, golden_scenes, name):
             m = re.search(label + r"\s*:\s*([0-9.]+)\s*([KMG]?)", stats); mult = {"": 1, "K": 1e3, "M": 1e6, "G": 1e9}[m.group(2)]
             return float(m.group(1)) * mult
         assert abs(num("Normal rays traced") - counters[0]) / counters[0] < 2e-3
-        assert abs(num("Shadow rays traced") - counters[1]) / counters[1] < 2e-3
+        if name.startswith("fog_masked"):
+            # an OPEN scene filled with fog under a `directional` light: scattering events beyond the scene's bounding sphere make DirectionalEmitter::sampleDirect
+            # return early (directional.cpp:165-170) WITHOUT touching dRec.pdf; Scene::sampleAttenuatedEmitterDirect then tests an uninitialised value
+            # (scene.cpp:896) and walks towards a stale point with a zero value -- radiance unaffected (samples and film above), extra "shadow rays" counted
+            # (+13 % here, none without the directional light).  The oracle follows the documented behaviour (pdf = 0: no walk).
+            assert 0 <= (num("Shadow rays traced") - counters[1]) / counters[1] < 0.25
+        else:
+            assert abs(num("Shadow rays traced") - counters[1]) / counters[1] < 2e-3
 
 
 def test_fresnel_diffuse_reflectance_table(mi):
