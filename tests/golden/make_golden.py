@@ -127,6 +127,7 @@ def golden_scenes():
         # `mask` inside volumetric renders: its ENull lobe (1 - opacity, textured) in the transmittance walks and the emitter search; volpath_simple goes through the pdf-less sample overload
         "fog_masked": scenes.masked_room(width=96, height=64, spp=16, fog=scenes.INTEGRATOR_VOLPATH_SIMPLE),
         "fog_masked_mis": scenes.masked_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=31, hide_emitters=True),
+        "fog_layered_procedural": scenes.layered_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, procedural_maps=True),      # (for the drop-in test: no bitmap textures)
         "fog_layered_mis": scenes.layered_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=23, strict_normals=True),
         "fog_mis_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5, integrator=scenes.INTEGRATOR_VOLPATH),
     }
@@ -233,7 +234,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
+        if name in ("fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky", "fog_masked", "fog_masked_mis", "fog_pane_mis", "fog_layered_procedural", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", {1: "volpath_simple", 2: "volpath"}.get(sc.get("integrator", 0), "path"), -1, base + "_resp")

@@ -80,10 +80,11 @@ def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
-@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky"])
+@pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky", "fog_pane_mis", "fog_masked", "fog_masked_mis", "fog_layered_procedural"])
 def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
     """`volpath_simple` / `volpath` swapped for `path_hip` with integrator = "volpath_simple" / "volpath", same responsive driver: live HomogeneousMedium objects (sampling parameters read from their
     serialised form), IsotropicPhaseFunction / HGPhaseFunction, Null BSDFs, interior / exterior media of meshes and of an analytic sphere, the sensor's medium.
+    fog_pane_mis / fog_masked* / fog_layered_procedural: live ThinDielectric, Mask (textured opacity) and MixtureBSDF / BumpMap / NormalMap objects inside the volumetric loops.
     Alpha (EOpacity, records.inl:124-137): 1 on an opaque hit, 1 - the transmittance of what lies behind a medium-transition shape, what the sensor's medium removes over two scene radii on a miss."""
     sc = golden_scenes[name]
     path = str(tmp_path / "s.miscene"); mi.scenes.save_scene(sc, path); out = str(tmp_path / "hip")
@@ -91,7 +92,8 @@ def test_plugin_drop_in_volumetric(mi, golden_scenes, tmp_path, name):
     got = np.load(out + "_target.npy"); ref = np.load(os.path.join(GOLDEN, name + "_responsive.npz"))["target"]
     g, r = got[1:-2, 1:-2, :3], ref[1:-2, 1:-2, :3]
     rel = np.abs(g - r).max(2) / (np.abs(r).max(2) + 1e-6)
-    assert (rel < (1e-3 if name == "fog_sky" else 1e-4)).mean() > 0.99 and np.linalg.norm(g - r) / np.linalg.norm(r) < (1e-2 if name == "fog_sky" else 1e-3)      # fog_sky: an environment map (device atan2 / acos, -ffast-math forks as in the other envmap drop-ins)
+    loose = name == "fog_sky" or name.startswith("fog_masked") or name.startswith("fog_layered")      # rough conductors / the environment map under the shipped build's -ffast-math: a few forked paths, as in the other drop-in tests
+    assert (rel < (1e-3 if loose else 1e-4)).mean() > 0.99 and np.linalg.norm(g - r) / np.linalg.norm(r) < (1e-2 if loose else 1e-3)      # fog_sky: an environment map (device atan2 / acos, -ffast-math forks as in the other envmap drop-ins)
     assert (np.abs(got[1:-2, 1:-2, 3] - ref[1:-2, 1:-2, 3]) < 1e-3 * sc.spp).mean() > 0.99      # alpha incl. the transmittance behind medium-transition shapes (records.inl:124-137)
 
 

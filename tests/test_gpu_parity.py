@@ -992,7 +992,7 @@ def test_volpath_simple(mi, oracle, golden_scenes, name):
     assert (bits(ro.read_film(0)[..., :3]) == bits(film[..., :3])).all()                            # ... and the radiance does not notice
 
 
-@pytest.mark.parametrize("name", ["fog_layered", "fog_layered_mis", "fog_masked", "fog_masked_mis"])
+@pytest.mark.parametrize("name", ["fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])
 def test_volumetric_bsdf_adapters(mi, oracle, golden_scenes, name):
     """mixturebsdf / bumpmap / normalmap (and bumpmap(mixture)) inside volpath_simple / volpath: the layered room filled with fog, a `null` sphere of haze over the
     mound (WRAP variants of k_shade_vol / k_shade_volmis).  Tolerances as test_bsdf_adapters (the rough conductors' libm calls); ray counters equal the oracle's.
