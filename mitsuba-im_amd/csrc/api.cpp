@@ -515,13 +515,15 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for
-        // an adapter over a `null` / `thindielectric` has an ENull lobe the transmittance walks would have to evaluate through the adapter (plain records and `mask` are)
+        // a bumpmap / normalmap over a `null` / `thindielectric` has an ENull lobe the transmittance walks would have to evaluate in a perturbed frame (the reference reads an unset shading frame there); plain records, `mask` and `mixturebsdf` are seen through (surfaceNullEval)
         auto nullLobe = [&](uint32_t i) { return i < s->h.materials.size() && (s->h.materials[i].type == MI_BSDF_NULL || s->h.materials[i].type == MI_BSDF_THINDIELECTRIC); };
         for (const mi_material &m : s->h.materials) {
             bool bad = false;
-            if (m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) bad = nullLobe(m.distr);
-            if (m.type == MI_BSDF_MIXTURE) for (uint32_t c = 0; c < m.distr && c < 4; ++c) bad |= nullLobe((uint32_t) (c < 3 ? m.reflectance[c] : m.eta[0]));
-            if (bad) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with a null / thindielectric BSDF inside a mixturebsdf / bumpmap / normalmap is not implemented");
+            if ((m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) && m.distr < s->h.materials.size()) {
+                const mi_material &nm = s->h.materials[m.distr]; bad = nullLobe(m.distr);
+                if (nm.type == MI_BSDF_MIXTURE) for (uint32_t c = 0; c < nm.distr && c < 4; ++c) bad |= nullLobe((uint32_t) (c < 3 ? nm.reflectance[c] : nm.eta[0]));
+            }
+            if (bad) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with a null / thindielectric BSDF inside a bumpmap / normalmap is not implemented");
         }
         if (s->h.d.packet_n) return fail(MI_ERR_INVALID, "mi_render_create: the volumetric integrators need the tree traversal (scenes with media always have it; set MI355PT_NO_PACKET=1 for a scene without media)");
         if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth beyond 250");

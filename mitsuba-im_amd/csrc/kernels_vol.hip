@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     n = fn;
                 }
-                if (interactions == maxInteractions || !materialHasNull(loadMaterial(tb, material).type)) { blocked = true; break; }   // an occluder: zero transmittance
+                if (interactions == maxInteractions || !surfaceHasNull(tb, loadMaterial(tb, material))) { blocked = true; break; }   // an occluder: zero transmittance
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;

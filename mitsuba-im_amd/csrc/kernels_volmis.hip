@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                     const v3 segT = medium >= 0 ? mediumTransmittance(md, 0.0f, tHit) : V(1, 1, 1);
                     fill();
                     const int maxInteractions = rc.max_depth - depth;           // m_maxDepth - rRec.depth - 1 at the spawning vertex (depth has advanced by one since)
-                    const MaterialD hm = loadMaterial(tb, h.material); const bool isNull = materialHasNull(hm.type);
+                    const MaterialD hm = loadMaterial(tb, h.material); const bool isNull = surfaceHasNull(tb, hm);
                     if (h.emitter >= 0) {                                        // an emitter (also one behind a `null` BSDF, :388-390)
                         const v3 value = segT * emitterEval(tb, h.emitter, h.ns, -d);
                         if (!isZero(value)) {
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                 else if (prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], o, d, t, u, v, h);
                 else fillHit<false, true>(sc, tb, d, t, prim, u, v, h);
                 const MaterialD hm = loadMaterial(tb, h.material);
-                if (interactions == maxInteractions || !materialHasNull(hm.type) || h.emitter >= 0) break;
+                if (interactions == maxInteractions || !surfaceHasNull(tb, hm) || h.emitter >= 0) break;
                 if (isZero(tr)) { surface = false; break; }
                 const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
                 if (pm) medium = targetMedium(pm, h.ng, d);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     nn = fn;
                 }
-                if (interactions == maxInteractions || !materialHasNull(loadMaterial(tb, material).type)) { blocked = true; break; }
+                if (interactions == maxInteractions || !surfaceHasNull(tb, loadMaterial(tb, material))) { blocked = true; break; }
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;

@@ -1650,7 +1650,21 @@ DEV v3 materialNullEval(const MaterialD &m, float cosWi) {
 // the same at a hit: a `mask` answers 1 - opacity (mask.cpp:120-121), its opacity texture looked up at the hit's uv without differentials (level 0 of a bitmap).  walk:
 // the hit comes from ShapeKDTree::rayIntersect(ray, t, shape, n, uv), which gives a scene-level triangle mesh WITHOUT texture coordinates uv = (0, 0)
 // (skdtree.cpp:182-184), not the barycentrics
+// ... and of a record that may be a mixturebsdf: its children's components (mixturebsdf.cpp:150-166)
+template <bool L> DEV bool surfaceHasNull(const Tabs<L> &tb, const MaterialD &m) {
+    if (m.type != MI_BSDF_T_MIXTURE) return materialHasNull(m.type);
+    const MixD x = mixOf(m); bool r = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < x.n) { const uint32_t ct = loadMaterial(tb, (int) mixChild(x, i)).type; r |= ct == MI_BSDF_T_NULL || ct == MI_BSDF_T_THINDIELECTRIC; }
+    return r;
+}
 template <bool L> DEV v3 surfaceNullEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 o, v3 d, float t, uint32_t prim, float u, float v, int inst, float cosWi, bool walk) {
+    if (m.type == MI_BSDF_T_MIXTURE) {           // MixtureBSDF::eval (mixturebsdf.cpp:176-183) under EDiscrete / typeMask = ENull: weight x the pass-through value of every child that has an ENull lobe
+        const MixD x = mixOf(m); v3 r = V(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < x.n) { const MaterialD c = loadMaterial(tb, (int) mixChild(x, i)); if (c.type == MI_BSDF_T_NULL || c.type == MI_BSDF_T_THINDIELECTRIC) r = r + materialNullEval(c, cosWi) * mixWeight(x, i); }
+        return r;
+    }
     if (m.type != MI_BSDF_T_MASK) return materialNullEval(m, cosWi);
     float uvx = 0, uvy = 0;
     if (inst >= 0) { Hit hh; fillHitInstanced(sc, tb, sc.instances[inst], o, d, t, prim, u, v, hh); uvx = hh.uvx; uvy = hh.uvy; }

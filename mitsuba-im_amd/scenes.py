@@ -542,7 +542,7 @@ def _closed_box(b, top, y0, y1):
     b.quad([(p[0], y0, p[1]) for p in reversed(P)])
 
 
-def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, global_fog=False, strict_normals=False, hide_emitters=False, integrator=INTEGRATOR_VOLPATH_SIMPLE, pane=False):
+def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, global_fog=False, strict_normals=False, hide_emitters=False, integrator=INTEGRATOR_VOLPATH_SIMPLE, pane=False, dusty=False):
     """Cornell room for the volumetric path tracer (volpath_simple): a smoke cube behind an index-matched (`null`) boundary (isotropic, `balance`
     sampling), a glass block filled with a forward-scattering medium (hg, `single`), a `null` sphere of thin haze (hg backwards, `manual`); with global_fog the
     sensor sits in a thin isotropic medium that fills the room (the shapes name it as their exterior medium)."""
@@ -566,6 +566,8 @@ def fog_box(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_
     if pane:        # a thin glass pane in front of the smoke cube: its transmission is an ENull lobe -- emitter sampling and the emitter search look THROUGH it (attenuated)
         thin = b.bsdf(kind=BSDF_THINDIELECTRIC, ior=1.5, reflectance=(0.9, 0.95, 1.0))
         p0, e1, e2 = np.array([40.3, 1.2, 40.7]), np.array([290.4, 0.37, -20.3]), np.array([0.53, 318.9, 0.21])      # (odd numbers: no Sobol sample lands exactly on the quad's diagonal, cf. closed_box)
+        if dusty:   # a dusty pane: mixturebsdf of the thin glass and a diffuse film -- the walks see weight x the glass' pass-through value (mixturebsdf.cpp:176-183)
+            dust = b.bsdf(reflectance=(0.5, 0.45, 0.4)); thin = b.bsdf(kind=BSDF_MIXTURE, nested=[thin, dust], weights=[0.7, 0.3])
         b.begin(); b.quad([p0, p0 + e1, p0 + e1 + e2, p0 + e2]); b.end(thin)
     b.add_analytic(SHAPE_SPHERE, translate(150.0, 390.0, 300.0), null, radius=70.0, interior=2, exterior=ext)
     cam = look_at((278, 273, -800), (278, 273, -799), (0, 1, 0))

@@ -1847,6 +1847,7 @@ static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_
         const orc_material *mx = &sm.inner.m; sm.n_mix = (int) mx->distr; float total = 0;
         for (int i = 0; i < sm.n_mix; ++i) {
             sm.mix[i] = s->materials[(uint32_t) (i < 3 ? mx->reflectance[i] : mx->eta[0])]; sm.w[i] = i < 3 ? mx->k[i] : mx->specular[0];
+            sm.mix[i].m.flags &= ~THIN_SIGNED_COS;                        /* both MixtureBSDF::sample overloads call the child's sample WITH a pdf (mixturebsdf.cpp:217, :251) */
             total += sm.w[i];
         }
         if (total > 1) { float sc = 1.0f / total; for (int i = 0; i < sm.n_mix; ++i) sm.w[i] *= sc; }      /* ensureEnergyConservation (default true) */
@@ -2114,7 +2115,13 @@ static int ray_intersect_n(const orc_scene *s, v3 o, v3 d, float rmint, float rm
 }
 /* bsdf->eval(bRec, EDiscrete) with typeMask = ENull for a straight pass-through (wo = -wi): `null` -> 1 (null.cpp:48-50), `thindielectric` -> its transmittance with
  * the internal bounces summed (thindielectric.cpp:155-178); cosWi = Frame::cosTheta(bRec.wi).  has_null: the BSDF's type carries ENull at all */
-static int material_has_null(const orc_material *m) { return m->type == BSDF_NULL || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_MASK; }      /* mask.cpp:107-108: always an ENull component */
+static int leaf_has_null(const orc_material *m) { return m->type == BSDF_NULL || m->type == BSDF_THINDIELECTRIC; }
+#define MIX_CHILD(m, c) ((uint32_t) ((c) < 3 ? (m)->reflectance[c] : (m)->eta[0]))
+/* mask.cpp:107-108: always an ENull component; mixturebsdf.cpp:150-166: its children's components */
+static int surface_has_null(const orc_scene *s, const orc_material *m) {
+    if (m->type == BSDF_MIXTURE) { for (uint32_t c = 0; c < m->distr && c < 4; ++c) if (leaf_has_null(&s->materials[MIX_CHILD(m, c)].m)) return 1; return 0; }
+    return leaf_has_null(m) || m->type == BSDF_MASK;
+}
 static v3 material_null_eval(const orc_material *m, float cosWi) {
     if (m->type == BSDF_NULL) return V(1, 1, 1);
     float ct, R = fresnel_dielectric_ext(fabsf(cosWi), &ct, m->eta[0]), T = 1 - R;
@@ -2125,6 +2132,11 @@ static v3 material_null_eval(const orc_material *m, float cosWi) {
  * ShapeKDTree::rayIntersect(ray, t, shape, n, uv), which gives a scene-level triangle mesh WITHOUT texture coordinates uv = (0, 0) (skdtree.cpp:182-184), not the barycentrics */
 static v3 surface_null_eval(const orc_scene *s, const hit_t *its, float cosWi, int walk) {
     const mat_t *mt = &s->materials[its->material];
+    if (mt->m.type == BSDF_MIXTURE) {              /* MixtureBSDF::eval (mixturebsdf.cpp:171-183) under EDiscrete / typeMask = ENull: sum of weight x the children's pass-through values (0 for a child without an ENull lobe) */
+        const smat_t sm = resolve_material(s, (uint32_t) its->material, NULL, 0, V(0, 0, 0), NULL, NULL); v3 r = V(0, 0, 0);
+        for (int i = 0; i < sm.n_mix; ++i) if (leaf_has_null(&sm.mix[i].m)) r = add(r, scale(material_null_eval(&sm.mix[i].m, cosWi), sm.w[i])); else r = add(r, scale(V(0, 0, 0), sm.w[i]));
+        return r;
+    }
     if (mt->m.type != BSDF_MASK) return material_null_eval(&mt->m, cosWi);
     mat_t tmp = *mt; hit_t h = *its;
     if (walk && its->instance < 0 && its->prim < s->d.n_tris && !(s->uv && (s->shapes[its->shape].flags & 2u))) { h.uvx = 0; h.uvy = 0; }
@@ -2139,7 +2151,7 @@ static v3 eval_transmittance(const orc_scene *s, v3 p1, int p1OnSurface, v3 p2, 
     v3 transmittance = V(1, 1, 1); hit_t its; const int maxInteractions = *interactions; *interactions = 0;
     while (remaining > 0) {
         int surface = ray_intersect_n(s, o, d, mint, maxt, &its, shadow_rays);
-        if (surface && (*interactions == maxInteractions || !material_has_null(&s->materials[its.material].m))) return V(0, 0, 0);     /* !(bsdf->getType() & BSDF::ENull) */
+        if (surface && (*interactions == maxInteractions || !surface_has_null(s, &s->materials[its.material].m))) return V(0, 0, 0);     /* !(bsdf->getType() & BSDF::ENull) */
         if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, minf(its.t, remaining)));
         if (!surface || is_zero(transmittance)) break;
         /* its.geoFrame = Frame(n); wo = toLocal(ray.d); bRec(its, -wo, wo) with typeMask = ENull (scene.cpp:679-685): cosTheta(wi) = -dot(d, n) */
@@ -2276,7 +2288,7 @@ static void look_for_emitter(const orc_scene *s, int medium, int maxInteractions
         ++counters[0];
         surface = ray_intersect(s, o, d, mint, INFINITY, its, 0); if (!surface) its->t = INFINITY;
         if (medium >= 0) transmittance = mul(transmittance, medium_transmittance(&s->media[medium], 0, its->t));
-        if (surface && (interactions == maxInteractions || !material_has_null(&s->materials[its->material].m) || its->emitter >= 0)) break;
+        if (surface && (interactions == maxInteractions || !surface_has_null(s, &s->materials[its->material].m) || its->emitter >= 0)) break;
         if (!surface) break;
         if (is_zero(transmittance)) return;
         if (is_medium_transition(s, its->shape)) medium = target_medium(s, its->shape, its->ng, d);
@@ -2516,11 +2528,13 @@ static void *dup(const void *p, size_t n) { if (!p) return NULL; void *q = mallo
 
 orc_scene *orc_scene_create(const orc_scene_desc *d) {
     for (uint32_t i = 0; i < d->n_emitters; ++i) if (d->emitters[i].type > 5) return NULL;      /* e.g. the reference's compound `sunsky`: not restated */
-    if (d->integrator != 0) for (uint32_t i = 0; i < d->n_materials; ++i) {                      /* volumetric walks: ENull lobes of plain `null` / `thindielectric` records only (material_has_null) */
+    if (d->integrator != 0) for (uint32_t i = 0; i < d->n_materials; ++i) {                      /* volumetric walks see through plain records, masks and mixtures (surface_has_null), not through bumpmap / normalmap */
         const orc_material *m = &d->materials[i]; int bad = 0;
         #define ORC_NULL_LOBE(j) ((j) < d->n_materials && (d->materials[j].type == BSDF_NULL || d->materials[j].type == BSDF_THINDIELECTRIC))
-        if (m->type == BSDF_BUMPMAP || m->type == BSDF_NORMALMAP) bad |= ORC_NULL_LOBE(m->distr);
-        if (m->type == BSDF_MIXTURE) for (uint32_t c = 0; c < m->distr && c < 4; ++c) bad |= ORC_NULL_LOBE((uint32_t) (c < 3 ? m->reflectance[c] : m->eta[0]));
+        if ((m->type == BSDF_BUMPMAP || m->type == BSDF_NORMALMAP) && m->distr < d->n_materials) {
+            const orc_material *nm = &d->materials[m->distr]; bad |= ORC_NULL_LOBE(m->distr);
+            if (nm->type == BSDF_MIXTURE) for (uint32_t c = 0; c < nm->distr && c < 4; ++c) bad |= ORC_NULL_LOBE(MIX_CHILD(nm, c));
+        }
         #undef ORC_NULL_LOBE
         if (bad) return NULL;
     }

@@ -127,6 +127,8 @@ def golden_scenes():
         # `mask` inside volumetric renders: its ENull lobe (1 - opacity, textured) in the transmittance walks and the emitter search; volpath_simple goes through the pdf-less sample overload
         "fog_masked": scenes.masked_room(width=96, height=64, spp=16, fog=scenes.INTEGRATOR_VOLPATH_SIMPLE),
         "fog_masked_mis": scenes.masked_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=31, hide_emitters=True),
+        "fog_dusty": scenes.fog_box(width=96, height=96, spp=16, pane=True, dusty=True),
+        "fog_dusty_mis": scenes.fog_box(width=96, height=96, spp=8, pane=True, dusty=True, global_fog=True, integrator=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=41),
         "fog_layered_procedural": scenes.layered_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, procedural_maps=True),      # (for the drop-in test: no bitmap textures)
         "fog_layered_mis": scenes.layered_room(width=96, height=64, spp=8, fog=scenes.INTEGRATOR_VOLPATH, sampler=scenes.SAMPLER_INDEPENDENT, seed=23, strict_normals=True),
         "fog_mis_global_hide": scenes.fog_box(width=96, height=96, spp=8, global_fog=True, hide_emitters=True, strict_normals=True, max_depth=5, integrator=scenes.INTEGRATOR_VOLPATH),

@@ -42,7 +42,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
                                   "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
-                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])
+                                  "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis", "fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
     """Per-(pixel, sampleIndex) radiance through MIPathTracer::Li.  Integer sampler math is bit-exact (every value handed to the
     integrator equals the reference's); radiance is tolerance-pinned because the reference is built with -ffast-math."""
@@ -129,7 +129,7 @@ def test_li_samples_vs_reference(oracle, golden_scenes, name):
 
 STRICT_BIT_EXACT = ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide", "cornell_small_tent", "cornell_small_mitchell",
                     "cornell_small_catmullrom", "cornell_small_lanczos", "textured_room", "bitmap_room", "cornell_scramble", "cornell_crop", "bunny_box",
-                    "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis"]     # volpath_simple / volpath over homogeneous media: exp / log go through the double-precision routines on both sides
+                    "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis"]     # volpath_simple / volpath over homogeneous media: exp / log go through the double-precision routines on both sides
 STRICT_OTHERS = ["closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep", "cbox_materials",
                  "cbox_materials_strict_indep", "instanced_garden", "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "sky_view", "sky_view_indep", "veach_microfacets",
                  "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room",
@@ -255,7 +255,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
                                   "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong",
-                                  "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])
+                                  "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis", "fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])
 def test_film_vs_reference(oracle, golden_scenes, name):
     """Whole images through SamplingIntegrator::renderBlock + ImageBlock::put (raw 5-channel sums incl. border)."""
     sc = golden_scenes[name]; gd = g(name + "_image.npz")
