@@ -52,7 +52,7 @@ static void mi_launch_shade(const DScene &scIn, bool ldsTables, const RenderCons
         if (total <= 64 * 1024) { rcl.order_offset_words = off; lds = total; }
     }
     if (!sc.has_roughconductor) (env ? mi_launch_shade_d_env : mi_launch_shade_d)(sc, rcl, q, buf, grid, lds, st);
-    else if (sc.has_adapters) (env ? mi_launch_shade_rcw_env : mi_launch_shade_rcw)(sc, rcl, q, buf, grid, lds, st);      // mixturebsdf / bumpmap / normalmap present
+    else if (sc.has_adapters & 1u) (env ? mi_launch_shade_rcw_env : mi_launch_shade_rcw)(sc, rcl, q, buf, grid, lds, st);      // mixturebsdf / bumpmap / normalmap present
     else (env ? mi_launch_shade_rc_env : mi_launch_shade_rc)(sc, rcl, q, buf, grid, lds, st);
 }
 static thread_local std::string g_err;
@@ -351,7 +351,12 @@ int SceneHost::upload(int dev) {
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
     d.has_adapters = 0;
-    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) d.has_adapters = 1; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) d.has_adapters |= 1u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    // bit 1: ENull lobes the volumetric walks have to evaluate through a wrapper -- a `mask`, or a mixturebsdf with a `null` / `thindielectric` child (surfaceNullEval; the NX kernel variants)
+    for (const mi_material &m : materials) {
+        if (m.type == MI_BSDF_MASK) d.has_adapters |= 2u;
+        if (m.type == MI_BSDF_MIXTURE) for (uint32_t c = 0; c < m.distr && c < 4; ++c) { const uint32_t ci = (uint32_t) (c < 3 ? m.reflectance[c] : m.eta[0]); if (ci < materials.size() && (materials[ci].type == MI_BSDF_NULL || materials[ci].type == MI_BSDF_THINDIELECTRIC)) d.has_adapters |= 2u; }
+    }
     const char *noPacket = getenv("MI355PT_NO_PACKET");
     d.packet_n = (nTris <= MI_PACKET_MAX && analyticD.size() <= MI_ANALYTIC_PACKET_MAX && instancesD.empty() && media.empty() && !(noPacket && noPacket[0] == '1')) ? (uint32_t) tris.size() : 0;   // used as a flag
     if (up(&dPacketGroups, packetGroups) | up(&dPacketExact, packetExact)) return 1;

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WG) void k_shade_vol(DScene sc, RenderConst rc, Que
 }
 
 // Scene::evalTransmittance (scene.cpp:650-713) for every shadow record of the segment, then the deferred `Li += throughput * value * (bsdf | phase)`
-template <bool WIDE>
+template <bool WIDE, bool NX>      // NX: ENull lobes behind a wrapper (mask, mixturebsdf with an index-matched child) are present: surfaceNullEval instead of the plain records' pass-through value
 __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
     __shared__ int s_stk[STACK_DEPTH * WG];
     const uint32_t tid = threadIdx.x;
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     n = fn;
                 }
-                if (interactions == maxInteractions || !surfaceHasNull(tb, loadMaterial(tb, material))) { blocked = true; break; }   // an occluder: zero transmittance
+                if (interactions == maxInteractions || !(NX ? surfaceHasNull(tb, loadMaterial(tb, material)) : materialHasNull(loadMaterial(tb, material).type))) { blocked = true; break; }   // an occluder: zero transmittance
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
-            tr = tr * surfaceNullEval(sc, tb, loadMaterial(tb, material), o, d, t, prim, u, v, inst, -dot(d, n), true);      // its.geoFrame = Frame(n): cosTheta(wi) = -dot(d, n)
+            tr = tr * (NX ? surfaceNullEval(sc, tb, loadMaterial(tb, material), o, d, t, prim, u, v, inst, -dot(d, n), true) : materialNullEval(loadMaterial(tb, material), -dot(d, n)));      // its.geoFrame = Frame(n): cosTheta(wi) = -dot(d, n)
             const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;   // `null`: bsdf->eval(bRec, EDiscrete) with typeMask = ENull is 1 (null.cpp:48-50)
             if (pm) {
                 if (medium != targetMedium(pm, n, -d)) { blocked = true; break; }      // medium inconsistency (scene.cpp:689-692)
@@ -308,12 +308,13 @@ __global__ __launch_bounds__(WG) void k_shadow_vol(DScene sc, Queues q) {
 extern "C" {
 void mi_launch_shade_vol(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool env = sc.env_index >= 0;
-    if (sc.has_adapters) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    if (sc.has_adapters & 1u) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
     else if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_vol<true, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<true, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
     else { if (env) hipLaunchKernelGGL((k_shade_vol<false, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_vol<false, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_vol(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
-    if (sc.bvh_wide) hipLaunchKernelGGL((k_shadow_vol<true>), dim3(grid), dim3(WG), 0, st, sc, q);
-    else hipLaunchKernelGGL((k_shadow_vol<false>), dim3(grid), dim3(WG), 0, st, sc, q);
+    const bool nx = (sc.has_adapters & 2u) != 0;
+    if (sc.bvh_wide) { if (nx) hipLaunchKernelGGL((k_shadow_vol<true, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_vol<true, false>), dim3(grid), dim3(WG), 0, st, sc, q); }
+    else { if (nx) hipLaunchKernelGGL((k_shadow_vol<false, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_vol<false, false>), dim3(grid), dim3(WG), 0, st, sc, q); }
 }
 }

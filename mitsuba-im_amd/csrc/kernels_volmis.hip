@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
     if (lane == 0 && pathLen) atomicAdd(&q.counters[2], pathLen);
 }
 
-template <bool WIDE, bool ENV>
+template <bool WIDE, bool ENV, bool NX>      // NX: as in k_shadow_vol
 __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
     __shared__ int s_stk[STACK_DEPTH * WG];
     const uint32_t tid = threadIdx.x;
@@ -318,11 +318,11 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                 else if (prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], o, d, t, u, v, h);
                 else fillHit<false, true>(sc, tb, d, t, prim, u, v, h);
                 const MaterialD hm = loadMaterial(tb, h.material);
-                if (interactions == maxInteractions || !surfaceHasNull(tb, hm) || h.emitter >= 0) break;
+                if (interactions == maxInteractions || !(NX ? surfaceHasNull(tb, hm) : materialHasNull(hm.type)) || h.emitter >= 0) break;
                 if (isZero(tr)) { surface = false; break; }
                 const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
                 if (pm) medium = targetMedium(pm, h.ng, d);
-                tr = tr * surfaceNullEval(sc, tb, hm, o, d, t, prim, u, v, inst, -dot(d, h.ns), false);
+                tr = tr * (NX ? surfaceNullEval(sc, tb, hm, o, d, t, prim, u, v, inst, -dot(d, h.ns), false) : materialNullEval(hm, -dot(d, h.ns)));
                 o = o + d * t;
                 if (++interactions > 100) { surface = false; break; }
             }
@@ -370,11 +370,11 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     nn = fn;
                 }
-                if (interactions == maxInteractions || !surfaceHasNull(tb, loadMaterial(tb, material))) { blocked = true; break; }
+                if (interactions == maxInteractions || !(NX ? surfaceHasNull(tb, loadMaterial(tb, material)) : materialHasNull(loadMaterial(tb, material).type))) { blocked = true; break; }
             }
             if (medium >= 0) tr = tr * mediumTransmittance(sc.media[medium], 0.0f, minf(t, remaining));
             if (!surface || isZero(tr)) break;
-            tr = tr * surfaceNullEval(sc, tb, loadMaterial(tb, material), o, d, t, prim, u, v, inst, -dot(d, nn), true);
+            tr = tr * (NX ? surfaceNullEval(sc, tb, loadMaterial(tb, material), o, d, t, prim, u, v, inst, -dot(d, nn), true) : materialNullEval(loadMaterial(tb, material), -dot(d, nn)));
             const uint32_t pm = sc.prim_media ? sc.prim_media[prim] : 0u;
             if (pm) { if (medium != targetMedium(pm, nn, -d)) { blocked = true; break; } medium = targetMedium(pm, nn, d); }
             if (++interactions > 100) break;
@@ -402,13 +402,15 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
 extern "C" {
 void mi_launch_shade_volmis(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool env = sc.env_index >= 0;
-    if (sc.has_adapters) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    if (sc.has_adapters & 1u) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
     else if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
     else { if (env) hipLaunchKernelGGL((k_shade_volmis<false, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<false, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_volmis(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     const bool env = sc.env_index >= 0;
-    if (sc.bvh_wide) { if (env) hipLaunchKernelGGL((k_shadow_volmis<true, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_volmis<true, false>), dim3(grid), dim3(WG), 0, st, sc, q); }
-    else { if (env) hipLaunchKernelGGL((k_shadow_volmis<false, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_volmis<false, false>), dim3(grid), dim3(WG), 0, st, sc, q); }
+#define MI_SHV(W, E) do { if (sc.has_adapters & 2u) hipLaunchKernelGGL((k_shadow_volmis<W, E, true>), dim3(grid), dim3(WG), 0, st, sc, q); else hipLaunchKernelGGL((k_shadow_volmis<W, E, false>), dim3(grid), dim3(WG), 0, st, sc, q); } while (0)
+    if (sc.bvh_wide) { if (env) MI_SHV(true, true); else MI_SHV(true, false); }
+    else { if (env) MI_SHV(false, true); else MI_SHV(false, false); }
+#undef MI_SHV
 }
 }

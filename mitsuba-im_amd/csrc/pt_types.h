@@ -144,7 +144,7 @@ struct DScene {
     const struct PacketGroupD *packet_groups; const TriAccelD *packet_exact; uint32_t packet_gk[3]; float packet_scale;
     // participating media (volumetric integrators only): prim_media[primitive] = (interior + 1) | (exterior + 1) << 16 for triangles, then analytic shapes; 0 = none
     const MediumD *media; const uint32_t *prim_media; uint32_t n_media; int32_t sensor_medium;
-    uint32_t has_adapters;   // mixturebsdf / bumpmap / normalmap records present: the WRAP variants of k_shade
+    uint32_t has_adapters;   // bit 0: mixturebsdf / bumpmap / normalmap records present (the WRAP variants of k_shade); bit 1: ENull lobes behind a mask / mixture (NX variants of the volumetric shadow stages)
     uint32_t has_roughconductor, has_diffuse;   // non-diffuse / plain diffuse materials present: select the shade kernel variants (both: two launches per bounce, shade.h)
     uint32_t small_tables, area_cdf_len;   // small_tables: shading records / materials / emitters / CDFs fit the LDS staging budget
     // environment emitter (reference src/emitters/envmap.cpp); env_index = its position in the emitter list, -1 = none
