@@ -21,6 +21,10 @@ void mi_launch_shade_rc_env(const DScene &, const RenderConst &, const Queues &,
 void mi_launch_shade_rcw(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shade_rcw_env(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shadow(const DScene &, const Queues &, uint32_t, hipStream_t);
+bool mi_fused_walk(const DScene &);
+uint32_t mi_fused_grid(void);
+void mi_launch_extend_fused(const DScene &, const Queues &, int, uint32_t *, hipStream_t);
+void mi_launch_shadow_fused(const DScene &, const Queues &, uint32_t *, hipStream_t);
 void mi_launch_shade_vol(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
 void mi_launch_shadow_vol(const DScene &, const Queues &, uint32_t, hipStream_t);
 void mi_launch_shade_volmis(const DScene &, const RenderConst &, const Queues &, int, uint32_t, size_t, hipStream_t);
@@ -345,7 +349,7 @@ int SceneHost::upload(int dev) {
         d.env_pixel_w = 2 * MI_PI / (float) envW; d.env_pixel_h = MI_PI / (float) envH; d.env_bs_radius = envBsRadius;
         memcpy(d.env_to_world, envToWorld3, 36); memcpy(d.env_to_local, envToLocal3, 36); memcpy(d.env_bs_center, envBsCenter, 12);
     }
-    d.bvh_depth = (uint32_t) bvhDepth; d.bvh_wide = wideBvh ? 1u : 0u;
+    d.bvh_depth = (uint32_t) bvhDepth; d.bvh_wide = wideBvh ? 1u : 0u; d.bvh_stack_direct = (uint32_t) bvhStackDirect;
     d.area_cdf_len = (uint32_t) areaCdf.size();
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
@@ -492,6 +496,10 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     if (r->rc.integrator != MI_INTEGRATOR_PATH) { ALLOC(Q.shT, float4, shSlots); ALLOC(Q.shX, float4, shSlots); } else { Q.shT = nullptr; Q.shX = nullptr; }
     ALLOC(Q.acc, float4, slots); ALLOC(Q.pos, float2, slots); ALLOC(Q.shCount, uint32_t, grid);
     ALLOC(Q.counters, unsigned long long, 4);
+    ALLOC(Q.ticket, uint32_t, MI_TICKETS);
+    Q.stkSpill = nullptr;
+    if (mi_fused_walk(r->scene->h.d) && r->scene->h.d.bvh_stack_direct > 12u)      // FZ_LDS_STACK (trace_fused.h) entries live in LDS, the rest of the builder's bound here
+        ALLOC(Q.stkSpill, int32_t, (size_t) (r->scene->h.d.bvh_stack_direct - 12u) * mi_fused_grid() * 256u);
     HIPCHK(hipMemset(Q.counters, 0, 32));
     return MI_OK;
 }
@@ -660,10 +668,14 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
     const DScene &sc = r->scene->h.d; hipStream_t st = r->poolStream(pool); Queues &Q = r->pool(pool);
     (void) list;
     mark(r, 0, evUsed, st);
+    const bool fused = r->rc.integrator == MI_INTEGRATOR_PATH && mi_fused_walk(sc);      // trace_fused.h: persistent waves fetch segments through per-launch tickets
+    if (fused) HIPCHK(hipMemsetAsync(Q.ticket, 0, MI_TICKETS * sizeof(uint32_t), st));
     mi_launch_generate(sc, r->rc, Q, bd, r->grid, st);
     int buf = 0; const int maxDepth = r->rc.max_depth > 0 ? r->rc.max_depth : 250;
     for (int depth = 1; depth <= maxDepth; ++depth) {
-        mark(r, 1, evUsed, st); mi_launch_extend(sc, Q, buf, r->gridExtend, st); ++r->launchesAll;
+        mark(r, 1, evUsed, st);
+        if (fused && 2 * depth + 1 < MI_TICKETS) mi_launch_extend_fused(sc, Q, buf, Q.ticket + 2 * depth, st); else mi_launch_extend(sc, Q, buf, r->gridExtend, st);
+        ++r->launchesAll;
         if (r->rc.integrator != MI_INTEGRATOR_PATH) {      // the same loop over media: its own shade and shadow stages (kernels_vol.hip, kernels_volmis.hip)
             const size_t lds = r->rc.sampler == MI_SAMPLER_SOBOL ? (size_t) r->rc.nib_dims * r->rc.nib_count * 64 : 16; const bool mis = r->rc.integrator == MI_INTEGRATOR_VOLPATH;
             mark(r, 2, evUsed, st); (mis ? mi_launch_shade_volmis : mi_launch_shade_vol)(sc, r->rc, Q, buf, r->gridShade, lds, st);
@@ -671,7 +683,7 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
         } else {
         if (depth == 1 && sc.env_texture && !r->rc.hide_emitters) mi_launch_env_primary(sc, r->rc, Q, buf, r->gridExtend, st);   // camera rays that see the sky: filtered lookup (envmap.cpp:398-411)
         mark(r, 2, evUsed, st); mi_launch_shade(sc, r->ldsTables, r->rc, Q, buf, r->gridShade, st);
-        if (depth < maxDepth) { mark(r, 3, evUsed, st); mi_launch_shadow(sc, Q, r->gridShadow, st); }
+        if (depth < maxDepth) { mark(r, 3, evUsed, st); if (fused && 2 * depth + 1 < MI_TICKETS) mi_launch_shadow_fused(sc, Q, Q.ticket + 2 * depth + 1, st); else mi_launch_shadow(sc, Q, r->gridShadow, st); }
         }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces

@@ -1,6 +1,8 @@
 // kernels_trace.hip -- extend (closest hit) and shadow (any hit) stages, unit-level intersection entry point (see kernels_common.h)
 #include "kernels_common.h"
+#include <algorithm>
 #include "trace.h"
+#include "trace_fused.h"
 
 // ---------------------------------------------------------------------------------------------- extend
 // Scene::rayIntersect -> ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:112-142): closest hit (t, u, v, prim)
@@ -58,6 +60,19 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
     }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------- fused walk (trace_fused.h): triangle-only trees
+template <bool WIDE>
+__global__ __launch_bounds__(WG) void k_extend_f(DScene sc, Queues q, int buf, uint32_t *ticket, uint32_t thr) {
+    __shared__ int s_stk[FZ_LDS_STACK * WG];
+    fusedStage<false, WIDE>(sc, q, buf, ticket, thr, s_stk);
+}
+template <bool WIDE>
+__global__ __launch_bounds__(WG) void k_shadow_f(DScene sc, Queues q, uint32_t *ticket, uint32_t thr) {
+    __shared__ int s_stk[FZ_LDS_STACK * WG];
+    fusedStage<true, WIDE>(sc, q, 0, ticket, thr, s_stk);
+}
 
 // ---------------------------------------------------------------------------------------------- unit-level entry point (parity tests)
 __global__ __launch_bounds__(WG) void k_debug_intersect(DScene sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst) {
@@ -137,6 +152,22 @@ void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStrea
 }
 #undef MI_BY_STACK
 #undef MI_BY_STACK_W
+// The fused walk serves triangle-only trees (no analytic shapes, no instances, not the packet); MI355PT_FUSED=0 restores the while-while kernels for A/B runs.
+// `ticket`: a zeroed word of Queues::ticket (one per traversal launch of a batch); grid = persistent workgroups (waves fetch segments through the ticket).
+static const int kFused = [] { const char *e = getenv("MI355PT_FUSED"); return e && e[0] ? atoi(e) : 1; }();
+static const uint32_t kFusedThr = [] { const char *e = getenv("MI355PT_FUSED_THR"); const int v = e && e[0] ? atoi(e) : 48; return (uint32_t) (v < 1 ? 1 : (v > 64 ? 64 : v)); }();
+static const uint32_t kFusedGrid = [] { const char *e = getenv("MI355PT_FUSED_GRID"); const int v = e && e[0] ? atoi(e) : 2048; return (uint32_t) (v < 1 ? 1 : (v > 16384 ? 16384 : v)); }();
+// wide (4-way) trees only: on the small binary trees the while-while kernels win (Veach-MIS 1080p: 1931 vs 1454 Msamples/s), MI355PT_FUSED=2 forces it there too
+bool mi_fused_walk(const DScene &sc) { return kFused && (sc.bvh_wide || kFused == 2) && !sc.packet_n && !sc.n_analytic && !sc.n_instances; }
+uint32_t mi_fused_grid(void) { return kFusedGrid; }
+void mi_launch_extend_fused(const DScene &sc, const Queues &q, int buf, uint32_t *ticket, hipStream_t st) {
+    const uint32_t g = kFusedGrid;
+    if (sc.bvh_wide) hipLaunchKernelGGL((k_extend_f<true>), dim3(g), dim3(WG), 0, st, sc, q, buf, ticket, kFusedThr); else hipLaunchKernelGGL((k_extend_f<false>), dim3(g), dim3(WG), 0, st, sc, q, buf, ticket, kFusedThr);
+}
+void mi_launch_shadow_fused(const DScene &sc, const Queues &q, uint32_t *ticket, hipStream_t st) {
+    const uint32_t g = kFusedGrid;
+    if (sc.bvh_wide) hipLaunchKernelGGL((k_shadow_f<true>), dim3(g), dim3(WG), 0, st, sc, q, ticket, kFusedThr); else hipLaunchKernelGGL((k_shadow_f<false>), dim3(g), dim3(WG), 0, st, sc, q, ticket, kFusedThr);
+}
 void mi_launch_ray_intersect(const DScene &sc, const float *rays, uint64_t n, mi_intersection *out, hipStream_t st) { hipLaunchKernelGGL(k_ray_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, out); }
 void mi_launch_debug_intersect(const DScene &sc, const float *rays, uint64_t n, int anyHit, float *out, int *outInst, hipStream_t st) { hipLaunchKernelGGL(k_debug_intersect, dim3((unsigned) ((n + WG - 1) / WG)), dim3(WG), 0, st, sc, rays, n, anyHit, out, outInst); }
 }

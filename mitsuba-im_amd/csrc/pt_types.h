@@ -138,6 +138,7 @@ struct DScene {
     uint32_t sobol_dims, log_res; float resolution;
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
+    uint32_t bvh_stack_direct;            // stack entries per lane the fused walk of trace_fused.h can need on the scene-level tree
     uint32_t packet_n, bvh_depth, bvh_wide;   // bvh_depth: traversal stack entries the tree(s) can need; bvh_wide: the node array holds Bvh4Node records
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
     // triangles dropped), exact Wald records in ORIGINAL triangle order for pass 2, largest |coordinate| of the scene box (error-margin scale)

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include "../../include/mi355pt.h"
 
+#define MI_TICKETS 1024
 struct Queues {
     float4 *rayO[2], *rayD[2];
     uint4 *st0[2]; float4 *st1[2]; float *st2[2];
@@ -18,6 +19,8 @@ struct Queues {
     float4 *shT, *shX;                          // volumetric integrators only: throughput and BSDF / phase value of a shadow record (the transmittance between the two enters before them, shade_vol.h)
     float4 *acc; float2 *pos;
     uint32_t *count[2]; uint32_t *shCount;      // per segment
+    uint32_t *ticket;                           // [MI_TICKETS] segment tickets of the fused traversal launches of a batch (trace_fused.h), zeroed when the batch starts
+    int32_t *stkSpill;                          // fused walk: stack entries beyond FZ_LDS_STACK, one column per lane of the persistent grid (entry e of lane l at [e * lanes + l])
     unsigned long long *counters;               // [0] closest-hit rays, [1] shadow rays, [2] sum of path depths
     uint32_t cap;                               // slots per segment (multiple of 64)
     uint32_t n_seg;                             // number of segments

@@ -309,7 +309,7 @@ void SceneHost::commitHost() {
     // +12 %); on small trees and on the two-level trees of instanced scenes the binary nodes' cheaper per-node arithmetic wins (instanced garden: +5 %).
     // MI355PT_BVH2 = 1 / 0 forces binary / wide (A/B runs, parity tests of both kinds).
     { const char *e2 = getenv("MI355PT_BVH2"); wideBvh = e2 && e2[0] ? e2[0] == '0' : (ni == 0 && nt >= 16384u); }
-    std::vector<int> treeNeed;    // traversal stack entries each emitted tree can need
+    std::vector<int> treeNeed, treeNeedDirect;    // traversal stack entries each emitted tree can need (one entry per level / child codes pushed one by one)
     auto emitTree = [&](const std::vector<uint32_t> &prims) -> int {
         Builder bld; bld.order = prims; bld.tlo = &tlo; bld.thi = &thi; bld.cen = &cen; bld.single = &single; bld.nodes.reserve(2 * prims.size() + 2);
         const int nodeBase = (int) nodes.size(), triBase = (int) tris.size();
@@ -321,7 +321,7 @@ void SceneHost::commitHost() {
             static_assert(sizeof(Bvh4Node) == sizeof(BvhNode), "both node kinds share one array");
             auto area = [](const BuildNode &n) { V3 e = n.hi - n.lo; return e.x * e.y + e.y * e.z + e.z * e.x; };
             struct Emit { std::vector<BvhNode> &nodes; Builder &bld; int triBase; decltype(area) &areaOf;
-                int run(int id, int &need) {
+                int run(int id, int &need, int &needD) {
                     std::vector<int> kids;
                     if (id < 0) { /* empty tree */ } else if (bld.nodes[id].count > 0) kids.push_back(id); else { kids.push_back(bld.nodes[id].left); kids.push_back(bld.nodes[id].right); }
                     while (kids.size() < 4) {
@@ -340,7 +340,7 @@ void SceneHost::commitHost() {
                         const float ext = comp(hi, a) - comp(lo, a); int e = 0; std::frexp(ext > 0 ? ext / 254.0f : 1e-30f, &e);      // ext / 254 = m 2^e, m in [0.5, 1): 2^e >= ext / 254
                         e = std::min(std::max(e + 127, 1), 254); ex[a] = e; w.exps |= (uint32_t) e << (8 * a);
                     }
-                    int sub = 0;
+                    int sub = 0, subD = 0;
                     for (int c = 0; c < 4; ++c) {
                         if (c >= (int) kids.size()) { for (int a = 0; a < 3; ++a) { w.qlo[a] |= 255u << (8 * c); } w.child[c] = BVH_EMPTY_CHILD; continue; }
                         const BuildNode &k = bld.nodes[kids[c]];
@@ -353,13 +353,14 @@ void SceneHost::commitHost() {
                             w.qlo[a] |= (uint32_t) ql << (8 * c); w.qhi[a] |= (uint32_t) qh << (8 * c);
                         }
                         if (k.count > 0) w.child[c] = leafCode(triBase + k.first, k.count);
-                        else { int need = 0; w.child[c] = run(kids[c], need); sub = std::max(sub, need); }
+                        else { int need = 0, needD = 0; w.child[c] = run(kids[c], need, needD); sub = std::max(sub, need); subD = std::max(subD, needD); }
                     }
                     std::memcpy(&nodes[dev], &w, sizeof(w));
                     need = sub + (kids.size() > 1 ? 1 : 0);      // one stack entry per level: the node's pending children (trace.h)
+                    needD = subD + (kids.size() > 1 ? (int) kids.size() - 1 : 0);      // child codes pushed one by one (trace_fused.h): up to kids - 1 siblings wait while a subtree is walked
                     return dev;
                 } };
-            Emit em{nodes, bld, triBase, area}; int need = 0; const int dev = em.run(root, need); treeNeed.push_back(need + 1);
+            Emit em{nodes, bld, triBase, area}; int need = 0, needD = 0; const int dev = em.run(root, need, needD); treeNeed.push_back(need + 1); treeNeedDirect.push_back(needD + 1);
             (void) nodeBase; return dev;
         }
         std::vector<int> devIndex(bld.nodes.size(), -1); int nInner = 0;
@@ -390,10 +391,12 @@ void SceneHost::commitHost() {
     if (wideBvh) {      // treeNeed[0]: the scene level, then one entry per group
         int groupNeed = 0; for (uint32_t g = 0; g < ng; ++g) groupNeed = std::max(groupNeed, treeNeed[1 + g]);
         bvhDepth = treeNeed[0] + (ni ? 1 + groupNeed : 0);
+        bvhStackDirect = treeNeedDirect[0];
     } else {
         struct Depth { const std::vector<BvhNode> &n; int of(int i) const { if (i < 0) return 0; int a = of(n[i].c0), b = of(n[i].c1); return 1 + (a > b ? a : b); } } dep{nodes};
         int groupDepth = 0; for (uint32_t g = 0; g < ng; ++g) groupDepth = std::max(groupDepth, dep.of(groupRoot[g]));
         bvhDepth = dep.of(0) + (ni ? 1 + groupDepth : 0);
+        bvhStackDirect = dep.of(0);
     }
     // packet mode (no instances, <= MI_PACKET_MAX triangles): exact records in original order + pass-1 group records (pt_types.h PacketGroupD).  Coplanar
     // pairs that form a parallelogram (the two halves of a quad) share one record: for the vertices (X, Y, Z) of a triangle, taken cyclically, the partner is

@@ -22,7 +22,8 @@ struct SceneHost {
     std::vector<uint32_t> triShape, i2; std::vector<TriAccelD> tris; std::vector<TriShade> shade; std::vector<BvhNode> nodes;
     std::vector<TriUV> triuv; bool anyUV = false;   // per-triangle uv + UV tangents (only when some mesh has texcoords)
     bool wideBvh = true;   // 4-wide quantised nodes (default) or the binary tree (MI355PT_BVH2=1)
-    std::vector<InstanceD> instancesD; int bvhDepth = 0;   // stack entries the traversal needs (scene tree + return marker + deepest group tree)
+    std::vector<InstanceD> instancesD; int bvhStackDirect = 0;   // stack entries of the fused walk (trace_fused.h: child codes pushed one by one), scene-level tree
+    int bvhDepth = 0;   // stack entries the traversal needs (scene tree + return marker + deepest group tree)
     std::vector<AnalyticD> analyticD; uint32_t nTris = 0;   // analytic shapes: primitive index nTris + i; `tris` (BVH leaf order) holds a k = MI_K_ANALYTIC record for each
     std::vector<TriAccelD> packetExact;   // Wald records in ORIGINAL triangle order (packet mode, <= MI_PACKET_MAX triangles): pass 2 of trace.h
     std::vector<PacketGroupD> packetGroups; uint32_t packetGK[3] = {0, 0, 0}; float packetScale = 1.0f;   // pass-1 records sorted by projection axis
