@@ -296,7 +296,12 @@ int SceneHost::upload(int dev) {
         m.eta[1] = sl / (dl + sl);
     }
     std::vector<float> filt(filterValues, filterValues + MI_FILTER_RES + 1);
-    int bad = up(&dNodes, nodes) | up(&dTris, tris) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
+    // tree nodes and leaf records share ONE allocation (nodes first): the fused walk (trace_fused.h) addresses both through one base + a 32-bit byte offset
+    std::vector<unsigned char> geo(nodes.size() * sizeof(BvhNode) + std::max<size_t>(tris.size(), 1) * sizeof(TriAccelD) + 16);
+    if (!nodes.empty()) std::memcpy(geo.data(), nodes.data(), nodes.size() * sizeof(BvhNode));
+    if (!tris.empty()) std::memcpy(geo.data() + nodes.size() * sizeof(BvhNode), tris.data(), tris.size() * sizeof(TriAccelD));
+    dTris = nullptr;
+    int bad = up(&dNodes, geo) | up(&dShade, shade) | up(&dI2, i2) | up(&dNrm, nrm) | up(&dMaterials, mats) |
               up(&dEmitters, emittersD) | up(&dAnalytic, analyticD) | up(&dInstances, instancesD) | up(&dMaterialTables, materialTables) | up(&dTriUV, triuv) | up(&dTextures, textures) | up(&dEmitterX, emitterX) | up(&dEmitterCdf, emitterCdf) | up(&dAreaCdf, areaCdf) | up(&dFilter, filt);
     if (bad) return 1;
     d = DScene{};
@@ -308,7 +313,7 @@ int SceneHost::upload(int dev) {
         d.sobol_m32 = (const uint32_t *) dSobolM32; d.sobol_vdc = (const uint64_t *) dSobolVdc; d.sobol_vdc_inv = (const uint64_t *) dSobolVdcInv;
         d.sobol_dims = g_sobolDims;
     }
-    d.nodes = (const BvhNode *) dNodes; d.tris = (const TriAccelD *) dTris; d.shade = (const TriShade *) dShade; d.i2 = (const uint32_t *) dI2;
+    d.nodes = (const BvhNode *) dNodes; d.tris = (const TriAccelD *) ((const unsigned char *) dNodes + nodes.size() * sizeof(BvhNode)); d.geo_bytes = geo.size(); d.shade = (const TriShade *) dShade; d.i2 = (const uint32_t *) dI2;
     d.nrm = (const float *) dNrm; d.materials = (const MaterialD *) dMaterials; d.emitters = (const EmitterD *) dEmitters;
     d.emitter_cdf = (const float *) dEmitterCdf; d.area_cdf = (const float *) dAreaCdf; d.filter_values = (const float *) dFilter;
     d.analytic = (const AnalyticD *) dAnalytic; d.n_analytic = (uint32_t) analyticD.size();
@@ -498,8 +503,8 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     ALLOC(Q.counters, unsigned long long, 4);
     ALLOC(Q.ticket, uint32_t, MI_TICKETS);
     Q.stkSpill = nullptr;
-    if (mi_fused_walk(r->scene->h.d) && r->scene->h.d.bvh_stack_direct > 12u)      // FZ_LDS_STACK (trace_fused.h) entries live in LDS, the rest of the builder's bound here
-        ALLOC(Q.stkSpill, int32_t, (size_t) (r->scene->h.d.bvh_stack_direct - 12u) * mi_fused_grid() * 256u);
+    if (mi_fused_walk(r->scene->h.d) && r->scene->h.d.bvh_stack_direct > 10u)      // FZ_LDS_STACK (trace_fused.h) entries live in LDS, the rest of the builder's bound here
+        ALLOC(Q.stkSpill, int32_t, (size_t) (r->scene->h.d.bvh_stack_direct - 10u) * mi_fused_grid() * 256u);
     HIPCHK(hipMemset(Q.counters, 0, 32));
     return MI_OK;
 }

@@ -65,13 +65,13 @@ __global__ __launch_bounds__(WG) void k_shadow(DScene sc, Queues q) {
 // ---------------------------------------------------------------------------------------------- fused walk (trace_fused.h): triangle-only trees
 template <bool WIDE>
 __global__ __launch_bounds__(WG) void k_extend_f(DScene sc, Queues q, int buf, uint32_t *ticket, uint32_t thr) {
-    __shared__ int s_stk[FZ_LDS_STACK * WG];
-    fusedStage<false, WIDE>(sc, q, buf, ticket, thr, s_stk);
+    __shared__ int s_lds[FZ_LDS_WORDS];
+    fusedStage<false, WIDE>(sc, q, buf, ticket, thr, s_lds);
 }
 template <bool WIDE>
 __global__ __launch_bounds__(WG) void k_shadow_f(DScene sc, Queues q, uint32_t *ticket, uint32_t thr) {
-    __shared__ int s_stk[FZ_LDS_STACK * WG];
-    fusedStage<true, WIDE>(sc, q, 0, ticket, thr, s_stk);
+    __shared__ int s_lds[FZ_LDS_WORDS];
+    fusedStage<true, WIDE>(sc, q, 0, ticket, thr, s_lds);
 }
 
 // ---------------------------------------------------------------------------------------------- unit-level entry point (parity tests)
@@ -156,9 +156,9 @@ void mi_launch_shadow(const DScene &sc, const Queues &q, uint32_t grid, hipStrea
 // `ticket`: a zeroed word of Queues::ticket (one per traversal launch of a batch); grid = persistent workgroups (waves fetch segments through the ticket).
 static const int kFused = [] { const char *e = getenv("MI355PT_FUSED"); return e && e[0] ? atoi(e) : 1; }();
 static const uint32_t kFusedThr = [] { const char *e = getenv("MI355PT_FUSED_THR"); const int v = e && e[0] ? atoi(e) : 48; return (uint32_t) (v < 1 ? 1 : (v > 64 ? 64 : v)); }();
-static const uint32_t kFusedGrid = [] { const char *e = getenv("MI355PT_FUSED_GRID"); const int v = e && e[0] ? atoi(e) : 2048; return (uint32_t) (v < 1 ? 1 : (v > 16384 ? 16384 : v)); }();
+static const uint32_t kFusedGrid = [] { const char *e = getenv("MI355PT_FUSED_GRID"); const int v = e && e[0] ? atoi(e) : 1792; return (uint32_t) (v < 1 ? 1 : (v > 16384 ? 16384 : v)); }();
 // wide (4-way) trees only: on the small binary trees the while-while kernels win (Veach-MIS 1080p: 1931 vs 1454 Msamples/s), MI355PT_FUSED=2 forces it there too
-bool mi_fused_walk(const DScene &sc) { return kFused && (sc.bvh_wide || kFused == 2) && !sc.packet_n && !sc.n_analytic && !sc.n_instances; }
+bool mi_fused_walk(const DScene &sc) { return kFused && (sc.bvh_wide || kFused == 2) && !sc.packet_n && !sc.n_analytic && !sc.n_instances && sc.geo_bytes < 0xFFFFFF00ull; }
 uint32_t mi_fused_grid(void) { return kFusedGrid; }
 void mi_launch_extend_fused(const DScene &sc, const Queues &q, int buf, uint32_t *ticket, hipStream_t st) {
     const uint32_t g = kFusedGrid;

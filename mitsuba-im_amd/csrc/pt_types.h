@@ -38,13 +38,14 @@ struct BvhNode {
     float hi1[3]; int32_t pad1;
 };
 
-// 4-wide node with quantised child boxes, 64 B (same size and array as BvhNode): child box c = org + q * 2^(e - 127) per axis, q in 0..255 (lo rounded down,
-// hi rounded up: the boxes only grow).  child: >= 0 inner node index, < 0 leaf code as in BvhNode; an unused slot has an inverted box (lo 255, hi 0).
+// 4-wide node with quantised child boxes, 64 B (same size and array as BvhNode): child box c = org + q * step per axis, q in 0..255 (lo rounded down,
+// hi rounded up: the boxes only grow), step = a power of two stored as a float (the walk multiplies it with 1 / d without decoding anything).
+// child: >= 0 inner node index, < 0 leaf code as in BvhNode; an unused slot has an inverted box (lo 255, hi 0).
 struct Bvh4Node {
-    float org[3]; uint32_t exps;          // exps: biased exponents of the x / y / z quantisation step in bytes 0 / 1 / 2
-    uint32_t qlo[3], qhi[3];              // per axis: the four children's bytes, child c in bits 8c..8c+7
-    uint32_t pad[2];
-    int32_t child[4];
+    float org[3]; float step_x;           // 16-B word 0
+    uint32_t qlo[3], qhi[3];              // words 1 / 2: per axis the four children's bytes, child c in bits 8c..8c+7
+    float step_y, step_z;
+    int32_t child[4];                     // word 3
 };
 
 // Per-triangle shading record in ORIGINAL triangle order, 96 B = six 16-B loads.
@@ -138,6 +139,7 @@ struct DScene {
     uint32_t sobol_dims, log_res; float resolution;
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
+    uint64_t geo_bytes;                   // nodes + leaf records live in one allocation of this many bytes (nodes first)
     uint32_t bvh_stack_direct;            // stack entries per lane the fused walk of trace_fused.h can need on the scene-level tree
     uint32_t packet_n, bvh_depth, bvh_wide;   // bvh_depth: traversal stack entries the tree(s) can need; bvh_wide: the node array holds Bvh4Node records
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate

@@ -77,8 +77,7 @@ DEV bool traverse(const DScene &sc, v3 o, v3 d, float mint, float maxt, int *stk
         if (WIDE) {
             while (cur >= 0 && cur != BVH_DONE) {
                 const f4 n0 = nodes4[cur * 4 + 0], n1 = nodes4[cur * 4 + 1], n2 = nodes4[cur * 4 + 2], n3 = nodes4[cur * 4 + 3];
-                const uint32_t ex = __float_as_uint(n0.w);
-                const float sx = __uint_as_float((ex & 0xFFu) << 23), sy = __uint_as_float(((ex >> 8) & 0xFFu) << 23), sz = __uint_as_float(((ex >> 16) & 0xFFu) << 23);
+                const float sx = n0.w, sy = n2.z, sz = n2.w;      // quantisation steps (powers of two)
                 // plane distance t = (org + q s - o) inv = q (s inv) + (org inv - o inv)
                 const float bx = sx * inv.x, by = sy * inv.y, bz = sz * inv.z;
                 const float ax = __builtin_fmaf(n0.x, inv.x, oi.x), ay = __builtin_fmaf(n0.y, inv.y, oi.y), az = __builtin_fmaf(n0.z, inv.z, oi.z);

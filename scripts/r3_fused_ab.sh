@@ -13,7 +13,7 @@ for thr in 32 40 56; do
   echo "== thr $thr" | tee -a $L
   MI355PT_FUSED_THR=$thr timeout -k 10 300 python scripts/perf_atrium.py 2>&1 | tee -a $L || exit 1
 done
-for g in 1024 1536 3072 4096; do
+for g in 1536 2048 3072; do
   echo "== grid $g" | tee -a $L
   MI355PT_FUSED_GRID=$g timeout -k 10 300 python scripts/perf_atrium.py 2>&1 | tee -a $L || exit 1
 done

@@ -62,11 +62,11 @@ static void pop(Lane &L) {
         L.cur = N4()[node].child[slots & 3u]; }
     else L.cur = DONE;
 }
+static std::vector<double> nodeVisits;
+static int gOrder = 0;      // children after the nearest one: 0 by distance, 1 in slot order, 2 in reverse slot order, 3 no ordering at all (slot order incl. the first)
 static void nodeStep(Lane &L) {       // trace.h traverse<..., WIDE = true>, one inner node
-    const Bvh4Node &n = N4()[L.cur]; ++L.nodes;
-    const uint32_t ex = n.exps;
-    auto sc = [](uint32_t e) { uint32_t b = (e & 0xFFu) << 23; float f; memcpy(&f, &b, 4); return f; };
-    const float sx = sc(ex), sy = sc(ex >> 8), sz = sc(ex >> 16);
+    const Bvh4Node &n = N4()[L.cur]; ++L.nodes; if (!nodeVisits.empty()) nodeVisits[L.cur] += 1;
+    const float sx = n.step_x, sy = n.step_y, sz = n.step_z;
     const float bx = sx * L.inv.x, by = sy * L.inv.y, bz = sz * L.inv.z;
     const float ax = std::fmaf(n.org[0], L.inv.x, L.oi.x), ay = std::fmaf(n.org[1], L.inv.y, L.oi.y), az = std::fmaf(n.org[2], L.inv.z, L.oi.z);
     const uint32_t nxq = L.inv.x >= 0 ? n.qlo[0] : n.qhi[0], fxq = L.inv.x >= 0 ? n.qhi[0] : n.qlo[0], nyq = L.inv.y >= 0 ? n.qlo[1] : n.qhi[1], fyq = L.inv.y >= 0 ? n.qhi[1] : n.qlo[1], nzq = L.inv.z >= 0 ? n.qlo[2] : n.qhi[2], fzq = L.inv.z >= 0 ? n.qhi[2] : n.qlo[2];
@@ -77,7 +77,15 @@ static void nodeStep(Lane &L) {       // trace.h traverse<..., WIDE = true>, one
         uint32_t tb; memcpy(&tb, &tn, 4);
         key[c] = (tn <= tf * 1.000002f + 1e-30f) ? ((tb & ~3u) | (uint32_t) c) : 0xFFFFFFFFu;
     }
-    std::sort(key, key + 4);
+    if (gOrder == 0) std::sort(key, key + 4);
+    else {
+        if (gOrder != 3) { int m = 0; for (int c = 1; c < 4; ++c) if (key[c] < key[m]) m = c; std::swap(key[0], key[m]); }
+        // the rest: hits first, in slot order (or reverse)
+        uint32_t rest[3]; int nr = 0; const int lo = gOrder == 3 ? 0 : 1;
+        uint32_t all[4]; int na = 0; for (int c = lo; c < 4; ++c) if (key[c] != 0xFFFFFFFFu) all[na++] = key[c];
+        std::sort(all, all + na, [](uint32_t a, uint32_t b) { return (a & 3u) < (b & 3u); }); if (gOrder == 2) std::reverse(all, all + na);
+        (void) rest; (void) nr; for (int c = lo; c < 4; ++c) key[c] = (c - lo) < na ? all[c - lo] : 0xFFFFFFFFu;
+    }
     if (key[0] == 0xFFFFFFFFu) pop(L);
     else {
         const uint32_t more = (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
@@ -104,8 +112,7 @@ static int directDepth(const Ray &r) {
     while (true) {
         if (cur >= 0) {
             const Bvh4Node &n = N4()[cur];
-            auto sc = [](uint32_t e) { uint32_t b = (e & 0xFFu) << 23; float f; memcpy(&f, &b, 4); return f; };
-            const float sx = sc(n.exps), sy = sc(n.exps >> 8), sz = sc(n.exps >> 16), bx = sx * L.inv.x, by = sy * L.inv.y, bz = sz * L.inv.z;
+            const float sx = n.step_x, sy = n.step_y, sz = n.step_z, bx = sx * L.inv.x, by = sy * L.inv.y, bz = sz * L.inv.z;
             const float ax = std::fmaf(n.org[0], L.inv.x, L.oi.x), ay = std::fmaf(n.org[1], L.inv.y, L.oi.y), az = std::fmaf(n.org[2], L.inv.z, L.oi.z);
             const uint32_t nxq = L.inv.x >= 0 ? n.qlo[0] : n.qhi[0], fxq = L.inv.x >= 0 ? n.qhi[0] : n.qlo[0], nyq = L.inv.y >= 0 ? n.qlo[1] : n.qhi[1], fyq = L.inv.y >= 0 ? n.qhi[1] : n.qlo[1], nzq = L.inv.z >= 0 ? n.qlo[2] : n.qhi[2], fzq = L.inv.z >= 0 ? n.qhi[2] : n.qlo[2];
             uint32_t key[4];
@@ -160,7 +167,7 @@ static void waveWalk(const Ray *rays, int n, Stats &S) {
 // A wave working through a STREAM of rays under a schedule: `thr` = refill idle lanes (from the stream) whenever fewer than thr lanes are busy at the top of the
 // outer loop (thr = 1: only when the whole wave is done -- today's kernel; thr = 64: whenever a lane is idle); ifif = one fused loop in which every lane takes
 // one step of whatever it needs (node or triangle) per iteration.  Returns the estimated VALU instructions issued by the wave.
-struct Sched { const char *name; int thr; bool ifif; int spec; };
+struct Sched { const char *name; int thr; bool ifif; int spec; int triThr = 1; };
 static double streamWalk(const std::vector<Ray> &stream, const Sched &sc, Stats &S) {
     static Lane L[64]; static uint32_t triPos[64]; static int post[64];
     for (int i = 0; i < 64; ++i) { L[i].cur = DONE; L[i].nodes = L[i].tris = 0; post[i] = DONE; }
@@ -174,13 +181,15 @@ static double streamWalk(const std::vector<Ray> &stream, const Sched &sc, Stats 
             cost += 40;
         }
         if (sc.ifif) {
-            bool anyNode = false, anyTri = false; int act = 0;
+            bool anyNode = false, anyTri = false; int act = 0, nTri = 0, nNode = 0;
+            for (int i = 0; i < 64; ++i) if (L[i].cur != DONE) { if (L[i].cur >= 0) ++nNode; else ++nTri; }
+            const bool doTri = nTri >= sc.triThr || nNode == 0;      // the triangle block runs only when enough lanes want it (or nobody wants a node)
             for (int i = 0; i < 64; ++i) {
-                if (L[i].cur == DONE) continue; ++act;
-                if (L[i].cur >= 0) { nodeStep(L[i]); anyNode = true; if (L[i].cur == DONE) retire(i); else triPos[i] = 0; }
-                else { leafTri(L[i], triPos[i]++); anyTri = true; if (triPos[i] >= leafCount(L[i].cur)) { pop(L[i]); triPos[i] = 0; if (L[i].cur == DONE) retire(i); } }
+                if (L[i].cur == DONE) continue;
+                if (L[i].cur >= 0) { ++act; nodeStep(L[i]); anyNode = true; if (L[i].cur == DONE) retire(i); else triPos[i] = 0; }
+                else if (doTri) { ++act; leafTri(L[i], triPos[i]++); anyTri = true; if (triPos[i] >= leafCount(L[i].cur)) { pop(L[i]); triPos[i] = 0; if (L[i].cur == DONE) retire(i); } }
             }
-            cost += (anyNode ? 120 : 0) + (anyTri ? 55 : 0) + 6; S.waveNodeIters += anyNode; S.waveTriIters += anyTri; S.nodeLaneSum += act;
+            cost += (anyNode ? 175 : 0) + (anyTri ? 71 : 0) + 38; S.waveNodeIters += 1; S.waveTriIters += anyTri; S.nodeLaneSum += act;
             continue;
         }
         while (true) {      // inner nodes (spec: a lane that reaches its first leaf parks it and keeps descending)
@@ -218,12 +227,14 @@ int main(int argc, char **argv) {
     const int W = argc > 2 ? atoi(argv[2]) : 3840, Hh = argc > 3 ? atoi(argv[3]) : 2160;
     const int segStride = argc > 4 ? atoi(argv[4]) : 64;     // simulate every segStride-th segment
     const int maxDepth = argc > 5 ? atoi(argv[5]) : 4;
+    gOrder = argc > 6 ? atoi(argv[6]) : 0;
     auto pos = readFile<float>(base + ".pos"); auto idx = readFile<uint32_t>(base + ".idx"); auto cam = readFile<float>(base + ".cam");
     H.pos = pos; H.idx = idx; mi_shape sh{}; sh.first_tri = 0; sh.tri_count = (uint32_t) (idx.size() / 3); sh.first_vert = 0; sh.vert_count = (uint32_t) (pos.size() / 3); sh.bsdf = 0; sh.emitter = -1; sh.flags = 1; sh.group = 0;
     H.shapes.push_back(sh); mi_material m{}; m.type = 0; m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f; H.materials.push_back(m);
     H.width = W; H.height = Hh; for (int i = 0; i < 16; ++i) H.c2w[i] = cam[i];
     setenv("MI355PT_BVH2", "0", 1);
     H.commitHost();
+    nodeVisits.assign(H.nodes.size(), 0.0);
     printf("tree: %zu nodes (4-wide), %zu leaf records, stack need %d\n", H.nodes.size(), H.tris.size(), H.bvhDepth);
     // pinhole camera (xfov 60 degrees)
     const V3 co = mk(cam[3], cam[7], cam[11]); const V3 cx = mk(cam[0], cam[4], cam[8]), cy = mk(cam[1], cam[5], cam[9]), cz = mk(cam[2], cam[6], cam[10]);
@@ -237,7 +248,7 @@ int main(int argc, char **argv) {
         const uint64_t nPix = (uint64_t) W * Hh; const uint32_t cap = md.segCap; const uint64_t nSeg = (nPix + cap - 1) / cap;
         std::vector<Stats> S(maxDepth + 1);
         static const Sched scheds[] = {{"while-while, refill when the wave is done (today)", 1, false, 0}, {"refill below 32 busy lanes", 32, false, 0}, {"refill below 48", 48, false, 0}, {"refill below 64", 64, false, 0},
-                                       {"fused if-if loop, refill when done", 1, true, 0}, {"fused if-if loop, refill below 32", 32, true, 0}, {"fused if-if loop, refill below 48", 48, true, 0}, {"fused if-if loop, refill below 64", 64, true, 0}, {"speculative (one parked leaf), refill when done", 1, false, 1}, {"speculative, refill below 48", 48, false, 1}};
+                                       {"fused if-if loop, refill when done", 1, true, 0}, {"fused if-if loop, refill below 32", 32, true, 0}, {"fused if-if loop, refill below 48", 48, true, 0}, {"fused if-if loop, refill below 64", 64, true, 0}, {"fused, refill below 48, triangle block at >= 8 lanes", 48, true, 0, 8}, {"fused, refill below 48, triangle block at >= 16 lanes", 48, true, 0, 16}, {"fused, refill below 48, triangle block at >= 24", 48, true, 0, 24}, {"fused, refill below 56, triangle block at >= 16", 56, true, 0, 16}, {"speculative (one parked leaf), refill when done", 1, false, 1}, {"speculative, refill below 48", 48, false, 1}};
         const int NS = (int) (sizeof(scheds) / sizeof(scheds[0]));
         std::vector<std::vector<double> > schedCost(NS, std::vector<double>(maxDepth + 1, 0.0)), schedIters = schedCost, schedLane = schedCost;
         for (uint64_t seg = 0; seg < nSeg; seg += segStride) {
@@ -310,6 +321,8 @@ int main(int argc, char **argv) {
         printf("  all depths: est VALU/ray %.0f\n", totalCost / totalRays);
         for (int k = 0; k < NS; ++k) { double c = 0; printf("  schedule %-52s VALU/ray by depth:", scheds[k].name); for (int d = 1; d <= maxDepth; ++d) { c += schedCost[k][d]; printf(" %6.0f (eff %2.0f%%)", schedCost[k][d] / std::max(1.0, S[d].rays), 100 * schedLane[k][d] / std::max(1.0, schedIters[k][d] * 64)); } printf("  | all %.0f\n", c / totalRays); }
     }
+    { std::vector<double> v = nodeVisits; std::sort(v.begin(), v.end(), [](double a, double b) { return a > b; }); double tot = 0; for (double x : v) tot += x; double acc = 0; printf("\nshare of node visits that go to the K most visited nodes:\n");
+      for (size_t i = 0; i < v.size(); ++i) { acc += v[i]; if (i + 1 == 16 || i + 1 == 32 || i + 1 == 64 || i + 1 == 85 || i + 1 == 128 || i + 1 == 192 || i + 1 == 256 || i + 1 == 341 || i + 1 == 512 || i + 1 == 1024 || i + 1 == 2048 || i + 1 == 4096) printf("  K = %4zu: %5.1f%%\n", i + 1, 100 * acc / tot); } }
     { double tot = 0, acc = 0; for (double v : depthHist) tot += v; printf("\nfused walk: deepest stack per ray (entries: share of rays, cumulative)\n"); for (int i = 0; i < 64; ++i) if (depthHist[i]) { acc += depthHist[i]; printf("  %2d: %8.5f%%  %9.5f%%\n", i, 100 * depthHist[i] / tot, 100 * acc / tot); } printf("builder's bound: %d\n", H.bvhStackDirect); }
     return 0;
 }
