@@ -69,6 +69,7 @@ struct mi_scene { mi::SceneHost h; };
 
 struct mi_render {
     mi_scene *scene = nullptr; mi_render_params p{}; RenderConst rc{};
+    DScene sc{};   // this render's view of the scene: the scene's record, with the triangle packet switched off for the volumetric integrators (their stages walk the tree, which every scene has)
     Queues q{}; std::vector<void *> allocs; uint64_t poolPaths = 0; uint32_t grid = 0, gridExtend = 0, gridShade = 0, gridShadow = 0;
     float *film = nullptr, *spill = nullptr; size_t filmFloats = 0; float *layoutTmp = nullptr, *mergeTmp = nullptr;   // mergeTmp: staging for another device's film (mi_render_merge_film)   // film: own-pixel sums; spill: cross-pixel splats (atomics)
     hipStream_t stream = nullptr; hipEvent_t evBegin = nullptr, evEnd = nullptr;
@@ -469,9 +470,9 @@ static int allocQ(std::vector<void *> &allocs, void **p, size_t bytes) {
 }
 #define ALLOC(ptr, type, count) do { void *p_ = nullptr; int rc_ = allocQ(allocs, &p_, sizeof(type) * (size_t) (count)); if (rc_) return rc_; ptr = (type *) p_; } while (0)
 
+static void freePoolQ(Queues &Q, std::vector<void *> &allocs) { for (void *p : allocs) (void) hipFree(p); allocs.clear(); Q = Queues{}; }      // no dangling queue pointer survives
+// allocates the queues of ONE pool into an empty Q (freePoolQ first); on failure the caller releases whatever was allocated
 static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void *> &allocs) {
-    for (void *p : allocs) (void) hipFree(p);
-    allocs.clear();
     auto envU = [](const char *name, uint32_t dflt) { const char *v = getenv(name); return v && v[0] ? (uint32_t) atoi(v) : dflt; };
     // segments of the path pool (each owned by one wave in the shade stage): 16384, or -- where the shade stage sorts a segment's paths by material class and its
     // index list must fit LDS -- as many as keep a segment at ~1000 slots (C3 at 64 M paths: 1916 Msamples/s with 16384 segments, 1983 with 65536)
@@ -479,7 +480,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     uint64_t minGrid = (paths + 63) / 64; if (grid > minGrid) grid = (uint32_t) std::max<uint64_t>(minGrid, 1);
     if (r->rc.integrator != MI_INTEGRATOR_PATH && (paths + grid - 1) / grid > 65472u) grid = (uint32_t) ((paths + 65471u) / 65472u);      // the volumetric stages count two kinds of shadow records per segment in 16 bits each
     uint64_t cap = (paths + grid - 1) / grid; cap = (cap + 63) / 64 * 64;
-    r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid; r->poolPaths = paths;
+    r->grid = grid; Q.cap = (uint32_t) cap; Q.n_seg = grid;
     // workgroups launched per stage (each walks segments b, b + grid, ...): sized to the stage's occupancy on 256 CUs
     r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", r->scene->h.d.has_roughconductor ? 512u : 768u));      // 3 workgroups per CU since the diffuse kernels hold 4 waves per SIMD (C2: 512 -> 2970, 640 -> 3022, 768 -> 3078, 896 -> 2890 Msamples/s); the 2-wave microfacet kernels stay at 2
     r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
@@ -508,13 +509,25 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     HIPCHK(hipMemset(Q.counters, 0, 32));
     return MI_OK;
 }
+// (Re)allocates every pool for `paths` paths.  The ray counters survive (they are cleared by mi_render_clear only).  Nothing is valid until ALL pools are
+// allocated: on any failure every pool is released, every queue pointer nulled and poolPaths = 0, so a later run / samples call allocates afresh instead of
+// launching on freed buffers; the counters saved before the release move into the handle's merged totals.
 static int allocPool(mi_render *r, uint64_t paths) {
-    for (int i = 0; i < r->nStreams; ++i) {
-        Queues &Q = r->pool(i); unsigned long long keep[4] = {0, 0, 0, 0};      // ray counters survive a re-allocation (they are cleared by mi_render_clear only)
-        if (Q.counters) (void) hipMemcpy(keep, Q.counters, 32, hipMemcpyDeviceToHost);
-        int rc = allocPoolQ(r, paths, Q, i ? r->allocsx[i - 1] : r->allocs); if (rc) return rc;
-        HIPCHK(hipMemcpy(Q.counters, keep, 32, hipMemcpyHostToDevice));
+    unsigned long long keep[mi_render::kMaxPools][4] = {};
+    for (int i = 0; i < r->nStreams; ++i) { Queues &Q = r->pool(i); if (Q.counters && hipMemcpy(keep[i], Q.counters, 32, hipMemcpyDeviceToHost) != hipSuccess) { (void) hipGetLastError(); memset(keep[i], 0, 32); } }
+    r->poolPaths = 0;
+    for (int i = 0; i < r->nStreams; ++i) freePoolQ(r->pool(i), i ? r->allocsx[i - 1] : r->allocs);
+    int rc = MI_OK;
+    for (int i = 0; i < r->nStreams && !rc; ++i) {
+        rc = allocPoolQ(r, paths, r->pool(i), i ? r->allocsx[i - 1] : r->allocs);
+        if (!rc && hipMemcpy(r->pool(i).counters, keep[i], 32, hipMemcpyHostToDevice) != hipSuccess) rc = fail(MI_ERR_DEVICE, "mi_render_run: cannot restore the ray counters");
     }
+    if (rc) {
+        (void) hipGetLastError();
+        for (int i = 0; i < r->nStreams; ++i) { freePoolQ(r->pool(i), i ? r->allocsx[i - 1] : r->allocs); r->mergedRays += keep[i][0]; r->mergedShadow += keep[i][1]; r->mergedPathLen += keep[i][2]; }
+        return rc;
+    }
+    r->poolPaths = paths;
     return MI_OK;
 }
 
@@ -543,7 +556,6 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
             }
             if (bad) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: volpath_simple / volpath with a null / thindielectric BSDF inside a bumpmap / normalmap is not implemented");
         }
-        if (s->h.d.packet_n) return fail(MI_ERR_INVALID, "mi_render_create: the volumetric integrators need the tree traversal (scenes with media always have it; set MI355PT_NO_PACKET=1 for a scene without media)");
         if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth beyond 250");
     }
     if (p->sampler == MI_SAMPLER_SOBOL) {
@@ -558,6 +570,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     }
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
+    r->sc = s->h.d; if (vol) r->sc.packet_n = 0;      // packet or tree is decided per render: volpath / volpath_simple on a <= 64-triangle scene without media walk its tree
     struct Guard { mi_render *r; ~Guard() { if (r) mi_render_destroy(r); } } guard{r};      // every early return below releases what was created so far
     r->rc.max_depth = p->max_depth; r->rc.rr_depth = p->rr_depth; r->rc.strict_normals = p->strict_normals; r->rc.hide_emitters = p->hide_emitters; r->rc.opacity = p->opacity;
     r->rc.sobol_scramble = 0;
@@ -670,7 +683,7 @@ static void mark(mi_render *r, int tag, size_t &used, hipStream_t st = nullptr) 
 
 // trace one batch: paths = tile pixels x planes (or an explicit list), all bounces
 static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, size_t &evUsed, int pool = 0) {
-    const DScene &sc = r->scene->h.d; hipStream_t st = r->poolStream(pool); Queues &Q = r->pool(pool);
+    const DScene &sc = r->sc; hipStream_t st = r->poolStream(pool); Queues &Q = r->pool(pool);
     (void) list;
     mark(r, 0, evUsed, st);
     const bool fused = r->rc.integrator == MI_INTEGRATOR_PATH && mi_fused_walk(sc);      // trace_fused.h: persistent waves fetch segments through per-launch tickets
@@ -835,6 +848,7 @@ int mi_render_samples(mi_render *r, const uint32_t *pairs, uint64_t n, float *ou
     HIPCHK(hipMemcpy(dSlots, slots.data(), n * 4, hipMemcpyHostToDevice));
     BatchDesc bd{}; bd.tile = mi_tile{0, 0, h.width, h.height}; bd.n_pix = (uint32_t) n; bd.n_planes = 1; bd.sample_begin = 0; bd.n_paths = n; bd.list = dList; bd.row_stride = 1;
     size_t evUsed = 0; bool prof = r->profiling; r->profiling = false;
+    if (!r->q.counters) return fail(MI_ERR_DEVICE, "mi_render_samples: no path pool");
     unsigned long long keep[4]; HIPCHK(hipMemcpy(keep, r->q.counters, 32, hipMemcpyDeviceToHost));     // the parity entry point leaves the ray counters untouched
     int rc = traceBatch(r, bd, dList, evUsed); r->profiling = prof;
     if (!rc) { hipError_t e = hipStreamSynchronize(r->stream); if (e == hipSuccess) e = hipMemcpy(r->q.counters, keep, 32, hipMemcpyHostToDevice); if (e != hipSuccess) rc = fail(MI_ERR_DEVICE, hipGetErrorString(e)); }

@@ -9,6 +9,13 @@ from tests.conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
+def bit_share(got, ref, tag):
+    """share of samples whose three channels equal the oracle's bit for bit; printed (pytest -s) so that the floors asserted in the tests can be checked against measured values"""
+    share = float((bits(got) == bits(ref)).all(1).mean())
+    print(f"[bit-share] {tag}: {share:.4f}")
+    return share
+
+
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -356,7 +363,7 @@ def test_analytic_shapes(mi, oracle, golden_scenes, name, bvh, monkeypatch):
         assert (bits(got) == bits(ref)).all()
     else:
         err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and (bits(got) == bits(ref)).all(1).mean() > 0.7
+        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and bit_share(got, ref, "analytic_shapes " + name) > 0.7
     err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
     assert (err < 1e-4).mean() > 0.99 and (err < 5e-3).mean() > 0.998 and np.median(err) < 1e-6
     # whole film + the ray counters
@@ -437,7 +444,7 @@ def test_instances(mi, oracle, golden_scenes):
     pairs = np.stack([rng.integers(0, sc.width, 20000), rng.integers(0, sc.height, 20000), rng.integers(0, sc.spp, 20000)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    assert (bits(got) == bits(ref)).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    assert bit_share(got, ref, "instances") > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
@@ -748,7 +755,7 @@ def test_thin_dielectric(mi, oracle, golden_scenes, name):
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)          # the gold sphere's rough conductor goes through the device math library
-    assert (bits(got) == bits(ref)).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
+    assert bit_share(got, ref, "thin_dielectric " + name) > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
@@ -773,7 +780,7 @@ def test_mask(mi, oracle, golden_scenes, name):
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    assert (bits(got) == bits(ref)).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0, ((bits(got) == bits(ref)).all(1).mean(), (err < 1e-4).mean())
+    assert bit_share(got, ref, "mask " + name) > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
@@ -956,7 +963,7 @@ def test_both_tree_node_kinds(mi, golden_scenes, name, monkeypatch):
     if name in ("atrium_small", "bunny_box"):        # atrium: the lat-long lookups use the device's atan2 / acos (test_envmap_atrium) -> not every sample bit-equal
         st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
         err = np.abs(got["wide"] - st["li"]).max(1) / (np.abs(st["li"]).max(1) + 1e-6)
-        assert (bits(got["wide"]) == bits(st["li"])).all(1).mean() > 0.7 and (err < 1e-4).mean() > 0.99
+        assert bit_share(got["wide"], st["li"], "tree_node_kinds " + name) > 0.7 and (err < 1e-4).mean() > 0.99
 
 
 @pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis"])
@@ -1052,17 +1059,14 @@ def test_volpath_simple_refusals(mi, golden_scenes):
     sc = golden_scenes["open_constant"]
     with pytest.raises(RuntimeError, match="integrators path"):
         mi.Render(mi.Scene(golden_scenes["cornell_small"]), integrator=7)
-    # a scene without media through the volumetric loop = the same estimator without MIS: converges to the same image (loose check on the mean)
-    os.environ["MI355PT_NO_PACKET"] = "1"
-    try:
-        sc = S.cornell_box(64, 36, 64); gs = mi.Scene(sc)
-        a = mi.Render(gs); a.run(); b = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE); b.run(); c = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH); c.run()
-        fa, fb, fc = a.read_film(0), b.read_film(0), c.read_film(0)
-        assert abs(fa[..., :3].mean() - fb[..., :3].mean()) / fa[..., :3].mean() < 0.05
-        # ... and volpath without media IS path: same sampler requests, same estimator (volpath.cpp vs path.cpp) -> the same film up to the operation order of the weights
-        assert np.linalg.norm(fa[..., :3] - fc[..., :3]) / np.linalg.norm(fa[..., :3]) < 1e-5
-    finally:
-        del os.environ["MI355PT_NO_PACKET"]
+    # a scene without media through the volumetric loop = the same estimator without MIS: converges to the same image (loose check on the mean).  The Cornell box
+    # commits as a triangle packet; the volumetric stages walk its tree instead (decided per render, no environment switch needed)
+    sc = S.cornell_box(64, 36, 64); gs = mi.Scene(sc)
+    a = mi.Render(gs); a.run(); b = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH_SIMPLE); b.run(); c = mi.Render(gs, integrator=S.INTEGRATOR_VOLPATH); c.run()
+    fa, fb, fc = a.read_film(0), b.read_film(0), c.read_film(0)
+    assert abs(fa[..., :3].mean() - fb[..., :3].mean()) / fa[..., :3].mean() < 0.05
+    # ... and volpath without media IS path: same sampler requests, same estimator (volpath.cpp vs path.cpp) -> the same film up to the operation order of the weights
+    assert np.linalg.norm(fa[..., :3] - fc[..., :3]) / np.linalg.norm(fa[..., :3]) < 1e-5
 
 
 @pytest.mark.parametrize("integrator", ["volpath_simple", "volpath"])
@@ -1114,3 +1118,14 @@ def test_batch_size_falls_back_when_memory_is_short(mi, monkeypatch):
     monkeypatch.setenv("MI355PT_POOL_LIMIT", "1000")                          # nothing fits: the error of the last attempt comes back
     with pytest.raises(RuntimeError, match="MI355PT_POOL_LIMIT"):
         mi.Render(gs).run()
+    # a handle that HAS pools and then fails to grow them: no queue pointer survives the failed re-allocation -- the next run allocates afresh, the film and the
+    # ray counters are those of an undisturbed render (the retry used to leave freed buffers behind)
+    monkeypatch.delenv("MI355PT_POOL_LIMIT")
+    c = mi.Render(gs, planes_per_batch=1); c.run(s1=1); first = c.stats()["rays"]; assert first > 0
+    monkeypatch.setenv("MI355PT_POOL_LIMIT", "1000")
+    with pytest.raises(RuntimeError, match="MI355PT_POOL_LIMIT"):
+        c.samples(np.asarray([[x % 640, (x // 640) % 360, 0] for x in range(640 * 360 * 2)], np.uint32))      # more paths than the pool holds -> re-allocation -> refused
+    assert c.stats()["rays"] == first                                         # the counters of the released pools are kept
+    monkeypatch.delenv("MI355PT_POOL_LIMIT")
+    c.clear(); c.run(); fc = c.read_film(0)
+    assert (bits(fa) == bits(fc)).all() and c.stats()["rays"] == a.stats()["rays"]
