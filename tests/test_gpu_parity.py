@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 def bit_share(got, ref, tag):
     """share of samples whose three channels equal the oracle's bit for bit; printed (pytest -s) so that the floors asserted in the tests can be checked against measured values"""
     share = float((bits(got) == bits(ref)).all(1).mean())
-    print(f"[bit-share] {tag}: {share:.4f}")
-    return share
+    print(f"[bit-share] {tag}: {share:.4f}")      # round 3 on MI355X: analytic_shapes 0.9897 / 0.9956, instances 0.9957, thin_dielectric 0.9887 / 0.9922, mask 0.9942 / 0.9932,
+    return share                                   # tree_node_kinds atrium_small 0.8276 (envmap: device atan2 / acos, DESIGN.md section 4) / bunny_box 1.0 -- the floors asserted sit just under these
 
 
 def bits(a):
@@ -363,7 +363,7 @@ def test_analytic_shapes(mi, oracle, golden_scenes, name, bvh, monkeypatch):
         assert (bits(got) == bits(ref)).all()
     else:
         err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and bit_share(got, ref, "analytic_shapes " + name) > 0.7
+        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and bit_share(got, ref, "analytic_shapes " + name) > 0.98      # measured 0.9897 / 0.9956 (round 3); the rest: the cone / sphere sampling maps go through the device library's sincos / acos
     err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
     assert (err < 1e-4).mean() > 0.99 and (err < 5e-3).mean() > 0.998 and np.median(err) < 1e-6
     # whole film + the ray counters
@@ -444,7 +444,7 @@ def test_instances(mi, oracle, golden_scenes):
     pairs = np.stack([rng.integers(0, sc.width, 20000), rng.integers(0, sc.height, 20000), rng.integers(0, sc.spp, 20000)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    assert bit_share(got, ref, "instances") > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    assert bit_share(got, ref, "instances") > 0.99 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
@@ -755,7 +755,7 @@ def test_thin_dielectric(mi, oracle, golden_scenes, name):
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)          # the gold sphere's rough conductor goes through the device math library
-    assert bit_share(got, ref, "thin_dielectric " + name) > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
+    assert bit_share(got, ref, "thin_dielectric " + name) > 0.98 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
@@ -780,7 +780,7 @@ def test_mask(mi, oracle, golden_scenes, name):
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    assert bit_share(got, ref, "mask " + name) > 0.7 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
+    assert bit_share(got, ref, "mask " + name) > 0.99 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
@@ -963,7 +963,7 @@ def test_both_tree_node_kinds(mi, golden_scenes, name, monkeypatch):
     if name in ("atrium_small", "bunny_box"):        # atrium: the lat-long lookups use the device's atan2 / acos (test_envmap_atrium) -> not every sample bit-equal
         st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
         err = np.abs(got["wide"] - st["li"]).max(1) / (np.abs(st["li"]).max(1) + 1e-6)
-        assert bit_share(got["wide"], st["li"], "tree_node_kinds " + name) > 0.7 and (err < 1e-4).mean() > 0.99
+        assert bit_share(got["wide"], st["li"], "tree_node_kinds " + name) > {"atrium_small": 0.80, "bunny_box": 0.999}[name] and (err < 1e-4).mean() > 0.99
 
 
 @pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis"])
