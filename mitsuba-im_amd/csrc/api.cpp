@@ -485,6 +485,7 @@ static int allocPoolQ(mi_render *r, uint64_t paths, Queues &Q, std::vector<void 
     r->gridExtend = std::min(grid, envU("MI355PT_GRID_EXTEND", 4096u)); r->gridShade = std::min(grid, envU("MI355PT_GRID_SHADE", r->scene->h.d.has_roughconductor ? 512u : 768u));      // 3 workgroups per CU since the diffuse kernels hold 4 waves per SIMD (C2: 512 -> 2970, 640 -> 3022, 768 -> 3078, 896 -> 2890 Msamples/s); the 2-wave microfacet kernels stay at 2
     r->gridShadow = std::min(grid, envU("MI355PT_GRID_SHADOW", 4096u));
     const uint64_t slots = cap * grid;
+    if (slots >= (1ull << 28)) return fail(MI_ERR_INVALID, "mi_render_run: a path pool holds fewer than 2^28 slots (the stages address the queues through 32-bit byte offsets); lower planes_per_batch");
     {   // MI355PT_POOL_LIMIT (bytes per pool; tests): behave as if the card had no more room than this -- mi_render_run then falls back to smaller batches
         const char *lim = getenv("MI355PT_POOL_LIMIT");
         if (lim && atoll(lim) > 0 && slots * 224ull > (uint64_t) atoll(lim)) return fail(MI_ERR_DEVICE, "mi_render_run: path pool larger than MI355PT_POOL_LIMIT");
@@ -602,13 +603,13 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         if (vol) perBounceDims += 2;
         uint32_t sppBits = 0; while ((1ull << sppBits) < p->spp) ++sppBits;
         const uint32_t bits = (s->h.logRes > 1 ? 2 * s->h.logRes : 0) + sppBits + 1;
-        const uint32_t nibs = std::max<uint32_t>(1, (bits + 3) / 4), dims = std::min<uint32_t>(s->h.d.sobol_dims, (uint32_t) (4 + perBounceDims * p->max_depth));
+        const uint32_t nibs = std::max<uint32_t>(8, (bits + 3) / 4), dims      /* at least the eight nibbles of the low index word (pt_device.h sobolBitsNib unrolls them) */ = std::min<uint32_t>(s->h.d.sobol_dims, (uint32_t) (4 + perBounceDims * p->max_depth));
         std::vector<uint32_t> nib((size_t) dims * nibs * 16);
         for (uint32_t dmn = 0; dmn < dims; ++dmn) for (uint32_t n = 0; n < nibs; ++n) for (uint32_t v = 0; v < 16; ++v) {
             uint32_t x = 0; for (uint32_t b = 0; b < 4; ++b) if (((v >> b) & 1u) && 4 * n + b < MI_SOBOL_SIZE) x ^= g_sobolM32[(size_t) dmn * MI_SOBOL_SIZE + 4 * n + b];
             nib[((size_t) dmn * nibs + n) * 16 + v] = x;
         }
-        if ((size_t) dims * nibs * 64 + 64 > 64 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the Sobol lookup tables (maxDepth x index bits) exceed the 64 KB of LDS a workgroup may request (reduce maxDepth or spp)");
+        if ((size_t) dims * nibs * 64 + 64 > 144 * 1024) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the Sobol lookup tables (maxDepth x index bits) exceed the 144 KB of LDS the shading stage may request (reduce maxDepth or spp)");
         HIPCHK(hipMalloc((void **) &r->dNib, nib.size() * 4)); HIPCHK(hipMemcpy(r->dNib, nib.data(), nib.size() * 4, hipMemcpyHostToDevice));
         r->rc.sobol_nib = r->dNib; r->rc.nib_count = nibs; r->rc.nib_dims = dims;
         // look_up tables of k_generate.  index(frame, px, py) = (frame << 2m) ^ Inv * ((px << m | py) ^ Delta * frame)  (sobolseq.h:99-131, all XOR-linear) =

@@ -14,3 +14,11 @@
 
 #define WG 256
 #define STACK_DEPTH 32   // >= BVH depth (scene_build.cpp caps it; mi_scene_commit refuses deeper trees)
+
+// Launch with `lds` bytes of dynamic LDS.  gfx950 has 160 KB per CU; beyond the 64 KB a launch may request by default the kernel is told so first
+// (deep maxDepth x many Sobol index bits: the lookup tables alone can pass 64 KB).
+template <typename K, typename... A>
+static inline void launchWithLds(K kernel, uint32_t grid, size_t lds, hipStream_t st, A... args) {
+    if (lds > 64 * 1024) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(WG), lds, st, args...);
+}

@@ -402,9 +402,9 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
 extern "C" {
 void mi_launch_shade_volmis(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool env = sc.env_index >= 0;
-    if (sc.has_adapters & 1u) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, true>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
-    else if (sc.n_textures) { if (env) hipLaunchKernelGGL((k_shade_volmis<true, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<true, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
-    else { if (env) hipLaunchKernelGGL((k_shade_volmis<false, true, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); else hipLaunchKernelGGL((k_shade_volmis<false, false, false>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); }
+    if (sc.has_adapters & 1u) { if (env) launchWithLds(k_shade_volmis<true, true, true>, grid, lds, st, sc, rc, q, buf); else launchWithLds(k_shade_volmis<true, false, true>, grid, lds, st, sc, rc, q, buf); }
+    else if (sc.n_textures) { if (env) launchWithLds(k_shade_volmis<true, true, false>, grid, lds, st, sc, rc, q, buf); else launchWithLds(k_shade_volmis<true, false, false>, grid, lds, st, sc, rc, q, buf); }
+    else { if (env) launchWithLds(k_shade_volmis<false, true, false>, grid, lds, st, sc, rc, q, buf); else launchWithLds(k_shade_volmis<false, false, false>, grid, lds, st, sc, rc, q, buf); }
 }
 void mi_launch_shadow_volmis(const DScene &sc, const Queues &q, uint32_t grid, hipStream_t st) {
     const bool env = sc.env_index >= 0;

@@ -52,14 +52,20 @@ typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;   // expl
 template <typename P> struct SobolTabT { P tab; uint32_t nibs; uint32_t scramble; };
 typedef SobolTabT<const uint32_t *> SobolTab;       // global memory
 typedef SobolTabT<lds_u32_ptr> SobolTabLds;         // LDS copy
+// nibs >= 8 always (mi_render_create pads with empty tables: entry 0 of a nibble table is 0, and index bits the render never sets read entry 0), so the eight
+// nibbles of the low index word are eight independent lookups at compile-time offsets -- no loop, no dependent chain (a v_bfe + v_lshl_add per nibble, ds_read with
+// an immediate offset, v_xor3) -- and the nibble extraction is shared between the two dimensions of a 2-D request.
+template <typename P>
+DEV uint32_t sobolBitsNib(SobolTabT<P> st, uint32_t lo, uint32_t hi, uint32_t dim) {
+    P T = st.tab + dim * st.nibs * 16u;
+    uint32_t result = (st.scramble ^ T[lo & 15u] ^ T[16u + ((lo >> 4) & 15u)]) ^ (T[32u + ((lo >> 8) & 15u)] ^ T[48u + ((lo >> 12) & 15u)] ^ T[64u + ((lo >> 16) & 15u)])
+                    ^ (T[80u + ((lo >> 20) & 15u)] ^ T[96u + ((lo >> 24) & 15u)] ^ T[112u + (lo >> 28)]);
+    for (uint32_t n = 8; n < st.nibs; ++n) result ^= T[n * 16u + ((hi >> (4u * (n - 8u))) & 15u)];
+    return result;
+}
 template <typename P>
 DEV float sobolSampleNib(SobolTabT<P> st, uint32_t lo, uint32_t hi, uint32_t dim) {
-    P T = st.tab + dim * st.nibs * 16u;
-    uint32_t result = st.scramble;
-    const uint32_t nlo = st.nibs < 8u ? st.nibs : 8u;
-    for (uint32_t n = 0; n < nlo; ++n) result ^= T[n * 16u + ((lo >> (4u * n)) & 15u)];
-    for (uint32_t n = 8; n < st.nibs; ++n) result ^= T[n * 16u + ((hi >> (4u * (n - 8u))) & 15u)];
-    return minf((float) result * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
+    return minf((float) sobolBitsNib(st, lo, hi, dim) * (1.0f / 4294967296.0f), MI_ONE_MINUS_EPS);
 }
 // Scene tables as seen by the shading kernel: either the global-memory arrays or (small scenes) a copy staged in LDS.  The pointer types
 // carry the address space so that the LDS variant compiles to ds_read instead of flat loads.

@@ -26,6 +26,12 @@ struct Queues {
     uint32_t n_seg;                             // number of segments
 };
 
+// Element i of a queue array through a 32-bit BYTE offset: the address is base (a uniform pointer: SGPR pair) + a 32-bit vector offset, one shift instead of the
+// 64-bit shift-and-add per access that `base[i]` costs with a 64-bit index -- integer vector operations issue at half the rate of fp32 multiply-adds on gfx950
+// (scripts/ubench/valu_rates.hip), and the shade stage touches ~20 arrays per path.  Holds while a pool has fewer than 2^28 slots (allocPoolQ enforces it).
+template <typename T> __device__ __forceinline__ T &qat(T *base, uint32_t i) { return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (uint32_t) (i * (uint32_t) sizeof(T))); }
+template <typename T> __device__ __forceinline__ const T &qat(const T *base, uint32_t i) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t) (i * (uint32_t) sizeof(T))); }
+
 struct BatchDesc {
     mi_tile tile; uint32_t n_pix; uint32_t n_planes; uint32_t sample_begin; uint64_t n_paths;
     uint32_t row_stride;    // film rows of the tile: y0, y0 + row_stride, ... (1 = contiguous rectangle; N = rows interleaved over N ranks)

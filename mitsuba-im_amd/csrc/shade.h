@@ -52,14 +52,14 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t seg = blockIdx.x * (WG / 64) + wave; seg < q.n_seg; seg += gridDim.x * (WG / 64)) {
     const uint32_t n = q.count[buf][seg];
-    const uint64_t segBase = (uint64_t) seg * q.cap;
+    const uint32_t segBase = seg * q.cap;                    // (a pool has fewer than 2^28 slots: queues.h qat)
     uint32_t outA = 0, outS = 0;                             // survivors / shadow records written so far (uniform)
     uint32_t done0 = 0, done1 = 0;                           // uniform running counts (front / back)
     if (doSort) {
         for (uint32_t base = 0; base < n; base += 64) {
             const uint32_t i = base + lane; int cls = 2;
             if (i < n) {
-                const uint32_t prim = __float_as_uint(q.hit[segBase + i].w);
+                const uint32_t prim = __float_as_uint(qat(q.hit, segBase + i).w);
                 if (prim == 0xFFFFFFFFu) cls = 0;
                 else if (AN && prim >= sc.n_tris) cls = (sc.analytic[prim - sc.n_tris].flags & 8u) ? 1 : 0;
                 else cls = (__float_as_uint(tb.shade4[prim * 6u + 2u].w) & 8u) ? 1 : 0;
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false; bool bumped = false; v3 bps = V(0, 0, 0), bpt = bps, bpn = bps;   // bumpmap / normalmap: perturbed frame (RC variants)
           // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
         if (i < n) {
-            const uint64_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
-            float4 rd = q.rayD[buf][slot], hr = q.hit[slot]; uint4 s0 = q.st0[buf][slot]; float4 s1 = q.st1[buf][slot];
-            float prevPdf = q.st2[buf][slot];
+            const uint32_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
+            float4 rd = qat(q.rayD[buf], slot), hr = qat(q.hit, slot); uint4 s0 = qat(q.st0[buf], slot); float4 s1 = qat(q.st1[buf], slot);
+            float prevPdf = qat(q.st2[buf], slot);
             pid = s0.x; ss.a = s0.y; ss.b = s0.z; ss.dim = s0.w & 0xFFu;
             depth = (int) ((s0.w >> 8) & 0xFFu); const bool facingRef = ((s0.w >> 16) & 1u) != 0;
             const bool prevDelta = RC && ((s0.w >> 17) & 1u) != 0;      // the BSDF sample that spawned this ray was a delta component -> lumPdf = 0 (path.cpp:259-260)
@@ -94,17 +94,17 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             do {
                 if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :234-248
                     pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
-                    if (depth == 1 && rc.opacity) { float4 a = q.acc[pid]; a.w = 0.0f; q.acc[pid] = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
+                    if (depth == 1 && rc.opacity) { float4 a = qat(q.acc, pid); a.w = 0.0f; qat(q.acc, pid) = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
                     if (ENV) {
                         if (depth == 1) { if (!rc.hide_emitters && !sc.env_texture) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141; with a MIP pyramid k_env_primary has added the filtered lookup
                         else {
                             // BSDF ray left the scene: env->evalEnvironment + fillDirectSamplingRecord (envmap.cpp:362-378), MIS term path.cpp:257-264
-                            float4 ro = q.rayO[buf][slot]; float nearT, farT;
+                            float4 ro = qat(q.rayO[buf], slot); float nearT, farT;
                             if (!(rc.hide_emitters && unscattered) && bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {   // path.cpp:238-239: hideEmitters && !scattered
                                 v3 value = envEval(sc, d);
                                 float pdfSA;
                                 if (sc.env_constant) {      // ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233): needs the reference normal of the previous vertex
-                                    const float c = q.st3[buf][slot]; pdfSA = c != 2.0f ? MI_INV_PI * maxf(0.0f, c) : MI_INV_FOURPI;
+                                    const float c = qat(q.st3[buf], slot); pdfSA = c != 2.0f ? MI_INV_PI * maxf(0.0f, c) : MI_INV_FOURPI;
                                 } else pdfSA = envPdfDirection(sc, mat3(sc.env_to_local, d));
                                 float lumPdf = prevDelta ? 0.0f : pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
                                 add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     break;
                 }
                 v3 ro3 = V(0, 0, 0);
-                if (AN) { float4 ro = q.rayO[buf][slot]; ro3 = V(ro.x, ro.y, ro.z); }      // analytic shapes: hit point = o + t d; sphere lights: reference point of pdfDirect
-                const int inst = (AN && q.hitInst) ? q.hitInst[slot] : -1;
+                if (AN) { float4 ro = qat(q.rayO[buf], slot); ro3 = V(ro.x, ro.y, ro.z); }      // analytic shapes: hit point = o + t d; sphere lights: reference point of pdfDirect
+                const int inst = (AN && q.hitInst) ? qat(q.hitInst, slot) : -1;
                 if (AN && inst >= 0) fillHitInstanced(sc, tb, sc.instances[inst], ro3, d, hr.x, prim, hr.y, hr.z, h);
                 else if (AN && prim >= sc.n_tris) fillHitAnalytic(sc.analytic[prim - sc.n_tris], ro3, d, hr.x, hr.y, hr.z, h);
                 else fillHit<SMALL, AN>(sc, tb, d, hr.x, prim, hr.y, hr.z, h);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                                 else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
                                 else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                                 if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
-                                const float2 sp = q.pos[pid]; v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
+                                const float2 sp = qat(q.pos, pid); v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
                                 float pa[4]; computePartials(h.p, h.ng, dpdu, dpdv, ro3, rxd, ryd, pa);
                                 c = mipEval(sc, tx, uvx, uvy, pa[0] * tx.uscale, pa[1] * tx.vscale, pa[2] * tx.uscale, pa[3] * tx.vscale);
                             } else c = tx.filter != 0u ? mipBilinear(sc, tx, 0, uvx, uvy) : mipBox(sc, tx, 0, uvx, uvy);
@@ -204,13 +204,13 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 }
                 toSample = true;
             } while (false);
-            if (haveAdd) { float4 a = q.acc[pid]; a.x += add.x; a.y += add.y; a.z += add.z; q.acc[pid] = a; }
+            if (haveAdd) { float4 a = qat(q.acc, pid); a.x += add.x; a.y += add.y; a.z += add.z; qat(q.acc, pid) = a; }
         }
         // wave64 ballots: order-preserving compaction inside the (wave-owned) segment
         const unsigned long long mS = __ballot(wantShadow);
         if (wantShadow) {
-            const uint64_t o = segBase + outS + (uint32_t) __popcll(mS & lt);
-            q.shO[o] = shO; q.shD[o] = shD; q.shC[o] = shC;
+            const uint32_t o = segBase + outS + (uint32_t) __popcll(mS & lt);
+            qat(q.shO, o) = shO; qat(q.shD, o) = shD; qat(q.shC, o) = shC;
         }
         outS += (uint32_t) __popcll(mS);
         float4 nrO, nrD, nS1; uint4 nS0; float nS2 = 0, nS3 = 0;
@@ -252,9 +252,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
         }
         const unsigned long long mA = __ballot(alive);
         if (alive) {
-            const uint64_t o = segBase + outA + (uint32_t) __popcll(mA & lt);
-            q.rayO[nb][o] = nrO; q.rayD[nb][o] = nrD; q.st0[nb][o] = nS0; q.st1[nb][o] = nS1; q.st2[nb][o] = nS2;
-            if (ENV && sc.env_constant) q.st3[nb][o] = nS3;
+            const uint32_t o = segBase + outA + (uint32_t) __popcll(mA & lt);
+            qat(q.rayO[nb], o) = nrO; qat(q.rayD[nb], o) = nrD; qat(q.st0[nb], o) = nS0; qat(q.st1[nb], o) = nS1; qat(q.st2[nb], o) = nS2;
+            if (ENV && sc.env_constant) qat(q.st3[nb], o) = nS3;
         }
         outA += (uint32_t) __popcll(mA);
     }
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
 template <bool RC, bool ENV, bool WRAP>
 static void launchShadeVariant(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
     const bool small = sc.small_tables != 0;
-#define MI_SHADE(SM) do { if ((sc.ext || WRAP) && sc.n_textures) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, true, WRAP>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
-                          else if (sc.ext || WRAP) hipLaunchKernelGGL((k_shade<RC, ENV, SM, true, false, WRAP>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); \
-                          else hipLaunchKernelGGL((k_shade<RC, ENV, SM, WRAP, false, WRAP>), dim3(grid), dim3(WG), lds, st, sc, rc, q, buf); } while (0)
+#define MI_SHADE(SM) do { if ((sc.ext || WRAP) && sc.n_textures) launchWithLds(k_shade<RC, ENV, SM, true, true, WRAP>, grid, lds, st, sc, rc, q, buf); \
+                          else if (sc.ext || WRAP) launchWithLds(k_shade<RC, ENV, SM, true, false, WRAP>, grid, lds, st, sc, rc, q, buf); \
+                          else launchWithLds(k_shade<RC, ENV, SM, WRAP, false, WRAP>, grid, lds, st, sc, rc, q, buf); } while (0)
     if (small) MI_SHADE(true); else MI_SHADE(false);
 #undef MI_SHADE
 }
