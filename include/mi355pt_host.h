@@ -14,6 +14,8 @@ void *mi_host_create(int maxDepth, int rrDepth, int strictNormals, int hideEmitt
 /* the same with the build-specific `devices` property: the film rows are spread over these HIP devices (an entry may repeat); the scene given to
  * mi_host_preprocess must live on devices[0], the other devices receive replicas (mi_scene_clone) and their films are merged (mi_render_merge_film) */
 void *mi_host_create_devices(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, const uint32_t *devices, uint32_t n_devices, uint32_t planes_per_batch);
+/* everything at once: `integrator` = MI_INTEGRATOR_PATH / _VOLPATH_SIMPLE / _VOLPATH (the plugin's `integrator` property), preview_interval_ms < 0 = the default (100 ms) */
+void *mi_host_create_ex(int maxDepth, int rrDepth, int strictNormals, int hideEmitters, int sampler, uint32_t spp, uint64_t seed, const uint32_t *devices, uint32_t n_devices, uint32_t planes_per_batch, int integrator, double preview_interval_ms);
 void mi_host_destroy(void *integrator);
 int mi_host_preprocess(void *integrator, mi_scene *scene);
 /* Controls = {continu, abort, interrupt}: returns 0 done, -1 *abort set, -2 *continu cleared, otherwise progress()'s non-zero value;

@@ -67,7 +67,7 @@ EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_s
            "mi_scene_commit", "mi_scene_ray_intersect", "mi_scene_clone", "mi_render_merge_film", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
            "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays", "mi_debug_sincosf"]
-HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_create_devices", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
+HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_create_devices", "mi_host_create_ex", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
 
 
 def build(force=False):
@@ -314,3 +314,46 @@ class Render:
     def stats(self):
         s = MiStats(); self.L.check(self.L.L.mi_render_stats(self.h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in MiStats._fields_}
+
+
+class HostIntegrator:
+    """The product path as a reference user sees it: the C++ host mirror mi355::MIPathTracerHIP (csrc/integrator_host.h) behind its C shim (include/mi355pt_host.h).
+    face "classic" = Integrator::render as Scene::render drives it (no target, no controls: one submission); "responsive" = ResponsiveIntegrator::render with a target
+    film and a progress callback between submissions (src/mitsuba/im_render.cpp:103-222).  devices = HIP devices the film rows are spread over (entries may repeat)."""
+    _CB = C.CFUNCTYPE(C.c_int, C.c_double, C.c_void_p)
+
+    def __init__(self, scene, spp=None, devices=(0,), planes_per_batch=0, integrator=None, preview_interval_ms=-1.0, max_depth=None):
+        L = scene.L.L; self.L = L; self.scene = scene; sc = scene.sc
+        L.mi_host_create_ex.restype = C.c_void_p; L.mi_host_last_error.restype = C.c_char_p; L.mi_host_statistics.restype = C.c_char_p
+        L.mi_host_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_int, C.c_double]
+        L.mi_host_preprocess.argtypes = [C.c_void_p, C.c_void_p]; L.mi_host_destroy.argtypes = [C.c_void_p]; L.mi_host_statistics.argtypes = [C.c_void_p]
+        L.mi_host_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), self._CB, C.c_void_p, C.c_int, C.c_int]
+        dev = (C.c_uint32 * len(devices))(*devices)
+        self.spp = sc.spp if spp is None else spp
+        self.h = L.mi_host_create_ex(sc.max_depth if max_depth is None else max_depth, sc.rr_depth, sc.strict_normals, sc.hide_emitters, sc.sampler, self.spp, sc.seed, dev, len(devices),
+                                     planes_per_batch, int(sc.get("integrator", 0) or 0) if integrator is None else int(integrator), float(preview_interval_ms))
+        if not self.h:
+            raise RuntimeError(L.mi_host_last_error().decode())
+        if L.mi_host_preprocess(self.h, scene.h) != 0:
+            raise RuntimeError(L.mi_host_last_error().decode())
+        self.cont = C.c_int(1); self.abort = C.c_int(0); self.calls = 0
+
+    def render(self, face="classic", target=None):
+        """returns the integrator's return code (0 = all sample planes done)"""
+        if face == "classic":
+            return self.L.mi_host_render(self.h, None, None, None, self._CB(), None, 0, 1)
+
+        def progress(spp, user):
+            self.calls += 1; return 0
+        cb = self._CB(progress)
+        return self.L.mi_host_render(self.h, target.ctypes.data if target is not None else None, C.byref(self.cont), C.byref(self.abort), cb, None, 0, 1)
+
+    def statistics(self):
+        return (self.L.mi_host_statistics(self.h) or b"").decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_host_destroy(self.h); self.h = None
+
+    def __del__(self):
+        self.close()

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <set>
 #include "scene_host.h"
 #include "queues.h"
 
@@ -817,7 +819,8 @@ int mi_render_read_film(mi_render *r, int layout, float *host) {
 
 // dst += src (raw film sums: own-pixel planes and spill planes).  The merge step of a multi-device render, where every device renders its own rows of the
 // frame (mi_render_run_rows) into its own film: the reference merges worker blocks with Film::put under a mutex (src/librender/renderproc.cpp:142-149).
-// Same device: one add kernel; different devices: peer copy (xGMI) into a staging buffer on dst's device, then the add.  Both renders must be idle.
+// Same device: one add kernel; different devices: peer copy (xGMI, peer access enabled once per pair) into a staging buffer on dst's device, then the add; devices
+// without peer access: staged through the host.  Both renders must be idle.  The host mirror calls this along a reduction tree (integrator_host.cpp).
 int mi_render_merge_film(mi_render *dst, mi_render *src) {
     if (!dst || !src || dst == src) return fail(MI_ERR_INVALID, "mi_render_merge_film: two different render handles are needed");
     if (dst->filmFloats != src->filmFloats) return fail(MI_ERR_INVALID, "mi_render_merge_film: the two renders have different films");
@@ -825,9 +828,21 @@ int mi_render_merge_film(mi_render *dst, mi_render *src) {
     HIPCHK(hipSetDevice(dd));
     const float *sFilm = src->film, *sSpill = src->spill;
     if (dd != sd) {
+        // Peer access is set up once per (destination, source) pair: where the two devices can reach each other (xGMI inside a node) the add kernel's input is copied
+        // device to device; where they cannot, the film is staged through a host buffer -- never silently assumed.
         if (!dst->mergeTmp) HIPCHK(hipMalloc((void **) &dst->mergeTmp, 2 * n * 4));
-        HIPCHK(hipMemcpyPeerAsync(dst->mergeTmp, dd, src->film, sd, n * 4, dst->stream));
-        HIPCHK(hipMemcpyPeerAsync(dst->mergeTmp + n, dd, src->spill, sd, n * 4, dst->stream));
+        int can = 0; HIPCHK(hipDeviceCanAccessPeer(&can, dd, sd));
+        if (can) {
+            static std::mutex peerMutex; static std::set<std::pair<int, int> > enabled;
+            { std::lock_guard<std::mutex> l(peerMutex);
+              if (!enabled.count({dd, sd})) { hipError_t e = hipDeviceEnablePeerAccess(sd, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(MI_ERR_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e)); (void) hipGetLastError(); enabled.insert({dd, sd}); } }
+            HIPCHK(hipMemcpyPeerAsync(dst->mergeTmp, dd, src->film, sd, n * 4, dst->stream));
+            HIPCHK(hipMemcpyPeerAsync(dst->mergeTmp + n, dd, src->spill, sd, n * 4, dst->stream));
+        } else {
+            std::vector<float> host(2 * n);
+            HIPCHK(hipSetDevice(sd)); HIPCHK(hipMemcpy(host.data(), src->film, n * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(host.data() + n, src->spill, n * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipSetDevice(dd)); HIPCHK(hipMemcpy(dst->mergeTmp, host.data(), 2 * n * 4, hipMemcpyHostToDevice));
+        }
         sFilm = dst->mergeTmp; sSpill = dst->mergeTmp + n;
     }
     mi_launch_film_add(dst->film, sFilm, n, dst->stream); mi_launch_film_add(dst->spill, sSpill, n, dst->stream);

@@ -11,6 +11,7 @@
 // (adapter/path_hip.cpp) wraps it in the real mitsuba::Integrator / ResponsiveIntegrator classes.
 #pragma once
 #include <atomic>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,6 +28,7 @@ struct Properties {                 // the subset of mitsuba::Properties this in
     std::vector<uint32_t> devices;   // build-specific (SURVEY §8b `devices`): HIP devices to spread the film rows over; empty = {device}.  An entry may repeat (two
                                      // replicas on one GPU).  The scene handed to preprocess() lives on devices[0]; the others get clones (mi_scene_clone)
     int integrator = MI_INTEGRATOR_PATH;   // build-specific: MI_INTEGRATOR_VOLPATH_SIMPLE / MI_INTEGRATOR_VOLPATH = the loops of volpath_simple / volpath over the scene's participating media
+    double previewIntervalMs = 100.0;   // build-specific: the responsive face copies the film into its target at most this often between submissions (always after the last one); 0 = after every submission
     bool opacity = true;   // RadianceQueryRecord::EOpacity: the responsive drivers always request it (integrator.cpp:474)
 };
 
@@ -59,6 +61,7 @@ private:
     Properties m_props; mi_scene *m_scene = nullptr; mi_render *m_render = nullptr; std::string m_stats; int m_threads = 1;
     std::vector<mi_scene *> m_replicaScenes; std::vector<mi_render *> m_replicaRenders;   // devices[1..]: one scene clone + one render handle each, driven by one host thread each
     void releaseReplicas();
+    struct Workers; std::unique_ptr<Workers> m_workers;   // one persistent host thread per replica (multi-device renders)
     std::atomic<int> m_cancel{0};   // set by cancel(), reset at the start of render(): a cancel between two batches or two mi_render_run calls is never lost
 };
 

@@ -163,6 +163,27 @@ __device__ __noinline__ static float2 glibcSincosf2(float y) {
     return make_float2(sn, cs);
 }
 DEV void glibcSincosf(float y, float &sn, float &cs) { const float2 r = glibcSincosf2(y); sn = r.x; cs = r.y; }
+// The rest of libm the path calls, restated from glibc 2.35 like sincosf above (libm_glibc.h; every routine pinned against the host's libm by scripts/check_libm.c):
+// real function calls for the same reason as glibcSincosf2.  From here on the plain names mean these routines in all device code.
+#include "libm_glibc.h"
+__device__ __noinline__ static float miExpf(float x) { return mi_expf(x); }
+__device__ __noinline__ static float miLogf(float x) { return mi_logf(x); }
+__device__ __noinline__ static float miPowf(float x, float y) { return mi_powf(x, y); }
+__device__ __noinline__ static float miTanf(float x) { return mi_tanf(x); }
+__device__ __noinline__ static float miAtanf(float x) { return mi_atanf(x); }
+__device__ __noinline__ static float miAtan2f(float y, float x) { return mi_atan2f(y, x); }
+__device__ __noinline__ static float miAcosf(float x) { return mi_acosf(x); }
+DEV float miSinf(float x) { return glibcSincosf2(x).x; }      // glibc's sinf / cosf are sincosf's two halves (same polynomials, same reduction: scripts/check_sincosf.c)
+DEV float miCosf(float x) { return glibcSincosf2(x).y; }
+#define expf miExpf
+#define logf miLogf
+#define powf miPowf
+#define tanf miTanf
+#define atanf miAtanf
+#define atan2f miAtan2f
+#define acosf miAcosf
+#define sinf miSinf
+#define cosf miCosf
 // src/libcore/warp.cpp:81-101 squareToUniformDiskConcentric
 DEV void diskConcentric(float sx, float sy, float &ox, float &oy) {
     float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f, r, phi, sn, cs;
@@ -339,7 +360,7 @@ DEV v3 mipEval(const DScene &sc, const TextureD &t, float uvx, float uvy, float 
     }
     if (minorRadius * t.max_anisotropy < majorRadius) {
         minorRadius = majorRadius / t.max_anisotropy;
-        float theta = 0.5f * atanf(B / (A - C)), sinTheta = sinf(theta), cosTheta = cosf(theta);
+        float theta = 0.5f * atanf(B / (A - C)); const float2 scT_ = glibcSincosf2(theta); float sinTheta = scT_.x, cosTheta = scT_.y;
         float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta, cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
         A = a2 * cosTheta2 + b2 * sinTheta2; B = (a2 - b2) * sin2Theta; C = a2 * sinTheta2 + b2 * cosTheta2; F = a2 * b2;
     }
@@ -750,7 +771,7 @@ DEV float mfSmithG1(uint32_t distr, float alpha, v3 v, v3 m) {
 DEV void mfSampleVisible11(uint32_t distr, float thetaI, float sx, float sy, float &slx, float &sly) {
     const float SQRT_PI_INV = 1 / sqrtf(MI_PI);
     if (distr == 0) {
-        if (thetaI < 1e-4f) { float r = sqrtf(-fastlogf_(1.0f - sx)), ph = 2 * MI_PI * sy; slx = r * cosf(ph); sly = r * sinf(ph); return; }
+        if (thetaI < 1e-4f) { float r = sqrtf(-fastlogf_(1.0f - sx)), ph = 2 * MI_PI * sy; const float2 scp_ = glibcSincosf2(ph); slx = r * scp_.y; sly = r * scp_.x; return; }
         float tanThetaI = tanf(thetaI), cotThetaI = 1 / tanThetaI;
         float a = -1, c = miErf(cotThetaI);
         float sample_x = maxf(sx, 1e-6f);
@@ -770,7 +791,7 @@ DEV void mfSampleVisible11(uint32_t distr, float thetaI, float sx, float sy, flo
         slx = miErfinv(b);
         sly = miErfinv(2.0f * maxf(sy, 1e-6f) - 1.0f);
     } else {
-        if (thetaI < 1e-4f) { float r = sqrtf(maxf(sx / (1 - sx), 0.0f)), ph = 2 * MI_PI * sy; slx = r * cosf(ph); sly = r * sinf(ph); return; }
+        if (thetaI < 1e-4f) { float r = sqrtf(maxf(sx / (1 - sx), 0.0f)), ph = 2 * MI_PI * sy; const float2 scp_ = glibcSincosf2(ph); slx = r * scp_.y; sly = r * scp_.x; return; }
         float tanThetaI = tanf(thetaI), a = 1 / tanThetaI;
         float G1 = 2.0f / (1.0f + sqrtf(maxf(1.0f + 1.0f / (a * a), 0.0f)));
         float A = 2.0f * sx / G1 - 1.0f;
@@ -791,7 +812,7 @@ DEV v3 mfSampleVisible(uint32_t distr, float alpha, v3 wi_, float sx, float sy) 
     v3 wi = normalize(V(alpha * wi_.x, alpha * wi_.y, wi_.z));
     float theta = 0, phi = 0;
     if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
-    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    const float2 scPhi_ = glibcSincosf2(phi); float sinPhi = scPhi_.x, cosPhi = scPhi_.y;
     float slx, sly; mfSampleVisible11(distr, theta, sx, sy, slx, sly);
     float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
     rx *= alpha; ry *= alpha;
@@ -824,7 +845,7 @@ DEV v3 mfSampleVisible2(uint32_t distr, float au, float av, v3 wi_, float sx, fl
     v3 wi = normalize(V(au * wi_.x, av * wi_.y, wi_.z));
     float theta = 0, phi = 0;
     if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
-    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    const float2 scPhi_ = glibcSincosf2(phi); float sinPhi = scPhi_.x, cosPhi = scPhi_.y;
     float slx, sly; mfSampleVisible11(distr, theta, sx, sy, slx, sly);
     float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
     rx *= au; ry *= av;
@@ -841,16 +862,16 @@ DEV float mfSmithG1_2(uint32_t distr, float au, float av, v3 v, v3 m) { return m
 // microfacet.h:722-731 sampleFirstQuadrant (Ashikhmin-Shirley); :286-392 sampleAll (all normals, density D(m) cos(theta_m))
 DEV void mfSampleFirstQuadrant(float eu, float ev, float u1, float &phi, float &exponent) {
     phi = atanf(sqrtf((eu + 2.0f) / (ev + 2.0f)) * tanf(MI_PI * u1 * 0.5f));
-    float sinPhi = sinf(phi), cosPhi = cosf(phi);
+    const float2 scPhi_ = glibcSincosf2(phi); float sinPhi = scPhi_.x, cosPhi = scPhi_.y;
     exponent = eu * cosPhi * cosPhi + ev * sinPhi * sinPhi;
 }
 DEV v3 mfSampleAll(uint32_t distr, float au, float av, float sx, float sy, float &pdf) {
     float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
     if (distr <= 1u) {
-        if (au == av) { float ph = (2.0f * MI_PI) * sy; sinPhiM = sinf(ph); cosPhiM = cosf(ph); alphaSqr = au * au; }
+        if (au == av) { float ph = (2.0f * MI_PI) * sy; const float2 sc_ = glibcSincosf2(ph); sinPhiM = sc_.x; cosPhiM = sc_.y; alphaSqr = au * au; }
         else {
             float phiM = atanf(av / au * tanf(MI_PI + 2 * MI_PI * sy)) + MI_PI * floorf(2 * sy + 0.5f);
-            sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+            { const float2 sc_ = glibcSincosf2(phiM); sinPhiM = sc_.x; cosPhiM = sc_.y; }
             float cosSc = cosPhiM / au, sinSc = sinPhiM / av; alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
         }
         if (distr == 0u) {
@@ -871,7 +892,7 @@ DEV v3 mfSampleAll(uint32_t distr, float au, float av, float sx, float sy, float
         else if (sy < 0.5f) { mfSampleFirstQuadrant(eu, ev, 4 * (0.5f - sy), phiM, exponent); phiM = MI_PI - phiM; }
         else if (sy < 0.75f) { mfSampleFirstQuadrant(eu, ev, 4 * (sy - 0.5f), phiM, exponent); phiM += MI_PI; }
         else { mfSampleFirstQuadrant(eu, ev, 4 * (1 - sy), phiM, exponent); phiM = 2 * MI_PI - phiM; }
-        sinPhiM = sinf(phiM); cosPhiM = cosf(phiM);
+        { const float2 sc_ = glibcSincosf2(phiM); sinPhiM = sc_.x; cosPhiM = sc_.y; }
         cosThetaM = powf(sx, 1.0f / (exponent + 2.0f));
         pdf = sqrtf((eu + 2.0f) * (ev + 2.0f)) * MI_INV_TWOPI * powf(cosThetaM, exponent + 1.0f);
     }
@@ -1356,9 +1377,7 @@ DEV v3 envTexel(const DScene &sc, int x, int y) {
     return ld3(sc.env_rgb + ((size_t) y * sc.env_w + x) * 3);
 }
 // The device library's atan2f / acosf / sinf / cosf as real calls (not inlined): their expansions are register-hungry and sit inside the environment-map code of k_shade<ENV>
-__device__ __noinline__ static float miAtan2f(float y, float x) { return atan2f(y, x); }
-__device__ __noinline__ static float miAcosf(float x) { return acosf(x); }
-__device__ __noinline__ static float2 miSinCosf(float x) { return make_float2(sinf(x), cosf(x)); }
+DEV float2 miSinCosf(float x) { return glibcSincosf2(x); }
 // mipmap.h:576-597 evalBilinear(0, uv)
 DEV v3 envBilinear(const DScene &sc, float uvx, float uvy) {
     if (!isfinite(uvx) || !isfinite(uvy)) return V(0, 0, 0);

@@ -204,3 +204,21 @@ def test_plugin_classic_face_through_renderjob(mi, golden_scenes, tmp_path, name
     rel = np.abs(ia[..., :3] - ib[..., :3]).max(2) / (np.abs(ib[..., :3]).max(2) + 1e-6)
     assert (rel < 1e-4).mean() > 0.99                          # the reference is a -ffast-math build: a handful of forked paths
     assert np.linalg.norm(ia[..., :3] - ib[..., :3]) / np.linalg.norm(ib[..., :3]) < 5e-3
+
+
+@pytest.mark.gpu
+def test_bench_faces_and_devices(tmp_path):
+    """bench.py's product-path modes end to end on one GPU: both faces of the host mirror, and the in-process `devices` path with two replicas on device 0
+    (MI355PT_BENCH_DEVICES=0,0) -- same JSON schema as the C-ABI line, the fixed job as `value` and the weak-scaling job beside it."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--spp", "8", "--width", "640", "--height", "360", "--no-cpu-baseline"]
+    lines = {}
+    for tag, extra, env in (("abi", [], {}), ("classic", ["--face", "classic"], {}), ("responsive", ["--face", "responsive"], {}),
+                            ("devices", ["--gpus", "2", "--via", "devices", "--face", "responsive"], {"MI355PT_BENCH_DEVICES": "0,0"})):
+        out = subprocess.run(base + extra, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines[tag] = json.loads(out.stdout.strip().splitlines()[-1])
+        assert lines[tag]["value"] > 0 and lines[tag]["unit"] == "Msamples/s" and "face" in lines[tag]["config"]
+    assert lines["devices"]["n_gpus"] == 2 and lines["devices"]["scaling"] == "strong" and lines["devices"]["weak"]["value"] > 0
+    assert lines["abi"]["roofline"] is not None and lines["classic"]["roofline"] is None

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 def bit_share(got, ref, tag):
     """share of samples whose three channels equal the oracle's bit for bit; printed (pytest -s) so that the floors asserted in the tests can be checked against measured values"""
     share = float((bits(got) == bits(ref)).all(1).mean())
-    print(f"[bit-share] {tag}: {share:.4f}")      # round 3 on MI355X: analytic_shapes 0.9897 / 0.9956, instances 0.9957, thin_dielectric 0.9887 / 0.9922, mask 0.9942 / 0.9932,
-    return share                                   # tree_node_kinds atrium_small 0.8276 (envmap: device atan2 / acos, DESIGN.md section 4) / bunny_box 1.0 -- the floors asserted sit just under these
+    print(f"[bit-share] {tag}: {share:.4f}")      # round 3 on MI355X, device library's libm: analytic_shapes 0.9897 / 0.9956, instances 0.9957, thin_dielectric 0.9887 / 0.9922, mask 0.9942 / 0.9932,
+    return share                                   # tree_node_kinds atrium_small 0.8276; with glibc's routines restated on the device (csrc/libm_glibc.h): 1.0000 in every one -- the floors are 0.9999
 
 
 def bits(a):
@@ -259,14 +259,16 @@ def test_roughconductor_veach_mis(mi, oracle, golden_scenes):
     ref = oracle.Oracle(sc).render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6, ((err < 1e-4).mean(), np.median(err))
+    assert bit_share(got, ref, "veach_small") > 0.9999      # glibc's libm restated on the device: the microfacet scene equals the oracle bit for bit
     gd = np.load(os.path.join(GOLDEN, "veach_small_samples.npz"))            # the reference's own Li
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
     assert (err < 2e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); st = r.stats()
     ofilm, cnt = oracle.Oracle(sc).render_image(threads=4)
     rel = np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3])
-    assert rel < 2e-3, rel                                                   # 16 spp: a forked path moves a whole pixel
-    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3 and abs(st["shadow_rays"] - int(cnt[1])) / cnt[1] < 1e-3
+    print(f"[film-rel] veach_small: {rel:.3e} rays {st['rays']} vs {int(cnt[0])} shadow {st['shadow_rays']} vs {int(cnt[1])}")
+    assert rel < 1e-6, rel                                                   # (round 2: 2e-3 -- a forked path moved a whole pixel; round 3: no path forks any more)
+    assert st["rays"] == int(cnt[0]) and st["shadow_rays"] == int(cnt[1])
     ref_film = np.load(os.path.join(GOLDEN, "veach_small_image.npz"))["film"]
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 2e-3
 
@@ -280,12 +282,14 @@ def test_envmap_atrium(mi, oracle, golden_scenes):
     ref = oracle.Oracle(sc).render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
     assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6, ((err < 1e-4).mean(), np.median(err))
+    assert bit_share(got, ref, "atrium_small") > 0.9999      # atan2f / acosf of the lat-long lookups = glibc's: bit-exact
     gd = np.load(os.path.join(GOLDEN, "atrium_small_samples.npz"))           # the reference's own Li
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
     assert (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = oracle.Oracle(sc).render_image(threads=4); st = r.stats()
-    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 2e-3
-    assert abs(st["rays"] - int(cnt[0])) / cnt[0] < 1e-3
+    print(f"[film-rel] atrium_small: {np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]):.3e} rays {st['rays']} vs {int(cnt[0])}")
+    assert np.linalg.norm(film[..., :3] - ofilm[..., :3]) / np.linalg.norm(ofilm[..., :3]) < 1e-6
+    assert st["rays"] == int(cnt[0])
     assert film[1:-1, 1:-1, :3].mean() > 0.05                               # the sky actually lights the scene
 
 
@@ -320,6 +324,7 @@ def test_integrator_switches(mi, oracle, golden_scenes, name):
     else:
         err = np.abs(got - o["li"]).max(1) / (np.abs(o["li"]).max(1) + 1e-6)
         assert (err < 1e-4).mean() > 0.99 and np.median(err) < 1e-6
+        assert bit_share(got, o["li"], "integrator_switches " + name) > 0.9999
         err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
         assert (err < 1e-4).mean() > 0.97 and (err < 1e-2).mean() > 0.995
     r.run(); film = r.read_film(0); ofilm, cnt = oracle.Oracle(sc).render_image(threads=4); st = r.stats()
@@ -363,7 +368,7 @@ def test_analytic_shapes(mi, oracle, golden_scenes, name, bvh, monkeypatch):
         assert (bits(got) == bits(ref)).all()
     else:
         err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and bit_share(got, ref, "analytic_shapes " + name) > 0.98      # measured 0.9897 / 0.9956 (round 3); the rest: the cone / sphere sampling maps go through the device library's sincos / acos
+        assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6 and bit_share(got, ref, "analytic_shapes " + name) > 0.9999
     err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)
     assert (err < 1e-4).mean() > 0.99 and (err < 5e-3).mean() > 0.998 and np.median(err) < 1e-6
     # whole film + the ray counters
@@ -444,7 +449,7 @@ def test_instances(mi, oracle, golden_scenes):
     pairs = np.stack([rng.integers(0, sc.width, 20000), rng.integers(0, sc.height, 20000), rng.integers(0, sc.spp, 20000)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    assert bit_share(got, ref, "instances") > 0.99 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
+    assert bit_share(got, ref, "instances") > 0.9999 and (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 2e-4).mean() > 0.99 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); st = r.stats(); ofilm, cnt = orc.render_image(threads=4)
@@ -576,7 +581,38 @@ def test_full_size_configs_spot_check_vs_oracle(mi, oracle, config):
     else:
         err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
         assert (err < 1e-4).mean() > 0.99 and (err < 1e-2).mean() > 0.998 and np.median(err) < 1e-6, ((err < 1e-4).mean(), (err < 1e-2).mean())
+        assert bit_share(got, ref, "full_size " + config) > 0.9999      # Veach (rough conductors) and the atrium (environment map) at full size: bit-exact as well
     assert np.isfinite(got).all() and (got >= 0).all() and got.max() > 0
+
+
+def test_config5_rows_of_eight_ranks_on_one_gpu(mi, oracle):
+    """BASELINE config 5 (the 4K atrium at 1024 spp, film rows interleaved over 8 GPUs) as far as ONE GPU can show it: 35-bit Sobol indices on the 251 k-triangle
+    scene, every row class k = y mod 8 spot-checked against the oracle with sample indices from the whole range [0, 1024), and the eight rank shares
+    (mi_render_run_rows, stride 8, two high sample planes) summing to the unsplit film.  What is NOT shown here: eight devices, RCCL, xGMI (no such node in the loop)."""
+    S = mi.scenes
+    sc = S.atrium(3840, 2160, 1024); gs = mi.Scene(sc); r = mi.Render(gs); orc = oracle.Oracle(sc)
+    rng = np.random.default_rng(55); n = 4800
+    pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, 1024, n)], 1).astype(np.uint32)
+    pairs[:, 1] = (pairs[:, 1] // 8) * 8 + (np.arange(n) % 8)                  # 600 samples per row class
+    pairs[:3] = [[0, 0, 1023], [sc.width - 1, sc.height - 1, 1023], [sc.width // 2, 7, 512]]
+    ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
+    err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
+    assert bit_share(got, ref, "config5") > 0.9999
+    for k in range(8):
+        sel = (pairs[:, 1] % 8) == k
+        assert sel.sum() >= 590 and (err[sel] < 1e-4).mean() > 0.985 and np.median(err[sel]) < 1e-6, (k, (err[sel] < 1e-4).mean())
+    assert np.isfinite(got).all() and (got >= 0).all() and got.max() > 0
+    r.clear(); r.run(s0=1000, s1=1002); full = r.read_film(0); rays_full = r.stats()["rays"]
+    acc = np.zeros_like(full); rays = 0
+    for k in range(8):
+        r.clear(); r.run(tile=(0, k, sc.width, sc.height), s0=1000, s1=1002, row_stride=8); part = r.read_film(0); rays += r.stats()["rays"]
+        b = r.film_shape(0)[3]; pin = part[b:part.shape[0] - b, b:part.shape[1] - b]; fin = full[b:full.shape[0] - b, b:full.shape[1] - b]      # (the film carries the filter's border)
+        other = np.delete(pin[..., 4], np.s_[k::8], axis=0)
+        assert (bits(pin[k::8]) == bits(fin[k::8])).all(2).mean() > 0.9999 and (other == 0.0).mean() > 0.9999      # own rows: the unsplit film's; other ranks' rows untouched (edge splats of the box filter aside)
+        acc += part
+    assert rays == rays_full
+    same = (bits(acc) == bits(full)).all(2)
+    assert same.mean() > 0.9999 and np.allclose(acc, full, rtol=1e-6, atol=1e-7)
 
 
 def test_scene_file_bunny(mi, oracle, golden_scenes, tmp_path):
@@ -755,7 +791,7 @@ def test_thin_dielectric(mi, oracle, golden_scenes, name):
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)          # the gold sphere's rough conductor goes through the device math library
-    assert bit_share(got, ref, "thin_dielectric " + name) > 0.98 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
+    assert bit_share(got, ref, "thin_dielectric " + name) > 0.9999 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
@@ -780,7 +816,7 @@ def test_mask(mi, oracle, golden_scenes, name):
     pairs = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(pairs)["li"]; got = r.samples(pairs)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    assert bit_share(got, ref, "mask " + name) > 0.99 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
+    assert bit_share(got, ref, "mask " + name) > 0.9999 and (err < 1e-4).mean() > 0.995 and np.median(err) == 0
     got = r.samples(gd["pairs"]); err = np.abs(got - gd["li"]).max(1) / (np.abs(gd["li"]).max(1) + 1e-6)      # the reference's own Li
     assert (err < 1e-4).mean() > 0.995 and np.median(err) < 1e-6
     r.run(); film = r.read_film(0); ofilm, cnt = orc.render_image(threads=4); st = r.stats()
@@ -963,7 +999,7 @@ def test_both_tree_node_kinds(mi, golden_scenes, name, monkeypatch):
     if name in ("atrium_small", "bunny_box"):        # atrium: the lat-long lookups use the device's atan2 / acos (test_envmap_atrium) -> not every sample bit-equal
         st = np.load(os.path.join(GOLDEN, "strict", name + ".npz"))
         err = np.abs(got["wide"] - st["li"]).max(1) / (np.abs(st["li"]).max(1) + 1e-6)
-        assert bit_share(got["wide"], st["li"], "tree_node_kinds " + name) > {"atrium_small": 0.80, "bunny_box": 0.999}[name] and (err < 1e-4).mean() > 0.99
+        assert bit_share(got["wide"], st["li"], "tree_node_kinds " + name) > 0.9999 and (err < 1e-4).mean() > 0.99
 
 
 @pytest.mark.parametrize("name", ["fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis"])
