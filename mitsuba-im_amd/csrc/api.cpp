@@ -51,7 +51,7 @@ static void mi_launch_shade(const DScene &scIn, bool ldsTables, const RenderCons
     DScene sc = scIn; sc.small_tables = ldsTables ? 1u : 0u;
     size_t lds = rc.sampler == 1 ? (size_t) rc.nib_dims * rc.nib_count * 64 : 16;
     const bool env = sc.env_index >= 0;
-    if (sc.small_tables) lds += 16 + 4 * ((size_t) sc.n_tris * 24 + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
+    if (sc.small_tables) lds += 16 + 4 * ((size_t) sc.n_tris * (4 * MI_SHADE_WORDS) + sc.n_materials * 16 + sc.n_emitters * 12 + ((sc.n_emitters + 4) & ~3u) + sc.area_cdf_len);
     RenderConst rcl = rc; rcl.order_offset_words = 0;
     if (sc.has_roughconductor && q.cap <= 8192u) {      // path-order list: only where it still fits the 64 KB a launch may request (else unsorted shading)
         const uint32_t off = (uint32_t) ((lds + 15) / 16 * 4); const size_t total = (size_t) off * 4 + (size_t) q.cap * 2 * 4 + 16;
@@ -537,7 +537,7 @@ static int allocPool(mi_render *r, uint64_t paths) {
 // LDS bytes k_shade stages for a small scene (shading records, materials, emitters, CDFs); must match mi_launch_shade (kernels.hip)
 static size_t smallTableBytes(const mi::SceneHost &h) {
     if (!h.d.small_tables) return 0;
-    return 16 + 4 * ((size_t) h.d.n_tris * 24 + h.d.n_materials * 16 + h.d.n_emitters * 12 + ((h.d.n_emitters + 4) & ~3u) + h.d.area_cdf_len);
+    return 16 + 4 * ((size_t) h.d.n_tris * (4 * MI_SHADE_WORDS) + h.d.n_materials * 16 + h.d.n_emitters * 12 + ((h.d.n_emitters + 4) & ~3u) + h.d.area_cdf_len);
 }
 int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (!s || !p || !out) return fail(MI_ERR_INVALID, "mi_render_create: null argument");

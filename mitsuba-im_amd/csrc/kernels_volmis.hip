@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                                     v3 dpdu, dpdv;
                                     if (onAnalytic) { float tu_, tv_; analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, o + d * hr.x, tu_, tv_, dpdu, dpdv); }
                                     else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
-                                    else { AS<false>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                                    else { AS<false>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                                     if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
                                     const float2 sp = q.pos[pid]; v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
                                     float pa[4]; computePartials(h.p, h.ng, dpdu, dpdv, o, rxd, ryd, pa);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WG) void k_shade_volmis(DScene sc, RenderConst rc, 
                         float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
                         if (inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, o + d * hr.x, huvx, huvy, dpdu, dpdv);
                         else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
-                        else { AS<false>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                        else { AS<false>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                         if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
                         perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
                         bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(WG) void k_shadow_volmis(DScene sc, Queues q) {
             if (surface) {
                 if (prim >= sc.n_tris) { const AnalyticD &a = sc.analytic[prim - sc.n_tris]; material = a.material; Hit h; fillHitAnalytic(a, o, d, t, u, v, h); nn = h.ng; }
                 else {
-                    AS<false>::p4 rec = tb.shade4 + prim * 6u; const f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; material = __float_as_int(r0.w);
+                    AS<false>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS; const f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; material = __float_as_int(r0.w);
                     v3 fn = cross(V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z), V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z)); const float len = sqrtf(dot(fn, fn));
                     if (!isZero(fn)) { const float r = 1.0f / len; fn = fn * r; }
                     nn = fn;

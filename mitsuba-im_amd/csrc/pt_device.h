@@ -73,7 +73,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 template <bool L> struct AS { typedef const f4 *p4; typedef const float *pf; };
 template <> struct AS<true> { typedef const __attribute__((address_space(3))) f4 *p4; typedef const __attribute__((address_space(3))) float *pf; };
 template <bool L> struct Tabs {
-    typename AS<L>::p4 shade4;      // TriShade: 6 x 16 B per triangle
+    typename AS<L>::p4 shade4;      // TriShade: MI_SHADE_WORDS x 16 B per triangle
     typename AS<L>::p4 materials4;  // MaterialD: 4 x 16 B
     typename AS<L>::p4 emitters4;   // EmitterD: 3 x 16 B
     typename AS<L>::pf emitter_cdf, area_cdf;
@@ -419,7 +419,7 @@ DEV v3 textureEval(const TextureD &t, float u, float v) {
 // UVT: honour texture coordinates (the EXT kernel variants): its.uv and dpdu = UV tangent for triangles whose mesh has texcoords
 template <bool L, bool UVT = false>
 DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
-    typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
+    typename AS<L>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS;
     f4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
     v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z), p2 = V(r2.x, r2.y, r2.z);
     h.material = __float_as_int(r0.w); h.emitter = __float_as_int(r1.w); h.flags = __float_as_uint(r2.w);
@@ -438,8 +438,8 @@ DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t pr
     if (h.flags & 1u) {          // face normals: the precomputed face frame (built from the UV tangent where there is one) is the shading frame
         h.ns = fn; h.ng = fn; h.s = V(r4.x, r4.y, r4.z); h.t = V(r5.x, r5.y, r5.z);
     } else {
-        uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
-        v3 n = (ld3(sc.nrm + 3 * i0) * bx + ld3(sc.nrm + 3 * i1) * by) + ld3(sc.nrm + 3 * i2) * bz;
+        const f4 r6 = rec[6];      // the vertex normals travel in the record (words 4, 5, 6)
+        v3 n = (V(r4.x, r4.y, r4.z) * bx + V(r5.x, r5.y, r5.z) * by) + V(r6.x, r6.y, r6.z) * bz;
         h.ns = normalize(n);
         if (dot(fn, h.ns) < 0) fn = -fn;
         h.ng = fn;
@@ -455,7 +455,7 @@ DEV void fillHit(const DScene &sc, const Tabs<L> &tb, v3 d, float t, uint32_t pr
 // dpdu and p through the forward transform; the scene level recomputes the shading frame and wi (skdtree.h:425-426).
 template <bool L>
 DEV void fillHitInstanced(const DScene &sc, const Tabs<L> &tb, const InstanceD &in, v3 o, v3 d, float t, uint32_t prim, float u, float v, Hit &h) {
-    typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
+    typename AS<L>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS;
     f4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
     v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z);
     h.material = __float_as_int(r0.w); h.emitter = __float_as_int(r1.w); h.flags = __float_as_uint(r2.w);
@@ -466,8 +466,8 @@ DEV void fillHitInstanced(const DScene &sc, const Tabs<L> &tb, const InstanceD &
     v3 fn = V(r3.x, r3.y, r3.z), ns;
     if (h.flags & 1u) ns = fn;
     else {
-        uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
-        v3 n = (ld3(sc.nrm + 3 * i0) * bx + ld3(sc.nrm + 3 * i1) * by) + ld3(sc.nrm + 3 * i2) * bz;
+        const f4 r6 = rec[6];      // the vertex normals travel in the record (words 4, 5, 6)
+        v3 n = (V(r4.x, r4.y, r4.z) * bx + V(r5.x, r5.y, r5.z) * by) + V(r6.x, r6.y, r6.z) * bz;
         ns = normalize(n);
         if (dot(fn, ns) < 0) fn = -fn;
     }
@@ -1563,7 +1563,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
     float a0 = acdf[ti], a1 = acdf[ti + 1];
     sy = (sy - a0) / (a1 - a0);
     uint32_t prim = em.first_tri + ti;
-    typename AS<L>::p4 rec = tb.shade4 + prim * 6u;
+    typename AS<L>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS;
     f4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
     v3 p0 = V(r0.x, r0.y, r0.z), p1 = V(r1.x, r1.y, r1.z), p2 = V(r2.x, r2.y, r2.z);
     float bx, by; uniformTriangle(sx, sy, bx, by);
@@ -1572,8 +1572,8 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
     if (__float_as_uint(r2.w) & 1u) dr.n = normalize(cross(sideA, sideB));
     else {
         f4 r4 = rec[4], r5 = rec[5];
-        uint32_t i0 = __float_as_uint(r4.w), i1 = __float_as_uint(r5.w), i2 = sc.i2[prim];
-        dr.n = normalize((ld3(sc.nrm + 3 * i0) * (1.0f - bx - by) + ld3(sc.nrm + 3 * i1) * bx) + ld3(sc.nrm + 3 * i2) * by);
+        const f4 r6 = rec[6];
+        dr.n = normalize((V(r4.x, r4.y, r4.z) * (1.0f - bx - by) + V(r5.x, r5.y, r5.z) * bx) + V(r6.x, r6.y, r6.z) * by);
     }
     dr.pdf = em.inv_area;
     dr.d = dr.p - ref;

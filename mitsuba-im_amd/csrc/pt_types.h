@@ -48,15 +48,20 @@ struct Bvh4Node {
     int32_t child[4];                     // word 3
 };
 
-// Per-triangle shading record in ORIGINAL triangle order, 96 B = six 16-B loads.
-// ng/s/t are the face frame (used as-is by face-normal meshes; recomputed at run time for smooth meshes).
+// Per-triangle shading record in ORIGINAL triangle order, 128 B = eight 16-B words = ONE aligned cache line: everything a hit needs of its triangle arrives with
+// one line fetch (round 2: a 96-B record straddling lines + the index of the third vertex + three vertex normals from three more lines -- the shade stage of the
+// 251 k-triangle atrium moved 2.3 x its algorithmic bytes).  Words 4 / 5 hold the face frame (s, t) of a face-normal triangle or the first two VERTEX NORMALS of a
+// smooth one (its frame is recomputed from the interpolated normal anyway), word 6 the third vertex normal.
+#define MI_SHADE_WORDS 8
 struct TriShade {
     float p0[3]; int32_t material;
     float p1[3]; int32_t emitter;
     float p2[3]; uint32_t flags;          // bit4: the mesh has texture coordinates (TriUV record: uv + UV tangents); bit0 face normals, bit1 material has a back side (twosided), bit2 BSDF without a smooth component (no NEE), bit3 rough conductor (material class for sorted shading)
     float ng[3]; uint32_t local_prim;
-    float s[3]; uint32_t i0;
-    float t[3]; uint32_t i1;              // i0,i1,i2: vertex indices for smooth normals (i2 in `i2` array)
+    float s[3]; uint32_t i0;              // smooth triangles: vertex normal 0 (i0, i1, i2: the vertex indices, kept for tools)
+    float t[3]; uint32_t i1;              // smooth triangles: vertex normal 1
+    float n2[3]; uint32_t i2;             // smooth triangles: vertex normal 2
+    float pad[4];
 };
 
 // Per-triangle texture-coordinate record (meshes with texcoords only), 48 B: its.uv interpolation (skdtree.h:402-408) and the UV tangents of

@@ -237,6 +237,10 @@ void SceneHost::commitHost() {
         }
         V3 s = normalize(dpdu - fn * dot(fn, dpdu)), tt = cross(fn, s);
         ts.ng[0] = fn.x; ts.ng[1] = fn.y; ts.ng[2] = fn.z; ts.s[0] = s.x; ts.s[1] = s.y; ts.s[2] = s.z; ts.t[0] = tt.x; ts.t[1] = tt.y; ts.t[2] = tt.z;
+        ts.i2 = c;
+        if (!faceN) {      // a smooth triangle carries its three vertex normals instead of the (unused) face frame
+            for (int k = 0; k < 3; ++k) { ts.s[k] = nrm[a * 3 + k]; ts.t[k] = nrm[b * 3 + k]; ts.n2[k] = nrm[c * 3 + k]; }
+        }
         V3 lo = vmin(vmin(p0, p1), p2), hi = vmax(vmax(p0, p1), p2);
         // conservative padding: the Wald test is evaluated in its own arithmetic, boxes may only over-approximate
         V3 e = hi - lo; float mag = std::max(std::max(std::fabs(lo.x) + std::fabs(hi.x), std::fabs(lo.y) + std::fabs(hi.y)), std::fabs(lo.z) + std::fabs(hi.z));

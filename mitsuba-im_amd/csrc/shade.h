@@ -25,7 +25,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
     Tabs<SMALL> tb;
     if (SMALL) {
         uint32_t *base = s_dyn + ((nibWords + 3u) & ~3u);
-        const uint32_t wShade = sc.n_tris * 24u, wMat = sc.n_materials * 16u, wEm = sc.n_emitters * 12u, wEc = (sc.n_emitters + 1u + 3u) & ~3u, wAc = sc.area_cdf_len;
+        const uint32_t wShade = sc.n_tris * (4u * MI_SHADE_WORDS), wMat = sc.n_materials * 16u, wEm = sc.n_emitters * 12u, wEc = (sc.n_emitters + 1u + 3u) & ~3u, wAc = sc.area_cdf_len;
         uint32_t *pS = base, *pM = pS + wShade, *pE = pM + wMat, *pEc = pE + wEm, *pAc = pEc + wEc;
         const uint32_t *gS = (const uint32_t *) sc.shade, *gM = (const uint32_t *) sc.materials, *gE = (const uint32_t *) sc.emitters, *gEc = (const uint32_t *) sc.emitter_cdf, *gAc = (const uint32_t *) sc.area_cdf;
         for (uint32_t i = tid; i < wShade; i += WG) pS[i] = gS[i];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                 const uint32_t prim = __float_as_uint(qat(q.hit, segBase + i).w);
                 if (prim == 0xFFFFFFFFu) cls = 0;
                 else if (AN && prim >= sc.n_tris) cls = (sc.analytic[prim - sc.n_tris].flags & 8u) ? 1 : 0;
-                else cls = (__float_as_uint(tb.shade4[prim * 6u + 2u].w) & 8u) ? 1 : 0;
+                else cls = (__float_as_uint(tb.shade4[prim * (uint32_t) MI_SHADE_WORDS + 2u].w) & 8u) ? 1 : 0;
             }
             const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
             if (cls == 0) s_order[done0 + (uint32_t) __popcll(m0 & lt)] = (uint16_t) i;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                                 v3 dpdu, dpdv;
                                 if (onAnalytic) { float tu_, tv_; analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, ro3 + d * hr.x, tu_, tv_, dpdu, dpdv); }
                                 else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
-                                else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                                else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                                 if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
                                 const float2 sp = qat(q.pos, pid); v3 rxd, ryd; cameraDifferentials(sc, rc.inv_sqrt_spp, sp.x, sp.y, d, rxd, ryd);
                                 float pa[4]; computePartials(h.p, h.ng, dpdu, dpdv, ro3, rxd, ryd, pa);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                     float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
                     if (AN && inst < 0 && prim >= sc.n_tris) analyticUV(sc.analytic[prim - sc.n_tris], hr.y, hr.z, ro3 + d * hr.x, huvx, huvy, dpdu, dpdv);
                     else if (h.flags & 16u) { const TriUV &tu = sc.triuv[prim]; dpdu = ld3(tu.dpdu); dpdv = ld3(tu.dpdv); }
-                    else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * 6u; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
+                    else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                     if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
                     perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
                     bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
