@@ -1,5 +1,5 @@
 // api.cpp -- C-ABI of libmi355pt.so (include/mi355pt.h): scene upload, wavefront batch scheduling, film read-back.
-// Host orchestration only; all arithmetic on the sample path lives in kernels.hip / pt_device.h.
+// Host orchestration only; all arithmetic on the sample path lives in the kernel translation units (kernels_*.hip over trace.h, trace_fused.h, shade.h, pt_device.h).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cmath>
@@ -80,6 +80,7 @@ struct mi_render {
     mi_stats stats{};
     uint64_t samplesTotal = 0, launchesAll = 0; uint64_t mergedRays = 0, mergedShadow = 0, mergedPathLen = 0, mergedSamples = 0;   // counters of replicas merged into this film
     bool ldsTables = false;   // this render stages the scene tables in LDS (scene eligible and everything fits 64 KB together with the Sobol tables and the order list)
+    uint32_t *pollHost = nullptr; size_t pollWords = 0; hipEvent_t pollEv = nullptr;   // unbounded depth: pinned landing buffer + event for the survivor-count poll
     uint32_t *dNib = nullptr; void *dSobolTabs = nullptr;   // dSobolTabs: the three look_up tables of k_generate (frame, px, py), one allocation
     // optional further path pools + streams: consecutive batches go round-robin through them, so the ALU-bound traversal kernels of one batch
     // overlap the latency-bound shading kernels of the others on the same CUs (MI355PT_STREAMS = 1..4 pools, default 2)
@@ -534,7 +535,7 @@ static int allocPool(mi_render *r, uint64_t paths) {
     return MI_OK;
 }
 
-// LDS bytes k_shade stages for a small scene (shading records, materials, emitters, CDFs); must match mi_launch_shade (kernels.hip)
+// LDS bytes k_shade stages for a small scene (shading records, materials, emitters, CDFs); must match mi_launch_shade (above) and shade.h
 static size_t smallTableBytes(const mi::SceneHost &h) {
     if (!h.d.small_tables) return 0;
     return 16 + 4 * ((size_t) h.d.n_tris * (4 * MI_SHADE_WORDS) + h.d.n_materials * 16 + h.d.n_emitters * 12 + ((h.d.n_emitters + 4) & ~3u) + h.d.area_cdf_len);
@@ -570,6 +571,13 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         if (vol) perBounce += 2;      // + the one or two draws of HomogeneousMedium::sampleDistance per iteration
         if (p->max_depth > 0 && (uint32_t) (3 + perBounce * depth) > s->h.d.sobol_dims) return fail(MI_ERR_INVALID, "Lookup dimension exceeds the direction number table size! You may have to reduce the 'maxDepth' parameter of your integrator.");
         if (p->max_depth < 0) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth = -1 with the Sobol sampler needs more dimensions than are loaded");
+    }
+    if (p->sampler == MI_SAMPLER_INDEPENDENT && p->max_depth > 0) {
+        // the build-defined independent stream numbers a path's draws with 8 bits: a path that could draw more than 256 values would re-read
+        // its own stream from call 0 -- refused by name rather than silently correlated (unbounded depth keeps the documented period)
+        int perBounce = 5; for (const mi_material &m : s->h.materials) if (m.type == MI_BSDF_ROUGHDIELECTRIC) perBounce = 6;
+        if (vol) perBounce += 2;
+        if (2 + perBounce * p->max_depth > 256) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: the independent sampler stream numbers 256 draws per path; maxDepth x draws per bounce exceeds that (use the Sobol sampler or a smaller maxDepth)");
     }
     HIPCHK(hipSetDevice(s->h.device));
     mi_render *r = new mi_render(); r->scene = s; r->p = *p;
@@ -661,6 +669,8 @@ void mi_render_destroy(mi_render *r) {
     if (r->layoutTmp) (void) hipFree(r->layoutTmp);
     if (r->mergeTmp) (void) hipFree(r->mergeTmp);
     if (r->dNib) (void) hipFree(r->dNib);
+    if (r->pollHost) (void) hipHostFree(r->pollHost);
+    if (r->pollEv) (void) hipEventDestroy(r->pollEv);
     if (r->dSobolTabs) (void) hipFree(r->dSobolTabs);
     for (hipEvent_t e : r->evPool) (void) hipEventDestroy(e);
     if (r->evBegin) (void) hipEventDestroy(r->evBegin);
@@ -708,9 +718,11 @@ static int traceBatch(mi_render *r, const BatchDesc &bd, const uint32_t *list, s
         }
         buf ^= 1;
         if (r->rc.max_depth < 0 && (depth % 4) == 0) {   // unbounded depth: poll the survivor counts every few bounces
-            std::vector<uint32_t> cnt(r->grid);
-            HIPCHK(hipMemcpyAsync(cnt.data(), Q.count[buf], r->grid * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
-            uint64_t alive = 0; for (uint32_t c : cnt) alive += c;
+            // survivor counts land in a pinned buffer (a true asynchronous copy), the host waits on an event of THIS stream only -- the other pool's stream keeps running
+            if (r->pollWords < r->grid) { if (r->pollHost) (void) hipHostFree(r->pollHost); r->pollHost = nullptr; HIPCHK(hipHostMalloc((void **) &r->pollHost, (size_t) r->grid * 4, hipHostMallocDefault)); r->pollWords = r->grid; }
+            if (!r->pollEv) HIPCHK(hipEventCreateWithFlags(&r->pollEv, hipEventDisableTiming));
+            HIPCHK(hipMemcpyAsync(r->pollHost, Q.count[buf], (size_t) r->grid * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipEventRecord(r->pollEv, st)); HIPCHK(hipEventSynchronize(r->pollEv));
+            uint64_t alive = 0; for (uint32_t k = 0; k < r->grid; ++k) alive += r->pollHost[k];
             if (!alive) break;
         }
     }

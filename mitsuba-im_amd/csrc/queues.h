@@ -1,4 +1,4 @@
-// queues.h -- SoA wavefront queues in HBM (device pointers), shared by api.cpp and kernels.hip.
+// queues.h -- SoA wavefront queues in HBM (device pointers), shared by api.cpp and the kernel translation units (kernels_*.hip).
 // Layout per path slot (algorithmic bytes, DESIGN.md §"bytes per segment"):
 //   extension ray 32 B (rayO: o.xyz,mint | rayD: d.xyz,maxt), hit 16 B (t,u,v,prim), path state 36 B
 //   (st0: path id, sampler word a, sampler word b, dim|depth|flags; st1: throughput rgb, eta; st2: bsdfPdf),

@@ -8,7 +8,11 @@ pass() { local name=$1; shift
     && cp $(find $OUT/diag_${C}_$name -name '*counter_collection.csv' | head -1) $OUT/diag_${C}_$name.csv || echo "pass $name failed (see $OUT/diag_${C}_$name.log)"
   rm -rf $OUT/diag_${C}_$name; }
 pass sq SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-# (TA-block counters abort inside rocprofv3 7.2 on this image: pass left out)
+# TA block, ONE derived counter per pass: round 2's single pass of four TA counters was rejected at rocprofiler_create_counter_config ("error code 38: Request exceeds the
+# capabilities of the hardware to collect", gpurun_out/r02.prev/diag_C4_ta.log) -- before the program launched anything: a counter-SET rejection (the TA block has two
+# counter slots per instance and the *_sum / _avr forms take one each per shader engine), not a GPU fault.  Two counters per pass fit.
+pass ta1 TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum
+pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tlb TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum

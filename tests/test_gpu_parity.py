@@ -238,6 +238,14 @@ def test_edge_cases_and_errors(mi, scenes):
     r.cancel(); r.clear(); r.run(); assert r.stats()["samples"] > 0        # mi_render_clear drops a pending cancel
 
 
+def test_independent_stream_period_is_refused(mi, golden_scenes):
+    """the build-defined independent stream numbers a path's draws with 8 bits: a maxDepth that could draw more than 256 values is refused by name"""
+    S = mi.scenes; gs = mi.Scene(golden_scenes["cornell_small"])
+    mi.Render(gs, sampler=S.SAMPLER_INDEPENDENT, max_depth=50).run(s1=1)      # 2 + 5 * 50 = 252
+    with pytest.raises(RuntimeError, match="independent sampler stream"):
+        mi.Render(gs, sampler=S.SAMPLER_INDEPENDENT, max_depth=51)
+
+
 def test_opacity_alpha_channel(mi, oracle, golden_scenes):
     """EOpacity (records.inl:121-137): alpha = 1 where the camera ray hits, 0 where it leaves the scene; off -> alpha = 1 everywhere."""
     sc = golden_scenes["cornell_small"]
