@@ -1455,6 +1455,23 @@ DEV float envPdfDirection(const DScene &sc, v3 d) {
     return (luminance(v1) * sc.env_row_weights[clampi(yPos, 0, sc.env_h - 1)] + luminance(v2) * sc.env_row_weights[clampi(yPos + 1, 0, sc.env_h - 1)])
            * sc.env_normalization / maxf(fabsf(sinTheta), MI_EPSILON);
 }
+// evalEnvironment + pdfDirect of ONE direction (a BSDF-sampled ray that left the scene: path.cpp:234-264 asks for both): the lat-long coordinates (atan2f, acosf) and
+// the four texels are the same in envEval and envPdfDirection -- computed / fetched once here, each result then in its own routine's operation order (bit-identical).
+DEV void envEvalAndPdf(const DScene &sc, v3 dWorld, v3 &value, float &pdfSA) {
+    const v3 d = mat3(sc.env_to_local, dWorld);
+    const float uvx = miAtan2f(d.x, -d.z) * MI_INV_TWOPI, uvy = miAcosf(minf(1.0f, maxf(-1.0f, d.y))) * MI_INV_PI;
+    if (!isfinite(uvx) || !isfinite(uvy)) { value = V(0, 0, 0); pdfSA = 0.0f; return; }
+    const float u = uvx * (float) sc.env_w - 0.5f, v = uvy * (float) sc.env_h - 0.5f;
+    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const float dx1 = u - (float) xPos, dx2 = 1.0f - dx1, dy1 = v - (float) yPos, dy2 = 1.0f - dy1;
+    const v3 t00 = envTexel(sc, xPos, yPos), t01 = envTexel(sc, xPos, yPos + 1), t10 = envTexel(sc, xPos + 1, yPos), t11 = envTexel(sc, xPos + 1, yPos + 1);
+    v3 r = (t00 * dx2) * dy2; r = r + (t01 * dx2) * dy1; r = r + (t10 * dx1) * dy2; r = r + (t11 * dx1) * dy1;      // envBilinear
+    value = r * sc.env_scale;
+    const v3 v1 = (t00 * dx2) * dy2 + (t10 * dx1) * dy2, v2 = (t01 * dx2) * dy1 + (t11 * dx1) * dy1;               // envBilinearPair
+    const float sinTheta = sqrtf(maxf(1 - d.y * d.y, 0.0f));
+    pdfSA = (luminance(v1) * sc.env_row_weights[clampi(yPos, 0, sc.env_h - 1)] + luminance(v2) * sc.env_row_weights[clampi(yPos + 1, 0, sc.env_h - 1)])
+            * sc.env_normalization / maxf(fabsf(sinTheta), MI_EPSILON);
+}
 // include/mitsuba/core/bsphere.h:88-95 + src/libcore/util.cpp:449-487 solveQuadratic
 DEV bool bsphereIntersect(const DScene &sc, v3 ro, v3 rd, float &nearT, float &farT) {
     v3 o = ro - ld3(sc.env_bs_center);

@@ -101,11 +101,11 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                             // BSDF ray left the scene: env->evalEnvironment + fillDirectSamplingRecord (envmap.cpp:362-378), MIS term path.cpp:257-264
                             float4 ro = qat(q.rayO[buf], slot); float nearT, farT;
                             if (!(rc.hide_emitters && unscattered) && bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {   // path.cpp:238-239: hideEmitters && !scattered
-                                v3 value = envEval(sc, d);
-                                float pdfSA;
+                                v3 value; float pdfSA;
                                 if (sc.env_constant) {      // ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233): needs the reference normal of the previous vertex
+                                    value = envEval(sc, d);
                                     const float c = qat(q.st3[buf], slot); pdfSA = c != 2.0f ? MI_INV_PI * maxf(0.0f, c) : MI_INV_FOURPI;
-                                } else pdfSA = envPdfDirection(sc, mat3(sc.env_to_local, d));
+                                } else envEvalAndPdf(sc, d, value, pdfSA);      // one atan2f / acosf and one set of texels for both
                                 float lumPdf = prevDelta ? 0.0f : pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
                                 add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
                             }
