@@ -100,6 +100,9 @@ typedef struct {
 #define MI_EMITTER_POINT 3        /* src/emitters/point.cpp: `radiance` = intensity, position = translation of to_world     */
 #define MI_EMITTER_SPOT 4         /* src/emitters/spot.cpp: intensity, to_world, cutoff / beam = cutoffAngle / beamWidth in degrees (no texture) */
 #define MI_EMITTER_DIRECTIONAL 5  /* src/emitters/directional.cpp: `radiance` = irradiance, travel direction = to_world z axis */
+/* 6: reserved (scene files: the compound `sunsky`, expanded by the reference itself inside the drop-in plugin) */
+#define MI_EMITTER_COLLIMATED 7   /* src/emitters/collimated.cpp: `radiance` = power, position = translation of to_world.  A 0-D emitter: sampleDirect always fails (collimated.cpp:129-133), so in this
+                                     unidirectional integrator it contributes nothing itself -- but it takes its share of the emitter-selection probability, exactly as in the reference */
 /* shape: area lights only (index into the shape list; >= n_shapes: analytic shape shape - n_shapes), else -1 */
 typedef struct { uint32_t type; int32_t shape; float radiance[3]; float weight; float cutoff, beam; float to_world[16]; } mi_emitter;
 

@@ -532,6 +532,7 @@ static void flatten(const Scene *scene, FlatScene &fs) {
                 me.cutoff = ep.getFloat("cutoffAngle", 20); me.beam = ep.getFloat("beamWidth", me.cutoff * 3.0f / 4.0f);
                 if (ep.hasProperty("texture")) SLog(EError, "path_hip: spot emitters with a projection texture are not implemented");
             } else if (cls == "DirectionalEmitter") { me.type = MI_EMITTER_DIRECTIONAL; value = ep.getSpectrum("irradiance", Spectrum::getD65()); }
+            else if (cls == "CollimatedBeamEmitter") { me.type = MI_EMITTER_COLLIMATED; value = ep.getSpectrum("power", Spectrum::getD65()); }      // collimated.cpp:60
             else known = false;
             if (known) {
                 if (em->getWorldTransform() && !em->getWorldTransform()->isStatic()) SLog(EError, "path_hip: animated transforms are not implemented");

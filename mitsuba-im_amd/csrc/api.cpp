@@ -239,7 +239,7 @@ int mi_scene_set_emitters(mi_scene *s, const mi_emitter *e, uint32_t n) {
     if (!s || (n && !e)) return fail(MI_ERR_INVALID, "mi_scene_set_emitters: null argument");
     uint32_t nEnv = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        if (e[i].type > MI_EMITTER_DIRECTIONAL) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: implemented emitters: area, envmap, constant, point, spot, directional");
+        if (e[i].type > MI_EMITTER_COLLIMATED || e[i].type == 6u) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_emitters: implemented emitters: area, envmap, constant, point, spot, directional, collimated");
         nEnv += e[i].type == MI_EMITTER_ENVMAP || e[i].type == MI_EMITTER_CONSTANT;
         if (e[i].type == MI_EMITTER_SPOT && !(e[i].cutoff >= e[i].beam && e[i].beam >= 0 && e[i].cutoff > 0)) return fail(MI_ERR_INVALID, "mi_scene_set_emitters: spot needs cutoffAngle >= beamWidth >= 0");   // spot.cpp:77
     }
@@ -590,7 +590,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
         float lo[3], hi[3]; for (int i = 0; i < 3; ++i) { lo[i] = s->h.aabbLo[i]; hi[i] = s->h.aabbHi[i]; }
         auto expand = [&](float x, float y, float z) { const float v[3] = {x, y, z}; for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], v[i]); hi[i] = std::max(hi[i], v[i]); } };
         expand(s->h.c2w[3], s->h.c2w[7], s->h.c2w[11]);
-        for (const mi_emitter &e : s->h.emitters) if (e.type == MI_EMITTER_POINT || e.type == MI_EMITTER_SPOT) expand(e.to_world[3], e.to_world[7], e.to_world[11]);
+        for (const mi_emitter &e : s->h.emitters) if (e.type == MI_EMITTER_POINT || e.type == MI_EMITTER_SPOT || e.type == MI_EMITTER_COLLIMATED) expand(e.to_world[3], e.to_world[7], e.to_world[11]);
         float c[3], d2 = 0; for (int i = 0; i < 3; ++i) { c[i] = (hi[i] + lo[i]) * 0.5f; const float d = c[i] - hi[i]; d2 += d * d; }
         r->rc.alpha_dist = std::sqrt(d2) * 2;
     }

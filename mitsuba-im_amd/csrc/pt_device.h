@@ -1554,6 +1554,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
             dr.p = ref - d * distance; dr.d = -d; dr.n = d; dr.dist = distance; dr.pdf = 1.0f;
             value = V(em.radiance[0], em.radiance[1], em.radiance[2]);
         }
+        // (type 7, CollimatedBeamEmitter::sampleDirect, collimated.cpp:129-133: "direct sampling always fails for a response function on a 0D space" -- pdf stays 0)
         if (dr.pdf != 0) {
             dr.emitter = (int) ei; dr.pdf *= emPdf;
             if (RAW) dr.em_pdf = emPdf; else { float r = 1.0f / emPdf; value = value * r; }

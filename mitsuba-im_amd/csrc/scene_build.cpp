@@ -479,6 +479,7 @@ void SceneHost::commitHost() {
         d.analytic = -1;
         float *x = &emitterX[e * 16];
         if (src.type == MI_EMITTER_POINT || src.type == MI_EMITTER_SPOT) { x[0] = src.to_world[3]; x[1] = src.to_world[7]; x[2] = src.to_world[11]; hasDeltaEmitters = true; }
+        if (src.type == MI_EMITTER_COLLIMATED) { x[0] = src.to_world[3]; x[1] = src.to_world[7]; x[2] = src.to_world[11]; hasDeltaEmitters = true; }      // (selects the kernel variants whose sampleEmitterDirect knows emitter types >= 2)
         if (src.type == MI_EMITTER_DIRECTIONAL) { x[0] = src.to_world[2]; x[1] = src.to_world[6]; x[2] = src.to_world[10]; hasDeltaEmitters = true; }
         if (src.type == MI_EMITTER_SPOT) {                        // SpotEmitter constructor + configure (spot.cpp:70-96); trafo.inverse() of the rigid toWorld
             float beam = src.beam * (MI_PI / 180.0f), cutoff = src.cutoff * (MI_PI / 180.0f);

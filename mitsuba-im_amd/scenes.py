@@ -32,6 +32,7 @@ EMITTER_CONSTANT = 2      # src/emitters/constant.cpp
 EMITTER_POINT = 3         # src/emitters/point.cpp
 EMITTER_SPOT = 4          # src/emitters/spot.cpp
 EMITTER_DIRECTIONAL = 5   # src/emitters/directional.cpp
+EMITTER_COLLIMATED = 7    # src/emitters/collimated.cpp (6: the compound sunsky of scene files)
 FILTER_BOX = 0
 FILTER_GAUSSIAN = 1
 FILTER_TENT = 2
@@ -1140,6 +1141,12 @@ def spot_emitter(origin, target, intensity, cutoff=20.0, beam=None, up=(0, 1, 0)
                 cutoff=float(cutoff), beam=float(cutoff * 0.75 if beam is None else beam))
 
 
+def collimated_emitter(origin, target, power, up=(0, 1, 0), weight=1.0):
+    """src/emitters/collimated.cpp: a beam from `origin` towards `target`.  Direct sampling of a 0-D emitter always fails, so a unidirectional path tracer never
+    receives its light -- it only takes its share of the emitter-selection probability."""
+    return dict(type=EMITTER_COLLIMATED, shape=-1, radiance=tuple(map(float, power)), weight=float(weight), to_world=look_at(origin, target, up))
+
+
 def directional_emitter(direction, irradiance, weight=1.0):
     """direction = where the light travels; toWorld = lookAt(0, d, u) with u from coordinateSystem(d) (directional.cpp:64-67)."""
     d = np.asarray(direction, f32); d = (d / np.sqrt(np.dot(d, d), dtype=f32)).astype(f32)
@@ -1169,6 +1176,14 @@ def cbox_lights(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8,
     sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, hide_emitters=hide_emitters)
     sc.name = "cbox_lights"
     return add_scene_emitters(sc, [point_emitter((120, 420, 150), (4e5, 5e5, 9e5)),
+                                   spot_emitter((430, 500, 100), (300, 0, 330), (3e6, 2.2e6, 1.2e6), cutoff=28.0, beam=17.0)])
+
+
+def cbox_collimated(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0):
+    """cbox_lights plus a `collimated` beam: four emitters in the selection CDF, one of which never returns a sample (collimated.cpp:129-133)."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed)
+    sc.name = "cbox_collimated"
+    return add_scene_emitters(sc, [point_emitter((120, 420, 150), (4e5, 5e5, 9e5)), collimated_emitter((278, 540, 280), (278, 0, 280), (50.0, 50.0, 50.0), up=(0, 0, 1), weight=1.5),
                                    spot_emitter((430, 500, 100), (300, 0, 330), (3e6, 2.2e6, 1.2e6), cutoff=28.0, beam=17.0)])
 
 

@@ -829,6 +829,8 @@ class _SceneBuilder:
                 raise SceneError("spot: projection textures are not supported")
             rec = dict(type=S.EMITTER_SPOT, shape=-1, radiance=tuple(map(float, spec("intensity"))), weight=float(w), to_world=np.eye(4, dtype=f32) if tw is None else tw,
                        cutoff=float(cutoff), beam=float(e.get("beamWidth", float(f32(cutoff) * f32(3.0) / f32(4.0)))))
+        elif t == "collimated":                    # src/emitters/collimated.cpp:60-66: `power`, toWorld without scale factors
+            rec = dict(type=S.EMITTER_COLLIMATED, shape=-1, radiance=tuple(map(float, spec("power"))), weight=float(w), to_world=np.eye(4, dtype=f32) if tw is None else tw)
         elif t == "directional":
             if e.has("direction"):
                 if tw is not None:
@@ -1132,6 +1134,8 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
         elif e["type"] == S.EMITTER_SPOT:
             out.append(f'\t<emitter type="spot">{rgb("intensity", e["radiance"])}{w}<float name="cutoffAngle" value="{fmt([e["cutoff"]])}"/>'
                        f'<float name="beamWidth" value="{fmt([e["beam"]])}"/>{mat("toWorld", e["to_world"])}</emitter>')
+        elif e["type"] == S.EMITTER_COLLIMATED:
+            out.append(f'\t<emitter type="collimated">{rgb("power", e["radiance"])}{w}{mat("toWorld", e["to_world"])}</emitter>')
         elif e["type"] == S.EMITTER_DIRECTIONAL:
             out.append(f'\t<emitter type="directional">{rgb("irradiance", e["radiance"])}{w}{mat("toWorld", e["to_world"])}</emitter>')
     meshes = []

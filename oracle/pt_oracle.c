@@ -1530,6 +1530,9 @@ static v3 sample_emitter_direct(const orc_scene *s, v3 ref, v3 refN, float sx, f
                 I = scale(I, f);
             }
             value = scale(I, invDist * invDist);
+        } else if (em->type == 7) {
+            /* CollimatedBeamEmitter::sampleDirect (collimated.cpp:129-133): direct sampling always fails for a response function on a 0-D space */
+            dr->pdf = 0.0f; return V(0, 0, 0);
         } else {
             /* DirectionalEmitter::sampleDirect (directional.cpp:159-180) */
             dr->delta = 1;
@@ -2185,7 +2188,7 @@ static float sensor_ray_alpha(const orc_scene *s, v3 o, v3 d, const hit_t *its, 
     v3 lo = s->aabb_lo, hi = s->aabb_hi, c;
     v3 cam = V(s->d.cam_to_world[3], s->d.cam_to_world[7], s->d.cam_to_world[11]);
     lo = V(minf(lo.x, cam.x), minf(lo.y, cam.y), minf(lo.z, cam.z)); hi = V(maxf(hi.x, cam.x), maxf(hi.y, cam.y), maxf(hi.z, cam.z));
-    for (uint32_t e = 0; e < s->d.n_emitters; ++e) if (s->emitters[e].type == 3 || s->emitters[e].type == 4) {
+    for (uint32_t e = 0; e < s->d.n_emitters; ++e) if (s->emitters[e].type == 3 || s->emitters[e].type == 4 || s->emitters[e].type == 7) {
         v3 p = V(s->emitters[e].to_world[3], s->emitters[e].to_world[7], s->emitters[e].to_world[11]);
         lo = V(minf(lo.x, p.x), minf(lo.y, p.y), minf(lo.z, p.z)); hi = V(maxf(hi.x, p.x), maxf(hi.y, p.y), maxf(hi.z, p.z));
     }
@@ -2527,7 +2530,7 @@ static int build_bvh(orc_scene *s, uint32_t *tris, int first, int count, v3 *cen
 static void *dup(const void *p, size_t n) { if (!p) return NULL; void *q = malloc(n ? n : 1); memcpy(q, p, n); return q; }
 
 orc_scene *orc_scene_create(const orc_scene_desc *d) {
-    for (uint32_t i = 0; i < d->n_emitters; ++i) if (d->emitters[i].type > 5) return NULL;      /* e.g. the reference's compound `sunsky`: not restated */
+    for (uint32_t i = 0; i < d->n_emitters; ++i) if (d->emitters[i].type > 7 || d->emitters[i].type == 6) return NULL;      /* 6 = the reference's compound `sunsky`: not restated; 7 = collimated */
     if (d->integrator != 0) for (uint32_t i = 0; i < d->n_materials; ++i) {                      /* volumetric walks see through plain records, masks and mixtures (surface_has_null), not through bumpmap / normalmap */
         const orc_material *m = &d->materials[i]; int bad = 0;
         #define ORC_NULL_LOBE(j) ((j) < d->n_materials && (d->materials[j].type == BSDF_NULL || d->materials[j].type == BSDF_THINDIELECTRIC))

@@ -337,12 +337,13 @@ static Built buildScene(const FScene &fs) {
             continue;
         }
         if (fe.type >= 2) {      // constant / point / spot / directional
-            static const char *names[] = {"", "", "constant", "point", "spot", "directional"};
+            static const char *names[] = {"", "", "constant", "point", "spot", "directional", "", "collimated"};
             Properties p(names[fe.type]);
             p.setFloat("samplingWeight", fe.weight);
             Matrix4x4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = fe.toWorld[i * 4 + j];
             if (fe.type == 2) p.setSpectrum("radiance", rgb(fe.radiance));
             else if (fe.type == 5) { p.setSpectrum("irradiance", rgb(fe.radiance)); p.setTransform("toWorld", Transform(m)); }
+            else if (fe.type == 7) { p.setSpectrum("power", rgb(fe.radiance)); p.setTransform("toWorld", Transform(m)); }
             else { p.setSpectrum("intensity", rgb(fe.radiance)); p.setTransform("toWorld", Transform(m)); }
             if (fe.type == 4) { p.setFloat("cutoffAngle", fe.cutoff); p.setFloat("beamWidth", fe.beam); }
             ref<Emitter> em = static_cast<Emitter *>(create(MTS_CLASS(Emitter), p));
