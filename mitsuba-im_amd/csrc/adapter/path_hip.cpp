@@ -67,7 +67,7 @@ static void roughPlasticTables(mi_material &m) {
 /// parent, and every BSDF keeps its textures private, so wrappers and spatially varying BSDFs are read through the one public door that shows their
 /// content: serialisation.  InstanceManager::serialize (src/libcore/serialization.cpp:76-91) writes id, class name, then the object's own serialize();
 /// the layouts parsed here are TwoSidedBRDF (twosided.cpp:79-84), RoughConductor (roughconductor.cpp:219-229), SmoothConductor (conductor.cpp:204-209),
-/// SmoothPlastic (plastic.cpp:180-187), RoughPlastic (roughplastic.cpp:247-257), SmoothDiffuse (diffuse.cpp:163-167), DiffuseTransmitter
+/// SmoothPlastic (plastic.cpp:180-187), RoughPlastic (roughplastic.cpp:247-257), SmoothDiffuse (diffuse.cpp:163-167), RoughDiffuse (roughdiffuse.cpp:269-275), DiffuseTransmitter
 /// (difftrans.cpp:66-70), constant textures (src/librender/basictexture.cpp:29-49), Texture2D (src/librender/texture.cpp:106-110) with Checkerboard /
 /// GridTexture / BitmapTexture (bitmap.cpp:404-432).
 static std::vector<mi_texture> *g_textures = NULL; static std::vector<uint32_t> *g_texLevels = NULL; static std::vector<float> *g_texTexels = NULL;
@@ -176,13 +176,16 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         memcpy(m.reflectance, op.data(), 12); if (opTex >= 0) m.flags |= MI_BSDF_TEXTURE(opTex);
     } else if (cls == "DiffuseTransmitter") {
         std::vector<float> tr = rd.texture(); m.type = MI_BSDF_DIFFTRANS; bind(tr);
+    } else if (cls == "RoughDiffuse") {                                 // roughdiffuse.cpp:269-275: reflectance, alpha, useFastApprox
+        std::vector<float> refl = rd.texture(); m.type = MI_BSDF_ROUGHDIFFUSE; bind(refl);
+        std::vector<float> a = rd.constant("alpha"); m.alpha = a[0]; m.distr = rd.ms->readBool() ? 1u : 0u;
     } else if (cls == "MixtureBSDF") {                                  // mixturebsdf.cpp:104-113: count, then (weight, BSDF) pairs; the children become records of their own
         const size_t count = rd.ms->readSize();
         if (count < 2 || count > 4) SLog(EError, "path_hip: a mixturebsdf with %i BSDFs is not implemented (2..4)", (int) count);
         const uint32_t keepFlags = m.flags; memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MIXTURE; m.flags = keepFlags; m.distr = (uint32_t) count;
         for (size_t i = 0; i < count; ++i) {
             const float w = rd.ms->readFloat(); mi_material child; memset(&child, 0, sizeof(child));
-            if (!readNestedInstance(rd, child) || child.type >= MI_BSDF_MASK) SLog(EError, "path_hip: this BSDF inside a mixturebsdf is not implemented (plain BSDFs, optionally twosided)");
+            if (!readNestedInstance(rd, child) || (child.type >= MI_BSDF_MASK && child.type != MI_BSDF_ROUGHDIFFUSE)) SLog(EError, "path_hip: this BSDF inside a mixturebsdf is not implemented (plain BSDFs, optionally twosided)");
             const float idx = (float) g_materials->size(); g_materials->push_back(child);
             if (i < 3) { m.reflectance[i] = idx; m.k[i] = w; } else { m.eta[0] = idx; m.specular[0] = w; }
         }
@@ -248,6 +251,10 @@ static mi_material convertBSDF(const BSDF *bsdf) {
     if ((bsdf->getType() & BSDF::ESpatiallyVarying) && bsdf->getClass()->getName() != "TwoSidedBRDF") {      // textures are private members: never fall through to the Properties (constants only)
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on diffuse.reflectance, plastic / roughplastic.diffuseReflectance and difftrans.transmittance", bsdf->getClass()->getName().c_str());
+    }
+    if (bsdf->getClass()->getName() == "RoughDiffuse") {      // the constructor wraps its parameters in textures: the serialised form holds them either way
+        if (convertSpatiallyVarying(bsdf, m)) return m;
+        SLog(EError, "path_hip: this `roughdiffuse` is not implemented");
     }
     if (bsdf->getClass()->getName() == "Null") { m.type = MI_BSDF_NULL; return m; }      // src/bsdfs/null.cpp: the index-matched boundary of a medium
     if (bsdf->getClass()->getName() == "RoughConductor") {

@@ -205,7 +205,7 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_NULL) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_ROUGHDIFFUSE) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if (m[i].type == MI_BSDF_BUMPMAP || m[i].type == MI_BSDF_NORMALMAP) {
             // adapters nest in the order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF
@@ -397,7 +397,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
         if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
             (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
-        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK && m.type != MI_BSDF_BUMPMAP && m.type != MI_BSDF_NORMALMAP)))
+        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_ROUGHDIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK && m.type != MI_BSDF_BUMPMAP && m.type != MI_BSDF_NORMALMAP)))
             return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance, mask.opacity or are the map of a bumpmap / normalmap (and must exist)");
     }
     if (s->h.envTexture >= 0) {       // MIP pyramid of the environment map (camera-ray lookups, envmap.cpp:398-411)

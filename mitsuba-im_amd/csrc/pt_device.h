@@ -1195,6 +1195,48 @@ DEV v3 thinDielectricSample(const MaterialD &m, v3 wi, float sx, v3 &wo, float &
     if (sx <= R) { wo = V(-wi.x, -wi.y, wi.z); pdf = R; return ld3(m.specular); }
     nullComp = true; wo = V(-wi.x, -wi.y, -wi.z); pdf = 1 - R; return ld3(m.reflectance);
 }
+// src/bsdfs/roughdiffuse.cpp:131-261 (Oren-Nayar): alpha = the Beckmann-style roughness, distr = 1: useFastApprox.  `m_alpha->eval(its).average()` of the constant
+// texture = ((0 + a) + a + a) * (1 / 3) (spectrum.h:481-486); Frame::sinTheta / cosPhi / sinPhi as in include/mitsuba/core/frame.h:107-154.
+#define MI_BSDF_T_ROUGHDIFFUSE 14u
+DEV float frameSinTheta(v3 v) { const float t = 1.0f - v.z * v.z; return t <= 0.0f ? 0.0f : sqrtf(t); }
+DEV v3 roughDiffuseEval(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    const float conversionFactor = 1 / sqrtf(2.0f);
+    const float avg = (((0.0f + m.alpha) + m.alpha) + m.alpha) * (1.0f / 3);
+    const float sigma = avg * conversionFactor, sigma2 = sigma * sigma;
+    const float sinThetaI = frameSinTheta(wi), sinThetaO = frameSinTheta(wo);
+    float cosPhiDiff = 0;
+    if (sinThetaI > MI_EPSILON && sinThetaO > MI_EPSILON) {
+        const float sinPhiI = minf(1.0f, maxf(-1.0f, wi.y / sinThetaI)), cosPhiI = minf(1.0f, maxf(-1.0f, wi.x / sinThetaI));
+        const float sinPhiO = minf(1.0f, maxf(-1.0f, wo.y / sinThetaO)), cosPhiO = minf(1.0f, maxf(-1.0f, wo.x / sinThetaO));
+        cosPhiDiff = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+    }
+    const v3 rho = V(m.reflectance[0], m.reflectance[1], m.reflectance[2]);
+    if (m.distr == 1u) {
+        const float A = 1.0f - 0.5f * sigma2 / (sigma2 + 0.33f), B = 0.45f * sigma2 / (sigma2 + 0.09f);
+        float sinAlpha, tanBeta;
+        if (wi.z > wo.z) { sinAlpha = sinThetaO; tanBeta = sinThetaI / wi.z; } else { sinAlpha = sinThetaI; tanBeta = sinThetaO / wo.z; }
+        return rho * (MI_INV_PI * wo.z * (A + B * maxf(cosPhiDiff, 0.0f) * sinAlpha * tanBeta));
+    }
+    const float thetaI = acosf(minf(1.0f, maxf(-1.0f, wi.z))), thetaO = acosf(minf(1.0f, maxf(-1.0f, wo.z)));
+    const float alpha = maxf(thetaI, thetaO), beta = minf(thetaI, thetaO);
+    float sinAlpha, sinBeta, tanBeta;
+    if (wi.z > wo.z) { sinAlpha = sinThetaO; sinBeta = sinThetaI; tanBeta = sinThetaI / wi.z; } else { sinAlpha = sinThetaI; sinBeta = sinThetaO; tanBeta = sinThetaO / wo.z; }
+    const float tmp = sigma2 / (sigma2 + 0.09f), tmp2 = (4 * MI_INV_PI * MI_INV_PI) * alpha * beta, tmp3 = 2 * beta * MI_INV_PI;
+    const float C1 = 1.0f - 0.5f * sigma2 / (sigma2 + 0.33f); float C2 = 0.45f * tmp; const float C3 = 0.125f * tmp * tmp2 * tmp2, C4 = 0.17f * sigma2 / (sigma2 + 0.13f);
+    if (cosPhiDiff > 0) C2 *= sinAlpha; else C2 *= sinAlpha - tmp3 * tmp3 * tmp3;
+    const float tanHalf = (sinAlpha + sinBeta) / (sqrtf(maxf(0.0f, 1.0f - sinAlpha * sinAlpha)) + sqrtf(maxf(0.0f, 1.0f - sinBeta * sinBeta)));
+    const v3 snglScat = rho * (C1 + cosPhiDiff * C2 * tanBeta + (1.0f - fabsf(cosPhiDiff)) * C3 * tanHalf);
+    const v3 dblScat = V(rho.x * rho.x, rho.y * rho.y, rho.z * rho.z) * (C4 * (1.0f - cosPhiDiff * tmp3 * tmp3));
+    return (snglScat + dblScat) * (MI_INV_PI * wo.z);
+}
+DEV float roughDiffusePdf(v3 wi, v3 wo) { if (wi.z <= 0 || wo.z <= 0) return 0.0f; return MI_INV_PI * wo.z; }
+DEV v3 roughDiffuseSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float &pdf, float &eta) {      // roughdiffuse.cpp:239-253: eval / pdf, Spectrum / Float = multiplication by the reciprocal (spectrum.h:415-425)
+    if (wi.z <= 0) return V(0, 0, 0);
+    wo = cosHemisphere(sx, sy); eta = 1.0f; pdf = MI_INV_PI * wo.z;
+    const v3 f = roughDiffuseEval(m, wi, wo); const float recip = 1.0f / pdf;
+    return V(f.x * recip, f.y * recip, f.z * recip);
+}
 template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     if (RC && m.type != 0) {
@@ -1203,6 +1245,7 @@ template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, 
         if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) return rdEval(m, wi, wo);
         if (m.type == MI_BSDF_T_DIFFTRANS) return dtEval(m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpEval(sc, m, wi, wo);
+        if (m.type == MI_BSDF_T_ROUGHDIFFUSE) return roughDiffuseEval(m, wi, wo);
         return V(0, 0, 0);
     }
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
@@ -1217,6 +1260,7 @@ template <bool RC> DEV float bsdfPdf(const DScene &sc, const MaterialD &m, v3 wi
         if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) return rdPdf(m, wi, wo);
         if (m.type == MI_BSDF_T_DIFFTRANS) return dtPdf(wi, wo);
         if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpPdf(sc, m, wi, wo);
+        if (m.type == MI_BSDF_T_ROUGHDIFFUSE) return roughDiffusePdf(wi, wo);
         return 0.0f;
     }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
@@ -1236,6 +1280,7 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
         else if (m.type == MI_BSDF_T_ROUGHDIELECTRIC) w = rdSample(m, wi, u, v, extra, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_DIFFTRANS) w = dtSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_ROUGHPLASTIC) w = rpSample(sc, m, wi, u, v, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_ROUGHDIFFUSE) w = roughDiffuseSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_THINDIELECTRIC) w = thinDielectricSample(m, wi, u, wo, pdf, eta, delta, nullComp);
         else if (m.type == MI_BSDF_T_NULL) { wo = V(-wi.x, -wi.y, -wi.z); pdf = 1.0f; eta = 1.0f; delta = true; nullComp = true; w = V(1, 1, 1); }      // src/bsdfs/null.cpp:56-66
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);

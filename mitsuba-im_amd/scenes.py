@@ -24,6 +24,7 @@ BSDF_MASK = 9             # src/bsdfs/mask.cpp: reflectance = opacity (constant 
 BSDF_MIXTURE = 10         # src/bsdfs/mixturebsdf.cpp: distr = number of children (2..4); their material indices in reflectance[0..2], eta[0] (as numbers), weights in k[0..2], specular[0]
 BSDF_BUMPMAP = 11         # src/bsdfs/bumpmap.cpp: distr = index of the nested material record, bound texture = the displacement, alpha = factor of an enclosing `scale` texture
 BSDF_NULL = 13            # src/bsdfs/null.cpp: index-matched boundary of a participating medium (passes straight through, ENull)
+BSDF_ROUGHDIFFUSE = 14     # src/bsdfs/roughdiffuse.cpp (Oren-Nayar): reflectance, alpha (roughness, averaged over the channels there), distr = useFastApprox
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -149,6 +150,8 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
                     reflectance=tuple(ch[:3]), alpha=0.0, eta=(ch[3], 0.0, 0.0), k=tuple(w[:3]), specular=(w[3], 0.0, 0.0))
     if kind == BSDF_ROUGHDIELECTRIC:
         eta = (float(f32(ior)), 0.0, 0.0)
+    if kind == BSDF_ROUGHDIFFUSE:
+        distr = 1 if distr else 0; sample_visible = False     # distr = useFastApprox
     table = None
     if kind == BSDF_ROUGHPLASTIC:
         eta = (float(f32(ior)), 0.0, 0.0); tdiff, table = rough_transmittance_slice(distr, ior, alpha); k = (tdiff, 0.0, float(len(table)))
@@ -1185,6 +1188,20 @@ def cbox_collimated(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_dept
     sc.name = "cbox_collimated"
     return add_scene_emitters(sc, [point_emitter((120, 420, 150), (4e5, 5e5, 9e5)), collimated_emitter((278, 540, 280), (278, 0, 280), (50.0, 50.0, 50.0), up=(0, 0, 1), weight=1.5),
                                    spot_emitter((430, 500, 100), (300, 0, 330), (3e6, 2.2e6, 1.2e6), cutoff=28.0, beam=17.0)])
+
+
+def cbox_roughdiffuse(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False):
+    """Cornell box with `roughdiffuse` (Oren-Nayar) walls, floor and blocks: the full model and the qualitative approximation (useFastApprox), one of them `twosided`."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, strict_normals=strict_normals)
+    sc.name = "cbox_roughdiffuse"
+    mats = [make_bsdf(kind=BSDF_ROUGHDIFFUSE, reflectance=(0.725, 0.71, 0.68), alpha=0.2),                      # floor (full model)
+            make_bsdf(kind=BSDF_ROUGHDIFFUSE, reflectance=(0.725, 0.71, 0.68), alpha=0.7, distr=1),             # back wall (fast approximation)
+            make_bsdf(kind=BSDF_ROUGHDIFFUSE, reflectance=(0.14, 0.45, 0.091), alpha=0.45),                     # right wall
+            make_bsdf(kind=BSDF_ROUGHDIFFUSE, reflectance=(0.2, 0.35, 0.7), alpha=1.0, distr=1, twosided=True), # short block
+            make_bsdf(kind=BSDF_ROUGHDIFFUSE, reflectance=(0.8, 0.6, 0.2), alpha=0.05)]                         # tall block
+    base = len(sc.bsdfs); sc.bsdfs.extend(mats)
+    sc.shapes[0]["bsdf"] = base; sc.shapes[2]["bsdf"] = base + 1; sc.shapes[3]["bsdf"] = base + 2; sc.shapes[6]["bsdf"] = base + 3; sc.shapes[7]["bsdf"] = base + 4
+    return sc
 
 
 def open_constant(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0, hide_emitters=False):

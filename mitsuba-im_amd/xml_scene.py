@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
+    bsdf        diffuse, roughdiffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -552,6 +552,12 @@ class _SceneBuilder:
         elif t == "diffuse":
             refl, tex = _spectrum_or_texture(p, ("reflectance", "diffuseReflectance"), (0.5, 0.5, 0.5))
             rec = S.make_bsdf(S.BSDF_DIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), twosided=twosided)
+        elif t == "roughdiffuse":                          # src/bsdfs/roughdiffuse.cpp:90-101: reflectance (or diffuseReflectance), alpha (0.2), useFastApprox (false)
+            refl, tex = _spectrum_or_texture(p, ("reflectance", "diffuseReflectance"), (0.5, 0.5, 0.5))
+            a = p.get("alpha", 0.2)
+            if not isinstance(a, (int, float)):
+                raise SceneError("roughdiffuse: a textured alpha is not supported")
+            rec = S.make_bsdf(S.BSDF_ROUGHDIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), alpha=float(a), distr=int(bool(p.get("useFastApprox", False))), twosided=twosided)
         elif t == "difftrans":
             tr, tex = _spectrum_or_texture(p, ("transmittance", "diffuseTransmittance"), (0.5, 0.5, 0.5))
             rec = S.make_bsdf(S.BSDF_DIFFTRANS, reflectance=tr or (0.5, 0.5, 0.5))
@@ -1114,6 +1120,8 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="roughplastic">{mf}{sv}{ior}{nl}{rgb("specularReflectance", b["specular"])}{diffuse_param("diffuseReflectance")}</bsdf>'
         elif t == S.BSDF_DIFFTRANS:
             inner = f'<bsdf type="difftrans">{diffuse_param("transmittance")}</bsdf>'
+        elif t == S.BSDF_ROUGHDIFFUSE:
+            inner = f'<bsdf type="roughdiffuse">{diffuse_param("reflectance")}<float name="alpha" value="{fmt([b["alpha"]])}"/><boolean name="useFastApprox" value="{str(bool(b["distr"])).lower()}"/></bsdf>'
         elif t == S.BSDF_NULL:
             inner = '<bsdf type="null"></bsdf>'
         else:

@@ -802,7 +802,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
@@ -1316,6 +1316,46 @@ static v3 rp_sample(const orc_material *mt, v3 wi, float sx, float sy, v3 *wo, f
     float r = 1.0f / *pdf; return scale(rp_eval(mt, wi, *wo), r);       /* Spectrum / Float */
 }
 
+/* ---- rough diffuse (Oren-Nayar): src/bsdfs/roughdiffuse.cpp:131-261.  alpha = m_alpha (constant), distr = 1: useFastApprox; m_alpha->eval(its).average() of the
+ * constant texture = ((0 + a) + a + a) * (1 / 3) (include/mitsuba/core/spectrum.h:481-486); Frame::sinTheta / cosPhi / sinPhi: include/mitsuba/core/frame.h:107-154;
+ * math::clamp = min(max, max(min, v)) (math.h:51-53); sample() returns eval / pdf = eval * (1 / pdf) (spectrum.h:415-425) */
+static float frame_sin_theta(v3 v) { float t = 1.0f - v.z * v.z; if (t <= 0.0f) return 0.0f; return sqrtf(t); }
+static v3 roughdiffuse_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    const float conversionFactor = 1 / sqrtf(2.0f);
+    float avg = 0.0f; avg += m->alpha; avg += m->alpha; avg += m->alpha; avg = avg * (1.0f / 3);
+    float sigma = avg * conversionFactor, sigma2 = sigma * sigma;
+    float sinThetaI = frame_sin_theta(wi), sinThetaO = frame_sin_theta(wo), cosPhiDiff = 0;
+    if (sinThetaI > EPSILON && sinThetaO > EPSILON) {
+        float sinPhiI = minf(1.0f, maxf(-1.0f, wi.y / sinThetaI)), cosPhiI = minf(1.0f, maxf(-1.0f, wi.x / sinThetaI));
+        float sinPhiO = minf(1.0f, maxf(-1.0f, wo.y / sinThetaO)), cosPhiO = minf(1.0f, maxf(-1.0f, wo.x / sinThetaO));
+        cosPhiDiff = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+    }
+    v3 rho = V(m->reflectance[0], m->reflectance[1], m->reflectance[2]);
+    if (m->distr == 1u) {
+        float A = 1.0f - 0.5f * sigma2 / (sigma2 + 0.33f), B = 0.45f * sigma2 / (sigma2 + 0.09f), sinAlpha, tanBeta;
+        if (wi.z > wo.z) { sinAlpha = sinThetaO; tanBeta = sinThetaI / wi.z; } else { sinAlpha = sinThetaI; tanBeta = sinThetaO / wo.z; }
+        return scale(rho, INV_PI * wo.z * (A + B * maxf(cosPhiDiff, 0.0f) * sinAlpha * tanBeta));
+    }
+    float thetaI = acosf(minf(1.0f, maxf(-1.0f, wi.z))), thetaO = acosf(minf(1.0f, maxf(-1.0f, wo.z)));
+    float alpha = maxf(thetaI, thetaO), beta = minf(thetaI, thetaO), sinAlpha, sinBeta, tanBeta;
+    if (wi.z > wo.z) { sinAlpha = sinThetaO; sinBeta = sinThetaI; tanBeta = sinThetaI / wi.z; } else { sinAlpha = sinThetaI; sinBeta = sinThetaO; tanBeta = sinThetaO / wo.z; }
+    float tmp = sigma2 / (sigma2 + 0.09f), tmp2 = (4 * INV_PI * INV_PI) * alpha * beta, tmp3 = 2 * beta * INV_PI;
+    float C1 = 1.0f - 0.5f * sigma2 / (sigma2 + 0.33f), C2 = 0.45f * tmp, C3 = 0.125f * tmp * tmp2 * tmp2, C4 = 0.17f * sigma2 / (sigma2 + 0.13f);
+    if (cosPhiDiff > 0) C2 *= sinAlpha; else C2 *= sinAlpha - tmp3 * tmp3 * tmp3;
+    float tanHalf = (sinAlpha + sinBeta) / (sqrtf(maxf(0.0f, 1.0f - sinAlpha * sinAlpha)) + sqrtf(maxf(0.0f, 1.0f - sinBeta * sinBeta)));
+    v3 snglScat = scale(rho, C1 + cosPhiDiff * C2 * tanBeta + (1.0f - fabsf(cosPhiDiff)) * C3 * tanHalf);
+    v3 dblScat = scale(V(rho.x * rho.x, rho.y * rho.y, rho.z * rho.z), C4 * (1.0f - cosPhiDiff * tmp3 * tmp3));
+    return scale(add(snglScat, dblScat), INV_PI * wo.z);
+}
+static float roughdiffuse_pdf(v3 wi, v3 wo) { if (wi.z <= 0 || wo.z <= 0) return 0.0f; return INV_PI * wo.z; }
+static v3 roughdiffuse_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *eta) {
+    if (wi.z <= 0) return V(0, 0, 0);
+    *wo = cos_hemisphere(sx, sy); *eta = 1.0f; *pdf = INV_PI * wo->z;
+    v3 f = roughdiffuse_eval(m, wi, *wo); float recip = 1.0f / *pdf;
+    return V(f.x * recip, f.y * recip, f.z * recip);
+}
+
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
@@ -1325,6 +1365,7 @@ static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_ROUGHDIELECTRIC: return rd_eval(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_eval(m, wi, wo);
         case BSDF_ROUGHPLASTIC: return rp_eval(m, wi, wo);
+        case BSDF_ROUGHDIFFUSE: return roughdiffuse_eval(m, wi, wo);
         default: return diffuse_eval(m, wi, wo);
     }
 }
@@ -1337,6 +1378,7 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_ROUGHDIELECTRIC: return rd_pdf(m, wi, wo);
         case BSDF_DIFFTRANS: return dt_pdf(wi, wo);
         case BSDF_ROUGHPLASTIC: return rp_pdf(m, wi, wo);
+        case BSDF_ROUGHDIFFUSE: return roughdiffuse_pdf(wi, wo);
         default: return diffuse_pdf(wi, wo);
     }
 }
@@ -1355,6 +1397,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_ROUGHDIELECTRIC: w = rd_sample(m, wi, u, v, sp ? next1D(sp) : g_extra_unit, wo, pdf, eta); break;
         case BSDF_DIFFTRANS: w = dt_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_ROUGHPLASTIC: w = rp_sample(m, wi, u, v, wo, pdf, eta); break;
+        case BSDF_ROUGHDIFFUSE: w = roughdiffuse_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_THINDIELECTRIC: w = thindielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
         case BSDF_NULL: *wo = neg(wi); *pdf = 1.0f; *eta = 1.0f; *delta = 2; w = V(1, 1, 1); break;      /* src/bsdfs/null.cpp:56-66: the index-matched boundary, sampledType = ENull */
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;
