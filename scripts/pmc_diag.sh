@@ -11,6 +11,9 @@ pass sq SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES
 # TA block, ONE derived counter per pass: round 2's single pass of four TA counters was rejected at rocprofiler_create_counter_config ("error code 38: Request exceeds the
 # capabilities of the hardware to collect", gpurun_out/r02.prev/diag_C4_ta.log) -- before the program launched anything: a counter-SET rejection (the TA block has two
 # counter slots per instance and the *_sum / _avr forms take one each per shader engine), not a GPU fault.  Two counters per pass fit.
+# what the waves wait FOR: vector loads vs stores vs LDS vs scalar memory (instruction counts and the cycles each kind keeps a wave busy), one group per pass (8 SQ counters fit)
+pass sq2 SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_LDS
+pass tcpw TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_GATE_EN1_sum
 pass ta1 TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum
 pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum
