@@ -94,7 +94,11 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
             do {
                 if (prim == 0xFFFFFFFFu) {                                     // miss: path.cpp:136-143 / :234-248
                     pathLen += (unsigned) (depth > 1 ? depth - 1 : 1);
-                    if (depth == 1 && rc.opacity) { float4 a = qat(q.acc, pid); a.w = 0.0f; qat(q.acc, pid) = a; }   // records.inl:121-137: alpha = 0 on a camera-ray miss
+                    // the pixel's accumulator is read HERE, next to the ray origin, so that its round trip to HBM overlaps the environment lookup instead of following it
+                    const bool clearAlpha = depth == 1 && rc.opacity;                                                 // records.inl:121-137: alpha = 0 on a camera-ray miss
+                    float4 accum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (ENV || clearAlpha) accum = qat(q.acc, pid);
+                    if (clearAlpha) accum.w = 0.0f;
                     if (ENV) {
                         if (depth == 1) { if (!rc.hide_emitters && !sc.env_texture) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141; with a MIP pyramid k_env_primary has added the filtered lookup
                         else {
@@ -111,6 +115,9 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                             }
                         }
                     }
+                    if (haveAdd) { accum.x += add.x; accum.y += add.y; accum.z += add.z; }
+                    if (haveAdd || clearAlpha) qat(q.acc, pid) = accum;
+                    haveAdd = false;
                     break;
                 }
                 v3 ro3 = V(0, 0, 0);
