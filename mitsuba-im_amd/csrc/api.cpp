@@ -360,6 +360,8 @@ int SceneHost::upload(int dev) {
     }
     d.bvh_depth = (uint32_t) bvhDepth; d.bvh_wide = wideBvh ? 1u : 0u; d.bvh_stack_direct = (uint32_t) bvhStackDirect;
     d.area_cdf_len = (uint32_t) areaCdf.size();
+    { uint32_t maxLightTris = 0; for (const EmitterD &e : emittersD) if (e.tri_count > maxLightTris) maxLightTris = e.tri_count;
+      const char *sf = getenv("MI355PT_SEARCH"); d.search_flags = sf ? (uint32_t) atoi(sf) : ((emittersD.size() <= 3 ? 1u : 0u) | (maxLightTris <= 3u ? 2u : 0u)); }
     { const char *ns = getenv("MI355PT_NO_LDS_TABLES");
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;

@@ -22,6 +22,7 @@ DEV v3 normalize(v3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; } 
 DEV bool isZero(v3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 DEV float maxf(float a, float b) { return a > b ? a : b; }
 DEV float minf(float a, float b) { return a < b ? a : b; }
+DEV uint32_t minu(uint32_t a, uint32_t b) { return a < b ? a : b; }
 DEV v3 ld3(const float *p) { return V(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------------------------------------- samplers
@@ -1541,6 +1542,27 @@ DEV uint32_t cdfSample(P cdf, uint32_t n, float x) {
     while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
     return index;
 }
+// The same search and the two entries around its result (the caller's sample reuse) for tables of up to three bins -- emitter selection and the triangles of a quad light in
+// most scenes -- from ONE round trip: cdf[0..n] is fetched whole and lower_bound is the number of entries below x (the table is non-decreasing).  The binary search and the
+// reuse after it are five dependent loads, and in the shade stage every dependent load is a latency the resident waves cannot cover.  `whole` is uniform over
+// the launch (DScene::search_flags): with light meshes of both kinds in one scene the lanes of a wave would run both searches one after the other (Veach-MIS: -2 %).
+template <typename P>
+DEV uint32_t cdfSampleReuse(P cdf, uint32_t n, float x, float &a0, float &a1, bool whole) {
+    if (whole && n <= 3u) {
+        const float c0 = cdf[0], c1 = cdf[1], c2 = cdf[n >= 2u ? 2u : n], c3 = cdf[n >= 3u ? 3u : n];
+        const uint32_t lo = (c0 < x ? 1u : 0u) + (c1 < x ? 1u : 0u) + ((n >= 2u && c2 < x) ? 1u : 0u) + ((n >= 3u && c3 < x) ? 1u : 0u);
+        uint32_t index = lo > 0 ? lo - 1 : 0; if (index > n - 1) index = n - 1;
+        if (index == 0u && c1 - c0 == 0) index = 1u;
+        if (index == 1u && n > 1u && c2 - c1 == 0) index = 2u;
+        if (index == 2u && n > 2u && c3 - c2 == 0) index = 3u;
+        if (index >= n) { a0 = cdf[index]; a1 = cdf[index + 1]; return index; }      // (a table that ends in empty bins: what the loop below reads)
+        a0 = index == 0u ? c0 : index == 1u ? c1 : c2; a1 = index == 0u ? c1 : index == 1u ? c2 : c3;
+        return index;
+    }
+    const uint32_t index = cdfSample(cdf, n, x);
+    a0 = cdf[index]; a1 = cdf[index + 1];
+    return index;
+}
 struct Direct { v3 p, n, d; float dist, pdf; float em_pdf; /* probability of the chosen emitter (RAW) */ int emitter; bool delta; /* !isOnSurface: point / spot / directional */ };
 // src/emitters/area.cpp:106-111
 template <bool L>
@@ -1554,8 +1576,7 @@ DEV v3 emitterEval(const Tabs<L> &tb, int e, v3 ns, v3 d) {
 // RAW (Scene::sampleAttenuatedEmitterDirect, scene.cpp:886-931): the value is NOT yet divided by the emitter-selection probability (dr.em_pdf): the transmittance joins it first
 template <bool ENV, bool AN, bool L, bool RAW = false>
 DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN, float sx, float sy, Direct &dr) {
-    uint32_t ei = cdfSample(tb.emitter_cdf, sc.n_emitters, sx);
-    float c0 = tb.emitter_cdf[ei], c1 = tb.emitter_cdf[ei + 1];
+    float c0, c1; const uint32_t ei = cdfSampleReuse(tb.emitter_cdf, sc.n_emitters, sx, c0, c1, (sc.search_flags & 1u) != 0);
     float emPdf = c1 - c0;
     sx = (sx - c0) / (c1 - c0);
     const EmitterD em = loadEmitter(tb, (int) ei);
@@ -1622,8 +1643,7 @@ DEV v3 sampleEmitterDirect(const DScene &sc, const Tabs<L> &tb, v3 ref, v3 refN,
         analyticSampleDirect(sc.analytic[em.analytic], ref, sx, sy, dr.p, dr.n, dr.d, dr.dist, dr.pdf);
     } else {
     typename AS<L>::pf acdf = tb.area_cdf + em.cdf_offset;
-    uint32_t ti = cdfSample(acdf, em.tri_count, sy);
-    float a0 = acdf[ti], a1 = acdf[ti + 1];
+    float a0, a1; const uint32_t ti = cdfSampleReuse(acdf, em.tri_count, sy, a0, a1, (sc.search_flags & 2u) != 0);
     sy = (sy - a0) / (a1 - a0);
     uint32_t prim = em.first_tri + ti;
     typename AS<L>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS;

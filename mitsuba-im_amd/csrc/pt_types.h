@@ -145,6 +145,7 @@ struct DScene {
     // traversal variant: packet_n > 0 -> the whole scene is ONE triangle packet held in constant memory (scenes of <= MI_PACKET_MAX
     // triangles: every lane tests every triangle with wave-uniform operands, no stack, no divergence); else BVH of depth bvh_depth
     uint64_t geo_bytes;                   // nodes + leaf records live in one allocation of this many bytes (nodes first)
+    uint32_t search_flags;                // table searches of emitter sampling fetched whole (cdfSampleReuse): bit 0 the emitter-selection table (<= 3 emitters), bit 1 the triangle tables of the area lights (every light mesh <= 3 triangles); MI355PT_SEARCH overrides (A/B runs)
     uint32_t bvh_stack_direct;            // stack entries per lane the fused walk of trace_fused.h can need on the scene-level tree
     uint32_t packet_n, bvh_depth, bvh_wide;   // bvh_depth: traversal stack entries the tree(s) can need; bvh_wide: the node array holds Bvh4Node records
     // packet mode (trace.h): pass-1 records (PacketGroupD, sorted by projection axis: [0,gk[0]) axis 0, [gk[0],gk[1]) axis 1, [gk[1],gk[2]) axis 2; degenerate
