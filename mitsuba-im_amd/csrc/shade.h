@@ -2,6 +2,9 @@
 // unit per (RC, ENV) pair so that `make -j` compiles the variants side by side.
 #pragma once
 #include "kernels_common.h"
+#ifndef MI_SHADE_MIN_WAVES
+#define MI_SHADE_MIN_WAVES 1      // waves per SIMD asked of the compiler (A/B builds; DESIGN.md §3: a register cap only moves the live set into scratch)
+#endif
 
 // ---------------------------------------------------------------------------------------------- shade
 // One bounce of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for every live path of the segment:
@@ -10,7 +13,7 @@
 //   BSDF sampling :207-226.  Survivors are compacted into the other ray/state buffer, shadow rays into the shadow queue.
 // WRAP: the BSDF adapters mixturebsdf / bumpmap / normalmap are present (only with RC and AN): scenes without them keep the leaner kernels
 template <bool RC, bool ENV, bool SMALL, bool AN, bool TEX, bool WRAP>   // TEX: textures bound to materials (implies AN); RC: rough conductors present; ENV: environment emitter present; SMALL: scene tables staged in LDS; AN ("extended"): analytic shapes or delta emitters (point / spot / directional) present
-__global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
+__global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, RenderConst rc, Queues q, int buf) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t *s_nib = s_dyn;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,15 +106,19 @@ __global__ __launch_bounds__(WG) void k_shade(DScene sc, RenderConst rc, Queues 
                         if (depth == 1) { if (!rc.hide_emitters && !sc.env_texture) { add = T * envEval(sc, d); haveAdd = true; } }     // path.cpp:139-141; with a MIP pyramid k_env_primary has added the filtered lookup
                         else {
                             // BSDF ray left the scene: env->evalEnvironment + fillDirectSamplingRecord (envmap.cpp:362-378), MIS term path.cpp:257-264
-                            float4 ro = qat(q.rayO[buf], slot); float nearT, farT;
-                            if (!(rc.hide_emitters && unscattered) && bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {   // path.cpp:238-239: hideEmitters && !scattered
+                            // (the ray origin is only needed for the bounding-sphere test: it is requested first and consumed after the environment lookup, whose
+                            // atan2f / acosf and texel fetches then cover its round trip to HBM)
+                            const float4 ro = qat(q.rayO[buf], slot); float nearT, farT;
+                            if (!(rc.hide_emitters && unscattered)) {   // path.cpp:238-239: hideEmitters && !scattered
                                 v3 value; float pdfSA;
                                 if (sc.env_constant) {      // ConstantBackgroundEmitter::pdfDirect (constant.cpp:219-233): needs the reference normal of the previous vertex
                                     value = envEval(sc, d);
                                     const float c = qat(q.st3[buf], slot); pdfSA = c != 2.0f ? MI_INV_PI * maxf(0.0f, c) : MI_INV_FOURPI;
                                 } else envEvalAndPdf(sc, d, value, pdfSA);      // one atan2f / acosf and one set of texels for both
+                                if (bsphereIntersect(sc, V(ro.x, ro.y, ro.z), d, nearT, farT) && !(nearT > 0) && !(farT < 0)) {
                                 float lumPdf = prevDelta ? 0.0f : pdfSA * (loadEmitter(tb, sc.env_index).weight * sc.emitter_norm);
                                 add = (T * value) * miWeight(prevPdf, lumPdf); haveAdd = true;
+                                }
                             }
                         }
                     }
