@@ -73,6 +73,8 @@ typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling
                                      order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF */
 #define MI_BSDF_NULL 13           /* src/bsdfs/null.cpp: the index-matched boundary of a participating medium (straight pass-through, ENull; no parameters) */
 #define MI_BSDF_ROUGHDIFFUSE 14    /* src/bsdfs/roughdiffuse.cpp (Oren-Nayar): reflectance (constant or a bound texture), alpha, distr = 1: useFastApprox */
+#define MI_BSDF_PHONG 15           /* src/bsdfs/phong.cpp (modified Phong): reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent,
+                                      k[0] = specular sampling weight = lum(specular) / (lum(diffuse) + lum(specular)) (phong.cpp:104-108); constants only */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

@@ -205,7 +205,7 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_ROUGHDIFFUSE) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_PHONG) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if (m[i].type == MI_BSDF_BUMPMAP || m[i].type == MI_BSDF_NORMALMAP) {
             // adapters nest in the order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF

@@ -1238,6 +1238,42 @@ DEV v3 roughDiffuseSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo,
     const v3 f = roughDiffuseEval(m, wi, wo); const float recip = 1.0f / pdf;
     return V(f.x * recip, f.y * recip, f.z * recip);
 }
+// src/bsdfs/phong.cpp:130-256 (modified Phong): reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent, k[0] = m_specularSamplingWeight
+// (configure(), :104-108: luminance of the specular average over the sum of both); two components (glossy 0, diffuse 1), always queried together on this path
+#define MI_BSDF_T_PHONG 15u
+DEV float phongExponent(const MaterialD &m) { return (((0.0f + m.alpha) + m.alpha) + m.alpha) * (1.0f / 3); }      // m_exponent->eval(its).average()
+DEV v3 phongEval(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    v3 result = V(0, 0, 0);
+    const float alpha = dot(wo, V(-wi.x, -wi.y, wi.z)), exponent = phongExponent(m);
+    if (alpha > 0.0f) result = ld3(m.specular) * ((exponent + 2) * MI_INV_TWOPI * powf(alpha, exponent));
+    result = result + ld3(m.reflectance) * MI_INV_PI;
+    return result * wo.z;
+}
+DEV float phongPdf(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    const float diffuseProb = MI_INV_PI * wo.z; float specProb = 0.0f;
+    const float alpha = dot(wo, V(-wi.x, -wi.y, wi.z)), exponent = phongExponent(m);
+    if (alpha > 0) specProb = powf(alpha, exponent) * (exponent + 1.0f) / (2.0f * MI_PI);
+    return m.k[0] * specProb + (1 - m.k[0]) * diffuseProb;
+}
+DEV v3 phongSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float &pdf, float &eta) {
+    const float w = m.k[0]; bool choseSpecular = true;
+    if (sx <= w) sx /= w; else { sx = (sx - w) / (1 - w); choseSpecular = false; }
+    if (choseSpecular) {
+        const v3 R = V(-wi.x, -wi.y, wi.z); const float exponent = phongExponent(m);
+        const float sinAlpha = sqrtf(1 - powf(sy, 2 / (exponent + 1))), cosAlpha = powf(sy, 1 / (exponent + 1)), phi = (2.0f * MI_PI) * sx;
+        const float2 sc = glibcSincosf2(phi);
+        const v3 local = V(sinAlpha * sc.y, sinAlpha * sc.x, cosAlpha);
+        v3 fs, ft; coordinateSystem(R, fs, ft);
+        wo = (fs * local.x + ft * local.y) + R * local.z;
+        if (wo.z <= 0) return V(0, 0, 0);
+    } else wo = cosHemisphere(sx, sy);
+    eta = 1.0f; pdf = phongPdf(m, wi, wo);
+    if (pdf == 0) return V(0, 0, 0);
+    const v3 f = phongEval(m, wi, wo); const float recip = 1.0f / pdf;
+    return V(f.x * recip, f.y * recip, f.z * recip);
+}
 template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     if (RC && m.type != 0) {
@@ -1247,6 +1283,7 @@ template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, 
         if (m.type == MI_BSDF_T_DIFFTRANS) return dtEval(m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpEval(sc, m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHDIFFUSE) return roughDiffuseEval(m, wi, wo);
+        if (m.type == MI_BSDF_T_PHONG) return phongEval(m, wi, wo);
         return V(0, 0, 0);
     }
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
@@ -1262,6 +1299,7 @@ template <bool RC> DEV float bsdfPdf(const DScene &sc, const MaterialD &m, v3 wi
         if (m.type == MI_BSDF_T_DIFFTRANS) return dtPdf(wi, wo);
         if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpPdf(sc, m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHDIFFUSE) return roughDiffusePdf(wi, wo);
+        if (m.type == MI_BSDF_T_PHONG) return phongPdf(m, wi, wo);
         return 0.0f;
     }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
@@ -1282,6 +1320,7 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
         else if (m.type == MI_BSDF_T_DIFFTRANS) w = dtSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_ROUGHPLASTIC) w = rpSample(sc, m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_ROUGHDIFFUSE) w = roughDiffuseSample(m, wi, u, v, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_PHONG) w = phongSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_THINDIELECTRIC) w = thinDielectricSample(m, wi, u, wo, pdf, eta, delta, nullComp);
         else if (m.type == MI_BSDF_T_NULL) { wo = V(-wi.x, -wi.y, -wi.z); pdf = 1.0f; eta = 1.0f; delta = true; nullComp = true; w = V(1, 1, 1); }      // src/bsdfs/null.cpp:56-66
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);

@@ -25,6 +25,7 @@ BSDF_MIXTURE = 10         # src/bsdfs/mixturebsdf.cpp: distr = number of childre
 BSDF_BUMPMAP = 11         # src/bsdfs/bumpmap.cpp: distr = index of the nested material record, bound texture = the displacement, alpha = factor of an enclosing `scale` texture
 BSDF_NULL = 13            # src/bsdfs/null.cpp: index-matched boundary of a participating medium (passes straight through, ENull)
 BSDF_ROUGHDIFFUSE = 14     # src/bsdfs/roughdiffuse.cpp (Oren-Nayar): reflectance, alpha (roughness, averaged over the channels there), distr = useFastApprox
+BSDF_PHONG = 15            # src/bsdfs/phong.cpp: reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent, k[0] = specular sampling weight
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -152,6 +153,10 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         eta = (float(f32(ior)), 0.0, 0.0)
     if kind == BSDF_ROUGHDIFFUSE:
         distr = 1 if distr else 0; sample_visible = False     # distr = useFastApprox
+    if kind == BSDF_PHONG:                            # alpha = exponent; k[0] = m_specularSamplingWeight (phong.cpp:104-108), float arithmetic as in Spectrum::getLuminance (spectrum.h:725-727)
+        lum = lambda c: f32(f32(f32(f32(c[0]) * f32(0.212671)) + f32(f32(c[1]) * f32(0.715160))) + f32(f32(c[2]) * f32(0.072169)))
+        if max(float(f32(a) + f32(b)) for a, b in zip(reflectance, specular)) > 1.0: raise ValueError("phong: diffuseReflectance + specularReflectance > 1 (the reference rescales both, BSDF::ensureEnergyConservation): not implemented")
+        d_avg, s_avg = lum(reflectance), lum(specular); k = (float(f32(s_avg / f32(d_avg + s_avg))), 0.0, 0.0); distr = 0; sample_visible = False
     table = None
     if kind == BSDF_ROUGHPLASTIC:
         eta = (float(f32(ior)), 0.0, 0.0); tdiff, table = rough_transmittance_slice(distr, ior, alpha); k = (tdiff, 0.0, float(len(table)))
@@ -1201,6 +1206,19 @@ def cbox_roughdiffuse(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_de
             make_bsdf(kind=BSDF_ROUGHDIFFUSE, reflectance=(0.8, 0.6, 0.2), alpha=0.05)]                         # tall block
     base = len(sc.bsdfs); sc.bsdfs.extend(mats)
     sc.shapes[0]["bsdf"] = base; sc.shapes[2]["bsdf"] = base + 1; sc.shapes[3]["bsdf"] = base + 2; sc.shapes[6]["bsdf"] = base + 3; sc.shapes[7]["bsdf"] = base + 4
+    return sc
+
+
+def cbox_phong(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False):
+    """Cornell box with modified-`phong` floor, back wall and blocks (exponents 5 .. 300, one `twosided`, one purely specular-dominated)."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, strict_normals=strict_normals)
+    sc.name = "cbox_phong"
+    mats = [make_bsdf(kind=BSDF_PHONG, reflectance=(0.5, 0.5, 0.5), specular=(0.2, 0.2, 0.2), alpha=30.0),                      # floor (the plugin's defaults)
+            make_bsdf(kind=BSDF_PHONG, reflectance=(0.3, 0.28, 0.25), specular=(0.6, 0.6, 0.65), alpha=300.0),                  # back wall
+            make_bsdf(kind=BSDF_PHONG, reflectance=(0.1, 0.3, 0.6), specular=(0.3, 0.2, 0.1), alpha=5.0, twosided=True),        # short block
+            make_bsdf(kind=BSDF_PHONG, reflectance=(0.02, 0.02, 0.02), specular=(0.9, 0.7, 0.3), alpha=80.0)]                   # tall block
+    base = len(sc.bsdfs); sc.bsdfs.extend(mats)
+    sc.shapes[0]["bsdf"] = base; sc.shapes[2]["bsdf"] = base + 1; sc.shapes[6]["bsdf"] = base + 2; sc.shapes[7]["bsdf"] = base + 3
     return sc
 
 

@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughdiffuse, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
+    bsdf        diffuse, roughdiffuse, phong, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -558,6 +558,16 @@ class _SceneBuilder:
             if not isinstance(a, (int, float)):
                 raise SceneError("roughdiffuse: a textured alpha is not supported")
             rec = S.make_bsdf(S.BSDF_ROUGHDIFFUSE, reflectance=refl or (0.5, 0.5, 0.5), alpha=float(a), distr=int(bool(p.get("useFastApprox", False))), twosided=twosided)
+        elif t == "phong":                                 # src/bsdfs/phong.cpp:63-72: diffuseReflectance (0.5), specularReflectance (0.2), exponent (30); constants only
+            dr, tex = _spectrum_or_texture(p, ("diffuseReflectance",), (0.5, 0.5, 0.5))
+            sr, stex = _spectrum_or_texture(p, ("specularReflectance",), (0.2, 0.2, 0.2))
+            ex = p.get("exponent", 30.0)
+            if tex is not None or stex is not None or not isinstance(ex, (int, float)):
+                raise SceneError("phong: textured parameters are not supported")
+            try:
+                rec = S.make_bsdf(S.BSDF_PHONG, reflectance=dr or (0.5, 0.5, 0.5), specular=sr or (0.2, 0.2, 0.2), alpha=float(ex), twosided=twosided)
+            except ValueError as e:
+                raise SceneError(str(e))
         elif t == "difftrans":
             tr, tex = _spectrum_or_texture(p, ("transmittance", "diffuseTransmittance"), (0.5, 0.5, 0.5))
             rec = S.make_bsdf(S.BSDF_DIFFTRANS, reflectance=tr or (0.5, 0.5, 0.5))
@@ -613,7 +623,7 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, thindielectric, mask, twosided)")
+                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, thindielectric, mask, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -1122,6 +1132,8 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="difftrans">{diffuse_param("transmittance")}</bsdf>'
         elif t == S.BSDF_ROUGHDIFFUSE:
             inner = f'<bsdf type="roughdiffuse">{diffuse_param("reflectance")}<float name="alpha" value="{fmt([b["alpha"]])}"/><boolean name="useFastApprox" value="{str(bool(b["distr"])).lower()}"/></bsdf>'
+        elif t == S.BSDF_PHONG:
+            inner = f'<bsdf type="phong">{rgb("diffuseReflectance", b["reflectance"])}{rgb("specularReflectance", b["specular"])}<float name="exponent" value="{fmt([b["alpha"]])}"/></bsdf>'
         elif t == S.BSDF_NULL:
             inner = '<bsdf type="null"></bsdf>'
         else:

@@ -802,7 +802,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
@@ -1356,6 +1356,42 @@ static v3 roughdiffuse_sample(const orc_material *m, v3 wi, float sx, float sy, 
     return V(f.x * recip, f.y * recip, f.z * recip);
 }
 
+/* ---- modified Phong: src/bsdfs/phong.cpp:130-256.  reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent (a constant texture:
+ * eval(its).average() = ((0 + e) + e + e) * (1 / 3)), k[0] = m_specularSamplingWeight (configure(), :104-108).  M_PI is the float constant (constants.h:63, 80);
+ * Frame(R).toWorld (frame.h:83-85) over coordinateSystem (util.cpp:594-603) */
+static float phong_exponent(const orc_material *m) { float e = 0.0f; e += m->alpha; e += m->alpha; e += m->alpha; return e * (1.0f / 3); }
+static v3 phong_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    v3 result = V(0, 0, 0);
+    float alpha = dot(wo, V(-wi.x, -wi.y, wi.z)), exponent = phong_exponent(m);
+    if (alpha > 0.0f) result = scale(V(m->specular[0], m->specular[1], m->specular[2]), (exponent + 2) * INV_TWOPI * powf(alpha, exponent));
+    result = add(result, scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), INV_PI));
+    return scale(result, wo.z);
+}
+static float phong_pdf(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    float diffuseProb = INV_PI * wo.z, specProb = 0.0f;
+    float alpha = dot(wo, V(-wi.x, -wi.y, wi.z)), exponent = phong_exponent(m);
+    if (alpha > 0) specProb = powf(alpha, exponent) * (exponent + 1.0f) / (2.0f * M_PI_F);
+    return m->k[0] * specProb + (1 - m->k[0]) * diffuseProb;
+}
+static v3 phong_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *eta) {
+    float w = m->k[0]; int choseSpecular = 1;
+    if (sx <= w) sx /= w; else { sx = (sx - w) / (1 - w); choseSpecular = 0; }
+    if (choseSpecular) {
+        v3 R = V(-wi.x, -wi.y, wi.z), fs, ft; float exponent = phong_exponent(m);
+        float sinAlpha = sqrtf(1 - powf(sy, 2 / (exponent + 1))), cosAlpha = powf(sy, 1 / (exponent + 1)), phi = (2.0f * M_PI_F) * sx;
+        v3 local = V(sinAlpha * cosf(phi), sinAlpha * sinf(phi), cosAlpha);
+        coordinate_system(R, &fs, &ft);
+        *wo = add(add(scale(fs, local.x), scale(ft, local.y)), scale(R, local.z));
+        if (wo->z <= 0) return V(0, 0, 0);
+    } else *wo = cos_hemisphere(sx, sy);
+    *eta = 1.0f; *pdf = phong_pdf(m, wi, *wo);
+    if (*pdf == 0) return V(0, 0, 0);
+    v3 f = phong_eval(m, wi, *wo); float recip = 1.0f / *pdf;
+    return V(f.x * recip, f.y * recip, f.z * recip);
+}
+
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
@@ -1366,6 +1402,7 @@ static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_DIFFTRANS: return dt_eval(m, wi, wo);
         case BSDF_ROUGHPLASTIC: return rp_eval(m, wi, wo);
         case BSDF_ROUGHDIFFUSE: return roughdiffuse_eval(m, wi, wo);
+        case BSDF_PHONG: return phong_eval(m, wi, wo);
         default: return diffuse_eval(m, wi, wo);
     }
 }
@@ -1379,6 +1416,7 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_DIFFTRANS: return dt_pdf(wi, wo);
         case BSDF_ROUGHPLASTIC: return rp_pdf(m, wi, wo);
         case BSDF_ROUGHDIFFUSE: return roughdiffuse_pdf(wi, wo);
+        case BSDF_PHONG: return phong_pdf(m, wi, wo);
         default: return diffuse_pdf(wi, wo);
     }
 }
@@ -1398,6 +1436,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_DIFFTRANS: w = dt_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_ROUGHPLASTIC: w = rp_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_ROUGHDIFFUSE: w = roughdiffuse_sample(m, wi, u, v, wo, pdf, eta); break;
+        case BSDF_PHONG: w = phong_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_THINDIELECTRIC: w = thindielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
         case BSDF_NULL: *wo = neg(wi); *pdf = 1.0f; *eta = 1.0f; *delta = 2; w = V(1, 1, 1); break;      /* src/bsdfs/null.cpp:56-66: the index-matched boundary, sampledType = ENull */
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;

@@ -297,6 +297,9 @@ static Built buildScene(const FScene &fs) {
         } else if (fb.type == 14) {          // roughdiffuse (Oren-Nayar): distr = useFastApprox
             Properties p("roughdiffuse"); p.setSpectrum("reflectance", rgb(fb.refl)); p.setFloat("alpha", fb.alpha); p.setBoolean("useFastApprox", fb.distr == 1);
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 15) {          // phong: alpha = exponent
+            Properties p("phong"); p.setSpectrum("diffuseReflectance", rgb(fb.refl)); p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setFloat("exponent", fb.alpha);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 4) {
             Properties p("plastic");
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);
