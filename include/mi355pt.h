@@ -75,6 +75,8 @@ typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling
 #define MI_BSDF_ROUGHDIFFUSE 14    /* src/bsdfs/roughdiffuse.cpp (Oren-Nayar): reflectance (constant or a bound texture), alpha, distr = 1: useFastApprox */
 #define MI_BSDF_PHONG 15           /* src/bsdfs/phong.cpp (modified Phong): reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent,
                                       k[0] = specular sampling weight = lum(specular) / (lum(diffuse) + lum(specular)) (phong.cpp:104-108); constants only */
+#define MI_BSDF_WARD 16            /* src/bsdfs/ward.cpp: reflectance = diffuseReflectance, specular = specularReflectance, alpha = alphaU, k[1] = alphaV, distr = variant
+                                      (0 ward, 1 ward-duer, 2 balanced), k[0] = specular sampling weight as for phong; constants only */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */
@@ -240,6 +242,8 @@ int mi_debug_intersect(mi_scene *s, const float *rays8, uint64_t n, int any_hit,
 int mi_debug_intersect_inst(mi_scene *s, const float *rays8, uint64_t n, int any_hit, float *out_hits4, int32_t *out_instance);   /* + instance index of the hit (-1: scene-level primitive) */
 int mi_debug_sobol(mi_scene *s, const uint32_t *px_py_k, uint64_t n, uint32_t ndims, uint64_t *out_index, float *out_values);
 int mi_debug_camera_rays(mi_scene *s, const float *sample_pos2, uint64_t n, float *out_rays8);
+int mi_debug_libm(int fn, const float *x, const float *y, uint64_t n, float *out);   /* the device restatements of glibc's routines (libm_glibc.h) as the kernels call them:
+                                      fn 0 expf(x), 1 logf(x), 2 powf(x, y), 3 tanf(x), 4 atanf(x), 5 atan2f(x, y), 6 acosf(x); y may be NULL for the one-argument routines */
 int mi_debug_sincosf(const float *x, uint64_t n, float *out_sin_cos2);   /* the device restatement of glibc's sincosf (warps): out[2i] = sin, out[2i+1] = cos */
 
 #ifdef __cplusplus

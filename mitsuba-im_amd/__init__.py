@@ -5,4 +5,4 @@ the product is libmi355pt.so (mitsuba-im_amd/csrc).  The package directory name 
 `importlib.import_module("mitsuba-im_amd")`.
 """
 from . import scenes  # noqa: F401
-from .api import (Lib, Scene, Render, MiError, lib, build, load_sobol_tables, device_sincosf)  # noqa: F401
+from .api import (Lib, Scene, Render, MiError, lib, build, load_sobol_tables, device_sincosf, device_libm)  # noqa: F401

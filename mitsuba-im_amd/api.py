@@ -66,7 +66,7 @@ EXPORTS = ["mi_last_error", "mi_set_sobol_tables", "mi_load_sobol_tables", "mi_s
            "mi_scene_set_analytic", "mi_scene_set_instances", "mi_scene_set_media", "mi_scene_set_materials", "mi_scene_set_material_tables", "mi_scene_set_textures", "mi_scene_set_texture_data", "mi_scene_set_emitters", "mi_scene_set_envmap", "mi_scene_set_envmap_filter", "mi_scene_set_camera", "mi_scene_set_film",
            "mi_scene_commit", "mi_scene_ray_intersect", "mi_scene_clone", "mi_render_merge_film", "mi_render_create", "mi_render_destroy", "mi_render_run", "mi_render_run_rows", "mi_render_clear", "mi_render_cancel",
            "mi_render_film_size", "mi_render_read_film", "mi_render_read_film_device", "mi_render_samples", "mi_render_stats",
-           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays", "mi_debug_sincosf"]
+           "mi_render_set_profiling", "mi_debug_intersect", "mi_debug_intersect_inst", "mi_debug_sobol", "mi_debug_camera_rays", "mi_debug_sincosf", "mi_debug_libm"]
 HOST_EXPORTS = ["mi_host_last_error", "mi_host_create", "mi_host_create_devices", "mi_host_create_ex", "mi_host_destroy", "mi_host_preprocess", "mi_host_render", "mi_host_cancel", "mi_host_statistics"]
 
 
@@ -122,6 +122,7 @@ class Lib:
         L.mi_debug_sobol.argtypes = [vp, vp, u64, u32, vp, vp]
         L.mi_debug_camera_rays.argtypes = [vp, vp, u64, vp]
         L.mi_debug_sincosf.argtypes = [vp, u64, vp]
+        L.mi_debug_libm.argtypes = [i32, vp, vp, u64, vp]
 
     def check(self, rc):
         if rc != 0:
@@ -159,6 +160,16 @@ def device_sincosf(x):
     """glibcSincosf of pt_device.h on an array of floats -> (sin, cos)."""
     L = lib(); a = np.ascontiguousarray(x, np.float32).reshape(-1); out = np.zeros((len(a), 2), np.float32)
     L.check(L.L.mi_debug_sincosf(_p(a), len(a), _p(out))); return out[:, 0], out[:, 1]
+
+
+LIBM_FUNCTIONS = {"expf": 0, "logf": 1, "powf": 2, "tanf": 3, "atanf": 4, "atan2f": 5, "acosf": 6}
+
+
+def device_libm(name, x, y=None):
+    """The device's restatement of glibc's `name` (libm_glibc.h, as the kernels call it) on arrays of floats."""
+    L = lib(); a = np.ascontiguousarray(x, np.float32).reshape(-1); out = np.zeros(len(a), np.float32)
+    b = None if y is None else np.ascontiguousarray(y, np.float32).reshape(-1)
+    L.check(L.L.mi_debug_libm(LIBM_FUNCTIONS[name], _p(a), _p(b) if b is not None else None, len(a), _p(out))); return out
 
 
 class Scene:

@@ -182,6 +182,14 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         Spectrum d, s; d.fromLinearRGB(diff[0], diff[1], diff[2]); s.fromLinearRGB(spec[0], spec[1], spec[2]);
         for (int c = 0; c < 3; ++c) if (diff[c] + spec[c] > 1.0f) SLog(EError, "path_hip: phong with diffuseReflectance + specularReflectance > 1 (rescaled by the reference) is not implemented");
         const Float dAvg = d.getLuminance(), sAvg = s.getLuminance(); m.k[0] = sAvg / (dAvg + sAvg);
+    } else if (cls == "Ward") {                                         // ward.cpp:340-348: variant, diffuse, specular, alphaU, alphaV; the sampling weight as configure() derives it (:160-164)
+        const uint32_t variant = rd.ms->readUInt();
+        std::vector<float> diff = rd.constant("diffuseReflectance"), spec = rd.constant("specularReflectance"), au = rd.constant("alphaU"), av = rd.constant("alphaV");
+        if (variant > 2) SLog(EError, "path_hip: unknown ward variant");
+        m.type = MI_BSDF_WARD; m.distr = variant; memcpy(m.reflectance, diff.data(), 12); memcpy(m.specular, spec.data(), 12); m.alpha = au[0]; m.k[1] = av[0]; if (au[0] != av[0]) m.flags |= MI_BSDF_FLAG_ANISOTROPIC;
+        Spectrum d, s; d.fromLinearRGB(diff[0], diff[1], diff[2]); s.fromLinearRGB(spec[0], spec[1], spec[2]);
+        for (int c = 0; c < 3; ++c) if (diff[c] + spec[c] > 1.0f) SLog(EError, "path_hip: ward with diffuseReflectance + specularReflectance > 1 (rescaled by the reference) is not implemented");
+        const Float dAvg = d.getLuminance(), sAvg = s.getLuminance(); m.k[0] = sAvg / (dAvg + sAvg);
     } else if (cls == "RoughDiffuse") {                                 // roughdiffuse.cpp:269-275: reflectance, alpha, useFastApprox
         std::vector<float> refl = rd.texture(); m.type = MI_BSDF_ROUGHDIFFUSE; bind(refl);
         std::vector<float> a = rd.constant("alpha"); m.alpha = a[0]; m.distr = rd.ms->readBool() ? 1u : 0u;
@@ -191,7 +199,7 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         const uint32_t keepFlags = m.flags; memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MIXTURE; m.flags = keepFlags; m.distr = (uint32_t) count;
         for (size_t i = 0; i < count; ++i) {
             const float w = rd.ms->readFloat(); mi_material child; memset(&child, 0, sizeof(child));
-            if (!readNestedInstance(rd, child) || (child.type >= MI_BSDF_MASK && child.type != MI_BSDF_ROUGHDIFFUSE && child.type != MI_BSDF_PHONG)) SLog(EError, "path_hip: this BSDF inside a mixturebsdf is not implemented (plain BSDFs, optionally twosided)");
+            if (!readNestedInstance(rd, child) || (child.type >= MI_BSDF_MASK && child.type != MI_BSDF_ROUGHDIFFUSE && child.type != MI_BSDF_PHONG && child.type != MI_BSDF_WARD)) SLog(EError, "path_hip: this BSDF inside a mixturebsdf is not implemented (plain BSDFs, optionally twosided)");
             const float idx = (float) g_materials->size(); g_materials->push_back(child);
             if (i < 3) { m.reflectance[i] = idx; m.k[i] = w; } else { m.eta[0] = idx; m.specular[0] = w; }
         }
@@ -257,6 +265,10 @@ static mi_material convertBSDF(const BSDF *bsdf) {
     if ((bsdf->getType() & BSDF::ESpatiallyVarying) && bsdf->getClass()->getName() != "TwoSidedBRDF") {      // textures are private members: never fall through to the Properties (constants only)
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: spatially varying BSDF \"%s\": textures are implemented on diffuse.reflectance, plastic / roughplastic.diffuseReflectance and difftrans.transmittance", bsdf->getClass()->getName().c_str());
+    }
+    if (bsdf->getClass()->getName() == "Ward") {
+        if (convertSpatiallyVarying(bsdf, m)) return m;
+        SLog(EError, "path_hip: this `ward` is not implemented");
     }
     if (bsdf->getClass()->getName() == "Phong") {
         if (convertSpatiallyVarying(bsdf, m)) return m;

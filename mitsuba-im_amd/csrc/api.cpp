@@ -41,6 +41,7 @@ void mi_launch_ray_intersect(const DScene &, const float *, uint64_t, mi_interse
 void mi_launch_debug_sobol(const DScene &, const uint32_t *, uint64_t, uint32_t, unsigned long long *, float *, hipStream_t);
 void mi_launch_debug_camera(const DScene &, const float *, uint64_t, float *, hipStream_t);
 void mi_launch_debug_sincosf(const float *, uint64_t, float *, hipStream_t);
+void mi_launch_debug_libm(int, const float *, const float *, uint64_t, float *, hipStream_t);
 }
 
 // Shading stage dispatch.  Dynamic LDS: Sobol nibble tables + (small scenes) the scene tables + (scenes with non-diffuse BSDFs) the per-wave path-order list.
@@ -205,7 +206,7 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_PHONG) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_WARD) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if (m[i].type == MI_BSDF_BUMPMAP || m[i].type == MI_BSDF_NORMALMAP) {
             // adapters nest in the order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF
@@ -231,7 +232,7 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
         if (m[i].type == MI_BSDF_ROUGHPLASTIC && (m[i].distr > 2 || (m[i].flags & MI_BSDF_FLAG_ANISOTROPIC)))
             return fail(MI_ERR_INVALID, "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");        // roughplastic.cpp:225-227
         if ((m[i].type == MI_BSDF_ROUGHCONDUCTOR || m[i].type == MI_BSDF_ROUGHDIELECTRIC) && m[i].distr > 2) return fail(MI_ERR_INVALID, "Specified an invalid distribution, must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!");   // microfacet.h:113-115
-        if ((m[i].flags & MI_BSDF_FLAG_ANISOTROPIC) && m[i].type != MI_BSDF_ROUGHCONDUCTOR && m[i].type != MI_BSDF_ROUGHDIELECTRIC) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: anisotropic roughness is implemented for roughconductor and roughdielectric");
+        if ((m[i].flags & MI_BSDF_FLAG_ANISOTROPIC) && m[i].type != MI_BSDF_ROUGHCONDUCTOR && m[i].type != MI_BSDF_ROUGHDIELECTRIC && m[i].type != MI_BSDF_WARD) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: anisotropic roughness is implemented for roughconductor and roughdielectric");
     }
     s->h.materials.assign(m, m + n); s->h.committed = false; return MI_OK;
 }
@@ -927,6 +928,11 @@ int mi_debug_sobol(mi_scene *s, const uint32_t *in, uint64_t n, uint32_t ndims, 
 int mi_debug_sincosf(const float *x, uint64_t n, float *out) {
     if (!x || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_sincosf: bad argument");
     return withBuffers(x, n * 4, out, n * 8, [&](void *i, void *o) { mi_launch_debug_sincosf((const float *) i, n, (float *) o, nullptr); });
+}
+int mi_debug_libm(int fn, const float *x, const float *y, uint64_t n, float *out) {
+    if (!x || !out || !n || fn < 0 || fn > 6 || ((fn == 2 || fn == 5) && !y)) return fail(MI_ERR_INVALID, "mi_debug_libm: bad argument");
+    std::vector<float> xy(2 * n); memcpy(xy.data(), x, n * 4); if (y) memcpy(xy.data() + n, y, n * 4);
+    return withBuffers(xy.data(), n * 8, out, n * 4, [&](void *i, void *o) { mi_launch_debug_libm(fn, (const float *) i, y ? (const float *) i + n : nullptr, n, (float *) o, nullptr); });
 }
 int mi_debug_camera_rays(mi_scene *s, const float *pos, uint64_t n, float *out) {
     if (!s || !s->h.committed || !pos || !out || !n) return fail(MI_ERR_INVALID, "mi_debug_camera_rays: bad argument");

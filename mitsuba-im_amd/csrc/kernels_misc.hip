@@ -163,6 +163,13 @@ __global__ void k_debug_sincosf(const float *in, uint64_t n, float *out) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { float s, c; glibcSincosf(in[i], s, c); out[i * 2] = s; out[i * 2 + 1] = c; }
 }
+__global__ void k_debug_libm(int fn, const float *x, const float *y, uint64_t n, float *out) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = x[i], b = y ? y[i] : 0.0f; float r;
+    switch (fn) { case 0: r = expf(a); break; case 1: r = logf(a); break; case 2: r = powf(a, b); break; case 3: r = tanf(a); break; case 4: r = atanf(a); break; case 5: r = atan2f(a, b); break; default: r = acosf(a); break; }
+    out[i] = r;
+}
 __global__ void k_debug_camera(DScene sc, const float *pos, uint64_t n, float *out) {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -183,5 +190,6 @@ void mi_launch_film_add(float *dst, const float *src, size_t n, hipStream_t st) 
 void mi_launch_gather_samples(const Queues &q, const uint32_t *slots, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_gather_samples, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, q, slots, n, out); }
 void mi_launch_debug_sobol(const DScene &sc, const uint32_t *in, uint64_t n, uint32_t ndims, unsigned long long *oi, float *ov, hipStream_t st) { hipLaunchKernelGGL(k_debug_sobol, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, in, n, ndims, oi, ov); }
 void mi_launch_debug_sincosf(const float *in, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_sincosf, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, in, n, out); }
+void mi_launch_debug_libm(int fn, const float *x, const float *y, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_libm, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, fn, x, y, n, out); }
 void mi_launch_debug_camera(const DScene &sc, const float *pos, uint64_t n, float *out, hipStream_t st) { hipLaunchKernelGGL(k_debug_camera, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, sc, pos, n, out); }
 }

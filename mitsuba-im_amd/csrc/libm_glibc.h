@@ -239,14 +239,18 @@ MI_LIBM_FN float mi_kernel_tanf(float x, float y, int iy) {
     s = 1.0f + t * z;
     return t + a * (s + t * v);
 }
-// sysdeps/ieee754/flt-32/s_tanf.c over e_rem_pio2f.c's first branch (|x| < 3 pi / 4); larger arguments: the platform's tanf
+// sysdeps/ieee754/flt-32/s_tanf.c over __ieee754_rem_pio2f for |x| <= 64 (n = rint(|x| 2 / pi) <= 41); larger arguments: the platform's tanf.
+// The reduction |x| - n pi / 2 is done in binary64 with the one 53-bit constant, head and tail rounded to float: against the host's libm (glibc 2.35) this form differs in
+// none of the 2.2e9 arguments of the range (scripts/check_libm.c), while the 24 + 24-bit Cody-Waite steps of fdlibm's float version differ in 277 arguments below 3 pi / 4
+// alone.  (First mismatches of this form: four arguments next to 77 pi / 2 = 120.95.)
 MI_LIBM_FN float mi_tanf(float x) {
     const int32_t hx = (int32_t) mi_asuint(x), ix = hx & 0x7fffffff;
     if (ix <= 0x3f490fda) return mi_kernel_tanf(x, 0.0f, 1);      /* |x| ~<= pi / 4 */
-    if (ix >= 0x4016cbe4) return MI_LIBM_FALLBACK(tanf, x);        /* |x| >= 3 pi / 4 (also inf / NaN) */
-    /* __ieee754_rem_pio2f as glibc 2.35 has it for n = +-1: the subtraction in binary64, head and tail rounded to float (the 24 + 24-bit Cody-Waite steps of
-       fdlibm's float version differ from the host's libm in 277 of the 1.1e9 arguments of this range; this form in none) */
-    const double r = hx > 0 ? (double) x - 1.57079632679489661923 : (double) x + 1.57079632679489661923;
-    const float y0 = (float) r, y1 = (float) (r - (double) y0);
-    return mi_kernel_tanf(y0, y1, -1);      /* n = +-1: 1 - ((n & 1) << 1) = -1 */
+    if (ix > 0x42800000) return MI_LIBM_FALLBACK(tanf, x);         /* |x| > 64 (also inf / NaN) */
+    const double t = fabs((double) x);
+    int n = (int) (t * 6.36619772367581382433e-01 + 0.5);
+    const double r = t - (double) n * 1.57079632679489661923;
+    float y0 = (float) r, y1 = (float) (r - (double) y0);
+    if (hx < 0) { y0 = -y0; y1 = -y1; n = -n; }
+    return mi_kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
 }

@@ -1274,6 +1274,57 @@ DEV v3 phongSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float 
     const v3 f = phongEval(m, wi, wo); const float recip = 1.0f / pdf;
     return V(f.x * recip, f.y * recip, f.z * recip);
 }
+// src/bsdfs/ward.cpp:178-338 (anisotropic Ward in its three variants): reflectance = diffuseReflectance, specular = specularReflectance, alpha = alphaU, k[1] = alphaV,
+// distr = variant (0 ward, 1 ward-duer, 2 balanced), k[0] = m_specularSamplingWeight (:160-164).  std::pow(Float, int) promotes to binary64 (so do the factors around it);
+// H.z^4 and H.z^3 are single roundings of exact 48-bit squares here.  math::fastexp / fastlog are the binary64 routines (math.h:185-195).
+#define MI_BSDF_T_WARD 16u
+DEV float avg3(float a) { return (((0.0f + a) + a) + a) * (1.0f / 3); }      // a constant texture's eval(its).average()
+DEV float wardExp(v3 H, float alphaU, float alphaV) {
+    const float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+    return fastexpf_(-(factor2 * factor2 + factor3 * factor3) / (H.z * H.z));
+}
+DEV v3 wardEval(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    v3 result = V(0, 0, 0);
+    const v3 H = wi + wo; const float alphaU = avg3(m.alpha), alphaV = avg3(m.k[1]);
+    float factor1;
+    if (m.distr == 0u) factor1 = 1.0f / (4.0f * MI_PI * alphaU * alphaV * sqrtf(wi.z * wo.z));
+    else if (m.distr == 1u) factor1 = 1.0f / (4.0f * MI_PI * alphaU * alphaV * wi.z * wo.z);
+    else { const double z2 = (double) H.z * (double) H.z; factor1 = (float) ((double) dot(H, H) / ((double) (MI_PI * alphaU * alphaV) * (z2 * z2))); }
+    const float specRef = factor1 * wardExp(H, alphaU, alphaV);
+    if (specRef > 1e-10f) result = ld3(m.specular) * specRef;
+    result = result + ld3(m.reflectance) * MI_INV_PI;
+    return result * wo.z;
+}
+DEV float wardPdf(const MaterialD &m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    const float alphaU = avg3(m.alpha), alphaV = avg3(m.k[1]);
+    const v3 H = normalize(wi + wo);
+    const double z2 = (double) H.z * (double) H.z;
+    const float factor1 = (float) (1.0 / ((double) (4.0f * MI_PI * alphaU * alphaV * dot(H, wi)) * (z2 * (double) H.z)));
+    const float specProb = factor1 * wardExp(H, alphaU, alphaV), diffuseProb = MI_INV_PI * wo.z;
+    return m.k[0] * specProb + (1 - m.k[0]) * diffuseProb;
+}
+DEV v3 wardSample(const MaterialD &m, v3 wi, float sx, float sy, v3 &wo, float &pdf, float &eta) {
+    const float w = m.k[0]; bool choseSpecular = true;
+    if (sx <= w) sx /= w; else { sx = (sx - w) / (1 - w); choseSpecular = false; }
+    if (choseSpecular) {
+        const float alphaU = avg3(m.alpha), alphaV = avg3(m.k[1]);
+        float phiH = atanf(alphaV / alphaU * tanf(2.0f * MI_PI * sy));
+        if (sy > 0.5f) phiH += MI_PI;
+        const float2 scPhi = glibcSincosf2(phiH);
+        const float cosPhiH = scPhi.y, sinPhiH = sqrtf(maxf(0.0f, 1.0f - cosPhiH * cosPhiH));
+        const float thetaH = atanf(sqrtf(maxf(0.0f, -fastlogf_(sx) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV)))));
+        const float2 scTheta = glibcSincosf2(thetaH);
+        const v3 H = V(scTheta.x * scPhi.y, scTheta.x * scPhi.x, scTheta.y);
+        wo = H * (2.0f * dot(wi, H)) - wi;
+        if (wo.z <= 0.0f) return V(0, 0, 0);
+    } else wo = cosHemisphere(sx, sy);
+    eta = 1.0f; pdf = wardPdf(m, wi, wo);
+    if (pdf == 0) return V(0, 0, 0);
+    const v3 f = wardEval(m, wi, wo); const float recip = 1.0f / pdf;
+    return V(f.x * recip, f.y * recip, f.z * recip);
+}
 template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, v3 wo) {
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     if (RC && m.type != 0) {
@@ -1284,6 +1335,7 @@ template <bool RC> DEV v3 bsdfEval(const DScene &sc, const MaterialD &m, v3 wi, 
         if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpEval(sc, m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHDIFFUSE) return roughDiffuseEval(m, wi, wo);
         if (m.type == MI_BSDF_T_PHONG) return phongEval(m, wi, wo);
+        if (m.type == MI_BSDF_T_WARD) return wardEval(m, wi, wo);
         return V(0, 0, 0);
     }
     if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
@@ -1300,6 +1352,7 @@ template <bool RC> DEV float bsdfPdf(const DScene &sc, const MaterialD &m, v3 wi
         if (m.type == MI_BSDF_T_ROUGHPLASTIC) return rpPdf(sc, m, wi, wo);
         if (m.type == MI_BSDF_T_ROUGHDIFFUSE) return roughDiffusePdf(wi, wo);
         if (m.type == MI_BSDF_T_PHONG) return phongPdf(m, wi, wo);
+        if (m.type == MI_BSDF_T_WARD) return wardPdf(m, wi, wo);
         return 0.0f;
     }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
@@ -1321,6 +1374,7 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
         else if (m.type == MI_BSDF_T_ROUGHPLASTIC) w = rpSample(sc, m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_ROUGHDIFFUSE) w = roughDiffuseSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_PHONG) w = phongSample(m, wi, u, v, wo, pdf, eta);
+        else if (m.type == MI_BSDF_T_WARD) w = wardSample(m, wi, u, v, wo, pdf, eta);
         else if (m.type == MI_BSDF_T_THINDIELECTRIC) w = thinDielectricSample(m, wi, u, wo, pdf, eta, delta, nullComp);
         else if (m.type == MI_BSDF_T_NULL) { wo = V(-wi.x, -wi.y, -wi.z); pdf = 1.0f; eta = 1.0f; delta = true; nullComp = true; w = V(1, 1, 1); }      // src/bsdfs/null.cpp:56-66
         else w = plasticSample(m, wi, u, v, wo, pdf, eta, delta);

@@ -26,6 +26,8 @@ BSDF_BUMPMAP = 11         # src/bsdfs/bumpmap.cpp: distr = index of the nested m
 BSDF_NULL = 13            # src/bsdfs/null.cpp: index-matched boundary of a participating medium (passes straight through, ENull)
 BSDF_ROUGHDIFFUSE = 14     # src/bsdfs/roughdiffuse.cpp (Oren-Nayar): reflectance, alpha (roughness, averaged over the channels there), distr = useFastApprox
 BSDF_PHONG = 15            # src/bsdfs/phong.cpp: reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent, k[0] = specular sampling weight
+BSDF_WARD = 16             # src/bsdfs/ward.cpp: as phong, alpha = alphaU, k[1] = alphaV, distr = variant (WARD_*)
+WARD_WARD, WARD_DUER, WARD_BALANCED = 0, 1, 2
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -153,6 +155,11 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         eta = (float(f32(ior)), 0.0, 0.0)
     if kind == BSDF_ROUGHDIFFUSE:
         distr = 1 if distr else 0; sample_visible = False     # distr = useFastApprox
+    if kind == BSDF_WARD:                             # distr = variant; alpha / alpha_v = alphaU / alphaV; k[0] as for phong (ward.cpp:160-164)
+        lum = lambda c: f32(f32(f32(f32(c[0]) * f32(0.212671)) + f32(f32(c[1]) * f32(0.715160))) + f32(f32(c[2]) * f32(0.072169)))
+        if max(float(f32(a) + f32(b)) for a, b in zip(reflectance, specular)) > 1.0: raise ValueError("ward: diffuseReflectance + specularReflectance > 1 (the reference rescales both, BSDF::ensureEnergyConservation): not implemented")
+        d_avg, s_avg = lum(reflectance), lum(specular); k = (float(f32(s_avg / f32(d_avg + s_avg))), float(f32(alpha if alpha_v is None else alpha_v)), 0.0); sample_visible = False
+        if distr not in (0, 1, 2): raise ValueError("ward: variant 0 (ward), 1 (ward-duer) or 2 (balanced)")
     if kind == BSDF_PHONG:                            # alpha = exponent; k[0] = m_specularSamplingWeight (phong.cpp:104-108), float arithmetic as in Spectrum::getLuminance (spectrum.h:725-727)
         lum = lambda c: f32(f32(f32(f32(c[0]) * f32(0.212671)) + f32(f32(c[1]) * f32(0.715160))) + f32(f32(c[2]) * f32(0.072169)))
         if max(float(f32(a) + f32(b)) for a, b in zip(reflectance, specular)) > 1.0: raise ValueError("phong: diffuseReflectance + specularReflectance > 1 (the reference rescales both, BSDF::ensureEnergyConservation): not implemented")
@@ -169,6 +176,8 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         if distr == DISTR_PHONG: sample_visible = False      # microfacet.h:141-145
         sample_visible = (1 if sample_visible else 0) | (2 if nonlinear else 0)      # container field: bit 0 sampleVisible, bit 1 the nonlinear flag of roughplastic (read by the harness)
     aniso = 0
+    if kind == BSDF_WARD and k[1] != float(f32(alpha)):
+        aniso = 1                                      # EAnisotropic (ward.cpp:143-145): the shape then needs texture coordinates (tangents)
     if kind in (BSDF_ROUGHCONDUCTOR, BSDF_ROUGHDIELECTRIC):
         if distr == DISTR_PHONG:
             sample_visible = False                     # microfacet.h:141-145: the Phong / Ashikhmin-Shirley distribution samples all normals
@@ -1219,6 +1228,29 @@ def cbox_phong(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, 
             make_bsdf(kind=BSDF_PHONG, reflectance=(0.02, 0.02, 0.02), specular=(0.9, 0.7, 0.3), alpha=80.0)]                   # tall block
     base = len(sc.bsdfs); sc.bsdfs.extend(mats)
     sc.shapes[0]["bsdf"] = base; sc.shapes[2]["bsdf"] = base + 1; sc.shapes[6]["bsdf"] = base + 2; sc.shapes[7]["bsdf"] = base + 3
+    return sc
+
+
+def cbox_ward(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False):
+    """Cornell box with `ward` floor, back wall and blocks: the three variants, one `twosided` (isotropic: the box has no texture coordinates; ward_room has the anisotropic ones)."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, strict_normals=strict_normals)
+    sc.name = "cbox_ward"
+    mats = [make_bsdf(kind=BSDF_WARD, reflectance=(0.5, 0.5, 0.5), specular=(0.2, 0.2, 0.2), alpha=0.1, distr=WARD_BALANCED),                          # floor (the plugin's defaults)
+            make_bsdf(kind=BSDF_WARD, reflectance=(0.3, 0.28, 0.25), specular=(0.6, 0.6, 0.65), alpha=0.05, distr=WARD_BALANCED),                        # back wall
+            make_bsdf(kind=BSDF_WARD, reflectance=(0.1, 0.3, 0.6), specular=(0.3, 0.2, 0.1), alpha=0.4, distr=WARD_WARD, twosided=True),                 # short block
+            make_bsdf(kind=BSDF_WARD, reflectance=(0.05, 0.05, 0.05), specular=(0.9, 0.7, 0.3), alpha=0.2, distr=WARD_DUER)]                             # tall block
+    base = len(sc.bsdfs); sc.bsdfs.extend(mats)
+    sc.shapes[0]["bsdf"] = base; sc.shapes[2]["bsdf"] = base + 1; sc.shapes[6]["bsdf"] = base + 2; sc.shapes[7]["bsdf"] = base + 3
+    return sc
+
+
+def ward_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
+    """The textured room (meshes with texture coordinates: shading frames from the UV tangents) with ANISOTROPIC `ward` on the wall and the mound."""
+    sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed=seed)
+    sc.name = "ward_room"
+    sc.bsdfs[2] = make_bsdf(kind=BSDF_WARD, reflectance=(0.2, 0.45, 0.25), specular=(0.5, 0.5, 0.3), alpha=0.08, alpha_v=0.35, distr=WARD_BALANCED)       # mound (smooth normals)
+    sc.textures = sc.textures[:1]                           # (the wall's and the mound's textures go with their BSDFs)
+    sc.bsdfs[1] = make_bsdf(kind=BSDF_WARD, reflectance=(0.3, 0.3, 0.35), specular=(0.6, 0.55, 0.5), alpha=0.4, alpha_v=0.1, distr=WARD_DUER, twosided=True)   # wall (sheared uv: non-orthogonal tangents)
     return sc
 
 

@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughdiffuse, phong, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
+    bsdf        diffuse, roughdiffuse, phong, ward, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -568,6 +568,20 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PHONG, reflectance=dr or (0.5, 0.5, 0.5), specular=sr or (0.2, 0.2, 0.2), alpha=float(ex), twosided=twosided)
             except ValueError as e:
                 raise SceneError(str(e))
+        elif t == "ward":                                  # src/bsdfs/ward.cpp:99-127: variant (balanced), alpha (0.1) | alphaU / alphaV, the two reflectances; constants only
+            dr, tex = _spectrum_or_texture(p, ("diffuseReflectance",), (0.5, 0.5, 0.5))
+            sr, stex = _spectrum_or_texture(p, ("specularReflectance",), (0.2, 0.2, 0.2))
+            variant = str(p.get("variant", "balanced")).lower()
+            if variant not in ("ward", "ward-duer", "balanced"):
+                raise SceneError(f'Specified an invalid model type "{variant}", must be "ward", "ward-duer", or "balanced"!')
+            a = p.get("alpha", 0.1); au = p.get("alphaU", a); av = p.get("alphaV", a)
+            if tex is not None or stex is not None or not all(isinstance(v, (int, float)) for v in (a, au, av)):
+                raise SceneError("ward: textured parameters are not supported")
+            try:
+                rec = S.make_bsdf(S.BSDF_WARD, reflectance=dr or (0.5, 0.5, 0.5), specular=sr or (0.2, 0.2, 0.2), alpha=float(au), alpha_v=float(av),
+                                  distr=("ward", "ward-duer", "balanced").index(variant), twosided=twosided)
+            except ValueError as e:
+                raise SceneError(str(e))
         elif t == "difftrans":
             tr, tex = _spectrum_or_texture(p, ("transmittance", "diffuseTransmittance"), (0.5, 0.5, 0.5))
             rec = S.make_bsdf(S.BSDF_DIFFTRANS, reflectance=tr or (0.5, 0.5, 0.5))
@@ -623,7 +637,7 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, thindielectric, mask, twosided)")
+                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, thindielectric, mask, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -1134,6 +1148,9 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="roughdiffuse">{diffuse_param("reflectance")}<float name="alpha" value="{fmt([b["alpha"]])}"/><boolean name="useFastApprox" value="{str(bool(b["distr"])).lower()}"/></bsdf>'
         elif t == S.BSDF_PHONG:
             inner = f'<bsdf type="phong">{rgb("diffuseReflectance", b["reflectance"])}{rgb("specularReflectance", b["specular"])}<float name="exponent" value="{fmt([b["alpha"]])}"/></bsdf>'
+        elif t == S.BSDF_WARD:
+            inner = (f'<bsdf type="ward"><string name="variant" value="{("ward", "ward-duer", "balanced")[b["distr"]]}"/>{rgb("diffuseReflectance", b["reflectance"])}{rgb("specularReflectance", b["specular"])}'
+                     f'<float name="alphaU" value="{fmt([b["alpha"]])}"/><float name="alphaV" value="{fmt([b["k"][1]])}"/></bsdf>')
         elif t == S.BSDF_NULL:
             inner = '<bsdf type="null"></bsdf>'
         else:

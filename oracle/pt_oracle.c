@@ -802,7 +802,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
@@ -1392,6 +1392,52 @@ static v3 phong_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo,
     return V(f.x * recip, f.y * recip, f.z * recip);
 }
 
+/* ---- Ward (ward / ward-duer / balanced): src/bsdfs/ward.cpp:178-338.  reflectance = diffuseReflectance, specular = specularReflectance, alpha = alphaU, k[1] = alphaV,
+ * distr = variant, k[0] = m_specularSamplingWeight (:160-164).  std::pow(Float, int) is the binary64 pow (C++11 promotion), and the factors around it are evaluated in
+ * binary64 as the usual arithmetic conversions make them; math::fastexp / fastlog = exp / log in binary64 (math.h:185-195); sphericalDirection: util.cpp:581-592 */
+static float avg3(float a) { float e = 0.0f; e += a; e += a; e += a; return e * (1.0f / 3); }
+static float ward_exp(v3 H, float alphaU, float alphaV) {
+    float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+    return fastexpf_(-(factor2 * factor2 + factor3 * factor3) / (H.z * H.z));
+}
+static v3 ward_eval(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return V(0, 0, 0);
+    v3 result = V(0, 0, 0), H = add(wi, wo); float alphaU = avg3(m->alpha), alphaV = avg3(m->k[1]), factor1;
+    if (m->distr == 0u) factor1 = 1.0f / (4.0f * M_PI_F * alphaU * alphaV * sqrtf(wi.z * wo.z));
+    else if (m->distr == 1u) factor1 = 1.0f / (4.0f * M_PI_F * alphaU * alphaV * wi.z * wo.z);
+    else factor1 = (float) (dot(H, H) / (M_PI_F * alphaU * alphaV * pow((double) H.z, 4.0)));
+    float specRef = factor1 * ward_exp(H, alphaU, alphaV);
+    if (specRef > 1e-10f) result = scale(V(m->specular[0], m->specular[1], m->specular[2]), specRef);
+    result = add(result, scale(V(m->reflectance[0], m->reflectance[1], m->reflectance[2]), INV_PI));
+    return scale(result, wo.z);
+}
+static float ward_pdf(const orc_material *m, v3 wi, v3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    float alphaU = avg3(m->alpha), alphaV = avg3(m->k[1]); v3 H = normalize(add(wi, wo));
+    float factor1 = (float) (1.0f / (4.0f * M_PI_F * alphaU * alphaV * dot(H, wi) * pow((double) H.z, 3.0)));
+    float specProb = factor1 * ward_exp(H, alphaU, alphaV), diffuseProb = INV_PI * wo.z;
+    return m->k[0] * specProb + (1 - m->k[0]) * diffuseProb;
+}
+static v3 ward_sample(const orc_material *m, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *eta) {
+    float w = m->k[0]; int choseSpecular = 1;
+    if (sx <= w) sx /= w; else { sx = (sx - w) / (1 - w); choseSpecular = 0; }
+    if (choseSpecular) {
+        float alphaU = avg3(m->alpha), alphaV = avg3(m->k[1]);
+        float phiH = atanf(alphaV / alphaU * tanf(2.0f * M_PI_F * sy));
+        if (sy > 0.5f) phiH += M_PI_F;
+        float cosPhiH = cosf(phiH), sinPhiH = sqrtf(maxf(0.0f, 1.0f - cosPhiH * cosPhiH));
+        float thetaH = atanf(sqrtf(maxf(0.0f, -fastlogf_(sx) / ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV)))));
+        float sinTheta, cosTheta, sinPhi, cosPhi; sincosf(thetaH, &sinTheta, &cosTheta); sincosf(phiH, &sinPhi, &cosPhi);
+        v3 H = V(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+        *wo = sub(scale(H, 2.0f * dot(wi, H)), wi);
+        if (wo->z <= 0.0f) return V(0, 0, 0);
+    } else *wo = cos_hemisphere(sx, sy);
+    *eta = 1.0f; *pdf = ward_pdf(m, wi, *wo);
+    if (*pdf == 0) return V(0, 0, 0);
+    v3 f = ward_eval(m, wi, *wo); float recip = 1.0f / *pdf;
+    return V(f.x * recip, f.y * recip, f.z * recip);
+}
+
 static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
     if ((m->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     switch (m->type) {
@@ -1403,6 +1449,7 @@ static v3 bsdf_eval(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_ROUGHPLASTIC: return rp_eval(m, wi, wo);
         case BSDF_ROUGHDIFFUSE: return roughdiffuse_eval(m, wi, wo);
         case BSDF_PHONG: return phong_eval(m, wi, wo);
+        case BSDF_WARD: return ward_eval(m, wi, wo);
         default: return diffuse_eval(m, wi, wo);
     }
 }
@@ -1417,6 +1464,7 @@ static float bsdf_pdf(const orc_material *m, v3 wi, v3 wo) {
         case BSDF_ROUGHPLASTIC: return rp_pdf(m, wi, wo);
         case BSDF_ROUGHDIFFUSE: return roughdiffuse_pdf(wi, wo);
         case BSDF_PHONG: return phong_pdf(m, wi, wo);
+        case BSDF_WARD: return ward_pdf(m, wi, wo);
         default: return diffuse_pdf(wi, wo);
     }
 }
@@ -1437,6 +1485,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
         case BSDF_ROUGHPLASTIC: w = rp_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_ROUGHDIFFUSE: w = roughdiffuse_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_PHONG: w = phong_sample(m, wi, u, v, wo, pdf, eta); break;
+        case BSDF_WARD: w = ward_sample(m, wi, u, v, wo, pdf, eta); break;
         case BSDF_THINDIELECTRIC: w = thindielectric_sample(m, wi, u, wo, pdf, eta, delta); break;
         case BSDF_NULL: *wo = neg(wi); *pdf = 1.0f; *eta = 1.0f; *delta = 2; w = V(1, 1, 1); break;      /* src/bsdfs/null.cpp:56-66: the index-matched boundary, sampledType = ENull */
         default: w = diffuse_sample(m, wi, u, v, wo, pdf, eta); break;

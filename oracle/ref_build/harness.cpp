@@ -300,6 +300,10 @@ static Built buildScene(const FScene &fs) {
         } else if (fb.type == 15) {          // phong: alpha = exponent
             Properties p("phong"); p.setSpectrum("diffuseReflectance", rgb(fb.refl)); p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setFloat("exponent", fb.alpha);
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 16) {          // ward: alpha = alphaU, k[1] = alphaV, distr = variant
+            Properties p("ward"); p.setSpectrum("diffuseReflectance", rgb(fb.refl)); p.setSpectrum("specularReflectance", rgb(fb.spec));
+            p.setString("variant", fb.distr == 0 ? "ward" : fb.distr == 1 ? "ward-duer" : "balanced"); p.setFloat("alphaU", fb.alpha); p.setFloat("alphaV", fb.k[1]);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         } else if (fb.type == 4) {
             Properties p("plastic");
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f);

@@ -390,7 +390,7 @@ def test_analytic_shapes(mi, oracle, golden_scenes, name, bvh, monkeypatch):
     assert np.linalg.norm(film[..., :3] - ref_film[..., :3]) / np.linalg.norm(ref_film[..., :3]) < 3e-3
 
 
-@pytest.mark.parametrize("name", ["cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "open_constant", "open_constant_hide_indep"])
+@pytest.mark.parametrize("name", ["cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "cbox_ward", "cbox_ward_strict_indep", "ward_room", "open_constant", "open_constant_hide_indep"])
 def test_scene_level_emitters(mi, oracle, golden_scenes, name):
     """SURVEY.md §8f-4 emitters: `point` + `spot` next to the area light (emitter selection, delta lights: MIS weight 1) and a `constant`
     environment + `directional` light (cosine-hemisphere / uniform-sphere sampling, pdfDirect from the previous vertex' reference normal)."""
@@ -400,7 +400,7 @@ def test_scene_level_emitters(mi, oracle, golden_scenes, name):
     more = np.stack([rng.integers(0, sc.width, n), rng.integers(0, sc.height, n), rng.integers(0, sc.spp, n)], 1).astype(np.uint32)
     ref = orc.render_samples(more)["li"]; got = r.samples(more)
     err = np.abs(got - ref).max(1) / (np.abs(ref).max(1) + 1e-6)
-    if name in ("cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep"):
+    if name in ("cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "cbox_ward", "cbox_ward_strict_indep", "ward_room"):
         # all-diffuse; the spot's transition zone calls acosf (glibc's on both sides since round 3): bit-exact.  cbox_collimated: a `collimated` beam sits in the
         # emitter-selection CDF and never returns a sample (collimated.cpp:129-133).  cbox_roughdiffuse: Oren-Nayar, acosf / tanf / sincos from the glibc restatements
         assert bit_share(got, ref, name) > 0.9999 and (err < 1e-5).mean() > 0.999
@@ -901,6 +901,27 @@ def test_device_sincosf_equals_glibc(mi):
         libm.sincosf(float(x[i]), ctypes.byref(a), ctypes.byref(b)); rs[i], rc[i] = a.value, b.value
     sel = slice(0, len(x), 7)
     assert (bits(s[sel]) == bits(rs[sel])).all() and (bits(c[sel]) == bits(rc[sel])).all()
+
+
+@pytest.mark.parametrize("name", ["expf", "logf", "powf", "tanf", "atanf", "atan2f", "acosf"])
+def test_device_libm_equals_glibc(mi, name):
+    """libm_glibc.h as compiled into the kernels against the host's glibc, bit for bit, on the argument ranges the path produces (scripts/check_libm.c is the exhaustive
+    check of the same source compiled for the host): microfacet exponents and logs, roughness-derived powers, the tangent of Ward's azimuth ([0, 2 pi]) and of the
+    rough-diffuse angles, arc functions of direction cosines."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); f = getattr(libm, name); two = name in ("powf", "atan2f")
+    f.restype = ctypes.c_float; f.argtypes = [ctypes.c_float] * (2 if two else 1)
+    rng = np.random.default_rng(29); n = 60000
+    lo, hi = {"expf": (-100, 80), "logf": (1e-30, 1e30), "powf": (0, 4), "tanf": (-64, 64), "atanf": (-1e6, 1e6), "atan2f": (-8, 8), "acosf": (-1, 1)}[name]
+    x = (rng.random(n) * (hi - lo) + lo).astype(np.float32)
+    if name in ("logf", "atanf"): x = (np.exp(rng.random(n) * 80 - 40) * (1 if name == "logf" else rng.choice([-1.0, 1.0], n))).astype(np.float32)
+    x[:8] = np.float32([lo, hi, 1.0, 0.5, 1e-3, 0.0 if name != "logf" else 1.0, np.pi / 4 if name != "acosf" else 0.7, 2 * np.pi if name not in ("acosf",) else -0.7])
+    y = None
+    if two: y = ((rng.random(n) * 128 - 64) * rng.choice([1.0, 0.03125], n)).astype(np.float32) if name == "powf" else (rng.random(n) * 16 - 8).astype(np.float32)
+    got = mi.device_libm(name, x, y)
+    ref = np.float32([f(float(a), float(b)) for a, b in zip(x, y)]) if two else np.float32([f(float(a)) for a in x])
+    same = (bits(got) == bits(ref)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), (name, x[~same][:4], got[~same][:4], ref[~same][:4])
 
 
 @pytest.mark.parametrize("key", ["S1_cornell", "S2_veach", "S3_atrium", "S4_fog"])
