@@ -77,6 +77,9 @@ typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling
                                       k[0] = specular sampling weight = lum(specular) / (lum(diffuse) + lum(specular)) (phong.cpp:104-108); constants only */
 #define MI_BSDF_WARD 16            /* src/bsdfs/ward.cpp: reflectance = diffuseReflectance, specular = specularReflectance, alpha = alphaU, k[1] = alphaV, distr = variant
                                       (0 ward, 1 ward-duer, 2 balanced), k[0] = specular sampling weight as for phong; constants only */
+#define MI_BSDF_COATING 17         /* src/bsdfs/coating.cpp (smooth dielectric layer): distr = nested record (a plain BSDF without transmission, not twosided itself), eta[0] = intIOR /
+                                      extIOR, alpha = thickness, reflectance = sigmaA, specular = specularReflectance; may be twosided, and may sit under a mask / bumpmap / normalmap.
+                                      Path integrator only */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

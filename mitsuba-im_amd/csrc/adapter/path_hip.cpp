@@ -174,6 +174,16 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         const uint32_t keepFlags = m.flags;
         memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MASK; m.flags = keepFlags; m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
         memcpy(m.reflectance, op.data(), 12); if (opTex >= 0) m.flags |= MI_BSDF_TEXTURE(opTex);
+    } else if (cls == "SmoothCoating") {                                // coating.cpp:150-158: eta, thickness, the nested BSDF, sigmaA, specularReflectance
+        const float eta = rd.ms->readFloat(), thickness = rd.ms->readFloat();
+        mi_material nested; memset(&nested, 0, sizeof(nested));
+        if (!readNestedInstance(rd, nested)) SLog(EError, "path_hip: the BSDF nested in `coating` is not implemented");
+        if (nested.type == MI_BSDF_MASK || nested.type == MI_BSDF_MIXTURE || nested.type == MI_BSDF_BUMPMAP || nested.type == MI_BSDF_NORMALMAP || nested.type == MI_BSDF_COATING || (nested.flags & MI_BSDF_FLAG_TWOSIDED))
+            SLog(EError, "path_hip: a coating over an adapter (mask, mixturebsdf, bumpmap, normalmap, twosided, coating) is not implemented");
+        std::vector<float> sa = rd.constant("sigmaA"), spec = rd.constant("specularReflectance");
+        const uint32_t keepFlags = m.flags;
+        memset(&m, 0, sizeof(m)); m.type = MI_BSDF_COATING; m.flags = keepFlags; m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
+        m.eta[0] = eta; m.alpha = thickness; memcpy(m.reflectance, sa.data(), 12); memcpy(m.specular, spec.data(), 12);
     } else if (cls == "DiffuseTransmitter") {
         std::vector<float> tr = rd.texture(); m.type = MI_BSDF_DIFFTRANS; bind(tr);
     } else if (cls == "Phong") {                                        // phong.cpp:262-268: diffuse, specular, exponent; the sampling weight as configure() derives it (:104-108)
@@ -258,7 +268,7 @@ static bool convertSpatiallyVarying(const BSDF *bsdf, mi_material &m) {
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
     if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
-    if (bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
+    if (bsdf->getClass()->getName() == "SmoothCoating" || bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: this `%s` is not implemented", bsdf->getClass()->getName().c_str());
     }

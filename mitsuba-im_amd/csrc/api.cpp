@@ -203,11 +203,20 @@ int mi_scene_set_media(mi_scene *s, const mi_medium *media, uint32_t n, const in
 }
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
-    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP; };
+    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP || t == MI_BSDF_COATING; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_WARD) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_COATING) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, coating, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
+        if (m[i].type == MI_BSDF_COATING) {
+            // adapters nest in the order mask -> bumpmap / normalmap -> coating -> plain BSDF (a coating over a mixturebsdf, or as the child of one, is not implemented)
+            if (m[i].distr >= n || isWrapper(m[m[i].distr].type)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a coating nests a plain BSDF record (index in `distr`)");
+            const mi_material &nm = m[m[i].distr];
+            if ((nm.flags & MI_BSDF_FLAG_TWOSIDED) || nm.type == MI_BSDF_DIELECTRIC || nm.type == MI_BSDF_ROUGHDIELECTRIC || nm.type == MI_BSDF_DIFFTRANS || nm.type == MI_BSDF_THINDIELECTRIC || nm.type == MI_BSDF_NULL)
+                return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: the BSDF under a coating is a reflective one, `twosided` goes on the coating");
+            if (!(m[i].eta[0] > 0) || m[i].eta[0] == 1.0f) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive and differ!");      // coating.cpp:119-121
+            if ((m[i].flags >> 8) & 0xFFFFu) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a textured sigmaA is not implemented");
+        }
         if (m[i].type == MI_BSDF_BUMPMAP || m[i].type == MI_BSDF_NORMALMAP) {
             // adapters nest in the order mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDF
             if (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || m[m[i].distr].type == MI_BSDF_BUMPMAP || m[m[i].distr].type == MI_BSDF_NORMALMAP) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a bumpmap / normalmap nests a plain BSDF or a mixturebsdf (record index in `distr`)");
@@ -286,6 +295,10 @@ int SceneHost::upload(int dev) {
     if (hipSetDevice(dev) != hipSuccess) return 1;
     std::vector<MaterialD> mats(materials.size());
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
+    for (MaterialD &m : mats) if (m.type == MI_BSDF_COATING) {      // SmoothCoating::configure (coating.cpp:182-186): m_specularSamplingWeight from the layer's average absorption -> k[0]
+        float avg = 0.0f; for (int c = 0; c < 3; ++c) avg += (float) exp((double) (m.reflectance[c] * (-2 * m.alpha)));      // Spectrum::exp = math::fastexp per channel, then average()
+        avg = avg * (1.0f / 3); m.k[0] = 1.0f / (avg + 1.0f);
+    }
     for (MaterialD &m : mats) {          // plastic / roughplastic: m_specularSamplingWeight = sAvg / (dAvg + sAvg) over Texture::getAverage() (plastic.cpp:204-207, roughplastic.cpp:244-246) -> eta[1]
         if (m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC) continue;
         float d[3] = {m.reflectance[0], m.reflectance[1], m.reflectance[2]}; const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
@@ -367,7 +380,7 @@ int SceneHost::upload(int dev) {
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
     d.has_adapters = 0;
-    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP) d.has_adapters |= 1u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP || m.type == MI_BSDF_COATING) d.has_adapters |= 1u; if (m.type == MI_BSDF_COATING) d.has_adapters |= 4u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     // bit 1: ENull lobes the volumetric walks have to evaluate through a wrapper -- a `mask`, or a mixturebsdf with a `null` / `thindielectric` child (surfaceNullEval; the NX kernel variants)
     for (const mi_material &m : materials) {
         if (m.type == MI_BSDF_MASK) d.has_adapters |= 2u;
@@ -414,6 +427,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         if (b < 0 || (size_t) b >= s->h.materials.size()) return false;
         const mi_material *mm = &s->h.materials[b];
         if (mm->type == MI_BSDF_MASK && mm->distr < s->h.materials.size()) mm = &s->h.materials[mm->distr];
+        if (mm->type == MI_BSDF_COATING && mm->distr < s->h.materials.size()) mm = &s->h.materials[mm->distr];
         return (mm->flags & MI_BSDF_FLAG_ANISOTROPIC) != 0 || mm->type == MI_BSDF_BUMPMAP || mm->type == MI_BSDF_NORMALMAP;
     };
     for (const mi_shape &sh : s->h.shapes)         // TriMesh::computeUVTangents (trimesh.cpp:683-692): such BSDFs take their tangents from the texture coordinates
@@ -550,6 +564,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
+    if (p->integrator != MI_INTEGRATOR_PATH && (s->h.d.has_adapters & 4u)) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: `coating` is implemented for the path integrator only");
     if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for

@@ -1457,6 +1457,64 @@ template <bool RC, bool MIX, bool L, typename F> DEV v3 mxSample(const DScene &s
     if (flip) wo.z = -wo.z;
     return result;
 }
+// ---- smooth dielectric coating (src/bsdfs/coating.cpp:205-372) around the level below.  `coat`: the layer's record (eta[0], alpha = thickness, reflectance = sigmaA, specular,
+// k[0] = m_specularSamplingWeight as configure() derives it, filled in at commit); `m`: the nested record.  Queried as the path tracer does: all components, solid angle.
+#define MI_BSDF_T_COATING 17u
+DEV v3 ctRefractIn(v3 wi, float eta, float invEta, float &R) { float cosThetaT; R = fresnelDielectricExt(fabsf(wi.z), cosThetaT, eta); return V(invEta * wi.x, invEta * wi.y, -copysignf(1.0f, wi.z) * cosThetaT); }
+DEV v3 ctRefractOut(v3 wi, float eta, float invEta, float &R) { float cosThetaT; R = fresnelDielectricExt(fabsf(wi.z), cosThetaT, invEta); return V(eta * wi.x, eta * wi.y, -copysignf(1.0f, wi.z) * cosThetaT); }
+DEV v3 ctAbsorb(const MaterialD &c, v3 result, v3 wiP, v3 woP) {
+    const v3 sigmaA = ld3(c.reflectance) * c.alpha;
+    if (isZero(sigmaA)) return result;
+    const float f = 1 / fabsf(wiP.z) + 1 / fabsf(woP.z);
+    return V(result.x * fastexpf_(-sigmaA.x * f), result.y * fastexpf_(-sigmaA.y * f), result.z * fastexpf_(-sigmaA.z * f));
+}
+DEV float ctProbSpecular(const MaterialD &c, float R12) { return (R12 * c.k[0]) / (R12 * c.k[0] + (1 - R12) * (1 - c.k[0])); }
+template <bool RC, bool MIX, bool L> DEV v3 ctEval(const DScene &sc, const Tabs<L> &tb, bool coated, const MaterialD &c, const MaterialD &m, v3 wi, v3 wo) {
+    if (!MIX || !coated) return mxEval<RC, MIX>(sc, tb, m, wi, wo);
+    const float eta = c.eta[0], invEta = 1 / eta;
+    if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    float R12, R21; const v3 wiP = ctRefractIn(wi, eta, invEta, R12), woP = ctRefractIn(wo, eta, invEta, R21);
+    if (R12 == 1 || R21 == 1) return V(0, 0, 0);
+    v3 result = (mxEval<RC, MIX>(sc, tb, m, wiP, woP) * (1 - R12)) * (1 - R21);
+    result = ctAbsorb(c, result, wiP, woP);
+    return result * (invEta * invEta * wo.z / woP.z);
+}
+template <bool RC, bool MIX, bool L> DEV float ctPdf(const DScene &sc, const Tabs<L> &tb, bool coated, const MaterialD &c, const MaterialD &m, v3 wi, v3 wo) {
+    if (!MIX || !coated) return mxPdf<RC, MIX>(sc, tb, m, wi, wo);
+    const float eta = c.eta[0], invEta = 1 / eta;
+    if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    float R12, R21; const v3 wiP = ctRefractIn(wi, eta, invEta, R12); const float probSpecular = ctProbSpecular(c, R12);
+    const v3 woP = ctRefractIn(wo, eta, invEta, R21);
+    if (R12 == 1 || R21 == 1) return 0.0f;
+    float pdf = mxPdf<RC, MIX>(sc, tb, m, wiP, woP);
+    pdf *= invEta * invEta * wo.z / woP.z;
+    return pdf * (1 - probSpecular);
+}
+template <bool RC, bool MIX, bool L, typename F> DEV v3 ctSample(const DScene &sc, const Tabs<L> &tb, bool coated, const MaterialD &c, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
+    if (!MIX || !coated) return mxSample<RC, MIX>(sc, tb, m, wi, u, v, extra, wo, pdf, etaOut, delta, nullComp);
+    const float eta = c.eta[0], invEta = 1 / eta;
+    const bool flip = (c.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
+    float R12; const v3 wiP = ctRefractIn(wi, eta, invEta, R12); const float probSpecular = ctProbSpecular(c, R12);
+    v3 result;
+    if (u < probSpecular) {
+        wo = V(-wi.x, -wi.y, wi.z); etaOut = 1.0f; pdf = probSpecular; delta = true; nullComp = false;
+        result = ld3(c.specular) * (R12 / pdf);
+    } else {
+        u = (u - probSpecular) / (1 - probSpecular);
+        if (R12 == 1.0f) return V(0, 0, 0);
+        v3 woP = V(0, 0, 0);
+        result = mxSample<RC, MIX>(sc, tb, m, wiP, u, v, extra, woP, pdf, etaOut, delta, nullComp);
+        if (isZero(result)) return V(0, 0, 0);
+        result = ctAbsorb(c, result, wiP, woP);
+        float R21; wo = ctRefractOut(woP, eta, invEta, R21);
+        if (R21 == 1.0f) return V(0, 0, 0);
+        pdf *= 1.0f - probSpecular; { const float r = 1.0f / (1.0f - probSpecular); result = result * r; }
+        result = result * ((1 - R12) * (1 - R21));
+        if (!delta) pdf *= invEta * invEta * wo.z / woP.z;
+    }
+    if (flip) wo.z = -wo.z;
+    return result;
+}
 // bumpmap / normalmap (src/bsdfs/bumpmap.cpp:140-250, normalmap.cpp:108-260): the nested BSDF runs in a perturbed shading frame (ps, pt, pn); directions whose
 // cosines differ in sign between the hit's frame and the perturbed one are rejected.  Texture2D::evalGradient (src/librender/texture.cpp:123-141): finite
 // differences over eps = 1e-4 for procedural textures, the bilinear gradient of MIP level 0 for bitmaps (bitmap.cpp:459-483, mipmap.h:602-627).

@@ -190,12 +190,13 @@ void SceneHost::commitHost() {
         const mi_material *mat = &materials[bsdf]; bool masked = false, wrapped = false;
         if (mat->type == MI_BSDF_MASK) { masked = true; mat = &materials[mat->distr]; }          // mask.cpp:104-121: the nested BSDF's components + an ENull | EFrontSide | EBackSide one
         if (mat->type == MI_BSDF_BUMPMAP || mat->type == MI_BSDF_NORMALMAP) { wrapped = true; mat = &materials[mat->distr]; }     // the nested BSDF's component types (bumpmap.cpp:97-100)
-        bool backside, smooth;
+        bool backside, smooth, coated = false;
+        if (mat->type == MI_BSDF_COATING) { coated = true; wrapped = true; mat = &materials[mat->distr]; }      // coating.cpp:166-173: the nested components + a delta reflection that is EFrontSide | EBackSide
         if (mat->type == MI_BSDF_MIXTURE) {                                                         // the children's components (mixturebsdf.cpp:150-166)
             backside = (mat->flags & MI_BSDF_FLAG_TWOSIDED) != 0; smooth = false; wrapped = true;
             for (uint32_t c = 0; c < mat->distr; ++c) { const mi_material &ch = materials[(uint32_t) (c < 3 ? mat->reflectance[c] : mat->eta[0])]; backside |= leafBackside(ch); smooth |= leafSmooth(ch); }
         } else { backside = leafBackside(*mat); smooth = leafSmooth(*mat); }
-        return ((backside || masked) ? 2u : 0u) | (smooth ? 0u : 4u) | ((mat->type != MI_BSDF_DIFFUSE || masked || wrapped) ? 8u : 0u);
+        return ((backside || masked || coated) ? 2u : 0u) | (smooth ? 0u : 4u) | ((mat->type != MI_BSDF_DIFFUSE || masked || wrapped) ? 8u : 0u);
     };
     for (uint32_t t = 0; t < nt; ++t) {
         uint32_t a = idx[t * 3], b = idx[t * 3 + 1], c = idx[t * 3 + 2];

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
         //   B: BSDF sampling                                                     -> next ray / state
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
-        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false; bool bumped = false; v3 bps = V(0, 0, 0), bpt = bps, bpn = bps;   // bumpmap / normalmap: perturbed frame (RC variants)
+        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false; bool bumped = false; v3 bps = V(0, 0, 0), bpt = bps, bpn = bps; bool coated = false; MaterialD coat = {};   // bumpmap / normalmap: perturbed frame (RC variants)
           // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
         if (i < n) {
             const uint32_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                     perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
                     bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
                 }
+                if (WRAP && bsdf.type == MI_BSDF_T_COATING) { coat = bsdf; coated = true; bsdf = loadMaterial(tb, (int) coat.distr); applyTexture(bsdf); }      // coating.cpp: the layer around the nested record
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }
@@ -202,10 +203,10 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                         if (WRAP && bumped) {                                                // bumpmap.cpp:165-180: the query in the perturbed frame
                             wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0;
                         }
-                        v3 bsdfVal = rejected ? V(0, 0, 0) : mxEval<RC, WRAP>(sc, tb, bsdf, wiQ, woQ);
+                        v3 bsdfVal = rejected ? V(0, 0, 0) : ctEval<RC, WRAP>(sc, tb, coated, coat, bsdf, wiQ, woQ);
                         if (RC && masked) bsdfVal = bsdfVal * opac;                          // mask.cpp:124-127
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = (dr.delta || rejected) ? 0.0f : mxPdf<RC, WRAP>(sc, tb, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
+                            float bp = (dr.delta || rejected) ? 0.0f : ctPdf<RC, WRAP>(sc, tb, coated, coat, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
                             if (RC && masked) bp *= luminance3(opac);                          // mask.cpp:141-146
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
@@ -244,9 +245,9 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                 (void) extra;
                 if (WRAP && bumped) {                                                  // bumpmap.cpp:199-222
                     const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
-                    bw = mxSample<RC, WRAP>(sc, tb, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
+                    bw = ctSample<RC, WRAP>(sc, tb, coated, coat, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
                     if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
-                } else bw = mxSample<RC, WRAP>(sc, tb, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                } else bw = ctSample<RC, WRAP>(sc, tb, coated, coat, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (RC && masked) { const float prob = luminance3(opac); bw = V(bw.x * opac.x / prob, bw.y * opac.y / prob, bw.z * opac.z / prob); bPdf *= prob; }
             }
             v3 wo = toWorld(h, woL);

@@ -28,6 +28,7 @@ BSDF_ROUGHDIFFUSE = 14     # src/bsdfs/roughdiffuse.cpp (Oren-Nayar): reflectanc
 BSDF_PHONG = 15            # src/bsdfs/phong.cpp: reflectance = diffuseReflectance, specular = specularReflectance, alpha = exponent, k[0] = specular sampling weight
 BSDF_WARD = 16             # src/bsdfs/ward.cpp: as phong, alpha = alphaU, k[1] = alphaV, distr = variant (WARD_*)
 WARD_WARD, WARD_DUER, WARD_BALANCED = 0, 1, 2
+BSDF_COATING = 17          # src/bsdfs/coating.cpp: distr = nested record, eta[0] = intIOR / extIOR, alpha = thickness, reflectance = sigmaA, specular = specularReflectance
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -146,6 +147,9 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         d = dict(type=kind, twosided=0, distr=int(nested), sample_visible=0, nonlinear=0, table=None, texture=int(texture), aniso=0,
                  reflectance=(0.0, 0.0, 0.0), alpha=float(scale), eta=(0.0, 0.0, 0.0), k=(0.0, 0.0, 0.0), specular=(0.0, 0.0, 0.0))
         return d
+    if kind == BSDF_COATING:                          # smooth dielectric layer over record `nested`; reflectance = sigmaA (absorption per unit thickness), scale = thickness
+        return dict(type=kind, twosided=int(twosided), distr=int(nested), sample_visible=0, nonlinear=0, table=None, texture=-1, aniso=0,
+                    reflectance=tuple(map(float, reflectance)), alpha=float(scale), eta=(float(f32(ior)), 0.0, 0.0), k=(0.0, 0.0, 0.0), specular=tuple(map(float, specular)))
     if kind == BSDF_MIXTURE:                          # children = `nested` (list of 2..4 earlier records), `weights` as given (rescaled by the BSDF itself when they sum to > 1)
         ch = [float(int(c)) for c in nested] + [0.0] * (4 - len(nested)); w = [float(f32(x)) for x in weights] + [0.0] * (4 - len(weights))
         if not (2 <= len(nested) <= 4) or len(nested) != len(weights): raise ValueError("mixturebsdf: 2..4 children with one weight each")
@@ -1251,6 +1255,26 @@ def ward_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, r
     sc.bsdfs[2] = make_bsdf(kind=BSDF_WARD, reflectance=(0.2, 0.45, 0.25), specular=(0.5, 0.5, 0.3), alpha=0.08, alpha_v=0.35, distr=WARD_BALANCED)       # mound (smooth normals)
     sc.textures = sc.textures[:1]                           # (the wall's and the mound's textures go with their BSDFs)
     sc.bsdfs[1] = make_bsdf(kind=BSDF_WARD, reflectance=(0.3, 0.3, 0.35), specular=(0.6, 0.55, 0.5), alpha=0.4, alpha_v=0.1, distr=WARD_DUER, twosided=True)   # wall (sheared uv: non-orthogonal tangents)
+    return sc
+
+
+def cbox_coating(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False):
+    """Cornell box with `coating` layers: clear varnish over diffuse, an absorbing layer over diffuse (twosided), a layer over a rough conductor, one over a smooth
+    conductor (a delta component under the layer) and one over a rough plastic."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, strict_normals=strict_normals)
+    sc.name = "cbox_coating"
+    eta, k = CONDUCTOR_IOR["Cu"]
+    base = len(sc.bsdfs)
+    sc.bsdfs.extend([make_bsdf(reflectance=(0.6, 0.55, 0.45)),                                                                  # base + 0: nested diffuse
+                     make_bsdf(kind=BSDF_COATING, nested=base, ior=1.5046, reflectance=(0.0, 0.0, 0.0)),                       # base + 1: floor
+                     make_bsdf(reflectance=(0.7, 0.7, 0.7)),                                                                    # base + 2
+                     make_bsdf(kind=BSDF_COATING, nested=base + 2, ior=1.33, reflectance=(0.2, 0.8, 1.6), scale=0.7, specular=(0.9, 0.9, 0.9), twosided=True),   # base + 3: back wall
+                     make_bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.15, distr=DISTR_GGX, eta=eta, k=k),                            # base + 4
+                     make_bsdf(kind=BSDF_COATING, nested=base + 4, ior=1.7, reflectance=(0.1, 0.3, 0.05), scale=1.0),           # base + 5: short block
+                     make_bsdf(kind=BSDF_CONDUCTOR, eta=eta, k=k),                                                              # base + 6
+                     make_bsdf(kind=BSDF_COATING, nested=base + 6, ior=1.5, reflectance=(0.0, 0.0, 0.0)),                       # base + 7: tall block
+                     ])
+    sc.shapes[0]["bsdf"] = base + 1; sc.shapes[2]["bsdf"] = base + 3; sc.shapes[6]["bsdf"] = base + 5; sc.shapes[7]["bsdf"] = base + 7
     return sc
 
 

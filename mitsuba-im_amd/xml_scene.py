@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughdiffuse, phong, ward, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
+    bsdf        diffuse, roughdiffuse, phong, ward, coating, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -547,6 +547,22 @@ class _SceneBuilder:
             if self.bsdfs[ni]["type"] == S.BSDF_MASK:
                 raise SceneError("mask: a mask nested in a mask is not supported")
             rec = S.make_bsdf(S.BSDF_MASK, reflectance=op or (0.5, 0.5, 0.5), nested=ni)
+        elif t == "coating":                              # src/bsdfs/coating.cpp:110-136: intIOR (bk7) / extIOR (air), thickness (1), sigmaA (0), specularReflectance (1), one nested BSDF
+            inner = p.children_of("bsdf")
+            if len(inner) != 1:
+                raise SceneError("coating: exactly one nested BSDF is expected")
+            sa, satex = _spectrum_or_texture(p, ("sigmaA",), (0.0, 0.0, 0.0))
+            sr, srtex = _spectrum_or_texture(p, ("specularReflectance",), (1.0, 1.0, 1.0))
+            if satex is not None or srtex is not None:
+                raise SceneError("coating: textured parameters are not supported")
+            int_ior, ext_ior = f32(_ior(p, "intIOR", "bk7")), f32(_ior(p, "extIOR", "air"))
+            if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
+                raise SceneError("The interior and exterior indices of refraction must be positive and differ!")
+            ni = self.bsdf(inner[0][1])
+            if self.bsdfs[ni]["type"] in (S.BSDF_MASK, S.BSDF_MIXTURE, S.BSDF_BUMPMAP, S.BSDF_NORMALMAP, S.BSDF_COATING, S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC, S.BSDF_DIFFTRANS, S.BSDF_THINDIELECTRIC, S.BSDF_NULL):
+                raise SceneError("coating: the nested BSDF must be a plain reflective one (adapters go around the coating)")
+            rec = S.make_bsdf(S.BSDF_COATING, nested=ni, ior=float(int_ior / ext_ior), reflectance=sa or (0.0, 0.0, 0.0), scale=float(p.get("thickness", 1.0)),
+                              specular=sr or (1.0, 1.0, 1.0), twosided=twosided)
         elif t == "null":                                 # src/bsdfs/null.cpp: the index-matched boundary of a medium
             rec = S.make_bsdf(S.BSDF_NULL)
         elif t == "diffuse":
@@ -637,7 +653,7 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, thindielectric, mask, twosided)")
+                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, coating, thindielectric, mask, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -1132,6 +1148,9 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="conductor">{cond}</bsdf>'
         elif t == S.BSDF_DIELECTRIC:
             inner = f'<bsdf type="dielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_COATING:
+            inner = (f'<bsdf type="coating">{ior}<float name="thickness" value="{fmt([b["alpha"]])}"/>{rgb("sigmaA", b["reflectance"])}{rgb("specularReflectance", b["specular"])}'
+                     f'<ref id="bsdf{b["distr"]}"/></bsdf>')
         elif t == S.BSDF_MASK:
             inner = f'<bsdf type="mask">{diffuse_param("opacity")}<ref id="bsdf{b["distr"]}"/></bsdf>'
         elif t == S.BSDF_THINDIELECTRIC:

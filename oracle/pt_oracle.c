@@ -802,7 +802,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16, BSDF_COATING = 17 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
@@ -1496,6 +1496,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
 /* a hit's material with its textures evaluated and its wrappers resolved (below): mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDFs */
 typedef struct { mat_t inner; int masked; int pdfless; v3 opacity; float prob;
                  int bumped; v3 ps, pt, pn; const hit_t *its;           /* bumpmap / normalmap: the perturbed shading frame; the hit's own frame stays the query frame */
+                 int coated; orc_material coat; float coat_w;            /* coating: the layer's record and its m_specularSamplingWeight; `inner` is the nested BSDF */
                  int n_mix; mat_t mix[4]; float w[4], p[4], cdf[5]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
 static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo);
@@ -1965,7 +1966,7 @@ static void perturb_frame(const orc_scene *s, const orc_material *m, const hit_t
 }
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd) {
     smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.pdfless = s->d.integrator == 1;      /* volpath_simple calls BSDF::sample(bRec, sample), the overload without a pdf */
-     sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its;
+     sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its; sm.coated = 0;
     if (its && sm.inner.m.type != BSDF_BUMPMAP && sm.inner.m.type != BSDF_NORMALMAP) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     if (sm.inner.m.type == BSDF_MASK) {
         sm.masked = 1; sm.opacity = V(sm.inner.m.reflectance[0], sm.inner.m.reflectance[1], sm.inner.m.reflectance[2]); sm.prob = luminance(sm.opacity);
@@ -1975,6 +1976,14 @@ static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_
     if (sm.inner.m.type == BSDF_BUMPMAP || sm.inner.m.type == BSDF_NORMALMAP) {
         if (its) { sm.bumped = 1; perturb_frame(s, &sm.inner.m, its, &sm.ps, &sm.pt, &sm.pn); }
         sm.inner = s->materials[sm.inner.m.distr];
+        if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    }
+    if (sm.inner.m.type == BSDF_COATING) {                                /* SmoothCoating::configure (coating.cpp:160-192): reflectance = sigmaA, alpha = thickness, eta[0] = eta, specular */
+        sm.coated = 1; sm.coat = sm.inner.m;
+        float e0 = fastexpf_(sm.coat.reflectance[0] * (-2 * sm.coat.alpha)), e1 = fastexpf_(sm.coat.reflectance[1] * (-2 * sm.coat.alpha)), e2 = fastexpf_(sm.coat.reflectance[2] * (-2 * sm.coat.alpha));
+        float avgAbsorption = 0.0f; avgAbsorption += e0; avgAbsorption += e1; avgAbsorption += e2; avgAbsorption = avgAbsorption * (1.0f / 3);
+        sm.coat_w = 1.0f / (avgAbsorption + 1.0f);
+        sm.inner = s->materials[sm.coat.distr];
         if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     }
     if (sm.inner.m.type == BSDF_MIXTURE) {                                /* MixtureBSDF::configure (mixturebsdf.cpp:115-169) */
@@ -2027,25 +2036,87 @@ static v3 mx_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pd
     if (flip) wo->z = -wo->z;
     return result;
 }
+/* ---- smooth dielectric coating: src/bsdfs/coating.cpp:205-372 around the level below (queried with component = -1, typeMask = EAll, measure = ESolidAngle on this path) */
+static v3 ct_refract_in(v3 wi, float eta, float invEta, float *R) {      /* :214-218; math::signum = copysignf(1, x) (math.h:270-278) */
+    float cosThetaT; *R = fresnel_dielectric_ext(fabsf(wi.z), &cosThetaT, eta);
+    return V(invEta * wi.x, invEta * wi.y, -copysignf(1.0f, wi.z) * cosThetaT);
+}
+static v3 ct_refract_out(v3 wi, float eta, float invEta, float *R) {     /* :221-225 */
+    float cosThetaT; *R = fresnel_dielectric_ext(fabsf(wi.z), &cosThetaT, invEta);
+    return V(eta * wi.x, eta * wi.y, -copysignf(1.0f, wi.z) * cosThetaT);
+}
+static v3 ct_absorb(const orc_material *c, v3 result, v3 wiP, v3 woP) {  /* Spectrum::exp = math::fastexp per channel (spectrum.h:521-526) */
+    v3 sigmaA = scale(V(c->reflectance[0], c->reflectance[1], c->reflectance[2]), c->alpha);
+    if (is_zero(sigmaA)) return result;
+    float f = 1 / fabsf(wiP.z) + 1 / fabsf(woP.z);
+    return mul(result, V(fastexpf_(-sigmaA.x * f), fastexpf_(-sigmaA.y * f), fastexpf_(-sigmaA.z * f)));
+}
+static v3 ct_eval(const smat_t *sm, v3 wi, v3 wo) {                       /* :227-265 */
+    if (!sm->coated) return mx_eval(sm, wi, wo);
+    const orc_material *c = &sm->coat; const float eta = c->eta[0], invEta = 1 / eta;
+    if ((c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    float R12, R21; v3 wiP = ct_refract_in(wi, eta, invEta, &R12), woP = ct_refract_in(wo, eta, invEta, &R21);
+    if (R12 == 1 || R21 == 1) return V(0, 0, 0);
+    v3 result = scale(scale(mx_eval(sm, wiP, woP), 1 - R12), 1 - R21);
+    result = ct_absorb(c, result, wiP, woP);
+    return scale(result, invEta * invEta * wo.z / woP.z);
+}
+static float ct_prob_specular(const smat_t *sm, float R12) { return (R12 * sm->coat_w) / (R12 * sm->coat_w + (1 - R12) * (1 - sm->coat_w)); }
+static float ct_pdf(const smat_t *sm, v3 wi, v3 wo) {                     /* :267-303 */
+    if (!sm->coated) return mx_pdf(sm, wi, wo);
+    const orc_material *c = &sm->coat; const float eta = c->eta[0], invEta = 1 / eta;
+    if ((c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    float R12, R21; v3 wiP = ct_refract_in(wi, eta, invEta, &R12); float probSpecular = ct_prob_specular(sm, R12);
+    v3 woP = ct_refract_in(wo, eta, invEta, &R21);
+    if (R12 == 1 || R21 == 1) return 0.0f;
+    float pdf = mx_pdf(sm, wiP, woP);
+    pdf *= invEta * invEta * wo.z / woP.z;
+    return pdf * (1 - probSpecular);
+}
+static v3 ct_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *etaOut, int *delta, sampler_t *sp) {      /* :305-372 */
+    if (!sm->coated) return mx_sample(sm, wi, u, v, wo, pdf, etaOut, delta, sp);
+    const orc_material *c = &sm->coat; const float eta = c->eta[0], invEta = 1 / eta;
+    int flip = (c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) wi.z = -wi.z;
+    float R12; v3 wiP = ct_refract_in(wi, eta, invEta, &R12); float probSpecular = ct_prob_specular(sm, R12);
+    v3 result;
+    if (u < probSpecular) {
+        *wo = V(-wi.x, -wi.y, wi.z); *etaOut = 1.0f; *pdf = probSpecular; *delta = 1;
+        result = scale(V(c->specular[0], c->specular[1], c->specular[2]), R12 / *pdf);
+    } else {
+        u = (u - probSpecular) / (1 - probSpecular);
+        if (R12 == 1.0f) return V(0, 0, 0);
+        v3 woP = V(0, 0, 0);
+        result = mx_sample(sm, wiP, u, v, &woP, pdf, etaOut, delta, sp);
+        if (is_zero(result)) return V(0, 0, 0);
+        result = ct_absorb(c, result, wiP, woP);
+        float R21; *wo = ct_refract_out(woP, eta, invEta, &R21);
+        if (R21 == 1.0f) return V(0, 0, 0);
+        *pdf *= 1.0f - probSpecular; { float r = 1.0f / (1.0f - probSpecular); result = scale(result, r); }
+        result = scale(result, (1 - R12) * (1 - R21));
+        if (!*delta) *pdf *= invEta * invEta * wo->z / woP.z;
+    }
+    if (flip) wo->z = -wo->z;
+    return result;
+}
 static inline v3 frame_to_local(v3 fs, v3 ft, v3 fn, v3 w) { return V(dot(w, fs), dot(w, ft), dot(w, fn)); }
 static inline v3 frame_to_world(v3 fs, v3 ft, v3 fn, v3 w) { return add(add(scale(fs, w.x), scale(ft, w.y)), scale(fn, w.z)); }
 /* bump / normal map level (bumpmap.cpp:165-250): wi, wo are given in the hit's own frame */
 static v3 bp_eval(const smat_t *sm, v3 wi, v3 wo) {
-    if (!sm->bumped) return mx_eval(sm, wi, wo);
+    if (!sm->bumped) return ct_eval(sm, wi, wo);
     const hit_t *h = sm->its; v3 wiP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wi)), woP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wo));
     if (wo.z * woP.z <= 0) return V(0, 0, 0);
-    return mx_eval(sm, wiP, woP);
+    return ct_eval(sm, wiP, woP);
 }
 static float bp_pdf(const smat_t *sm, v3 wi, v3 wo) {
-    if (!sm->bumped) return mx_pdf(sm, wi, wo);
+    if (!sm->bumped) return ct_pdf(sm, wi, wo);
     const hit_t *h = sm->its; v3 wiP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wi)), woP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wo));
     if (wo.z * woP.z <= 0) return 0.0f;
-    return mx_pdf(sm, wiP, woP);
+    return ct_pdf(sm, wiP, woP);
 }
 static v3 bp_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *eta, int *delta, sampler_t *sp) {
-    if (!sm->bumped) return mx_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
+    if (!sm->bumped) return ct_sample(sm, wi, u, v, wo, pdf, eta, delta, sp);
     const hit_t *h = sm->its; v3 wiP = frame_to_local(sm->ps, sm->pt, sm->pn, frame_to_world(h->s, h->tt, h->ns, wi)), woP = V(0, 0, 0);
-    v3 result = mx_sample(sm, wiP, u, v, &woP, pdf, eta, delta, sp);
+    v3 result = ct_sample(sm, wiP, u, v, &woP, pdf, eta, delta, sp);
     if (!is_zero(result)) {
         *wo = frame_to_local(h->s, h->tt, h->ns, frame_to_world(sm->ps, sm->pt, sm->pn, woP));
         if (wo->z * woP.z <= 0) return V(0, 0, 0);
@@ -2072,7 +2143,7 @@ static int sm_is_smooth(const smat_t *sm) {
     int r = 0; for (int i = 0; i < sm->n_mix; ++i) r |= material_is_smooth(&sm->mix[i].m); return r;      /* the mixture's components are its children's (mixturebsdf.cpp:150-166) */
 }
 static int sm_has_backside(const smat_t *sm) {
-    if (sm->masked) return 1;
+    if (sm->masked || sm->coated) return 1;                              /* coating.cpp:172-173: the layer's delta component is EFrontSide | EBackSide */
     if (!sm->n_mix) return material_has_backside(&sm->inner.m);
     int r = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) != 0; for (int i = 0; i < sm->n_mix; ++i) r |= material_has_backside(&sm->mix[i].m); return r;
 }

@@ -279,6 +279,12 @@ static Built buildScene(const FScene &fs) {
             p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
             p.setSpectrum("specularReflectance", rgb(fb.spec)); p.setSpectrum("specularTransmittance", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+        } else if (fb.type == 17) {          // coating: eta[0] = intIOR / extIOR, alpha = thickness, refl = sigmaA, spec = specularReflectance, nested BSDF = an EARLIER record (index in distr)
+            Properties p("coating"); p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setFloat("thickness", fb.alpha);
+            p.setSpectrum("sigmaA", rgb(fb.refl)); p.setSpectrum("specularReflectance", rgb(fb.spec));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+            if (fb.distr >= bsdfs.size()) { fprintf(stderr, "coating: the nested material must precede it\n"); _exit(2); }
+            bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
         } else if (fb.type == 9) {           // mask: opacity in refl (or the bound texture), nested BSDF = an EARLIER record (index in distr)
             Properties p("mask"); p.setSpectrum("opacity", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
@@ -322,7 +328,7 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         }
         { size_t bi = bsdfs.size();
-          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0 && fb.type != 11 && fb.type != 12) {      // texture bound to the record's `reflectance`
+          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0 && fb.type != 11 && fb.type != 12 && fb.type != 17) {      // texture bound to the record's `reflectance`
               ref<Texture> tex = makeTexture(fs.textures[fs.bsdfTexture[bi]], false);
               // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance or mask.opacity (the material record's `reflectance`)
               bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : fb.type == 9 ? "opacity" : "reflectance", tex); tex->setParent(bsdf);
