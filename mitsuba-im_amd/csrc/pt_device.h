@@ -1469,8 +1469,10 @@ DEV v3 ctAbsorb(const MaterialD &c, v3 result, v3 wiP, v3 woP) {
     return V(result.x * fastexpf_(-sigmaA.x * f), result.y * fastexpf_(-sigmaA.y * f), result.z * fastexpf_(-sigmaA.z * f));
 }
 DEV float ctProbSpecular(const MaterialD &c, float R12) { return (R12 * c.k[0]) / (R12 * c.k[0] + (1 - R12) * (1 - c.k[0])); }
-template <bool RC, bool MIX, bool L> DEV v3 ctEval(const DScene &sc, const Tabs<L> &tb, bool coated, const MaterialD &c, const MaterialD &m, v3 wi, v3 wo) {
-    if (!MIX || !coated) return mxEval<RC, MIX>(sc, tb, m, wi, wo);
+// (`coat`: index of the layer's record, -1 = no coating; the record is re-read where it is needed rather than carried through the shade stage: 16 registers)
+template <bool RC, bool MIX, bool L> DEV v3 ctEval(const DScene &sc, const Tabs<L> &tb, int coat, const MaterialD &m, v3 wi, v3 wo) {
+    if (!MIX || coat < 0) return mxEval<RC, MIX>(sc, tb, m, wi, wo);
+    const MaterialD c = loadMaterial(tb, coat);
     const float eta = c.eta[0], invEta = 1 / eta;
     if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     float R12, R21; const v3 wiP = ctRefractIn(wi, eta, invEta, R12), woP = ctRefractIn(wo, eta, invEta, R21);
@@ -1479,8 +1481,9 @@ template <bool RC, bool MIX, bool L> DEV v3 ctEval(const DScene &sc, const Tabs<
     result = ctAbsorb(c, result, wiP, woP);
     return result * (invEta * invEta * wo.z / woP.z);
 }
-template <bool RC, bool MIX, bool L> DEV float ctPdf(const DScene &sc, const Tabs<L> &tb, bool coated, const MaterialD &c, const MaterialD &m, v3 wi, v3 wo) {
-    if (!MIX || !coated) return mxPdf<RC, MIX>(sc, tb, m, wi, wo);
+template <bool RC, bool MIX, bool L> DEV float ctPdf(const DScene &sc, const Tabs<L> &tb, int coat, const MaterialD &m, v3 wi, v3 wo) {
+    if (!MIX || coat < 0) return mxPdf<RC, MIX>(sc, tb, m, wi, wo);
+    const MaterialD c = loadMaterial(tb, coat);
     const float eta = c.eta[0], invEta = 1 / eta;
     if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     float R12, R21; const v3 wiP = ctRefractIn(wi, eta, invEta, R12); const float probSpecular = ctProbSpecular(c, R12);
@@ -1490,8 +1493,9 @@ template <bool RC, bool MIX, bool L> DEV float ctPdf(const DScene &sc, const Tab
     pdf *= invEta * invEta * wo.z / woP.z;
     return pdf * (1 - probSpecular);
 }
-template <bool RC, bool MIX, bool L, typename F> DEV v3 ctSample(const DScene &sc, const Tabs<L> &tb, bool coated, const MaterialD &c, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
-    if (!MIX || !coated) return mxSample<RC, MIX>(sc, tb, m, wi, u, v, extra, wo, pdf, etaOut, delta, nullComp);
+template <bool RC, bool MIX, bool L, typename F> DEV v3 ctSample(const DScene &sc, const Tabs<L> &tb, int coat, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
+    if (!MIX || coat < 0) return mxSample<RC, MIX>(sc, tb, m, wi, u, v, extra, wo, pdf, etaOut, delta, nullComp);
+    const MaterialD c = loadMaterial(tb, coat);
     const float eta = c.eta[0], invEta = 1 / eta;
     const bool flip = (c.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
     float R12; const v3 wiP = ctRefractIn(wi, eta, invEta, R12); const float probSpecular = ctProbSpecular(c, R12);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
         //   B: BSDF sampling                                                     -> next ray / state
         bool alive = false, wantShadow = false, toSample = false;
         float4 shO, shD, shC;
-        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false; bool bumped = false; v3 bps = V(0, 0, 0), bpt = bps, bpn = bps; bool coated = false; MaterialD coat = {};   // bumpmap / normalmap: perturbed frame (RC variants)
+        Hit h; MaterialD bsdf; SamplerState ss; v3 T = V(0, 0, 0); float eta = 1.0f; uint32_t pid = 0; int depth = 0; bool unscattered = false; v3 opac = V(1, 1, 1); bool masked = false; bool bumped = false; v3 bps = V(0, 0, 0), bpt = bps, bpn = bps; int coat = -1;   // bumpmap / normalmap: perturbed frame (RC variants)
           // mask wrapper (mask.cpp): opacity in front of `bsdf` (RC variants)
         if (i < n) {
             const uint32_t slot = segBase + (doSort ? (uint32_t) s_order[i] : i);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                     }
                 }
                 if (!(depth <= rc.max_depth || rc.max_depth < 0)) { pathLen += (unsigned) depth; break; }   // loop guard path.cpp:135
-                bsdf = loadMaterial(tb, h.material);
+                int curMat = h.material; bsdf = loadMaterial(tb, curMat);
                 auto applyTexture = [&](MaterialD &mm) {
                 if (TEX) {                                                   // a textured parameter: m_reflectance->eval(bRec.its) (diffuse.cpp:112-121) and its siblings
                     const uint32_t tex = (mm.type == MI_BSDF_T_BUMPMAP || mm.type == MI_BSDF_T_NORMALMAP) ? 0u : (mm.flags >> 8) & 0xFFFFu;      // (an adapter's texture is its displacement / normal map)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                 };
                 applyTexture(bsdf);
                 if (RC && bsdf.type == MI_BSDF_T_MASK) {                     // mask.cpp: this record's (textured) `reflectance` is the opacity in front of the nested record `distr`
-                    opac = ld3(bsdf.reflectance); masked = true; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
+                    opac = ld3(bsdf.reflectance); masked = true; curMat = (int) bsdf.distr; bsdf = loadMaterial(tb, curMat); applyTexture(bsdf);
                 }
                 if (WRAP && TEX && (bsdf.type == MI_BSDF_T_BUMPMAP || bsdf.type == MI_BSDF_T_NORMALMAP)) {      // bumpmap.cpp / normalmap.cpp: getFrame(its), then the nested record
                     float huvx = h.uvx, huvy = h.uvy; v3 dpdu, dpdv;
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                     else { typename AS<SMALL>::p4 rec = tb.shade4 + prim * (uint32_t) MI_SHADE_WORDS; f4 r0 = rec[0], r1 = rec[1], r2 = rec[2]; dpdu = V(r1.x - r0.x, r1.y - r0.y, r1.z - r0.z); dpdv = V(r2.x - r0.x, r2.y - r0.y, r2.z - r0.z); }
                     if (inst >= 0) { dpdu = xfVector(sc.instances[inst].to_world, dpdu); dpdv = xfVector(sc.instances[inst].to_world, dpdv); }
                     perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
-                    bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf);
+                    curMat = (int) bsdf.distr; bsdf = loadMaterial(tb, curMat); applyTexture(bsdf);
                 }
-                if (WRAP && bsdf.type == MI_BSDF_T_COATING) { coat = bsdf; coated = true; bsdf = loadMaterial(tb, (int) coat.distr); applyTexture(bsdf); }      // coating.cpp: the layer around the nested record
+                if (WRAP && bsdf.type == MI_BSDF_T_COATING) { coat = curMat; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf); }      // coating.cpp: the layer around the nested record
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }
@@ -203,10 +203,10 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                         if (WRAP && bumped) {                                                // bumpmap.cpp:165-180: the query in the perturbed frame
                             wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); woQ = frameToLocal(bps, bpt, bpn, toWorld(h, wo)); rejected = wo.z * woQ.z <= 0;
                         }
-                        v3 bsdfVal = rejected ? V(0, 0, 0) : ctEval<RC, WRAP>(sc, tb, coated, coat, bsdf, wiQ, woQ);
+                        v3 bsdfVal = rejected ? V(0, 0, 0) : ctEval<RC, WRAP>(sc, tb, coat, bsdf, wiQ, woQ);
                         if (RC && masked) bsdfVal = bsdfVal * opac;                          // mask.cpp:124-127
                         if (!isZero(value) && !isZero(bsdfVal) && (!rc.strict_normals || dot(h.ng, dr.d) * wo.z > 0)) {
-                            float bp = (dr.delta || rejected) ? 0.0f : ctPdf<RC, WRAP>(sc, tb, coated, coat, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
+                            float bp = (dr.delta || rejected) ? 0.0f : ctPdf<RC, WRAP>(sc, tb, coat, bsdf, wiQ, woQ);     // emitter->isOnSurface() && measure == ESolidAngle (path.cpp:191-192)
                             if (RC && masked) bp *= luminance3(opac);                          // mask.cpp:141-146
                             float weight = miWeight(dr.pdf, bp);
                             v3 c = ((T * value) * bsdfVal) * weight;
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                 (void) extra;
                 if (WRAP && bumped) {                                                  // bumpmap.cpp:199-222
                     const v3 wiQ = frameToLocal(bps, bpt, bpn, toWorld(h, h.wi)); v3 woQ = V(0, 0, 0);
-                    bw = ctSample<RC, WRAP>(sc, tb, coated, coat, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
+                    bw = ctSample<RC, WRAP>(sc, tb, coat, bsdf, wiQ, sx, sy, drawExtra, woQ, bPdf, bEta, sampledDelta, sampledNull);
                     if (!isZero(bw)) { woL = toLocal(h, frameToWorld(bps, bpt, bpn, woQ)); if (woL.z * woQ.z <= 0) bw = V(0, 0, 0); }
-                } else bw = ctSample<RC, WRAP>(sc, tb, coated, coat, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
+                } else bw = ctSample<RC, WRAP>(sc, tb, coat, bsdf, h.wi, sx, sy, drawExtra, woL, bPdf, bEta, sampledDelta, sampledNull);
                 if (RC && masked) { const float prob = luminance3(opac); bw = V(bw.x * opac.x / prob, bw.y * opac.y / prob, bw.z * opac.z / prob); bPdf *= prob; }
             }
             v3 wo = toWorld(h, woL);
