@@ -80,6 +80,8 @@ typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling
 #define MI_BSDF_COATING 17         /* src/bsdfs/coating.cpp (smooth dielectric layer): distr = nested record (a plain BSDF without transmission, not twosided itself), eta[0] = intIOR /
                                       extIOR, alpha = thickness, reflectance = sigmaA, specular = specularReflectance; may be twosided, and may sit under a mask / bumpmap / normalmap.
                                       Path integrator only */
+#define MI_BSDF_BLEND 18           /* src/bsdfs/blendbsdf.cpp: eta[0], eta[1] = the two child records (plain BSDFs, as for mixturebsdf), reflectance = (w, w, w) for a constant
+                                      weight or the value of the bound `weight` texture; may be twosided and may sit under a mask / bumpmap / normalmap.  Path integrator only */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

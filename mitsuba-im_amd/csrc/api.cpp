@@ -203,11 +203,21 @@ int mi_scene_set_media(mi_scene *s, const mi_medium *media, uint32_t n, const in
 }
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
-    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP || t == MI_BSDF_COATING; };
+    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP || t == MI_BSDF_COATING || t == MI_BSDF_BLEND; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_COATING) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, coating, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_BLEND) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, coating, blendbsdf, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
+        if (m[i].type == MI_BSDF_BLEND) {
+            int deltas = 0;
+            for (int c = 0; c < 2; ++c) {
+                const float idxf = m[i].eta[c];
+                if (!(idxf >= 0) || idxf >= (float) n || isWrapper(m[(uint32_t) idxf].type)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: the two BSDFs of a blendbsdf are plain BSDF records (indices in eta[0], eta[1])");
+                if (((m[(uint32_t) idxf].flags >> 8) & 0xFFFFu)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: textures on the BSDFs inside a blendbsdf are not implemented");
+                deltas += hasDelta(m[(uint32_t) idxf].type);
+            }
+            if (deltas > 1) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a blendbsdf of two BSDFs that both have a Dirac delta component is not implemented");
+        }
         if (m[i].type == MI_BSDF_COATING) {
             // adapters nest in the order mask -> bumpmap / normalmap -> coating -> plain BSDF (a coating over a mixturebsdf, or as the child of one, is not implemented)
             if (m[i].distr >= n || isWrapper(m[m[i].distr].type)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a coating nests a plain BSDF record (index in `distr`)");
@@ -380,7 +390,7 @@ int SceneHost::upload(int dev) {
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
     d.has_adapters = 0;
-    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP || m.type == MI_BSDF_COATING) d.has_adapters |= 1u; if (m.type == MI_BSDF_COATING) d.has_adapters |= 4u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP || m.type == MI_BSDF_COATING) d.has_adapters |= 1u; if (m.type == MI_BSDF_COATING || m.type == MI_BSDF_BLEND) d.has_adapters |= 4u; if (m.type == MI_BSDF_BLEND) d.has_adapters |= 1u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     // bit 1: ENull lobes the volumetric walks have to evaluate through a wrapper -- a `mask`, or a mixturebsdf with a `null` / `thindielectric` child (surfaceNullEval; the NX kernel variants)
     for (const mi_material &m : materials) {
         if (m.type == MI_BSDF_MASK) d.has_adapters |= 2u;
@@ -413,7 +423,7 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         const uint32_t tex = (m.flags >> 8) & 0xFFFFu;
         if (tex && tex <= s->h.textures.size() && s->h.textures[tex - 1].type == MI_TEXTURE_BITMAP &&
             (size_t) s->h.textures[tex - 1].first_level + s->h.textures[tex - 1].n_levels > s->h.texLevels.size() / 3) return fail(MI_ERR_INVALID, "mi_scene_commit: bitmap texture without its MIP levels (mi_scene_set_texture_data)");
-        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_ROUGHDIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK && m.type != MI_BSDF_BUMPMAP && m.type != MI_BSDF_NORMALMAP)))
+        if (tex && (tex > s->h.textures.size() || (m.type != MI_BSDF_DIFFUSE && m.type != MI_BSDF_ROUGHDIFFUSE && m.type != MI_BSDF_PLASTIC && m.type != MI_BSDF_ROUGHPLASTIC && m.type != MI_BSDF_DIFFTRANS && m.type != MI_BSDF_MASK && m.type != MI_BSDF_BLEND && m.type != MI_BSDF_BUMPMAP && m.type != MI_BSDF_NORMALMAP)))
             return fail(MI_ERR_UNSUPPORTED, "mi_scene_commit: textures bind to diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance, mask.opacity or are the map of a bumpmap / normalmap (and must exist)");
     }
     if (s->h.envTexture >= 0) {       // MIP pyramid of the environment map (camera-ray lookups, envmap.cpp:398-411)
@@ -564,7 +574,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
-    if (p->integrator != MI_INTEGRATOR_PATH && (s->h.d.has_adapters & 4u)) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: `coating` is implemented for the path integrator only");
+    if (p->integrator != MI_INTEGRATOR_PATH && (s->h.d.has_adapters & 4u)) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: `coating` and `blendbsdf` are implemented for the path integrator only");
     if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for

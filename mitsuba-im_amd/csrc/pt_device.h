@@ -1395,9 +1395,15 @@ template <bool RC> DEV v3 bsdfSample(const DScene &sc, const MaterialD &m, v3 wi
 #define MI_BSDF_T_MIXTURE 10u
 #define MI_BSDF_T_BUMPMAP 11u
 #define MI_BSDF_T_NORMALMAP 12u
-struct MixD { int n; float w0, w1, w2, w3, c1, c2, c3; uint32_t i0, i1, i2, i3; };      // weights, cdf[1..3] (cdf[0] = 0, cdf[n] = 1), child records
+#define MI_BSDF_T_BLEND 18u
+struct MixD { int n; float w0, w1, w2, w3, c1, c2, c3; uint32_t i0, i1, i2, i3; bool blend; };      // weights, cdf[1..3] (cdf[0] = 0, cdf[n] = 1), child records
 DEV MixD mixOf(const MaterialD &m) {
-    MixD x; x.n = (int) m.distr; x.w0 = m.k[0]; x.w1 = m.k[1]; x.w2 = x.n > 2 ? m.k[2] : 0.0f; x.w3 = x.n > 3 ? m.specular[0] : 0.0f;
+    if (m.type == MI_BSDF_T_BLEND) {      // blendbsdf.cpp:138-141: weight = clamp(m_weight->eval(its).average(), 0, 1) on the second BSDF, 1 - weight on the first; `reflectance` = the texture's value or (w, w, w)
+        MixD b; b.n = 2; b.blend = true; b.w1 = minf(1.0f, maxf(0.0f, (((0.0f + m.reflectance[0]) + m.reflectance[1]) + m.reflectance[2]) * (1.0f / 3))); b.w0 = 1 - b.w1; b.w2 = b.w3 = 0.0f;
+        b.i0 = (uint32_t) m.eta[0]; b.i1 = (uint32_t) m.eta[1]; b.i2 = b.i3 = 0u; b.c1 = b.w0; b.c2 = b.c3 = 1.0f;
+        return b;
+    }
+    MixD x; x.blend = false; x.n = (int) m.distr; x.w0 = m.k[0]; x.w1 = m.k[1]; x.w2 = x.n > 2 ? m.k[2] : 0.0f; x.w3 = x.n > 3 ? m.specular[0] : 0.0f;
     x.i0 = (uint32_t) m.reflectance[0]; x.i1 = (uint32_t) m.reflectance[1]; x.i2 = (uint32_t) m.reflectance[2]; x.i3 = (uint32_t) m.eta[0];
     float total = x.w0 + x.w1; if (x.n > 2) total += x.w2; if (x.n > 3) total += x.w3;
     if (total > 1) { const float sc_ = 1.0f / total; x.w0 *= sc_; x.w1 *= sc_; x.w2 *= sc_; x.w3 *= sc_; }
@@ -1408,11 +1414,11 @@ DEV MixD mixOf(const MaterialD &m) {
     return x;
 }
 DEV float mixCdf(const MixD &x, int i) { return i <= 0 ? 0.0f : (i == 1 ? x.c1 : (i == 2 ? x.c2 : (i == 3 ? x.c3 : 1.0f))); }      // cdf[n] = 1 is baked into c2 / c3
-DEV float mixProb(const MixD &x, int i) { return (i + 1 >= x.n ? 1.0f : mixCdf(x, i + 1)) - mixCdf(x, i); }
+DEV float mixProb(const MixD &x, int i) { if (x.blend) return i == 0 ? x.w0 : x.w1; return (i + 1 >= x.n ? 1.0f : mixCdf(x, i + 1)) - mixCdf(x, i); }
 DEV float mixWeight(const MixD &x, int i) { return i == 0 ? x.w0 : (i == 1 ? x.w1 : (i == 2 ? x.w2 : x.w3)); }
 DEV uint32_t mixChild(const MixD &x, int i) { return i == 0 ? x.i0 : (i == 1 ? x.i1 : (i == 2 ? x.i2 : x.i3)); }
 template <bool RC, bool MIX, bool L> DEV v3 mxEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
-    if (!MIX || m.type != MI_BSDF_T_MIXTURE) return bsdfEval<RC>(sc, m, wi, wo);
+    if (!MIX || (m.type != MI_BSDF_T_MIXTURE && m.type != MI_BSDF_T_BLEND)) return bsdfEval<RC>(sc, m, wi, wo);
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     const MixD x = mixOf(m); v3 r = V(0, 0, 0);
 #pragma unroll
@@ -1420,7 +1426,7 @@ template <bool RC, bool MIX, bool L> DEV v3 mxEval(const DScene &sc, const Tabs<
     return r;
 }
 template <bool RC, bool MIX, bool L> DEV float mxPdf(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, v3 wo) {
-    if (!MIX || m.type != MI_BSDF_T_MIXTURE) return bsdfPdf<RC>(sc, m, wi, wo);
+    if (!MIX || (m.type != MI_BSDF_T_MIXTURE && m.type != MI_BSDF_T_BLEND)) return bsdfPdf<RC>(sc, m, wi, wo);
     if ((m.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     const MixD x = mixOf(m); float r = 0.0f;
 #pragma unroll
@@ -1429,7 +1435,7 @@ template <bool RC, bool MIX, bool L> DEV float mxPdf(const DScene &sc, const Tab
 }
 // `extra`: functor drawing one more sampler value, called only if the chosen BSDF asks for it (BSDF::EUsesSampler)
 template <bool RC, bool MIX, bool L, typename F> DEV v3 mxSample(const DScene &sc, const Tabs<L> &tb, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &eta, bool &delta, bool &nullComp) {
-    if (!MIX || m.type != MI_BSDF_T_MIXTURE) { const float e = (RC && bsdfUsesSampler(m)) ? extra() : 0.0f; return bsdfSample<RC>(sc, m, wi, u, v, e, wo, pdf, eta, delta, nullComp); }
+    if (!MIX || (m.type != MI_BSDF_T_MIXTURE && m.type != MI_BSDF_T_BLEND)) { const float e = (RC && bsdfUsesSampler(m)) ? extra() : 0.0f; return bsdfSample<RC>(sc, m, wi, u, v, e, wo, pdf, eta, delta, nullComp); }
     const bool flip = (m.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
     const MixD x = mixOf(m);
     // m_pdf.sampleReuse(sample.x) (pmf.h:124-190): lower_bound over the cdf = number of entries below u, minus one; zero-probability entries are skipped forward
@@ -1437,9 +1443,13 @@ template <bool RC, bool MIX, bool L, typename F> DEV v3 mxSample(const DScene &s
 #pragma unroll
     for (int j = 0; j <= 4; ++j) if (j <= x.n && (j >= x.n ? 1.0f : mixCdf(x, j)) < u) ++lo;
     int entry = lo > 0 ? lo - 1 : 0; if (entry > x.n - 1) entry = x.n - 1;
+    if (x.blend) {                                   // blendbsdf.cpp:226-232: `sample.x < weights[0]`, rescaled by the weights themselves
+        if (u < x.w0) { entry = 0; u /= x.w0; } else { entry = 1; u = (u - x.w0) / x.w1; }
+    } else {
     while (entry < x.n && mixProb(x, entry) == 0) ++entry;
     const float c0 = mixCdf(x, entry), c1 = entry + 1 >= x.n ? 1.0f : mixCdf(x, entry + 1);
     u = (u - c0) / (c1 - c0);
+    }
     const MaterialD child = loadMaterial(tb, (int) mixChild(x, entry));
     const float e = bsdfUsesSampler(child) ? extra() : 0.0f;
     v3 result = bsdfSample<RC>(sc, child, wi, u, v, e, wo, pdf, eta, delta, nullComp);

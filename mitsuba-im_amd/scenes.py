@@ -29,6 +29,7 @@ BSDF_PHONG = 15            # src/bsdfs/phong.cpp: reflectance = diffuseReflectan
 BSDF_WARD = 16             # src/bsdfs/ward.cpp: as phong, alpha = alphaU, k[1] = alphaV, distr = variant (WARD_*)
 WARD_WARD, WARD_DUER, WARD_BALANCED = 0, 1, 2
 BSDF_COATING = 17          # src/bsdfs/coating.cpp: distr = nested record, eta[0] = intIOR / extIOR, alpha = thickness, reflectance = sigmaA, specular = specularReflectance
+BSDF_BLEND = 18            # src/bsdfs/blendbsdf.cpp: eta[0..1] = the two child records, reflectance = (w, w, w) or the value of the bound `weight` texture
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -150,6 +151,11 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
     if kind == BSDF_COATING:                          # smooth dielectric layer over record `nested`; reflectance = sigmaA (absorption per unit thickness), scale = thickness
         return dict(type=kind, twosided=int(twosided), distr=int(nested), sample_visible=0, nonlinear=0, table=None, texture=-1, aniso=0,
                     reflectance=tuple(map(float, reflectance)), alpha=float(scale), eta=(float(f32(ior)), 0.0, 0.0), k=(0.0, 0.0, 0.0), specular=tuple(map(float, specular)))
+    if kind == BSDF_BLEND:                            # children = `nested` (two earlier records), weight = `alpha` (constant) or the bound texture
+        if len(nested) != 2: raise ValueError("blendbsdf: BSDF count mismatch: expected two nested BSDF instances!")
+        w = float(f32(alpha))
+        return dict(type=kind, twosided=int(twosided), distr=0, sample_visible=0, nonlinear=0, table=None, texture=int(texture), aniso=0,
+                    reflectance=(w, w, w), alpha=0.0, eta=(float(int(nested[0])), float(int(nested[1])), 0.0), k=(0.0, 0.0, 0.0), specular=(0.0, 0.0, 0.0))
     if kind == BSDF_MIXTURE:                          # children = `nested` (list of 2..4 earlier records), `weights` as given (rescaled by the BSDF itself when they sum to > 1)
         ch = [float(int(c)) for c in nested] + [0.0] * (4 - len(nested)); w = [float(f32(x)) for x in weights] + [0.0] * (4 - len(weights))
         if not (2 <= len(nested) <= 4) or len(nested) != len(weights): raise ValueError("mixturebsdf: 2..4 children with one weight each")
@@ -1275,6 +1281,25 @@ def cbox_coating(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8
                      make_bsdf(kind=BSDF_COATING, nested=base + 6, ior=1.5, reflectance=(0.0, 0.0, 0.0)),                       # base + 7: tall block
                      ])
     sc.shapes[0]["bsdf"] = base + 1; sc.shapes[2]["bsdf"] = base + 3; sc.shapes[6]["bsdf"] = base + 5; sc.shapes[7]["bsdf"] = base + 7
+    return sc
+
+
+def blend_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, rr_depth=4, seed=0):
+    """The textured room with `blendbsdf`: the floor blends a rough conductor into a diffuse record through its checkerboard (a TEXTURED weight), the mound blends
+    plastic and diffuse with a constant weight, the wall (twosided) blends two diffuse records through a grid texture."""
+    sc = textured_room(width, height, spp, sampler, max_depth, rr_depth, seed=seed)
+    sc.name = "blend_room"
+    eta, k = CONDUCTOR_IOR["Au"]
+    base = len(sc.bsdfs)
+    sc.bsdfs.extend([make_bsdf(reflectance=(0.7, 0.65, 0.5)), make_bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.2, distr=DISTR_BECKMANN, eta=eta, k=k),       # base, base + 1
+                     make_bsdf(kind=BSDF_PLASTIC, reflectance=(0.2, 0.5, 0.25), ior=1.49), make_bsdf(reflectance=(0.8, 0.2, 0.2)),                      # base + 2, base + 3
+                     make_bsdf(reflectance=(0.1, 0.15, 0.6)), make_bsdf(reflectance=(0.9, 0.85, 0.3))])                                                # base + 4, base + 5
+    sc.bsdfs.extend([make_bsdf(kind=BSDF_BLEND, nested=(base, base + 1), texture=0),                               # base + 6, floor: weight = the checkerboard
+                     make_bsdf(kind=BSDF_BLEND, nested=(base + 4, base + 5), texture=1, twosided=True),             # base + 7, wall: weight = the grid texture
+                     make_bsdf(kind=BSDF_BLEND, nested=(base + 2, base + 3), alpha=0.35)])                          # base + 8, mound: constant weight
+    for i in range(3):                                     # (the children precede the blends; the room's own records 0..2 stay in the table, unused)
+        for sh in sc.shapes:
+            if sh["bsdf"] == i: sh["bsdf"] = base + 6 + i
     return sc
 
 

@@ -802,7 +802,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16, BSDF_COATING = 17 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16, BSDF_COATING = 17, BSDF_BLEND = 18 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
@@ -1497,6 +1497,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
 typedef struct { mat_t inner; int masked; int pdfless; v3 opacity; float prob;
                  int bumped; v3 ps, pt, pn; const hit_t *its;           /* bumpmap / normalmap: the perturbed shading frame; the hit's own frame stays the query frame */
                  int coated; orc_material coat; float coat_w;            /* coating: the layer's record and its m_specularSamplingWeight; `inner` is the nested BSDF */
+                 int blend;                                              /* blendbsdf: two children in mix[0..1], w[1] = the (textured) weight, w[0] = 1 - w[1]; selection by `sample.x < w[0]` */
                  int n_mix; mat_t mix[4]; float w[4], p[4], cdf[5]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
 static v3 sm_eval(const smat_t *sm, v3 wi, v3 wo);
@@ -1966,7 +1967,7 @@ static void perturb_frame(const orc_scene *s, const orc_material *m, const hit_t
 }
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd) {
     smat_t sm; sm.inner = s->materials[material]; sm.masked = 0; sm.pdfless = s->d.integrator == 1;      /* volpath_simple calls BSDF::sample(bRec, sample), the overload without a pdf */
-     sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its; sm.coated = 0;
+     sm.opacity = V(1, 1, 1); sm.prob = 1.0f; sm.bumped = 0; sm.n_mix = 0; sm.its = its; sm.coated = 0; sm.blend = 0;
     if (its && sm.inner.m.type != BSDF_BUMPMAP && sm.inner.m.type != BSDF_NORMALMAP) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     if (sm.inner.m.type == BSDF_MASK) {
         sm.masked = 1; sm.opacity = V(sm.inner.m.reflectance[0], sm.inner.m.reflectance[1], sm.inner.m.reflectance[2]); sm.prob = luminance(sm.opacity);
@@ -1985,6 +1986,12 @@ static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_
         sm.coat_w = 1.0f / (avgAbsorption + 1.0f);
         sm.inner = s->materials[sm.coat.distr];
         if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    }
+    if (sm.inner.m.type == BSDF_BLEND) {                                  /* BlendBSDF (blendbsdf.cpp:138-141): weight = clamp(m_weight->eval(its).average(), 0, 1); `reflectance` holds the texture's value (or w, w, w) */
+        const orc_material *bl = &sm.inner.m; sm.n_mix = 2; sm.blend = 1;
+        float avg = 0.0f; avg += bl->reflectance[0]; avg += bl->reflectance[1]; avg += bl->reflectance[2]; avg = avg * (1.0f / 3);
+        sm.w[1] = minf(1.0f, maxf(0.0f, avg)); sm.w[0] = 1 - sm.w[1]; sm.p[0] = sm.w[0]; sm.p[1] = sm.w[1];
+        for (int i = 0; i < 2; ++i) { sm.mix[i] = s->materials[(uint32_t) bl->eta[i]]; sm.mix[i].m.flags &= ~THIN_SIGNED_COS; }
     }
     if (sm.inner.m.type == BSDF_MIXTURE) {                                /* MixtureBSDF::configure (mixturebsdf.cpp:115-169) */
         const orc_material *mx = &sm.inner.m; sm.n_mix = (int) mx->distr; float total = 0;
@@ -2019,10 +2026,13 @@ static v3 mx_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pd
     int flip = (sm->inner.m.flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) wi.z = -wi.z;
     /* m_pdf.sampleReuse(sample.x) (pmf.h:124-190): lower_bound over the cdf, then rescale */
     const float *cdf = sm->cdf;
-    int entry = 0; { int lo = 0, hi = sm->n_mix + 1; while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
+    int entry = 0;
+    if (sm->blend) {                                                      /* blendbsdf.cpp:226-232 */
+        if (u < sm->w[0]) { entry = 0; u /= sm->w[0]; } else { entry = 1; u = (u - sm->w[0]) / sm->w[1]; }
+    } else { int lo = 0, hi = sm->n_mix + 1; while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] < u) lo = mid + 1; else hi = mid; }
                      entry = lo > 0 ? lo - 1 : 0; if (entry > sm->n_mix - 1) entry = sm->n_mix - 1;
-                     while (cdf[entry + 1] - cdf[entry] == 0 && entry < sm->n_mix) ++entry; }
-    u = (u - cdf[entry]) / (cdf[entry + 1] - cdf[entry]);
+                     while (cdf[entry + 1] - cdf[entry] == 0 && entry < sm->n_mix) ++entry;
+                     u = (u - cdf[entry]) / (cdf[entry + 1] - cdf[entry]); }
     v3 result = bsdf_sample(&sm->mix[entry].m, wi, u, v, wo, pdf, eta, delta, sp);
     if (is_zero(result)) return result;
     result = scale(result, sm->w[entry] * *pdf); *pdf *= sm->p[entry];

@@ -285,6 +285,11 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
             if (fb.distr >= bsdfs.size()) { fprintf(stderr, "coating: the nested material must precede it\n"); _exit(2); }
             bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
+        } else if (fb.type == 18) {          // blendbsdf: children = EARLIER records (indices in eta[0], eta[1]); weight = refl[0] (constant) or the bound texture
+            Properties p("blendbsdf"); p.setFloat("weight", fb.refl[0]);
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+            for (int i = 0; i < 2; ++i) { size_t c = (size_t) fb.eta[i]; if (c >= bsdfs.size()) { fprintf(stderr, "blendbsdf: the children must precede it\n"); _exit(2); }
+                                          bsdf->addChild(bsdfs[c]); bsdfs[c]->setParent(bsdf); }
         } else if (fb.type == 9) {           // mask: opacity in refl (or the bound texture), nested BSDF = an EARLIER record (index in distr)
             Properties p("mask"); p.setSpectrum("opacity", rgb(fb.refl));
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
@@ -331,7 +336,7 @@ static Built buildScene(const FScene &fs) {
           if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0 && fb.type != 11 && fb.type != 12 && fb.type != 17) {      // texture bound to the record's `reflectance`
               ref<Texture> tex = makeTexture(fs.textures[fs.bsdfTexture[bi]], false);
               // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance or mask.opacity (the material record's `reflectance`)
-              bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : fb.type == 9 ? "opacity" : "reflectance", tex); tex->setParent(bsdf);
+              bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : fb.type == 9 ? "opacity" : fb.type == 18 ? "weight" : "reflectance", tex); tex->setParent(bsdf);
           } }
         bsdf->configure();
         if (fb.twosided) {

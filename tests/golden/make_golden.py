@@ -146,6 +146,7 @@ def golden_scenes():
         "ward_room": scenes.ward_room(width=96, height=64, spp=16),
         # `coating` over diffuse / rough conductor / smooth conductor, with and without absorption
         "cbox_coating": scenes.cbox_coating(width=96, height=96, spp=16),
+        "blend_room": scenes.blend_room(width=96, height=64, spp=16),      # `blendbsdf` with textured and constant weights
         "cbox_coating_strict_indep": scenes.cbox_coating(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=25, strict_normals=True),
     }
 
