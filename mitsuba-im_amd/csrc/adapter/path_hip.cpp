@@ -174,6 +174,17 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         const uint32_t keepFlags = m.flags;
         memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MASK; m.flags = keepFlags; m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
         memcpy(m.reflectance, op.data(), 12); if (opTex >= 0) m.flags |= MI_BSDF_TEXTURE(opTex);
+    } else if (cls == "BlendBSDF") {                                    // blendbsdf.cpp:94-101: the weight texture, then the two BSDFs; the children become records of their own
+        std::vector<float> w = rd.texture(); const int wTex = rd.lastTexture;
+        const uint32_t keepFlags = m.flags; memset(&m, 0, sizeof(m)); m.type = MI_BSDF_BLEND; m.flags = keepFlags;
+        for (int i = 0; i < 2; ++i) {
+            mi_material child; memset(&child, 0, sizeof(child));
+            if (!readNestedInstance(rd, child) || (child.type >= MI_BSDF_MASK && child.type != MI_BSDF_ROUGHDIFFUSE && child.type != MI_BSDF_PHONG && child.type != MI_BSDF_WARD))
+                SLog(EError, "path_hip: this BSDF inside a blendbsdf is not implemented (plain BSDFs, optionally twosided)");
+            if ((child.flags >> 8) & 0xFFFFu) SLog(EError, "path_hip: textures on the BSDFs inside a blendbsdf are not implemented");
+            m.eta[i] = (float) g_materials->size(); g_materials->push_back(child);
+        }
+        m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = w[0]; if (wTex >= 0) m.flags |= MI_BSDF_TEXTURE(wTex);
     } else if (cls == "SmoothCoating") {                                // coating.cpp:150-158: eta, thickness, the nested BSDF, sigmaA, specularReflectance
         const float eta = rd.ms->readFloat(), thickness = rd.ms->readFloat();
         mi_material nested; memset(&nested, 0, sizeof(nested));
@@ -268,7 +279,7 @@ static bool convertSpatiallyVarying(const BSDF *bsdf, mi_material &m) {
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
     if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
-    if (bsdf->getClass()->getName() == "SmoothCoating" || bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
+    if (bsdf->getClass()->getName() == "BlendBSDF" || bsdf->getClass()->getName() == "SmoothCoating" || bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: this `%s` is not implemented", bsdf->getClass()->getName().c_str());
     }

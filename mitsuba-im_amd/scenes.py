@@ -1297,9 +1297,11 @@ def blend_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, 
     sc.bsdfs.extend([make_bsdf(kind=BSDF_BLEND, nested=(base, base + 1), texture=0),                               # base + 6, floor: weight = the checkerboard
                      make_bsdf(kind=BSDF_BLEND, nested=(base + 4, base + 5), texture=1, twosided=True),             # base + 7, wall: weight = the grid texture
                      make_bsdf(kind=BSDF_BLEND, nested=(base + 2, base + 3), alpha=0.35)])                          # base + 8, mound: constant weight
-    for i in range(3):                                     # (the children precede the blends; the room's own records 0..2 stay in the table, unused)
+    for i in range(3):                                     # (the children precede the blends; the room's own records 0..2 stay in the table as plain, unused ones)
         for sh in sc.shapes:
             if sh["bsdf"] == i: sh["bsdf"] = base + 6 + i
+        sc.bsdfs[i] = make_bsdf(reflectance=(0.5, 0.5, 0.5))
+    sc.textures = sc.textures[:2]
     return sc
 
 

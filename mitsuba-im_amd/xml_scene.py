@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughdiffuse, phong, ward, coating, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
+    bsdf        diffuse, roughdiffuse, phong, ward, coating, blendbsdf, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -563,6 +563,20 @@ class _SceneBuilder:
                 raise SceneError("coating: the nested BSDF must be a plain reflective one (adapters go around the coating)")
             rec = S.make_bsdf(S.BSDF_COATING, nested=ni, ior=float(int_ior / ext_ior), reflectance=sa or (0.0, 0.0, 0.0), scale=float(p.get("thickness", 1.0)),
                               specular=sr or (1.0, 1.0, 1.0), twosided=twosided)
+        elif t == "blendbsdf":                            # src/bsdfs/blendbsdf.cpp:72-76, 103-108: weight (0.5, float or texture) and exactly two nested BSDFs
+            inner = p.children_of("bsdf")
+            if len(inner) != 2:
+                raise SceneError("BSDF count mismatch: expected two nested BSDF instances!")
+            wtex = [c for n, c in p.children_of("texture") if n == "weight"]
+            w = p.get("weight", 0.5) if not wtex else 0.5
+            if not isinstance(w, (int, float)):
+                raise SceneError("blendbsdf: `weight` is a float or a texture")
+            kids = [self.bsdf(c[1]) for c in inner]
+            for ci in kids:
+                if self.bsdfs[ci]["type"] in (S.BSDF_MASK, S.BSDF_MIXTURE, S.BSDF_BUMPMAP, S.BSDF_NORMALMAP, S.BSDF_COATING, S.BSDF_BLEND) or self.bsdfs[ci].get("texture", -1) >= 0:
+                    raise SceneError("blendbsdf: the nested BSDFs must be plain, untextured ones")
+            rec = S.make_bsdf(S.BSDF_BLEND, nested=kids, alpha=float(w), twosided=twosided)
+            if wtex: tex = wtex[0]
         elif t == "null":                                 # src/bsdfs/null.cpp: the index-matched boundary of a medium
             rec = S.make_bsdf(S.BSDF_NULL)
         elif t == "diffuse":
@@ -653,7 +667,7 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, coating, thindielectric, mask, twosided)")
+                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, coating, blendbsdf, thindielectric, mask, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -1148,6 +1162,9 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="conductor">{cond}</bsdf>'
         elif t == S.BSDF_DIELECTRIC:
             inner = f'<bsdf type="dielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_BLEND:
+            wx = texture_xml(sc.textures[b["texture"]], "weight") if b.get("texture", -1) >= 0 else f'<float name="weight" value="{fmt([b["reflectance"][0]])}"/>'
+            inner = f'<bsdf type="blendbsdf">{wx}<ref id="bsdf{int(b["eta"][0])}"/><ref id="bsdf{int(b["eta"][1])}"/></bsdf>'
         elif t == S.BSDF_COATING:
             inner = (f'<bsdf type="coating">{ior}<float name="thickness" value="{fmt([b["alpha"]])}"/>{rgb("sigmaA", b["reflectance"])}{rgb("specularReflectance", b["specular"])}'
                      f'<ref id="bsdf{b["distr"]}"/></bsdf>')

@@ -63,7 +63,7 @@ def test_plugin_drop_in_analytic_shapes(mi, golden_scenes, tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(PLUGIN)), reason="reference build (oracle/_ref) or adapter plugin not present")
-@pytest.mark.parametrize("name", ["cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room_procedural"])
+@pytest.mark.parametrize("name", ["cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room_procedural"])
 def test_plugin_drop_in_scene_level_emitters(mi, golden_scenes, tmp_path, name):
     """Same driver; live PointEmitter / SpotEmitter / DirectionalEmitter / ConstantBackgroundEmitter objects, and (cbox_materials) SmoothDielectric /
     SmoothConductor / SmoothPlastic BSDFs, flattened from their Properties; twosided(conductor) and (veach_small, BASELINE config 3 at test size)
