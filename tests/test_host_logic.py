@@ -44,6 +44,31 @@ def test_argument_validation_without_gpu(mi):
         mi.api.Lib("/nonexistent/libmi355pt.so")
 
 
+def test_round3_material_validation_without_gpu(mi):
+    """mi_scene_set_materials on the adapter records added in round 3: a coating nests ONE plain reflective record and needs two different indices of refraction
+    (coating.cpp:119-121); a blendbsdf blends two plain, untextured records; neither may be the child of a mixturebsdf; anisotropic `ward` passes the material
+    check (the texture-coordinate requirement is a commit-time check)."""
+    L = mi.lib(); h = C.c_void_p(); L.check(L.L.mi_scene_create(C.byref(h))); M = mi.api.MiMaterial
+    def mat(t, flags=0, distr=0, alpha=0.1, refl=(0.5, 0.5, 0.5), eta=(0, 0, 0), k=(0, 0, 0), spec=(1, 1, 1)):
+        return M(t, flags, distr, alpha, (C.c_float * 3)(*refl), (C.c_float * 3)(*eta), (C.c_float * 3)(*k), (C.c_float * 3)(*spec))
+    def rc(*ms):
+        arr = (M * len(ms))(*ms); return L.L.mi_scene_set_materials(h, C.cast(arr, C.c_void_p), len(ms)), L.L.mi_last_error()
+    COAT, BLEND, MIX, DIEL, WARD = 17, 18, 10, 3, 16
+    assert rc(mat(0), mat(COAT, distr=0, eta=(1.5, 0, 0)))[0] == 0
+    r, msg = rc(mat(0), mat(COAT, distr=0, eta=(1.0, 0, 0))); assert r == 1 and b"must be positive and differ" in msg
+    r, msg = rc(mat(0), mat(COAT, distr=5, eta=(1.5, 0, 0))); assert r == 3 and b"coating nests a plain BSDF" in msg
+    r, msg = rc(mat(DIEL, eta=(1.5, 0, 0)), mat(COAT, distr=0, eta=(1.5, 0, 0))); assert r == 3 and b"reflective" in msg
+    r, msg = rc(mat(0, flags=1), mat(COAT, distr=0, eta=(1.5, 0, 0))); assert r == 3 and b"twosided" in msg
+    r, msg = rc(mat(0), mat(COAT, distr=0, eta=(1.5, 0, 0)), mat(COAT, distr=1, eta=(1.3, 0, 0))); assert r == 3          # a coating over a coating
+    assert rc(mat(0), mat(0), mat(BLEND, eta=(0, 1, 0)))[0] == 0
+    r, msg = rc(mat(0), mat(0, flags=1 << 8), mat(BLEND, eta=(0, 1, 0))); assert r == 3 and b"textures on the BSDFs inside a blendbsdf" in msg
+    r, msg = rc(mat(0), mat(0), mat(BLEND, eta=(0, 1, 0)), mat(BLEND, eta=(0, 2, 0))); assert r == 3 and b"plain BSDF records" in msg
+    r, msg = rc(mat(0), mat(COAT, distr=0, eta=(1.5, 0, 0)), mat(MIX, distr=2, refl=(0, 1, 0), k=(0.5, 0.5, 0))); assert r == 3 and b"children of a mixturebsdf" in msg
+    assert rc(mat(WARD, flags=8, distr=2, alpha=0.1, k=(0.3, 0.4, 0), spec=(0.2, 0.2, 0.2)))[0] == 0
+    assert rc(mat(19))[0] == 3
+    L.L.mi_scene_destroy(h)
+
+
 def test_scene_generators(mi):
     S = mi.scenes
     sc = S.cornell_box()
