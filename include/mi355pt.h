@@ -82,6 +82,9 @@ typedef struct { float sigma_a[3], sigma_s[3]; uint32_t strategy; float sampling
                                       Path integrator only */
 #define MI_BSDF_BLEND 18           /* src/bsdfs/blendbsdf.cpp: eta[0], eta[1] = the two child records (plain BSDFs, as for mixturebsdf), reflectance = (w, w, w) for a constant
                                       weight or the value of the bound `weight` texture; may be twosided and may sit under a mask / bumpmap / normalmap.  Path integrator only */
+#define MI_BSDF_ROUGHCOATING 19    /* src/bsdfs/roughcoating.cpp (rough dielectric layer): distr = nested record (a plain reflective BSDF without a delta lobe), eta[0] = intIOR / extIOR,
+                                      eta[1] = thickness, eta[2] = microfacet distribution (0 beckmann, 1 ggx, 2 phong), alpha, flags bit 1 = sampleVisible, reflectance = sigmaA, specular,
+                                      k[1], k[2] = offset / length of its rough-transmittance slice in the material tables (as for roughplastic).  Path integrator only */
 #define MI_BSDF_FLAG_TWOSIDED 1u  /* wrapped in src/bsdfs/twosided.cpp             */
 #define MI_BSDF_FLAG_SAMPLE_VISIBLE 2u
 #define MI_BSDF_FLAG_NONLINEAR 4u /* plastic "nonlinear" */

@@ -174,6 +174,20 @@ static bool readSerializedBSDF(NestedReader &rd, const std::string &cls, mi_mate
         const uint32_t keepFlags = m.flags;
         memset(&m, 0, sizeof(m)); m.type = MI_BSDF_MASK; m.flags = keepFlags; m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
         memcpy(m.reflectance, op.data(), 12); if (opTex >= 0) m.flags |= MI_BSDF_TEXTURE(opTex);
+    } else if (cls == "RoughCoating") {                                 // roughcoating.cpp:174-185: type, sampleVisible, nested, sigmaA, specularReflectance, alpha, eta, thickness
+        const uint32_t distr = rd.ms->readUInt(); const bool sampleVisible = rd.ms->readBool();
+        mi_material nested; memset(&nested, 0, sizeof(nested));
+        if (!readNestedInstance(rd, nested)) SLog(EError, "path_hip: the BSDF nested in `roughcoating` is not implemented");
+        if (nested.type == MI_BSDF_MASK || nested.type == MI_BSDF_MIXTURE || nested.type == MI_BSDF_BUMPMAP || nested.type == MI_BSDF_NORMALMAP || nested.type == MI_BSDF_COATING || nested.type == MI_BSDF_ROUGHCOATING || nested.type == MI_BSDF_BLEND || (nested.flags & MI_BSDF_FLAG_TWOSIDED))
+            SLog(EError, "path_hip: a roughcoating over an adapter (mask, mixturebsdf, blendbsdf, bumpmap, normalmap, twosided, coating) is not implemented");
+        std::vector<float> sa = rd.constant("sigmaA"), spec = rd.constant("specularReflectance"), alpha = rd.constant("alpha");
+        const float eta = rd.ms->readFloat(), thickness = rd.ms->readFloat();
+        if (distr > 2) SLog(EError, "path_hip: unknown microfacet distribution");
+        const uint32_t keepFlags = m.flags;
+        memset(&m, 0, sizeof(m)); m.type = MI_BSDF_ROUGHCOATING; m.flags = keepFlags | (sampleVisible ? MI_BSDF_FLAG_SAMPLE_VISIBLE : 0u);
+        m.eta[0] = eta; m.alpha = alpha[0]; m.distr = distr; roughPlasticTables(m);      // (the slice for (distribution, eta, alpha); k[0] is overwritten at commit)
+        m.distr = (uint32_t) g_materials->size(); g_materials->push_back(nested);
+        m.eta[1] = thickness; m.eta[2] = (float) distr; memcpy(m.reflectance, sa.data(), 12); memcpy(m.specular, spec.data(), 12);
     } else if (cls == "BlendBSDF") {                                    // blendbsdf.cpp:94-101: the weight texture, then the two BSDFs; the children become records of their own
         std::vector<float> w = rd.texture(); const int wTex = rd.lastTexture;
         const uint32_t keepFlags = m.flags; memset(&m, 0, sizeof(m)); m.type = MI_BSDF_BLEND; m.flags = keepFlags;
@@ -279,7 +293,7 @@ static bool convertSpatiallyVarying(const BSDF *bsdf, mi_material &m) {
 static mi_material convertBSDF(const BSDF *bsdf) {
     mi_material m; memset(&m, 0, sizeof(m));
     if (bsdf->getClass()->getName() == "TwoSidedBRDF" && convertTwoSided(bsdf, m)) return m;
-    if (bsdf->getClass()->getName() == "BlendBSDF" || bsdf->getClass()->getName() == "SmoothCoating" || bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
+    if (bsdf->getClass()->getName() == "RoughCoating" || bsdf->getClass()->getName() == "BlendBSDF" || bsdf->getClass()->getName() == "SmoothCoating" || bsdf->getClass()->getName() == "Mask" || bsdf->getClass()->getName() == "MixtureBSDF" || bsdf->getClass()->getName() == "BumpMap" || bsdf->getClass()->getName() == "NormalMap") {   // nested BSDFs, weights and maps are private: serialised form
         if (convertSpatiallyVarying(bsdf, m)) return m;
         SLog(EError, "path_hip: this `%s` is not implemented", bsdf->getClass()->getName().c_str());
     }

@@ -203,10 +203,10 @@ int mi_scene_set_media(mi_scene *s, const mi_medium *media, uint32_t n, const in
 }
 int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
     if (!s || !m || !n) return fail(MI_ERR_INVALID, "mi_scene_set_materials: null argument");
-    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP || t == MI_BSDF_COATING || t == MI_BSDF_BLEND; };
+    auto isWrapper = [](uint32_t t) { return t == MI_BSDF_MASK || t == MI_BSDF_MIXTURE || t == MI_BSDF_BUMPMAP || t == MI_BSDF_NORMALMAP || t == MI_BSDF_COATING || t == MI_BSDF_BLEND || t == MI_BSDF_ROUGHCOATING; };
     auto hasDelta = [](uint32_t t) { return t == MI_BSDF_CONDUCTOR || t == MI_BSDF_DIELECTRIC || t == MI_BSDF_THINDIELECTRIC || t == MI_BSDF_PLASTIC; };
     for (uint32_t i = 0; i < n; ++i) {
-        if (m[i].type > MI_BSDF_BLEND) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, coating, blendbsdf, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
+        if (m[i].type > MI_BSDF_ROUGHCOATING) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: implemented BSDFs: diffuse, roughdiffuse, phong, ward, coating, roughcoating, blendbsdf, roughconductor, conductor, dielectric, plastic, roughdielectric, difftrans, roughplastic, thindielectric, mask, mixturebsdf, bumpmap, normalmap (those without transmission optionally twosided)");
         if (m[i].type == MI_BSDF_MASK && (m[i].distr >= n || m[m[i].distr].type == MI_BSDF_MASK || (m[i].flags & MI_BSDF_FLAG_TWOSIDED))) return fail(MI_ERR_INVALID, "mi_scene_set_materials: a mask refers to its nested material record by index (not another mask) and cannot itself be twosided");
         if (m[i].type == MI_BSDF_BLEND) {
             int deltas = 0;
@@ -217,6 +217,15 @@ int mi_scene_set_materials(mi_scene *s, const mi_material *m, uint32_t n) {
                 deltas += hasDelta(m[(uint32_t) idxf].type);
             }
             if (deltas > 1) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a blendbsdf of two BSDFs that both have a Dirac delta component is not implemented");
+        }
+        if (m[i].type == MI_BSDF_ROUGHCOATING) {
+            if (m[i].distr >= n || isWrapper(m[m[i].distr].type)) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a roughcoating nests a plain BSDF record (index in `distr`)");
+            const mi_material &nm = m[m[i].distr];
+            if ((nm.flags & MI_BSDF_FLAG_TWOSIDED) || hasDelta(nm.type) || nm.type == MI_BSDF_ROUGHDIELECTRIC || nm.type == MI_BSDF_DIFFTRANS || nm.type == MI_BSDF_NULL)
+                return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: the BSDF under a roughcoating is a reflective one without a Dirac delta lobe, `twosided` goes on the coating");
+            if (!(m[i].eta[0] > 0) || m[i].eta[0] == 1.0f) return fail(MI_ERR_INVALID, "The interior and exterior indices of refraction must be positive and differ!");      // roughcoating.cpp:126-128
+            if (m[i].eta[2] != 0.0f && m[i].eta[2] != 1.0f && m[i].eta[2] != 2.0f) return fail(MI_ERR_INVALID, "Specified an invalid distribution, must be \"beckmann\", \"ggx\", or \"phong\"/\"as\"!");
+            if ((m[i].flags >> 8) & 0xFFFFu) return fail(MI_ERR_UNSUPPORTED, "mi_scene_set_materials: a textured sigmaA is not implemented");
         }
         if (m[i].type == MI_BSDF_COATING) {
             // adapters nest in the order mask -> bumpmap / normalmap -> coating -> plain BSDF (a coating over a mixturebsdf, or as the child of one, is not implemented)
@@ -305,6 +314,10 @@ int SceneHost::upload(int dev) {
     if (hipSetDevice(dev) != hipSuccess) return 1;
     std::vector<MaterialD> mats(materials.size());
     for (size_t i = 0; i < materials.size(); ++i) memcpy(&mats[i], &materials[i], sizeof(MaterialD));
+    for (MaterialD &m : mats) if (m.type == MI_BSDF_ROUGHCOATING) {      // RoughCoating::configure (roughcoating.cpp:205-209): the same weight, thickness in eta[1]
+        float avg = 0.0f; for (int c = 0; c < 3; ++c) avg += (float) exp((double) (m.reflectance[c] * (-2 * m.eta[1])));
+        avg = avg * (1.0f / 3); m.k[0] = 1.0f / (avg + 1.0f);
+    }
     for (MaterialD &m : mats) if (m.type == MI_BSDF_COATING) {      // SmoothCoating::configure (coating.cpp:182-186): m_specularSamplingWeight from the layer's average absorption -> k[0]
         float avg = 0.0f; for (int c = 0; c < 3; ++c) avg += (float) exp((double) (m.reflectance[c] * (-2 * m.alpha)));      // Spectrum::exp = math::fastexp per channel, then average()
         avg = avg * (1.0f / 3); m.k[0] = 1.0f / (avg + 1.0f);
@@ -390,7 +403,7 @@ int SceneHost::upload(int dev) {
       d.small_tables = (nTris <= 400 && mats.size() <= 64 && emittersD.size() <= 32 && areaCdf.size() <= 2048 && !(ns && ns[0] == '1')) ? 1u : 0u; }   // ELIGIBLE for LDS staging; mi_render_create decides per render whether it fits next to the Sobol tables
     d.has_roughconductor = 0; d.has_diffuse = 0;
     d.has_adapters = 0;
-    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP || m.type == MI_BSDF_COATING) d.has_adapters |= 1u; if (m.type == MI_BSDF_COATING || m.type == MI_BSDF_BLEND) d.has_adapters |= 4u; if (m.type == MI_BSDF_BLEND) d.has_adapters |= 1u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
+    for (const mi_material &m : materials) { if (m.type != MI_BSDF_DIFFUSE) d.has_roughconductor = 1; else d.has_diffuse = 1; if (m.type == MI_BSDF_MIXTURE || m.type == MI_BSDF_BUMPMAP || m.type == MI_BSDF_NORMALMAP || m.type == MI_BSDF_COATING || m.type == MI_BSDF_ROUGHCOATING) d.has_adapters |= 1u; if (m.type == MI_BSDF_COATING || m.type == MI_BSDF_BLEND || m.type == MI_BSDF_ROUGHCOATING) d.has_adapters |= 4u; if (m.type == MI_BSDF_BLEND) d.has_adapters |= 1u; }   // any non-diffuse material -> k_shade<RC = true>; both kinds -> two shading launches per bounce (class split)
     // bit 1: ENull lobes the volumetric walks have to evaluate through a wrapper -- a `mask`, or a mixturebsdf with a `null` / `thindielectric` child (surfaceNullEval; the NX kernel variants)
     for (const mi_material &m : materials) {
         if (m.type == MI_BSDF_MASK) d.has_adapters |= 2u;
@@ -437,14 +450,14 @@ int mi_scene_commit(mi_scene *s, uint32_t device) {
         if (b < 0 || (size_t) b >= s->h.materials.size()) return false;
         const mi_material *mm = &s->h.materials[b];
         if (mm->type == MI_BSDF_MASK && mm->distr < s->h.materials.size()) mm = &s->h.materials[mm->distr];
-        if (mm->type == MI_BSDF_COATING && mm->distr < s->h.materials.size()) mm = &s->h.materials[mm->distr];
+        if ((mm->type == MI_BSDF_COATING || mm->type == MI_BSDF_ROUGHCOATING) && mm->distr < s->h.materials.size()) mm = &s->h.materials[mm->distr];
         return (mm->flags & MI_BSDF_FLAG_ANISOTROPIC) != 0 || mm->type == MI_BSDF_BUMPMAP || mm->type == MI_BSDF_NORMALMAP;
     };
     for (const mi_shape &sh : s->h.shapes)         // TriMesh::computeUVTangents (trimesh.cpp:683-692): such BSDFs take their tangents from the texture coordinates
         if (wantsTangents(sh.bsdf) && !((sh.flags & 2u) && !s->h.uv.empty()))
             return fail(MI_ERR_INVALID, "computeUVTangents(): texture coordinates are required to generate tangent vectors. If you want to render with an anisotropic material, please make sure that all associated shapes have valid texture coordinates.");
     for (const mi_material &m : s->h.materials)
-        if (m.type == MI_BSDF_ROUGHPLASTIC && (m.k[2] < 2 || m.k[1] < 0 || (size_t) m.k[1] + (size_t) m.k[2] > s->h.materialTables.size()))
+        if ((m.type == MI_BSDF_ROUGHPLASTIC || m.type == MI_BSDF_ROUGHCOATING) && (m.k[2] < 2 || m.k[1] < 0 || (size_t) m.k[1] + (size_t) m.k[2] > s->h.materialTables.size()))
             return fail(MI_ERR_INVALID, "mi_scene_commit: roughplastic material without its rough-transmittance slice (mi_scene_set_material_tables)");
     for (const mi_analytic &a : s->h.analytic) {
         if (a.bsdf < 0 || (size_t) a.bsdf >= s->h.materials.size()) return fail(MI_ERR_INVALID, "mi_scene_commit: analytic shape refers to a missing material");
@@ -574,7 +587,7 @@ int mi_render_create(mi_scene *s, const mi_render_params *p, mi_render **out) {
     if (p->max_depth <= 0 && p->max_depth != -1) return fail(MI_ERR_INVALID, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");   // :224-225
     if (p->max_depth > 250) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: maxDepth > 250");
     if (p->sampler > 1) return fail(MI_ERR_INVALID, "mi_render_create: unknown sampler");
-    if (p->integrator != MI_INTEGRATOR_PATH && (s->h.d.has_adapters & 4u)) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: `coating` and `blendbsdf` are implemented for the path integrator only");
+    if (p->integrator != MI_INTEGRATOR_PATH && (s->h.d.has_adapters & 4u)) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: `coating`, `roughcoating` and `blendbsdf` are implemented for the path integrator only");
     if (p->integrator > MI_INTEGRATOR_VOLPATH) return fail(MI_ERR_UNSUPPORTED, "mi_render_create: integrators path (0), volpath_simple (1) and volpath (2) are implemented");
     const bool vol = p->integrator != MI_INTEGRATOR_PATH;
     if (vol) {       // what the volumetric stages (kernels_vol.hip) are built for

@@ -1479,10 +1479,87 @@ DEV v3 ctAbsorb(const MaterialD &c, v3 result, v3 wiP, v3 woP) {
     return V(result.x * fastexpf_(-sigmaA.x * f), result.y * fastexpf_(-sigmaA.y * f), result.z * fastexpf_(-sigmaA.z * f));
 }
 DEV float ctProbSpecular(const MaterialD &c, float R12) { return (R12 * c.k[0]) / (R12 * c.k[0] + (1 - R12) * (1 - c.k[0])); }
+// ---- rough dielectric coating (src/bsdfs/roughcoating.cpp:236-443): a microfacet interface (isotropic MicrofacetDistribution) over the nested record; directions enter and
+// leave by Snell's law alone (refractTo), the energy balance is the rough-transmittance slice (table at k[1], length k[2]); sample() re-evaluates pdf and value (:432-438)
+#define MI_BSDF_T_ROUGHCOATING 19u
+DEV v3 rctRefractTo(bool interior, v3 wi, float eta, float invEtaC) {
+    const float invEta = interior ? invEtaC : eta; const bool entering = wi.z > 0.0f;
+    const float sinThetaTSqr = invEta * invEta * (1.0f - wi.z * wi.z);
+    if (sinThetaTSqr >= 1.0f) return V(0, 0, 0);
+    const float cosThetaT = sqrtf(1.0f - sinThetaTSqr);
+    return V(invEta * wi.x, invEta * wi.y, entering ? cosThetaT : -cosThetaT);
+}
+DEV MfD rctDistr(const MaterialD &c) { MfD d; d.distr = (uint32_t) c.eta[2]; d.au = d.av = maxf(avg3(c.alpha), 1e-4f); d.visible = (c.flags & 2u) != 0 && d.distr != 2u; return d; }
+DEV float rctProbSpecular(const DScene &sc, const MaterialD &c, float cosThetaI) {
+    const float p = 1 - rpTransmittance(sc, c, fabsf(cosThetaI)), w = c.k[0];
+    return (p * w) / (p * w + (1 - p) * (1 - w));
+}
+DEV v3 rctAbsorb(const MaterialD &c, v3 result, v3 wiP, v3 woP) {
+    const v3 sigmaA = ld3(c.reflectance) * c.eta[1];
+    if (isZero(sigmaA)) return result;
+    const float f = 1 / fabsf(wiP.z) + 1 / fabsf(woP.z);
+    return V(result.x * fastexpf_(-sigmaA.x * f), result.y * fastexpf_(-sigmaA.y * f), result.z * fastexpf_(-sigmaA.z * f));
+}
+template <bool RC, bool MIX, bool L> DEV v3 rctEval(const DScene &sc, const Tabs<L> &tb, const MaterialD &c, const MaterialD &m, v3 wi, v3 wo) {
+    const float eta = c.eta[0], invEta = 1 / eta; const MfD d = rctDistr(c);
+    if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    v3 result = V(0, 0, 0);
+    if (wo.z * wi.z > 0) {
+        const v3 H = normalize(wo + wi) * copysignf(1.0f, wo.z); float ct;
+        const float D = mfEval2(d.distr, d.au, d.av, H), F = fresnelDielectricExt(fabsf(dot(wi, H)), ct, eta);
+        const float G = mfSmithG1_2(d.distr, d.au, d.av, wi, H) * mfSmithG1_2(d.distr, d.au, d.av, wo, H);
+        const float value = F * D * G / (4.0f * fabsf(wi.z));
+        result = result + ld3(c.specular) * value;
+    }
+    const v3 wiP = rctRefractTo(true, wi, eta, invEta), woP = rctRefractTo(true, wo, eta, invEta);
+    v3 nested = (mxEval<RC, MIX>(sc, tb, m, wiP, woP) * rpTransmittance(sc, c, fabsf(wi.z))) * rpTransmittance(sc, c, fabsf(wo.z));
+    nested = rctAbsorb(c, nested, wiP, woP);
+    nested = nested * (invEta * invEta * wo.z / woP.z);
+    return result + nested;
+}
+template <bool RC, bool MIX, bool L> DEV float rctPdf(const DScene &sc, const Tabs<L> &tb, const MaterialD &c, const MaterialD &m, v3 wi, v3 wo) {
+    const float eta = c.eta[0], invEta = 1 / eta; const MfD d = rctDistr(c);
+    if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    const v3 H = normalize(wo + wi) * copysignf(1.0f, wo.z);
+    const float probSpecular = rctProbSpecular(sc, c, wi.z), probNested = 1 - probSpecular; float result = 0.0f;
+    if (wo.z * wi.z > 0) {
+        const float dwh_dwo = 1.0f / (4.0f * fabsf(dot(wo, H))), prob = mfdPdf(d, wi, H);
+        result = prob * dwh_dwo * probSpecular;
+    }
+    const v3 wiP = rctRefractTo(true, wi, eta, invEta), woP = rctRefractTo(true, wo, eta, invEta);
+    float prob = mxPdf<RC, MIX>(sc, tb, m, wiP, woP);
+    prob *= invEta * invEta * wo.z / woP.z;
+    result += prob * probNested;
+    return result;
+}
+template <bool RC, bool MIX, bool L, typename F> DEV v3 rctSample(const DScene &sc, const Tabs<L> &tb, const MaterialD &c, const MaterialD &m, v3 wi, float sx, float sy, F extra, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
+    const float eta = c.eta[0], invEta = 1 / eta; const MfD d = rctDistr(c);
+    const bool flip = (c.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
+    const float probSpecular = rctProbSpecular(sc, c, wi.z); bool choseSpecular = true;
+    if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = false; }
+    delta = false; nullComp = false;
+    if (choseSpecular) {
+        float mpdf; const v3 mm = mfdSample(d, wi, sx, sy, mpdf);
+        const float cc = 2 * dot(wi, mm); wo = mm * cc - wi; etaOut = 1.0f;
+        if (wo.z * wi.z <= 0) return V(0, 0, 0);
+    } else {
+        const v3 wiP = rctRefractTo(true, wi, eta, invEta); v3 woP = V(0, 0, 0);
+        const v3 r = mxSample<RC, MIX>(sc, tb, m, wiP, sx, sy, extra, woP, pdf, etaOut, delta, nullComp);
+        if (isZero(r)) return V(0, 0, 0);
+        wo = rctRefractTo(false, woP, eta, invEta);
+        if (isZero(wo)) return V(0, 0, 0);
+    }
+    pdf = rctPdf<RC, MIX>(sc, tb, c, m, wi, wo);
+    if (pdf == 0) return V(0, 0, 0);
+    const float r = 1.0f / pdf; const v3 result = rctEval<RC, MIX>(sc, tb, c, m, wi, wo) * r;
+    if (flip) wo.z = -wo.z;
+    return result;
+}
 // (`coat`: index of the layer's record, -1 = no coating; the record is re-read where it is needed rather than carried through the shade stage: 16 registers)
 template <bool RC, bool MIX, bool L> DEV v3 ctEval(const DScene &sc, const Tabs<L> &tb, int coat, const MaterialD &m, v3 wi, v3 wo) {
     if (!MIX || coat < 0) return mxEval<RC, MIX>(sc, tb, m, wi, wo);
     const MaterialD c = loadMaterial(tb, coat);
+    if (c.type == MI_BSDF_T_ROUGHCOATING) return rctEval<RC, MIX>(sc, tb, c, m, wi, wo);
     const float eta = c.eta[0], invEta = 1 / eta;
     if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     float R12, R21; const v3 wiP = ctRefractIn(wi, eta, invEta, R12), woP = ctRefractIn(wo, eta, invEta, R21);
@@ -1494,6 +1571,7 @@ template <bool RC, bool MIX, bool L> DEV v3 ctEval(const DScene &sc, const Tabs<
 template <bool RC, bool MIX, bool L> DEV float ctPdf(const DScene &sc, const Tabs<L> &tb, int coat, const MaterialD &m, v3 wi, v3 wo) {
     if (!MIX || coat < 0) return mxPdf<RC, MIX>(sc, tb, m, wi, wo);
     const MaterialD c = loadMaterial(tb, coat);
+    if (c.type == MI_BSDF_T_ROUGHCOATING) return rctPdf<RC, MIX>(sc, tb, c, m, wi, wo);
     const float eta = c.eta[0], invEta = 1 / eta;
     if ((c.flags & 1u) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     float R12, R21; const v3 wiP = ctRefractIn(wi, eta, invEta, R12); const float probSpecular = ctProbSpecular(c, R12);
@@ -1506,6 +1584,7 @@ template <bool RC, bool MIX, bool L> DEV float ctPdf(const DScene &sc, const Tab
 template <bool RC, bool MIX, bool L, typename F> DEV v3 ctSample(const DScene &sc, const Tabs<L> &tb, int coat, const MaterialD &m, v3 wi, float u, float v, F extra, v3 &wo, float &pdf, float &etaOut, bool &delta, bool &nullComp) {
     if (!MIX || coat < 0) return mxSample<RC, MIX>(sc, tb, m, wi, u, v, extra, wo, pdf, etaOut, delta, nullComp);
     const MaterialD c = loadMaterial(tb, coat);
+    if (c.type == MI_BSDF_T_ROUGHCOATING) return rctSample<RC, MIX>(sc, tb, c, m, wi, u, v, extra, wo, pdf, etaOut, delta, nullComp);
     const float eta = c.eta[0], invEta = 1 / eta;
     const bool flip = (c.flags & 1u) && wi.z < 0; if (flip) wi.z = -wi.z;
     float R12; const v3 wiP = ctRefractIn(wi, eta, invEta, R12); const float probSpecular = ctProbSpecular(c, R12);

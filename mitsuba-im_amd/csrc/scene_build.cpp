@@ -191,7 +191,7 @@ void SceneHost::commitHost() {
         if (mat->type == MI_BSDF_MASK) { masked = true; mat = &materials[mat->distr]; }          // mask.cpp:104-121: the nested BSDF's components + an ENull | EFrontSide | EBackSide one
         if (mat->type == MI_BSDF_BUMPMAP || mat->type == MI_BSDF_NORMALMAP) { wrapped = true; mat = &materials[mat->distr]; }     // the nested BSDF's component types (bumpmap.cpp:97-100)
         bool backside, smooth, coated = false;
-        if (mat->type == MI_BSDF_COATING) { coated = true; wrapped = true; mat = &materials[mat->distr]; }      // coating.cpp:166-173: the nested components + a delta reflection that is EFrontSide | EBackSide
+        if (mat->type == MI_BSDF_COATING || mat->type == MI_BSDF_ROUGHCOATING) { coated = true; wrapped = true; mat = &materials[mat->distr]; }      // coating.cpp:166-173: the nested components + a delta reflection that is EFrontSide | EBackSide
         if (mat->type == MI_BSDF_BLEND) {                                                           // the two BSDFs' components (blendbsdf.cpp:103-134)
             backside = (mat->flags & MI_BSDF_FLAG_TWOSIDED) != 0; smooth = false; wrapped = true;
             for (int c = 0; c < 2; ++c) { const mi_material &ch = materials[(uint32_t) mat->eta[c]]; backside |= leafBackside(ch); smooth |= leafSmooth(ch); }

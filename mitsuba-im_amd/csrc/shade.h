@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
                     perturbFrame(sc, bsdf, h, huvx, huvy, dpdu, dpdv, bps, bpt, bpn); bumped = true;
                     curMat = (int) bsdf.distr; bsdf = loadMaterial(tb, curMat); applyTexture(bsdf);
                 }
-                if (WRAP && bsdf.type == MI_BSDF_T_COATING) { coat = curMat; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf); }      // coating.cpp: the layer around the nested record
+                if (WRAP && (bsdf.type == MI_BSDF_T_COATING || bsdf.type == MI_BSDF_T_ROUGHCOATING)) { coat = curMat; bsdf = loadMaterial(tb, (int) bsdf.distr); applyTexture(bsdf); }      // coating.cpp: the layer around the nested record
                 if (depth == 1 && h.emitter >= 0 && !rc.hide_emitters) {    // path.cpp:148-150 (EEmittedRadiance only on the camera segment)
                     add = T * emitterEval(tb, h.emitter, h.ns, -d); haveAdd = true;
                 }

@@ -30,6 +30,7 @@ BSDF_WARD = 16             # src/bsdfs/ward.cpp: as phong, alpha = alphaU, k[1] 
 WARD_WARD, WARD_DUER, WARD_BALANCED = 0, 1, 2
 BSDF_COATING = 17          # src/bsdfs/coating.cpp: distr = nested record, eta[0] = intIOR / extIOR, alpha = thickness, reflectance = sigmaA, specular = specularReflectance
 BSDF_BLEND = 18            # src/bsdfs/blendbsdf.cpp: eta[0..1] = the two child records, reflectance = (w, w, w) or the value of the bound `weight` texture
+BSDF_ROUGHCOATING = 19     # src/bsdfs/roughcoating.cpp: distr = nested record, eta = (intIOR / extIOR, thickness, microfacet distribution), alpha, reflectance = sigmaA, specular, k[1..2] = transmittance slice
 BSDF_NORMALMAP = 12       # src/bsdfs/normalmap.cpp: distr = nested record, bound texture = the tangent-space normals
 BSDF_PLASTIC = 4          # src/bsdfs/plastic.cpp: eta[0], specular, reflectance = diffuseReflectance, k[0] = fdrInt, nonlinear
 EMITTER_AREA = 0
@@ -148,6 +149,11 @@ def make_bsdf(kind=BSDF_DIFFUSE, reflectance=(0.5, 0.5, 0.5), twosided=False, al
         d = dict(type=kind, twosided=0, distr=int(nested), sample_visible=0, nonlinear=0, table=None, texture=int(texture), aniso=0,
                  reflectance=(0.0, 0.0, 0.0), alpha=float(scale), eta=(0.0, 0.0, 0.0), k=(0.0, 0.0, 0.0), specular=(0.0, 0.0, 0.0))
         return d
+    if kind == BSDF_ROUGHCOATING:                     # rough dielectric layer over record `nested`; `distr` = its microfacet distribution, alpha = its roughness, scale = thickness
+        if distr == DISTR_PHONG: sample_visible = False
+        _, table = rough_transmittance_slice(distr, ior, alpha)
+        return dict(type=kind, twosided=int(twosided), distr=int(nested), sample_visible=int(bool(sample_visible)), nonlinear=0, table=table, texture=-1, aniso=0,
+                    reflectance=tuple(map(float, reflectance)), alpha=float(alpha), eta=(float(f32(ior)), float(scale), float(distr)), k=(0.0, 0.0, float(len(table))), specular=tuple(map(float, specular)))
     if kind == BSDF_COATING:                          # smooth dielectric layer over record `nested`; reflectance = sigmaA (absorption per unit thickness), scale = thickness
         return dict(type=kind, twosided=int(twosided), distr=int(nested), sample_visible=0, nonlinear=0, table=None, texture=-1, aniso=0,
                     reflectance=tuple(map(float, reflectance)), alpha=float(scale), eta=(float(f32(ior)), 0.0, 0.0), k=(0.0, 0.0, 0.0), specular=tuple(map(float, specular)))
@@ -1302,6 +1308,29 @@ def blend_room(width=96, height=64, spp=16, sampler=SAMPLER_SOBOL, max_depth=6, 
             if sh["bsdf"] == i: sh["bsdf"] = base + 6 + i
         sc.bsdfs[i] = make_bsdf(reflectance=(0.5, 0.5, 0.5))
     sc.textures = sc.textures[:2]
+    return sc
+
+
+def cbox_roughcoating(width=96, height=96, spp=16, sampler=SAMPLER_SOBOL, max_depth=8, rr_depth=5, seed=0, strict_normals=False):
+    """Cornell box with `roughcoating` layers (Beckmann / GGX / Phong interfaces, with and without absorption, one `twosided`) over diffuse and rough-conductor records."""
+    sc = cornell_box(width, height, spp, sampler, max_depth, rr_depth, seed=seed, strict_normals=strict_normals)
+    sc.name = "cbox_roughcoating"
+    eta, k = CONDUCTOR_IOR["Cu"]
+    base = len(sc.bsdfs)
+    sc.bsdfs.extend([make_bsdf(reflectance=(0.6, 0.55, 0.45)),                                                                                                  # base + 0
+                     make_bsdf(kind=BSDF_ROUGHCOATING, nested=base, ior=1.5046, alpha=0.1, distr=DISTR_BECKMANN, reflectance=(0.0, 0.0, 0.0)),                 # base + 1: floor
+                     make_bsdf(reflectance=(0.7, 0.7, 0.7)),                                                                                                    # base + 2
+                     make_bsdf(kind=BSDF_ROUGHCOATING, nested=base + 2, ior=1.49, alpha=0.3, distr=DISTR_GGX, reflectance=(0.2, 0.8, 1.6), scale=0.7, specular=(0.9, 0.9, 0.9), twosided=True),   # base + 3: back wall
+                     make_bsdf(kind=BSDF_ROUGHCONDUCTOR, alpha=0.15, distr=DISTR_GGX, eta=eta, k=k),                                                            # base + 4
+                     make_bsdf(kind=BSDF_ROUGHCOATING, nested=base + 4, ior=1.9, alpha=0.05, distr=DISTR_BECKMANN, reflectance=(0.1, 0.3, 0.05), scale=1.0, sample_visible=False),   # base + 5: short block
+                     make_bsdf(reflectance=(0.2, 0.3, 0.65)),                                                                                                   # base + 6
+                     make_bsdf(kind=BSDF_ROUGHCOATING, nested=base + 6, ior=1.49, alpha=0.1, distr=DISTR_PHONG)])                                               # base + 7: tall block
+    sc.shapes[0]["bsdf"] = base + 1; sc.shapes[2]["bsdf"] = base + 3; sc.shapes[6]["bsdf"] = base + 5; sc.shapes[7]["bsdf"] = base + 7
+    tabs = []
+    for bd in sc.bsdfs:
+        if bd.get("table") is not None:
+            off = sum(len(t) for t in tabs); tabs.append(bd["table"]); bd["k"] = (bd["k"][0], float(off), float(len(bd["table"])))
+    sc.material_tables = np.concatenate(tabs).astype(f32)
     return sc
 
 

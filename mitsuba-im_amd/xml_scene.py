@@ -12,7 +12,7 @@ substitution, <include>, <ref>, <integer> <float> <boolean> <string> <point> <ve
     film        hdrfilm / ldrfilm / mfilm (size + reconstruction filter; the file-format options do not concern the path)
     rfilter     box, tent, gaussian, mitchell, catmullrom, lanczos
     shape       obj, ply, serialized, cube (mitsuba-im_amd/meshio.py), rectangle, disk, sphere, cylinder, shapegroup, instance
-    bsdf        diffuse, roughdiffuse, phong, ward, coating, blendbsdf, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
+    bsdf        diffuse, roughdiffuse, phong, ward, coating, roughcoating, blendbsdf, roughconductor, conductor, dielectric, thindielectric, plastic, roughdielectric, difftrans, roughplastic, mask, twosided
     texture     checkerboard, gridtexture, bitmap (diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance; images .exr / .png / .jpg / .bmp / .tga / .hdr / .pfm / .npy (imageio.py) or a precomputed pyramid .npz)
     emitter     area, constant, envmap, point, spot, directional
 Anything else raises SceneError naming the plugin: there is no silent substitution.
@@ -563,6 +563,27 @@ class _SceneBuilder:
                 raise SceneError("coating: the nested BSDF must be a plain reflective one (adapters go around the coating)")
             rec = S.make_bsdf(S.BSDF_COATING, nested=ni, ior=float(int_ior / ext_ior), reflectance=sa or (0.0, 0.0, 0.0), scale=float(p.get("thickness", 1.0)),
                               specular=sr or (1.0, 1.0, 1.0), twosided=twosided)
+        elif t == "roughcoating":                         # src/bsdfs/roughcoating.cpp:117-151: as coating + a MicrofacetDistribution (distribution, alpha, sampleVisible)
+            inner = p.children_of("bsdf")
+            if len(inner) != 1:
+                raise SceneError("roughcoating: exactly one nested BSDF is expected")
+            sa, satex = _spectrum_or_texture(p, ("sigmaA",), (0.0, 0.0, 0.0))
+            sr, srtex = _spectrum_or_texture(p, ("specularReflectance",), (1.0, 1.0, 1.0))
+            if satex is not None or srtex is not None:
+                raise SceneError("roughcoating: textured parameters are not supported")
+            distr, alpha, sv = _microfacet(p)                  # (isotropic only: roughcoating.cpp:149-151)
+            int_ior, ext_ior = f32(_ior(p, "intIOR", "bk7")), f32(_ior(p, "extIOR", "air"))
+            if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
+                raise SceneError("The interior and exterior indices of refraction must be positive and differ!")
+            ni = self.bsdf(inner[0][1])
+            if self.bsdfs[ni]["type"] in (S.BSDF_MASK, S.BSDF_MIXTURE, S.BSDF_BLEND, S.BSDF_BUMPMAP, S.BSDF_NORMALMAP, S.BSDF_COATING, S.BSDF_ROUGHCOATING, S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC,
+                                          S.BSDF_DIFFTRANS, S.BSDF_THINDIELECTRIC, S.BSDF_NULL, S.BSDF_CONDUCTOR, S.BSDF_PLASTIC):
+                raise SceneError("roughcoating: the nested BSDF must be a plain reflective one without a Dirac delta lobe (adapters go around the coating)")
+            try:
+                rec = S.make_bsdf(S.BSDF_ROUGHCOATING, nested=ni, ior=float(int_ior / ext_ior), alpha=alpha, distr=distr, sample_visible=sv, reflectance=sa or (0.0, 0.0, 0.0),
+                                  scale=float(p.get("thickness", 1.0)), specular=sr or (1.0, 1.0, 1.0), twosided=twosided)
+            except ValueError as e:
+                raise SceneError(str(e))
         elif t == "blendbsdf":                            # src/bsdfs/blendbsdf.cpp:72-76, 103-108: weight (0.5, float or texture) and exactly two nested BSDFs
             inner = p.children_of("bsdf")
             if len(inner) != 2:
@@ -667,7 +688,7 @@ class _SceneBuilder:
                 rec = S.make_bsdf(S.BSDF_PLASTIC if plastic else S.BSDF_THINDIELECTRIC if t == "thindielectric" else S.BSDF_DIELECTRIC, **kw)
         else:
             raise SceneError(f"BSDF plugin \"{t}\" is not supported by the path (supported: diffuse, roughconductor, conductor, dielectric, plastic, "
-                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, coating, blendbsdf, thindielectric, mask, twosided)")
+                             "roughdielectric, difftrans, roughplastic, roughdiffuse, phong, ward, coating, roughcoating, blendbsdf, thindielectric, mask, twosided)")
         if tex is not None:
             rec["texture"] = self.texture(tex)
         p.check_all_used()
@@ -1162,6 +1183,10 @@ def export_scene(sc, directory, name=None, mesh_format="serialized"):
             inner = f'<bsdf type="conductor">{cond}</bsdf>'
         elif t == S.BSDF_DIELECTRIC:
             inner = f'<bsdf type="dielectric">{ior}{rgb("specularReflectance", b["specular"])}{rgb("specularTransmittance", b["reflectance"])}</bsdf>'
+        elif t == S.BSDF_ROUGHCOATING:
+            inner = (f'<bsdf type="roughcoating"><string name="distribution" value="{distr.get(int(b["eta"][2]), "beckmann")}"/><float name="alpha" value="{fmt([b["alpha"]])}"/>{sv}'
+                     f'<float name="intIOR" value="{fmt([b["eta"][0]])}"/><float name="extIOR" value="1"/><float name="thickness" value="{fmt([b["eta"][1]])}"/>'
+                     f'{rgb("sigmaA", b["reflectance"])}{rgb("specularReflectance", b["specular"])}<ref id="bsdf{b["distr"]}"/></bsdf>')
         elif t == S.BSDF_BLEND:
             wx = texture_xml(sc.textures[b["texture"]], "weight") if b.get("texture", -1) >= 0 else f'<float name="weight" value="{fmt([b["reflectance"][0]])}"/>'
             inner = f'<bsdf type="blendbsdf">{wx}<ref id="bsdf{int(b["eta"][0])}"/><ref id="bsdf{int(b["eta"][1])}"/></bsdf>'

@@ -802,7 +802,7 @@ void orc_camera_ray(const orc_scene *s, float sx, float sy, float *o8) { v3 o, d
 /* ------------------------------------------------------------------------------------------------ BSDFs */
 #define BSDF_FLAG_TWOSIDED 1u
 /* BSDF type bits that matter on this path: ESmooth (all supported BSDFs are smooth), EBackSide (twosided.cpp:99-102) */
-enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16, BSDF_COATING = 17, BSDF_BLEND = 18 };
+enum { BSDF_DIFFUSE = 0, BSDF_ROUGHCONDUCTOR = 1, BSDF_CONDUCTOR = 2, BSDF_DIELECTRIC = 3, BSDF_PLASTIC = 4, BSDF_ROUGHDIELECTRIC = 5, BSDF_DIFFTRANS = 6, BSDF_ROUGHPLASTIC = 7, BSDF_THINDIELECTRIC = 8, BSDF_MASK = 9, BSDF_MIXTURE = 10, BSDF_BUMPMAP = 11, BSDF_NORMALMAP = 12, BSDF_NULL = 13, BSDF_ROUGHDIFFUSE = 14, BSDF_PHONG = 15, BSDF_WARD = 16, BSDF_COATING = 17, BSDF_BLEND = 18, BSDF_ROUGHCOATING = 19 };
 #define BSDF_FLAG_NONLINEAR 4u
 /* BSDF type has ETransmission or EBackSide -> dRec.refN = 0 (records.inl:160-164): twosided wrapper; dielectric (dielectric.cpp:199-202) */
 static int material_has_backside(const orc_material *m) { return (m->flags & BSDF_FLAG_TWOSIDED) != 0 || m->type == BSDF_DIELECTRIC || m->type == BSDF_ROUGHDIELECTRIC || m->type == BSDF_DIFFTRANS || m->type == BSDF_THINDIELECTRIC || m->type == BSDF_NULL; }
@@ -1496,7 +1496,7 @@ static v3 bsdf_sample(const orc_material *m, v3 wi, float u, float v, v3 *wo, fl
 /* a hit's material with its textures evaluated and its wrappers resolved (below): mask -> bumpmap / normalmap -> mixturebsdf -> plain BSDFs */
 typedef struct { mat_t inner; int masked; int pdfless; v3 opacity; float prob;
                  int bumped; v3 ps, pt, pn; const hit_t *its;           /* bumpmap / normalmap: the perturbed shading frame; the hit's own frame stays the query frame */
-                 int coated; orc_material coat; float coat_w;            /* coating: the layer's record and its m_specularSamplingWeight; `inner` is the nested BSDF */
+                 int coated; mat_t coatm; float coat_w;                              /* coating: the layer's record and its m_specularSamplingWeight; `inner` is the nested BSDF */
                  int blend;                                              /* blendbsdf: two children in mix[0..1], w[1] = the (textured) weight, w[0] = 1 - w[1]; selection by `sample.x < w[0]` */
                  int n_mix; mat_t mix[4]; float w[4], p[4], cdf[5]; } smat_t;  /* mixturebsdf: children, weights, normalised selection probabilities */
 static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_t *its, int want_partials, v3 o, const v3 *rxd, const v3 *ryd);
@@ -1979,12 +1979,20 @@ static smat_t resolve_material(const orc_scene *s, uint32_t material, const hit_
         sm.inner = s->materials[sm.inner.m.distr];
         if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     }
-    if (sm.inner.m.type == BSDF_COATING) {                                /* SmoothCoating::configure (coating.cpp:160-192): reflectance = sigmaA, alpha = thickness, eta[0] = eta, specular */
-        sm.coated = 1; sm.coat = sm.inner.m;
-        float e0 = fastexpf_(sm.coat.reflectance[0] * (-2 * sm.coat.alpha)), e1 = fastexpf_(sm.coat.reflectance[1] * (-2 * sm.coat.alpha)), e2 = fastexpf_(sm.coat.reflectance[2] * (-2 * sm.coat.alpha));
+    if (sm.inner.m.type == BSDF_ROUGHCOATING) {                           /* RoughCoating::configure (roughcoating.cpp:183-230): eta[0] = eta, eta[1] = thickness, eta[2] = microfacet type, alpha, k[1..2] = the transmittance slice */
+        sm.coated = 2; sm.coatm = sm.inner; const orc_material *c = &sm.coatm.m;
+        float e0 = fastexpf_(c->reflectance[0] * (-2 * c->eta[1])), e1 = fastexpf_(c->reflectance[1] * (-2 * c->eta[1])), e2 = fastexpf_(c->reflectance[2] * (-2 * c->eta[1]));
         float avgAbsorption = 0.0f; avgAbsorption += e0; avgAbsorption += e1; avgAbsorption += e2; avgAbsorption = avgAbsorption * (1.0f / 3);
         sm.coat_w = 1.0f / (avgAbsorption + 1.0f);
-        sm.inner = s->materials[sm.coat.distr];
+        sm.inner = s->materials[c->distr];
+        if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
+    }
+    if (sm.inner.m.type == BSDF_COATING) {                                /* SmoothCoating::configure (coating.cpp:160-192): reflectance = sigmaA, alpha = thickness, eta[0] = eta, specular */
+        sm.coated = 1; sm.coatm = sm.inner;
+        float e0 = fastexpf_(sm.coatm.m.reflectance[0] * (-2 * sm.coatm.m.alpha)), e1 = fastexpf_(sm.coatm.m.reflectance[1] * (-2 * sm.coatm.m.alpha)), e2 = fastexpf_(sm.coatm.m.reflectance[2] * (-2 * sm.coatm.m.alpha));
+        float avgAbsorption = 0.0f; avgAbsorption += e0; avgAbsorption += e1; avgAbsorption += e2; avgAbsorption = avgAbsorption * (1.0f / 3);
+        sm.coat_w = 1.0f / (avgAbsorption + 1.0f);
+        sm.inner = s->materials[sm.coatm.m.distr];
         if (its) apply_texture(s, &sm.inner, its, NULL, want_partials, o, rxd, ryd);
     }
     if (sm.inner.m.type == BSDF_BLEND) {                                  /* BlendBSDF (blendbsdf.cpp:138-141): weight = clamp(m_weight->eval(its).average(), 0, 1); `reflectance` holds the texture's value (or w, w, w) */
@@ -2061,9 +2069,86 @@ static v3 ct_absorb(const orc_material *c, v3 result, v3 wiP, v3 woP) {  /* Spec
     float f = 1 / fabsf(wiP.z) + 1 / fabsf(woP.z);
     return mul(result, V(fastexpf_(-sigmaA.x * f), fastexpf_(-sigmaA.y * f), fastexpf_(-sigmaA.z * f)));
 }
+/* ---- rough dielectric coating: src/bsdfs/roughcoating.cpp:236-443.  The layer's interface is a microfacet surface (MicrofacetDistribution(type, alpha, sampleVisible),
+ * isotropic); directions enter and leave the layer by Snell's law alone (refractTo, :239-259), the energy balance is the precomputed rough transmittance (rtrans.h, the
+ * same 1-D slice as roughplastic's: table at k[1], length k[2]).  Nested BSDFs with delta lobes are not supported here (they would need EDiscrete queries) */
+static v3 rct_refract_to(int interior, v3 wi, float eta, float invEtaC) {
+    float invEta = interior ? invEtaC : eta; int entering = wi.z > 0.0f;
+    float sinThetaTSqr = invEta * invEta * (1.0f - wi.z * wi.z);
+    if (sinThetaTSqr >= 1.0f) return V(0, 0, 0);
+    float cosThetaT = sqrtf(1.0f - sinThetaTSqr);
+    return V(invEta * wi.x, invEta * wi.y, entering ? cosThetaT : -cosThetaT);
+}
+static mfd_t rct_distr(const orc_material *c) { mfd_t d; d.distr = (uint32_t) c->eta[2]; d.au = d.av = maxf(avg3(c->alpha), 1e-4f); d.visible = (c->flags & 2u) != 0 && d.distr != 2; return d; }
+static float rct_prob_specular(const smat_t *sm, float cosThetaI) {
+    float p = 1 - rp_transmittance(&sm->coatm.m, fabsf(cosThetaI)), w = sm->coat_w;
+    return (p * w) / (p * w + (1 - p) * (1 - w));
+}
+static v3 rct_absorb(const orc_material *c, v3 result, v3 wiP, v3 woP) {
+    v3 sigmaA = scale(V(c->reflectance[0], c->reflectance[1], c->reflectance[2]), c->eta[1]);
+    if (is_zero(sigmaA)) return result;
+    float f = 1 / fabsf(wiP.z) + 1 / fabsf(woP.z);
+    return mul(result, V(fastexpf_(-sigmaA.x * f), fastexpf_(-sigmaA.y * f), fastexpf_(-sigmaA.z * f)));
+}
+static v3 rct_eval(const smat_t *sm, v3 wi, v3 wo) {                      /* :261-322 */
+    const orc_material *c = &sm->coatm.m; const float eta = c->eta[0], invEta = 1 / eta; const mfd_t d = rct_distr(c);
+    if ((c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    v3 result = V(0, 0, 0);
+    if (wo.z * wi.z > 0) {
+        v3 H = scale(normalize(add(wo, wi)), copysignf(1.0f, wo.z)); float ct;
+        float D = mf_eval2(d.distr, d.au, d.av, H), F = fresnel_dielectric_ext(fabsf(dot(wi, H)), &ct, eta);
+        float G = mf_smith_g1_2(d.distr, d.au, d.av, wi, H) * mf_smith_g1_2(d.distr, d.au, d.av, wo, H);
+        float value = F * D * G / (4.0f * fabsf(wi.z));
+        result = add(result, scale(V(c->specular[0], c->specular[1], c->specular[2]), value));
+    }
+    v3 wiP = rct_refract_to(1, wi, eta, invEta), woP = rct_refract_to(1, wo, eta, invEta);
+    v3 nested = scale(scale(mx_eval(sm, wiP, woP), rp_transmittance(c, fabsf(wi.z))), rp_transmittance(c, fabsf(wo.z)));
+    nested = rct_absorb(c, nested, wiP, woP);
+    nested = scale(nested, invEta * invEta * wo.z / woP.z);
+    return add(result, nested);
+}
+static float rct_pdf(const smat_t *sm, v3 wi, v3 wo) {                    /* :324-383 */
+    const orc_material *c = &sm->coatm.m; const float eta = c->eta[0], invEta = 1 / eta; const mfd_t d = rct_distr(c);
+    if ((c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
+    v3 H = scale(normalize(add(wo, wi)), copysignf(1.0f, wo.z));
+    float probSpecular = rct_prob_specular(sm, wi.z), probNested = 1 - probSpecular, result = 0.0f;
+    if (wo.z * wi.z > 0) {
+        float dwh_dwo = 1.0f / (4.0f * fabsf(dot(wo, H))), prob = mfd_pdf(&d, wi, H);
+        result = prob * dwh_dwo * probSpecular;
+    }
+    v3 wiP = rct_refract_to(1, wi, eta, invEta), woP = rct_refract_to(1, wo, eta, invEta);
+    float prob = mx_pdf(sm, wiP, woP);
+    prob *= invEta * invEta * wo.z / woP.z;
+    result += prob * probNested;
+    return result;
+}
+static v3 rct_sample(const smat_t *sm, v3 wi, float sx, float sy, v3 *wo, float *pdf, float *etaOut, int *delta, sampler_t *sp) {      /* :385-443 */
+    const orc_material *c = &sm->coatm.m; const float eta = c->eta[0], invEta = 1 / eta; const mfd_t d = rct_distr(c);
+    int flip = (c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) wi.z = -wi.z;
+    float probSpecular = rct_prob_specular(sm, wi.z); int choseSpecular = 1;
+    if (sy < probSpecular) sy /= probSpecular; else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = 0; }
+    *delta = 0;
+    if (choseSpecular) {
+        float mpdf; v3 m = mfd_sample(&d, wi, sx, sy, &mpdf);
+        float cc = 2 * dot(wi, m); *wo = sub(scale(m, cc), wi); *etaOut = 1.0f;
+        if (wo->z * wi.z <= 0) return V(0, 0, 0);
+    } else {
+        v3 wiP = rct_refract_to(1, wi, eta, invEta), woP = V(0, 0, 0);
+        v3 r = mx_sample(sm, wiP, sx, sy, &woP, pdf, etaOut, delta, sp);      /* (the nested pdf stays in *pdf when the way out fails, as in the reference: the weight is zero then) */
+        if (is_zero(r)) return V(0, 0, 0);
+        *wo = rct_refract_to(0, woP, eta, invEta);
+        if (is_zero(*wo)) return V(0, 0, 0);
+    }
+    *pdf = rct_pdf(sm, wi, *wo);                                          /* "guard against numerical imprecisions": pdf and value are re-evaluated (:432-438) */
+    if (*pdf == 0) return V(0, 0, 0);
+    float r = 1.0f / *pdf; v3 result = scale(rct_eval(sm, wi, *wo), r);
+    if (flip) wo->z = -wo->z;
+    return result;
+}
 static v3 ct_eval(const smat_t *sm, v3 wi, v3 wo) {                       /* :227-265 */
     if (!sm->coated) return mx_eval(sm, wi, wo);
-    const orc_material *c = &sm->coat; const float eta = c->eta[0], invEta = 1 / eta;
+    if (sm->coated == 2) return rct_eval(sm, wi, wo);
+    const orc_material *c = &sm->coatm.m; const float eta = c->eta[0], invEta = 1 / eta;
     if ((c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     float R12, R21; v3 wiP = ct_refract_in(wi, eta, invEta, &R12), woP = ct_refract_in(wo, eta, invEta, &R21);
     if (R12 == 1 || R21 == 1) return V(0, 0, 0);
@@ -2074,7 +2159,8 @@ static v3 ct_eval(const smat_t *sm, v3 wi, v3 wo) {                       /* :22
 static float ct_prob_specular(const smat_t *sm, float R12) { return (R12 * sm->coat_w) / (R12 * sm->coat_w + (1 - R12) * (1 - sm->coat_w)); }
 static float ct_pdf(const smat_t *sm, v3 wi, v3 wo) {                     /* :267-303 */
     if (!sm->coated) return mx_pdf(sm, wi, wo);
-    const orc_material *c = &sm->coat; const float eta = c->eta[0], invEta = 1 / eta;
+    if (sm->coated == 2) return rct_pdf(sm, wi, wo);
+    const orc_material *c = &sm->coatm.m; const float eta = c->eta[0], invEta = 1 / eta;
     if ((c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0) { wi.z = -wi.z; wo.z = -wo.z; }
     float R12, R21; v3 wiP = ct_refract_in(wi, eta, invEta, &R12); float probSpecular = ct_prob_specular(sm, R12);
     v3 woP = ct_refract_in(wo, eta, invEta, &R21);
@@ -2085,7 +2171,8 @@ static float ct_pdf(const smat_t *sm, v3 wi, v3 wo) {                     /* :26
 }
 static v3 ct_sample(const smat_t *sm, v3 wi, float u, float v, v3 *wo, float *pdf, float *etaOut, int *delta, sampler_t *sp) {      /* :305-372 */
     if (!sm->coated) return mx_sample(sm, wi, u, v, wo, pdf, etaOut, delta, sp);
-    const orc_material *c = &sm->coat; const float eta = c->eta[0], invEta = 1 / eta;
+    if (sm->coated == 2) return rct_sample(sm, wi, u, v, wo, pdf, etaOut, delta, sp);
+    const orc_material *c = &sm->coatm.m; const float eta = c->eta[0], invEta = 1 / eta;
     int flip = (c->flags & BSDF_FLAG_TWOSIDED) && wi.z < 0; if (flip) wi.z = -wi.z;
     float R12; v3 wiP = ct_refract_in(wi, eta, invEta, &R12); float probSpecular = ct_prob_specular(sm, R12);
     v3 result;

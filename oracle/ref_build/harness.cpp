@@ -285,6 +285,14 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
             if (fb.distr >= bsdfs.size()) { fprintf(stderr, "coating: the nested material must precede it\n"); _exit(2); }
             bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
+        } else if (fb.type == 19) {          // roughcoating: eta[0] = intIOR / extIOR, eta[1] = thickness, eta[2] = distribution, alpha, refl = sigmaA, spec, nested = an EARLIER record (distr)
+            Properties p("roughcoating"); p.setFloat("intIOR", fb.eta[0]); p.setFloat("extIOR", 1.0f); p.setFloat("thickness", fb.eta[1]);
+            const int mf = (int) fb.eta[2]; p.setString("distribution", mf == 0 ? "beckmann" : mf == 1 ? "ggx" : "phong"); p.setFloat("alpha", fb.alpha);
+            p.setBoolean("sampleVisible", (fb.sampleVisible & 1u) != 0);
+            p.setSpectrum("sigmaA", rgb(fb.refl)); p.setSpectrum("specularReflectance", rgb(fb.spec));
+            bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
+            if (fb.distr >= bsdfs.size()) { fprintf(stderr, "roughcoating: the nested material must precede it\n"); _exit(2); }
+            bsdf->addChild(bsdfs[fb.distr]); bsdfs[fb.distr]->setParent(bsdf);
         } else if (fb.type == 18) {          // blendbsdf: children = EARLIER records (indices in eta[0], eta[1]); weight = refl[0] (constant) or the bound texture
             Properties p("blendbsdf"); p.setFloat("weight", fb.refl[0]);
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
@@ -333,7 +341,7 @@ static Built buildScene(const FScene &fs) {
             bsdf = static_cast<BSDF *>(create(MTS_CLASS(BSDF), p));
         }
         { size_t bi = bsdfs.size();
-          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0 && fb.type != 11 && fb.type != 12 && fb.type != 17) {      // texture bound to the record's `reflectance`
+          if (bi < fs.bsdfTexture.size() && fs.bsdfTexture[bi] >= 0 && fb.type != 11 && fb.type != 12 && fb.type != 17 && fb.type != 19) {      // texture bound to the record's `reflectance`
               ref<Texture> tex = makeTexture(fs.textures[fs.bsdfTexture[bi]], false);
               // the texture drives diffuse.reflectance, plastic / roughplastic.diffuseReflectance, difftrans.transmittance or mask.opacity (the material record's `reflectance`)
               bsdf->addChild(fb.type == 4 || fb.type == 7 ? "diffuseReflectance" : fb.type == 6 ? "transmittance" : fb.type == 9 ? "opacity" : fb.type == 18 ? "weight" : "reflectance", tex); tex->setParent(bsdf);

@@ -146,6 +146,7 @@ def golden_scenes():
         "ward_room": scenes.ward_room(width=96, height=64, spp=16),
         # `coating` over diffuse / rough conductor / smooth conductor, with and without absorption
         "cbox_coating": scenes.cbox_coating(width=96, height=96, spp=16),
+        "cbox_roughcoating": scenes.cbox_roughcoating(width=96, height=96, spp=16),      # `roughcoating`: Beckmann / GGX / Phong interfaces
         "blend_room": scenes.blend_room(width=96, height=64, spp=16),      # `blendbsdf` with textured and constant weights
         "cbox_coating_strict_indep": scenes.cbox_coating(width=96, height=96, spp=8, sampler=scenes.SAMPLER_INDEPENDENT, seed=25, strict_normals=True),
     }
@@ -244,7 +245,7 @@ def main():
                             li=np.load(base + "_li.npy"), pos=np.load(base + "_pos.npy"), ray=np.load(base + "_ray.npy"),
                             depth=np.load(base + "_depth.npy"), nvals=np.load(base + "_nsamples.npy"),
                             vals=np.load(base + "_svalues.npy")[:512])
-        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop", "layered_room"):
+        if name in ("cornell_sobol", "closed_box", "veach_small", "atrium_small", "cbox_shapes", "shape_lights", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "cbox_roughcoating", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "bitmap_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop", "layered_room"):
             run(path, "hits", 97 if sc.width > 1000 else 5, base + "_hits.npy")
             run(path, "camera", base)
             run(path, "units", base)
@@ -252,7 +253,7 @@ def main():
                                 camrays=np.load(base + "_camrays.npy"), filter=np.load(base + "_filter.npy"),
                                 warp=np.load(base + "_warp.npy"), triaccel=np.load(base + "_triaccel.npy"),
                                 emitter=np.load(base + "_emitter.npy"), bsdf=np.load(base + "_bsdf.npy"))
-        if name in ("fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky", "fog_masked", "fog_masked_mis", "fog_pane_mis", "fog_layered_procedural", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
+        if name in ("fog_box", "fog_box_global", "fog_mis", "fog_mis_global", "fog_sky", "fog_masked", "fog_masked_mis", "fog_pane_mis", "fog_layered_procedural", "cornell_small", "atrium_small", "cbox_shapes", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "cbox_roughcoating", "open_constant", "cbox_materials", "veach_small", "instanced_garden", "cbox_translucent", "textured_room", "sky_view", "veach_microfacets", "textured_plastics_smooth", "glass_pane", "masked_room", "cornell_crop", "layered_room", "layered_room_procedural"):
             # the reference's own `path` through the RESPONSIVE interface (ImageOrderIntegrator -> ClassicSamplingIntegrator), one thread:
             # the target the drop-in plugin must reproduce (tests/test_gpu_dropin.py)
             run(path, "responsive", {1: "volpath_simple", 2: "volpath"}.get(sc.get("integrator", 0), "path"), -1, base + "_resp")

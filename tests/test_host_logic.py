@@ -65,7 +65,11 @@ def test_round3_material_validation_without_gpu(mi):
     r, msg = rc(mat(0), mat(0), mat(BLEND, eta=(0, 1, 0)), mat(BLEND, eta=(0, 2, 0))); assert r == 3 and b"plain BSDF records" in msg
     r, msg = rc(mat(0), mat(COAT, distr=0, eta=(1.5, 0, 0)), mat(MIX, distr=2, refl=(0, 1, 0), k=(0.5, 0.5, 0))); assert r == 3 and b"children of a mixturebsdf" in msg
     assert rc(mat(WARD, flags=8, distr=2, alpha=0.1, k=(0.3, 0.4, 0), spec=(0.2, 0.2, 0.2)))[0] == 0
-    assert rc(mat(19))[0] == 3
+    RCOAT, COND = 19, 2
+    r, msg = rc(mat(COND), mat(RCOAT, distr=0, eta=(1.5, 1.0, 0.0), k=(0, 0, 100))); assert r == 3 and b"without a Dirac delta lobe" in msg
+    assert rc(mat(0), mat(RCOAT, distr=0, eta=(1.5, 1.0, 1.0), k=(0, 0, 100)))[0] == 0          # (its transmittance slice is checked at commit)
+    r, msg = rc(mat(0), mat(RCOAT, distr=0, eta=(1.5, 1.0, 3.0), k=(0, 0, 100))); assert r == 1 and b"invalid distribution" in msg
+    assert rc(mat(20))[0] == 3
     L.L.mi_scene_destroy(h)
 
 

@@ -40,7 +40,7 @@ def test_sobol_index_math_bit_exact(oracle, golden_scenes):
 
 @pytest.mark.parametrize("name", ["cornell_sobol", "cornell_indep", "cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small", "atrium_strict", "atrium_hide_indep", "cornell_hide",
                                   "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep",
-                                  "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "cbox_ward", "cbox_ward_strict_indep", "ward_room", "cbox_coating", "cbox_coating_strict_indep", "blend_room", "open_constant", "open_constant_hide_indep",
+                                  "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "cbox_ward", "cbox_ward_strict_indep", "ward_room", "cbox_coating", "cbox_coating_strict_indep", "blend_room", "cbox_roughcoating", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
                                   "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong", "layered_room", "layered_room_strict_indep", "layered_room_procedural", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis", "fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])
 def test_li_samples_vs_reference(oracle, golden_scenes, name):
@@ -169,7 +169,7 @@ def test_image_vs_strict_reference(oracle, golden_scenes, name):
     assert rel < {"cornell_small": 2e-5, "veach_small": 2e-5}.get(name, 4e-4), rel
 
 
-@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop", "layered_room"])
+@pytest.mark.parametrize("name", ["cornell_sobol", "closed_box", "veach_small", "cbox_shapes", "shape_lights", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "cbox_roughcoating", "open_constant", "cbox_materials", "instanced_garden", "cbox_translucent", "cbox_roughplastic", "textured_room", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "glass_pane", "masked_room", "textured_shapes", "cornell_crop", "layered_room"])
 def test_units_vs_reference(oracle, golden_scenes, name):
     sc = golden_scenes[name]; u = g(name + "_units.npz"); orc = oracle.Oracle(sc); L = oracle.lib()
     # camera rays (perspective.cpp:271-287)
@@ -238,11 +238,11 @@ def test_units_vs_reference(oracle, golden_scenes, name):
         if needs_hit(mat): continue                                            # covered by the radiance / image comparisons
         wi = np.ascontiguousarray(row[1:4]); wo = np.ascontiguousarray(row[14:17])
         L.orc_bsdf_sample(orc.h, mat, wi.ctypes.data, float(row[4]), float(row[5]), o8.ctypes.data)
-        assert np.allclose(o8[0:4], row[6:10], rtol=5e-4 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf")) else 1e-5, atol=1e-7)     # all-normal sampling: weight = D(m) G (wi.m) / (pdf cos) with D(m) recomputed from m; for alpha = 0.03 sin^2 = 1 - cos^2 cancels (1e-4 relative, in the reference too)
+        assert np.allclose(o8[0:4], row[6:10], rtol=5e-4 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf") or name == "cbox_roughcoating") else 1e-5, atol=1e-7)     # all-normal sampling: weight = D(m) G (wi.m) / (pdf cos) with D(m) recomputed from m; for alpha = 0.03 sin^2 = 1 - cos^2 cancels (1e-4 relative, in the reference too)
         if row[6:9].any():
-            assert np.allclose(o8[4:7], row[10:13], atol=3e-7 if sc.bsdfs[mat]["type"] == 0 else 2e-5 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf")) else 2e-6) and o8[7] == row[13]   # rough conductor: libm (atan/tan/erf) in the visible-normal sampler
+            assert np.allclose(o8[4:7], row[10:13], atol=3e-7 if sc.bsdfs[mat]["type"] == 0 else 2e-5 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf") or name == "cbox_roughcoating") else 2e-6) and o8[7] == row[13]   # rough conductor: libm (atan/tan/erf) in the visible-normal sampler
         L.orc_bsdf_eval(orc.h, mat, wi.ctypes.data, wo.ctypes.data, o4.ctypes.data)
-        rt = 1e-4 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf")) else 1e-5
+        rt = 1e-4 if (name.startswith("veach_microfacets") or name.startswith("cbox_translucent_mf") or name == "cbox_roughcoating") else 1e-5
         assert np.allclose(o4[0:3], row[17:20], rtol=rt, atol=1e-8) and np.allclose(o4[3], row[20], rtol=rt, atol=1e-8)
     # filter table + border (rfilter.cpp:37-56)
     ft = u["filter"]; radius = ft[-2]
@@ -252,7 +252,7 @@ def test_units_vs_reference(oracle, golden_scenes, name):
 
 
 @pytest.mark.parametrize("name", ["cornell_small", "cornell_small_gauss", "closed_box", "veach_small", "atrium_small",
-                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "cbox_ward", "cbox_ward_strict_indep", "ward_room", "cbox_coating", "cbox_coating_strict_indep", "blend_room", "open_constant", "open_constant_hide_indep",
+                                  "cbox_shapes", "shape_lights", "cbox_shapes_strict_indep", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_roughdiffuse_strict_indep", "cbox_phong", "cbox_phong_strict_indep", "cbox_ward", "cbox_ward_strict_indep", "ward_room", "cbox_coating", "cbox_coating_strict_indep", "blend_room", "cbox_roughcoating", "open_constant", "open_constant_hide_indep",
                                   "cbox_materials", "cbox_materials_strict_indep", "instanced_garden",
                                   "cbox_translucent", "cbox_translucent_indep", "cbox_roughplastic", "textured_room", "bitmap_room", "bunny_box", "sky_view", "sky_view_indep", "cornell_scramble", "veach_microfacets", "veach_microfacets_2", "cbox_translucent_mf", "cbox_translucent_mf2", "textured_plastics", "textured_plastics_smooth", "glass_pane", "glass_pane_hide_indep", "masked_room", "masked_room_hide_indep", "textured_shapes", "cornell_crop", "cbox_roughplastic_allnormals", "cbox_roughplastic_phong",
                                   "cornell_small_tent", "cornell_small_mitchell", "cornell_small_catmullrom", "cornell_small_lanczos", "fog_box", "fog_box_global", "fog_box_global_hide", "fog_mis", "fog_mis_global", "fog_mis_global_hide", "fog_sky", "fog_sky_simple", "fog_sky_global_hide", "fog_constant", "fog_constant_simple_indep", "fog_pane", "fog_pane_mis", "fog_dusty", "fog_dusty_mis", "fog_layered", "fog_layered_mis", "fog_layered_procedural", "fog_masked", "fog_masked_mis"])

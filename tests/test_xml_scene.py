@@ -14,7 +14,7 @@ MESHES = os.path.join(HERE, "golden", "meshes")
 X = importlib.import_module("mitsuba-im_amd.xml_scene")
 S = importlib.import_module("mitsuba-im_amd.scenes")
 
-GENERATORS = ["cornell_box", "cbox_shapes", "cbox_materials", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "open_constant", "cbox_translucent", "cbox_roughplastic", "textured_room",
+GENERATORS = ["cornell_box", "cbox_shapes", "cbox_materials", "cbox_lights", "cbox_collimated", "cbox_roughdiffuse", "cbox_phong", "cbox_ward", "ward_room", "cbox_coating", "blend_room", "cbox_roughcoating", "open_constant", "cbox_translucent", "cbox_roughplastic", "textured_room",
               "shape_lights", "veach_mis", "veach_microfacets", "textured_plastics", "bitmap_room", "glass_pane", "masked_room", "textured_shapes"]
 
 
