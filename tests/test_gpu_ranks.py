@@ -54,3 +54,15 @@ def test_rank_processes_on_the_hip_path(mi, tmp_path, world):
                 assert own[j::world, :, 4].sum() <= 1e-3 * own[k::world, :, 4].sum()      # only samples that sit exactly on a row edge reach a neighbour's row
     cnt = json.load(open(tmp_path / "counters.json"))
     assert cnt == {k: st[k] for k in cnt}
+
+
+def test_bench_two_ranks_share_the_card():
+    """bench.py's N = 2 path end to end on the one-GPU box: the self-spawning launcher, two ranks on the HIP path (MI355PT_SHARE_DEVICE=1 maps both to device 0),
+    the film reduce (gloo through the host: the rehearsal backend), barrier + max-over-ranks timing, rank 0's JSON line with the fixed job as `value` and the weak job beside it."""
+    env = dict(os.environ, MI355PT_SHARE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--spp", "8", "--width", "640",
+                          "--height", "360", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and line["weak"]["value"] > 0 and line["weak"]["spp"] == 16
+    assert "REHEARSAL" in line["config"]["workload"] and 3.5 < line["counters"]["rays_per_sample"] < 5.0
