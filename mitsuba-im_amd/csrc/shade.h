@@ -282,13 +282,16 @@ __global__ __launch_bounds__(WG, MI_SHADE_MIN_WAVES) void k_shade(DScene sc, Ren
 
 
 
-// launch the (SMALL, AN, TEX) variant of one (RC, ENV, WRAP) combination that fits the scene; WRAP variants exist for AN = true only
+// launch the (AN, TEX) variant of one (RC, ENV, WRAP, SMALL) combination that fits the scene; WRAP variants exist for AN = true only
+template <bool RC, bool ENV, bool WRAP, bool SM>
+static void launchShadeVariantSM(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
+    if ((sc.ext || WRAP) && sc.n_textures) launchWithLds(k_shade<RC, ENV, SM, true, true, WRAP>, grid, lds, st, sc, rc, q, buf);
+    else if (sc.ext || WRAP) launchWithLds(k_shade<RC, ENV, SM, true, false, WRAP>, grid, lds, st, sc, rc, q, buf);
+    else launchWithLds(k_shade<RC, ENV, SM, WRAP, false, WRAP>, grid, lds, st, sc, rc, q, buf);
+}
+// both SMALL halves from one translation unit (the WRAP combinations compile theirs in two: kernels_shade_rcw*_small.hip, for the build time)
 template <bool RC, bool ENV, bool WRAP>
 static void launchShadeVariant(const DScene &sc, const RenderConst &rc, const Queues &q, int buf, uint32_t grid, size_t lds, hipStream_t st) {
-    const bool small = sc.small_tables != 0;
-#define MI_SHADE(SM) do { if ((sc.ext || WRAP) && sc.n_textures) launchWithLds(k_shade<RC, ENV, SM, true, true, WRAP>, grid, lds, st, sc, rc, q, buf); \
-                          else if (sc.ext || WRAP) launchWithLds(k_shade<RC, ENV, SM, true, false, WRAP>, grid, lds, st, sc, rc, q, buf); \
-                          else launchWithLds(k_shade<RC, ENV, SM, WRAP, false, WRAP>, grid, lds, st, sc, rc, q, buf); } while (0)
-    if (small) MI_SHADE(true); else MI_SHADE(false);
-#undef MI_SHADE
+    if (sc.small_tables != 0) launchShadeVariantSM<RC, ENV, WRAP, true>(sc, rc, q, buf, grid, lds, st);
+    else launchShadeVariantSM<RC, ENV, WRAP, false>(sc, rc, q, buf, grid, lds, st);
 }
